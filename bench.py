@@ -1,0 +1,212 @@
+"""bench.py -- BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE configs[1] -- 10M x 768 fp32 FLAT, COSINE, top-10, single-query
+stream through the VecSim C ABI (VecSimIndex_TopKQuery -> reply), corpus resident in HBM, synthetic
+U(-1,1) data.  A "step" is one KNN query = one pass over the rank's corpus shard.
+N > 1: the corpus is row-sharded, 10M rows per GPU (weak scaling: 80M rows at N=8, BASELINE
+configs[3]); every query runs on all shards, per-shard top-10 (fp32 score, u64 label) are exchanged
+with an RCCL all-gather over xGMI and merged.  `value` counts 10M-row shard scans per second over all
+ranks (N x the global QPS on the sharded corpus), so that perfect weak scaling reads N x the 1-GPU
+value; the global QPS is in config.
+
+Adds `roofline` (scan kernel, HIP events on its own stream inside the timed region) and
+`cpu_baseline` (the CPU oracle's FLAT scan on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (default: the BASELINE config)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0):
+    """The oracle's FLAT scan (scalar max-heap, one thread = how one RediSearch worker runs one FLAT
+    query) timed on a bounded sample of the same workload, scaled linearly in rows to the full size."""
+    import oracle as O
+    import subprocess
+    lib = O.lib
+    native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
+    try:  # prefer a -march=native build made on THIS host
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        nat = C.CDLL(native)
+        for name in ("oflat_new", "oflat_add_bulk", "oflat_topk_heap", "oflat_free"):
+            getattr(nat, name).restype = getattr(lib, name).restype
+            getattr(nat, name).argtypes = getattr(lib, name).argtypes
+        lib = nat
+        flavour = "march=native"
+    except Exception:
+        flavour = "portable(avx512/avx2 clones)"
+    rng = np.random.default_rng(47)
+    data = rng.uniform(-1, 1, (sample_rows, dim)).astype(np.float32)
+    h = lib.oflat_new(O.F32, dim, O.COSINE, 0, 1024)
+    lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), sample_rows, 1)
+    qs = np.random.default_rng(48).uniform(-1, 1, (64, dim)).astype(np.float32)
+    ids = np.zeros(k, np.uint64)
+    sc = np.zeros(k, np.float64)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        q = qs[n % len(qs)]
+        lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p))
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 2000:
+            break
+    lib.oflat_free(h)
+    qps_sample = n / el
+    return {"value": qps_sample * sample_rows / full_rows, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "%d queries over a %d x %d fp32 cosine sample in %.1f s (oracle/flat_oracle.c oflat_topk_heap, %s), "
+                      "scaled by rows to %d" % (n, sample_rows, dim, el, flavour, full_rows)}
+
+
+def main():
+    a = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, "launch with --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from redisearch_amd import vecsim as V
+    lib = V.load()
+
+    # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
+    rows, dim, k = a.rows, a.dim, a.k
+    index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_Cosine)
+    index.reserve(rows)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(47 + rank)
+    chunk = 1_000_000
+    done = 0
+    while done < rows:
+        m = min(chunk, rows - done)
+        t = torch.rand((m, dim), device=dev, dtype=torch.float32, generator=gen).mul_(2.0).sub_(1.0)
+        torch.cuda.synchronize()
+        index.add_device_rows(t.data_ptr(), m, rank * rows + done + 1)
+        done += m
+        del t
+    torch.cuda.empty_cache()
+    assert index.index_size() == rows
+    queries = np.random.default_rng(48).uniform(-1, 1, (1000, dim)).astype(np.float32)
+
+    if world > 1:
+        loc_s = torch.empty(k, device=dev, dtype=torch.float32)
+        loc_l = torch.empty(k, device=dev, dtype=torch.int64)
+        all_s = torch.empty(k * world, device=dev, dtype=torch.float32)
+        all_l = torch.empty(k * world, device=dev, dtype=torch.int64)
+        out_s = np.zeros(k, np.float64)
+        out_l = np.zeros(k, np.uint64)
+
+    def one_query(i):
+        q = queries[i % len(queries)]
+        if world == 1:
+            rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
+            n = lib.VecSimQueryReply_Len(rep)
+            lib.VecSimQueryReply_Free(rep)
+            return n
+        index.topk_device(q, k, loc_s.data_ptr(), loc_l.data_ptr())
+        dist.all_gather_into_tensor(all_s, loc_s)
+        dist.all_gather_into_tensor(all_l, loc_l)
+        stream = torch.cuda.current_stream().cuda_stream
+        return lib.RSGPU_MergeTopK(local_rank, all_s.data_ptr(), all_l.data_ptr(), k * world, k,
+                                   out_s.ctypes.data_as(C.c_void_p), out_l.ctypes.data_as(C.c_void_p), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        assert one_query(i) == k
+    lib.RSGPU_ResetProfile()
+    lib.RSGPU_SetProfiling(1)
+    lat = np.zeros(a.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        s = time.perf_counter()
+        one_query(a.warmup + i)
+        lat[i] = time.perf_counter() - s
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.RSGPU_SetProfiling(0)
+    launches, kern_ms, kern_bytes = V.scan_profile()
+
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        global_qps = a.steps / elapsed
+        avg_kernel_s = (kern_ms / 1e3) / max(launches, 1)
+        achieved = (kern_bytes / max(launches, 1)) / avg_kernel_s / 1e9 if launches else 0.0
+        out = {
+            "metric": "KNN queries/sec, 10Mx768 fp32 FLAT top-10 (per 10M-row shard scan, aggregated over GPUs)",
+            "value": global_qps * world,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d fp32 FLAT COSINE top-%d per GPU, single-query stream via VecSimIndex_TopKQuery"
+                            % (rows, dim, k),
+                "rows_per_gpu": rows, "dim": dim, "k": k, "metric": "COSINE",
+                "corpus_rows_total": rows * world,
+                "parallelism": "row-sharded x%d, RCCL all-gather of per-shard top-k + merge" % world if world > 1 else "single GPU",
+                "global_qps_on_sharded_corpus": global_qps,
+                "p50_ms": float(np.percentile(lat, 50) * 1e3), "p95_ms": float(np.percentile(lat, 95) * 1e3),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "scan_kernel<f32,IP,G=64,ITERS=3> (FLAT scan)", "launches": int(launches),
+                "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dim, k, min(a.cpu_sample_rows, rows), rows)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

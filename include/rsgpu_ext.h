@@ -1,0 +1,60 @@
+/*
+ * rsgpu_ext.h -- NON-ABI extensions of the MI355X FLAT engine.
+ *
+ * Nothing here exists in VecSim; RediSearch never calls these.  They serve (a) bulk loading of
+ * device-resident corpora (the 30 GB bench corpus is generated in HBM), (b) device-side results for
+ * the multi-GPU top-K merge over RCCL, (c) the batched-query GEMM path the reference has no API for
+ * (VecSim answers B queries with B TopKQuery calls), (d) the GPU posting-list /
+ * scorer kernels whose reference counterparts sit behind Rust iterators (SURVEY.md 8b boundary 3),
+ * and (e) measurement hooks for bench.py.  Plain C, pointers and sizes only.
+ */
+#ifndef RSGPU_EXT_H
+#define RSGPU_EXT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "VecSim/vec_sim.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* last error message of the calling thread ("" if none) */
+const char *RSGPU_LastError(void);
+/* number of usable HIP devices (0 => every VecSimIndex_New fails) */
+int RSGPU_DeviceCount(void);
+
+/* ---- FLAT index extensions -------------------------------------------------------------------- */
+/* Pre-size the HBM corpus (rows). 0 on success. */
+int RSGPU_FlatIndex_Reserve(VecSimIndex *index, size_t rows);
+/* Append n rows that already live on the index's device, tightly packed (dim*sizeof(type) bytes
+ * each), labelled first_label .. first_label+n-1. Cosine rows are normalised on the device.
+ * Returns rows added or -1. */
+int RSGPU_FlatIndex_AddDeviceRows(VecSimIndex *index, const void *dev_rows, size_t n, size_t first_label);
+/* Top-k of one host query written to DEVICE buffers (k fp32 scores, k u64 labels; unused slots get
+ * +inf / UINT64_MAX), ordered by (score,label). The call returns after the results are complete.
+ * Returns the number of hits or -1. */
+int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, float *dev_scores,
+                               uint64_t *dev_labels);
+/* k best of m (score,label) candidates held in device memory (e.g. after an RCCL all-gather of
+ * per-shard top-k), ascending (score,label), written to HOST arrays. `wait_stream` (hipStream_t or
+ * NULL) is synchronised first. Returns the number written or -1. */
+int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
+                    double *scores_out, uint64_t *labels_out, void *wait_stream);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* When on, every FLAT scan launch is bracketed by HIP events on its own stream. */
+void RSGPU_SetProfiling(int on);
+void RSGPU_ResetProfile(void);
+/* launches, summed kernel milliseconds, algorithmic bytes (rows*dim*sizeof(type)) */
+void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes);
+/* keys: "blocks_per_cu", "rows_per_group", "nontemporal". Returns 0 if the key is known. */
+int RSGPU_SetTuning(const char *key, int value);
+/* frees idle per-query workspaces */
+void RSGPU_ReleaseWorkspaces(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSGPU_EXT_H */

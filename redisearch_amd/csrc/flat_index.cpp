@@ -1,0 +1,763 @@
+// flat_index.cpp -- host drivers of the MI355X FLAT index (see flat_index.hpp for the layout).
+//
+// Restates, as GPU orchestration, what the reference gets from VecSim's BruteForceIndex through
+// VecSimIndex_{AddVector,DeleteVector,TopKQuery,RangeQuery,GetDistanceFrom_Unsafe,PreferAdHocSearch}
+// (call sites: reference src/document.c:721, src/indexer.c:186, src/iterators/hybrid_reader.c:316,374,
+// src/vector_index.c:152).  No CPU distance code exists here: without a device every entry point
+// fails loudly.
+#include "flat_index.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace rsgpu {
+
+// ---------------------------------------------------------------------------------------------------
+Hooks &hooks() {
+  static Hooks h;
+  return h;
+}
+
+void logf(void *ctx, const char *level, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (hooks().log) hooks().log(ctx, level, buf);
+  else if (getenv("RSGPU_VERBOSE")) fprintf(stderr, "[rsgpu:%s] %s\n", level, buf);
+}
+
+bool device_available(std::string *why) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    if (why) *why = std::string("no HIP device: ") + hipGetErrorString(e);
+    return false;
+  }
+  return true;
+}
+
+bool timed_out(void *timeout_ctx) {
+  timeoutCallbackFunction cb = hooks().timeout;
+  return cb && cb(timeout_ctx) != 0;
+}
+
+ScanProfile &scan_profile() {
+  static ScanProfile p;
+  return p;
+}
+
+VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code) {
+  VecSimQueryReply *r = host_alloc<VecSimQueryReply>(1);
+  r->results = len ? host_alloc<VecSimQueryResult>(len) : nullptr;
+  r->len = len;
+  r->code = code;
+  return r;
+}
+
+// ---- fp16 / bf16 on the host (blob normalisation only) ---------------------------------------------
+static float h2f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ffu, bits;
+  if (exp == 0) {
+    if (!man) bits = sign;
+    else {
+      int e = -1;
+      do { man <<= 1; e++; } while (!(man & 0x400u));
+      bits = sign | ((uint32_t)(112 - e) << 23) | ((man & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 112) << 23) | (man << 13);
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+static uint16_t f2h(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u, a = x & 0x7fffffffu;
+  if (a >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (a > 0x7f800000u ? 0x200u : 0));
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (a < 0x33000001u) return (uint16_t)sign;
+  int e = (int)(a >> 23) - 127;
+  uint32_t man = (a & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? 13 + (-14 - e) : 13;
+  uint32_t half = man >> shift, rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+  if (rem > mid || (rem == mid && (half & 1))) half++;
+  if (e < -14) return (uint16_t)(sign | half);
+  return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (half - 0x400u)));
+}
+static float bf2f(uint16_t h) {
+  uint32_t b = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &b, 4);
+  return f;
+}
+static uint16_t f2bf(float f) {
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40);
+  x += 0x7fffu + ((x >> 16) & 1);
+  return (uint16_t)(x >> 16);
+}
+
+// VecSim_Normalize semantics (reference src/iterators/hybrid_reader.c:304): in place, fp32 math.
+void normalize_blob(void *blob, size_t dim, VecSimType type) {
+  switch (type) {
+    case VecSimType_FLOAT32: {
+      float *v = (float *)blob;
+      float s[8] = {0};
+      for (size_t i = 0; i < dim; i++) s[i & 7] += v[i] * v[i];
+      float n = sqrtf(((s[0] + s[4]) + (s[2] + s[6])) + ((s[1] + s[5]) + (s[3] + s[7])));
+      for (size_t i = 0; i < dim; i++) v[i] /= n;
+      break;
+    }
+    case VecSimType_FLOAT64: {
+      double *v = (double *)blob, s = 0;
+      for (size_t i = 0; i < dim; i++) s += v[i] * v[i];
+      s = sqrt(s);
+      for (size_t i = 0; i < dim; i++) v[i] /= s;
+      break;
+    }
+    case VecSimType_FLOAT16:
+    case VecSimType_BFLOAT16: {
+      uint16_t *v = (uint16_t *)blob;
+      bool half = type == VecSimType_FLOAT16;
+      float s = 0;
+      for (size_t i = 0; i < dim; i++) {
+        float a = half ? h2f(v[i]) : bf2f(v[i]);
+        s += a * a;
+      }
+      float n = sqrtf(s);
+      for (size_t i = 0; i < dim; i++) {
+        float a = (half ? h2f(v[i]) : bf2f(v[i])) / n;
+        v[i] = half ? f2h(a) : f2bf(a);
+      }
+      break;
+    }
+    case VecSimType_INT8:
+    case VecSimType_UINT8: {  // elements untouched, fp32 norm appended behind them
+      long long s = 0;
+      for (size_t i = 0; i < dim; i++) {
+        int a = type == VecSimType_INT8 ? (int)((int8_t *)blob)[i] : (int)((uint8_t *)blob)[i];
+        s += (long long)a * a;
+      }
+      float n = sqrtf((float)s);
+      memcpy((char *)blob + dim, &n, 4);
+      break;
+    }
+    default: break;
+  }
+}
+
+// ---- workspaces -------------------------------------------------------------------------------------
+template <typename T>
+static void dev_realloc(T *&p, size_t old_n, size_t new_n) {
+  if (p) {
+    HIP_CHECK(hipFree(p));
+    CtxPool::get().account(-(long)(old_n * sizeof(T)));
+  }
+  p = nullptr;
+  HIP_CHECK(hipMalloc((void **)&p, new_n * sizeof(T)));
+  CtxPool::get().account((long)(new_n * sizeof(T)));
+}
+template <typename T>
+static void pin_realloc(T *&p, size_t new_n) {
+  if (p) HIP_CHECK(hipHostFree(p));
+  p = nullptr;
+  HIP_CHECK(hipHostMalloc((void **)&p, new_n * sizeof(T), hipHostMallocDefault));
+}
+
+QueryCtx::QueryCtx(int dev) : device(dev) {
+  HIP_CHECK(hipSetDevice(dev));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreate(&ev0));
+  HIP_CHECK(hipEventCreate(&ev1));
+  dev_realloc(d_hist, 0, 8 * 256);
+  dev_realloc(d_counters, 0, 4);
+  dev_realloc(d_bound, 0, 1);
+  pin_realloc(h_counters, 8);
+}
+#define HIP_IGNORE(x) (void)(x)
+QueryCtx::~QueryCtx() {
+  HIP_IGNORE(hipSetDevice(device));
+  HIP_IGNORE(hipStreamSynchronize(stream));
+  void *dev[] = {d_query, d_keys, d_hist, d_counters, d_bound, d_out_rows, d_out_keys, d_ids, d_dists};
+  void *pin[] = {h_query, h_out_rows, h_out_keys, h_counters, h_ids, h_dists};
+  for (void *p : dev) if (p) HIP_IGNORE(hipFree(p));
+  for (void *p : pin) if (p) HIP_IGNORE(hipHostFree(p));
+  HIP_IGNORE(hipEventDestroy(ev0));
+  HIP_IGNORE(hipEventDestroy(ev1));
+  HIP_IGNORE(hipStreamDestroy(stream));
+}
+void QueryCtx::ensure_query(size_t bytes) {
+  if (bytes <= query_cap) return;
+  size_t cap = round_up(bytes, 4096);
+  dev_realloc(d_query, query_cap, cap);
+  pin_realloc(h_query, cap);
+  query_cap = cap;
+  cached_query_owner = 0;
+}
+void QueryCtx::ensure_keys(size_t rows) {
+  if (rows <= keys_cap) return;
+  size_t cap = round_up(rows + rows / 8 + 1024, 1024);
+  dev_realloc(d_keys, keys_cap, cap);
+  keys_cap = cap;
+}
+void QueryCtx::ensure_out(size_t k) {
+  if (k <= out_cap) return;
+  size_t cap = round_up(k + k / 2 + 256, 256);
+  dev_realloc(d_out_rows, out_cap, cap);
+  dev_realloc(d_out_keys, out_cap, cap);
+  pin_realloc(h_out_rows, cap);
+  pin_realloc(h_out_keys, cap);
+  out_cap = cap;
+}
+void QueryCtx::ensure_gather(size_t m) {
+  if (m <= gather_cap) return;
+  size_t cap = round_up(m + m / 2 + 256, 256);
+  dev_realloc(d_ids, gather_cap, cap);
+  dev_realloc(d_dists, gather_cap, cap);
+  pin_realloc(h_ids, cap);
+  pin_realloc(h_dists, cap);
+  gather_cap = cap;
+}
+
+CtxPool &CtxPool::get() {
+  static CtxPool *p = new CtxPool();  // intentionally leaked: outlives static destructors
+  return *p;
+}
+QueryCtx *CtxPool::acquire(int device) {
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    for (size_t i = 0; i < idle_.size(); i++)
+      if (idle_[i]->device == device) {
+        QueryCtx *c = idle_[i];
+        idle_.erase(idle_.begin() + (long)i);
+        return c;
+      }
+  }
+  return new QueryCtx(device);
+}
+void CtxPool::release(QueryCtx *c) {
+  std::lock_guard<std::mutex> g(mu_);
+  idle_.push_back(c);
+}
+void CtxPool::drain() {
+  std::vector<QueryCtx *> v;
+  {
+    std::lock_guard<std::mutex> g(mu_);
+    v.swap(idle_);
+  }
+  for (QueryCtx *c : v) delete c;
+}
+
+// ---- index -----------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_uid{1};
+
+FlatIndex::FlatIndex(const BFParams &p, void *lctx)
+    : type(p.type), metric(p.metric), dim(p.dim), multi(p.multi),
+      block_size(p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE), log_ctx(lctx) {
+  ktype = (int)type;
+  kmetric = metric == VecSimMetric_L2 ? KM_L2 : KM_IP;
+  elem_bytes_ = dim * type_size(type);
+  stride_ = round_up(elem_bytes_, 16);
+  uid = g_uid++;
+  HIP_CHECK(hipGetDevice(&device));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  scan_tuning().num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_CHECK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
+  // staging block: up to 4096 rows or 8 MiB
+  stage_cap_ = std::max<size_t>(1, std::min<size_t>(4096, (8u << 20) / stride_));
+  HIP_CHECK(hipHostMalloc((void **)&h_stage_, stage_cap_ * stride_, hipHostMallocDefault));
+  size_t init = block_size;
+  if (p.initialCapacity && p.initialCapacity != SIZE_MAX) init = std::max(init, std::min<size_t>(p.initialCapacity, 1u << 20));
+  grow(init);
+}
+
+FlatIndex::~FlatIndex() {
+  HIP_IGNORE(hipSetDevice(device));
+  HIP_IGNORE(hipStreamSynchronize(wstream_));
+  if (d_rows_) HIP_IGNORE(hipFree(d_rows_));
+  if (d_labels_) HIP_IGNORE(hipFree(d_labels_));
+  if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
+  HIP_IGNORE(hipStreamDestroy(wstream_));
+}
+
+size_t FlatIndex::memory() const {
+  return cap_rows_ * (stride_ + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
+         (single_map_.size() + multi_map_.size()) * 48;
+}
+
+void FlatIndex::grow(size_t min_rows) {
+  if (min_rows <= cap_rows_) return;
+  if (min_rows > 0xFFFFFFF0ull) throw std::runtime_error("FLAT index is limited to 2^32 rows per device");
+  size_t cap = cap_rows_ ? cap_rows_ : 0;
+  size_t next = cap < (1u << 22) ? cap * 2 : cap + cap / 2;
+  size_t new_cap = std::max(min_rows, next);
+  new_cap = round_up(new_cap, 64);
+  uint8_t *nr = nullptr;
+  uint64_t *nl = nullptr;
+  HIP_CHECK(hipMalloc((void **)&nr, new_cap * stride_));
+  HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
+  if (n_rows_) {
+    HIP_CHECK(hipMemcpyAsync(nr, d_rows_, (size_t)n_rows_ * stride_, hipMemcpyDeviceToDevice, wstream_));
+    HIP_CHECK(hipMemcpyAsync(nl, d_labels_, (size_t)n_rows_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
+    HIP_CHECK(hipStreamSynchronize(wstream_));
+  }
+  if (d_rows_) HIP_CHECK(hipFree(d_rows_));
+  if (d_labels_) HIP_CHECK(hipFree(d_labels_));
+  d_rows_ = nr;
+  d_labels_ = nl;
+  cap_rows_ = new_cap;
+}
+
+void FlatIndex::reserve(size_t rows) {
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  grow(rows);
+}
+
+void FlatIndex::normalize_host(void *blob) const { normalize_blob(blob, dim, type); }
+
+void FlatIndex::break_identity() {
+  if (!identity_) return;
+  identity_ = false;
+  size_t total = row_label_.size();
+  if (multi) {
+    multi_map_.reserve(total);
+    for (size_t r = 0; r < total; r++) multi_map_[row_label_[r]].push_back((uint32_t)r);
+  } else {
+    single_map_.reserve(total);
+    for (size_t r = 0; r < total; r++) single_map_[row_label_[r]] = (uint32_t)r;
+  }
+}
+
+void FlatIndex::map_insert(size_t label, uint32_t row) {
+  if (identity_) {
+    if (row == 0) identity_base_ = label;
+    if (label == identity_base_ + row) return;
+    break_identity();  // row_label_ does not contain `row` yet
+  }
+  if (multi) multi_map_[label].push_back(row);
+  else single_map_[label] = row;
+}
+
+void FlatIndex::rows_of(size_t label, std::vector<uint32_t> &out) const {
+  out.clear();
+  if (identity_) {
+    if (label >= identity_base_ && label - identity_base_ < row_label_.size()) out.push_back((uint32_t)(label - identity_base_));
+    return;
+  }
+  if (multi) {
+    auto it = multi_map_.find(label);
+    if (it != multi_map_.end()) out = it->second;
+  } else {
+    auto it = single_map_.find(label);
+    if (it != single_map_.end()) out.push_back(it->second);
+  }
+}
+
+void FlatIndex::flush_if_needed() {
+  {
+    std::shared_lock<std::shared_mutex> g(mu);
+    if (!stage_n_) return;
+  }
+  std::unique_lock<std::shared_mutex> g(mu);
+  flush();
+}
+
+void FlatIndex::flush() {
+  if (!stage_n_) return;
+  HIP_CHECK(hipSetDevice(device));
+  grow((size_t)n_rows_ + stage_n_);
+  HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)n_rows_ * stride_, h_stage_, stage_n_ * stride_, hipMemcpyHostToDevice, wstream_));
+  HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + n_rows_, stage_n_ * sizeof(uint64_t),
+                           hipMemcpyHostToDevice, wstream_));
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  n_rows_ += (uint32_t)stage_n_;
+  stage_n_ = 0;
+}
+
+int FlatIndex::add(const void *blob, size_t label) {
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  int ret = 1;
+  if (!multi) {
+    std::vector<uint32_t> rows;
+    rows_of(label, rows);
+    if (!rows.empty()) {  // overwrite: drop the old vector first (SURVEY.md 8c viii)
+      g.unlock();
+      remove(label);
+      g.lock();
+      ret = 0;
+    }
+  }
+  if (stage_n_ == stage_cap_) flush();
+  uint8_t *dst = h_stage_ + stage_n_ * stride_;
+  memset(dst, 0, stride_);
+  memcpy(dst, blob, elem_bytes_);
+  if (metric == VecSimMetric_Cosine) normalize_host(dst);
+  uint32_t row = (uint32_t)(n_rows_ + stage_n_);
+  map_insert(label, row);
+  row_label_.push_back(label);
+  stage_n_++;
+  return ret;
+}
+
+int FlatIndex::remove(size_t label) {
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  flush();
+  std::vector<uint32_t> rows;
+  rows_of(label, rows);
+  if (rows.empty()) return 0;
+  break_identity();
+  std::sort(rows.begin(), rows.end(), std::greater<uint32_t>());
+  for (uint32_t r : rows) {
+    uint32_t last = n_rows_ - 1;
+    if (r != last) {  // move the last row into the hole
+      uint64_t moved = row_label_[last];
+      HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)r * stride_, d_rows_ + (size_t)last * stride_, stride_,
+                               hipMemcpyDeviceToDevice, wstream_));
+      HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
+      row_label_[r] = moved;
+      if (multi) {
+        auto &v = multi_map_[moved];
+        for (auto &x : v) if (x == last) x = r;
+      } else {
+        single_map_[moved] = r;
+      }
+    }
+    row_label_.pop_back();
+    n_rows_--;
+  }
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  if (multi) multi_map_.erase(label);
+  else single_map_.erase(label);
+  return (int)rows.size();
+}
+
+int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_label) {
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  flush();
+  if (!n) return 0;
+  grow((size_t)n_rows_ + n);
+  uint8_t *dst = d_rows_ + (size_t)n_rows_ * stride_;
+  if (stride_ == elem_bytes_) {
+    HIP_CHECK(hipMemcpyAsync(dst, dev_rows, n * stride_, hipMemcpyDeviceToDevice, wstream_));
+  } else {
+    HIP_CHECK(hipMemsetAsync(dst, 0, n * stride_, wstream_));
+    HIP_CHECK(hipMemcpy2DAsync(dst, stride_, dev_rows, elem_bytes_, elem_bytes_, n, hipMemcpyDeviceToDevice, wstream_));
+  }
+  if (metric == VecSimMetric_Cosine)
+    launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
+  size_t old = row_label_.size();
+  row_label_.resize(old + n);
+  for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
+  if (identity_ && old == 0) identity_base_ = first_label;
+  if (!(identity_ && first_label == identity_base_ + old)) {
+    break_identity();  // builds the maps from row_label_, new rows included
+  }
+  HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + old, n * sizeof(uint64_t), hipMemcpyHostToDevice, wstream_));
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  HIP_CHECK(hipGetLastError());
+  n_rows_ += (uint32_t)n;
+  return (int)n;
+}
+
+size_t FlatIndex::size() {
+  std::shared_lock<std::shared_mutex> g(mu);
+  return (size_t)n_rows_ + stage_n_;
+}
+size_t FlatIndex::label_count() {
+  std::shared_lock<std::shared_mutex> g(mu);
+  if (!multi || identity_) return (size_t)n_rows_ + stage_n_;
+  return multi_map_.size();
+}
+
+VecSimIndexBasicInfo FlatIndex::basic_info() const {
+  VecSimIndexBasicInfo i;
+  memset(&i, 0, sizeof i);
+  i.algo = VecSimAlgo_BF;
+  i.metric = metric;
+  i.type = type;
+  i.isMulti = multi;
+  i.isTiered = false;
+  i.isDisk = false;
+  i.blockSize = block_size;
+  i.dim = dim;
+  return i;
+}
+
+// ---- query building blocks ---------------------------------------------------------------------------
+void FlatIndex::upload_query(QueryCtx *c, const void *blob, bool normalize) {
+  c->ensure_query(stride_ + 16);
+  memset(c->h_query, 0, stride_);
+  memcpy(c->h_query, blob, elem_bytes_);
+  if (normalize && metric == VecSimMetric_Cosine) normalize_host(c->h_query);
+  HIP_CHECK(hipMemcpyAsync(c->d_query, c->h_query, stride_, hipMemcpyHostToDevice, c->stream));
+  c->cached_query_owner = 0;
+}
+
+void FlatIndex::scan_all(QueryCtx *c, uint32_t n) {
+  c->ensure_keys(n);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  // profiling brackets the scan launch with events on ITS stream; they are read back after the
+  // query's own stream synchronisation (collect_profile), so the timed path gains no extra sync
+  if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  launch_scan(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, 0, n, c->d_query, c->d_keys, c->stream);
+  HIP_CHECK(hipGetLastError());
+  if (prof) {
+    HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    c->prof_rows = n;
+    c->prof_bytes_per_row = elem_bytes_;
+    c->prof_pending = true;
+  }
+}
+
+static void collect_profile(QueryCtx *c) {
+  if (!c->prof_pending) return;
+  c->prof_pending = false;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return;
+  ScanProfile &pf = scan_profile();
+  pf.launches++;
+  pf.bytes += (uint64_t)c->prof_rows * c->prof_bytes_per_row;
+  pf.nanos += (uint64_t)((double)ms * 1e6);
+}
+
+bool FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, uint64_t lower, bool has_lower, std::vector<Hit> &out,
+                       uint64_t *bound_out) {
+  out.clear();
+  if (!k || !n) return true;
+  c->ensure_out(k);
+  SelectBufs b{c->d_hist, c->d_counters, c->d_out_rows, c->d_out_keys, c->d_bound};
+  HIP_CHECK(hipMemsetAsync(c->d_hist, 0, 8 * 256 * sizeof(uint32_t), c->stream));
+  HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  int done = 0;
+  for (int round = 0; round < 2; round++) {
+    for (int p = done; p < done + 4; p++) launch_select_pass(c->d_keys, n, p, k, lower, has_lower ? 1 : 0, b, c->stream);
+    done += 4;
+    launch_select_collect(c->d_keys, n, done, k, lower, has_lower ? 1 : 0, b, (uint32_t)c->out_cap, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->h_bound(), c->d_bound, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    collect_profile(c);
+    if (c->h_counters[1] == 0) break;  // exact
+    if (round == 1) throw std::runtime_error("radix select did not converge");
+  }
+  uint32_t got = std::min<uint32_t>(c->h_counters[0], k);
+  out.resize(got);
+  for (uint32_t i = 0; i < got; i++) out[i] = Hit{c->h_out_rows[i], c->h_out_keys[i]};
+  std::sort(out.begin(), out.end(), [](const Hit &a, const Hit &b2) {
+    return a.key != b2.key ? a.key < b2.key : a.row < b2.row;
+  });
+  if (bound_out) *bound_out = *c->h_bound();
+  return true;
+}
+
+static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
+  if (order == BY_ID)
+    std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
+  else
+    std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
+      return a.score != b.score ? a.score < b.score : a.id < b.id;
+    });
+}
+
+VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
+  void *tctx = qp ? qp->timeoutCtx : nullptr;
+  last_mode = STANDARD_KNN;
+  flush_if_needed();
+  std::shared_lock<std::shared_mutex> g(mu);
+  // the callback is polled at least once, even for an index smaller than one block (App. B-7)
+  if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+  const uint32_t n = n_rows_;
+  if (!n || !k) return new_reply(0, VecSim_QueryReply_OK);
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  upload_query(c.c, query, true);
+  scan_all(c.c, n);
+  std::vector<Hit> hits;
+  std::vector<VecSimQueryResult> res;
+  if (!multi) {
+    uint32_t kk = (uint32_t)std::min<size_t>(k, n);
+    select(c.c, n, kk, 0, false, hits, nullptr);
+    if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+    res.reserve(hits.size());
+    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], (double)key_to_dist(h.key)});
+  } else {
+    // multi-value: walk batches in ascending composite order, first occurrence of a label is its best
+    std::unordered_map<uint64_t, char> seen;
+    uint64_t lower = 0;
+    bool has_lower = false;
+    uint32_t consumed = 0;
+    size_t want = std::min<size_t>(k, n);
+    while (res.size() < want && consumed < n) {
+      uint32_t ask = (uint32_t)std::min<size_t>(n - consumed, std::max<size_t>((want - res.size()) * 2, 16));
+      uint64_t bound = 0;
+      select(c.c, n, ask, lower, has_lower, hits, &bound);
+      if (hits.empty()) break;
+      consumed += (uint32_t)hits.size();
+      for (const Hit &h : hits) {
+        uint64_t lab = row_label_[h.row];
+        if (res.size() < want && seen.emplace(lab, 1).second)
+          res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist(h.key)});
+      }
+      lower = bound;
+      has_lower = true;
+      if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+    }
+  }
+  VecSimQueryReply *r = new_reply(res.size(), VecSim_QueryReply_OK);
+  if (!res.empty()) memcpy(r->results, res.data(), res.size() * sizeof(VecSimQueryResult));
+  sort_reply(r, order);
+  return r;
+}
+
+VecSimQueryReply *FlatIndex::range(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
+  void *tctx = qp ? qp->timeoutCtx : nullptr;
+  last_mode = RANGE_QUERY;
+  flush_if_needed();
+  std::shared_lock<std::shared_mutex> g(mu);
+  if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+  const uint32_t n = n_rows_;
+  if (!n || std::isnan(radius)) return new_reply(0, VecSim_QueryReply_OK);
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  upload_query(c.c, query, true);
+  scan_all(c.c, n);
+  // largest fp32 value whose widening is <= radius: `(double)dist <= radius`, inclusive (App. B-12)
+  float fr = (float)radius;
+  if ((double)fr > radius) fr = std::nextafterf(fr, -INFINITY);
+  uint32_t max_key = dist_to_key(fr);
+  HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  launch_range(c->d_keys, n, max_key, 0, c->d_counters, nullptr, nullptr, 0, c->stream);
+  HIP_CHECK(hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  collect_profile(c.c);
+  uint32_t cnt = c->h_counters[0];
+  if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+  if (!cnt) return new_reply(0, VecSim_QueryReply_OK);
+  c->ensure_out(cnt);
+  HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  launch_range(c->d_keys, n, max_key, 1, c->d_counters, c->d_out_rows, c->d_out_keys, (uint32_t)c->out_cap, c->stream);
+  HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  std::vector<VecSimQueryResult> res;
+  res.reserve(cnt);
+  if (!multi) {
+    for (uint32_t i = 0; i < cnt; i++)
+      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], (double)key_to_dist(c->h_out_keys[i])});
+  } else {
+    std::unordered_map<uint64_t, size_t> best;
+    for (uint32_t i = 0; i < cnt; i++) {
+      uint64_t lab = row_label_[c->h_out_rows[i]];
+      double d = (double)key_to_dist(c->h_out_keys[i]);
+      auto it = best.find(lab);
+      if (it == best.end()) {
+        best[lab] = res.size();
+        res.push_back(VecSimQueryResult{(size_t)lab, d});
+      } else if (d < res[it->second].score) res[it->second].score = d;
+    }
+  }
+  VecSimQueryReply *r = new_reply(res.size(), VecSim_QueryReply_OK);
+  memcpy(r->results, res.data(), res.size() * sizeof(VecSimQueryResult));
+  sort_reply(r, order);
+  return r;
+}
+
+void FlatIndex::gather(QueryCtx *c, const size_t *labels, size_t m, double *out) {
+  // the caller holds (at least) the shared lock and has uploaded the query into c->d_query
+  std::vector<uint32_t> rows, ids;
+  std::vector<uint32_t> first(m), count(m);
+  ids.reserve(m);
+  for (size_t i = 0; i < m; i++) {
+    rows_of(labels[i], rows);
+    first[i] = (uint32_t)ids.size();
+    uint32_t cnt = 0;
+    for (uint32_t r : rows)
+      if (r < n_rows_) { ids.push_back(r); cnt++; }
+    if (!cnt) { ids.push_back(0xFFFFFFFFu); cnt = 1; }
+    count[i] = cnt;
+  }
+  size_t t = ids.size();
+  c->ensure_gather(t);
+  memcpy(c->h_ids, ids.data(), t * sizeof(uint32_t));
+  HIP_CHECK(hipMemcpyAsync(c->d_ids, c->h_ids, t * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  launch_gather(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, c->d_ids, (uint32_t)t, c->d_query, c->d_dists, c->stream);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c->h_dists, c->d_dists, t * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < m; i++) {
+    double best = NAN;
+    for (uint32_t j = 0; j < count[i]; j++) {
+      double d = (double)c->h_dists[first[i] + j];
+      if (std::isnan(best) || d < best) best = d;  // multi-value: minimum over the label's vectors
+    }
+    out[i] = best;
+  }
+}
+
+// Per-thread workspace for GetDistanceFrom_Unsafe: the caller loops over candidates with the same
+// (pre-normalised) blob, so the query stays resident on the device between calls.
+struct TlsCtx {
+  QueryCtx *c = nullptr;
+  ~TlsCtx() {
+    if (c) CtxPool::get().release(c);
+  }
+};
+static thread_local TlsCtx tls_adhoc;
+
+double FlatIndex::distance_from(size_t label, const void *blob) {
+  flush_if_needed();
+  std::shared_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  if (tls_adhoc.c && tls_adhoc.c->device != device) {
+    CtxPool::get().release(tls_adhoc.c);
+    tls_adhoc.c = nullptr;
+  }
+  if (!tls_adhoc.c) tls_adhoc.c = CtxPool::get().acquire(device);
+  QueryCtx *c = tls_adhoc.c;
+  c->ensure_query(stride_ + 16);
+  if (!(c->cached_query_owner == uid && c->cached_query_len == elem_bytes_ && memcmp(c->h_query, blob, elem_bytes_) == 0)) {
+    upload_query(c, blob, false);  // blob is already normalised by the caller (hybrid_reader.c:295-305)
+    c->cached_query_owner = uid;
+    c->cached_query_len = elem_bytes_;
+  }
+  double out;
+  gather(c, &label, 1, &out);
+  return out;
+}
+
+// VecSimIndex_PreferAdHocSearch for a brute-force index ([upstream-memory D6]; the four decision
+// points the reference pins are listed in SURVEY.md 8 a6).
+bool FlatIndex::prefer_adhoc(size_t subset, size_t k, bool initial_check) {
+  (void)k;
+  size_t N = size(), d = dim;
+  if (subset > N) subset = N;
+  float r = N ? (float)subset / (float)N : 0.0f;
+  bool res;
+  if (N <= 5500) res = true;
+  else if (d <= 300) {
+    if (r <= 0.15f) res = true;
+    else if (r <= 0.35f) res = d <= 75 ? false : N <= 550000;
+    else res = false;
+  } else {
+    if (r <= 0.55f) res = true;
+    else if (d <= 750) res = false;
+    else res = r <= 0.75f;
+  }
+  last_mode = res ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
+  return res;
+}
+
+}  // namespace rsgpu

@@ -1,0 +1,219 @@
+// flat_index.hpp -- host side of the MI355X FLAT index: HBM-resident corpus, label maps, per-query
+// workspaces and the query drivers that string the HIP kernels together.
+//
+// What lives where (DESIGN.md "data layout"):
+//   HBM   rows      [cap_rows][stride]  row-contiguous, stride = dim*sizeof(T) rounded up to 16 B,
+//                                       zero padded; cosine rows are stored normalised
+//         labels    [cap_rows] u64      row -> label (doc id)
+//         per query keys [n] u32 (orderable distance), 8x256 histograms, <=K winners
+//   host  row_label vector, label -> row(s) hash map, a pinned staging block for AddVector
+// Rows are dense: DeleteVector moves the last row into the hole ([upstream-memory D8]).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "VecSim/vec_sim.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace rsgpu {
+
+struct Hit {
+  uint32_t row;
+  uint32_t key;
+};
+
+// Per in-flight query workspace: own stream, device scratch and pinned host mirrors.
+struct QueryCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // query blob
+  uint8_t *d_query = nullptr, *h_query = nullptr;
+  size_t query_cap = 0;
+  uint64_t cached_query_owner = 0;  // index uid whose query is resident in d_query (adhoc cache)
+  size_t cached_query_len = 0;
+  // keys
+  uint32_t *d_keys = nullptr;
+  size_t keys_cap = 0;
+  // select state
+  uint32_t *d_hist = nullptr, *d_counters = nullptr;
+  uint64_t *d_bound = nullptr;
+  uint32_t *d_out_rows = nullptr, *d_out_keys = nullptr;
+  uint32_t *h_out_rows = nullptr, *h_out_keys = nullptr;
+  size_t out_cap = 0;
+  uint32_t *h_counters = nullptr;  // [4] + bound (u64) behind it
+  // gather
+  uint32_t *d_ids = nullptr, *h_ids = nullptr;
+  float *d_dists = nullptr, *h_dists = nullptr;
+  size_t gather_cap = 0;
+  // scan profiling (events read back after the query's own sync)
+  bool prof_pending = false;
+  uint32_t prof_rows = 0;
+  size_t prof_bytes_per_row = 0;
+
+  explicit QueryCtx(int dev);
+  ~QueryCtx();
+  void ensure_query(size_t bytes);
+  void ensure_keys(size_t rows);
+  void ensure_out(size_t k);
+  void ensure_gather(size_t m);
+  uint64_t *h_bound() { return reinterpret_cast<uint64_t *>(h_counters + 4); }
+};
+
+class CtxPool {
+ public:
+  static CtxPool &get();
+  QueryCtx *acquire(int device);
+  void release(QueryCtx *c);
+  void drain();  // frees every idle workspace (tests / VecSim_GetSharedMemory accounting)
+  size_t bytes() const { return bytes_.load(); }
+  void account(long delta) { bytes_ += delta; }
+
+ private:
+  std::mutex mu_;
+  std::vector<QueryCtx *> idle_;
+  std::atomic<long> bytes_{0};
+};
+
+struct CtxLease {
+  QueryCtx *c;
+  explicit CtxLease(int device) : c(CtxPool::get().acquire(device)) {}
+  ~CtxLease() {
+    if (c) CtxPool::get().release(c);
+  }
+  QueryCtx *operator->() { return c; }
+  QueryCtx *release() {
+    QueryCtx *r = c;
+    c = nullptr;
+    return r;
+  }
+};
+
+// Scan-kernel profile, filled when profiling is on (bench.py's roofline leg).
+struct ScanProfile {
+  std::atomic<uint64_t> launches{0};
+  std::atomic<uint64_t> bytes{0};
+  std::atomic<uint64_t> nanos{0};
+  std::atomic<int> enabled{0};
+};
+ScanProfile &scan_profile();
+
+class FlatIndex {
+ public:
+  explicit FlatIndex(const BFParams &p, void *log_ctx);
+  ~FlatIndex();
+
+  // writes (single writer, excluded from readers by the caller; guarded again here)
+  int add(const void *blob, size_t label);
+  int remove(size_t label);
+  void reserve(size_t rows);
+  int add_device_rows(const void *dev_rows, size_t n, size_t first_label);
+
+  size_t size();
+  size_t label_count();
+  VecSimIndexBasicInfo basic_info() const;
+  size_t memory() const;
+
+  // queries
+  VecSimQueryReply *topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order);
+  VecSimQueryReply *range(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order);
+  double distance_from(size_t label, const void *normalized_blob);
+  bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
+
+  // building blocks shared with the batch iterator / adhoc ctx / device-output extension
+  void flush();                                                 // staged adds -> HBM (unique lock held)
+  void flush_if_needed();                                       // takes the locks itself
+  void upload_query(QueryCtx *c, const void *blob, bool normalize);
+  void scan_all(QueryCtx *c, uint32_t n);                        // keys for rows [0,n)
+  // exact selection of the k smallest composites above `lower`; returns hits sorted by composite
+  bool select(QueryCtx *c, uint32_t n, uint32_t k, uint64_t lower, bool has_lower, std::vector<Hit> &out,
+              uint64_t *bound_out);
+  void gather(QueryCtx *c, const size_t *labels, size_t m, double *out);
+  size_t label_of_row(uint32_t row) const { return row_label_[row]; }
+  uint32_t committed_rows() const { return n_rows_; }
+  const uint64_t *device_labels() const { return d_labels_; }
+  const void *device_rows() const { return d_rows_; }
+  size_t stride() const { return stride_; }
+
+  VecSimType type;
+  VecSimMetric metric;
+  size_t dim;
+  bool multi;
+  size_t block_size;
+  int ktype, kmetric;
+  int device;
+  uint64_t uid;
+  void *log_ctx;
+  std::atomic<int> last_mode{EMPTY_MODE};
+  std::shared_mutex mu;
+
+ private:
+  void grow(size_t min_rows);
+  void break_identity();
+  void normalize_host(void *blob) const;
+  void map_insert(size_t label, uint32_t row);
+  void rows_of(size_t label, std::vector<uint32_t> &out) const;
+
+  size_t elem_bytes_, stride_;
+  uint8_t *d_rows_ = nullptr;
+  uint64_t *d_labels_ = nullptr;
+  size_t cap_rows_ = 0;
+  uint32_t n_rows_ = 0;  // rows resident in HBM
+  // pinned staging block for AddVector
+  uint8_t *h_stage_ = nullptr;
+  size_t stage_cap_ = 0, stage_n_ = 0;
+  hipStream_t wstream_ = nullptr;
+  // host maps
+  std::vector<uint64_t> row_label_;  // committed + staged rows
+  bool identity_ = true;             // label == identity_base_ + row for every row, map unused
+  uint64_t identity_base_ = 0;
+  std::unordered_map<uint64_t, uint32_t> single_map_;
+  std::unordered_map<uint64_t, std::vector<uint32_t>> multi_map_;
+};
+
+// ---- reply objects (plain C structs behind the opaque ABI types) ----------------------------------
+}  // namespace rsgpu
+
+struct VecSimQueryResult {
+  size_t id;
+  double score;
+};
+struct VecSimQueryReply {
+  VecSimQueryResult *results;
+  size_t len;
+  VecSimQueryReply_Code code;
+};
+struct VecSimQueryReply_Iterator {
+  VecSimQueryReply *reply;
+  size_t pos;
+};
+
+namespace rsgpu {
+VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code);
+bool timed_out(void *timeout_ctx);
+
+// Batch iterator: keys for all rows are computed once, every Next() selects the next-best n
+// composites above the previous batch ([upstream-memory D7]).
+struct BatchIterator {
+  FlatIndex *index;
+  QueryCtx *ctx;
+  void *timeout_ctx;
+  std::vector<uint8_t> query;  // copied at New (reference c_wrappers/vecsim/src/batch.rs:52-55)
+  uint32_t n = 0;              // rows at creation
+  uint32_t returned = 0;
+  uint64_t lower = 0;
+  bool has_lower = false, scanned = false;
+  std::vector<uint64_t> seen_labels;  // multi-value: labels already yielded
+};
+
+struct AdhocCtx {
+  FlatIndex *index;
+  QueryCtx *ctx;
+};
+}  // namespace rsgpu

@@ -1,0 +1,78 @@
+// kernels.hpp -- launch interface of the hand-written gfx950 kernels (scan_kernels.hip,
+// select_kernels.hip).  Host code sees only these plain functions; every pointer is a device pointer
+// unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace rsgpu {
+
+// element types served by the scan kernels (values match VecSimType)
+enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3 };
+// kernel metrics: cosine is IP over rows/query normalised up front
+enum : int { KM_L2 = 0, KM_IP = 1 };
+
+// Orderable key of an fp32 distance: ascending key <=> ascending distance, NaN last.
+// (host mirror of the device f2key in scan_kernels.hip)
+inline uint32_t dist_to_key(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+inline float key_to_dist(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct ScanTuning {
+  int blocks_per_cu = 8;   // resident 256-thread blocks per CU the grid is sized for
+  int rows_per_group = 0;  // 0 = per-shape default (U in the kernel)
+  int nontemporal = 1;     // stream the corpus with nt loads
+  int num_cus = 256;
+};
+ScanTuning &scan_tuning();
+
+// Distances of rows [row_begin,row_end) to `query`, written as orderable keys keys[row].
+// rows: row-contiguous, `stride` bytes per row (multiple of 16, zero padded), query padded alike.
+void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
+                 uint32_t row_end, const void *query, uint32_t *keys, hipStream_t s);
+
+// Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as fp32 values out[i].
+void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
+                   uint32_t m, const void *query, float *out, hipStream_t s);
+
+// In-place L2 normalisation of rows [row_begin,row_end) (cosine indexes, bulk device loads).
+void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, uint32_t row_begin, uint32_t row_end,
+                           hipStream_t s);
+
+// ---- top-K selection over keys[0..n) -------------------------------------------------------------
+// Total order: composite (key << 32 | row).  Radix select, 8 bits per pass, most significant first;
+// passes 0-3 refine the key, 4-7 the row (only needed when equal keys straddle rank K).
+// `lower` (exclusive) restricts the candidates to composites > lower (batch iterator); has_lower=0
+// means none.  hist is [8][256] u32, zeroed by the caller before pass 0.
+struct SelectBufs {
+  uint32_t *hist;     // [8*256]
+  uint32_t *counters; // [0] out_count  [1] status (0 ok, 1 need more passes)  [2] selected-below count
+  uint32_t *out_rows; // [cap]
+  uint32_t *out_keys; // [cap]
+  uint64_t *bound;    // [1] composite upper bound (inclusive) of what was selected
+};
+void launch_select_pass(const uint32_t *keys, uint32_t n, int pass, uint32_t k, uint64_t lower, int has_lower,
+                        const SelectBufs &b, hipStream_t s);
+// After `passes_done` passes: if the selection is exact, writes the k winners (unordered) to
+// out_rows/out_keys and counters[0]=k, counters[1]=0; otherwise counters[1]=1 and nothing else.
+void launch_select_collect(const uint32_t *keys, uint32_t n, int passes_done, uint32_t k, uint64_t lower,
+                           int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s);
+
+// ---- range query: all rows with key <= max_key ----------------------------------------------------
+// counters[0] receives the count (collect=0) or is used as the append cursor (collect=1).
+void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,
+                  uint32_t *out_rows, uint32_t *out_keys, uint32_t cap, hipStream_t s);
+
+}  // namespace rsgpu

@@ -1,0 +1,461 @@
+// scan_kernels.hip -- the FLAT distance scan for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces the N x dim loop behind VecSimIndex_TopKQuery / VecSimBatchIterator_Next /
+// VecSimIndex_RangeQuery (reference call sites src/iterators/hybrid_reader.c:374,417 and
+// src/vector_index.c:152) and the per-candidate loop of VecSimIndex_GetDistanceFrom_Unsafe
+// (hybrid_reader.c:309-327).
+//
+// Shape of the work: one pass over a row-contiguous corpus, HBM-bound by ~10x (2-3 flops per 4
+// bytes).  Design, MI355X first:
+//   * a row is split in 16-byte chunks; a GROUP of G lanes (G = 1..64, power of two) owns a row, lane
+//     l reads chunks l, l+G, ...  For dim 768 fp32 a full 64-lane wavefront reads one 3072-byte row as
+//     3 x global_load_dwordx4 = 3 x 1 KiB fully coalesced requests;
+//   * the query never touches LDS on this path: lane l only ever needs query chunks l, l+G, ..., so
+//     they live in registers for the whole kernel (ITERS x 4 VGPRs);
+//   * U rows per group are issued back to back before the first use, so a wave keeps U*ITERS 16-byte
+//     loads in flight (12 KiB at 768 fp32) and ~7 such waves per SIMD hide the ~2 us HBM latency;
+//   * corpus loads are non-temporal: every byte is used exactly once per query;
+//   * partial sums are reduced across the group with cross-lane shuffles, the distance becomes an
+//     orderable u32 key and lanes 0..U-1 store the tile's keys with one coalesced store.  Keys (4 B
+//     per 3072 B read, +0.13 % traffic) feed the radix select in select_kernels.hip, the batch
+//     iterator and range queries -- no per-workgroup heaps, no divergent insertion path;
+//   * persistent-style grid: blocks_per_cu x 256 CUs blocks of 256 threads, tiles handed out in
+//     grid-stride order so that at any moment the whole chip streams one contiguous region.
+// MFMA is deliberately NOT used here: a single query is a GEMV (no operand reuse); the batched-query
+// GEMM path lives in gemm_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "kernels.hpp"
+
+namespace rsgpu {
+
+ScanTuning &scan_tuning() {
+  static ScanTuning t;
+  return t;
+}
+
+namespace {
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));  // one 16-byte chunk
+__device__ __forceinline__ u4 zero4() { return (u4){0u, 0u, 0u, 0u}; }
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;  // NaN sorts last
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <bool NT>
+__device__ __forceinline__ u4 load16(const u4 *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+// ---- one 16-byte chunk of a row against the matching query chunk ---------------------------------
+template <int TYPE, int METRIC>
+__device__ __forceinline__ float accumulate(float acc, u4 x, u4 q);
+
+template <>
+__device__ __forceinline__ float accumulate<KT_F32, KM_IP>(float acc, u4 x, u4 q) {
+  acc = fmaf(__uint_as_float(x.x), __uint_as_float(q.x), acc);
+  acc = fmaf(__uint_as_float(x.y), __uint_as_float(q.y), acc);
+  acc = fmaf(__uint_as_float(x.z), __uint_as_float(q.z), acc);
+  acc = fmaf(__uint_as_float(x.w), __uint_as_float(q.w), acc);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float accumulate<KT_F32, KM_L2>(float acc, u4 x, u4 q) {
+  float d0 = __uint_as_float(x.x) - __uint_as_float(q.x);
+  float d1 = __uint_as_float(x.y) - __uint_as_float(q.y);
+  float d2 = __uint_as_float(x.z) - __uint_as_float(q.z);
+  float d3 = __uint_as_float(x.w) - __uint_as_float(q.w);
+  acc = fmaf(d0, d0, acc);
+  acc = fmaf(d1, d1, acc);
+  acc = fmaf(d2, d2, acc);
+  acc = fmaf(d3, d3, acc);
+  return acc;
+}
+// fp16: products of two halves are exact in fp32, accumulation is fp32 (v_dot2_f32_f16)
+__device__ __forceinline__ half2_t as_h2(uint32_t u) {
+  half2_t h;
+  __builtin_memcpy(&h, &u, 4);
+  return h;
+}
+template <>
+__device__ __forceinline__ float accumulate<KT_F16, KM_IP>(float acc, u4 x, u4 q) {
+  acc = __builtin_amdgcn_fdot2(as_h2(x.x), as_h2(q.x), acc, false);
+  acc = __builtin_amdgcn_fdot2(as_h2(x.y), as_h2(q.y), acc, false);
+  acc = __builtin_amdgcn_fdot2(as_h2(x.z), as_h2(q.z), acc, false);
+  acc = __builtin_amdgcn_fdot2(as_h2(x.w), as_h2(q.w), acc, false);
+  return acc;
+}
+__device__ __forceinline__ float l2_h2(float acc, uint32_t a, uint32_t b) {
+  half2_t x = as_h2(a), y = as_h2(b);
+  float d0 = (float)x.x - (float)y.x, d1 = (float)x.y - (float)y.y;
+  acc = fmaf(d0, d0, acc);
+  return fmaf(d1, d1, acc);
+}
+template <>
+__device__ __forceinline__ float accumulate<KT_F16, KM_L2>(float acc, u4 x, u4 q) {
+  acc = l2_h2(acc, x.x, q.x);
+  acc = l2_h2(acc, x.y, q.y);
+  acc = l2_h2(acc, x.z, q.z);
+  return l2_h2(acc, x.w, q.w);
+}
+// bf16: widen by shifting into the top half of an fp32
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ float ip_bf2(float acc, uint32_t a, uint32_t b) {
+  acc = fmaf(bf_lo(a), bf_lo(b), acc);
+  return fmaf(bf_hi(a), bf_hi(b), acc);
+}
+__device__ __forceinline__ float l2_bf2(float acc, uint32_t a, uint32_t b) {
+  float d0 = bf_lo(a) - bf_lo(b), d1 = bf_hi(a) - bf_hi(b);
+  acc = fmaf(d0, d0, acc);
+  return fmaf(d1, d1, acc);
+}
+template <>
+__device__ __forceinline__ float accumulate<KT_BF16, KM_IP>(float acc, u4 x, u4 q) {
+  acc = ip_bf2(acc, x.x, q.x);
+  acc = ip_bf2(acc, x.y, q.y);
+  acc = ip_bf2(acc, x.z, q.z);
+  return ip_bf2(acc, x.w, q.w);
+}
+template <>
+__device__ __forceinline__ float accumulate<KT_BF16, KM_L2>(float acc, u4 x, u4 q) {
+  acc = l2_bf2(acc, x.x, q.x);
+  acc = l2_bf2(acc, x.y, q.y);
+  acc = l2_bf2(acc, x.z, q.z);
+  return l2_bf2(acc, x.w, q.w);
+}
+
+template <int G>
+__device__ __forceinline__ float group_reduce(float v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int METRIC>
+__device__ __forceinline__ float finish(float acc) {
+  return METRIC == KM_IP ? 1.0f - acc : acc;
+}
+
+// ---- the scan -------------------------------------------------------------------------------------
+// TYPE/METRIC: element type and metric.  G lanes per row, ITERS chunks per lane, U rows per group
+// per step.  EXACT: chunks == G*ITERS (no chunk masking).  GATHER: rows come from row_ids[] and the
+// result is an fp32 distance per candidate instead of a key per row.
+template <int TYPE, int METRIC, int G, int ITERS, int U, bool EXACT, bool NT, bool GATHER>
+__global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, uint32_t stride16,
+                                                   uint32_t chunks, uint32_t row_begin, uint32_t row_end,
+                                                   const u4 *__restrict__ query,
+                                                   const uint32_t *__restrict__ row_ids,
+                                                   uint32_t *__restrict__ keys, float *__restrict__ dists) {
+  constexpr int GPB = 256 / G;  // groups per block
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t grp = threadIdx.x / G;
+
+  u4 q[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; i++) {
+    uint32_t c = lane + i * G;
+    q[i] = (EXACT || c < chunks) ? query[c] : zero4();
+  }
+
+  // Row <-> group mapping.  G == 64: a wavefront owns U consecutive rows (one 1 KiB request per
+  // chunk, one coalesced U-key store).  G < 64: the block owns GPB*U consecutive rows and row
+  // base + u*GPB + grp goes to group grp, so that for a fixed u neighbouring groups read
+  // neighbouring rows and every load instruction stays contiguous across the wavefront.
+  constexpr bool INTERLEAVE = G < 64;
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  const uint32_t tile0 = INTERLEAVE ? blockIdx.x : blockIdx.x * GPB + grp;
+  const uint32_t tile_step = INTERLEAVE ? gridDim.x : gridDim.x * GPB;
+  const uint32_t u_stride = INTERLEAVE ? GPB : 1;
+
+  for (uint32_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + (INTERLEAVE ? grp : 0);
+    u4 x[U][ITERS];
+    uint32_t rid[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * u_stride;
+      if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      if (GATHER) {
+        r = row_ids[r];
+        rid[u] = r;
+        if (r == 0xFFFFFFFFu) r = 0;  // absent label: any valid row, result replaced by NaN
+      }
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) {
+        uint32_t c = lane + i * G;
+        x[u][i] = (EXACT || c < chunks) ? load16<NT>(p + c) : zero4();
+      }
+    }
+    float acc[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      acc[u] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) acc[u] = accumulate<TYPE, METRIC>(acc[u], x[u][i], q[i]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) acc[u] = group_reduce<G>(acc[u]);
+
+    if (INTERLEAVE) {
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          uint32_t r = r0 + u * u_stride;
+          if (r < row_end) {
+            float d = finish<METRIC>(acc[u]);
+            if (GATHER)
+              dists[r] = (rid[u] == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
+            else
+              keys[r] = f2key(d);
+          }
+        }
+      }
+    } else {
+      // lane u of the wavefront stores row r0+u
+      float mine = acc[0];
+      uint32_t my_rid = GATHER ? rid[0] : 0;
+#pragma unroll
+      for (int u = 1; u < U; u++) {
+        mine = (lane == (uint32_t)u) ? acc[u] : mine;
+        if (GATHER) my_rid = (lane == (uint32_t)u) ? rid[u] : my_rid;
+      }
+      if (lane < (uint32_t)U && r0 + lane < row_end) {
+        float d = finish<METRIC>(mine);
+        if (GATHER)
+          dists[r0 + lane] = (my_rid == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
+        else
+          keys[r0 + lane] = f2key(d);
+      }
+    }
+  }
+}
+
+// Fallback for very long rows (more than 512 chunks = 8 KiB): one wavefront per row, runtime loop,
+// query re-read through L1/L2 (it is tiny next to the corpus).
+template <int TYPE, int METRIC, bool NT, bool GATHER>
+__global__ __launch_bounds__(256) void scan_long_kernel(const u4 *__restrict__ rows, uint32_t stride16,
+                                                        uint32_t chunks, uint32_t row_begin, uint32_t row_end,
+                                                        const u4 *__restrict__ query,
+                                                        const uint32_t *__restrict__ row_ids,
+                                                        uint32_t *__restrict__ keys, float *__restrict__ dists) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = gridDim.x * 4;
+  for (uint32_t t = blockIdx.x * 4 + wave; t < row_end - row_begin; t += total) {
+    uint32_t r = row_begin + t, rid = 0;
+    if (GATHER) {
+      rid = row_ids[r];
+      r = rid == 0xFFFFFFFFu ? 0 : rid;
+    }
+    const u4 *p = rows + (size_t)r * stride16;
+    float a0 = 0.f, a1 = 0.f;
+    uint32_t c = lane;
+    for (; c + 64 < chunks; c += 128) {
+      u4 x0 = load16<NT>(p + c), x1 = load16<NT>(p + c + 64);
+      a0 = accumulate<TYPE, METRIC>(a0, x0, query[c]);
+      a1 = accumulate<TYPE, METRIC>(a1, x1, query[c + 64]);
+    }
+    if (c < chunks) a0 = accumulate<TYPE, METRIC>(a0, load16<NT>(p + c), query[c]);
+    float d = finish<METRIC>(group_reduce<64>(a0 + a1));
+    if (lane == 0) {
+      if (GATHER)
+        dists[row_begin + t] = (rid == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
+      else
+        keys[r] = f2key(d);
+    }
+  }
+}
+
+struct Shape {
+  int G, ITERS;
+};
+inline Shape pick_shape(uint32_t chunks) {
+  if (chunks > 64) return {64, (int)((chunks + 63) / 64)};
+  int g = 1;
+  while ((uint32_t)g < chunks) g <<= 1;
+  return {g, 1};
+}
+
+struct LaunchCtx {
+  const u4 *rows;
+  uint32_t stride16, chunks, row_begin, row_end;
+  const u4 *query;
+  const uint32_t *row_ids;
+  uint32_t *keys;
+  float *dists;
+  hipStream_t s;
+};
+
+template <int TYPE, int METRIC, int G, int ITERS, int U, bool GATHER>
+void launch_one(const LaunchCtx &c) {
+  const ScanTuning &t = scan_tuning();
+  constexpr int GPB = 256 / G;
+  uint32_t n = c.row_end - c.row_begin;
+  uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
+  uint32_t cap = (uint32_t)(t.num_cus * t.blocks_per_cu);
+  uint32_t grid = need < cap ? need : cap;
+  if (grid == 0) return;
+  bool exact = c.chunks == (uint32_t)(G * ITERS);
+  bool nt = t.nontemporal != 0;
+#define RSGPU_LAUNCH(EX, NTV)                                                                              \
+  hipLaunchKernelGGL((scan_kernel<TYPE, METRIC, G, ITERS, U, EX, NTV, GATHER>), dim3(grid), dim3(256), 0, c.s, \
+                     c.rows, c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists)
+  if (exact) {
+    if (nt) RSGPU_LAUNCH(true, true); else RSGPU_LAUNCH(true, false);
+  } else {
+    if (nt) RSGPU_LAUNCH(false, true); else RSGPU_LAUNCH(false, false);
+  }
+#undef RSGPU_LAUNCH
+}
+
+template <int TYPE, int METRIC, bool GATHER>
+void launch_shape(const LaunchCtx &c) {
+  Shape sh = pick_shape(c.chunks);
+  int u_over = scan_tuning().rows_per_group;
+  if (sh.ITERS > 8) {
+    const ScanTuning &t = scan_tuning();
+    uint32_t n = c.row_end - c.row_begin;
+    uint32_t need = (n + 3) / 4, cap = (uint32_t)(t.num_cus * t.blocks_per_cu);
+    uint32_t grid = need < cap ? need : cap;
+    if (!grid) return;
+    if (t.nontemporal)
+      hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, true, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
+                         c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists);
+    else
+      hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, false, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
+                         c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists);
+    return;
+  }
+  if (sh.ITERS == 1) {
+    switch (sh.G) {
+      case 1: return launch_one<TYPE, METRIC, 1, 1, 8, GATHER>(c);
+      case 2: return launch_one<TYPE, METRIC, 2, 1, 8, GATHER>(c);
+      case 4: return launch_one<TYPE, METRIC, 4, 1, 8, GATHER>(c);
+      case 8: return launch_one<TYPE, METRIC, 8, 1, 8, GATHER>(c);
+      case 16: return launch_one<TYPE, METRIC, 16, 1, 8, GATHER>(c);
+      case 32: return launch_one<TYPE, METRIC, 32, 1, 8, GATHER>(c);
+      default: return launch_one<TYPE, METRIC, 64, 1, 8, GATHER>(c);
+    }
+  }
+  switch (sh.ITERS) {
+    case 2: return launch_one<TYPE, METRIC, 64, 2, 4, GATHER>(c);
+    case 3:
+      if (u_over == 2) return launch_one<TYPE, METRIC, 64, 3, 2, GATHER>(c);
+      if (u_over == 8) return launch_one<TYPE, METRIC, 64, 3, 8, GATHER>(c);
+      return launch_one<TYPE, METRIC, 64, 3, 4, GATHER>(c);
+    case 4: return launch_one<TYPE, METRIC, 64, 4, 2, GATHER>(c);
+    case 5: return launch_one<TYPE, METRIC, 64, 5, 2, GATHER>(c);
+    case 6: return launch_one<TYPE, METRIC, 64, 6, 2, GATHER>(c);
+    case 7: return launch_one<TYPE, METRIC, 64, 7, 2, GATHER>(c);
+    default: return launch_one<TYPE, METRIC, 64, 8, 2, GATHER>(c);
+  }
+}
+
+template <bool GATHER>
+void dispatch(int type, int metric, const LaunchCtx &c) {
+#define RSGPU_CASE(T)                                               \
+  case T:                                                           \
+    if (metric == KM_L2) launch_shape<T, KM_L2, GATHER>(c);         \
+    else launch_shape<T, KM_IP, GATHER>(c);                         \
+    break;
+  switch (type) {
+    RSGPU_CASE(KT_F32)
+    RSGPU_CASE(KT_F16)
+    RSGPU_CASE(KT_BF16)
+    default: break;
+  }
+#undef RSGPU_CASE
+}
+
+// ---- row normalisation (cosine indexes, device bulk loads) -----------------------------------------
+template <int TYPE>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(u4 *rows, uint32_t stride16, uint32_t chunks,
+                                                             uint32_t row_begin, uint32_t row_end) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = gridDim.x * 4;
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += total) {
+    u4 *p = rows + (size_t)r * stride16;
+    float a = 0.f;
+    for (uint32_t c = lane; c < chunks; c += 64) {
+      u4 x = p[c];
+      a = accumulate<TYPE, KM_IP>(a, x, x);
+    }
+    float inv = 1.0f / sqrtf(group_reduce<64>(a));
+    for (uint32_t c = lane; c < chunks; c += 64) {
+      u4 x = p[c];
+      uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (TYPE == KT_F32) {
+          w[j] = __float_as_uint(__uint_as_float(w[j]) * inv);
+        } else if (TYPE == KT_F16) {
+          half2_t h = as_h2(w[j]);
+          h.x = (_Float16)((float)h.x * inv);
+          h.y = (_Float16)((float)h.y * inv);
+          __builtin_memcpy(&w[j], &h, 4);
+        } else {  // bf16, round to nearest even
+          uint32_t lo = __float_as_uint(bf_lo(w[j]) * inv), hi = __float_as_uint(bf_hi(w[j]) * inv);
+          lo = (lo + 0x7fffu + ((lo >> 16) & 1)) >> 16;
+          hi = (hi + 0x7fffu + ((hi >> 16) & 1)) & 0xffff0000u;
+          w[j] = hi | lo;
+        }
+      }
+      x = (u4){w[0], w[1], w[2], w[3]};
+      p[c] = x;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
+                 uint32_t row_end, const void *query, uint32_t *keys, hipStream_t s) {
+  (void)dim;
+  if (row_end <= row_begin) return;
+  LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
+              (const u4 *)query, nullptr, keys, nullptr, s};
+  dispatch<false>(type, metric, c);
+}
+
+void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
+                   uint32_t m, const void *query, float *out, hipStream_t s) {
+  (void)dim;
+  if (!m) return;
+  LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), 0, m,
+              (const u4 *)query, row_ids, nullptr, out, s};
+  dispatch<true>(type, metric, c);
+}
+
+void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, uint32_t row_begin, uint32_t row_end,
+                           hipStream_t s) {
+  (void)dim;
+  if (row_end <= row_begin) return;
+  uint32_t n = row_end - row_begin;
+  uint32_t need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  uint32_t grid = need < cap ? need : cap;
+  uint32_t s16 = (uint32_t)(stride / 16);
+  switch (type) {
+    case KT_F32:
+      hipLaunchKernelGGL(normalize_rows_kernel<KT_F32>, dim3(grid), dim3(256), 0, s, (u4 *)rows, s16, s16, row_begin, row_end);
+      break;
+    case KT_F16:
+      hipLaunchKernelGGL(normalize_rows_kernel<KT_F16>, dim3(grid), dim3(256), 0, s, (u4 *)rows, s16, s16, row_begin, row_end);
+      break;
+    case KT_BF16:
+      hipLaunchKernelGGL(normalize_rows_kernel<KT_BF16>, dim3(grid), dim3(256), 0, s, (u4 *)rows, s16, s16, row_begin, row_end);
+      break;
+    default: break;
+  }
+}
+
+}  // namespace rsgpu

@@ -1,0 +1,537 @@
+// vecsim_abi.cpp -- the VecSim C ABI (include/VecSim/*.h) implemented on the MI355X FLAT engine,
+// plus the non-ABI extensions of include/rsgpu_ext.h.
+//
+// This translation unit is the drop-in seam: every function below is bound by the reference at the
+// file:line quoted in the headers.  No exception crosses the boundary: failures become NULL / NaN /
+// an error code plus a message through the installed log callback (SURVEY.md 8b "Errors").
+#include <algorithm>
+#include <cmath>
+#include <strings.h>
+
+#include "flat_index.hpp"
+#include "rsgpu_ext.h"
+
+using namespace rsgpu;
+
+namespace rsgpu {
+void normalize_blob(void *blob, size_t dim, VecSimType type);
+}
+
+struct VecSimIndex {
+  FlatIndex *flat;
+};
+struct VecSimBatchIterator {
+  BatchIterator it;
+};
+struct VecSimAdhocBfCtx {
+  AdhocCtx a;
+};
+struct VecSimDebugInfoIterator {
+  std::vector<VecSim_InfoField> fields;
+  std::vector<std::string> strings;
+  size_t pos = 0;
+};
+
+static thread_local std::string tls_error;
+static void set_error(void *log_ctx, const char *where, const char *what) {
+  tls_error = std::string(where) + ": " + what;
+  logf(log_ctx, VecSimCommonStrings_LOG_WARNING_STRING, "%s", tls_error.c_str());
+}
+#define ABI_TRY try {
+#define ABI_CATCH(lctx, where, failval)              \
+  }                                                  \
+  catch (const std::exception &e) {                  \
+    set_error(lctx, where, e.what());                \
+    return failval;                                  \
+  }                                                  \
+  catch (...) {                                      \
+    set_error(lctx, where, "unknown error");         \
+    return failval;                                  \
+  }
+
+static bool type_supported(VecSimType t) {
+  return t == VecSimType_FLOAT32 || t == VecSimType_FLOAT16 || t == VecSimType_BFLOAT16;
+}
+
+extern "C" {
+
+// ---- lifecycle -----------------------------------------------------------------------------------
+VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
+  if (!params) return nullptr;
+  void *lctx = params->logCtx;
+  ABI_TRY
+  if (params->algo != VecSimAlgo_BF) {
+    set_error(lctx, "VecSimIndex_New", "only VecSimAlgo_BF (FLAT) is served by the MI355X engine");
+    return nullptr;
+  }
+  const BFParams &bf = params->algoParams.bfParams;
+  if (bf.dim == 0 || !type_supported(bf.type) || (int)bf.metric < 0 || (int)bf.metric > (int)VecSimMetric_Cosine) {
+    set_error(lctx, "VecSimIndex_New", "unsupported FLAT parameters (dim>0; type FLOAT32/FLOAT16/BFLOAT16)");
+    return nullptr;
+  }
+  std::string why;
+  if (!device_available(&why)) {  // no CPU fallback: fail loudly
+    set_error(lctx, "VecSimIndex_New", why.c_str());
+    return nullptr;
+  }
+  VecSimIndex *idx = new VecSimIndex{new FlatIndex(bf, lctx)};
+  return idx;
+  ABI_CATCH(lctx, "VecSimIndex_New", nullptr)
+}
+
+VecSimIndex *VecSimIndex_NewDisk(const VecSimParamsDisk *) { return nullptr; }
+
+void VecSimIndex_Free(VecSimIndex *index) {
+  if (!index) return;
+  try {
+    delete index->flat;
+  } catch (...) {
+  }
+  delete index;
+}
+
+size_t VecSimIndex_EstimateElementSize(const VecSimParams *params) {
+  if (!params || params->algo != VecSimAlgo_BF) return 0;
+  const BFParams &bf = params->algoParams.bfParams;
+  // one stored row + its label (host row_label entry and device label)
+  return round_up(bf.dim * type_size(bf.type), 16) + 2 * sizeof(uint64_t);
+}
+size_t VecSimIndex_EstimateInitialSize(const VecSimParams *params) {
+  if (!params || params->algo != VecSimAlgo_BF) return 0;
+  return sizeof(FlatIndex) + sizeof(VecSimIndex);
+}
+
+// ---- writes --------------------------------------------------------------------------------------
+int VecSimIndex_AddVector(VecSimIndex *index, const void *blob, size_t label) {
+  if (!index || !blob) return 0;
+  ABI_TRY
+  return index->flat->add(blob, label);
+  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_AddVector", 0)
+}
+int VecSimIndex_DeleteVector(VecSimIndex *index, size_t label) {
+  if (!index) return 0;
+  ABI_TRY
+  return index->flat->remove(label);
+  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_DeleteVector", 0)
+}
+
+// ---- info ----------------------------------------------------------------------------------------
+size_t VecSimIndex_IndexSize(VecSimIndex *index) { return index ? index->flat->size() : 0; }
+VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index) {
+  if (index) return index->flat->basic_info();
+  VecSimIndexBasicInfo i;
+  memset(&i, 0, sizeof i);
+  return i;
+}
+VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index) {
+  VecSimIndexStatsInfo s;
+  memset(&s, 0, sizeof s);
+  if (index) s.memory = index->flat->memory();
+  return s;
+}
+
+static const char *type_str(VecSimType t) {
+  switch (t) {
+    case VecSimType_FLOAT32: return "FLOAT32";
+    case VecSimType_FLOAT64: return "FLOAT64";
+    case VecSimType_BFLOAT16: return "BFLOAT16";
+    case VecSimType_FLOAT16: return "FLOAT16";
+    case VecSimType_INT8: return "INT8";
+    case VecSimType_UINT8: return "UINT8";
+    default: return "UNKNOWN";
+  }
+}
+static const char *metric_str(VecSimMetric m) {
+  return m == VecSimMetric_L2 ? "L2" : m == VecSimMetric_IP ? "IP" : "COSINE";
+}
+static const char *mode_str(int m) {
+  switch (m) {
+    case EMPTY_MODE: return "EMPTY_MODE";
+    case STANDARD_KNN: return "STANDARD_KNN";
+    case HYBRID_ADHOC_BF: return "HYBRID_ADHOC_BF";
+    case HYBRID_BATCHES: return "HYBRID_BATCHES";
+    case HYBRID_BATCHES_TO_ADHOC_BF: return "HYBRID_BATCHES_TO_ADHOC_BF";
+    case RANGE_QUERY: return "RANGE_QUERY";
+    default: return "UNKNOWN";
+  }
+}
+
+// Field list of a FLAT index as FT.DEBUG VECSIM_INFO prints it (reference
+// tests/pytests/test_vecsim.py:342, the FRONTEND_INDEX part).
+VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
+  if (!index) return nullptr;
+  FlatIndex *f = index->flat;
+  auto *it = new VecSimDebugInfoIterator();
+  auto add_s = [&](const char *n, const char *v) {
+    VecSim_InfoField fld; fld.fieldName = n; fld.fieldType = INFOFIELD_STRING; fld.fieldValue.stringValue = v;
+    it->fields.push_back(fld);
+  };
+  auto add_u = [&](const char *n, uint64_t v) {
+    VecSim_InfoField fld; fld.fieldName = n; fld.fieldType = INFOFIELD_UINT64; fld.fieldValue.uintegerValue = v;
+    it->fields.push_back(fld);
+  };
+  add_s("ALGORITHM", "FLAT");
+  add_s("TYPE", type_str(f->type));
+  add_u("DIMENSION", f->dim);
+  add_s("METRIC", metric_str(f->metric));
+  add_u("IS_MULTI_VALUE", f->multi);
+  add_u("IS_DISK", 0);
+  add_u("INDEX_SIZE", f->size());
+  add_u("INDEX_LABEL_COUNT", f->label_count());
+  add_u("MEMORY", f->memory());
+  add_s("LAST_SEARCH_MODE", mode_str(f->last_mode.load()));
+  add_u("BLOCK_SIZE", f->block_size);
+  return it;
+}
+size_t VecSimDebugInfoIterator_NumberOfFields(VecSimDebugInfoIterator *it) { return it ? it->fields.size() : 0; }
+bool VecSimDebugInfoIterator_HasNextField(VecSimDebugInfoIterator *it) { return it && it->pos < it->fields.size(); }
+VecSim_InfoField *VecSimDebugInfoIterator_NextField(VecSimDebugInfoIterator *it) {
+  return (it && it->pos < it->fields.size()) ? &it->fields[it->pos++] : nullptr;
+}
+void VecSimDebugInfoIterator_Free(VecSimDebugInfoIterator *it) { delete it; }
+
+// ---- query-param resolution (host logic; pins: reference tests/pytests/test_vecsim.py:692-765) -------
+static bool ieq(const VecSimRawParam &p, const char *name) {
+  return p.nameLen == strlen(name) && strncasecmp(p.name, name, p.nameLen) == 0;
+}
+static bool parse_positive(const VecSimRawParam &p, size_t *out) {
+  if (!p.valLen) return false;
+  std::string s(p.value, p.valLen);
+  char *end = nullptr;
+  errno = 0;
+  long long v = strtoll(s.c_str(), &end, 10);
+  if (errno || end == s.c_str() || *end != '\0' || v <= 0) return false;
+  *out = (size_t)v;
+  return true;
+}
+VecSimResolveCode VecSimIndex_ResolveParams(VecSimIndex *index, VecSimRawParam *rparams, int paramNum,
+                                            VecSimQueryParams *qparams, VecsimQueryType query_type) {
+  (void)index;
+  if (!qparams || (paramNum && !rparams)) return VecSimParamResolverErr_UnknownParam;
+  void *tctx = qparams->timeoutCtx;
+  memset(qparams, 0, sizeof *qparams);
+  qparams->timeoutCtx = tctx;
+  bool batch_set = false;
+  for (int i = 0; i < paramNum; i++) {
+    const VecSimRawParam &p = rparams[i];
+    if (ieq(p, "EPSILON")) {
+      // range-only, and only for approximate indexes: FLAT has no epsilon
+      if (query_type != QUERY_TYPE_RANGE) return VecSimParamResolverErr_InvalidPolicy_NRange;
+      return VecSimParamResolverErr_UnknownParam;
+    } else if (ieq(p, "BATCH_SIZE")) {
+      if (query_type != QUERY_TYPE_HYBRID) return VecSimParamResolverErr_InvalidPolicy_NHybrid;
+      if (batch_set) return VecSimParamResolverErr_AlreadySet;
+      size_t v;
+      if (!parse_positive(p, &v)) return VecSimParamResolverErr_BadValue;
+      qparams->batchSize = v;
+      batch_set = true;
+    } else if (ieq(p, "HYBRID_POLICY")) {
+      if (query_type != QUERY_TYPE_HYBRID) return VecSimParamResolverErr_InvalidPolicy_NHybrid;
+      if (qparams->searchMode != EMPTY_MODE) return VecSimParamResolverErr_AlreadySet;
+      if (p.valLen == 7 && !strncasecmp(p.value, "batches", 7)) qparams->searchMode = HYBRID_BATCHES;
+      else if (p.valLen == 8 && !strncasecmp(p.value, "adhoc_bf", 8)) qparams->searchMode = HYBRID_ADHOC_BF;
+      else return VecSimParamResolverErr_InvalidPolicy_NExits;
+    } else {
+      // EF_RUNTIME, RERANK, SVS knobs ...: not options of a FLAT index
+      return VecSimParamResolverErr_UnknownParam;
+    }
+  }
+  if (qparams->searchMode == HYBRID_ADHOC_BF && qparams->batchSize > 0)
+    return VecSimParamResolverErr_InvalidPolicy_AdHoc_With_BatchSize;
+  return VecSim_OK;
+}
+
+// ---- queries -------------------------------------------------------------------------------------
+VecSimQueryReply *VecSimIndex_TopKQuery(VecSimIndex *index, const void *queryBlob, size_t k,
+                                        VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
+  if (!index || !queryBlob) return nullptr;
+  ABI_TRY
+  return index->flat->topk(queryBlob, k, queryParams, order);
+  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_TopKQuery", nullptr)
+}
+
+VecSimQueryReply *VecSimIndex_RangeQuery(VecSimIndex *index, const void *queryBlob, double radius,
+                                         VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
+  if (!index || !queryBlob) return nullptr;
+  ABI_TRY
+  return index->flat->range(queryBlob, radius, queryParams, order);
+  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_RangeQuery", nullptr)
+}
+
+double VecSimIndex_GetDistanceFrom_Unsafe(VecSimIndex *index, size_t label, const void *blob) {
+  if (!index || !blob) return NAN;
+  ABI_TRY
+  return index->flat->distance_from(label, blob);
+  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_GetDistanceFrom_Unsafe", NAN)
+}
+
+bool VecSimIndex_PreferAdHocSearch(VecSimIndex *index, size_t subsetSize, size_t k, bool initialCheck) {
+  return index ? index->flat->prefer_adhoc(subsetSize, k, initialCheck) : true;
+}
+
+// ---- batch iterator ------------------------------------------------------------------------------
+VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *queryBlob, VecSimQueryParams *queryParams) {
+  if (!index || !queryBlob) return nullptr;
+  FlatIndex *f = index->flat;
+  ABI_TRY
+  f->flush_if_needed();
+  HIP_CHECK(hipSetDevice(f->device));
+  auto *b = new VecSimBatchIterator();
+  b->it.index = f;
+  b->it.ctx = CtxPool::get().acquire(f->device);
+  b->it.timeout_ctx = queryParams ? queryParams->timeoutCtx : nullptr;
+  size_t bytes = f->dim * type_size(f->type);
+  b->it.query.assign((const uint8_t *)queryBlob, (const uint8_t *)queryBlob + bytes);
+  b->it.n = f->committed_rows();
+  return b;
+  ABI_CATCH(f->log_ctx, "VecSimBatchIterator_New", nullptr)
+}
+
+bool VecSimBatchIterator_HasNext(VecSimBatchIterator *iterator) {
+  return iterator && iterator->it.returned < iterator->it.n;
+}
+
+VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t n_results, VecSimQueryReply_Order order) {
+  if (!iterator) return nullptr;
+  BatchIterator &b = iterator->it;
+  FlatIndex *f = b.index;
+  ABI_TRY
+  f->last_mode = HYBRID_BATCHES;
+  if (timed_out(b.timeout_ctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+  std::shared_lock<std::shared_mutex> g(f->mu);
+  HIP_CHECK(hipSetDevice(f->device));
+  uint32_t n = std::min<uint32_t>(b.n, f->committed_rows());
+  if (!b.scanned) {
+    f->upload_query(b.ctx, b.query.data(), true);
+    f->scan_all(b.ctx, n);
+    b.scanned = true;
+  }
+  std::vector<VecSimQueryResult> res;
+  std::vector<Hit> hits;
+  size_t want = n_results;
+  while (res.size() < want && b.returned < n) {
+    uint32_t ask = (uint32_t)std::min<size_t>(n - b.returned, want - res.size());
+    uint64_t bound = 0;
+    f->select(b.ctx, n, ask, b.lower, b.has_lower, hits, &bound);
+    if (hits.empty()) { b.returned = n; break; }
+    b.returned += (uint32_t)hits.size();
+    b.lower = bound;
+    b.has_lower = true;
+    for (const Hit &h : hits) {
+      uint64_t lab = f->label_of_row(h.row);
+      if (f->multi) {  // a label is yielded once, at its best vector
+        if (std::find(b.seen_labels.begin(), b.seen_labels.end(), lab) != b.seen_labels.end()) continue;
+        b.seen_labels.push_back(lab);
+      }
+      res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist(h.key)});
+    }
+    if (!f->multi) break;
+    if (timed_out(b.timeout_ctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
+  }
+  VecSimQueryReply *r = new_reply(res.size(), VecSim_QueryReply_OK);
+  if (!res.empty()) memcpy(r->results, res.data(), res.size() * sizeof(VecSimQueryResult));
+  if (order == BY_ID)
+    std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &c) { return a.id < c.id; });
+  else
+    std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &c) {
+      return a.score != c.score ? a.score < c.score : a.id < c.id;
+    });
+  return r;
+  ABI_CATCH(f->log_ctx, "VecSimBatchIterator_Next", nullptr)
+}
+
+void VecSimBatchIterator_Reset(VecSimBatchIterator *iterator) {
+  if (!iterator) return;
+  iterator->it.returned = 0;
+  iterator->it.has_lower = false;
+  iterator->it.lower = 0;
+  iterator->it.seen_labels.clear();
+}
+
+void VecSimBatchIterator_Free(VecSimBatchIterator *iterator) {
+  if (!iterator) return;
+  if (iterator->it.ctx) CtxPool::get().release(iterator->it.ctx);
+  delete iterator;
+}
+
+// ---- ad-hoc brute-force context (batched GPU gather) -----------------------------------------------
+VecSimAdhocBfCtx *VecSimIndex_AdhocBfCtx_New(VecSimIndex *index, const void *queryBlob) {
+  if (!index || !queryBlob) return nullptr;
+  FlatIndex *f = index->flat;
+  ABI_TRY
+  f->flush_if_needed();
+  HIP_CHECK(hipSetDevice(f->device));
+  auto *a = new VecSimAdhocBfCtx();
+  a->a.index = f;
+  a->a.ctx = CtxPool::get().acquire(f->device);
+  f->upload_query(a->a.ctx, queryBlob, true);  // normalises a copy for cosine (hybrid_reader.c:212-214)
+  return a;
+  ABI_CATCH(f->log_ctx, "VecSimIndex_AdhocBfCtx_New", nullptr)
+}
+void VecSimIndex_AdhocBfCtx_GetExactDistances(VecSimAdhocBfCtx *ctx, const size_t *labels, double *out, size_t count) {
+  if (!ctx || !count) return;
+  FlatIndex *f = ctx->a.index;
+  try {
+    std::shared_lock<std::shared_mutex> g(f->mu);
+    HIP_CHECK(hipSetDevice(f->device));
+    f->gather(ctx->a.ctx, labels, count, out);
+  } catch (const std::exception &e) {
+    set_error(f->log_ctx, "VecSimIndex_AdhocBfCtx_GetExactDistances", e.what());
+    for (size_t i = 0; i < count; i++) out[i] = NAN;
+  }
+}
+double VecSimIndex_AdhocBfCtx_GetDistanceFrom(VecSimAdhocBfCtx *ctx, size_t label) {
+  double d = NAN;
+  VecSimIndex_AdhocBfCtx_GetExactDistances(ctx, &label, &d, 1);
+  return d;
+}
+void VecSimIndex_AdhocBfCtx_Free(VecSimAdhocBfCtx *ctx) {
+  if (!ctx) return;
+  if (ctx->a.ctx) CtxPool::get().release(ctx->a.ctx);
+  delete ctx;
+}
+
+void VecSimTieredIndex_AcquireSharedLocks(VecSimIndex *) {}
+void VecSimTieredIndex_ReleaseSharedLocks(VecSimIndex *) {}
+void VecSimTieredIndex_GC(VecSimIndex *) {}
+int VecSimDebug_GetElementNeighborsInHNSWGraph(VecSimIndex *, size_t, int ***neighborsData) {
+  if (neighborsData) *neighborsData = nullptr;
+  return VecSimDebugCommandCode_BadIndex;
+}
+void VecSimDebug_ReleaseElementNeighborsInHNSWGraph(int **) {}
+
+// ---- blob helpers ----------------------------------------------------------------------------------
+void VecSim_Normalize(void *blob, size_t dim, VecSimType type) {
+  if (blob) normalize_blob(blob, dim, type);
+}
+size_t VecSimParams_GetQueryBlobSize(VecSimType type, size_t dim, VecSimMetric metric) {
+  size_t s = dim * type_size(type);
+  if (metric == VecSimMetric_Cosine && (type == VecSimType_INT8 || type == VecSimType_UINT8)) s += sizeof(float);
+  return s;
+}
+
+// ---- process-wide hooks ----------------------------------------------------------------------------
+void VecSim_SetMemoryFunctions(VecSimMemoryFunctions f) {
+  if (f.allocFunction && f.callocFunction && f.reallocFunction && f.freeFunction) hooks().mem = f;
+}
+void VecSim_SetTimeoutCallbackFunction(timeoutCallbackFunction cb) { hooks().timeout = cb; }
+void VecSim_SetLogCallbackFunction(logCallbackFunction cb) { hooks().log = cb; }
+void VecSim_SetWriteMode(VecSimWriteMode) {}
+void VecSim_UpdateThreadPoolSize(size_t n) { hooks().thread_pool_size = n; }
+size_t VecSim_GetSharedMemory(void) { return CtxPool::get().bytes(); }
+
+// ---- reply accessors ---------------------------------------------------------------------------------
+size_t VecSimQueryResult_GetId(const VecSimQueryResult *item) { return item ? item->id : (size_t)-1; }
+double VecSimQueryResult_GetScore(const VecSimQueryResult *item) { return item ? item->score : NAN; }
+size_t VecSimQueryReply_Len(VecSimQueryReply *reply) { return reply ? reply->len : 0; }
+VecSimQueryReply_Code VecSimQueryReply_GetCode(VecSimQueryReply *reply) {
+  return reply ? reply->code : VecSim_QueryReply_OK;
+}
+void VecSimQueryReply_Free(VecSimQueryReply *reply) {
+  if (!reply) return;
+  host_free(reply->results);
+  host_free(reply);
+}
+VecSimQueryReply_Iterator *VecSimQueryReply_GetIterator(VecSimQueryReply *reply) {
+  if (!reply) return nullptr;
+  VecSimQueryReply_Iterator *it = host_alloc<VecSimQueryReply_Iterator>(1);
+  it->reply = reply;
+  it->pos = 0;
+  return it;
+}
+VecSimQueryResult *VecSimQueryReply_IteratorNext(VecSimQueryReply_Iterator *it) {
+  if (!it || it->pos >= it->reply->len) return nullptr;
+  return &it->reply->results[it->pos++];
+}
+bool VecSimQueryReply_IteratorHasNext(VecSimQueryReply_Iterator *it) { return it && it->pos < it->reply->len; }
+void VecSimQueryReply_IteratorReset(VecSimQueryReply_Iterator *it) {
+  if (it) it->pos = 0;
+}
+void VecSimQueryReply_IteratorFree(VecSimQueryReply_Iterator *it) { host_free(it); }
+
+// ---- extensions (include/rsgpu_ext.h) ------------------------------------------------------------------
+const char *RSGPU_LastError(void) { return tls_error.c_str(); }
+int RSGPU_DeviceCount(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+int RSGPU_FlatIndex_Reserve(VecSimIndex *index, size_t rows) {
+  if (!index) return -1;
+  ABI_TRY
+  index->flat->reserve(rows);
+  return 0;
+  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_Reserve", -1)
+}
+int RSGPU_FlatIndex_AddDeviceRows(VecSimIndex *index, const void *dev_rows, size_t n, size_t first_label) {
+  if (!index) return -1;
+  ABI_TRY
+  return index->flat->add_device_rows(dev_rows, n, first_label);
+  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_AddDeviceRows", -1)
+}
+int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, float *dev_scores, uint64_t *dev_labels) {
+  if (!index || !query || !k) return -1;
+  FlatIndex *f = index->flat;
+  ABI_TRY
+  VecSimQueryReply *r = f->topk(query, k, nullptr, BY_SCORE);
+  std::vector<float> sc(k, INFINITY);
+  std::vector<uint64_t> lb(k, UINT64_MAX);
+  int got = (int)r->len;
+  for (size_t i = 0; i < r->len; i++) {
+    sc[i] = (float)r->results[i].score;
+    lb[i] = r->results[i].id;
+  }
+  VecSimQueryReply_Free(r);
+  HIP_CHECK(hipSetDevice(f->device));
+  HIP_CHECK(hipMemcpy(dev_scores, sc.data(), k * sizeof(float), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(dev_labels, lb.data(), k * sizeof(uint64_t), hipMemcpyHostToDevice));
+  return got;
+  ABI_CATCH(f->log_ctx, "RSGPU_FlatIndex_TopKDevice", -1)
+}
+int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
+                    double *scores_out, uint64_t *labels_out, void *wait_stream) {
+  ABI_TRY
+  HIP_CHECK(hipSetDevice(device));
+  if (wait_stream) HIP_CHECK(hipStreamSynchronize((hipStream_t)wait_stream));
+  std::vector<float> sc(m);
+  std::vector<uint64_t> lb(m);
+  HIP_CHECK(hipMemcpy(sc.data(), dev_scores, m * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(lb.data(), dev_labels, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  // the coordinator-style K-way merge of per-shard top-k lists (reference src/module.c:3541-3547)
+  std::vector<size_t> ord;
+  ord.reserve(m);
+  for (size_t i = 0; i < m; i++)
+    if (lb[i] != UINT64_MAX) ord.push_back(i);
+  size_t kk = std::min(k, ord.size());
+  std::partial_sort(ord.begin(), ord.begin() + (long)kk, ord.end(), [&](size_t a, size_t b) {
+    return sc[a] != sc[b] ? sc[a] < sc[b] : lb[a] < lb[b];
+  });
+  for (size_t i = 0; i < kk; i++) {
+    scores_out[i] = (double)sc[ord[i]];
+    labels_out[i] = lb[ord[i]];
+  }
+  return (int)kk;
+  ABI_CATCH(nullptr, "RSGPU_MergeTopK", -1)
+}
+
+void RSGPU_SetProfiling(int on) { scan_profile().enabled = on; }
+void RSGPU_ResetProfile(void) {
+  scan_profile().launches = 0;
+  scan_profile().bytes = 0;
+  scan_profile().nanos = 0;
+}
+void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes) {
+  if (launches) *launches = scan_profile().launches.load();
+  if (total_ms) *total_ms = (double)scan_profile().nanos.load() / 1e6;
+  if (bytes) *bytes = scan_profile().bytes.load();
+}
+int RSGPU_SetTuning(const char *key, int value) {
+  if (!key) return -1;
+  if (!strcmp(key, "blocks_per_cu")) scan_tuning().blocks_per_cu = value;
+  else if (!strcmp(key, "rows_per_group")) scan_tuning().rows_per_group = value;
+  else if (!strcmp(key, "nontemporal")) scan_tuning().nontemporal = value;
+  else return -1;
+  return 0;
+}
+void RSGPU_ReleaseWorkspaces(void) { CtxPool::get().drain(); }
+
+}  // extern "C"
