@@ -31,7 +31,7 @@ inline float key_to_dist(uint32_t k) {
 }
 
 struct ScanTuning {
-  int blocks_per_cu = 8;   // resident 256-thread blocks per CU the grid is sized for
+  int blocks_per_cu = 16;  // 256-thread blocks per CU the grid is sized for (profiles/r01_tune_scan_*.json)
   int rows_per_group = 0;  // 0 = per-shape default (U in the kernel)
   int nontemporal = 1;     // stream the corpus with nt loads
   int num_cus = 256;
