@@ -1,0 +1,126 @@
+/*
+ * rsgpu_search.h -- C ABI of the integer / scoring half of the hot path on MI355X: posting-list
+ * decode, N-way intersection, the built-in scorers and the score top-N, plus the hybrid
+ * (pre-filter -> FLAT ad-hoc KNN) step.
+ *
+ * What each entry point replaces in the reference:
+ *   RSGPU_Postings_Upload / _Decode   the block reader + codecs
+ *                                     (src/redisearch_rs/inverted_index/src/reader/core.rs,
+ *                                      codec/{full,freqs_only,doc_ids_only,...}.rs, qint/src/lib.rs:139-214)
+ *   RSGPU_Intersect                   Intersection::read / find_consensus
+ *                                     (src/redisearch_rs/rqe_iterators/src/intersection.rs:256-288,428-452)
+ *                                     C constructor NewIntersectionIterator, headers/iterators_ffi.h:309
+ *   RSGPU_Hits_Score                  the RSScoringFunction loop rpscoreNext drives
+ *                                     (src/result_processor.c:570-603 over src/ext/default.c:68-461)
+ *   RSGPU_Hits_TopN                   rpsortNext_innerLoop + cmpByScore (src/result_processor.c:752-850)
+ *   RSGPU_Hits_KnnRerank              HybridIterator ADHOC_BF: computeDistances_RAM
+ *                                     (src/iterators/hybrid_reader.c:289-335)
+ *   RSGPU_CalculateIDF / _BM25        CalculateIDF / CalculateIDF_BM25
+ *                                     (src/redisearch_rs/c_entrypoint/idf_ffi/src/lib.rs -> idf/src/lib.rs:67-108)
+ *
+ * These are batch-granular on purpose: the reference's per-result virtual calls (one Read(), one
+ * scorer call per hit) cannot feed a GPU (SURVEY.md 8b boundary 2/3).  INTEGRATION.md shows the
+ * adapter that hands a hit list back to the C pipeline through NewSortedIdListIterator /
+ * NewMetricIteratorSortedByScore (headers/iterators_ffi.h:574,480).
+ *
+ * The posting bytes are uploaded AS-IS in the reference's block format; decoding happens on the
+ * device.  Doc ids must be < 2^32 (they are monotonically assigned from 1).
+ */
+#ifndef RSGPU_SEARCH_H
+#define RSGPU_SEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "VecSim/vec_sim.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* posting codecs (record layouts under inverted_index/src/codec/) */
+typedef enum {
+  RSGPU_CODEC_FULL = 0,           /* qint[delta,freq,fieldMask,offsetsLen] + offsets bytes */
+  RSGPU_CODEC_FREQS_FIELDS = 1,   /* qint[delta,freq,fieldMask] */
+  RSGPU_CODEC_FREQS_ONLY = 2,     /* qint[delta,freq] */
+  RSGPU_CODEC_FIELDS_ONLY = 3,    /* qint[delta,fieldMask] */
+  RSGPU_CODEC_FIELDS_OFFSETS = 4, /* qint[delta,fieldMask,offsetsLen] + offsets */
+  RSGPU_CODEC_OFFSETS_ONLY = 5,   /* qint[delta,offsetsLen] + offsets */
+  RSGPU_CODEC_FREQS_OFFSETS = 6,  /* qint[delta,freq,offsetsLen] + offsets */
+  RSGPU_CODEC_DOCIDS_ONLY = 7,    /* varint delta */
+  RSGPU_CODEC_RAW_DOCIDS = 8      /* u32 delta from the block's first doc id */
+} RSGPU_Codec;
+
+/* scorers registered by DefaultExtensionInit (reference src/ext/default.c:737-) */
+typedef enum {
+  RSGPU_SCORER_BM25STD = 0,
+  RSGPU_SCORER_BM25STD_TANH = 1,
+  RSGPU_SCORER_BM25 = 2,
+  RSGPU_SCORER_TFIDF = 3,
+  RSGPU_SCORER_TFIDF_DOCNORM = 4,
+  RSGPU_SCORER_DOCSCORE = 5,
+  RSGPU_SCORER_DISMAX = 6
+} RSGPU_Scorer;
+
+typedef struct RSGPU_Postings RSGPU_Postings;
+typedef struct RSGPU_Hits RSGPU_Hits;
+typedef struct RSGPU_DocTable RSGPU_DocTable;
+
+/* Upload one posting list: per-block headers (IndexBlock first/last doc id, entry count; byte_offset
+ * has n_blocks+1 entries into `bytes`). NULL on failure (RSGPU_LastError). */
+RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t *first_doc_id,
+                                      const uint64_t *last_doc_id, const uint32_t *num_entries,
+                                      const uint64_t *byte_offset, const uint8_t *bytes);
+void RSGPU_Postings_Free(RSGPU_Postings *p);
+size_t RSGPU_Postings_NumEntries(const RSGPU_Postings *p);
+size_t RSGPU_Postings_NumBytes(const RSGPU_Postings *p);
+/* Decode every record on the device; any host output may be NULL. Returns #records or -1. */
+long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *freqs_out, uint32_t *masks_out);
+
+/* Docs present in ALL lists (decode + intersect on the device). Hits are ascending by doc id and carry
+ * the matched frequency of every input list. NULL on failure. */
+RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists);
+void RSGPU_Hits_Free(RSGPU_Hits *h);
+size_t RSGPU_Hits_Len(const RSGPU_Hits *h);
+/* doc_ids[len]; freqs[n_lists][len] in the order the lists were given. Either may be NULL. */
+int RSGPU_Hits_Read(const RSGPU_Hits *h, uint64_t *doc_ids, uint32_t *freqs);
+
+/* Per-document scorer inputs (RSDocumentMetadata: score, maxTermFreq, docLen -- reference
+ * src/redisearch.h:97-132), arrays indexed by doc id, n = max doc id + 1. */
+RSGPU_DocTable *RSGPU_DocTable_Upload(size_t n, const uint32_t *doc_len, const float *doc_score,
+                                      const uint32_t *max_term_freq);
+void RSGPU_DocTable_Free(RSGPU_DocTable *t);
+
+typedef struct {
+  int scorer;           /* RSGPU_Scorer */
+  size_t num_docs;      /* ScoringFunctionArgs.indexStats.numDocs */
+  double avg_doc_len;   /* indexStats.avgDocLen */
+  uint64_t tanh_factor; /* BM25STD.TANH */
+  double root_weight;   /* weight of the intersection node */
+  double min_score;     /* early-out threshold of TFIDF / legacy BM25 (0 = off) */
+  const double *idf;      /* [n_lists] QueryTerm_GetIDF */
+  const double *bm25_idf; /* [n_lists] QueryTerm_GetBM25_IDF */
+  const double *weight;   /* [n_lists] term node weights */
+} RSGPU_ScoreArgs;
+
+/* Score every hit as Intersection{Term...} (fp64, the C source's float constants). scores_out (host,
+ * [len]) may be NULL; the scores also stay on the device for _TopN. 0 on success. */
+int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreArgs *args, double *scores_out);
+/* n best hits by (score descending, doc id ascending). Returns #written or -1. */
+long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *scores_out);
+/* Ad-hoc brute force over the hits: k nearest (distance ascending, doc id ascending) among the hits
+ * that exist in the FLAT index. Returns #written or -1. */
+long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
+                          double *dist_out);
+
+/* idf = logb(1 + (N+1)/max(n,1)); bm25 idf = ln(1 + (max(N,n) - n + 0.5)/(n + 0.5)) */
+double RSGPU_CalculateIDF(size_t total_docs, size_t term_docs);
+double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs);
+
+/* GPU milliseconds (HIP events) of the last call of each stage on the calling thread */
+void RSGPU_SearchProfile(double *decode_ms, double *intersect_ms, double *score_ms, double *topn_ms, double *knn_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSGPU_SEARCH_H */

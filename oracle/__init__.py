@@ -86,6 +86,7 @@ _sig("oracle_varint_decode", _sz, _vp, _sz, C.POINTER(C.c_uint64))
 _sig("oinv_new", _vp, _i)
 _sig("oinv_free", None, _vp)
 _sig("oinv_add", _i, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32)
+_sig("oinv_add_many", None, _vp, _vp, _vp, _sz)
 _sig("oinv_num_blocks", _sz, _vp)
 _sig("oinv_unique_docs", C.c_uint32, _vp)
 _sig("oinv_total_bytes", _sz, _vp)
@@ -339,11 +340,9 @@ class InvertedIndex:
         return lib.oinv_add(self.h, doc, freq, mask, _p(ob), len(offsets))
 
     def add_many(self, docs, freqs=None):
-        dummy = np.zeros(1, dtype=np.uint8)
-        fr = freqs if freqs is not None else np.ones(len(docs), dtype=np.uint32)
-        add, h, pd = lib.oinv_add, self.h, _p(dummy)
-        for d, f in zip(docs.tolist(), fr.tolist()):
-            add(h, d, f, 1, pd, 0)
+        d = np.ascontiguousarray(docs, dtype=np.uint64)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32) if freqs is not None else None
+        lib.oinv_add_many(self.h, _p(d), _p(f) if f is not None else None, d.size)
 
     @property
     def unique_docs(self):

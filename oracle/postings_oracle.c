@@ -123,6 +123,9 @@ int oinv_add(OInv *ii, uint64_t doc, uint32_t freq, uint32_t mask, const uint8_t
   bl->n++; bl->last = doc; ii->n_unique++;
   return 1;
 }
+void oinv_add_many(OInv *ii, const uint64_t *docs, const uint32_t *freqs, size_t n) {
+  for (size_t i = 0; i < n; i++) oinv_add(ii, docs[i], freqs ? freqs[i] : 1, 1, NULL, 0);
+}
 size_t oinv_num_blocks(const OInv *ii) { return ii->nb; }
 uint32_t oinv_unique_docs(const OInv *ii) { return ii->n_unique; }
 size_t oinv_total_bytes(const OInv *ii) { size_t s = 0; for (size_t i = 0; i < ii->nb; i++) s += ii->b[i].len; return s; }

@@ -38,12 +38,16 @@ def _deps_mtime():
     return m
 
 
+# per-source extra flags: the scorers must not contract a*b+c behind the C source's back
+EXTRA = {"postings_kernels.hip": ["-ffp-contract=off"]}
+
+
 def _compile(src, force, hdr_m):
     obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_m):
         return obj
-    cmd = [HIPCC] + COMMON + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + COMMON + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     subprocess.check_call(cmd)
     return obj
 

@@ -44,6 +44,11 @@ bool timed_out(void *timeout_ctx) {
   return cb && cb(timeout_ctx) != 0;
 }
 
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
 ScanProfile &scan_profile() {
   static ScanProfile p;
   return p;
@@ -174,10 +179,10 @@ QueryCtx::QueryCtx(int dev) : device(dev) {
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreate(&ev0));
   HIP_CHECK(hipEventCreate(&ev1));
-  dev_realloc(d_hist, 0, 8 * 256);
+  dev_realloc(d_hist, 0, kSelectLevelsMax * 256);
   dev_realloc(d_counters, 0, 4);
-  dev_realloc(d_bound, 0, 1);
-  pin_realloc(h_counters, 8);
+  dev_realloc(d_bound, 0, 2);
+  pin_realloc(h_counters, 16);
 }
 #define HIP_IGNORE(x) (void)(x)
 QueryCtx::~QueryCtx() {
@@ -530,24 +535,29 @@ static void collect_profile(QueryCtx *c) {
   pf.nanos += (uint64_t)((double)ms * 1e6);
 }
 
-bool FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, uint64_t lower, bool has_lower, std::vector<Hit> &out,
-                       uint64_t *bound_out) {
+void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, uint32_t k, const Bound &lower,
+                  std::vector<Hit> &out, Bound *upper) {
   out.clear();
-  if (!k || !n) return true;
+  if (upper) *upper = lower;
+  if (!k || !n) return;
   c->ensure_out(k);
   SelectBufs b{c->d_hist, c->d_counters, c->d_out_rows, c->d_out_keys, c->d_bound};
-  HIP_CHECK(hipMemsetAsync(c->d_hist, 0, 8 * 256 * sizeof(uint32_t), c->stream));
+  HIP_CHECK(hipMemsetAsync(c->d_hist, 0, kSelectLevelsMax * 256 * sizeof(uint32_t), c->stream));
   HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+  const int levels = key_bytes + 4, has_lower = lower.valid ? 1 : 0;
   int done = 0;
+  // key levels first; the four row levels only when equal keys straddle rank k
   for (int round = 0; round < 2; round++) {
-    for (int p = done; p < done + 4; p++) launch_select_pass(c->d_keys, n, p, k, lower, has_lower ? 1 : 0, b, c->stream);
-    done += 4;
-    launch_select_collect(c->d_keys, n, done, k, lower, has_lower ? 1 : 0, b, (uint32_t)c->out_cap, c->stream);
+    int upto = round == 0 ? key_bytes : levels;
+    for (int p = done; p < upto; p++)
+      launch_select_pass(d_keys, key_bytes, n, p, k, lower.key, lower.row, has_lower, b, c->stream);
+    done = upto;
+    launch_select_collect(d_keys, key_bytes, n, done, k, lower.key, lower.row, has_lower, b, (uint32_t)c->out_cap, c->stream);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipMemcpyAsync(c->h_bound(), c->d_bound, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->h_bound(), c->d_bound, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, (size_t)k * key_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     collect_profile(c);
     if (c->h_counters[1] == 0) break;  // exact
@@ -555,12 +565,21 @@ bool FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, uint64_t lower, bool
   }
   uint32_t got = std::min<uint32_t>(c->h_counters[0], k);
   out.resize(got);
-  for (uint32_t i = 0; i < got; i++) out[i] = Hit{c->h_out_rows[i], c->h_out_keys[i]};
+  const uint32_t *k32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
+  for (uint32_t i = 0; i < got; i++)
+    out[i] = Hit{c->h_out_rows[i], key_bytes == 8 ? c->h_out_keys[i] : (uint64_t)k32[i]};
   std::sort(out.begin(), out.end(), [](const Hit &a, const Hit &b2) {
     return a.key != b2.key ? a.key < b2.key : a.row < b2.row;
   });
-  if (bound_out) *bound_out = *c->h_bound();
-  return true;
+  if (upper) {
+    upper->key = c->h_bound()[0];
+    upper->row = (uint32_t)c->h_bound()[1];
+    upper->valid = true;
+  }
+}
+
+void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper) {
+  radix_select(c, c->d_keys, 4, n, k, lower, out, upper);
 }
 
 static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
@@ -589,30 +608,28 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   std::vector<VecSimQueryResult> res;
   if (!multi) {
     uint32_t kk = (uint32_t)std::min<size_t>(k, n);
-    select(c.c, n, kk, 0, false, hits, nullptr);
+    select(c.c, n, kk, Bound(), hits, nullptr);
     if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
     res.reserve(hits.size());
-    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], (double)key_to_dist(h.key)});
+    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], (double)key_to_dist((uint32_t)h.key)});
   } else {
     // multi-value: walk batches in ascending composite order, first occurrence of a label is its best
     std::unordered_map<uint64_t, char> seen;
-    uint64_t lower = 0;
-    bool has_lower = false;
+    Bound lower;
     uint32_t consumed = 0;
     size_t want = std::min<size_t>(k, n);
     while (res.size() < want && consumed < n) {
       uint32_t ask = (uint32_t)std::min<size_t>(n - consumed, std::max<size_t>((want - res.size()) * 2, 16));
-      uint64_t bound = 0;
-      select(c.c, n, ask, lower, has_lower, hits, &bound);
+      Bound bound;
+      select(c.c, n, ask, lower, hits, &bound);
       if (hits.empty()) break;
       consumed += (uint32_t)hits.size();
       for (const Hit &h : hits) {
         uint64_t lab = row_label_[h.row];
         if (res.size() < want && seen.emplace(lab, 1).second)
-          res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist(h.key)});
+          res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist((uint32_t)h.key)});
       }
       lower = bound;
-      has_lower = true;
       if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
     }
   }
@@ -648,20 +665,21 @@ VecSimQueryReply *FlatIndex::range(const void *query, double radius, VecSimQuery
   if (!cnt) return new_reply(0, VecSim_QueryReply_OK);
   c->ensure_out(cnt);
   HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
-  launch_range(c->d_keys, n, max_key, 1, c->d_counters, c->d_out_rows, c->d_out_keys, (uint32_t)c->out_cap, c->stream);
+  launch_range(c->d_keys, n, max_key, 1, c->d_counters, c->d_out_rows, (uint32_t *)c->d_out_keys, (uint32_t)c->out_cap, c->stream);
   HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   std::vector<VecSimQueryResult> res;
   res.reserve(cnt);
+  const uint32_t *rk32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
   if (!multi) {
     for (uint32_t i = 0; i < cnt; i++)
-      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], (double)key_to_dist(c->h_out_keys[i])});
+      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], (double)key_to_dist(rk32[i])});
   } else {
     std::unordered_map<uint64_t, size_t> best;
     for (uint32_t i = 0; i < cnt; i++) {
       uint64_t lab = row_label_[c->h_out_rows[i]];
-      double d = (double)key_to_dist(c->h_out_keys[i]);
+      double d = (double)key_to_dist(rk32[i]);
       auto it = best.find(lab);
       if (it == best.end()) {
         best[lab] = res.size();

@@ -25,7 +25,13 @@ namespace rsgpu {
 
 struct Hit {
   uint32_t row;
-  uint32_t key;
+  uint64_t key;
+};
+// exclusive lower bound / inclusive upper bound of a selection in composite (key,row) order
+struct Bound {
+  uint64_t key = 0;
+  uint32_t row = 0;
+  bool valid = false;
 };
 
 // Per in-flight query workspace: own stream, device scratch and pinned host mirrors.
@@ -44,10 +50,10 @@ struct QueryCtx {
   // select state
   uint32_t *d_hist = nullptr, *d_counters = nullptr;
   uint64_t *d_bound = nullptr;
-  uint32_t *d_out_rows = nullptr, *d_out_keys = nullptr;
-  uint32_t *h_out_rows = nullptr, *h_out_keys = nullptr;
+  uint32_t *d_out_rows = nullptr, *h_out_rows = nullptr;
+  uint64_t *d_out_keys = nullptr, *h_out_keys = nullptr;  // sized for u64 keys, u32 keys use the front half
   size_t out_cap = 0;
-  uint32_t *h_counters = nullptr;  // [4] + bound (u64) behind it
+  uint32_t *h_counters = nullptr;  // [4] counters + bound (2 x u64) behind them
   // gather
   uint32_t *d_ids = nullptr, *h_ids = nullptr;
   float *d_dists = nullptr, *h_dists = nullptr;
@@ -131,11 +137,23 @@ class FlatIndex {
   void flush_if_needed();                                       // takes the locks itself
   void upload_query(QueryCtx *c, const void *blob, bool normalize);
   void scan_all(QueryCtx *c, uint32_t n);                        // keys for rows [0,n)
-  // exact selection of the k smallest composites above `lower`; returns hits sorted by composite
-  bool select(QueryCtx *c, uint32_t n, uint32_t k, uint64_t lower, bool has_lower, std::vector<Hit> &out,
-              uint64_t *bound_out);
+  // exact selection of the k smallest (key,row) composites of the scan's keys above `lower`
+  void select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper);
   void gather(QueryCtx *c, const size_t *labels, size_t m, double *out);
   size_t label_of_row(uint32_t row) const { return row_label_[row]; }
+  // labels are identity_base + row for every row (no hash map needed, device can translate)
+  bool identity_labels(uint64_t *base) const {
+    if (base) *base = identity_base_;
+    return identity_;
+  }
+  // first committed row of a label, 0xFFFFFFFF when absent
+  uint32_t first_row_of(size_t label) const {
+    std::vector<uint32_t> r;
+    rows_of(label, r);
+    for (uint32_t x : r)
+      if (x < n_rows_) return x;
+    return 0xFFFFFFFFu;
+  }
   uint32_t committed_rows() const { return n_rows_; }
   const uint64_t *device_labels() const { return d_labels_; }
   const void *device_rows() const { return d_rows_; }
@@ -194,7 +212,17 @@ struct VecSimQueryReply_Iterator {
   size_t pos;
 };
 
+// the opaque ABI handle
+struct VecSimIndex {
+  rsgpu::FlatIndex *flat;
+};
+
 namespace rsgpu {
+std::string &last_error();  // per-thread message behind RSGPU_LastError
+// Exact k smallest composites of keys[0..n) (u32 or u64 keys) above `lower`, sorted ascending.
+// Drives select_kernels.hip on c->stream and synchronises it.
+void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, uint32_t k, const Bound &lower,
+                  std::vector<Hit> &out, Bound *upper);
 VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code);
 bool timed_out(void *timeout_ctx);
 
@@ -207,8 +235,8 @@ struct BatchIterator {
   std::vector<uint8_t> query;  // copied at New (reference c_wrappers/vecsim/src/batch.rs:52-55)
   uint32_t n = 0;              // rows at creation
   uint32_t returned = 0;
-  uint64_t lower = 0;
-  bool has_lower = false, scanned = false;
+  Bound lower;
+  bool scanned = false;
   std::vector<uint64_t> seen_labels;  // multi-value: labels already yielded
 };
 

@@ -52,23 +52,24 @@ void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, ui
                            hipStream_t s);
 
 // ---- top-K selection over keys[0..n) -------------------------------------------------------------
-// Total order: composite (key << 32 | row).  Radix select, 8 bits per pass, most significant first;
-// passes 0-3 refine the key, 4-7 the row (only needed when equal keys straddle rank K).
-// `lower` (exclusive) restricts the candidates to composites > lower (batch iterator); has_lower=0
-// means none.  hist is [8][256] u32, zeroed by the caller before pass 0.
+// Total order: composite (key, row), key u32 (key_bytes=4) or u64 (key_bytes=8).  Radix select, 8
+// bits per level, most significant first; the first key_bytes levels refine the key, the last four
+// the row (only needed when equal keys straddle rank K).  (lkey,lrow) is an exclusive lower bound
+// (batch iterator); has_lower=0 means none.  hist is [12][256] u32, zeroed by the caller.
 struct SelectBufs {
-  uint32_t *hist;     // [8*256]
-  uint32_t *counters; // [0] out_count  [1] status (0 ok, 1 need more passes)  [2] selected-below count
-  uint32_t *out_rows; // [cap]
-  uint32_t *out_keys; // [cap]
-  uint64_t *bound;    // [1] composite upper bound (inclusive) of what was selected
+  uint32_t *hist;      // [12*256]
+  uint32_t *counters;  // [0] out_count  [1] status (0 ok, 1 need more levels)
+  uint32_t *out_rows;  // [cap]
+  void *out_keys;      // [cap] of the key type
+  uint64_t *bound;     // [2] inclusive upper bound of the selected set: key, row
 };
-void launch_select_pass(const uint32_t *keys, uint32_t n, int pass, uint32_t k, uint64_t lower, int has_lower,
-                        const SelectBufs &b, hipStream_t s);
-// After `passes_done` passes: if the selection is exact, writes the k winners (unordered) to
-// out_rows/out_keys and counters[0]=k, counters[1]=0; otherwise counters[1]=1 and nothing else.
-void launch_select_collect(const uint32_t *keys, uint32_t n, int passes_done, uint32_t k, uint64_t lower,
-                           int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s);
+constexpr int kSelectLevelsMax = 12;
+void launch_select_pass(const void *keys, int key_bytes, uint32_t n, int pass, uint32_t k, uint64_t lkey,
+                        uint32_t lrow, int has_lower, const SelectBufs &b, hipStream_t s);
+// After `passes_done` levels: if the selection is exact, writes the k winners (unordered) to
+// out_rows/out_keys, counters[0]=k, counters[1]=0 and the bound; otherwise counters[1]=1 only.
+void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int passes_done, uint32_t k, uint64_t lkey,
+                           uint32_t lrow, int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s);
 
 // ---- range query: all rows with key <= max_key ----------------------------------------------------
 // counters[0] receives the count (collect=0) or is used as the append cursor (collect=1).

@@ -1,0 +1,422 @@
+// search_abi.cpp -- host drivers + C ABI (include/rsgpu_search.h) of the integer / scoring half:
+// device-resident posting lists in the reference's block format, GPU decode + N-way intersection,
+// the built-in scorers over the hits, score top-N and the hybrid ad-hoc KNN step.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "flat_index.hpp"
+#include "rsgpu_search.h"
+#include "search_kernels.hpp"
+
+using namespace rsgpu;
+
+namespace {
+
+thread_local double prof_ms[5] = {0, 0, 0, 0, 0};  // decode, intersect, score, topn, knn
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { reset(); }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    reset();
+    if (!count) count = 1;
+    HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void ensure(size_t count) {
+    if (count > n) alloc(count + count / 4 + 64);
+  }
+  void upload(const T *src, size_t count) {
+    alloc(count);
+    if (count) HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+  }
+};
+
+// grow-only per-thread scratch for the intersection
+struct Scratch {
+  int device = -1;
+  DevBuf<uint8_t> flags;
+  DevBuf<uint32_t> pos, block_counts, total, rows, keys32;
+  DevBuf<float> dists;
+};
+thread_local Scratch tls_scratch;
+Scratch &scratch(int device) {
+  Scratch &s = tls_scratch;
+  if (s.device != device) {
+    s.flags.reset(); s.pos.reset(); s.block_counts.reset(); s.total.reset(); s.rows.reset(); s.keys32.reset();
+    s.dists.reset();
+    s.device = device;
+  }
+  return s;
+}
+
+struct StageTimer {
+  QueryCtx *c;
+  int slot;
+  StageTimer(QueryCtx *ctx, int s) : c(ctx), slot(s) { HIP_CHECK(hipEventRecord(c->ev0, c->stream)); }
+  void stop() {
+    HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    HIP_CHECK(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    prof_ms[slot] = ms;
+  }
+};
+
+inline double key2score(uint64_t inv_key) {  // inverse of ~d2key(score)
+  uint64_t k = ~inv_key;
+  uint64_t u = (k & 0x8000000000000000ull) ? (k ^ 0x8000000000000000ull) : ~k;
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+
+}  // namespace
+
+struct RSGPU_Postings {
+  int device = 0, codec = 0;
+  CodecDesc cd{};
+  uint32_t n_blocks = 0, n_entries = 0;
+  size_t n_bytes = 0;
+  DevBuf<uint8_t> bytes;
+  DevBuf<uint64_t> byte_off;
+  DevBuf<uint32_t> first, nent, entry_off;
+  DevBuf<uint32_t> ids, freqs, masks;  // decode targets
+};
+
+struct RSGPU_Hits {
+  int device = 0, n_lists = 0;
+  uint32_t len = 0, cap = 0;
+  int order[kMaxLists];  // internal list slot -> index in the caller's list array
+  DevBuf<uint32_t> ids, freqs;
+  DevBuf<double> scores;
+  DevBuf<uint64_t> keys;
+  bool scored = false;
+  std::vector<uint32_t> h_ids;  // lazily mirrored
+  const std::vector<uint32_t> &host_ids() {
+    if (h_ids.size() != len) {
+      h_ids.resize(len);
+      if (len) HIP_CHECK(hipMemcpy(h_ids.data(), ids.p, len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return h_ids;
+  }
+};
+
+struct RSGPU_DocTable {
+  int device = 0;
+  uint32_t n = 0;
+  DevBuf<uint32_t> doc_len, max_freq;
+  DevBuf<float> doc_score;
+};
+
+#define S_TRY try {
+#define S_CATCH(failval)                         \
+  }                                              \
+  catch (const std::exception &e) {              \
+    last_error() = e.what();                 \
+    logf(nullptr, "warning", "%s", e.what());    \
+    return failval;                              \
+  }
+
+static void decode_on(RSGPU_Postings *p, QueryCtx *c) {
+  launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
+                       p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
+  HIP_CHECK(hipGetLastError());
+}
+
+extern "C" {
+
+RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t *first_doc_id,
+                                      const uint64_t *last_doc_id, const uint32_t *num_entries,
+                                      const uint64_t *byte_offset, const uint8_t *bytes) {
+  S_TRY
+  CodecDesc cd = codec_desc(codec);
+  if (cd.kind < 0) throw std::runtime_error("unknown posting codec");
+  std::string why;
+  if (!device_available(&why)) throw std::runtime_error(why);
+  auto *p = new RSGPU_Postings();
+  std::unique_ptr<RSGPU_Postings> guard(p);
+  HIP_CHECK(hipGetDevice(&p->device));
+  p->codec = codec;
+  p->cd = cd;
+  p->n_blocks = (uint32_t)n_blocks;
+  std::vector<uint32_t> first(n_blocks), eoff(n_blocks + 1, 0);
+  for (size_t b = 0; b < n_blocks; b++) {
+    if (last_doc_id[b] > 0xFFFFFFFFull) throw std::runtime_error("doc ids >= 2^32 are not supported on the device path");
+    first[b] = (uint32_t)first_doc_id[b];
+    eoff[b + 1] = eoff[b] + num_entries[b];
+  }
+  p->n_entries = eoff[n_blocks];
+  p->n_bytes = n_blocks ? (size_t)byte_offset[n_blocks] : 0;
+  p->bytes.alloc(p->n_bytes + 16);  // slack: a truncated record never reads past the allocation
+  if (p->n_bytes) HIP_CHECK(hipMemcpy(p->bytes.p, bytes, p->n_bytes, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemset(p->bytes.p + p->n_bytes, 0, 16));
+  p->byte_off.upload(byte_offset, n_blocks + 1);
+  p->first.upload(first.data(), n_blocks);
+  p->nent.upload(num_entries, n_blocks);
+  p->entry_off.upload(eoff.data(), n_blocks + 1);
+  p->ids.alloc(p->n_entries);
+  p->freqs.alloc(p->n_entries);
+  p->masks.alloc(cd.mask >= 0 ? p->n_entries : 1);
+  return guard.release();
+  S_CATCH(nullptr)
+}
+void RSGPU_Postings_Free(RSGPU_Postings *p) { delete p; }
+size_t RSGPU_Postings_NumEntries(const RSGPU_Postings *p) { return p ? p->n_entries : 0; }
+size_t RSGPU_Postings_NumBytes(const RSGPU_Postings *p) { return p ? p->n_bytes : 0; }
+
+long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *freqs_out, uint32_t *masks_out) {
+  if (!p) return -1;
+  S_TRY
+  HIP_CHECK(hipSetDevice(p->device));
+  CtxLease c(p->device);
+  StageTimer t(c.c, 0);
+  decode_on(p, c.c);
+  t.stop();
+  const uint32_t n = p->n_entries;
+  if (doc_ids_out && n) {
+    std::vector<uint32_t> tmp(n);
+    HIP_CHECK(hipMemcpy(tmp.data(), p->ids.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; i++) doc_ids_out[i] = tmp[i];
+  }
+  if (freqs_out && n) {
+    if (p->cd.freq >= 0) HIP_CHECK(hipMemcpy(freqs_out, p->freqs.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else memset(freqs_out, 0, n * sizeof(uint32_t));
+  }
+  if (masks_out && n) {
+    if (p->cd.mask >= 0) HIP_CHECK(hipMemcpy(masks_out, p->masks.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else memset(masks_out, 0, n * sizeof(uint32_t));
+  }
+  return (long)n;
+  S_CATCH(-1)
+}
+
+RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
+  if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
+    last_error() = "RSGPU_Intersect: 1..8 lists";
+    return nullptr;
+  }
+  S_TRY
+  const int device = lists[0]->device;
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  auto *h = new RSGPU_Hits();
+  std::unique_ptr<RSGPU_Hits> guard(h);
+  h->device = device;
+  h->n_lists = (int)n_lists;
+  // children ordered by estimated size, ascending and stable (reference intersection.rs:60-119);
+  // the first one drives
+  std::iota(h->order, h->order + n_lists, 0);
+  std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
+
+  StageTimer td(c.c, 0);
+  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c.c);
+  td.stop();
+
+  ListView v;
+  memset(&v, 0, sizeof v);
+  v.n = (int)n_lists;
+  for (size_t s = 0; s < n_lists; s++) {
+    RSGPU_Postings *p = lists[h->order[s]];
+    v.ids[s] = p->ids.p;
+    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
+    v.len[s] = p->n_entries;
+  }
+  const uint32_t n0 = v.len[0];
+  h->cap = std::max<uint32_t>(n0, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc((size_t)h->cap * n_lists);
+  if (n0 == 0) {
+    h->len = 0;
+    return guard.release();
+  }
+  Scratch &sc = scratch(device);
+  const uint32_t nb = (n0 + 255) / 256;
+  sc.flags.ensure(n0);
+  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
+  sc.block_counts.ensure(nb);
+  sc.total.ensure(1);
+  StageTimer ti(c.c, 1);
+  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
+  launch_scan_counts(sc.block_counts.p, nb, sc.total.p, c->stream);
+  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream);
+  HIP_CHECK(hipGetLastError());
+  ti.stop();
+  uint32_t total = 0;
+  HIP_CHECK(hipMemcpy(&total, sc.total.p, sizeof total, hipMemcpyDeviceToHost));
+  h->len = total;
+  return guard.release();
+  S_CATCH(nullptr)
+}
+void RSGPU_Hits_Free(RSGPU_Hits *h) { delete h; }
+size_t RSGPU_Hits_Len(const RSGPU_Hits *h) { return h ? h->len : 0; }
+
+int RSGPU_Hits_Read(const RSGPU_Hits *hc, uint64_t *doc_ids, uint32_t *freqs) {
+  if (!hc) return -1;
+  RSGPU_Hits *h = const_cast<RSGPU_Hits *>(hc);
+  S_TRY
+  HIP_CHECK(hipSetDevice(h->device));
+  if (doc_ids) {
+    const std::vector<uint32_t> &ids = h->host_ids();
+    for (uint32_t i = 0; i < h->len; i++) doc_ids[i] = ids[i];
+  }
+  if (freqs && h->len)
+    for (int s = 0; s < h->n_lists; s++)  // back to the caller's list order
+      HIP_CHECK(hipMemcpy(freqs + (size_t)h->order[s] * h->len, h->freqs.p + (size_t)s * h->cap,
+                          h->len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return 0;
+  S_CATCH(-1)
+}
+
+RSGPU_DocTable *RSGPU_DocTable_Upload(size_t n, const uint32_t *doc_len, const float *doc_score,
+                                      const uint32_t *max_term_freq) {
+  S_TRY
+  std::string why;
+  if (!device_available(&why)) throw std::runtime_error(why);
+  auto *t = new RSGPU_DocTable();
+  std::unique_ptr<RSGPU_DocTable> guard(t);
+  HIP_CHECK(hipGetDevice(&t->device));
+  t->n = (uint32_t)n;
+  t->doc_len.upload(doc_len, n);
+  t->doc_score.upload(doc_score, n);
+  if (max_term_freq) t->max_freq.upload(max_term_freq, n);
+  return guard.release();
+  S_CATCH(nullptr)
+}
+void RSGPU_DocTable_Free(RSGPU_DocTable *t) { delete t; }
+
+int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreArgs *a, double *scores_out) {
+  if (!h || !t || !a) return -1;
+  S_TRY
+  HIP_CHECK(hipSetDevice(h->device));
+  CtxLease c(h->device);
+  ScoreParams P;
+  memset(&P, 0, sizeof P);
+  P.scorer = a->scorer;
+  P.n_lists = h->n_lists;
+  P.avg_doc_len = a->avg_doc_len;
+  P.root_weight = a->root_weight;
+  P.min_score = a->min_score;
+  P.inv_tanh = a->tanh_factor ? 1 / (double)a->tanh_factor : 0.0;
+  // IndexResult_MinOffsetDelta over children without offsets returns num-1 (reference
+  // src/index_result/index_result.c:102), 1 for a single child
+  P.slop = h->n_lists > 1 ? h->n_lists - 1 : 1;
+  for (int s = 0; s < h->n_lists; s++) {
+    int o = h->order[s];
+    P.idf[s] = a->idf ? a->idf[o] : 0.0;
+    P.bm25_idf[s] = a->bm25_idf ? a->bm25_idf[o] : 0.0;
+    P.weight[s] = a->weight ? a->weight[o] : 1.0;
+  }
+  h->scores.ensure(h->cap);
+  h->keys.ensure(h->cap);
+  StageTimer ts(c.c, 2);
+  launch_score(P, h->ids.p, h->freqs.p, h->len, h->cap, t->doc_len.p, t->doc_score.p,
+               t->max_freq.p, t->n, h->scores.p, h->keys.p, c->stream);
+  HIP_CHECK(hipGetLastError());
+  ts.stop();
+  h->scored = true;
+  if (scores_out && h->len) HIP_CHECK(hipMemcpy(scores_out, h->scores.p, h->len * sizeof(double), hipMemcpyDeviceToHost));
+  return 0;
+  S_CATCH(-1)
+}
+
+long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *scores_out) {
+  if (!h || !h->scored) {
+    last_error() = "RSGPU_Hits_TopN: score the hits first";
+    return -1;
+  }
+  S_TRY
+  HIP_CHECK(hipSetDevice(h->device));
+  CtxLease c(h->device);
+  uint32_t k = (uint32_t)std::min<size_t>(n, h->len);
+  std::vector<Hit> hits;
+  StageTimer tt(c.c, 3);
+  radix_select(c.c, h->keys.p, 8, h->len, k, Bound(), hits, nullptr);
+  tt.stop();
+  const std::vector<uint32_t> &ids = h->host_ids();
+  for (size_t i = 0; i < hits.size(); i++) {
+    if (doc_ids_out) doc_ids_out[i] = ids[hits[i].row];
+    if (scores_out) scores_out[i] = key2score(hits[i].key);
+  }
+  return (long)hits.size();
+  S_CATCH(-1)
+}
+
+long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
+                          double *dist_out) {
+  if (!h || !index || !query) return -1;
+  FlatIndex *f = index->flat;
+  S_TRY
+  if (f->device != h->device) throw std::runtime_error("hits and index live on different devices");
+  f->flush_if_needed();
+  std::shared_lock<std::shared_mutex> g(f->mu);
+  HIP_CHECK(hipSetDevice(h->device));
+  if (!h->len || !k) return 0;
+  CtxLease c(h->device);
+  Scratch &sc = scratch(h->device);
+  sc.rows.ensure(h->len);
+  sc.dists.ensure(h->len);
+  sc.keys32.ensure(h->len);
+  f->upload_query(c.c, query, true);
+  StageTimer tk(c.c, 4);
+  uint64_t base = 0;
+  if (f->identity_labels(&base)) {
+    launch_labels_to_rows(h->ids.p, h->len, base, f->committed_rows(), sc.rows.p, c->stream);
+  } else {  // general label map lives on the host
+    const std::vector<uint32_t> &ids = h->host_ids();
+    std::vector<uint32_t> rows(h->len);
+    for (uint32_t i = 0; i < h->len; i++) rows[i] = f->first_row_of(ids[i]);
+    HIP_CHECK(hipMemcpyAsync(sc.rows.p, rows.data(), h->len * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, h->len, c->d_query,
+                sc.dists.p, c->stream);
+  launch_dist_to_keys(sc.dists.p, h->len, sc.keys32.p, c->stream);
+  HIP_CHECK(hipGetLastError());
+  std::vector<Hit> hits;
+  radix_select(c.c, sc.keys32.p, 4, h->len, (uint32_t)std::min<size_t>(k, h->len), Bound(), hits, nullptr);
+  tk.stop();
+  const std::vector<uint32_t> &ids = h->host_ids();
+  long out = 0;
+  for (const Hit &hit : hits) {
+    if ((uint32_t)hit.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
+    if (doc_ids_out) doc_ids_out[out] = ids[hit.row];
+    if (dist_out) dist_out[out] = (double)key_to_dist((uint32_t)hit.key);
+    out++;
+  }
+  return out;
+  S_CATCH(-1)
+}
+
+// reference src/redisearch_rs/idf/src/lib.rs:67-108
+double RSGPU_CalculateIDF(size_t total_docs, size_t term_docs) {
+  if (!term_docs) term_docs = 1;
+  double value = 1.0 + (double)(total_docs + 1) / (double)term_docs;
+  return (double)std::ilogb(value);
+}
+double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs) {
+  if (total_docs < term_docs) total_docs = term_docs;
+  double total = (double)total_docs, term = (double)term_docs;
+  return std::log(1.0 + (total - term + 0.5) / (term + 0.5));
+}
+
+void RSGPU_SearchProfile(double *decode_ms, double *intersect_ms, double *score_ms, double *topn_ms, double *knn_ms) {
+  if (decode_ms) *decode_ms = prof_ms[0];
+  if (intersect_ms) *intersect_ms = prof_ms[1];
+  if (score_ms) *score_ms = prof_ms[2];
+  if (topn_ms) *topn_ms = prof_ms[3];
+  if (knn_ms) *knn_ms = prof_ms[4];
+}
+
+}  // extern "C"

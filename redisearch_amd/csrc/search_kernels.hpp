@@ -1,0 +1,56 @@
+// search_kernels.hpp -- launch interface of postings_kernels.hip (posting decode, intersection,
+// scorers).  Device pointers unless noted.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace rsgpu {
+
+// record layout of a codec: qint arity and slot of each field (-1 = absent); kind 0 qint, 1 varint
+// delta, 2 raw u32 delta from the block's first doc id
+struct CodecDesc {
+  int kind, n, freq, mask, osz;
+};
+CodecDesc codec_desc(int codec);
+
+// One thread per IndexBlock, sequential inside the block (records are variable-length and
+// delta-coded), blocks in parallel.  ids/freqs/masks receive entry_off[b] + e.
+void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
+                          const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
+                          uint32_t *freqs, uint32_t *masks, hipStream_t s);
+
+constexpr int kMaxLists = 8;
+struct ListView {
+  const uint32_t *ids[kMaxLists];
+  const uint32_t *freqs[kMaxLists];
+  uint32_t len[kMaxLists];
+  int n;  // lists; list 0 drives (the shortest)
+};
+// probe: for every element of list 0, binary-search the other lists; flags[i]=1 on consensus,
+// pos[(l-1)*len0 + i] = match position in list l; block_counts[b] = hits in block b
+void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s);
+// exclusive scan of block_counts[0..nb) in place, total -> total_out[0]
+void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s);
+// ordered compaction: out_ids[h], out_freqs[l*cap + h]
+void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
+                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s);
+
+struct ScoreParams {
+  int scorer, n_lists;
+  double avg_doc_len, root_weight, min_score, inv_tanh;
+  double idf[kMaxLists], bm25_idf[kMaxLists], weight[kMaxLists];
+  int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_lists-1, 1)
+};
+// scores[h] (fp64) and keys[h] = descending-score orderable u64 (for the top-N select)
+void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *freqs, uint32_t len, uint32_t cap,
+                  const uint32_t *doc_len, const float *doc_score, const uint32_t *max_freq, uint32_t table_n,
+                  double *scores, uint64_t *keys, hipStream_t s);
+
+// rows[i] = ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
+void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint32_t n_rows, uint32_t *rows, hipStream_t s);
+// keys[i] = orderable(dists[i]) (NaN last)
+void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s);
+
+}  // namespace rsgpu

@@ -1,27 +1,25 @@
-// select_kernels.hip -- GPU-side exact top-K selection and range compaction over the key array the
-// scan wrote (gfx950, hand-written HIP).
+// select_kernels.hip -- GPU-side exact top-K selection and range compaction over a key array
+// (gfx950, hand-written HIP).
 //
-// Replaces the K-bounded heap inside VecSimIndex_TopKQuery / VecSimBatchIterator_Next and the
-// iterator-side heap bookkeeping (reference src/iterators/hybrid_reader.c:88-138,372-443).
+// Replaces the K-bounded heap inside VecSimIndex_TopKQuery / VecSimBatchIterator_Next, the
+// iterator-side heap bookkeeping (reference src/iterators/hybrid_reader.c:88-138,372-443) and, with
+// 64-bit keys, the result sorter's top-N heap over scores (reference src/result_processor.c:752-850).
 //
-// Order.  Every row has the unique 64-bit composite  (key << 32) | row, key being the orderable
-// image of its fp32 distance.  "Top K" = the K smallest composites, i.e. ascending distance with
-// ties resolved by storage row -- the order in which the reference's scan would have met them
-// (oracle/flat_oracle.c header, [upstream-memory D3]).  Because the order is total the selection
-// is exact and deterministic for any K, any number of equal distances, and resumable: a batch
-// iterator restarts above the previous batch's largest composite (`lower`).
+// Order.  Element i has the unique composite (key_i, i): key is the orderable image of an fp32
+// distance (u32) or of an fp64 score (u64), i is the storage row / hit index.  "Top K" = the K
+// smallest composites, i.e. ascending key with ties resolved by position -- the order in which the
+// reference's sequential scan meets the elements (oracle/flat_oracle.c header, [upstream-memory D3];
+// reference src/result_processor.c:849 for scores: equal score => lower doc id first).  The order is
+// total, so the selection is exact and deterministic for any K and any number of equal keys, and it
+// is resumable: a batch iterator restarts above the previous batch's largest composite (`lower`).
 //
-// Algorithm.  MSB-first radix select, 8 bits per level.  Level p histograms digit p of the
-// candidates that match the digits chosen at levels 0..p-1; the histograms of all levels stay in
-// global memory, and every workgroup of the next kernel re-derives the chosen prefix from them
-// (256 counters per level -- a few hundred cycles) instead of waiting on an inter-workgroup
-// hand-off: kernel boundaries are the only synchronisation, so nothing depends on dispatch order or
-// XCD placement.  Selection is exact as soon as the chosen bucket holds exactly the number of
-// elements still wanted; for continuous data that happens after the 2nd-4th level, and levels 4-7
-// (row bits) run only when equal keys straddle rank K.
-//
-// Cost: each level is one coalesced pass over 4 B/row (40 MB at 10 M rows, ~8 us at HBM speed) --
-// about 1 % of the 30.7 GB scan it follows.
+// Algorithm.  MSB-first radix select, 8 bits per level, sizeof(key)+4 levels at most.  Level p
+// histograms digit p of the candidates that match the digits chosen at levels 0..p-1; all levels'
+// histograms stay in global memory and every workgroup of the next kernel re-derives the chosen
+// prefix from them (256 counters per level -- a few hundred cycles) instead of waiting on an
+// inter-workgroup hand-off: kernel boundaries are the only synchronisation, nothing depends on
+// dispatch order or XCD placement.  Selection is exact as soon as the chosen bucket holds exactly the
+// number of elements still wanted; the position levels run only when equal keys straddle rank K.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -30,22 +28,25 @@ namespace rsgpu {
 namespace {
 
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
 
 struct Decision {
-  unsigned long long prefix;  // chosen digits, left-aligned
-  uint32_t k_rem;             // still wanted inside the chosen bucket
-  int levels;                 // digits chosen (prefix valid in the top 8*levels bits)
-  int exact;                  // chosen bucket count == k_rem (or fewer candidates than k)
-  int take_all;               // fewer candidates than k: everything above `lower` is selected
+  u64 pkey;        // chosen key digits, left-aligned inside the key width
+  uint32_t prow;   // chosen row digits, left-aligned
+  uint32_t k_rem;  // still wanted inside the chosen bucket
+  int levels;      // digits chosen so far
+  int exact;       // chosen bucket count == k_rem (or fewer candidates than k)
+  int take_all;    // fewer candidates than k: everything above `lower` is selected
 };
 
 // Re-derive the decision from the histograms of levels [0, passes). Executed by wavefront 0 of every
-// workgroup, result published through LDS.
+// workgroup, published through LDS.  KB = key bytes.
+template <int KB>
 __device__ void decide(const uint32_t *__restrict__ hist, int passes, uint32_t k, Decision *out) {
   if (threadIdx.x < 64) {
     const uint32_t lane = threadIdx.x;
-    unsigned long long prefix = 0;
-    uint32_t k_rem = k;
+    u64 pkey = 0;
+    uint32_t prow = 0, k_rem = k;
     int exact = 0, levels = 0, take_all = 0;
     for (int p = 0; p < passes && !exact; ++p) {
       const uint32_t *h = hist + p * 256 + lane * 4;
@@ -59,8 +60,8 @@ __device__ void decide(const uint32_t *__restrict__ hist, int passes, uint32_t k
       }
       uint32_t exc = inc - s;
       bool mine = (exc < k_rem) && (k_rem <= inc);
-      unsigned long long ball = __ballot(mine);
-      if (ball == 0) {  // fewer candidates than k (host clamps k, so only on an empty remainder)
+      u64 ball = __ballot(mine);
+      if (ball == 0) {  // fewer candidates than k (the host clamps k; only an empty remainder gets here)
         exact = 1;
         take_all = 1;
         break;
@@ -85,12 +86,14 @@ __device__ void decide(const uint32_t *__restrict__ hist, int passes, uint32_t k
       below = __shfl(below, src, 64);
       cnt = __shfl(cnt, src, 64);
       k_rem -= below;
-      prefix |= (unsigned long long)D << (56 - 8 * p);
+      if (p < KB) pkey |= (u64)D << (8 * (KB - 1 - p));
+      else prow |= D << (8 * (3 - (p - KB)));
       levels = p + 1;
       if (cnt == k_rem) exact = 1;
     }
     if (lane == 0) {
-      out->prefix = prefix;
+      out->pkey = pkey;
+      out->prow = prow;
       out->k_rem = k_rem;
       out->levels = levels;
       out->exact = exact;
@@ -100,52 +103,85 @@ __device__ void decide(const uint32_t *__restrict__ hist, int passes, uint32_t k
   __syncthreads();
 }
 
-__device__ __forceinline__ unsigned long long comp_of(uint32_t key, uint32_t row) {
-  return ((unsigned long long)key << 32) | row;
+template <int KB>
+__device__ __forceinline__ uint32_t digit_of(int p, u64 key, uint32_t row) {
+  return p < KB ? (uint32_t)(key >> (8 * (KB - 1 - p))) & 0xffu : (row >> (8 * (3 - (p - KB)))) & 0xffu;
+}
+// do the top p digits of (key,row) equal those of (pkey,prow)?
+template <int KB>
+__device__ __forceinline__ bool prefix_match(int p, u64 key, uint32_t row, u64 pkey, uint32_t prow) {
+  if (p == 0) return true;
+  if (p <= KB) {
+    int sh = 8 * (KB - p);
+    return (key >> sh) == (pkey >> sh);
+  }
+  int sh = 8 * (4 - (p - KB));
+  return key == pkey && (sh >= 32 ? true : (row >> sh) == (prow >> sh));
+}
+__device__ __forceinline__ bool comp_gt(u64 key, uint32_t row, u64 lkey, uint32_t lrow) {
+  return key > lkey || (key == lkey && row > lrow);
+}
+__device__ __forceinline__ bool comp_le(u64 key, uint32_t row, u64 hkey, uint32_t hrow) {
+  return key < hkey || (key == hkey && row <= hrow);
+}
+
+// 4 consecutive keys starting at element 4*i (tail-safe); inactive slots read as all-ones
+template <typename KeyT>
+__device__ __forceinline__ void load4(const KeyT *__restrict__ keys, uint32_t n, uint32_t i, bool in_range, u64 out[4]) {
+  const uint32_t base = i * 4;
+#pragma unroll
+  for (int j = 0; j < 4; j++) out[j] = ~0ull;
+  if (!in_range) return;
+  if (base + 3 < n) {
+    if (sizeof(KeyT) == 4) {
+      u4 v = *(const u4 *)(keys + base);
+      out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+      const u4 *p = (const u4 *)(keys + base);
+      u4 a = p[0], b = p[1];
+      out[0] = (u64)a.x | ((u64)a.y << 32); out[1] = (u64)a.z | ((u64)a.w << 32);
+      out[2] = (u64)b.x | ((u64)b.y << 32); out[3] = (u64)b.z | ((u64)b.w << 32);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (base + j < n) out[j] = (u64)keys[base + j];
+  }
 }
 
 // ---- one histogram level ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void select_pass_kernel(const uint32_t *__restrict__ keys, uint32_t n, int pass,
-                                                          uint32_t k, unsigned long long lower, int has_lower,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void select_pass_kernel(const KeyT *__restrict__ keys, uint32_t n, int pass,
+                                                          uint32_t k, u64 lkey, uint32_t lrow, int has_lower,
                                                           uint32_t *__restrict__ hist) {
+  constexpr int KB = sizeof(KeyT);
   __shared__ Decision dec;
   __shared__ uint32_t lh[256];
   lh[threadIdx.x] = 0;
-  decide(hist, pass, k, &dec);  // ends with __syncthreads()
-  if (dec.exact) return;        // already resolved at an earlier level
-  const unsigned long long prefix = dec.prefix;
-  const int mshift = 64 - 8 * pass;  // bits below the matched prefix (64 at pass 0: no prefix)
-  const int dshift = 56 - 8 * pass;
+  decide<KB>(hist, pass, k, &dec);  // ends with __syncthreads()
+  if (dec.exact) return;            // already resolved at an earlier level
+  const u64 pkey = dec.pkey;
+  const uint32_t prow = dec.prow;
   const uint32_t lane = threadIdx.x & 63;
 
   const uint32_t n4 = (n + 3) / 4;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n4 + 255) / 256) * 256; i += gridDim.x * 256) {
-    u4 kv = (u4){0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    const uint32_t base = i * 4;
-    if (i < n4) {
-      if (base + 3 < n) kv = *(const u4 *)(keys + base);
-      else {
-        kv.x = keys[base];
-        if (base + 1 < n) kv.y = keys[base + 1];
-        if (base + 2 < n) kv.z = keys[base + 2];
-      }
-    }
-    uint32_t kk[4] = {kv.x, kv.y, kv.z, kv.w};
+    u64 kk[4];
+    load4<KeyT>(keys, n, i, i < n4, kk);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint32_t row = base + j;
-      const unsigned long long c = comp_of(kk[j], row);
+      const uint32_t row = i * 4 + j;
       bool active = (i < n4) && (row < n);
-      if (has_lower) active = active && (c > lower);
-      if (pass > 0) active = active && ((c >> mshift) == (prefix >> mshift));
-      const uint32_t d = (uint32_t)(c >> dshift) & 0xffu;
+      if (has_lower) active = active && comp_gt(kk[j], row, lkey, lrow);
+      active = active && prefix_match<KB>(pass, kk[j], row, pkey, prow);
+      const uint32_t d = digit_of<KB>(pass, kk[j], row);
       // wave-aggregated LDS increment when the whole wavefront agrees on the digit (the common case
       // at the top levels: distances cluster in a handful of exponent buckets)
-      unsigned long long act = __ballot(active);
+      u64 act = __ballot(active);
       if (act) {
         int first = __ffsll((long long)act) - 1;
         uint32_t d0 = __shfl(d, first, 64);
-        unsigned long long same = __ballot(active && d == d0);
+        u64 same = __ballot(active && d == d0);
         if (same == act) {
           if (lane == (uint32_t)first) atomicAdd(&lh[d0], (uint32_t)__popcll(act));
         } else if (active) {
@@ -160,9 +196,10 @@ __global__ __launch_bounds__(256) void select_pass_kernel(const uint32_t *__rest
 }
 
 // append one element per active lane with a single atomic per wavefront
-__device__ __forceinline__ void wave_append(bool take, uint32_t row, uint32_t key, uint32_t *cursor,
-                                            uint32_t *out_rows, uint32_t *out_keys, uint32_t cap) {
-  unsigned long long m = __ballot(take);
+template <typename KeyT>
+__device__ __forceinline__ void wave_append(bool take, uint32_t row, KeyT key, uint32_t *cursor,
+                                            uint32_t *out_rows, KeyT *out_keys, uint32_t cap) {
+  u64 m = __ballot(take);
   if (!m) return;
   const uint32_t lane = threadIdx.x & 63;
   int leader = __ffsll((long long)m) - 1;
@@ -178,47 +215,50 @@ __device__ __forceinline__ void wave_append(bool take, uint32_t row, uint32_t ke
   }
 }
 
-__global__ __launch_bounds__(256) void select_collect_kernel(const uint32_t *__restrict__ keys, uint32_t n,
-                                                             int passes_done, uint32_t k,
-                                                             unsigned long long lower, int has_lower,
-                                                             const uint32_t *__restrict__ hist,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void select_collect_kernel(const KeyT *__restrict__ keys, uint32_t n,
+                                                             int passes_done, uint32_t k, u64 lkey, uint32_t lrow,
+                                                             int has_lower, const uint32_t *__restrict__ hist,
                                                              uint32_t *__restrict__ counters,
                                                              uint32_t *__restrict__ out_rows,
-                                                             uint32_t *__restrict__ out_keys,
-                                                             unsigned long long *__restrict__ bound, uint32_t cap) {
+                                                             KeyT *__restrict__ out_keys, u64 *__restrict__ bound,
+                                                             uint32_t cap) {
+  constexpr int KB = sizeof(KeyT);
   __shared__ Decision dec;
-  decide(hist, passes_done, k, &dec);
+  decide<KB>(hist, passes_done, k, &dec);
   if (!dec.exact) {
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[1] = 1;  // caller runs more levels
     return;
   }
-  const int shift = 64 - 8 * dec.levels;  // unrefined low bits
-  const unsigned long long hi =
-      dec.take_all ? ~0ull : (shift >= 64 ? ~0ull : (dec.prefix | ((shift > 0) ? ((1ull << shift) - 1ull) : 0ull)));
+  // inclusive upper bound of the selected set: chosen prefix, unrefined digits all ones
+  u64 hkey = ~0ull;
+  uint32_t hrow = 0xFFFFFFFFu;
+  if (!dec.take_all) {
+    const int L = dec.levels;
+    if (L <= KB) {
+      int sh = 8 * (KB - L);
+      hkey = dec.pkey | (sh > 0 ? ((1ull << sh) - 1ull) : 0ull);
+    } else {
+      int sh = 8 * (4 - (L - KB));
+      hkey = dec.pkey;
+      hrow = dec.prow | (sh > 0 ? ((1u << sh) - 1u) : 0u);
+    }
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     counters[1] = 0;
-    bound[0] = hi;
+    bound[0] = hkey;
+    bound[1] = hrow;
   }
   const uint32_t n4 = (n + 3) / 4;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n4 + 255) / 256) * 256; i += gridDim.x * 256) {
-    u4 kv = (u4){0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    const uint32_t base = i * 4;
-    if (i < n4) {
-      if (base + 3 < n) kv = *(const u4 *)(keys + base);
-      else {
-        kv.x = keys[base];
-        if (base + 1 < n) kv.y = keys[base + 1];
-        if (base + 2 < n) kv.z = keys[base + 2];
-      }
-    }
-    uint32_t kk[4] = {kv.x, kv.y, kv.z, kv.w};
+    u64 kk[4];
+    load4<KeyT>(keys, n, i, i < n4, kk);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const uint32_t row = base + j;
-      const unsigned long long c = comp_of(kk[j], row);
-      bool take = (i < n4) && (row < n) && (c <= hi);
-      if (has_lower) take = take && (c > lower);
-      wave_append(take, row, kk[j], &counters[0], out_rows, out_keys, cap);
+      const uint32_t row = i * 4 + j;
+      bool take = (i < n4) && (row < n) && comp_le(kk[j], row, hkey, hrow);
+      if (has_lower) take = take && comp_gt(kk[j], row, lkey, lrow);
+      wave_append<KeyT>(take, row, (KeyT)kk[j], &counters[0], out_rows, out_keys, cap);
     }
   }
 }
@@ -232,7 +272,7 @@ __global__ __launch_bounds__(256) void range_kernel(const uint32_t *__restrict__
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n + 255) / 256) * 256; i += gridDim.x * 256) {
     uint32_t key = i < n ? keys[i] : 0xFFFFFFFFu;
     bool take = i < n && key <= max_key;
-    if (collect) wave_append(take, i, key, &counters[0], out_rows, out_keys, cap);
+    if (collect) wave_append<uint32_t>(take, i, key, &counters[0], out_rows, out_keys, cap);
     else local += take ? 1u : 0u;
   }
   if (!collect) {
@@ -244,24 +284,33 @@ __global__ __launch_bounds__(256) void range_kernel(const uint32_t *__restrict__
 
 inline uint32_t pass_grid(uint32_t n) {
   uint32_t need = ((n + 3) / 4 + 255) / 256;
-  uint32_t cap = (uint32_t)scan_tuning().num_cus * 2;
+  uint32_t cap = (uint32_t)scan_tuning().num_cus * 4;
   uint32_t g = need < cap ? need : cap;
   return g ? g : 1;
 }
 
 }  // namespace
 
-void launch_select_pass(const uint32_t *keys, uint32_t n, int pass, uint32_t k, uint64_t lower, int has_lower,
-                        const SelectBufs &b, hipStream_t s) {
-  hipLaunchKernelGGL(select_pass_kernel, dim3(pass_grid(n)), dim3(256), 0, s, keys, n, pass, k,
-                     (unsigned long long)lower, has_lower, b.hist);
+void launch_select_pass(const void *keys, int key_bytes, uint32_t n, int pass, uint32_t k, uint64_t lkey,
+                        uint32_t lrow, int has_lower, const SelectBufs &b, hipStream_t s) {
+  if (key_bytes == 8)
+    hipLaunchKernelGGL(select_pass_kernel<u64>, dim3(pass_grid(n)), dim3(256), 0, s, (const u64 *)keys, n, pass, k,
+                       (u64)lkey, lrow, has_lower, b.hist);
+  else
+    hipLaunchKernelGGL(select_pass_kernel<uint32_t>, dim3(pass_grid(n)), dim3(256), 0, s, (const uint32_t *)keys, n,
+                       pass, k, (u64)lkey, lrow, has_lower, b.hist);
 }
 
-void launch_select_collect(const uint32_t *keys, uint32_t n, int passes_done, uint32_t k, uint64_t lower,
-                           int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(select_collect_kernel, dim3(pass_grid(n)), dim3(256), 0, s, keys, n, passes_done, k,
-                     (unsigned long long)lower, has_lower, b.hist, b.counters, b.out_rows, b.out_keys,
-                     (unsigned long long *)b.bound, cap);
+void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int passes_done, uint32_t k, uint64_t lkey,
+                           uint32_t lrow, int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s) {
+  if (key_bytes == 8)
+    hipLaunchKernelGGL(select_collect_kernel<u64>, dim3(pass_grid(n)), dim3(256), 0, s, (const u64 *)keys, n,
+                       passes_done, k, (u64)lkey, lrow, has_lower, b.hist, b.counters, b.out_rows, (u64 *)b.out_keys,
+                       (u64 *)b.bound, cap);
+  else
+    hipLaunchKernelGGL(select_collect_kernel<uint32_t>, dim3(pass_grid(n)), dim3(256), 0, s, (const uint32_t *)keys,
+                       n, passes_done, k, (u64)lkey, lrow, has_lower, b.hist, b.counters, b.out_rows,
+                       (uint32_t *)b.out_keys, (u64 *)b.bound, cap);
 }
 
 void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,

@@ -17,9 +17,6 @@ namespace rsgpu {
 void normalize_blob(void *blob, size_t dim, VecSimType type);
 }
 
-struct VecSimIndex {
-  FlatIndex *flat;
-};
 struct VecSimBatchIterator {
   BatchIterator it;
 };
@@ -32,10 +29,9 @@ struct VecSimDebugInfoIterator {
   size_t pos = 0;
 };
 
-static thread_local std::string tls_error;
 static void set_error(void *log_ctx, const char *where, const char *what) {
-  tls_error = std::string(where) + ": " + what;
-  logf(log_ctx, VecSimCommonStrings_LOG_WARNING_STRING, "%s", tls_error.c_str());
+  last_error() = std::string(where) + ": " + what;
+  logf(log_ctx, VecSimCommonStrings_LOG_WARNING_STRING, "%s", last_error().c_str());
 }
 #define ABI_TRY try {
 #define ABI_CATCH(lctx, where, failval)              \
@@ -311,19 +307,18 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
   size_t want = n_results;
   while (res.size() < want && b.returned < n) {
     uint32_t ask = (uint32_t)std::min<size_t>(n - b.returned, want - res.size());
-    uint64_t bound = 0;
-    f->select(b.ctx, n, ask, b.lower, b.has_lower, hits, &bound);
+    Bound bound;
+    f->select(b.ctx, n, ask, b.lower, hits, &bound);
     if (hits.empty()) { b.returned = n; break; }
     b.returned += (uint32_t)hits.size();
     b.lower = bound;
-    b.has_lower = true;
     for (const Hit &h : hits) {
       uint64_t lab = f->label_of_row(h.row);
       if (f->multi) {  // a label is yielded once, at its best vector
         if (std::find(b.seen_labels.begin(), b.seen_labels.end(), lab) != b.seen_labels.end()) continue;
         b.seen_labels.push_back(lab);
       }
-      res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist(h.key)});
+      res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist((uint32_t)h.key)});
     }
     if (!f->multi) break;
     if (timed_out(b.timeout_ctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
@@ -343,8 +338,7 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
 void VecSimBatchIterator_Reset(VecSimBatchIterator *iterator) {
   if (!iterator) return;
   iterator->it.returned = 0;
-  iterator->it.has_lower = false;
-  iterator->it.lower = 0;
+  iterator->it.lower = Bound();
   iterator->it.seen_labels.clear();
 }
 
@@ -450,7 +444,7 @@ void VecSimQueryReply_IteratorReset(VecSimQueryReply_Iterator *it) {
 void VecSimQueryReply_IteratorFree(VecSimQueryReply_Iterator *it) { host_free(it); }
 
 // ---- extensions (include/rsgpu_ext.h) ------------------------------------------------------------------
-const char *RSGPU_LastError(void) { return tls_error.c_str(); }
+const char *RSGPU_LastError(void) { return last_error().c_str(); }
 int RSGPU_DeviceCount(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -1,0 +1,216 @@
+"""ctypes binding of include/rsgpu_search.h: GPU posting-list decode, intersection, scorers, score
+top-N and the hybrid ad-hoc KNN step.  Thin binding only -- all work happens in the HIP library."""
+import ctypes as C
+
+import numpy as np
+
+from . import vecsim as V
+
+_sz, _vp, _dbl, _i = C.c_size_t, C.c_void_p, C.c_double, C.c_int
+
+(CODEC_FULL, CODEC_FREQS_FIELDS, CODEC_FREQS_ONLY, CODEC_FIELDS_ONLY, CODEC_FIELDS_OFFSETS, CODEC_OFFSETS_ONLY,
+ CODEC_FREQS_OFFSETS, CODEC_DOCIDS_ONLY, CODEC_RAW_DOCIDS) = range(9)
+SCORERS = {"BM25STD": 0, "BM25STD.TANH": 1, "BM25": 2, "TFIDF": 3, "TFIDF.DOCNORM": 4, "DOCSCORE": 5, "DISMAX": 6}
+
+
+class ScoreArgs(C.Structure):
+    _fields_ = [("scorer", _i), ("num_docs", _sz), ("avg_doc_len", _dbl), ("tanh_factor", C.c_uint64),
+                ("root_weight", _dbl), ("min_score", _dbl), ("idf", _vp), ("bm25_idf", _vp), ("weight", _vp)]
+
+
+ABI = {
+    "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "RSGPU_Postings_Free": (None, [_vp]),
+    "RSGPU_Postings_NumEntries": (_sz, [_vp]),
+    "RSGPU_Postings_NumBytes": (_sz, [_vp]),
+    "RSGPU_Postings_Decode": (C.c_long, [_vp, _vp, _vp, _vp]),
+    "RSGPU_Intersect": (_vp, [_vp, _sz]),
+    "RSGPU_Hits_Free": (None, [_vp]),
+    "RSGPU_Hits_Len": (_sz, [_vp]),
+    "RSGPU_Hits_Read": (_i, [_vp, _vp, _vp]),
+    "RSGPU_DocTable_Upload": (_vp, [_sz, _vp, _vp, _vp]),
+    "RSGPU_DocTable_Free": (None, [_vp]),
+    "RSGPU_Hits_Score": (_i, [_vp, _vp, C.POINTER(ScoreArgs), _vp]),
+    "RSGPU_Hits_TopN": (C.c_long, [_vp, _sz, _vp, _vp]),
+    "RSGPU_Hits_KnnRerank": (C.c_long, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_CalculateIDF": (_dbl, [_sz, _sz]),
+    "RSGPU_CalculateIDF_BM25": (_dbl, [_sz, _sz]),
+    "RSGPU_SearchProfile": (None, [C.POINTER(_dbl)] * 5),
+}
+V.EXTRA_ABI = ABI
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        lib = V.load()
+        for name, (res, args) in ABI.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+def _check(ptr, what):
+    if not ptr:
+        raise RuntimeError(what + " failed: " + V.last_error())
+    return ptr
+
+
+class Postings:
+    """A posting list resident in HBM in the reference's block format (uploaded as-is)."""
+
+    def __init__(self, codec, first, last, num_entries, offset, data):
+        self.lib = load()
+        first, last = np.ascontiguousarray(first, np.uint64), np.ascontiguousarray(last, np.uint64)
+        nent, off = np.ascontiguousarray(num_entries, np.uint32), np.ascontiguousarray(offset, np.uint64)
+        data = np.ascontiguousarray(data, np.uint8)
+        if data.size == 0:
+            data = np.zeros(1, np.uint8)
+        self.codec = codec
+        self.ptr = _check(self.lib.RSGPU_Postings_Upload(codec, len(first), _p(first), _p(last), _p(nent), _p(off), _p(data)),
+                          "RSGPU_Postings_Upload")
+
+    @classmethod
+    def from_flat(cls, fl):
+        """fl: dict(first,last,num_entries,offset,bytes,codec) as produced by the block writer."""
+        return cls(fl["codec"], fl["first"], fl["last"], fl["num_entries"], fl["offset"], fl["bytes"])
+
+    @property
+    def num_entries(self):
+        return self.lib.RSGPU_Postings_NumEntries(self.ptr)
+
+    @property
+    def num_bytes(self):
+        return self.lib.RSGPU_Postings_NumBytes(self.ptr)
+
+    def decode(self):
+        n = self.num_entries
+        ids, fr, mk = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        m = self.lib.RSGPU_Postings_Decode(self.ptr, _p(ids), _p(fr), _p(mk))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return ids[:m], fr[:m], mk[:m]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.RSGPU_Postings_Free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+class DocTable:
+    def __init__(self, doc_len, doc_score, max_freq=None):
+        self.lib = load()
+        dl, ds = np.ascontiguousarray(doc_len, np.uint32), np.ascontiguousarray(doc_score, np.float32)
+        mf = np.ascontiguousarray(max_freq, np.uint32) if max_freq is not None else None
+        self.ptr = _check(self.lib.RSGPU_DocTable_Upload(len(dl), _p(dl), _p(ds), _p(mf) if mf is not None else None),
+                          "RSGPU_DocTable_Upload")
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.RSGPU_DocTable_Free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+class Hits:
+    def __init__(self, lists):
+        self.lib = load()
+        self.n_lists = len(lists)
+        arr = (_vp * len(lists))(*[l.ptr for l in lists])
+        self.ptr = _check(self.lib.RSGPU_Intersect(C.cast(arr, _vp), len(lists)), "RSGPU_Intersect")
+
+    def __len__(self):
+        return self.lib.RSGPU_Hits_Len(self.ptr)
+
+    def read(self):
+        n = len(self)
+        ids = np.zeros(max(n, 1), np.uint64)
+        fr = np.zeros((self.n_lists, max(n, 1)), np.uint32)
+        if self.lib.RSGPU_Hits_Read(self.ptr, _p(ids), _p(fr)) != 0:
+            raise RuntimeError(V.last_error())
+        return ids[:n], fr[:, :n]
+
+    def score(self, table, scorer, idf, bm25_idf, weight, num_docs, avg_doc_len, root_weight=1.0, min_score=0.0,
+              tanh_factor=4, want_scores=True):
+        idf, bidf, w = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
+        a = ScoreArgs(SCORERS[scorer], num_docs, avg_doc_len, tanh_factor, root_weight, min_score, _p(idf).value,
+                      _p(bidf).value, _p(w).value)
+        out = np.zeros(max(len(self), 1), np.float64) if want_scores else None
+        if self.lib.RSGPU_Hits_Score(self.ptr, table.ptr, C.byref(a), _p(out) if want_scores else None) != 0:
+            raise RuntimeError(V.last_error())
+        return out[: len(self)] if want_scores else None
+
+    def topn(self, n):
+        ids, sc = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.float64)
+        m = self.lib.RSGPU_Hits_TopN(self.ptr, n, _p(ids), _p(sc))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return ids[:m], sc[:m]
+
+    def knn_rerank(self, index, q, k):
+        ids, d = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64)
+        m = self.lib.RSGPU_Hits_KnnRerank(self.ptr, index.ptr, V._p(index._q(q)), k, _p(ids), _p(d))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return ids[:m], d[:m]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.RSGPU_Hits_Free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+def intersect(lists):
+    return Hits(lists)
+
+
+def calculate_idf(total, term):
+    return load().RSGPU_CalculateIDF(total, term)
+
+
+def calculate_idf_bm25(total, term):
+    return load().RSGPU_CalculateIDF_BM25(total, term)
+
+
+def profile():
+    v = [_dbl(0) for _ in range(5)]
+    load().RSGPU_SearchProfile(*[C.byref(x) for x in v])
+    return dict(zip(("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms"), [x.value for x in v]))
+
+
+def smoke():
+    """Tiny GPU intersection + BM25STD against the CPU oracle (called from __graft_entry__.smoke)."""
+    import oracle as O
+    rng = np.random.default_rng(49)
+    lists_o, lists_g = [], []
+    for n in (700, 1500):
+        docs = np.unique(rng.integers(1, 4000, n)).astype(np.uint64)
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(docs, rng.integers(1, 9, docs.size).astype(np.uint32))
+        lists_o.append(ii)
+        lists_g.append(Postings.from_flat(ii.flatten()))
+    oi, of, _ = O.intersect(lists_o)
+    h = intersect(lists_g)
+    gi, gf = h.read()
+    assert gi.tolist() == oi.tolist() and gf.tolist() == of.tolist()
+    doc_len = rng.integers(10, 300, 4001).astype(np.uint32)
+    doc_score = np.ones(4001, np.float32)
+    idf = [calculate_idf(4000, l.unique_docs) for l in lists_o]
+    bidf = [calculate_idf_bm25(4000, l.unique_docs) for l in lists_o]
+    gs = h.score(DocTable(doc_len, doc_score), "BM25STD", idf, bidf, [1.0, 1.0], 4000, float(doc_len[1:].mean()))
+    os_ = O.score_flat("BM25STD", of, doc_len[oi.astype(np.int64)], np.ones(len(oi)), doc_score[oi.astype(np.int64)],
+                       idf, bidf, [1.0, 1.0], 1.0, 4000, float(doc_len[1:].mean()))
+    assert np.allclose(gs, os_, rtol=1e-12, atol=0), float(np.max(np.abs(gs - os_)))
+    print("search smoke ok: %d hits" % len(gi))

@@ -1,0 +1,118 @@
+"""BASELINE configs[4] on MI355X: 2-term intersection over Zipf postings (50M docs) -> candidates that have
+a vector (FLAT 5M x 768 fp32 L2) -> ad-hoc BF top-10 -> BM25STD; plus BM25STD over ALL intersection hits
+(the full-text scoring loop) and its top-10.  Per-stage GPU time (HIP events), algorithmic bytes, GB/s and
+the CPU oracle's time for the same stages.  Writes gpurun_out/hybrid_bench.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle as O  # noqa: E402  (CPU baseline leg + checker only)
+from redisearch_amd import search as S  # noqa: E402
+from redisearch_amd import vecsim as V  # noqa: E402
+
+N_DOCS = int(os.environ.get("N_DOCS", 50_000_000))
+N_VEC = int(os.environ.get("N_VEC", 5_000_000))
+DIM = 768
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+rng = np.random.default_rng(49)
+out = {"config": "2-term intersect (Zipf df = 0.2*N/r, r=2,4; %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD"
+       % (N_DOCS, N_VEC, DIM)}
+
+# ---- postings (FreqsOnly and Full variants) -----------------------------------------------------------
+dfs = [int(0.2 * N_DOCS / r) for r in (2, 4)]
+host_lists = {}
+for name, codec in (("freqs_only", O.C_FREQS_ONLY), ("full", O.C_FULL)):
+    ls = []
+    r2 = np.random.default_rng(49)
+    for df in dfs:
+        docs = np.flatnonzero(r2.random(N_DOCS + 1) < df / N_DOCS).astype(np.uint64)
+        docs = docs[docs > 0]
+        freqs = np.minimum(1 + r2.geometric(0.5, docs.size), 255).astype(np.uint32)
+        ii = O.InvertedIndex(codec)
+        if codec == O.C_FULL:
+            O.lib.oinv_add_many(ii.h, O._p(docs), O._p(freqs), docs.size)  # offsets length 0, mask 1
+        else:
+            ii.add_many(docs, freqs)
+        ls.append(ii)
+    host_lists[name] = ls
+doc_len = (50 + rng.poisson(150, N_DOCS + 1)).astype(np.uint32)
+doc_score = np.ones(N_DOCS + 1, np.float32)
+avg = float(doc_len[1:].mean())
+table = S.DocTable(doc_len, doc_score)
+
+# ---- vector index: docs 1..N_VEC have a vector ----------------------------------------------------------
+idx = V.VecSimIndex(V.VecSimType_FLOAT32, DIM, V.VecSimMetric_L2)
+idx.reserve(N_VEC)
+gen = torch.Generator(device=dev)
+gen.manual_seed(47)
+done = 0
+while done < N_VEC:
+    m = min(1_000_000, N_VEC - done)
+    t = torch.rand((m, DIM), device=dev, generator=gen).mul_(2).sub_(1)
+    torch.cuda.synchronize()
+    idx.add_device_rows(t.data_ptr(), m, done + 1)
+    done += m
+    del t
+q = np.random.default_rng(48).uniform(-1, 1, DIM).astype(np.float32)
+
+for name, ls in host_lists.items():
+    g = [S.Postings.from_flat(l.flatten()) for l in ls]
+    enc_bytes = sum(x.num_bytes for x in g)
+    n_ent = [x.num_entries for x in g]
+    idf = [S.calculate_idf(N_DOCS, l.unique_docs) for l in ls]
+    bidf = [S.calculate_idf_bm25(N_DOCS, l.unique_docs) for l in ls]
+    reps, prof = 5, []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        h = S.intersect(g)
+        p = S.profile()
+        h.score(table, "BM25STD", idf, bidf, [1.0, 1.0], N_DOCS, avg, want_scores=False)
+        p["score_ms"] = S.profile()["score_ms"]
+        top_i, top_s = h.topn(10)
+        p["topn_ms"] = S.profile()["topn_ms"]
+        knn_i, knn_d = h.knn_rerank(idx, q, 10)
+        p["knn_ms"] = S.profile()["knn_ms"]
+        p["wall_ms"] = (time.perf_counter() - t0) * 1e3
+        prof.append(p)
+        n_hits = len(h)
+        if _ < reps - 1:
+            h.free()
+    best = {k: min(x[k] for x in prof[1:]) for k in prof[0]}
+    n_cand = int(np.searchsorted(h.read()[0], N_VEC, side="right"))
+    res = {"encoded_bytes": enc_bytes, "entries": n_ent, "hits": n_hits, "candidates_with_vector": n_cand, **best,
+           "decode_gbs": enc_bytes / best["decode_ms"] / 1e6,
+           "intersect_gbs": (sum(n_ent) * 4) / best["intersect_ms"] / 1e6,
+           "score_gbs": n_hits * (2 * 4 + 4 + 4 + 4 + 8) / best["score_ms"] / 1e6,
+           "knn_gather_gbs": n_cand * DIM * 4 / best["knn_ms"] / 1e6,
+           "top10_by_bm25": top_i.tolist(), "knn_top10": knn_i.tolist()}
+    # ---- CPU oracle on the same inputs: checker + single-thread baseline ---------------------------------
+    t0 = time.perf_counter()
+    oi, of, _ = O.intersect(ls)
+    t_int = time.perf_counter() - t0
+    sel = oi.astype(np.int64)
+    t0 = time.perf_counter()
+    os_ = O.score_flat("BM25STD", of, doc_len[sel], np.ones(len(sel)), doc_score[sel], idf, bidf, [1.0, 1.0], 1.0, N_DOCS, avg)
+    t_sc = time.perf_counter() - t0
+    gi, gf = h.read()
+    assert gi.tolist() == oi.tolist() and gf.tolist() == of.tolist(), "intersection mismatch"
+    order = np.lexsort((oi, -os_))[:10]
+    assert top_i.tolist() == oi[order].tolist(), "BM25 top-10 mismatch"
+    assert np.allclose(top_s, os_[order], rtol=1e-12, atol=0)
+    res["cpu_oracle_intersect_ms"] = t_int * 1e3
+    res["cpu_oracle_score_ms"] = t_sc * 1e3
+    res["parity"] = "ids/freqs identical; BM25STD top-10 identical"
+    out[name] = res
+    print(name, json.dumps(res), flush=True)
+
+# hybrid result through the reference's per-label seam on a sample of the candidates, as the checker
+adhoc = idx.adhoc_ctx(q)
+assert np.allclose(adhoc.get_exact_distances(knn_i), knn_d, rtol=0, atol=0)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/hybrid_bench.json", "w"), indent=1)
+print("HYBRID_OK")

@@ -39,7 +39,18 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_binding_table_covers_headers():
-    assert declared_symbols() - {"RSGPU_Search"} <= set(V.ABI) | set(getattr(V, "EXTRA_ABI", {}))
+    from redisearch_amd import search as S
+    assert declared_symbols() <= set(V.ABI) | set(S.ABI)
+
+
+def test_idf_host_entry_points(lib):
+    # reference src/redisearch_rs/idf/tests/tests.rs:23-80 through the C ABI (pure host functions)
+    from redisearch_amd import search as S
+    assert S.calculate_idf(100, 10) == 3.0 and S.calculate_idf(100, 0) == S.calculate_idf(100, 1)
+    assert S.calculate_idf(0, 1) == 1.0 and S.calculate_idf(0, 0) == 1.0 and S.calculate_idf(1, 1) == 1.0
+    assert S.calculate_idf(1000, 1) == 9.0 and S.calculate_idf(1000, 500) == 1.0 and S.calculate_idf(1000, 1000) == 1.0
+    assert abs(S.calculate_idf_bm25(5, 10) - S.calculate_idf_bm25(10, 10)) < 1e-15
+    assert S.calculate_idf_bm25(1000, 1) > S.calculate_idf_bm25(1000, 500)
 
 
 def test_struct_layout_matches_c(tmp_path):

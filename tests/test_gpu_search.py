@@ -1,0 +1,179 @@
+"""GPU parity tests of the integer / scoring half: posting decode, N-way intersection, scorers, score
+top-N and the hybrid ad-hoc KNN step, through include/rsgpu_search.h, against the CPU oracle.
+Doc-id sets and frequencies must be IDENTICAL (integer work); scores fp64 within 1e-12 relative."""
+import numpy as np
+import pytest
+
+import oracle as O
+from redisearch_amd import search as S
+from redisearch_amd import vecsim as V
+
+pytestmark = pytest.mark.gpu
+
+
+def make_list(rng, codec, n_docs, max_doc, with_offsets=False):
+    docs = np.unique(rng.integers(1, max_doc, n_docs)).astype(np.uint64)
+    freqs = rng.integers(1, 400, docs.size).astype(np.uint32)
+    ii = O.InvertedIndex(codec)
+    if with_offsets or codec in (O.C_FULL, O.C_FIELDS_OFFSETS, O.C_OFFSETS_ONLY, O.C_FREQS_OFFSETS, O.C_FREQS_FIELDS,
+                                 O.C_FIELDS_ONLY):
+        for d, f in zip(docs.tolist(), freqs.tolist()):
+            offs = b"".join(O.varint_encode(int(x)) for x in rng.integers(1, 300, int(rng.integers(0, 5))))
+            ii.add(d, f, int(rng.integers(1, 2 ** 32 - 1)), offs)
+    else:
+        ii.add_many(docs, freqs)
+    return ii
+
+
+@pytest.mark.parametrize("codec", range(9))
+def test_decode_matches_oracle_all_codecs(codec):
+    rng = np.random.default_rng(100 + codec)
+    ii = make_list(rng, codec, 5000, 3_000_000)
+    g = S.Postings.from_flat(ii.flatten())
+    gi, gf, gm = g.decode()
+    oi, of, om = ii.decode_all()
+    assert g.num_entries == ii.unique_docs and g.num_bytes == len(ii.flatten()["bytes"])
+    assert gi.tolist() == oi.tolist() and gf.tolist() == of.tolist() and gm.tolist() == om.tolist()
+
+
+def test_decode_edge_cases():
+    # empty list, single record, delta > 2^16, block boundaries, multi-byte varints
+    e = O.InvertedIndex(O.C_FREQS_ONLY)
+    assert len(S.Postings.from_flat(e.flatten()).decode()[0]) == 0
+    for codec in (O.C_FREQS_ONLY, O.C_DOCIDS_ONLY, O.C_RAW_DOCIDS, O.C_FULL):
+        ii = O.InvertedIndex(codec)
+        docs = [1, 2, 300, 70_000, 70_001, 20_000_000, 20_000_255, 4_000_000_000]
+        for d in docs:
+            ii.add(d, d % 1000 + 1, 7, b"\x01\x02")
+        gi, gf, _ = S.Postings.from_flat(ii.flatten()).decode()
+        assert gi.tolist() == docs
+        if codec in (O.C_FREQS_ONLY, O.C_FULL):
+            assert gf.tolist() == [d % 1000 + 1 for d in docs]
+
+
+def test_intersection_cpp_kat():
+    # reference tests/cpptests/test_cpp_index.cpp:542-601
+    def populate(size, step):
+        ii = O.InvertedIndex(O.C_FULL)
+        for i in range(size):
+            ii.add((i + 1) * step, 1, 1, bytes(range(step, step + i % 4)))
+        return ii
+    w, w2 = populate(100000, 4), populate(100000, 2)
+    h = S.intersect([S.Postings.from_flat(w.flatten()), S.Postings.from_flat(w2.flatten())])
+    ids, fr = h.read()
+    assert len(h) == 50000 and ids.tolist() == [(c * 2 + 2) * 2 for c in range(50000)]
+    assert (fr.sum(0) == 2).all()
+
+
+@pytest.mark.parametrize("nl", [1, 2, 3, 5])
+@pytest.mark.parametrize("codec", [O.C_FREQS_ONLY, O.C_DOCIDS_ONLY, O.C_FULL, O.C_RAW_DOCIDS])
+def test_intersection_parity_random(nl, codec):
+    rng = np.random.default_rng(nl * 10 + codec)
+    lists = [make_list(rng, codec, int(rng.integers(200, 30000)), 60000) for _ in range(nl)]
+    oi, of, _ = O.intersect(lists)
+    h = S.intersect([S.Postings.from_flat(l.flatten()) for l in lists])
+    gi, gf = h.read()
+    assert gi.tolist() == oi.tolist()
+    assert gf.tolist() == of.tolist()
+
+
+def test_intersection_edge_cases():
+    mk = lambda docs: (lambda ii: (ii.add_many(np.array(docs, np.uint64), np.arange(1, len(docs) + 1, dtype=np.uint32)), ii)[1])(
+        O.InvertedIndex(O.C_FREQS_ONLY))
+    a, b, e = mk([1, 5, 9]), mk([2, 6, 10]), O.InvertedIndex(O.C_FREQS_ONLY)
+    P = lambda ii: S.Postings.from_flat(ii.flatten())
+    assert len(S.intersect([P(a), P(b)])) == 0
+    assert len(S.intersect([P(a), P(e)])) == 0
+    assert S.intersect([P(a), P(a)]).read()[0].tolist() == [1, 5, 9]
+    ids, fr = S.intersect([P(a)]).read()
+    assert ids.tolist() == [1, 5, 9] and fr.tolist() == [[1, 2, 3]]
+
+
+def zipf_setup(rng, n_docs, dfs):
+    lists = []
+    for df in dfs:
+        docs = np.flatnonzero(rng.random(n_docs + 1) < df / n_docs).astype(np.uint64)
+        docs = docs[docs > 0]
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(docs, np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32))
+        lists.append(ii)
+    doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
+    doc_score = rng.uniform(0.2, 1.0, n_docs + 1).astype(np.float32)
+    return lists, doc_len, doc_score
+
+
+@pytest.mark.parametrize("scorer", list(S.SCORERS))
+def test_scorers_parity(scorer):
+    rng = np.random.default_rng(77)
+    N = 200_000
+    lists, doc_len, doc_score = zipf_setup(rng, N, [40_000, 20_000, 90_000])
+    oi, of, _ = O.intersect(lists)
+    assert len(oi) > 500
+    h = S.intersect([S.Postings.from_flat(l.flatten()) for l in lists])
+    idf = [S.calculate_idf(N, l.unique_docs) for l in lists]
+    bidf = [S.calculate_idf_bm25(N, l.unique_docs) for l in lists]
+    w = [1.0, 0.5, 2.0]
+    max_freq = np.maximum(doc_len // 7, 1).astype(np.uint32)
+    avg = float(doc_len[1:].mean())
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    gs = h.score(table, scorer, idf, bidf, w, N, avg, root_weight=0.7)
+    sel = oi.astype(np.int64)
+    os_ = O.score_flat(scorer, of, doc_len[sel], max_freq[sel], doc_score[sel], idf, bidf, w, 0.7, N, avg)
+    assert np.allclose(gs, os_, rtol=1e-12, atol=0)
+    if scorer not in ("BM25STD.TANH",):
+        assert np.array_equal(gs, os_), "fp64 scorers are expected to be bit-exact"
+    # top-N: score descending, equal score => lower doc id first (reference result_processor.c:849)
+    for n in (1, 10, 1000, len(oi) + 5):
+        ti, ts = h.topn(n)
+        order = np.lexsort((oi, -os_))[:n]
+        assert ti.tolist() == oi[order].tolist()
+        assert np.allclose(ts, os_[order], rtol=1e-12, atol=0)
+
+
+def test_topn_with_many_equal_scores():
+    rng = np.random.default_rng(5)
+    lists, doc_len, _ = zipf_setup(rng, 50_000, [20_000, 25_000])
+    oi, of, _ = O.intersect(lists)
+    h = S.intersect([S.Postings.from_flat(l.flatten()) for l in lists])
+    ones = np.ones(50_001, np.float32)
+    h.score(S.DocTable(doc_len, ones), "DOCSCORE", [1, 1], [1, 1], [1, 1], 50_000, 100.0, want_scores=False)
+    ti, ts = h.topn(25)                                     # every score equal: first 25 doc ids
+    assert ti.tolist() == oi[:25].tolist() and (ts == 1.0).all()
+
+
+def test_hybrid_prefilter_knn_rerank():
+    """BASELINE configs[4] in miniature: 2-term intersection -> candidates inside the vector index ->
+    ad-hoc BF distances -> top-10 (hybrid_reader.c:289-335) -> BM25STD on the survivors."""
+    rng = np.random.default_rng(49)
+    n_docs, n_vec, dim, k = 300_000, 30_000, 64, 10
+    lists, doc_len, doc_score = zipf_setup(rng, n_docs, [60_000, 30_000])
+    data = rng.uniform(-1, 1, (n_vec, dim)).astype(np.float32)
+    g = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+    g.add_bulk(data)                                        # labels 1..n_vec: docs beyond have no vector
+    o = O.FlatIndex(O.F32, dim, O.L2)
+    o.add_bulk(data)
+    q = rng.uniform(-1, 1, dim).astype(np.float32)
+    oi, of, _ = O.intersect(lists)
+    h = S.intersect([S.Postings.from_flat(l.flatten()) for l in lists])
+    gi, gd = h.knn_rerank(g, q, k)
+    nq = o.normalized_query(q)
+    cand = [(o.distance_from(int(i), nq), int(i)) for i in oi if i <= n_vec]
+    want = sorted(cand)[:k]
+    assert gi.tolist() == [i for _, i in want]
+    assert np.allclose(gd, [d for d, _ in want], rtol=1e-5, atol=1e-4)
+    # same through the per-label seam the reference uses today
+    adhoc = g.adhoc_ctx(q)
+    assert np.allclose(adhoc.get_exact_distances(gi), gd, rtol=0, atol=0)
+    # non-identity labels take the host label map
+    g2 = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+    perm = rng.permutation(n_vec) + 1
+    for row, lab in zip(data[:2000], perm[:2000]):
+        g2.add_vector(row, int(lab))
+    gi2, gd2 = h.knn_rerank(g2, q, k)
+    inv = {int(l): r for r, l in enumerate(perm[:2000])}
+    cand2 = sorted((float(np.sum((data[inv[int(i)]] - q) ** 2, dtype=np.float32)), int(i)) for i in oi if int(i) in inv)[:k]
+    assert gi2.tolist() == [i for _, i in cand2]
+
+
+def test_search_smoke_entry():
+    S.smoke()

@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size-2 gloo run of the row-sharded top-k exchange (redisearch_amd/sharded.py).
+Each rank holds a contiguous label range; the merged result must equal the single-index answer."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, rows, dim, k, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    from redisearch_amd.sharded import ShardedTopK
+    data = np.random.default_rng(47).uniform(-1, 1, (rows * world, dim)).astype(np.float32)
+    shard = O.FlatIndex(O.F32, dim, O.COSINE)
+    shard.add_bulk(data[rank * rows:(rank + 1) * rows], first_label=rank * rows + 1)
+
+    def local_topk(q, kk):                       # the CPU stand-in of RSGPU_FlatIndex_TopKDevice
+        ids, sc = shard.topk(q, kk)
+        s = torch.full((kk,), float("inf"), dtype=torch.float32)
+        l = torch.full((kk,), -1, dtype=torch.int64)
+        s[: len(sc)] = torch.from_numpy(sc.astype(np.float32))
+        l[: len(ids)] = torch.from_numpy(ids.astype(np.int64))
+        return s, l
+
+    sh = ShardedTopK(local_topk, k, torch.device("cpu"))
+    res = []
+    for q in np.random.default_rng(48).uniform(-1, 1, (6, dim)).astype(np.float32):
+        labels, scores = sh.query(q)
+        res.append((labels.tolist(), scores.tolist()))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "res.npy"), np.array([r[0] for r in res], dtype=np.uint64))
+        np.save(os.path.join(out_dir, "sc.npy"), np.array([r[1] for r in res], dtype=np.float64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,k", [(500, 10), (7, 10)])
+def test_sharded_topk_matches_single_index(tmp_path, rows, k):
+    import oracle as O
+    world, dim = 2, 24
+    mp.spawn(_worker, args=(world, _free_port(), rows, dim, k, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "res.npy", allow_pickle=True)
+    sc = np.load(tmp_path / "sc.npy", allow_pickle=True)
+    data = np.random.default_rng(47).uniform(-1, 1, (rows * world, dim)).astype(np.float32)
+    full = O.FlatIndex(O.F32, dim, O.COSINE)
+    full.add_bulk(data)
+    for i, q in enumerate(np.random.default_rng(48).uniform(-1, 1, (6, dim)).astype(np.float32)):
+        ids, s = full.topk(q, k)
+        assert list(got[i]) == ids.tolist()
+        assert np.allclose(sc[i], s.astype(np.float32), atol=1e-6)
+
+
+def test_merge_topk_ties_and_padding():
+    from redisearch_amd.sharded import merge_topk
+    s = np.array([0.5, 0.1, np.inf, 0.1, 0.3, np.inf], dtype=np.float32)
+    l = np.array([9, 7, -1, 3, 8, -1], dtype=np.int64).view(np.uint64)
+    labels, scores = merge_topk(s, l, 3)
+    assert labels.tolist() == [3, 7, 8] and np.allclose(scores, [0.1, 0.1, 0.3])
+    labels, _ = merge_topk(s, l, 10)
+    assert labels.tolist() == [3, 7, 8, 9]
