@@ -199,6 +199,14 @@ def main():
                 "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
+        # HBM traffic of the scan kernel from the committed PMC pass (separate rocprofv3 --pmc runs of
+        # this same command, corrected as MI355X_MICROARCH.md prescribes); bench.py cannot read PMCs itself
+        pmc = os.path.join(ROOT, "profiles", "r01_scan_pmc_hbm_traffic.json")
+        if os.path.exists(pmc):
+            p = json.load(open(pmc))
+            if p.get("rows") == rows and p.get("dim") == dim:
+                out["roofline"]["traffic"] = p["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_scan_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dim, k, min(a.cpu_sample_rows, rows), rows)
         print(json.dumps(out), flush=True)

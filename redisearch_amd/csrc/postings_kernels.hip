@@ -32,6 +32,9 @@ CodecDesc codec_desc(int codec) {
 namespace {
 
 // ---- decode ----------------------------------------------------------------------------------------
+// One kernel per record kind (0 qint, 1 varint delta, 2 raw u32 delta): keeping the three decoders in
+// one body made hipcc (ROCm 7.2) drop the cursor advance of the raw path.
+template <int KIND>
 __global__ __launch_bounds__(256) void decode_blocks_kernel(CodecDesc cd, const uint8_t *__restrict__ bytes,
                                                             const uint64_t *__restrict__ byte_off,
                                                             const uint32_t *__restrict__ first,
@@ -41,41 +44,45 @@ __global__ __launch_bounds__(256) void decode_blocks_kernel(CodecDesc cd, const 
                                                             uint32_t *__restrict__ masks) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= n_blocks) return;
-  const uint8_t *p = bytes + byte_off[b];
-  const uint8_t *end = bytes + byte_off[b + 1];
+  const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
   const uint32_t n = nent[b], f0 = first[b];
-  uint32_t base = f0, out = entry_off[b];
-  for (uint32_t e = 0; e < n && p < end; e++, out++) {
+  uint32_t out = entry_off[b];
+  uint64_t pos = beg;
+  uint32_t base = f0;
+  for (uint32_t e = 0; e < n && pos < fin; e++, out++) {
     uint32_t freq = 0, mask = 0;
-    if (cd.kind == 0) {
-      const uint32_t hdr = *p++;
+    if (KIND == 0) {
+      const uint32_t hdr = bytes[pos++];
       uint32_t v[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         if (i < cd.n) {
-          const int len = (int)((hdr >> (2 * i)) & 3u) + 1;
-          uint32_t x = 0;
-          for (int j = 0; j < len; j++) x |= (uint32_t)p[j] << (8 * j);
-          p += len;
+          const uint32_t len = ((hdr >> (2 * i)) & 3u) + 1u;
+          uint32_t x = bytes[pos];
+          if (len > 1) x |= (uint32_t)bytes[pos + 1] << 8;
+          if (len > 2) x |= (uint32_t)bytes[pos + 2] << 16;
+          if (len > 3) x |= (uint32_t)bytes[pos + 3] << 24;
+          pos += len;
           v[i] = x;
         }
       }
       base += v[0];
-      if (cd.freq >= 0) freq = v[cd.freq];
-      if (cd.mask >= 0) mask = v[cd.mask];
-      if (cd.osz >= 0) p += v[cd.osz];  // offsets bytes are skipped (BM25STD needs no positions)
-    } else if (cd.kind == 1) {
-      uint32_t c = *p++;
+      if (cd.freq >= 0) freq = cd.freq == 1 ? v[1] : (cd.freq == 2 ? v[2] : v[3]);
+      if (cd.mask >= 0) mask = cd.mask == 1 ? v[1] : (cd.mask == 2 ? v[2] : v[3]);
+      if (cd.osz >= 0) pos += cd.osz == 1 ? v[1] : (cd.osz == 2 ? v[2] : v[3]);  // offsets bytes skipped
+    } else if (KIND == 1) {
+      uint32_t c = bytes[pos++];
       uint32_t val = c & 0x7fu;
       while (c & 0x80u) {
         val++;
-        c = *p++;
+        c = bytes[pos++];
         val = (val << 7) | (c & 0x7fu);
       }
       base += val;
     } else {
-      uint32_t d = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-      p += 4;
+      const uint32_t d = (uint32_t)bytes[pos] | ((uint32_t)bytes[pos + 1] << 8) | ((uint32_t)bytes[pos + 2] << 16) |
+                         ((uint32_t)bytes[pos + 3] << 24);
+      pos += 4;
       base = f0 + d;
     }
     ids[out] = base;
@@ -276,8 +283,13 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s) {
   if (!n_blocks) return;
-  hipLaunchKernelGGL(decode_blocks_kernel, dim3(blocks_for(n_blocks)), dim3(256), 0, s, cd, bytes, byte_off, first,
-                     nent, entry_off, n_blocks, ids, freqs, masks);
+#define RSGPU_DECODE(K)                                                                                         \
+  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3(blocks_for(n_blocks)), dim3(256), 0, s, cd, bytes, byte_off, first, \
+                     nent, entry_off, n_blocks, ids, freqs, masks)
+  if (cd.kind == 0) RSGPU_DECODE(0);
+  else if (cd.kind == 1) RSGPU_DECODE(1);
+  else RSGPU_DECODE(2);
+#undef RSGPU_DECODE
 }
 void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s) {
   hipLaunchKernelGGL(intersect_probe_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_counts);
