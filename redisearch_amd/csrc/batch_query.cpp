@@ -1,0 +1,177 @@
+// batch_query.cpp -- host driver of the batched-query path (gemm_kernels.hip): B queries against the
+// whole FLAT corpus in one GEMM pass on the matrix cores, exact top-k per query.
+//
+// No reference counterpart exists: VecSim answers B queries with B VecSimIndex_TopKQuery calls
+// (reference src/iterators/hybrid_reader.c:374).  Results are identical to B single queries up to
+// the fp32 summation order (MFMA k-order vs the scan's lane order), i.e. inside the parity tolerance.
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+#include "flat_index.hpp"
+
+namespace rsgpu {
+
+namespace {
+
+constexpr uint32_t kBatch = 256;  // queries per GEMM pass (the kernel's M tile)
+
+template <typename T>
+struct Dev {
+  T *p = nullptr;
+  size_t n = 0;
+  ~Dev() {
+    if (p) (void)hipFree(p);
+  }
+  void ensure(size_t count) {
+    if (count <= n) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+};
+
+// grow-only device scratch of the calling thread
+struct BatchScratch {
+  int device = -1;
+  Dev<uint8_t> queries;
+  Dev<float> tau;
+  Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
+  Dev<uint64_t> cand;
+};
+thread_local BatchScratch tls_batch;
+
+}  // namespace
+
+void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
+                           size_t *counts_out) {
+  const bool gemm_ok = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 &&
+                       !multi && k > 0 && k <= 4096;
+  auto single = [&](size_t qi) {
+    VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
+    counts_out[qi] = r->len;
+    for (size_t j = 0; j < r->len; j++) {
+      ids_out[qi * k + j] = r->results[j].id;
+      scores_out[qi * k + j] = r->results[j].score;
+    }
+    host_free(r->results);
+    host_free(r);
+  };
+  if (!gemm_ok) {
+    for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+    return;
+  }
+  flush_if_needed();
+  std::vector<size_t> redo;
+  {
+    std::shared_lock<std::shared_mutex> g(mu);
+    const uint32_t n = n_rows_;
+    if (!n) {
+      for (size_t qi = 0; qi < n_queries; qi++) counts_out[qi] = 0;
+      return;
+    }
+    HIP_CHECK(hipSetDevice(device));
+    CtxLease c(device);
+    BatchScratch &sc = tls_batch;
+    if (sc.device != device) {
+      sc.~BatchScratch();
+      new (&sc) BatchScratch();
+      sc.device = device;
+    }
+    const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
+    const uint32_t stride16 = (uint32_t)(stride_ / 16);
+    // sample prefix for the thresholds; small corpora take the all-keys path
+    const bool small = n <= (1u << 19);
+    uint32_t n0 = small ? n : std::min<uint32_t>(std::max<uint32_t>(round_up(n / 64, 256), 1u << 16), 1u << 18);
+    n0 = std::max<uint32_t>(n0, std::min<uint32_t>(n, (uint32_t)round_up((size_t)kk * 8, 256)));
+    const uint32_t cand_cap =
+        small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, 4ull * kk * ((n + n0 - 1) / n0)));
+    sc.queries.ensure((size_t)kBatch * stride_);
+    sc.tau.ensure(kBatch);
+    sc.cand_count.ensure(kBatch);
+    sc.overflow.ensure(kBatch);
+    sc.keys.ensure((size_t)kBatch * n0);
+    sc.out_rows.ensure((size_t)kBatch * kk);
+    sc.out_keys.ensure((size_t)kBatch * kk);
+    sc.out_n.ensure(kBatch);
+    sc.cand.ensure((size_t)kBatch * cand_cap);
+    std::vector<uint8_t> hq((size_t)kBatch * stride_);
+    std::vector<uint32_t> h_rows((size_t)kBatch * kk), h_keys((size_t)kBatch * kk), h_n(kBatch), h_over(kBatch);
+
+    for (size_t q0 = 0; q0 < n_queries; q0 += kBatch) {
+      const uint32_t nb = (uint32_t)std::min<size_t>(kBatch, n_queries - q0);
+      std::fill(hq.begin(), hq.end(), 0);  // unused query rows stay zero (their results are ignored)
+      for (uint32_t i = 0; i < nb; i++) {
+        uint8_t *dst = hq.data() + (size_t)i * stride_;
+        memcpy(dst, (const uint8_t *)queries + (q0 + i) * elem_bytes_, elem_bytes_);
+        if (metric == VecSimMetric_Cosine) normalize_host(dst);
+      }
+      HIP_CHECK(hipMemcpyAsync(sc.queries.p, hq.data(), hq.size(), hipMemcpyHostToDevice, c->stream));
+      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+      if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+      if (small) {
+        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
+                         c->stream);
+        launch_batch_select_keys(sc.keys.p, n0, n, kk, kBatch, sc.out_rows.p, sc.out_keys.p, sc.out_n.p, kk, c->stream);
+        HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
+      } else {
+        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
+                         c->stream);
+        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream);
+        HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
+        HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
+        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
+                         sc.cand.p, cand_cap, c->stream);
+        launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
+                                 sc.out_n.p, kk, sc.overflow.p, c->stream);
+      }
+      HIP_CHECK(hipGetLastError());
+      if (prof) HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+      HIP_CHECK(hipMemcpyAsync(h_rows.data(), sc.out_rows.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(h_keys.data(), sc.out_keys.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(h_n.data(), sc.out_n.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(h_over.data(), sc.overflow.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+          ScanProfile &pf = scan_profile();
+          pf.launches++;
+          pf.bytes += (uint64_t)n * elem_bytes_;
+          pf.nanos += (uint64_t)((double)ms * 1e6);
+        }
+      }
+      std::vector<Hit> hits;
+      for (uint32_t i = 0; i < nb; i++) {
+        const size_t qi = q0 + i;
+        if (h_over[i]) {  // candidate list overflowed: redo this query on the single-query path
+          redo.push_back(qi);
+          continue;
+        }
+        const uint32_t got = std::min(h_n[i], kk);
+        hits.resize(got);
+        for (uint32_t j = 0; j < got; j++) hits[j] = Hit{h_rows[(size_t)i * kk + j], h_keys[(size_t)i * kk + j]};
+        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) {
+          return a.key != b.key ? a.key < b.key : a.row < b.row;
+        });
+        // reply order: (score, label) ascending
+        std::vector<VecSimQueryResult> res(got);
+        for (uint32_t j = 0; j < got; j++)
+          res[j] = VecSimQueryResult{(size_t)row_label_[hits[j].row], (double)key_to_dist((uint32_t)hits[j].key)};
+        std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
+          return a.score != b.score ? a.score < b.score : a.id < b.id;
+        });
+        counts_out[qi] = got;
+        for (uint32_t j = 0; j < got; j++) {
+          ids_out[qi * k + j] = res[j].id;
+          scores_out[qi * k + j] = res[j].score;
+        }
+      }
+    }
+  }
+  for (size_t qi : redo) single(qi);
+}
+
+}  // namespace rsgpu

@@ -130,6 +130,11 @@ class FlatIndex {
   VecSimQueryReply *topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order);
   VecSimQueryReply *range(const void *query, double radius, VecSimQueryParams *qp, VecSimQueryReply_Order order);
   double distance_from(size_t label, const void *normalized_blob);
+  // B queries at once (non-ABI): ids_out/scores_out are [B][k], counts_out[B] the hits per query.
+  // fp16/bf16 IP/cosine run as a GEMM on the matrix cores (batch_query.cpp); everything else loops
+  // over topk().
+  void topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
+                  size_t *counts_out);
   bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
 
   // building blocks shared with the batch iterator / adhoc ctx / device-output extension

@@ -71,6 +71,24 @@ void launch_select_pass(const void *keys, int key_bytes, uint32_t n, int pass, u
 void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int passes_done, uint32_t k, uint64_t lkey,
                            uint32_t lrow, int has_lower, const SelectBufs &b, uint32_t cap, hipStream_t s);
 
+// ---- batched queries on the matrix cores (gemm_kernels.hip) ------------------------------------------
+// S = Q[256 x K] * X^T, fp16/bf16 in, fp32 accumulate, distance = 1 - dot (IP / cosine).
+// mode 0: keys_out[q*keys_ld + (row-row_begin)] = orderable key of every distance;
+// mode 1: append (row,key) with distance <= tau[q] to cand[q*cand_cap + ...], counting in cand_count[q].
+void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
+                      uint32_t row_end, int mode, uint32_t *keys_out, uint32_t keys_ld, const float *tau,
+                      uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s);
+// per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
+void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
+                            uint32_t n_valid, float *tau_out, hipStream_t s);
+// per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
+void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
+                              uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);
+// per query: the k smallest (key,row) of its candidate list; overflow[q]=1 if the list overflowed
+void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
+                              uint32_t n_queries, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n,
+                              uint32_t k_ld, uint32_t *overflow, hipStream_t s);
+
 // ---- range query: all rows with key <= max_key ----------------------------------------------------
 // counters[0] receives the count (collect=0) or is used as the append cursor (collect=1).
 void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,

@@ -481,6 +481,14 @@ int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, 
   return got;
   ABI_CATCH(f->log_ctx, "RSGPU_FlatIndex_TopKDevice", -1)
 }
+int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_queries, size_t k, size_t *ids_out,
+                              double *scores_out, size_t *counts_out) {
+  if (!index || !queries || !ids_out || !scores_out || !counts_out) return -1;
+  ABI_TRY
+  index->flat->topk_batch(queries, n_queries, k, ids_out, scores_out, counts_out);
+  return 0;
+  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_TopKBatch", -1)
+}
 int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
                     double *scores_out, uint64_t *labels_out, void *wait_stream) {
   ABI_TRY

@@ -171,6 +171,7 @@ ABI = {
     "RSGPU_FlatIndex_Reserve": (_i, [_vp, _sz]),
     "RSGPU_FlatIndex_AddDeviceRows": (_i, [_vp, _vp, _sz, _sz]),
     "RSGPU_FlatIndex_TopKDevice": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_FlatIndex_TopKBatch": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "RSGPU_MergeTopK": (_i, [_i, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "RSGPU_SetProfiling": (None, [_i]),
     "RSGPU_ResetProfile": (None, []),
@@ -368,6 +369,18 @@ class VecSimIndex:
 
     def adhoc_ctx(self, q):
         return AdhocBfCtx(self, q)
+
+    def topk_batch(self, queries, k):
+        """B queries -> (ids [B,k] uint64, scores [B,k] float64, counts [B])."""
+        qm = to_blob(queries, self.vtype)
+        assert qm.ndim == 2 and qm.shape[1] == self.dim
+        b = qm.shape[0]
+        ids = np.zeros((b, k), dtype=np.uint64)
+        sc = np.full((b, k), np.inf, dtype=np.float64)
+        cnt = np.zeros(b, dtype=np.uint64)
+        if self.lib.RSGPU_FlatIndex_TopKBatch(self.ptr, _p(qm), b, k, _p(ids), _p(sc), _p(cnt)) != 0:
+            raise RuntimeError(last_error())
+        return ids, sc, cnt.astype(np.int64)
 
     def topk_device(self, q, k, dev_scores_ptr, dev_labels_ptr):
         r = self.lib.RSGPU_FlatIndex_TopKDevice(self.ptr, _p(self._q(q)), k, dev_scores_ptr, dev_labels_ptr)

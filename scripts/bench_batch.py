@@ -1,0 +1,58 @@
+"""BASELINE configs[2] on MI355X: 10M x 768 fp16 FLAT IP top-100, batch = 256 queries per corpus pass on
+the matrix cores (RSGPU_FlatIndex_TopKBatch).  Reports batches/s, QPS, HIP-event time of the whole device
+pipeline per batch, HBM GB/s (algorithmic corpus bytes) and MFMA TFLOP/s.  Writes gpurun_out/batch_bench.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from redisearch_amd import vecsim as V  # noqa: E402
+
+rows = int(os.environ.get("ROWS", 10_000_000))
+dim, k, batch = 768, 100, 256
+reps = int(os.environ.get("REPS", 12))
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+lib = V.load()
+idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
+idx.reserve(rows)
+gen = torch.Generator(device=dev)
+gen.manual_seed(47)
+done = 0
+while done < rows:
+    m = min(1_000_000, rows - done)
+    t = (torch.rand((m, dim), device=dev, generator=gen) * 2 - 1).to(torch.float16)
+    torch.cuda.synchronize()
+    idx.add_device_rows(t.data_ptr(), m, done + 1)
+    done += m
+    del t
+qs = np.random.default_rng(48).uniform(-1, 1, (40, batch, dim)).astype(np.float16)
+idx.topk_batch(qs[0], k)  # warm-up (allocations)
+lib.RSGPU_ResetProfile()
+lib.RSGPU_SetProfiling(1)
+t0 = time.perf_counter()
+for i in range(reps):
+    ids, sc, cnt = idx.topk_batch(qs[(i + 1) % 40], k)
+el = time.perf_counter() - t0
+lib.RSGPU_SetProfiling(0)
+launches, ms, by = V.scan_profile()
+dev_ms = ms / launches
+flops = 2.0 * batch * dim * rows
+out = {"config": "%dx%d fp16 FLAT IP top-%d, batch=%d (MFMA GEMM path)" % (rows, dim, k, batch),
+       "batches_per_s_wall": reps / el, "qps_wall": reps * batch / el, "ms_per_batch_wall": el / reps * 1e3,
+       "device_ms_per_batch": dev_ms, "qps_device": batch / dev_ms * 1e3,
+       "hbm_algorithmic_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac_of_8TBs": rows * dim * 2 / dev_ms / 1e6 / 8000,
+       "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac_of_2500TF": flops / dev_ms / 1e9 / 2500}
+# spot check against the single-query path
+for i in (0, 128, 255):
+    si, ss = idx.topk_query(qs[reps % 40][i], k).results()
+    same = len(set(si.tolist()) & set(ids[i].tolist()))
+    assert same >= k - 2 and np.allclose(np.sort(sc[i]), np.sort(ss), atol=2e-3), (i, same)
+out["parity_spot_check"] = "3 queries vs single-query path: top-%d overlap >= %d, distances within 2e-3" % (k, k - 2)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/batch_bench.json", "w"), indent=1)
+print(json.dumps(out))
