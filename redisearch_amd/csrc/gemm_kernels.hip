@@ -7,25 +7,32 @@
 // (BASELINE configs[2]; the single-query path in scan_kernels.hip stays a bandwidth-bound GEMV).
 //
 // S is never materialised (256 x 10M fp32 = 10 GB).  Three steps, all on the device:
-//   1. the GEMM kernel in KEYS mode over a small prefix of the corpus (n0 rows) writes every
-//      orderable distance key; batch_threshold_kernel finds, per query, the k-th smallest key of the
-//      sample: a valid upper bound tau[q] of the final k-th distance;
-//   2. the GEMM kernel in FILTER mode over ALL rows keeps only (row,key) with distance <= tau[q]
-//      -- expected k*N/n0 survivors per query -- appended to per-query candidate lists;
-//   3. batch_final_select_kernel picks, per query, the exact k smallest (key,row) composites of its
+//   1. the GEMM in KEYS mode over a small prefix of the corpus (n0 rows) writes every orderable
+//      distance key; batch_select_kernel finds, per query, the k-th smallest key of the sample: a valid
+//      upper bound tau[q] of the final k-th distance;
+//   2. the GEMM in FILTER mode over ALL rows keeps only (row,key) with distance <= tau[q] -- expected
+//      k*N/n0 survivors per query -- appended to per-query candidate lists;
+//   3. batch_select_kernel picks, per query, the exact k smallest (key,row) composites of its
 //      candidates (same total order as select_kernels.hip).
 // The result is exact whatever the data order (tau is a true upper bound); a candidate overflow makes
-// the host fall back to the single-query path for that query.
+// the host redo that query on the single-query path.
 //
-// GEMM kernel: 512 threads = 8 wavefronts (4 along the queries x 2 along the corpus rows), block tile
-// 256 queries x 128 rows x BK=64, v_mfma_f32_32x32x16_f16 (fp32 accumulate), each wave owns a
-// 64 x 64 sub-tile = 2 x 2 MFMA tiles = 64 accumulator VGPRs (a 256 x 256 tile with 128 accumulators
-// per lane spilled ~100 VGPRs under hipcc, so the smaller tile is the faster one here).  Both operands
-// are K-contiguous rows (an "NT" GEMM), staged global -> registers -> LDS in full 128-byte lines
-// (8 lanes x 16 B per row), double-buffered (96 KiB of the CU's 160 KiB LDS), 16-byte chunks
-// XOR-swizzled by (row & 7) so the ds_read_b128 fragment reads are at most 2-way conflicted.
-// Persistent grid: one workgroup per CU walks the corpus tiles; the 384 KiB query matrix is re-read
-// from L2 per tile.
+// GEMM: 512 threads = 8 wavefronts (4 along the queries x 2 along the corpus rows), block tile
+// 256 queries x 128 rows, v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulate; each wave owns a 64 x 64
+// sub-tile = 2 x 2 MFMA tiles = 64 accumulator VGPRs (a 256 x 256 tile with 128 accumulators per lane
+// spilled ~100 VGPRs under hipcc).  Both operands are K-contiguous rows (an "NT" GEMM).  Two staging
+// schemes:
+//   * gemm_topk_ring_kernel: global -> LDS directly (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction, no VGPRs, no ds_write pass) into a ring of three stages, two in flight while the
+//     third is multiplied; counted s_waitcnt vmcnt(N) + raw s_barrier keep the DMAs alive across the
+//     barrier (cdna_hip_programming.md "Pipelining across barriers").  The DMA destination is
+//     lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches and again on the
+//     fragment read (same involution on both sides).  KC = 8 chunks per stage (64 halves, 48 KiB stage,
+//     one workgroup per CU) or KC = 4 (24 KiB stage, two workgroups per CU so that one multiplies while
+//     the other waits).  Needs dim % (8*KC) == 0.
+//   * gemm_topk_kernel: global -> registers -> LDS, double-buffered, any K (zero-filled tail).
+// The epilogue is specialised per mode and its rare append path is out of line, so that it does not
+// inflate the register allocation of the K loop.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
@@ -39,10 +46,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
-constexpr int BM = 256, BN = 128, BKC = 8;  // BKC: 16-byte chunks per K step (64 halves)
-constexpr int A_CHUNKS = BM * BKC;          // 2048 chunks = 32 KiB of queries per stage
-constexpr int B_CHUNKS = BN * BKC;          // 1024 chunks = 16 KiB of corpus rows per stage
-constexpr int STAGE_CHUNKS = A_CHUNKS + B_CHUNKS;
+constexpr int BM = 256, BN = 128;
 
 __device__ __forceinline__ uint32_t f2key(float f) {
   uint32_t u = __float_as_uint(f);
@@ -65,41 +69,99 @@ __device__ __forceinline__ f32x16 mfma(u4 a, u4 b, f32x16 c) {
   }
 }
 
-// swizzled chunk slot of (row, chunk) inside a [256][8] tile
-__device__ __forceinline__ uint32_t slot(uint32_t row, uint32_t c) { return row * BKC + (c ^ (row & 7u)); }
+// XOR swizzle of the 16-byte chunk index inside an LDS row of KC chunks: conflict-free for the
+// 16-lane groups ds_read_b128 is serviced in (rows l, same chunk): KC=8 -> 128-byte rows, key
+// (row>>1)&7; KC=4 -> 64-byte rows, key (row>>2)&3.
+template <int KC>
+__device__ __forceinline__ uint32_t swz(uint32_t row) {
+  return KC == 8 ? ((row >> 1) & 7u) : ((row >> 2) & 3u);
+}
+template <int KC>
+__device__ __forceinline__ uint32_t slotk(uint32_t row, uint32_t c) { return row * KC + (c ^ swz<KC>(row)); }
 
 struct GemmArgs {
   const u4 *rows;      // corpus, row-contiguous
   const u4 *queries;   // [256][stride16], zero padded
   uint32_t stride16;   // row stride in 16-byte chunks == K chunks
   uint32_t row_begin, row_end;
-  int mode;            // 0: write keys, 1: filter
-  uint32_t *keys_out;  // mode 0: [256][keys_ld], column = row - row_begin
+  uint32_t *keys_out;  // KEYS mode: [256][keys_ld], column = row - row_begin
   uint32_t keys_ld;
-  const float *tau;    // mode 1: per-query distance upper bound
+  const float *tau;    // FILTER mode: per-query distance upper bound
   uint32_t *cand_count;  // [256]
   uint2 *cand;           // [256][cand_cap] (row, key)
   uint32_t cand_cap;
 };
 
-template <int DT>
-__global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
-  __shared__ u4 smem[2 * STAGE_CHUNKS];  // [stage][A 256x8 | B 128x8] = 96 KiB
-  __shared__ float tau_s[BM];
+__device__ __noinline__ void append_candidate(uint32_t *cand_count, uint2 *cand, uint32_t cand_cap, uint32_t q,
+                                              uint32_t row, float d) {
+  uint32_t s = atomicAdd(&cand_count[q], 1u);
+  if (s < cand_cap) cand[(size_t)q * cand_cap + s] = make_uint2(row, f2key(d));
+}
+
+// C row = query (reg&3)+8*(reg>>2)+4*(lane>>5) of the 32x32 MFMA tile, C col = corpus row lane&31.
+// MODE 0: write every key; MODE 1: keep distance <= tau[q].
+template <int MODE>
+__device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], const float *tau_s,
+                                         uint32_t row0, uint32_t wm, uint32_t wn, uint32_t lane) {
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const uint32_t xr = row0 + wn * 64 + nt * 32 + (lane & 31);
+      const bool live = xr < g.row_end;
+      const uint32_t qb = wm * 64 + mt * 32 + 4 * (lane >> 5);
+      if (MODE == 0) {
+        uint32_t *out = g.keys_out + (size_t)qb * g.keys_ld + (xr - g.row_begin);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (live) out[(size_t)((r & 3) + 8 * (r >> 2)) * g.keys_ld] = f2key(1.0f - acc[mt][nt][r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const uint32_t q = qb + (r & 3) + 8 * (r >> 2);
+          const float d = 1.0f - acc[mt][nt][r];
+          if (live && d <= tau_s[q]) append_candidate(g.cand_count, g.cand, g.cand_cap, q, xr, d);
+        }
+      }
+    }
+  }
+}
+
+// counted wait: at most n VMEM operations of this wave still outstanding (n must become an immediate)
+__device__ __forceinline__ void wait_vmcnt(uint32_t n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// ---- LDS-DMA ring ---------------------------------------------------------------------------------------
+// NS stages in the ring: NS-1 in flight while one is multiplied.
+template <int DT, int KC, int NS, int MINW, int MODE>
+__global__ __launch_bounds__(512, MINW) void gemm_topk_ring_kernel(GemmArgs g) {
+  constexpr int NSTAGE = NS;
+  constexpr int STAGE = (BM + BN) * KC;    // chunks per stage
+  constexpr int RPP = 64 / KC;             // rows per 64-chunk DMA piece
+  constexpr int PIECES = (BM + BN) / RPP;  // pieces per stage (48 or 24)
+  constexpr int PPW = PIECES / 8;          // pieces per wave (6 or 3)
+  constexpr int A_PIECES = BM / RPP;
+  __shared__ u4 smem[NSTAGE * STAGE + BM / 4];  // ring + tau[256]: ONE __shared__ object (a second one makes
+                                                // hipcc drain vmcnt before every ds_read)
+  float *tau_s = reinterpret_cast<float *>(smem + NSTAGE * STAGE);
   const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t wm = w >> 1, wn = w & 1;  // wave position: 4 along the queries x 2 along the rows
+  const uint32_t wm = w >> 1, wn = w & 1;  // 4 waves along the queries x 2 along the rows
   const uint32_t kchunks = g.stride16;
-  const uint32_t ksteps = (kchunks + BKC - 1) / BKC;
+  const uint32_t ksteps = kchunks / KC;
   const uint32_t n = g.row_end - g.row_begin;
   const uint32_t n_tiles = (n + BN - 1) / BN;
-  if (g.mode == 1) {
-    if (tid < BM) tau_s[tid] = g.tau[tid];
-  }
+  if (MODE == 1 && tid < BM) tau_s[tid] = g.tau[tid];
   __syncthreads();
-
-  // staging map: this thread moves chunks id = tid + i*512 of the query tile (i<4) and of the corpus
-  // tile (i<2): row id/8, chunk id%8 -- 8 consecutive lanes cover one 128-byte line
-  const uint32_t schunk = tid & 7u, srow0 = tid >> 3;  // rows srow0 + 64*i
 
   for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const uint32_t row0 = g.row_begin + tile * BN;
@@ -111,9 +173,100 @@ __global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
 
+    // DMA map: a stage is [384 rows][KC chunks] (256 query rows, then 128 corpus rows) cut in pieces of
+    // 64 chunks; wave w moves pieces PPW*w ...  Lane l of piece j lands in slot 64j + l = row
+    // RPP*j + l/KC, slot l%KC, and fetches source chunk (l%KC) ^ swz(row).
+    const u4 *src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; i++) {
+      const uint32_t j = w * PPW + i;
+      const uint32_t r = RPP * j + lane / KC;
+      const uint32_t c = (lane % KC) ^ swz<KC>(r);
+      if (j < A_PIECES) {
+        src[i] = g.queries + (size_t)r * kchunks + c;
+      } else {
+        uint32_t xr = row0 + (r - BM);
+        if (xr >= g.row_end) xr = g.row_end - 1;  // tail tile: recomputed, never emitted
+        src[i] = g.rows + (size_t)xr * kchunks + c;
+      }
+    }
+    auto issue = [&](uint32_t ks) {
+      u4 *stage = smem + (ks % NSTAGE) * STAGE;
+#pragma unroll
+      for (int i = 0; i < PPW; i++) {
+        const uint32_t j = w * PPW + i;
+        const __attribute__((address_space(1))) void *gp =
+            (const __attribute__((address_space(1))) void *)(src[i] + (size_t)ks * KC);
+        __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)(stage + j * 64);
+        if (j < A_PIECES) __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2);  // nt: corpus lines are used once
+      }
+    };
+
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; p++)
+      if ((uint32_t)p < ksteps) issue(p);
+    for (uint32_t ks = 0; ks < ksteps; ks++) {
+      // stage ks has landed once only this wave's DMAs of the younger stages are outstanding ...
+      const uint32_t younger = ksteps - 1 - ks < (uint32_t)(NSTAGE - 2) ? ksteps - 1 - ks : (uint32_t)(NSTAGE - 2);
+      wait_vmcnt(younger * PPW);
+      // ... for every wave; the barrier also says stage ks-1 has been consumed, freeing its slot
+      __builtin_amdgcn_s_barrier();
+      if (ks + NSTAGE - 1 < ksteps) issue(ks + NSTAGE - 1);
+      const u4 *A = smem + (ks % NSTAGE) * STAGE, *B = A + BM * KC;
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; kk++) {
+        const uint32_t c = kk * 2 + (lane >> 5);
+        u4 a[2], b[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) a[mt] = A[slotk<KC>(wm * 64 + mt * 32 + (lane & 31), c)];
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) b[nt] = B[slotk<KC>(wn * 64 + nt * 32 + (lane & 31), c)];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+          for (int nt = 0; nt < 2; nt++) acc[mt][nt] = mfma<DT>(a[mt], b[nt], acc[mt][nt]);
+      }
+    }
+    epilogue<MODE>(g, acc, tau_s, row0, wm, wn, lane);
+    // stores/atomics of the epilogue share the vmcnt queue with the next tile's DMAs: drain them, and
+    // make sure every wave is done reading the ring before it is refilled
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ---- register-staged fallback (any K) ---------------------------------------------------------------------
+template <int DT, int MODE>
+__global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
+  constexpr int KC = 8;
+  constexpr int A_CHUNKS = BM * KC, STAGE = (BM + BN) * KC;
+  __shared__ u4 smem[2 * STAGE + BM / 4];
+  float *tau_s = reinterpret_cast<float *>(smem + 2 * STAGE);
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t wm = w >> 1, wn = w & 1;
+  const uint32_t kchunks = g.stride16;
+  const uint32_t ksteps = (kchunks + KC - 1) / KC;
+  const uint32_t n = g.row_end - g.row_begin;
+  const uint32_t n_tiles = (n + BN - 1) / BN;
+  if (MODE == 1 && tid < BM) tau_s[tid] = g.tau[tid];
+  __syncthreads();
+  // staging map: chunks id = tid + i*512 of the query tile (i<4) and of the corpus tile (i<2): row id/8,
+  // chunk id%8 -- 8 consecutive lanes cover one 128-byte line
+  const uint32_t schunk = tid & 7u, srow0 = tid >> 3;
+
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t row0 = g.row_begin + tile * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.0f;
     u4 ra[4], rb[2];
     auto load_stage = [&](uint32_t ks) {
-      const uint32_t c = ks * BKC + schunk;
+      const uint32_t c = ks * KC + schunk;
       const bool in_k = c < kchunks;
 #pragma unroll
       for (int i = 0; i < 4; i++)
@@ -121,33 +274,32 @@ __global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         uint32_t xr = row0 + srow0 + 64 * i;
-        if (xr >= g.row_end) xr = g.row_end - 1;  // tail tile: recomputed, never emitted
+        if (xr >= g.row_end) xr = g.row_end - 1;
         rb[i] = in_k ? __builtin_nontemporal_load(g.rows + (size_t)xr * kchunks + c) : (u4){0u, 0u, 0u, 0u};
       }
     };
     auto store_stage = [&](uint32_t buf) {
-      u4 *A = smem + buf * STAGE_CHUNKS, *B = A + A_CHUNKS;
+      u4 *A = smem + buf * STAGE, *B = A + A_CHUNKS;
 #pragma unroll
-      for (int i = 0; i < 4; i++) A[slot(srow0 + 64 * i, schunk)] = ra[i];
+      for (int i = 0; i < 4; i++) A[slotk<KC>(srow0 + 64 * i, schunk)] = ra[i];
 #pragma unroll
-      for (int i = 0; i < 2; i++) B[slot(srow0 + 64 * i, schunk)] = rb[i];
+      for (int i = 0; i < 2; i++) B[slotk<KC>(srow0 + 64 * i, schunk)] = rb[i];
     };
-
     load_stage(0);
     store_stage(0);
     __syncthreads();
     for (uint32_t ks = 0; ks < ksteps; ks++) {
       const uint32_t buf = ks & 1u;
       if (ks + 1 < ksteps) load_stage(ks + 1);  // in flight during the MFMAs below
-      const u4 *A = smem + buf * STAGE_CHUNKS, *B = A + A_CHUNKS;
+      const u4 *A = smem + buf * STAGE, *B = A + A_CHUNKS;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const uint32_t c = kk * 2 + (lane >> 5);
         u4 a[2], b[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) a[mt] = A[slot(wm * 64 + mt * 32 + (lane & 31), c)];
+        for (int mt = 0; mt < 2; mt++) a[mt] = A[slotk<KC>(wm * 64 + mt * 32 + (lane & 31), c)];
 #pragma unroll
-        for (int nt = 0; nt < 2; nt++) b[nt] = B[slot(wn * 64 + nt * 32 + (lane & 31), c)];
+        for (int nt = 0; nt < 2; nt++) b[nt] = B[slotk<KC>(wn * 64 + nt * 32 + (lane & 31), c)];
 #pragma unroll
         for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -156,27 +308,7 @@ __global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
       if (ks + 1 < ksteps) store_stage(buf ^ 1u);
       __syncthreads();
     }
-
-    // epilogue: C row = query (reg&3)+8*(reg>>2)+4*(lane>>5) of the MFMA tile, C col = corpus row lane&31
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-#pragma unroll
-      for (int nt = 0; nt < 2; nt++) {
-        const uint32_t xr = row0 + wn * 64 + nt * 32 + (lane & 31);
-        const bool live = xr < g.row_end;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const uint32_t q = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const float d = 1.0f - acc[mt][nt][r];
-          if (g.mode == 0) {
-            if (live) g.keys_out[(size_t)q * g.keys_ld + (xr - g.row_begin)] = f2key(d);
-          } else if (live && d <= tau_s[q]) {
-            uint32_t s = atomicAdd(&g.cand_count[q], 1u);
-            if (s < g.cand_cap) g.cand[(size_t)q * g.cand_cap + s] = make_uint2(xr, f2key(d));
-          }
-        }
-      }
-    }
+    epilogue<MODE>(g, acc, tau_s, row0, wm, wn, lane);
     __syncthreads();
   }
 }
@@ -201,7 +333,7 @@ struct BatchSel {
 };
 
 template <bool PAIRS>
-__global__ __launch_bounds__(256) void batch_select_kernel(BatchSel s) {
+__global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
   __shared__ uint32_t hist[256];
   __shared__ u64 sh_prefix;
   __shared__ uint32_t sh_krem, sh_exact, sh_levels, sh_out;
@@ -233,11 +365,11 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchSel s) {
   };
   const bool take_all = (k == n);
   for (int p = 0; p < 8 && !sh_exact; p++) {
-    hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const u64 prefix = sh_prefix;
     const int mshift = 64 - 8 * p, dshift = 56 - 8 * p;
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += blockDim.x) {
       u64 c = elem(i);
       if (p == 0 || (c >> mshift) == (prefix >> mshift)) atomicAdd(&hist[(uint32_t)(c >> dshift) & 0xffu], 1u);
     }
@@ -292,7 +424,7 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchSel s) {
     }
   }
   if (s.out_rows) {
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
       const uint32_t i = i0 + tid;
       bool take = false;
       u64 c = 0;
@@ -313,38 +445,57 @@ __global__ __launch_bounds__(256) void batch_select_kernel(BatchSel s) {
   }
 }
 
+
+template <int DT, int MODE>
+static void launch_gemm_mode(const GemmArgs &g, uint32_t n_tiles, hipStream_t s) {
+  const uint32_t cus = (uint32_t)scan_tuning().num_cus;
+  const int variant = scan_tuning().gemm_dma;  // 0 register-staged; 1 ring KC=8, 1 WG/CU; 2 ring KC=4, 2 WG/CU
+  const uint32_t grid1 = n_tiles < cus ? n_tiles : cus, grid2 = n_tiles < 2 * cus ? n_tiles : 2 * cus;
+  if (variant == 2 && g.stride16 % 4 == 0)       // 24 KiB stages, ring of 3, two workgroups per CU
+    hipLaunchKernelGGL((gemm_topk_ring_kernel<DT, 4, 3, 4, MODE>), dim3(grid2), dim3(512), 0, s, g);
+  else if (variant == 3 && g.stride16 % 4 == 0)  // 24 KiB stages, ring of 6 (5 in flight), one workgroup per CU
+    hipLaunchKernelGGL((gemm_topk_ring_kernel<DT, 4, 6, 2, MODE>), dim3(grid1), dim3(512), 0, s, g);
+  else if (variant >= 1 && g.stride16 % 8 == 0)  // 48 KiB stages, ring of 3
+    hipLaunchKernelGGL((gemm_topk_ring_kernel<DT, 8, 3, 2, MODE>), dim3(grid1), dim3(512), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_topk_kernel<DT, MODE>), dim3(grid1), dim3(512), 0, s, g);
+}
+
 }  // namespace
 
 void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                       uint32_t row_end, int mode, uint32_t *keys_out, uint32_t keys_ld, const float *tau,
                       uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s) {
   if (row_end <= row_begin) return;
-  GemmArgs g{(const u4 *)rows, (const u4 *)queries, stride16, row_begin, row_end, mode, keys_out, keys_ld, tau,
+  GemmArgs g{(const u4 *)rows, (const u4 *)queries, stride16, row_begin, row_end, keys_out, keys_ld, tau,
              cand_count, (uint2 *)cand, cand_cap};
-  uint32_t n_tiles = (row_end - row_begin + BN - 1) / BN;
-  uint32_t cus = (uint32_t)scan_tuning().num_cus;
-  uint32_t grid = n_tiles < cus ? n_tiles : cus;
-  if (dtype == KT_F16) hipLaunchKernelGGL(gemm_topk_kernel<KT_F16>, dim3(grid), dim3(512), 0, s, g);
-  else hipLaunchKernelGGL(gemm_topk_kernel<KT_BF16>, dim3(grid), dim3(512), 0, s, g);
+  const uint32_t n_tiles = (row_end - row_begin + BN - 1) / BN;
+  if (dtype == KT_F16) {
+    if (mode == 0) launch_gemm_mode<KT_F16, 0>(g, n_tiles, s);
+    else launch_gemm_mode<KT_F16, 1>(g, n_tiles, s);
+  } else {
+    if (mode == 0) launch_gemm_mode<KT_BF16, 0>(g, n_tiles, s);
+    else launch_gemm_mode<KT_BF16, 1>(g, n_tiles, s);
+  }
 }
 
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                             uint32_t n_valid, float *tau_out, hipStream_t s) {
   BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid};
-  hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s) {
   BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries};
-  hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                               uint32_t n_queries, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n,
                               uint32_t k_ld, uint32_t *overflow, hipStream_t s) {
   BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries};
-  hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 }  // namespace rsgpu

@@ -34,6 +34,7 @@ struct ScanTuning {
   int blocks_per_cu = 16;  // 256-thread blocks per CU the grid is sized for (profiles/r01_tune_scan_*.json)
   int rows_per_group = 0;  // 0 = per-shape default (U in the kernel)
   int nontemporal = 1;     // stream the corpus with nt loads
+  int gemm_dma = 1;        // batched path: LDS-DMA ring kernel (0 = register-staged kernel)
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();

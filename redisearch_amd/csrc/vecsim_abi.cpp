@@ -531,6 +531,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   if (!strcmp(key, "blocks_per_cu")) scan_tuning().blocks_per_cu = value;
   else if (!strcmp(key, "rows_per_group")) scan_tuning().rows_per_group = value;
   else if (!strcmp(key, "nontemporal")) scan_tuning().nontemporal = value;
+  else if (!strcmp(key, "gemm_dma")) scan_tuning().gemm_dma = value;
   else return -1;
   return 0;
 }

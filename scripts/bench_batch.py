@@ -18,6 +18,7 @@ reps = int(os.environ.get("REPS", 12))
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 lib = V.load()
+lib.RSGPU_SetTuning(b"gemm_dma", int(os.environ.get("GEMM_DMA", "1")))
 idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
 idx.reserve(rows)
 gen = torch.Generator(device=dev)
@@ -42,7 +43,7 @@ lib.RSGPU_SetProfiling(0)
 launches, ms, by = V.scan_profile()
 dev_ms = ms / launches
 flops = 2.0 * batch * dim * rows
-out = {"config": "%dx%d fp16 FLAT IP top-%d, batch=%d (MFMA GEMM path)" % (rows, dim, k, batch),
+out = {"gemm_dma": int(os.environ.get("GEMM_DMA", "1")), "config": "%dx%d fp16 FLAT IP top-%d, batch=%d (MFMA GEMM path)" % (rows, dim, k, batch),
        "batches_per_s_wall": reps / el, "qps_wall": reps * batch / el, "ms_per_batch_wall": el / reps * 1e3,
        "device_ms_per_batch": dev_ms, "qps_device": batch / dev_ms * 1e3,
        "hbm_algorithmic_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac_of_8TBs": rows * dim * 2 / dev_ms / 1e6 / 8000,
@@ -54,5 +55,5 @@ for i in (0, 128, 255):
     assert same >= k - 2 and np.allclose(np.sort(sc[i]), np.sort(ss), atol=2e-3), (i, same)
 out["parity_spot_check"] = "3 queries vs single-query path: top-%d overlap >= %d, distances within 2e-3" % (k, k - 2)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/batch_bench.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/batch_bench_dma%s.json" % os.environ.get("GEMM_DMA", "1"), "w"), indent=1)
 print(json.dumps(out))
