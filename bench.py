@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--tuning", action="append", default=[], help="engine knob key=value (A/B experiments only)")
     return ap.parse_args()
 
 
@@ -99,6 +100,9 @@ def main():
 
     from redisearch_amd import vecsim as V
     lib = V.load()
+    for kv in a.tuning:
+        key, val = kv.split("=")
+        assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
 
     # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
     rows, dim, k = a.rows, a.dim, a.k

@@ -182,13 +182,18 @@ QueryCtx::QueryCtx(int dev) : device(dev) {
   dev_realloc(d_hist, 0, kSelectLevelsMax * 256);
   dev_realloc(d_counters, 0, 4);
   dev_realloc(d_bound, 0, 2);
+  dev_realloc(d_tau, 0, 1);
+  dev_realloc(d_cand, 0, kCandCap);
+  dev_realloc(d_fcnt, 0, 4);
+  pin_realloc(h_fcnt, 4);
   pin_realloc(h_counters, 16);
 }
 #define HIP_IGNORE(x) (void)(x)
 QueryCtx::~QueryCtx() {
   HIP_IGNORE(hipSetDevice(device));
   HIP_IGNORE(hipStreamSynchronize(stream));
-  void *dev[] = {d_query, d_keys, d_hist, d_counters, d_bound, d_out_rows, d_out_keys, d_ids, d_dists};
+  void *dev[] = {d_query, d_keys, d_hist, d_counters, d_bound, d_out_rows, d_out_keys, d_ids, d_dists, d_tau, d_cand, d_fcnt};
+  if (h_fcnt) HIP_IGNORE(hipHostFree(h_fcnt));
   void *pin[] = {h_query, h_out_rows, h_out_keys, h_counters, h_ids, h_dists};
   for (void *p : dev) if (p) HIP_IGNORE(hipFree(p));
   for (void *p : pin) if (p) HIP_IGNORE(hipHostFree(p));
@@ -578,7 +583,39 @@ void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, ui
   }
 }
 
+// Small-K fast path: K-th smallest group minimum of a spread key sample bounds the answer (tau), one streaming pass
+// keeps the keys <= tau, a single workgroup selects the exact K among them (select_kernels.hip
+// "threshold filter").  ~40 us after the scan instead of ~110 us for the four histogram levels.
+static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
+  // tau = k-th smallest of 1024 group minima over a 64 Ki (k <= 32) or 256 Ki key sample: its rank in
+  // the whole array is ~ k * n / sample, far below kCandCap
+  const uint32_t per = k <= 32 ? 64 : 256;
+  c->ensure_out(k);
+  HIP_CHECK(hipMemsetAsync(c->d_fcnt, 0, 4 * sizeof(uint32_t), c->stream));
+  launch_sample_threshold(c->d_keys, n, per, k, c->d_tau, c->stream);
+  launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
+  launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->d_out_rows, (uint32_t *)c->d_out_keys,
+                           c->d_fcnt + 2, k, c->d_fcnt + 1, c->stream);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(c->h_fcnt, c->d_fcnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  if (c->h_fcnt[1] || c->h_fcnt[0] > QueryCtx::kCandCap) return false;  // candidate overflow: radix path
+  const uint32_t got = std::min<uint32_t>(c->h_fcnt[2], k);
+  if (got < std::min<uint32_t>(k, n)) return false;  // cannot happen (tau is an upper bound); be safe
+  const uint32_t *k32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
+  out.resize(got);
+  for (uint32_t i = 0; i < got; i++) out[i] = Hit{c->h_out_rows[i], (uint64_t)k32[i]};
+  std::sort(out.begin(), out.end(), [](const Hit &a, const Hit &b) { return a.key != b.key ? a.key < b.key : a.row < b.row; });
+  return true;
+}
+
 void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper) {
+  if (!lower.valid && !upper && k > 0 && k <= 128 && n >= (1u << 18) && scan_tuning().filter_select) {
+    if (filter_select(c, n, k, out)) return;
+  }
   radix_select(c, c->d_keys, 4, n, k, lower, out, upper);
 }
 

@@ -58,6 +58,13 @@ struct QueryCtx {
   uint32_t *d_ids = nullptr, *h_ids = nullptr;
   float *d_dists = nullptr, *h_dists = nullptr;
   size_t gather_cap = 0;
+  // threshold-filter select (small K): tau, candidate list (row,key), its counter / overflow flag /
+  // winner count, and their pinned mirror [0]=out_n [1]=overflow [2]=cand_count
+  static constexpr uint32_t kCandCap = 1u << 16;
+  float *d_tau = nullptr;
+  uint64_t *d_cand = nullptr;
+  uint32_t *d_fcnt = nullptr;  // [0] cand_count [1] overflow [2] out_n
+  uint32_t *h_fcnt = nullptr;
   // scan profiling (events read back after the query's own sync)
   bool prof_pending = false;
   uint32_t prof_rows = 0;

@@ -330,6 +330,7 @@ struct BatchSel {
   uint32_t k_ld;
   uint32_t *overflow;  // [q] set when a candidate list overflowed
   uint32_t n_valid;    // queries >= n_valid are padding: tau = -inf so that they never collect candidates
+  uint32_t stride;     // PAIRS=false: element i is keys[q*ld + i*stride] (strided sample of a key array)
 };
 
 template <bool PAIRS>
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
       uint2 e = s.cand[(size_t)q * s.cand_cap + i];
       return ((u64)e.y << 32) | e.x;
     }
-    return ((u64)s.keys[(size_t)q * s.ld + i] << 32) | i;
+    return ((u64)s.keys[(size_t)q * s.ld + (size_t)i * s.stride] << 32) | i;
   };
   const bool take_all = (k == n);
   for (int p = 0; p < 8 && !sh_exact; p++) {
@@ -480,21 +481,21 @@ void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t
 }
 
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
-                            uint32_t n_valid, float *tau_out, hipStream_t s) {
-  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid};
+                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride) {
+  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid, stride};
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s) {
-  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries};
+  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries, 1};
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                               uint32_t n_queries, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n,
                               uint32_t k_ld, uint32_t *overflow, hipStream_t s) {
-  BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries};
+  BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries, 1};
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 

@@ -34,7 +34,8 @@ struct ScanTuning {
   int blocks_per_cu = 16;  // 256-thread blocks per CU the grid is sized for (profiles/r01_tune_scan_*.json)
   int rows_per_group = 0;  // 0 = per-shape default (U in the kernel)
   int nontemporal = 1;     // stream the corpus with nt loads
-  int gemm_dma = 1;        // batched path: LDS-DMA ring kernel (0 = register-staged kernel)
+  int gemm_dma = 1;        // batched path: 1 LDS-DMA ring KC=8 (default), 0 register-staged, 2/3 experiments
+  int filter_select = 1;   // small-K top-K: sample threshold + one filter pass (0 = radix levels only)
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();
@@ -80,8 +81,17 @@ void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t
                       uint32_t row_end, int mode, uint32_t *keys_out, uint32_t keys_ld, const float *tau,
                       uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s);
 // per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
+// (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
-                            uint32_t n_valid, float *tau_out, hipStream_t s);
+                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1);
+// tau_out[0] = upper bound of the k-th smallest key (k <= 1024) of keys[0..n): k-th smallest of the minima
+// of 1024 evenly spread groups of `per` consecutive keys (per % 4 == 0, n >= 1024*per)
+void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
+                             hipStream_t s);
+// candidates of a single key array: append (row,key) of every key <= orderable(*tau) to cand[0..cap),
+// counting in cand_count[0]
+void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
+                        uint32_t cap, hipStream_t s);
 // per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);

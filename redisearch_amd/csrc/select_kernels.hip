@@ -282,6 +282,80 @@ __global__ __launch_bounds__(256) void range_kernel(const uint32_t *__restrict__
   }
 }
 
+// ---- threshold filter --------------------------------------------------------------------------------
+// The fast top-K path for small K: a per-query upper bound tau of the K-th distance (K-th smallest of a
+// strided sample, gemm_kernels.hip batch_select_kernel) turns the selection into ONE streaming pass that
+// keeps the few keys <= tau, followed by a single-workgroup exact select of those candidates -- instead
+// of four histogram passes over all keys.  tau is a true upper bound, so the result is exact; only an
+// adversarial order can overflow the candidate buffer, and then the radix path above takes over.
+__device__ __forceinline__ uint32_t f2key_dev(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// tau = K-th smallest of 1024 group minima, group t = PER consecutive keys starting at t*seg_stride
+// (1024 segments spread evenly over the key array: coalesced to read, robust to sorted corpora).
+// K distinct keys are <= tau, so tau bounds the K-th smallest key of the whole array.  One workgroup.
+__global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                                uint32_t seg_stride, uint32_t per, uint32_t k,
+                                                                float *__restrict__ tau_out) {
+  __shared__ uint32_t mins[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t beg = t * seg_stride;
+  uint32_t m = 0xFFFFFFFFu;
+  for (uint32_t i = 0; i < per; i += 4) {  // beg and per are multiples of 4: aligned 16-byte loads
+    const uint32_t idx = beg + i;
+    if (idx + 3 < n) {
+      u4 v = *(const u4 *)(keys + idx);
+      uint32_t a = v.x < v.y ? v.x : v.y, b = v.z < v.w ? v.z : v.w;
+      a = a < b ? a : b;
+      m = m < a ? m : a;
+    } else {
+      for (uint32_t j = idx; j < n && j < idx + 4; j++) m = m < keys[j] ? m : keys[j];
+    }
+  }
+  mins[t] = m;
+  __syncthreads();
+  // rank of this group's minimum among the 1024 (ties by group index): the one of rank k-1 is tau
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < 1024; j++) {
+    const uint32_t o = mins[j];
+    rank += (o < m || (o == m && j < t)) ? 1u : 0u;
+  }
+  if (rank == k - 1) {
+    const uint32_t u = (m & 0x80000000u) ? (m ^ 0x80000000u) : ~m;
+    tau_out[0] = __uint_as_float(u);
+  }
+}
+
+__global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
+                                                          const float *__restrict__ tau, uint2 *__restrict__ cand,
+                                                          uint32_t *__restrict__ cand_count, uint32_t cap) {
+  const uint32_t max_key = f2key_dev(tau[0]);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n4 = (n + 3) / 4;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n4 + 255) / 256) * 256; i += gridDim.x * 256) {
+    u64 kk[4];
+    load4<uint32_t>(keys, n, i, i < n4, kk);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t row = i * 4 + j;
+      const bool take = (i < n4) && (row < n) && ((uint32_t)kk[j] <= max_key);
+      u64 m = __ballot(take);
+      if (m) {
+        int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(cand_count, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (take) {
+          uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          if (slot < cap) cand[slot] = make_uint2(row, (uint32_t)kk[j]);
+        }
+      }
+    }
+  }
+}
+
 inline uint32_t pass_grid(uint32_t n) {
   uint32_t need = ((n + 3) / 4 + 255) / 256;
   uint32_t cap = (uint32_t)scan_tuning().num_cus * 4;
@@ -311,6 +385,19 @@ void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int pass
     hipLaunchKernelGGL(select_collect_kernel<uint32_t>, dim3(pass_grid(n)), dim3(256), 0, s, (const uint32_t *)keys,
                        n, passes_done, k, (u64)lkey, lrow, has_lower, b.hist, b.counters, b.out_rows,
                        (uint32_t *)b.out_keys, (u64 *)b.bound, cap);
+}
+
+void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
+                             hipStream_t s) {
+  uint32_t seg_stride = (n / 1024) & ~3u;  // caller guarantees n >= 1024 * per
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(1024), 0, s, keys, n, seg_stride, per, k, tau_out);
+}
+
+void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
+                        uint32_t cap, hipStream_t s) {
+  uint32_t need = ((n + 3) / 4 + 255) / 256, cap_g = (uint32_t)scan_tuning().num_cus * 8;
+  uint32_t g = need < cap_g ? need : cap_g;
+  hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap);
 }
 
 void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,
