@@ -159,7 +159,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         // reply order: (score, label) ascending
         std::vector<VecSimQueryResult> res(got);
         for (uint32_t j = 0; j < got; j++)
-          res[j] = VecSimQueryResult{(size_t)row_label_[hits[j].row], (double)key_to_dist((uint32_t)hits[j].key)};
+          res[j] = VecSimQueryResult{(size_t)row_label_[hits[j].row], score_of(hits[j].key)};
         std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
           return a.score != b.score ? a.score < b.score : a.id < b.id;
         });

@@ -228,9 +228,9 @@ void QueryCtx::ensure_gather(size_t m) {
   if (m <= gather_cap) return;
   size_t cap = round_up(m + m / 2 + 256, 256);
   dev_realloc(d_ids, gather_cap, cap);
-  dev_realloc(d_dists, gather_cap, cap);
+  dev_realloc(d_dists, 2 * gather_cap, 2 * cap);  // fp32 distances, or fp64 for FLOAT64 indexes
   pin_realloc(h_ids, cap);
-  pin_realloc(h_dists, cap);
+  pin_realloc(h_dists, 2 * cap);
   gather_cap = cap;
 }
 
@@ -270,7 +270,9 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     : type(p.type), metric(p.metric), dim(p.dim), multi(p.multi),
       block_size(p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE), log_ctx(lctx) {
   ktype = (int)type;
-  kmetric = metric == VecSimMetric_L2 ? KM_L2 : KM_IP;
+  const bool int_type = type == VecSimType_INT8 || type == VecSimType_UINT8;
+  kmetric = metric == VecSimMetric_L2 ? KM_L2 : (metric == VecSimMetric_Cosine && int_type) ? KM_COS : KM_IP;
+  key_bytes = key_bytes_of(ktype);
   elem_bytes_ = dim * type_size(type);
   stride_ = round_up(elem_bytes_, 16);
   uid = g_uid++;
@@ -330,7 +332,12 @@ void FlatIndex::reserve(size_t rows) {
   grow(rows);
 }
 
-void FlatIndex::normalize_host(void *blob) const { normalize_blob(blob, dim, type); }
+// cosine rows/queries are stored normalised -- except INT8/UINT8, whose elements cannot carry a norm
+// (the scan divides by |x| and |q| instead, kernels.hpp KM_COS)
+void FlatIndex::normalize_host(void *blob) const {
+  if (type == VecSimType_INT8 || type == VecSimType_UINT8) return;
+  normalize_blob(blob, dim, type);
+}
 
 void FlatIndex::break_identity() {
   if (!identity_) return;
@@ -463,7 +470,7 @@ int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_labe
     HIP_CHECK(hipMemsetAsync(dst, 0, n * stride_, wstream_));
     HIP_CHECK(hipMemcpy2DAsync(dst, stride_, dev_rows, elem_bytes_, elem_bytes_, n, hipMemcpyDeviceToDevice, wstream_));
   }
-  if (metric == VecSimMetric_Cosine)
+  if (metric == VecSimMetric_Cosine && kmetric == KM_IP)
     launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
   size_t old = row_label_.size();
   row_label_.resize(old + n);
@@ -509,12 +516,26 @@ void FlatIndex::upload_query(QueryCtx *c, const void *blob, bool normalize) {
   memset(c->h_query, 0, stride_);
   memcpy(c->h_query, blob, elem_bytes_);
   if (normalize && metric == VecSimMetric_Cosine) normalize_host(c->h_query);
-  HIP_CHECK(hipMemcpyAsync(c->d_query, c->h_query, stride_, hipMemcpyHostToDevice, c->stream));
+  size_t bytes = stride_;
+  if (type == VecSimType_INT8 || type == VecSimType_UINT8) {
+    // one more chunk behind the padded query: {sum q^2 as i32/u32, |q| as f32, 0, 0}
+    long long qq = 0;
+    for (size_t i = 0; i < dim; i++) {
+      int a = type == VecSimType_INT8 ? (int)((const int8_t *)blob)[i] : (int)((const uint8_t *)blob)[i];
+      qq += (long long)a * a;
+    }
+    uint32_t extra[4] = {(uint32_t)qq, 0, 0, 0};
+    float qn = sqrtf((float)qq);
+    memcpy(&extra[1], &qn, 4);
+    memcpy(c->h_query + stride_, extra, 16);
+    bytes += 16;
+  }
+  HIP_CHECK(hipMemcpyAsync(c->d_query, c->h_query, bytes, hipMemcpyHostToDevice, c->stream));
   c->cached_query_owner = 0;
 }
 
 void FlatIndex::scan_all(QueryCtx *c, uint32_t n) {
-  c->ensure_keys(n);
+  c->ensure_keys((size_t)n * (key_bytes / 4));
   const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
   // profiling brackets the scan launch with events on ITS stream; they are read back after the
   // query's own stream synchronisation (collect_profile), so the timed path gains no extra sync
@@ -613,10 +634,10 @@ static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> 
 }
 
 void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper) {
-  if (!lower.valid && !upper && k > 0 && k <= 128 && n >= (1u << 18) && scan_tuning().filter_select) {
+  if (key_bytes == 4 && !lower.valid && !upper && k > 0 && k <= 128 && n >= (1u << 18) && scan_tuning().filter_select) {
     if (filter_select(c, n, k, out)) return;
   }
-  radix_select(c, c->d_keys, 4, n, k, lower, out, upper);
+  radix_select(c, c->d_keys, key_bytes, n, k, lower, out, upper);
 }
 
 static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
@@ -648,7 +669,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     select(c.c, n, kk, Bound(), hits, nullptr);
     if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
     res.reserve(hits.size());
-    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], (double)key_to_dist((uint32_t)h.key)});
+    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], score_of(h.key)});
   } else {
     // multi-value: walk batches in ascending composite order, first occurrence of a label is its best
     std::unordered_map<uint64_t, char> seen;
@@ -664,7 +685,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
       for (const Hit &h : hits) {
         uint64_t lab = row_label_[h.row];
         if (res.size() < want && seen.emplace(lab, 1).second)
-          res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist((uint32_t)h.key)});
+          res.push_back(VecSimQueryResult{(size_t)lab, score_of(h.key)});
       }
       lower = bound;
       if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
@@ -689,11 +710,16 @@ VecSimQueryReply *FlatIndex::range(const void *query, double radius, VecSimQuery
   upload_query(c.c, query, true);
   scan_all(c.c, n);
   // largest fp32 value whose widening is <= radius: `(double)dist <= radius`, inclusive (App. B-12)
-  float fr = (float)radius;
-  if ((double)fr > radius) fr = std::nextafterf(fr, -INFINITY);
-  uint32_t max_key = dist_to_key(fr);
+  uint64_t max_key;
+  if (key_bytes == 8) {
+    max_key = dist64_to_key(radius);
+  } else {
+    float fr = (float)radius;
+    if ((double)fr > radius) fr = std::nextafterf(fr, -INFINITY);
+    max_key = dist_to_key(fr);
+  }
   HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
-  launch_range(c->d_keys, n, max_key, 0, c->d_counters, nullptr, nullptr, 0, c->stream);
+  launch_range(c->d_keys, key_bytes, n, max_key, 0, c->d_counters, nullptr, nullptr, 0, c->stream);
   HIP_CHECK(hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   collect_profile(c.c);
@@ -702,21 +728,23 @@ VecSimQueryReply *FlatIndex::range(const void *query, double radius, VecSimQuery
   if (!cnt) return new_reply(0, VecSim_QueryReply_OK);
   c->ensure_out(cnt);
   HIP_CHECK(hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
-  launch_range(c->d_keys, n, max_key, 1, c->d_counters, c->d_out_rows, (uint32_t *)c->d_out_keys, (uint32_t)c->out_cap, c->stream);
+  launch_range(c->d_keys, key_bytes, n, max_key, 1, c->d_counters, c->d_out_rows, c->d_out_keys, (uint32_t)c->out_cap, c->stream);
   HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, (size_t)cnt * key_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   std::vector<VecSimQueryResult> res;
   res.reserve(cnt);
   const uint32_t *rk32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
+  const uint64_t *rk64 = c->h_out_keys;
+  auto range_score = [&](uint32_t i) { return key_bytes == 8 ? key_to_dist64(rk64[i]) : (double)key_to_dist(rk32[i]); };
   if (!multi) {
     for (uint32_t i = 0; i < cnt; i++)
-      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], (double)key_to_dist(rk32[i])});
+      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], range_score(i)});
   } else {
     std::unordered_map<uint64_t, size_t> best;
     for (uint32_t i = 0; i < cnt; i++) {
       uint64_t lab = row_label_[c->h_out_rows[i]];
-      double d = (double)key_to_dist(rk32[i]);
+      double d = range_score(i);
       auto it = best.find(lab);
       if (it == best.end()) {
         best[lab] = res.size();
@@ -750,12 +778,13 @@ void FlatIndex::gather(QueryCtx *c, const size_t *labels, size_t m, double *out)
   HIP_CHECK(hipMemcpyAsync(c->d_ids, c->h_ids, t * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   launch_gather(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, c->d_ids, (uint32_t)t, c->d_query, c->d_dists, c->stream);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemcpyAsync(c->h_dists, c->d_dists, t * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->h_dists, c->d_dists, t * (size_t)key_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
+  const double *h_d64 = reinterpret_cast<const double *>(c->h_dists);
   for (size_t i = 0; i < m; i++) {
     double best = NAN;
     for (uint32_t j = 0; j < count[i]; j++) {
-      double d = (double)c->h_dists[first[i] + j];
+      double d = key_bytes == 8 ? h_d64[first[i] + j] : (double)c->h_dists[first[i] + j];
       if (std::isnan(best) || d < best) best = d;  // multi-value: minimum over the label's vectors
     }
     out[i] = best;

@@ -73,7 +73,7 @@ struct QueryCtx {
   explicit QueryCtx(int dev);
   ~QueryCtx();
   void ensure_query(size_t bytes);
-  void ensure_keys(size_t rows);
+  void ensure_keys(size_t words);  // u32 words: rows x key_bytes/4
   void ensure_out(size_t k);
   void ensure_gather(size_t m);
   uint64_t *h_bound() { return reinterpret_cast<uint64_t *>(h_counters + 4); }
@@ -177,6 +177,8 @@ class FlatIndex {
   bool multi;
   size_t block_size;
   int ktype, kmetric;
+  int key_bytes;  // 4: fp32 distances / u32 keys, 8: fp64 distances / u64 keys (FLOAT64)
+  double score_of(uint64_t key) const { return key_bytes == 8 ? key_to_dist64(key) : (double)key_to_dist((uint32_t)key); }
   int device;
   uint64_t uid;
   void *log_ctx;

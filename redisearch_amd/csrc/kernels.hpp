@@ -11,9 +11,12 @@
 namespace rsgpu {
 
 // element types served by the scan kernels (values match VecSimType)
-enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3 };
-// kernel metrics: cosine is IP over rows/query normalised up front
-enum : int { KM_L2 = 0, KM_IP = 1 };
+enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3, KT_I8 = 4, KT_U8 = 5 };
+// kernel metrics: for the floating-point types cosine is IP over rows/query normalised up front;
+// INT8/UINT8 rows cannot be normalised in place, their cosine divides by the two norms (KM_COS)
+enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2 };
+// distances (and keys) of FLOAT64 indexes are 8 bytes wide, everything else computes fp32 distances
+inline int key_bytes_of(int type) { return type == KT_F64 ? 8 : 4; }
 
 // Orderable key of an fp32 distance: ascending key <=> ascending distance, NaN last.
 // (host mirror of the device f2key in scan_kernels.hip)
@@ -30,6 +33,19 @@ inline float key_to_dist(uint32_t k) {
   return f;
 }
 
+inline uint64_t dist64_to_key(double f) {
+  uint64_t u;
+  memcpy(&u, &f, 8);
+  if ((u & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) return ~0ull;
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline double key_to_dist64(uint64_t k) {
+  uint64_t u = (k >> 63) ? (k ^ 0x8000000000000000ull) : ~k;
+  double f;
+  memcpy(&f, &u, 8);
+  return f;
+}
+
 struct ScanTuning {
   int blocks_per_cu = 16;  // 256-thread blocks per CU the grid is sized for (profiles/r01_tune_scan_*.json)
   int rows_per_group = 0;  // 0 = per-shape default (U in the kernel)
@@ -40,14 +56,15 @@ struct ScanTuning {
 };
 ScanTuning &scan_tuning();
 
-// Distances of rows [row_begin,row_end) to `query`, written as orderable keys keys[row].
-// rows: row-contiguous, `stride` bytes per row (multiple of 16, zero padded), query padded alike.
+// Distances of rows [row_begin,row_end) to `query`, written as orderable keys keys[row] (u32, or u64
+// for KT_F64).  rows: row-contiguous, `stride` bytes per row (multiple of 16, zero padded), query padded
+// alike; for KT_I8/KT_U8 one more 16-byte chunk follows the padded query: {sum q^2 (i32/u32), |q| (f32)}.
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, uint32_t *keys, hipStream_t s);
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s);
 
-// Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as fp32 values out[i].
+// Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
-                   uint32_t m, const void *query, float *out, hipStream_t s);
+                   uint32_t m, const void *query, void *out, hipStream_t s);
 
 // In-place L2 normalisation of rows [row_begin,row_end) (cosine indexes, bulk device loads).
 void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, uint32_t row_begin, uint32_t row_end,
@@ -102,7 +119,7 @@ void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint
 
 // ---- range query: all rows with key <= max_key ----------------------------------------------------
 // counters[0] receives the count (collect=0) or is used as the append cursor (collect=1).
-void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,
-                  uint32_t *out_rows, uint32_t *out_keys, uint32_t cap, hipStream_t s);
+void launch_range(const void *keys, int key_bytes, uint32_t n, uint64_t max_key, int collect, uint32_t *counters,
+                  uint32_t *out_rows, void *out_keys, uint32_t cap, hipStream_t s);
 
 }  // namespace rsgpu

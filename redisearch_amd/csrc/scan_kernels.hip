@@ -54,30 +54,89 @@ __device__ __forceinline__ u4 load16(const u4 *p) {
   return *p;
 }
 
+// ---- per element type: accumulator, distance and key types ---------------------------------------
+struct I2 {
+  int xq, xx;  // sum x*q and sum x*x (bit patterns of u32 sums for KT_U8)
+};
+template <int TYPE>
+struct Tr {
+  typedef float acc_t;
+  typedef float out_t;
+  typedef uint32_t key_t;
+  static constexpr bool kExtra = false;  // the query carries one more chunk {sum q^2, |q|}
+};
+template <>
+struct Tr<KT_F64> {
+  typedef double acc_t;
+  typedef double out_t;
+  typedef uint64_t key_t;
+  static constexpr bool kExtra = false;
+};
+template <>
+struct Tr<KT_I8> {
+  typedef I2 acc_t;
+  typedef float out_t;
+  typedef uint32_t key_t;
+  static constexpr bool kExtra = true;
+};
+template <>
+struct Tr<KT_U8> : Tr<KT_I8> {};
+
+__device__ __forceinline__ uint64_t d2key(double f) {
+  uint64_t u = (uint64_t)__double_as_longlong(f);
+  if ((u & 0x7fffffffffffffffull) > 0x7ff0000000000000ull) return ~0ull;  // NaN sorts last
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ uint32_t to_key(float f) { return f2key(f); }
+__device__ __forceinline__ uint64_t to_key(double f) { return d2key(f); }
+__device__ __forceinline__ void set_nan(float &f) { f = __uint_as_float(0x7fc00000u); }
+__device__ __forceinline__ void set_nan(double &f) { f = __longlong_as_double(0x7ff8000000000000ll); }
+
 // ---- one 16-byte chunk of a row against the matching query chunk ---------------------------------
 template <int TYPE, int METRIC>
-__device__ __forceinline__ float accumulate(float acc, u4 x, u4 q);
+struct Op;
 
 template <>
-__device__ __forceinline__ float accumulate<KT_F32, KM_IP>(float acc, u4 x, u4 q) {
-  acc = fmaf(__uint_as_float(x.x), __uint_as_float(q.x), acc);
-  acc = fmaf(__uint_as_float(x.y), __uint_as_float(q.y), acc);
-  acc = fmaf(__uint_as_float(x.z), __uint_as_float(q.z), acc);
-  acc = fmaf(__uint_as_float(x.w), __uint_as_float(q.w), acc);
-  return acc;
-}
+struct Op<KT_F32, KM_IP> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    acc = fmaf(__uint_as_float(x.x), __uint_as_float(q.x), acc);
+    acc = fmaf(__uint_as_float(x.y), __uint_as_float(q.y), acc);
+    acc = fmaf(__uint_as_float(x.z), __uint_as_float(q.z), acc);
+    acc = fmaf(__uint_as_float(x.w), __uint_as_float(q.w), acc);
+    return acc;
+  }
+};
 template <>
-__device__ __forceinline__ float accumulate<KT_F32, KM_L2>(float acc, u4 x, u4 q) {
-  float d0 = __uint_as_float(x.x) - __uint_as_float(q.x);
-  float d1 = __uint_as_float(x.y) - __uint_as_float(q.y);
-  float d2 = __uint_as_float(x.z) - __uint_as_float(q.z);
-  float d3 = __uint_as_float(x.w) - __uint_as_float(q.w);
-  acc = fmaf(d0, d0, acc);
-  acc = fmaf(d1, d1, acc);
-  acc = fmaf(d2, d2, acc);
-  acc = fmaf(d3, d3, acc);
-  return acc;
-}
+struct Op<KT_F32, KM_L2> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    float d0 = __uint_as_float(x.x) - __uint_as_float(q.x);
+    float d1 = __uint_as_float(x.y) - __uint_as_float(q.y);
+    float d2 = __uint_as_float(x.z) - __uint_as_float(q.z);
+    float d3 = __uint_as_float(x.w) - __uint_as_float(q.w);
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+    return acc;
+  }
+};
+// fp64: two elements per chunk, fp64 accumulate
+__device__ __forceinline__ double as_d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+template <>
+struct Op<KT_F64, KM_IP> {
+  static __device__ __forceinline__ double add(double acc, u4 x, u4 q) {
+    acc = fma(as_d(x.x, x.y), as_d(q.x, q.y), acc);
+    return fma(as_d(x.z, x.w), as_d(q.z, q.w), acc);
+  }
+};
+template <>
+struct Op<KT_F64, KM_L2> {
+  static __device__ __forceinline__ double add(double acc, u4 x, u4 q) {
+    double d0 = as_d(x.x, x.y) - as_d(q.x, q.y), d1 = as_d(x.z, x.w) - as_d(q.z, q.w);
+    acc = fma(d0, d0, acc);
+    return fma(d1, d1, acc);
+  }
+};
 // fp16: products of two halves are exact in fp32, accumulation is fp32 (v_dot2_f32_f16)
 __device__ __forceinline__ half2_t as_h2(uint32_t u) {
   half2_t h;
@@ -85,13 +144,15 @@ __device__ __forceinline__ half2_t as_h2(uint32_t u) {
   return h;
 }
 template <>
-__device__ __forceinline__ float accumulate<KT_F16, KM_IP>(float acc, u4 x, u4 q) {
-  acc = __builtin_amdgcn_fdot2(as_h2(x.x), as_h2(q.x), acc, false);
-  acc = __builtin_amdgcn_fdot2(as_h2(x.y), as_h2(q.y), acc, false);
-  acc = __builtin_amdgcn_fdot2(as_h2(x.z), as_h2(q.z), acc, false);
-  acc = __builtin_amdgcn_fdot2(as_h2(x.w), as_h2(q.w), acc, false);
-  return acc;
-}
+struct Op<KT_F16, KM_IP> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    acc = __builtin_amdgcn_fdot2(as_h2(x.x), as_h2(q.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_h2(x.y), as_h2(q.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_h2(x.z), as_h2(q.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(as_h2(x.w), as_h2(q.w), acc, false);
+    return acc;
+  }
+};
 __device__ __forceinline__ float l2_h2(float acc, uint32_t a, uint32_t b) {
   half2_t x = as_h2(a), y = as_h2(b);
   float d0 = (float)x.x - (float)y.x, d1 = (float)x.y - (float)y.y;
@@ -99,12 +160,14 @@ __device__ __forceinline__ float l2_h2(float acc, uint32_t a, uint32_t b) {
   return fmaf(d1, d1, acc);
 }
 template <>
-__device__ __forceinline__ float accumulate<KT_F16, KM_L2>(float acc, u4 x, u4 q) {
-  acc = l2_h2(acc, x.x, q.x);
-  acc = l2_h2(acc, x.y, q.y);
-  acc = l2_h2(acc, x.z, q.z);
-  return l2_h2(acc, x.w, q.w);
-}
+struct Op<KT_F16, KM_L2> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    acc = l2_h2(acc, x.x, q.x);
+    acc = l2_h2(acc, x.y, q.y);
+    acc = l2_h2(acc, x.z, q.z);
+    return l2_h2(acc, x.w, q.w);
+  }
+};
 // bf16: widen by shifting into the top half of an fp32
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -118,19 +181,51 @@ __device__ __forceinline__ float l2_bf2(float acc, uint32_t a, uint32_t b) {
   return fmaf(d1, d1, acc);
 }
 template <>
-__device__ __forceinline__ float accumulate<KT_BF16, KM_IP>(float acc, u4 x, u4 q) {
-  acc = ip_bf2(acc, x.x, q.x);
-  acc = ip_bf2(acc, x.y, q.y);
-  acc = ip_bf2(acc, x.z, q.z);
-  return ip_bf2(acc, x.w, q.w);
-}
+struct Op<KT_BF16, KM_IP> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    acc = ip_bf2(acc, x.x, q.x);
+    acc = ip_bf2(acc, x.y, q.y);
+    acc = ip_bf2(acc, x.z, q.z);
+    return ip_bf2(acc, x.w, q.w);
+  }
+};
 template <>
-__device__ __forceinline__ float accumulate<KT_BF16, KM_L2>(float acc, u4 x, u4 q) {
-  acc = l2_bf2(acc, x.x, q.x);
-  acc = l2_bf2(acc, x.y, q.y);
-  acc = l2_bf2(acc, x.z, q.z);
-  return l2_bf2(acc, x.w, q.w);
+struct Op<KT_BF16, KM_L2> {
+  static __device__ __forceinline__ float add(float acc, u4 x, u4 q) {
+    acc = l2_bf2(acc, x.x, q.x);
+    acc = l2_bf2(acc, x.y, q.y);
+    acc = l2_bf2(acc, x.z, q.z);
+    return l2_bf2(acc, x.w, q.w);
+  }
+};
+// int8 / uint8: exact integer sums on the packed dot-product units (v_dot4_i32_i8 / v_dot4_u32_u8),
+// 16 elements per chunk.  L2 = sum x^2 + sum q^2 - 2 sum xq needs sum x^2 next to the dot, cosine needs
+// it for |x|; plain IP does not.
+template <int TYPE>
+__device__ __forceinline__ int dot4(uint32_t a, uint32_t b, int c) {
+  if (TYPE == KT_I8) return __builtin_amdgcn_sdot4((int)a, (int)b, c, false);
+  return (int)__builtin_amdgcn_udot4(a, b, (uint32_t)c, false);
 }
+template <int TYPE, int METRIC>
+struct OpInt {
+  static __device__ __forceinline__ I2 add(I2 acc, u4 x, u4 q) {
+    acc.xq = dot4<TYPE>(x.x, q.x, acc.xq);
+    acc.xq = dot4<TYPE>(x.y, q.y, acc.xq);
+    acc.xq = dot4<TYPE>(x.z, q.z, acc.xq);
+    acc.xq = dot4<TYPE>(x.w, q.w, acc.xq);
+    if (METRIC != KM_IP) {
+      acc.xx = dot4<TYPE>(x.x, x.x, acc.xx);
+      acc.xx = dot4<TYPE>(x.y, x.y, acc.xx);
+      acc.xx = dot4<TYPE>(x.z, x.z, acc.xx);
+      acc.xx = dot4<TYPE>(x.w, x.w, acc.xx);
+    }
+    return acc;
+  }
+};
+template <int METRIC>
+struct Op<KT_I8, METRIC> : OpInt<KT_I8, METRIC> {};
+template <int METRIC>
+struct Op<KT_U8, METRIC> : OpInt<KT_U8, METRIC> {};
 
 template <int G>
 __device__ __forceinline__ float group_reduce(float v) {
@@ -138,10 +233,40 @@ __device__ __forceinline__ float group_reduce(float v) {
   for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
+template <int G>
+__device__ __forceinline__ double group_reduce(double v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+template <int G>
+__device__ __forceinline__ I2 group_reduce(I2 v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) {
+    v.xq += __shfl_xor(v.xq, m, 64);
+    v.xx += __shfl_xor(v.xx, m, 64);
+  }
+  return v;
+}
 
-template <int METRIC>
-__device__ __forceinline__ float finish(float acc) {
+// reduced sums -> distance.  qx: the extra query chunk of the integer types {sum q^2, |q| as f32 bits}
+template <int TYPE, int METRIC>
+__device__ __forceinline__ float finish(float acc, u4) {
   return METRIC == KM_IP ? 1.0f - acc : acc;
+}
+template <int TYPE, int METRIC>
+__device__ __forceinline__ double finish(double acc, u4) {
+  return METRIC == KM_IP ? 1.0 - acc : acc;
+}
+template <int TYPE, int METRIC>
+__device__ __forceinline__ float finish(I2 acc, u4 qx) {
+  // the integer value is exact (|.| < 2^63); it becomes a float once, as in `float(res)` of the scalar loop
+  const long long xq = TYPE == KT_I8 ? (long long)acc.xq : (long long)(uint32_t)acc.xq;
+  const long long xx = TYPE == KT_I8 ? (long long)acc.xx : (long long)(uint32_t)acc.xx;
+  const long long qq = TYPE == KT_I8 ? (long long)(int)qx.x : (long long)qx.x;
+  if (METRIC == KM_L2) return (float)(xx + qq - 2 * xq);
+  if (METRIC == KM_IP) return 1.0f - (float)xq;
+  return 1.0f - (float)xq / (sqrtf((float)xx) * __uint_as_float(qx.y));
 }
 
 // ---- the scan -------------------------------------------------------------------------------------
@@ -153,7 +278,10 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
                                                    uint32_t chunks, uint32_t row_begin, uint32_t row_end,
                                                    const u4 *__restrict__ query,
                                                    const uint32_t *__restrict__ row_ids,
-                                                   uint32_t *__restrict__ keys, float *__restrict__ dists) {
+                                                   typename Tr<TYPE>::key_t *__restrict__ keys,
+                                                   typename Tr<TYPE>::out_t *__restrict__ dists) {
+  typedef typename Tr<TYPE>::acc_t acc_t;
+  typedef typename Tr<TYPE>::out_t out_t;
   constexpr int GPB = 256 / G;  // groups per block
   const uint32_t lane = threadIdx.x % G;
   const uint32_t grp = threadIdx.x / G;
@@ -164,6 +292,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
     uint32_t c = lane + i * G;
     q[i] = (EXACT || c < chunks) ? query[c] : zero4();
   }
+  const u4 qx = Tr<TYPE>::kExtra ? query[chunks] : zero4();
 
   // Row <-> group mapping.  G == 64: a wavefront owns U consecutive rows (one 1 KiB request per
   // chunk, one coalesced U-key store).  G < 64: the block owns GPB*U consecutive rows and row
@@ -197,15 +326,14 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
         x[u][i] = (EXACT || c < chunks) ? load16<NT>(p + c) : zero4();
       }
     }
-    float acc[U];
+    out_t d[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      acc[u] = 0.0f;
+      acc_t acc = acc_t();
 #pragma unroll
-      for (int i = 0; i < ITERS; i++) acc[u] = accumulate<TYPE, METRIC>(acc[u], x[u][i], q[i]);
+      for (int i = 0; i < ITERS; i++) acc = Op<TYPE, METRIC>::add(acc, x[u][i], q[i]);
+      d[u] = finish<TYPE, METRIC>(group_reduce<G>(acc), qx);
     }
-#pragma unroll
-    for (int u = 0; u < U; u++) acc[u] = group_reduce<G>(acc[u]);
 
     if (INTERLEAVE) {
       if (lane == 0) {
@@ -213,33 +341,40 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
         for (int u = 0; u < U; u++) {
           uint32_t r = r0 + u * u_stride;
           if (r < row_end) {
-            float d = finish<METRIC>(acc[u]);
-            if (GATHER)
-              dists[r] = (rid[u] == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
-            else
-              keys[r] = f2key(d);
+            out_t v = d[u];
+            if (GATHER) {
+              if (rid[u] == 0xFFFFFFFFu) set_nan(v);
+              dists[r] = v;
+            } else {
+              keys[r] = to_key(v);
+            }
           }
         }
       }
     } else {
       // lane u of the wavefront stores row r0+u
-      float mine = acc[0];
+      out_t mine = d[0];
       uint32_t my_rid = GATHER ? rid[0] : 0;
 #pragma unroll
       for (int u = 1; u < U; u++) {
-        mine = (lane == (uint32_t)u) ? acc[u] : mine;
+        mine = (lane == (uint32_t)u) ? d[u] : mine;
         if (GATHER) my_rid = (lane == (uint32_t)u) ? rid[u] : my_rid;
       }
       if (lane < (uint32_t)U && r0 + lane < row_end) {
-        float d = finish<METRIC>(mine);
-        if (GATHER)
-          dists[r0 + lane] = (my_rid == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
-        else
-          keys[r0 + lane] = f2key(d);
+        if (GATHER) {
+          if (my_rid == 0xFFFFFFFFu) set_nan(mine);
+          dists[r0 + lane] = mine;
+        } else {
+          keys[r0 + lane] = to_key(mine);
+        }
       }
     }
   }
 }
+
+__device__ __forceinline__ float acc_sum(float a, float b) { return a + b; }
+__device__ __forceinline__ double acc_sum(double a, double b) { return a + b; }
+__device__ __forceinline__ I2 acc_sum(I2 a, I2 b) { return I2{a.xq + b.xq, a.xx + b.xx}; }
 
 // Fallback for very long rows (more than 512 chunks = 8 KiB): one wavefront per row, runtime loop,
 // query re-read through L1/L2 (it is tiny next to the corpus).
@@ -248,9 +383,12 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const u4 *__restrict__ r
                                                         uint32_t chunks, uint32_t row_begin, uint32_t row_end,
                                                         const u4 *__restrict__ query,
                                                         const uint32_t *__restrict__ row_ids,
-                                                        uint32_t *__restrict__ keys, float *__restrict__ dists) {
+                                                        typename Tr<TYPE>::key_t *__restrict__ keys,
+                                                        typename Tr<TYPE>::out_t *__restrict__ dists) {
+  typedef typename Tr<TYPE>::acc_t acc_t;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = gridDim.x * 4;
+  const u4 qx = Tr<TYPE>::kExtra ? query[chunks] : zero4();
   for (uint32_t t = blockIdx.x * 4 + wave; t < row_end - row_begin; t += total) {
     uint32_t r = row_begin + t, rid = 0;
     if (GATHER) {
@@ -258,20 +396,22 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const u4 *__restrict__ r
       r = rid == 0xFFFFFFFFu ? 0 : rid;
     }
     const u4 *p = rows + (size_t)r * stride16;
-    float a0 = 0.f, a1 = 0.f;
+    acc_t a0 = acc_t(), a1 = acc_t();
     uint32_t c = lane;
     for (; c + 64 < chunks; c += 128) {
       u4 x0 = load16<NT>(p + c), x1 = load16<NT>(p + c + 64);
-      a0 = accumulate<TYPE, METRIC>(a0, x0, query[c]);
-      a1 = accumulate<TYPE, METRIC>(a1, x1, query[c + 64]);
+      a0 = Op<TYPE, METRIC>::add(a0, x0, query[c]);
+      a1 = Op<TYPE, METRIC>::add(a1, x1, query[c + 64]);
     }
-    if (c < chunks) a0 = accumulate<TYPE, METRIC>(a0, load16<NT>(p + c), query[c]);
-    float d = finish<METRIC>(group_reduce<64>(a0 + a1));
+    if (c < chunks) a0 = Op<TYPE, METRIC>::add(a0, load16<NT>(p + c), query[c]);
+    typename Tr<TYPE>::out_t d = finish<TYPE, METRIC>(group_reduce<64>(acc_sum(a0, a1)), qx);
     if (lane == 0) {
-      if (GATHER)
-        dists[row_begin + t] = (rid == 0xFFFFFFFFu) ? __uint_as_float(0x7fc00000u) : d;
-      else
-        keys[r] = f2key(d);
+      if (GATHER) {
+        if (rid == 0xFFFFFFFFu) set_nan(d);
+        dists[row_begin + t] = d;
+      } else {
+        keys[r] = to_key(d);
+      }
     }
   }
 }
@@ -291,8 +431,8 @@ struct LaunchCtx {
   uint32_t stride16, chunks, row_begin, row_end;
   const u4 *query;
   const uint32_t *row_ids;
-  uint32_t *keys;
-  float *dists;
+  void *keys;
+  void *dists;
   hipStream_t s;
 };
 
@@ -306,14 +446,19 @@ void launch_one(const LaunchCtx &c) {
   uint32_t grid = need < cap ? need : cap;
   if (grid == 0) return;
   bool exact = c.chunks == (uint32_t)(G * ITERS);
-  bool nt = t.nontemporal != 0;
+  // the nontemporal knob is an fp32 A/B experiment; every other type always streams with nt loads
+  bool nt = TYPE != KT_F32 || t.nontemporal != 0;
+  typename Tr<TYPE>::key_t *keys = (typename Tr<TYPE>::key_t *)c.keys;
+  typename Tr<TYPE>::out_t *dists = (typename Tr<TYPE>::out_t *)c.dists;
 #define RSGPU_LAUNCH(EX, NTV)                                                                              \
   hipLaunchKernelGGL((scan_kernel<TYPE, METRIC, G, ITERS, U, EX, NTV, GATHER>), dim3(grid), dim3(256), 0, c.s, \
-                     c.rows, c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists)
+                     c.rows, c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, keys, dists)
   if (exact) {
-    if (nt) RSGPU_LAUNCH(true, true); else RSGPU_LAUNCH(true, false);
+    if (nt) RSGPU_LAUNCH(true, true);
+    else if (TYPE == KT_F32) RSGPU_LAUNCH(true, TYPE != KT_F32);
   } else {
-    if (nt) RSGPU_LAUNCH(false, true); else RSGPU_LAUNCH(false, false);
+    if (nt) RSGPU_LAUNCH(false, true);
+    else if (TYPE == KT_F32) RSGPU_LAUNCH(false, TYPE != KT_F32);
   }
 #undef RSGPU_LAUNCH
 }
@@ -328,12 +473,9 @@ void launch_shape(const LaunchCtx &c) {
     uint32_t need = (n + 3) / 4, cap = (uint32_t)(t.num_cus * t.blocks_per_cu);
     uint32_t grid = need < cap ? need : cap;
     if (!grid) return;
-    if (t.nontemporal)
-      hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, true, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
-                         c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists);
-    else
-      hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, false, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
-                         c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, c.keys, c.dists);
+    hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, true, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
+                       c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids,
+                       (typename Tr<TYPE>::key_t *)c.keys, (typename Tr<TYPE>::out_t *)c.dists);
     return;
   }
   if (sh.ITERS == 1) {
@@ -369,13 +511,23 @@ void dispatch(int type, int metric, const LaunchCtx &c) {
     if (metric == KM_L2) launch_shape<T, KM_L2, GATHER>(c);         \
     else launch_shape<T, KM_IP, GATHER>(c);                         \
     break;
+#define RSGPU_CASE_INT(T)                                           \
+  case T:                                                           \
+    if (metric == KM_L2) launch_shape<T, KM_L2, GATHER>(c);         \
+    else if (metric == KM_IP) launch_shape<T, KM_IP, GATHER>(c);    \
+    else launch_shape<T, KM_COS, GATHER>(c);                        \
+    break;
   switch (type) {
     RSGPU_CASE(KT_F32)
+    RSGPU_CASE(KT_F64)
     RSGPU_CASE(KT_F16)
     RSGPU_CASE(KT_BF16)
+    RSGPU_CASE_INT(KT_I8)
+    RSGPU_CASE_INT(KT_U8)
     default: break;
   }
 #undef RSGPU_CASE
+#undef RSGPU_CASE_INT
 }
 
 // ---- row normalisation (cosine indexes, device bulk loads) -----------------------------------------
@@ -386,12 +538,24 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(u4 *rows, uint32_t 
   const uint32_t total = gridDim.x * 4;
   for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += total) {
     u4 *p = rows + (size_t)r * stride16;
-    float a = 0.f;
+    typename Tr<TYPE>::acc_t a = 0;
     for (uint32_t c = lane; c < chunks; c += 64) {
       u4 x = p[c];
-      a = accumulate<TYPE, KM_IP>(a, x, x);
+      a = Op<TYPE, KM_IP>::add(a, x, x);
     }
-    float inv = 1.0f / sqrtf(group_reduce<64>(a));
+    a = group_reduce<64>(a);
+    if (TYPE == KT_F64) {
+      const double n = sqrt((double)a);
+      for (uint32_t c = lane; c < chunks; c += 64) {
+        u4 x = p[c];
+        double v0 = as_d(x.x, x.y) / n, v1 = as_d(x.z, x.w) / n;
+        x = (u4){(uint32_t)__double2loint(v0), (uint32_t)__double2hiint(v0), (uint32_t)__double2loint(v1),
+                 (uint32_t)__double2hiint(v1)};
+        p[c] = x;
+      }
+      continue;
+    }
+    float inv = 1.0f / sqrtf((float)a);
     for (uint32_t c = lane; c < chunks; c += 64) {
       u4 x = p[c];
       uint32_t w[4] = {x.x, x.y, x.z, x.w};
@@ -420,7 +584,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(u4 *rows, uint32_t 
 }  // namespace
 
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, uint32_t *keys, hipStream_t s) {
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s) {
   (void)dim;
   if (row_end <= row_begin) return;
   LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
@@ -429,7 +593,7 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 }
 
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
-                   uint32_t m, const void *query, float *out, hipStream_t s) {
+                   uint32_t m, const void *query, void *out, hipStream_t s) {
   (void)dim;
   if (!m) return;
   LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), 0, m,
@@ -455,7 +619,10 @@ void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, ui
     case KT_BF16:
       hipLaunchKernelGGL(normalize_rows_kernel<KT_BF16>, dim3(grid), dim3(256), 0, s, (u4 *)rows, s16, s16, row_begin, row_end);
       break;
-    default: break;
+    case KT_F64:
+      hipLaunchKernelGGL(normalize_rows_kernel<KT_F64>, dim3(grid), dim3(256), 0, s, (u4 *)rows, s16, s16, row_begin, row_end);
+      break;
+    default: break;  // INT8/UINT8 rows stay as they are (KM_COS divides by the norms)
   }
 }
 

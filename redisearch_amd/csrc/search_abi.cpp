@@ -359,6 +359,7 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   FlatIndex *f = index->flat;
   S_TRY
   if (f->device != h->device) throw std::runtime_error("hits and index live on different devices");
+  if (f->key_bytes != 4) throw std::runtime_error("RSGPU_Hits_KnnRerank: FLOAT64 indexes are served by VecSimIndex_AdhocBfCtx_GetExactDistances");
   f->flush_if_needed();
   std::shared_lock<std::shared_mutex> g(f->mu);
   HIP_CHECK(hipSetDevice(h->device));

@@ -264,15 +264,16 @@ __global__ __launch_bounds__(256) void select_collect_kernel(const KeyT *__restr
 }
 
 // ---- range ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void range_kernel(const uint32_t *__restrict__ keys, uint32_t n, uint32_t max_key,
+template <typename KeyT>
+__global__ __launch_bounds__(256) void range_kernel(const KeyT *__restrict__ keys, uint32_t n, KeyT max_key,
                                                     int collect, uint32_t *__restrict__ counters,
-                                                    uint32_t *__restrict__ out_rows, uint32_t *__restrict__ out_keys,
+                                                    uint32_t *__restrict__ out_rows, KeyT *__restrict__ out_keys,
                                                     uint32_t cap) {
   uint32_t local = 0;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n + 255) / 256) * 256; i += gridDim.x * 256) {
-    uint32_t key = i < n ? keys[i] : 0xFFFFFFFFu;
+    KeyT key = i < n ? keys[i] : (KeyT)~(KeyT)0;
     bool take = i < n && key <= max_key;
-    if (collect) wave_append<uint32_t>(take, i, key, &counters[0], out_rows, out_keys, cap);
+    if (collect) wave_append<KeyT>(take, i, key, &counters[0], out_rows, out_keys, cap);
     else local += take ? 1u : 0u;
   }
   if (!collect) {
@@ -400,12 +401,16 @@ void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void
   hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap);
 }
 
-void launch_range(const uint32_t *keys, uint32_t n, uint32_t max_key, int collect, uint32_t *counters,
-                  uint32_t *out_rows, uint32_t *out_keys, uint32_t cap, hipStream_t s) {
+void launch_range(const void *keys, int key_bytes, uint32_t n, uint64_t max_key, int collect, uint32_t *counters,
+                  uint32_t *out_rows, void *out_keys, uint32_t cap, hipStream_t s) {
   uint32_t need = (n + 255) / 256, cap_g = (uint32_t)scan_tuning().num_cus * 4;
   uint32_t g = need < cap_g ? need : cap_g;
-  hipLaunchKernelGGL(range_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, max_key, collect, counters, out_rows,
-                     out_keys, cap);
+  if (key_bytes == 8)
+    hipLaunchKernelGGL(range_kernel<uint64_t>, dim3(g ? g : 1), dim3(256), 0, s, (const uint64_t *)keys, n, max_key,
+                       collect, counters, out_rows, (uint64_t *)out_keys, cap);
+  else
+    hipLaunchKernelGGL(range_kernel<uint32_t>, dim3(g ? g : 1), dim3(256), 0, s, (const uint32_t *)keys, n,
+                       (uint32_t)max_key, collect, counters, out_rows, (uint32_t *)out_keys, cap);
 }
 
 }  // namespace rsgpu

@@ -46,7 +46,8 @@ static void set_error(void *log_ctx, const char *where, const char *what) {
   }
 
 static bool type_supported(VecSimType t) {
-  return t == VecSimType_FLOAT32 || t == VecSimType_FLOAT16 || t == VecSimType_BFLOAT16;
+  return t == VecSimType_FLOAT32 || t == VecSimType_FLOAT64 || t == VecSimType_FLOAT16 || t == VecSimType_BFLOAT16 ||
+         t == VecSimType_INT8 || t == VecSimType_UINT8;
 }
 
 extern "C" {
@@ -62,7 +63,11 @@ VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
   }
   const BFParams &bf = params->algoParams.bfParams;
   if (bf.dim == 0 || !type_supported(bf.type) || (int)bf.metric < 0 || (int)bf.metric > (int)VecSimMetric_Cosine) {
-    set_error(lctx, "VecSimIndex_New", "unsupported FLAT parameters (dim>0; type FLOAT32/FLOAT16/BFLOAT16)");
+    set_error(lctx, "VecSimIndex_New", "unsupported FLAT parameters (dim>0; type FLOAT32/FLOAT64/FLOAT16/BFLOAT16/INT8/UINT8)");
+    return nullptr;
+  }
+  if ((bf.type == VecSimType_INT8 || bf.type == VecSimType_UINT8) && bf.dim > 65536) {
+    set_error(lctx, "VecSimIndex_New", "INT8/UINT8 FLAT: dim <= 65536 (exact 32-bit integer sums)");
     return nullptr;
   }
   std::string why;
@@ -318,7 +323,7 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
         if (std::find(b.seen_labels.begin(), b.seen_labels.end(), lab) != b.seen_labels.end()) continue;
         b.seen_labels.push_back(lab);
       }
-      res.push_back(VecSimQueryResult{(size_t)lab, (double)key_to_dist((uint32_t)h.key)});
+      res.push_back(VecSimQueryResult{(size_t)lab, f->score_of(h.key)});
     }
     if (!f->multi) break;
     if (timed_out(b.timeout_ctx)) return new_reply(0, VecSim_QueryReply_TimedOut);

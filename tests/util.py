@@ -4,7 +4,8 @@ import numpy as np
 import oracle as O
 from redisearch_amd import vecsim as V
 
-TYPE_TO_ORACLE = {V.VecSimType_FLOAT32: O.F32, V.VecSimType_FLOAT16: O.F16, V.VecSimType_BFLOAT16: O.BF16}
+TYPE_TO_ORACLE = {V.VecSimType_FLOAT32: O.F32, V.VecSimType_FLOAT16: O.F16, V.VecSimType_BFLOAT16: O.BF16,
+                  V.VecSimType_FLOAT64: O.F64, V.VecSimType_INT8: O.I8, V.VecSimType_UINT8: O.U8}
 # fp32 parity tolerance stated by BASELINE.json's north_star: distances within 1e-4 (absolute, for the
 # unit-scale distances of cosine / normalised IP; relative for large L2 magnitudes)
 ATOL, RTOL = 1e-4, 1e-5
@@ -34,6 +35,12 @@ def quantize(data, vtype):
     if vtype == V.VecSimType_BFLOAT16:
         u = V.to_blob(data, vtype).astype(np.uint32) << 16
         return u.view(np.float32).reshape(np.shape(data))
+    if vtype == V.VecSimType_FLOAT64:
+        return np.asarray(data, dtype=np.float64)
+    if vtype == V.VecSimType_INT8:
+        return np.clip(np.rint(np.asarray(data) * 127), -128, 127).astype(np.int8)
+    if vtype == V.VecSimType_UINT8:
+        return np.clip(np.rint(np.abs(np.asarray(data)) * 255), 0, 255).astype(np.uint8)
     return np.asarray(data, dtype=np.float32)
 
 
