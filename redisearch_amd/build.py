@@ -24,7 +24,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-
 
 # library name -> sources
 LIBS = {
-    "libVectorSimilarity.so": ["scan_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "postings_kernels.hip",
+    "libVectorSimilarity.so": ["scan_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "postings_kernels.hip",
                                "flat_index.cpp", "batch_query.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
 }
 

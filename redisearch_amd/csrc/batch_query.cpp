@@ -39,7 +39,8 @@ struct BatchScratch {
   Dev<uint8_t> queries;
   Dev<float> tau;
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
-  Dev<uint64_t> cand;
+  Dev<uint64_t> cand, sub_cand;
+  Dev<uint32_t> sub_count;
 };
 thread_local BatchScratch tls_batch;
 
@@ -97,6 +98,16 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     sc.out_keys.ensure((size_t)kBatch * kk);
     sc.out_n.ensure(kBatch);
     sc.cand.ensure((size_t)kBatch * cand_cap);
+    // query-stationary filter pass: per-(workgroup, query, lane half) sub-lists, 8x the expected length
+    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
+    const uint32_t qs_grid = use_qs ? gemm_qs_grid(n) : 0;
+    uint32_t sub_cap = 32;
+    if (use_qs) {
+      const uint64_t expect = (uint64_t)kk * ((n + n0 - 1) / n0) / (2ull * qs_grid) + 1;
+      while (sub_cap < 8 * expect) sub_cap *= 2;
+      sc.sub_count.ensure((size_t)qs_grid * kBatch * 2);
+      sc.sub_cand.ensure((size_t)qs_grid * kBatch * 2 * sub_cap);
+    }
     std::vector<uint8_t> hq((size_t)kBatch * stride_);
     std::vector<uint32_t> h_rows((size_t)kBatch * kk), h_keys((size_t)kBatch * kk), h_n(kBatch), h_over(kBatch);
 
@@ -122,8 +133,15 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream);
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
-        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
-                         sc.cand.p, cand_cap, c->stream);
+        if (use_qs) {
+          launch_gemm_qs(ktype, d_rows_, sc.queries.p, stride16, 0, n, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
+                         c->stream);
+          launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, qs_grid, sc.cand_count.p, sc.cand.p, cand_cap,
+                              c->stream);
+        } else {
+          launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
+                           sc.cand.p, cand_cap, c->stream);
+        }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);
       }

@@ -312,7 +312,8 @@ void FlatIndex::grow(size_t min_rows) {
   new_cap = round_up(new_cap, 64);
   uint8_t *nr = nullptr;
   uint64_t *nl = nullptr;
-  HIP_CHECK(hipMalloc((void **)&nr, new_cap * stride_));
+  // 32 rows of slack behind the capacity: the batched filter pass reads its ragged last tile whole
+  HIP_CHECK(hipMalloc((void **)&nr, (new_cap + 32) * stride_));
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
   if (n_rows_) {
     HIP_CHECK(hipMemcpyAsync(nr, d_rows_, (size_t)n_rows_ * stride_, hipMemcpyDeviceToDevice, wstream_));

@@ -1,0 +1,385 @@
+// gemm_qs_kernels.hip -- "query-stationary" batched FLAT filter pass on the gfx950 matrix cores.
+//
+// Step 2 of the batched-query path (gemm_kernels.hip header): S[256 x N] = Q[256 x dim] * X^T, keep
+// (row, distance) with distance 1 - S <= tau[q].  The tiled GEMM in gemm_kernels.hip moves BOTH operands
+// through LDS, re-fills its ring at every 128-row tile and needs one 16-byte LDS read per MFMA.  Here the
+// 256 queries never leave the register file:
+//   * wave w keeps its queries for the WHOLE K = dim as MFMA B fragments (N side): 32 queries = 192
+//     registers at dim 768.  Default: 8 waves x 32 queries, two waves per SIMD (256 registers each), so
+//     that while one wave pays the ~100-200 cycles an LDS-DMA piece costs at issue
+//     (MI355X_MICROARCH.md) or runs its filter epilogue, its partner keeps the SIMD's matrix pipe fed;
+//     gemm_qs=2 selects 4 waves x 64 queries (one 512-register wave per SIMD, half the LDS reads);
+//   * only the corpus streams: tiles of 32 rows x dim (48 KiB at 768 fp16) go global -> LDS by DMA
+//     (global_load_lds_dwordx4, fully coalesced 1 KiB pieces, nontemporal, SGPR tile base + a per-lane
+//     offset that never changes) into a ring that spans tile boundaries; the pieces of tile i+NS-1 are
+//     issued one at a time inside the MFMA stream of tile i;
+//   * one s_barrier per tile with a counted s_waitcnt vmcnt(N): DMAs of the younger tiles stay in flight;
+//   * corpus fragments are read with inline-asm ds_read_b128 + counted lgkmcnt waits, PF fragments ahead,
+//     pinned by sched_barrier (hipcc would sink each read next to its MFMA, wait lgkmcnt(0) every time and
+//     drain vmcnt before any LDS load it can see while DMAs are pending);
+//   * with the queries on N, all 16 accumulators of a lane belong to ONE query (C col = lane & 31): the
+//     filter is 8 v_max3 + one compare per tile and lane against a per-lane threshold register, and a
+//     lane's hits go to a sub-list only that lane writes -- register cursor, no atomics, nothing in the
+//     epilogue waits on vmcnt; compact_cand_kernel concatenates the sub-lists per query afterwards.
+// LDS layout of a tile: row-major, the 16-byte chunk index XOR-ed with (row & 15) so that the fragment
+// read (32 rows, same chunk) is bank-conflict free (SQ_LDS_BANK_CONFLICT = 0); the same XOR picks the
+// SOURCE chunk of each DMA lane (the DMA destination is lane-linear).
+// Measured on 10M x 768 fp16, batch 256 (profiles/r01_batch_qs.txt): 4.0 ms per pass vs 6.9 ms for the tiled
+// kernel; the matrix pipe is busy 62 % of the cycles but the chip clocks down to ~1.4 GHz under the combined
+// MFMA + LDS + 3.6 TB/s HBM load (power), which is what now bounds it.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace rsgpu {
+namespace {
+
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int DT>
+__device__ __forceinline__ f32x16 mfma(u4 a, u4 b, f32x16 c) {
+  if (DT == KT_F16) {
+    half8 x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+  } else {
+    bf16x8 x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+  }
+}
+
+struct QsArgs {
+  const u4 *rows;     // corpus, row-contiguous, 2*KS chunks per row
+  const u4 *queries;  // [256][2*KS chunks]
+  uint32_t row_begin, row_end;
+  const float *tau;     // [256]
+  uint32_t *sub_count;  // [gridDim.x][256][2]
+  uint2 *sub_cand;      // [gridDim.x][256][2][sub_cap] (row, distance bits): one list per (workgroup, query, lane half)
+  uint32_t sub_cap;
+};
+
+// same for a wave-uniform value: pinned to an SGPR (otherwise kernel arguments and gridDim are re-loaded with
+// s_load + s_waitcnt lgkmcnt(0) wherever they are used, which also drains the LDS pipeline)
+__device__ __forceinline__ uint32_t opaque_s(uint32_t v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory");
+}
+
+// value -> same value, opaque to the optimiser: stops loop-invariant address arithmetic from being hoisted
+// out of the tile loop into (scarce) registers
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// v_max3_f32 as is: fmaxf() would first canonicalise every operand (one more VALU op each); a NaN operand is
+// ignored, which is what the filter wants (NaN distances never qualify)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float m;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  return m;
+}
+
+// ds_read_b128 at addr + 256*o, o = 0..7 (a constant after unrolling: one case survives, the offset is an immediate)
+__device__ __forceinline__ u4 lds_read16(uint32_t addr, int o) {
+  u4 v;
+  switch (o) {
+    case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr)); break;
+    case 1: asm volatile("ds_read_b128 %0, %1 offset:256" : "=v"(v) : "v"(addr)); break;
+    case 2: asm volatile("ds_read_b128 %0, %1 offset:512" : "=v"(v) : "v"(addr)); break;
+    case 3: asm volatile("ds_read_b128 %0, %1 offset:768" : "=v"(v) : "v"(addr)); break;
+    case 4: asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(v) : "v"(addr)); break;
+    case 5: asm volatile("ds_read_b128 %0, %1 offset:1280" : "=v"(v) : "v"(addr)); break;
+    case 6: asm volatile("ds_read_b128 %0, %1 offset:1536" : "=v"(v) : "v"(addr)); break;
+    default: asm volatile("ds_read_b128 %0, %1 offset:1792" : "=v"(v) : "v"(addr)); break;
+  }
+  return v;
+}
+// n is a constant after unrolling: exactly one case survives
+__device__ __forceinline__ void wait_lgkm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)"); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)"); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)"); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)"); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(7)"); break;
+  }
+}
+
+// QB = 32-query blocks per wave: 2 -> 4 waves (one per SIMD, 512 registers), 1 -> 8 waves (two per SIMD, 256
+// registers each: while one wave pays the ~100-200 cycles an LDS-DMA piece costs at issue, or runs its filter
+// epilogue, its partner keeps the SIMD's matrix pipe busy -- MI355X_MICROARCH.md "Two waves per SIMD")
+template <int DT, int KS, int NS, int QB>
+__global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
+  constexpr int NW = 8 / QB;        // waves per workgroup
+  constexpr int ROWC = 2 * KS;     // 16-byte chunks per row
+  constexpr int TILE = 32 * ROWC;  // chunks per tile of 32 corpus rows
+  constexpr int PPW = KS / NW;     // 1 KiB DMA pieces per wave per tile (a tile is KS pieces)
+  constexpr int NA = QB == 2 ? 64 : 32;      // query fragments pinned to the accumulation registers (half the register file)
+  __shared__ u4 smem[NS * TILE];   // the ring, nothing else: one object (see gemm_kernels.hip)
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t r = lane & 31, h = lane >> 5;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+
+  // The wave's 64 queries as MFMA B fragments (N side): lane holds query 64w + 32nb + r, halves
+  // 16ks + 8h .. +8.  With the queries on N, every accumulator of a lane belongs to ONE query per nb
+  // (C col = lane&31), so the filter needs one threshold register per nb and a lane's hits go to a
+  // sub-list only this lane writes: the cursor is a register, no atomics anywhere.
+  u4 Q[QB][KS];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) Q[nb][ks] = g.queries[(size_t)(32 * QB * w + 32 * nb + r) * ROWC + 2 * ks + h];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      if (nb * KS + ks < NA) asm volatile("" : "+a"(Q[nb][ks]));  // the rest stays in VGPRs
+    }
+  // distance d = 1 - s <= tau, tested first on s with a margin that covers the rounding of both subtractions
+  float tau[QB], thr[QB];
+  uint32_t cur[QB];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++) {
+    cur[nb] = 0;
+    tau[nb] = g.tau[32 * QB * w + 32 * nb + r];
+    const float u = 1.0f - tau[nb];
+    thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : u - (fabsf(tau[nb]) + fabsf(u)) * 2.4e-7f;
+  }
+
+  const uint32_t n = g.row_end - g.row_begin;
+  const uint32_t n_tiles = (n + 31) / 32;
+  const uint32_t mine = n_tiles > blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t row_first = opaque_s(g.row_begin + blockIdx.x * 32);  // first row of this workgroup's tile 0
+  const uint32_t row_step = opaque_s(gridDim.x * 32);                  // ... and the distance to its next tile
+  const uint32_t row_end = opaque_s(g.row_end);
+
+  // DMA of piece p (64 consecutive LDS chunks, 1 KiB) of this workgroup's i-th tile into ring slot `stage`.
+  // The lane's source offset inside a tile never changes (poff, bytes); tile base and LDS destination are
+  // wave-uniform, so a piece costs a few scalar instructions plus the DMA itself (SGPR base + VGPR offset).
+  const uint32_t wu = __builtin_amdgcn_readfirstlane(w);
+  uint32_t poff[PPW];
+#pragma unroll
+  for (int p = 0; p < PPW; p++) {
+    const uint32_t s = 64 * (PPW * w + p) + lane;
+    const uint32_t rr = s / ROWC, cc = s - rr * ROWC;
+    poff[p] = 16u * (rr * ROWC + (cc ^ (rr & 15u)));
+  }
+  auto issue_piece = [&](uint32_t i, uint32_t stage, int p) {
+    const uint32_t row0 = row_first + i * row_step;
+    __attribute__((address_space(3))) void *lp =
+        (__attribute__((address_space(3))) void *)(smem + stage * TILE + 64 * (PPW * wu + p));
+    // a ragged last tile reads up to 31 rows past row_end: the caller guarantees they are allocated
+    // (launch_gemm_qs contract); they are multiplied but never emitted
+    const char *tile = reinterpret_cast<const char *>(g.rows) + (size_t)row0 * (ROWC * 16);
+    // (opaque: keeps the offset a 32-bit register instead of a hoisted 64-bit pair)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + opaque(poff[p])), lp, 16, 0,
+                                     2);  // nt: corpus lines are used once
+  };
+  auto issue = [&](uint32_t i, uint32_t stage) {
+#pragma unroll
+    for (int p = 0; p < PPW; p++) issue_piece(i, stage, p);
+  };
+
+  uint32_t fill = 0;  // ring slot of the next tile to issue
+#pragma unroll
+  for (int p = 0; p < NS - 1; p++)
+    if ((uint32_t)p < mine) {
+      issue(p, fill);
+      fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+  uint32_t stage = 0;
+  for (uint32_t i = 0; i < mine; i++) {
+    // tile i has landed once only this wave's DMAs of the younger tiles are outstanding (loads return
+    // in order; candidate stores in the queue can only make the wait conservative) ...
+    const uint32_t younger = mine - 1 - i < (uint32_t)(NS - 2) ? mine - 1 - i : (uint32_t)(NS - 2);
+    switch (younger) {
+      case 0: wait_vm<0>(); break;
+      case 1: wait_vm<PPW>(); break;
+      case 2: wait_vm<2 * PPW>(); break;
+      case 3: wait_vm<3 * PPW>(); break;
+      case 4: wait_vm<4 * PPW>(); break;
+      case 5: wait_vm<5 * PPW>(); break;
+      default: wait_vm<6 * PPW>(); break;
+    }
+    // ... for every wave; the barrier also says tile i-1 has been consumed by all, freeing its slot
+    __builtin_amdgcn_s_barrier();
+    // the DMAs of tile i+NS-1 are issued one piece every fourth k-step INSIDE the MFMA stream below: a
+    // burst here would block this wave -- the only one on its SIMD -- on the memory pipeline's back
+    // pressure while the matrix core idles (measured: DMA time and MFMA time added up)
+    const bool refill = i + NS - 1 < mine;
+    // corpus fragment (ks, lane): row r, chunk (2ks+h) ^ (r&15); the XOR only touches the low four bits, so
+    // eight lane addresses (ks & 7) plus an immediate 256-byte step per eight k-steps cover the whole row
+    const uint32_t lr = opaque(lane);
+    const uint32_t tbase = lds_base + 16u * (stage * TILE + (lr & 31u) * ROWC);
+    stage = stage + 1 == NS ? 0 : stage + 1;
+    // chunk (2ks+h)^x = 16(ks>>3) + (2(ks&7) ^ (h^x)): one v_xad_u32 per read, nothing held in registers
+    const uint32_t t16 = 16u * ((lr >> 5) ^ (lr & 15u));
+    auto frag_addr = [&](int ks) { return tbase + ((32u * (uint32_t)(ks & 7)) ^ t16); };
+    f32x16 acc[QB];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++) acc[nb][e] = 0.0f;
+    // Software pipeline, PF fragments ahead: with one wave per SIMD nothing else hides the LDS latency.
+    // The reads and their counted waits are inline asm (hipcc waits lgkmcnt(0) before every use once LDS
+    // DMAs are pending, and would drain vmcnt for an LDS load it can see); sched_barrier pins the order.
+    constexpr int PF = QB == 1 ? 3 : 6;
+    u4 xb[PF];
+#pragma unroll
+    for (int ks = 0; ks < PF; ks++) xb[ks] = lds_read16(frag_addr(ks), ks >> 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      wait_lgkm(KS - 1 - ks < PF - 1 ? KS - 1 - ks : PF - 1);  // fragment ks has arrived
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<DT>(xb[ks % PF], Q[nb][ks], acc[nb]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + PF < KS) xb[ks % PF] = lds_read16(frag_addr(ks + PF), (ks + PF) >> 3);
+      if (ks % (KS / PPW) == 1 && refill) issue_piece(i + NS - 1, fill, ks / (KS / PPW));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (refill) fill = fill + 1 == NS ? 0 : fill + 1;
+    // C row = corpus row (e&3)+8*(e>>2)+4h of the tile, C col = query r of the nb block
+    const uint32_t xr0 = row_first + i * row_step + 4 * (lr >> 5);
+#pragma unroll
+    for (int nb = 0; nb < QB; nb++) {
+      float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
+      m = max3(m, acc[nb][15], acc[nb][15]);
+      if (m >= thr[nb]) {  // rare: a few hits per tile over the whole wave
+        uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+#pragma unroll
+        for (int eg = 0; eg < 4; eg++) {
+          const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+          if (gm >= thr[nb]) {
+#pragma unroll
+            for (int el = 0; el < 4; el++) {
+              const float d = 1.0f - acc[nb][4 * eg + el];
+              const uint32_t xr = xr0 + 8 * eg + el;
+              if (d <= tau[nb] && xr < row_end) {
+                if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                cur[nb]++;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+    g.sub_count[((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + r) * 2 + h] = cur[nb];
+}
+
+// One workgroup per query: concatenate its 2 * n_wg sub-lists (row, distance bits) into
+// cand[q*cand_cap ..] as (row, orderable key) and set cand_count[q] (cand_cap+1 when a sub-list or the
+// list itself overflowed -> the select flags the query and the host redoes it).
+__global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__restrict__ sub_count,
+                                                           const uint2 *__restrict__ sub_cand, uint32_t sub_cap,
+                                                           uint32_t n_wg, uint32_t *__restrict__ cand_count,
+                                                           uint2 *__restrict__ cand, uint32_t cand_cap) {
+  __shared__ uint32_t offs[513];
+  __shared__ uint32_t over;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) over = 0;
+  __syncthreads();
+  for (uint32_t sg = tid; sg < 512; sg += 256) {  // segment sg = (workgroup sg/2, lane half sg%2)
+    uint32_t c = sg < 2 * n_wg ? sub_count[((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)] : 0;
+    if (c > sub_cap) {
+      over = 1;
+      c = sub_cap;
+    }
+    offs[sg + 1] = c;
+  }
+  if (tid == 0) offs[0] = 0;
+  __syncthreads();
+  if (tid == 0)
+    for (uint32_t i = 1; i <= 512; i++) offs[i] += offs[i - 1];
+  __syncthreads();
+  const uint32_t total = offs[512];
+  if (total > cand_cap) {
+    if (tid == 0) cand_count[q] = cand_cap + 1;
+    return;
+  }
+  const uint32_t lane = tid & 63, wv = tid >> 6;
+  for (uint32_t sg = wv; sg < 2 * n_wg; sg += 4) {  // wavefront per sub-list: coalesced copies
+    const uint32_t beg = offs[sg], cnt = offs[sg + 1] - beg;
+    const uint2 *src = sub_cand + (((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap;
+    for (uint32_t i = lane; i < cnt; i += 64) {
+      const uint2 e = src[i];
+      cand[(size_t)q * cand_cap + beg + i] = make_uint2(e.x, f2key(__uint_as_float(e.y)));
+    }
+  }
+  if (tid == 0) cand_count[q] = over ? cand_cap + 1 : total;
+}
+
+template <int DT, int KS, int NS>
+void launch_qs_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
+  switch (scan_tuning().gemm_qs) {  // 1: eight waves x 32 queries (default); 2: four waves x 64 queries
+    case 2: hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 2>), dim3(grid), dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 1>), dim3(grid), dim3(512), 0, s, g); break;
+  }
+}
+
+template <int DT>
+bool launch_qs_dt(const QsArgs &g, uint32_t stride16, uint32_t grid, hipStream_t s) {
+  switch (stride16) {  // chunks per row = 2 * KS; the ring is as deep as ~144 KiB of LDS allows
+    case 96: launch_qs_shape<DT, 48, 3>(g, grid, s); return true;
+    case 64: launch_qs_shape<DT, 32, 4>(g, grid, s); return true;
+    case 48: launch_qs_shape<DT, 24, 6>(g, grid, s); return true;
+    case 32: launch_qs_shape<DT, 16, 8>(g, grid, s); return true;
+    case 16: launch_qs_shape<DT, 8, 8>(g, grid, s); return true;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+bool gemm_qs_supported(uint32_t stride16) {
+  return stride16 == 96 || stride16 == 64 || stride16 == 48 || stride16 == 32 || stride16 == 16;
+}
+
+uint32_t gemm_qs_grid(uint32_t n_rows) {
+  const uint32_t cus = (uint32_t)scan_tuning().num_cus, tiles = (n_rows + 31) / 32;
+  const uint32_t cap = cus < 256 ? cus : 256;  // compact_cand_kernel handles up to 256 sub-lists
+  return tiles < cap ? tiles : cap;
+}
+
+bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
+                    uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
+                    hipStream_t s) {
+  if (row_end <= row_begin || !gemm_qs_supported(stride16)) return false;
+  QsArgs g{(const u4 *)rows, (const u4 *)queries, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap};
+  const uint32_t grid = gemm_qs_grid(row_end - row_begin);
+  return dtype == KT_F16 ? launch_qs_dt<KT_F16>(g, stride16, grid, s) : launch_qs_dt<KT_BF16>(g, stride16, grid, s);
+}
+
+void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s) {
+  hipLaunchKernelGGL(compact_cand_kernel, dim3(256), dim3(256), 0, s, sub_count, (const uint2 *)sub_cand, sub_cap, n_wg,
+                     cand_count, (uint2 *)cand, cand_cap);
+}
+
+}  // namespace rsgpu

@@ -52,6 +52,7 @@ struct ScanTuning {
   int nontemporal = 1;     // stream the corpus with nt loads
   int gemm_dma = 1;        // batched path: 1 LDS-DMA ring KC=8 (default), 0 register-staged, 2/3 experiments
   int filter_select = 1;   // small-K top-K: sample threshold + one filter pass (0 = radix levels only)
+  int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();
@@ -97,6 +98,18 @@ void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int pass
 void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                       uint32_t row_end, int mode, uint32_t *keys_out, uint32_t keys_ld, const float *tau,
                       uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s);
+// Query-stationary FILTER pass (gemm_qs_kernels.hip): same result as launch_gemm_topk mode 1, candidates go to
+// per-(workgroup, query, lane half) sub-lists sub_cand[grid][256][2][sub_cap] (row, distance bits) with
+// their lengths in sub_count[grid][256][2]; launch_compact_cand concatenates them into the (row,key) lists
+// launch_batch_select_cand reads.  Shapes: stride16 in {16,32,48,64,96} (dim 128..768 halves), else false.
+// The rows buffer must extend 31 rows past row_end (a ragged last tile is read whole, never emitted).
+bool gemm_qs_supported(uint32_t stride16);
+uint32_t gemm_qs_grid(uint32_t n_rows);
+bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
+                    uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
+                    hipStream_t s);
+void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s);
 // per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
 // (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,

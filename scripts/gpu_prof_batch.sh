@@ -16,7 +16,7 @@ for f in sorted(glob.glob("gpurun_out/prof_batch_pmc*/*counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        name = "gemm_dma" if "gemm_topk_dma" in k else ("gemm" if "gemm_topk" in k else ("batch_select" if "batch_select" in k else None))
+        name = "gemm_qs" if "gemm_qs" in k else ("gemm" if "gemm_topk" in k else ("batch_select" if "batch_select" in k else None))
         if name: agg[name][r["Counter_Name"]].append((float(r["Counter_Value"]), int(r.get("Grid_Size", 0) or 0)))
     for name, d in agg.items():
         for c, v in d.items():
