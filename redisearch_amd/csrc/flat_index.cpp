@@ -613,18 +613,18 @@ static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> 
   // the whole array is ~ k * n / sample, far below kCandCap
   const uint32_t per = k <= 32 ? 64 : 256;
   c->ensure_out(k);
-  HIP_CHECK(hipMemsetAsync(c->d_fcnt, 0, 4 * sizeof(uint32_t), c->stream));
-  launch_sample_threshold(c->d_keys, n, per, k, c->d_tau, c->stream);
+  // The K winners, their count and the overflow flag are written by the last kernel straight into the
+  // pinned (device-visible, coherent) host buffers: no memset, no D2H copies on the critical path.
+  c->h_fcnt[1] = 0;  // overflow flag, only ever set by the kernel
+  c->h_fcnt[2] = 0;
+  launch_sample_threshold(c->d_keys, n, per, k, c->d_tau, c->d_fcnt, c->stream);
   launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
-  launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->d_out_rows, (uint32_t *)c->d_out_keys,
-                           c->d_fcnt + 2, k, c->d_fcnt + 1, c->stream);
+  launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys,
+                           c->h_fcnt + 2, k, c->h_fcnt + 1, c->stream);
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipMemcpyAsync(c->h_fcnt, c->d_fcnt, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipMemcpyAsync(c->h_out_rows, c->d_out_rows, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipMemcpyAsync(c->h_out_keys, c->d_out_keys, k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   collect_profile(c);
-  if (c->h_fcnt[1] || c->h_fcnt[0] > QueryCtx::kCandCap) return false;  // candidate overflow: radix path
+  if (c->h_fcnt[1]) return false;  // candidate overflow: radix path
   const uint32_t got = std::min<uint32_t>(c->h_fcnt[2], k);
   if (got < std::min<uint32_t>(k, n)) return false;  // cannot happen (tau is an upper bound); be safe
   const uint32_t *k32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);

@@ -115,9 +115,9 @@ void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                             uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1);
 // tau_out[0] = upper bound of the k-th smallest key (k <= 1024) of keys[0..n): k-th smallest of the minima
-// of 1024 evenly spread groups of `per` consecutive keys (per % 4 == 0, n >= 1024*per)
+// of 1024 groups of `per` sampled keys (per % 4 == 0, n >= 1024*per); also zeroes zero4[0..3] if given
 void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
-                             hipStream_t s);
+                             uint32_t *zero4, hipStream_t s);
 // candidates of a single key array: append (row,key) of every key <= orderable(*tau) to cand[0..cap),
 // counting in cand_count[0]
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,

@@ -294,34 +294,43 @@ __device__ __forceinline__ uint32_t f2key_dev(float f) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-// tau = K-th smallest of 1024 group minima, group t = PER consecutive keys starting at t*seg_stride
-// (1024 segments spread evenly over the key array: coalesced to read, robust to sorted corpora).
-// K distinct keys are <= tau, so tau bounds the K-th smallest key of the whole array.  One workgroup.
+// tau = K-th smallest of 1024 group minima over a sample of `per` keys per group.  The sample is per/4
+// slabs of 4096 consecutive keys spread evenly over the array (robust to sorted corpora); thread t owns
+// the t-th 16-byte chunk of every slab, so each load instruction is a fully coalesced 16 KiB sweep and all
+// of a thread's loads are independent.  K distinct keys are <= tau, so tau bounds the K-th smallest key of
+// the whole array.  One workgroup.
 __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *__restrict__ keys, uint32_t n,
-                                                                uint32_t seg_stride, uint32_t per, uint32_t k,
-                                                                float *__restrict__ tau_out) {
+                                                                uint32_t slab_stride, uint32_t slabs, uint32_t k,
+                                                                float *__restrict__ tau_out,
+                                                                uint32_t *__restrict__ zero4) {
   __shared__ uint32_t mins[1024];
   const uint32_t t = threadIdx.x;
-  const uint32_t beg = t * seg_stride;
+  if (zero4 && t < 4) zero4[t] = 0;  // the filter pass's counters: saves a memset on the query's critical path
   uint32_t m = 0xFFFFFFFFu;
-  for (uint32_t i = 0; i < per; i += 4) {  // beg and per are multiples of 4: aligned 16-byte loads
-    const uint32_t idx = beg + i;
-    if (idx + 3 < n) {
-      u4 v = *(const u4 *)(keys + idx);
-      uint32_t a = v.x < v.y ? v.x : v.y, b = v.z < v.w ? v.z : v.w;
+  for (uint32_t c0 = 0; c0 < slabs; c0 += 16) {
+    u4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const uint32_t c = c0 + u < slabs ? c0 + u : slabs - 1;  // (repeats the last slab: harmless for a minimum)
+      v[u] = *(const u4 *)(keys + (size_t)c * slab_stride + 4 * t);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      uint32_t a = v[u].x < v[u].y ? v[u].x : v[u].y, b = v[u].z < v[u].w ? v[u].z : v[u].w;
       a = a < b ? a : b;
       m = m < a ? m : a;
-    } else {
-      for (uint32_t j = idx; j < n && j < idx + 4; j++) m = m < keys[j] ? m : keys[j];
     }
   }
   mins[t] = m;
   __syncthreads();
   // rank of this group's minimum among the 1024 (ties by group index): the one of rank k-1 is tau
   uint32_t rank = 0;
-  for (uint32_t j = 0; j < 1024; j++) {
-    const uint32_t o = mins[j];
-    rank += (o < m || (o == m && j < t)) ? 1u : 0u;
+  for (uint32_t j = 0; j < 1024; j += 4) {
+    const u4 o = *(const u4 *)(mins + j);
+    rank += (o.x < m || (o.x == m && j < t)) ? 1u : 0u;
+    rank += (o.y < m || (o.y == m && j + 1 < t)) ? 1u : 0u;
+    rank += (o.z < m || (o.z == m && j + 2 < t)) ? 1u : 0u;
+    rank += (o.w < m || (o.w == m && j + 3 < t)) ? 1u : 0u;
   }
   if (rank == k - 1) {
     const uint32_t u = (m & 0x80000000u) ? (m ^ 0x80000000u) : ~m;
@@ -329,31 +338,55 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
   }
 }
 
+// One streaming pass: (row, key) of every key <= orderable(*tau).  Four independent 16-byte loads per
+// thread and step, ONE ballot per step on the minimum of the 16 keys (hits are rare), then the appends.
 __global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                           const float *__restrict__ tau, uint2 *__restrict__ cand,
                                                           uint32_t *__restrict__ cand_count, uint32_t cap) {
   const uint32_t max_key = f2key_dev(tau[0]);
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t n4 = (n + 3) / 4;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < ((n4 + 255) / 256) * 256; i += gridDim.x * 256) {
-    u64 kk[4];
-    load4<uint32_t>(keys, n, i, i < n4, kk);
+  const uint32_t n4 = n / 4;  // whole 16-byte chunks; the 0..3 keys behind them are handled at the end
+  const u4 *k4 = (const u4 *)keys;
+  auto append = [&](bool take, uint32_t row, uint32_t key) {
+    u64 m = __ballot(take);
+    if (!m) return;
+    int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == (uint32_t)leader) base = atomicAdd(cand_count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (take) {
+      uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (slot < cap) cand[slot] = make_uint2(row, key);
+    }
+  };
+  for (uint32_t b0 = blockIdx.x * 1024; b0 < n4; b0 += gridDim.x * 1024) {  // wave-uniform trip count
+    u4 v[4];
+    uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t row = i * 4 + j;
-      const bool take = (i < n4) && (row < n) && ((uint32_t)kk[j] <= max_key);
-      u64 m = __ballot(take);
-      if (m) {
-        int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == (uint32_t)leader) base = atomicAdd(cand_count, (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (take) {
-          uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          if (slot < cap) cand[slot] = make_uint2(row, (uint32_t)kk[j]);
-        }
+    for (int u = 0; u < 4; u++) {
+      const uint32_t idx = b0 + u * 256 + threadIdx.x;
+      v[u] = idx < n4 ? __builtin_nontemporal_load(k4 + idx) : (u4){~0u, ~0u, ~0u, ~0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      uint32_t a = v[u].x < v[u].y ? v[u].x : v[u].y, b = v[u].z < v[u].w ? v[u].z : v[u].w;
+      a = a < b ? a : b;
+      mn = mn < a ? mn : a;
+    }
+    if (__ballot(mn <= max_key)) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t idx = b0 + u * 256 + threadIdx.x;
+        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) append(idx < n4 && w[j] <= max_key, idx * 4 + j, w[j]);
       }
     }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const uint32_t row = n4 * 4 + threadIdx.x;
+    const uint32_t key = row < n ? keys[row] : 0xFFFFFFFFu;
+    append(row < n && key <= max_key, row, key);
   }
 }
 
@@ -389,14 +422,16 @@ void launch_select_collect(const void *keys, int key_bytes, uint32_t n, int pass
 }
 
 void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
-                             hipStream_t s) {
-  uint32_t seg_stride = (n / 1024) & ~3u;  // caller guarantees n >= 1024 * per
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(1024), 0, s, keys, n, seg_stride, per, k, tau_out);
+                             uint32_t *zero4, hipStream_t s) {
+  const uint32_t slabs = per / 4;  // caller guarantees n >= 1024 * per (>= 4096 * slabs)
+  const uint32_t slab_stride = slabs > 1 ? ((n - 4096) / (slabs - 1)) & ~3u : 0;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(1024), 0, s, keys, n, slab_stride, slabs, k, tau_out,
+                     zero4);
 }
 
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
                         uint32_t cap, hipStream_t s) {
-  uint32_t need = ((n + 3) / 4 + 255) / 256, cap_g = (uint32_t)scan_tuning().num_cus * 8;
+  uint32_t need = (n / 4 + 1023) / 1024, cap_g = (uint32_t)scan_tuning().num_cus * 8;
   uint32_t g = need < cap_g ? need : cap_g;
   hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap);
 }
