@@ -113,6 +113,19 @@ long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *sco
 long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
                           double *dist_out);
 
+/* FT.HYBRID fusion of the ranked search list (doc ids + scores, best first) and the ranked vector list (doc ids
+ * + distances, nearest first): RPHybridMerger + HybridRRFScore / HybridLinearScore
+ * (reference src/result_processor.c:2549-2571,2613-2670; src/hybrid/hybrid_scoring.c:41-84) with the vector
+ * score normalised by VectorNorm_<metric> (src/vector_normalization.h:37-60; metric < 0: vec_scores are used
+ * as given).  scoring 0 = RRF: sum of 1/(constant + rank), rank = 1-based position within its list; 1 = LINEAR:
+ * weights[0]*search_score + weights[1]*norm(distance).  At most `window` (<= 4096) entries of each list are
+ * consumed.  Writes the fused list (score descending, lower doc id first) cut to top_n; returns #written or -1. */
+#define RSGPU_HYBRID_RRF 0
+#define RSGPU_HYBRID_LINEAR 1
+long RSGPU_HybridFuse(int scoring, double rrf_constant, const double *weights, int metric, const uint64_t *search_ids,
+                      const double *search_scores, size_t n_search, const uint64_t *vec_ids, const double *vec_scores,
+                      size_t n_vec, size_t window, size_t top_n, uint64_t *doc_ids_out, double *scores_out);
+
 /* idf = logb(1 + (N+1)/max(n,1)); bm25 idf = ln(1 + (max(N,n) - n + 0.5)/(n + 0.5)) */
 double RSGPU_CalculateIDF(size_t total_docs, size_t term_docs);
 double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs);

@@ -427,3 +427,23 @@ def varint_decode(buf):
     v = C.c_uint64(0)
     k = lib.oracle_varint_decode(_p(b), len(b), C.byref(v))
     return v.value, k
+
+
+_sig("oracle_vector_norm", _dbl, _i, _dbl)
+_sig("oracle_hybrid_fuse", _sz, _i, _dbl, _dbl, _dbl, _i, _vp, _vp, _sz, _vp, _vp, _sz, _sz, _vp, _vp)
+RRF, LINEAR = 0, 1
+
+
+def vector_norm(metric, d):
+    return lib.oracle_vector_norm(metric, d)
+
+
+def hybrid_fuse(scoring, a_ids, a_scores, b_ids, b_scores, window, constant=60.0, weights=(0.5, 0.5), metric=-1):
+    """FT.HYBRID merge of a search list and a vector list (oracle/scoring_oracle.c oracle_hybrid_fuse)."""
+    a_ids, b_ids = np.ascontiguousarray(a_ids, np.uint64), np.ascontiguousarray(b_ids, np.uint64)
+    a_scores, b_scores = np.ascontiguousarray(a_scores, np.float64), np.ascontiguousarray(b_scores, np.float64)
+    ids = np.zeros(len(a_ids) + len(b_ids) + 1, np.uint64)
+    sc = np.zeros(len(a_ids) + len(b_ids) + 1, np.float64)
+    m = lib.oracle_hybrid_fuse(scoring, constant, weights[0], weights[1], metric, _p(a_ids), _p(a_scores), len(a_ids),
+                               _p(b_ids), _p(b_scores), len(b_ids), window, _p(ids), _p(sc))
+    return ids[:m].copy(), sc[:m].copy()

@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 /* result-tree node kinds (same meaning as RSResultData_* in the reference) */
 enum { R_UNION = 1, R_INTERSECTION = 2, R_TERM = 4, R_VIRTUAL = 8, R_NUMERIC = 16, R_METRIC = 32, R_HYBRID = 64 };
@@ -255,4 +256,50 @@ void oracle_score_flat(int scorer, size_t M, size_t T, const uint32_t *freq, con
     }
     out[m] = s;
   }
+}
+
+/* ---- FT.HYBRID fusion (reference src/hybrid/hybrid_scoring.c:41-84, merger src/result_processor.c:2549-2571,
+ * vector-score normalisation src/vector_normalization.h:37-60) -----------------------------------------------
+ * Two ranked upstreams: a = search results (score descending), b = vector results (distance ascending, i.e.
+ * normalised score descending).  At most `window` results are consumed from each, in upstream order; a
+ * document found in both gets both contributions, added in upstream order (i = 0, then i = 1).
+ *   RRF:    contribution = 1 / (constant + rank), rank = 1-based position in its upstream
+ *   LINEAR: contribution = weight[i] * score;  the vector score is VectorNorm_<metric>(distance)
+ * Output: every distinct document once, sorted by fused score descending, ties by lower doc id
+ * (cmpByScore, src/result_processor.c:834-850).  metric < 0: b_scores are used as they are. */
+double oracle_vector_norm(int metric, double d) {
+  if (metric == 0) return 1.0 / (1.0 + d);          /* L2:     1/(1+distance)            */
+  if (metric == 1) return (1.0 + d) / 2.0;           /* IP:     (1+dot)/2                 */
+  if (metric == 2) return (1.0 + (1.0 - d)) / 2.0;   /* cosine: (1 + (1 - distance)) / 2  */
+  return d;
+}
+typedef struct { uint64_t id; double s; } OFused;
+static int cmp_fused(const void *x, const void *y) {
+  const OFused *a = x, *b = y;
+  if (a->s != b->s) return a->s > b->s ? -1 : 1;
+  return a->id < b->id ? -1 : (a->id > b->id ? 1 : 0);
+}
+size_t oracle_hybrid_fuse(int scoring, double constant, double w0, double w1, int metric,
+                          const uint64_t *a_ids, const double *a_scores, size_t na,
+                          const uint64_t *b_ids, const double *b_scores, size_t nb, size_t window,
+                          uint64_t *ids_out, double *scores_out) {
+  if (na > window) na = window;
+  if (nb > window) nb = window;
+  OFused *f = malloc((na + nb + 1) * sizeof *f);
+  size_t m = 0;
+  for (size_t i = 0; i < na; i++) {
+    double c = scoring == 0 ? 1.0 / (constant + (double)(i + 1)) : w0 * a_scores[i];
+    f[m].id = a_ids[i]; f[m].s = 0.0 + c; m++;
+  }
+  for (size_t j = 0; j < nb; j++) {
+    double c = scoring == 0 ? 1.0 / (constant + (double)(j + 1)) : w1 * oracle_vector_norm(metric, b_scores[j]);
+    size_t hit = m;
+    for (size_t i = 0; i < na; i++) if (f[i].id == b_ids[j]) { hit = i; break; }
+    if (hit < m) f[hit].s += c;
+    else { f[m].id = b_ids[j]; f[m].s = 0.0 + c; m++; }
+  }
+  qsort(f, m, sizeof *f, cmp_fused);
+  for (size_t i = 0; i < m; i++) { ids_out[i] = f[i].id; scores_out[i] = f[i].s; }
+  free(f);
+  return m;
 }

@@ -49,6 +49,7 @@ struct Scratch {
   DevBuf<uint8_t> flags;
   DevBuf<uint32_t> pos, block_counts, total, rows, keys32;
   DevBuf<float> dists;
+  DevBuf<uint64_t> fuse;
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -56,6 +57,7 @@ Scratch &scratch(int device) {
   if (s.device != device) {
     s.flags.reset(); s.pos.reset(); s.block_counts.reset(); s.total.reset(); s.rows.reset(); s.keys32.reset();
     s.dists.reset();
+    s.fuse.reset();
     s.device = device;
   }
   return s;
@@ -397,6 +399,51 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
     out++;
   }
   return out;
+  S_CATCH(-1)
+}
+
+// reference src/result_processor.c:2549-2571 (window, ranks), src/hybrid/hybrid_scoring.c:41-84
+long RSGPU_HybridFuse(int scoring, double rrf_constant, const double *weights, int metric, const uint64_t *search_ids,
+                      const double *search_scores, size_t n_search, const uint64_t *vec_ids, const double *vec_scores,
+                      size_t n_vec, size_t window, size_t top_n, uint64_t *doc_ids_out, double *scores_out) {
+  S_TRY
+  if (scoring != RSGPU_HYBRID_RRF && scoring != RSGPU_HYBRID_LINEAR) throw std::runtime_error("RSGPU_HybridFuse: unknown scoring");
+  if (scoring == RSGPU_HYBRID_LINEAR && !weights) throw std::runtime_error("RSGPU_HybridFuse: LINEAR needs two weights");
+  if (window > kFuseMaxWindow) throw std::runtime_error("RSGPU_HybridFuse: window is limited to 4096 per upstream");
+  const uint32_t na = (uint32_t)std::min(n_search, window), nb = (uint32_t)std::min(n_vec, window);
+  if ((na && (!search_ids || (scoring == RSGPU_HYBRID_LINEAR && !search_scores))) ||
+      (nb && (!vec_ids || (scoring == RSGPU_HYBRID_LINEAR && !vec_scores))))
+    throw std::runtime_error("RSGPU_HybridFuse: NULL list");
+  if (!na && !nb) return 0;
+  std::string why;
+  if (!device_available(&why)) throw std::runtime_error(why);
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  CtxLease c(dev);
+  Scratch &sc = scratch(dev);
+  const uint32_t m = na + nb;
+  sc.fuse.ensure((size_t)m * 4 * 8 + 8);  // ids_in | scores_in | ids_out | scores_out | count
+  uint64_t *d_ids = sc.fuse.p, *d_oid = d_ids + 2 * (size_t)m;
+  double *d_sc = reinterpret_cast<double *>(d_ids + m), *d_osc = reinterpret_cast<double *>(d_ids + 3 * (size_t)m);
+  uint32_t *d_cnt = reinterpret_cast<uint32_t *>(d_ids + 4 * (size_t)m);
+  std::vector<double> zeros(m, 0.0);
+  HIP_CHECK(hipMemcpyAsync(d_ids, search_ids, na * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_CHECK(hipMemcpyAsync(d_ids + na, vec_ids, nb * 8, hipMemcpyHostToDevice, c->stream));
+  HIP_CHECK(hipMemcpyAsync(d_sc, search_scores ? (const void *)search_scores : (const void *)zeros.data(), na * 8,
+                           hipMemcpyHostToDevice, c->stream));
+  HIP_CHECK(hipMemcpyAsync(d_sc + na, vec_scores ? (const void *)vec_scores : (const void *)zeros.data(), nb * 8,
+                           hipMemcpyHostToDevice, c->stream));
+  FuseParams p{scoring, rrf_constant, weights ? weights[0] : 0.0, weights ? weights[1] : 0.0, metric,
+               d_ids, d_ids + na, d_sc, d_sc + na, na, nb, d_oid, d_osc, d_cnt};
+  launch_hybrid_fuse(p, c->stream);
+  HIP_CHECK(hipGetLastError());
+  uint32_t cnt = 0;
+  HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  const size_t out = std::min<size_t>(cnt, top_n);
+  if (out && doc_ids_out) HIP_CHECK(hipMemcpy(doc_ids_out, d_oid, out * 8, hipMemcpyDeviceToHost));
+  if (out && scores_out) HIP_CHECK(hipMemcpy(scores_out, d_osc, out * 8, hipMemcpyDeviceToHost));
+  return (long)out;
   S_CATCH(-1)
 }
 

@@ -53,4 +53,19 @@ void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint3
 // keys[i] = orderable(dists[i]) (NaN last)
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s);
 
+// ---- FT.HYBRID fusion (fusion_kernels.hip) -------------------------------------------------------------
+constexpr uint32_t kFuseMaxWindow = 4096;  // per upstream: (2 * 4096) * 17 bytes of LDS
+struct FuseParams {
+  int scoring;  // 0 RRF, 1 LINEAR
+  double constant, w0, w1;
+  int metric;  // VecSimMetric of the vector upstream's distances, < 0: b_scores are final scores
+  const uint64_t *a_ids, *b_ids;      // device, already cut to the window
+  const double *a_scores, *b_scores;
+  uint32_t na, nb;
+  uint64_t *ids_out;   // [na + nb]
+  double *scores_out;  // [na + nb]
+  uint32_t *count_out;
+};
+void launch_hybrid_fuse(const FuseParams &p, hipStream_t s);
+
 }  // namespace rsgpu

@@ -33,6 +33,7 @@ ABI = {
     "RSGPU_Hits_Score": (_i, [_vp, _vp, C.POINTER(ScoreArgs), _vp]),
     "RSGPU_Hits_TopN": (C.c_long, [_vp, _sz, _vp, _vp]),
     "RSGPU_Hits_KnnRerank": (C.c_long, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_HybridFuse": (C.c_long, [_i, _dbl, _vp, _i, _vp, _vp, _sz, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "RSGPU_CalculateIDF": (_dbl, [_sz, _sz]),
     "RSGPU_CalculateIDF_BM25": (_dbl, [_sz, _sz]),
     "RSGPU_SearchProfile": (None, [C.POINTER(_dbl)] * 5),
@@ -182,6 +183,25 @@ def calculate_idf(total, term):
 
 def calculate_idf_bm25(total, term):
     return load().RSGPU_CalculateIDF_BM25(total, term)
+
+
+RRF, LINEAR = 0, 1
+
+
+def hybrid_fuse(scoring, search_ids, search_scores, vec_ids, vec_scores, window, top_n=None, constant=60.0,
+                weights=(0.5, 0.5), metric=-1):
+    """FT.HYBRID fusion on the device (RSGPU_HybridFuse): ranked search list + ranked vector list -> fused list."""
+    a_ids, b_ids = np.ascontiguousarray(search_ids, np.uint64), np.ascontiguousarray(vec_ids, np.uint64)
+    a_sc, b_sc = np.ascontiguousarray(search_scores, np.float64), np.ascontiguousarray(vec_scores, np.float64)
+    w = np.ascontiguousarray(weights, np.float64)
+    cap = len(a_ids) + len(b_ids) + 1
+    top_n = cap if top_n is None else top_n
+    ids, sc = np.zeros(cap, np.uint64), np.zeros(cap, np.float64)
+    m = load().RSGPU_HybridFuse(scoring, constant, _p(w), metric, _p(a_ids), _p(a_sc), len(a_ids), _p(b_ids), _p(b_sc),
+                                len(b_ids), window, min(top_n, cap), _p(ids), _p(sc))
+    if m < 0:
+        raise RuntimeError(V.last_error())
+    return ids[:m], sc[:m]
 
 
 def profile():
