@@ -113,6 +113,17 @@ long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *sco
 long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
                           double *dist_out);
 
+/* Union of 1..8 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
+ * contributes freq 0 (reference rqe_iterators/src/union_flat.rs:223-257,297-320).  Scoring a union hit list
+ * follows the reference's Union node: absent children add nothing, the slop divisor counts the matched
+ * children only, DISMAX takes the children's maximum.  Returns NULL on error. */
+RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists);
+/* NOT: doc ids 1..max_doc_id the child does not hold (rqe_iterators/src/not.rs:171-209), or -- with a
+ * `universe` list of existing documents -- the universe's entries <= max_doc_id the child does not hold
+ * (not_optimized.rs).  The hits are virtual results: one child with freq 1; score them with idf = 1
+ * (reference src/ext/default.c:289-293).  Returns NULL on error. */
+RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t max_doc_id);
+
 /* FT.HYBRID fusion of the ranked search list (doc ids + scores, best first) and the ranked vector list (doc ids
  * + distances, nearest first): RPHybridMerger + HybridRRFScore / HybridLinearScore
  * (reference src/result_processor.c:2549-2571,2613-2670; src/hybrid/hybrid_scoring.c:41-84) with the vector

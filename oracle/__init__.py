@@ -447,3 +447,26 @@ def hybrid_fuse(scoring, a_ids, a_scores, b_ids, b_scores, window, constant=60.0
     m = lib.oracle_hybrid_fuse(scoring, constant, weights[0], weights[1], metric, _p(a_ids), _p(a_scores), len(a_ids),
                                _p(b_ids), _p(b_scores), len(b_ids), window, _p(ids), _p(sc))
     return ids[:m].copy(), sc[:m].copy()
+
+
+_sig("oracle_union", _sz, _vp, _sz, _sz, _vp, _vp, _vp)
+_sig("oracle_not", _sz, _vp, _vp, C.c_uint64, _sz, _vp)
+
+
+def union_lists(lists):
+    """N-way OR of InvertedIndex objects -> (ids[H], freqs[N,H], masks[N,H]); absent = 0."""
+    n = len(lists)
+    cap = max(sum(l.unique_docs for l in lists), 1)
+    arr = (_vp * n)(*[l.h for l in lists])
+    ids = np.zeros(cap, np.uint64)
+    fr, mk = np.zeros((n, cap), np.uint32), np.zeros((n, cap), np.uint32)
+    h = lib.oracle_union(C.cast(arr, _vp), n, cap, _p(ids), _p(fr), _p(mk))
+    return ids[:h].copy(), fr[:, :h].copy(), mk[:, :h].copy()
+
+
+def not_list(child, max_doc_id, universe=None):
+    """Doc ids in 1..max_doc_id (or in `universe`) that `child` does not hold."""
+    cap = max(universe.unique_docs if universe is not None else max_doc_id, 1)
+    ids = np.zeros(cap, np.uint64)
+    h = lib.oracle_not(child.h, universe.h if universe is not None else None, max_doc_id, cap, _p(ids))
+    return ids[:h].copy()

@@ -284,3 +284,57 @@ size_t oracle_decode_offsets(const uint8_t *p, size_t len, uint32_t *out, size_t
   }
   return n;
 }
+
+/* ---- union and NOT over posting lists ------------------------------------------------------------------------
+ * Union (reference src/redisearch_rs/rqe_iterators/src/union_flat.rs:223-257 find the minimum doc id among
+ * the children, :297-320 aggregate every child positioned on it): documents present in ANY list, ascending;
+ * a list that does not hold the document contributes nothing (freq 0 / mask 0 in the [list][hit] layout).
+ * Returns the number of hits (stops at cap). */
+size_t oracle_union(const OInv **lists, size_t nl, size_t cap, uint64_t *ids, uint32_t *freqs, uint32_t *masks) {
+  if (!nl) return 0;
+  OReader **r = malloc(nl * sizeof *r);
+  int *live = malloc(nl * sizeof *live);
+  for (size_t i = 0; i < nl; i++) { r[i] = oreader_new(lists[i]); live[i] = oreader_next(r[i]); }
+  size_t hits = 0;
+  while (hits < cap) {
+    uint64_t min_id = UINT64_MAX;
+    for (size_t i = 0; i < nl; i++) if (live[i] && r[i]->doc < min_id) min_id = r[i]->doc;
+    if (min_id == UINT64_MAX) break;
+    ids[hits] = min_id;
+    for (size_t i = 0; i < nl; i++) {
+      int on = live[i] && r[i]->doc == min_id;
+      if (freqs) freqs[i * cap + hits] = on ? r[i]->freq : 0;
+      if (masks) masks[i * cap + hits] = on ? r[i]->mask : 0;
+      if (on) live[i] = oreader_next(r[i]);
+    }
+    hits++;
+  }
+  for (size_t i = 0; i < nl; i++) oreader_free(r[i]);
+  free(r); free(live);
+  return hits;
+}
+
+/* NOT (reference src/redisearch_rs/rqe_iterators/src/not.rs:171-209: every doc id in 1..=max_doc_id the child
+ * does not hold; not_optimized.rs: the same relative to a wildcard list of existing documents).  `universe`
+ * may be NULL.  Results are virtual (no term data). */
+size_t oracle_not(const OInv *child, const OInv *universe, uint64_t max_doc_id, size_t cap, uint64_t *ids) {
+  OReader *c = oreader_new(child), *u = universe ? oreader_new(universe) : NULL;
+  int clive = oreader_next(c);
+  size_t hits = 0;
+  if (u) {
+    while (hits < cap && oreader_next(u)) {
+      uint64_t d = u->doc;
+      if (d > max_doc_id) break;
+      while (clive && c->doc < d) clive = oreader_next(c);
+      if (!(clive && c->doc == d)) ids[hits++] = d;
+    }
+    oreader_free(u);
+  } else {
+    for (uint64_t d = 1; d <= max_doc_id && hits < cap; d++) {
+      while (clive && c->doc < d) clive = oreader_next(c);
+      if (!(clive && c->doc == d)) ids[hits++] = d;
+    }
+  }
+  oreader_free(c);
+  return hits;
+}

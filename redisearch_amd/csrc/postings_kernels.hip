@@ -180,6 +180,132 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, const 
   }
 }
 
+// ---- union / NOT --------------------------------------------------------------------------------------
+// Union of sorted lists without a sort: an element of list s is EMITTED by s iff no earlier list holds it
+// (union_flag); with the exclusive prefix counts of the emitted flags of every list (union_prefix), the
+// output slot of an emitted element x is  sum over lists t of  prefix_t[lower_bound_t(x)]  -- the number of
+// emitted elements smaller than x -- so every list writes its own elements straight to their final, doc-id
+// ordered position (union_write).  Reference: rqe_iterators/src/union_flat.rs:223-257,297-320.
+__global__ __launch_bounds__(256) void union_flag_kernel(ListView v, int s, uint8_t *__restrict__ flags,
+                                                         uint32_t *__restrict__ block_counts) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  bool emit = i < v.len[s];
+  if (emit) {
+    const uint32_t x = v.ids[s][i];
+    for (int t = 0; t < s; t++) {
+      const uint32_t p = lower_bound(v.ids[t], v.len[t], x);
+      if (p < v.len[t] && v.ids[t][p] == x) { emit = false; break; }
+    }
+    flags[i] = emit ? 1 : 0;
+  }
+  unsigned long long m = __ballot(emit);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+// prefix[i] = emitted elements before i, i in [0, len]; block_off = exclusive scan of the block counts
+__global__ __launch_bounds__(256) void union_prefix_kernel(const uint8_t *__restrict__ flags, uint32_t len,
+                                                           const uint32_t *__restrict__ block_off,
+                                                           const uint32_t *__restrict__ total,
+                                                           uint32_t *__restrict__ prefix) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool f = i < len && flags[i];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long m = __ballot(f);
+  if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t off = block_off[blockIdx.x];
+  for (uint32_t j = 0; j < w; j++) off += wave_cnt[j];
+  off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (i < len) prefix[i] = off;
+  if (i == len) prefix[len] = total[0];  // (the grid covers len + 1 slots)
+}
+
+__global__ __launch_bounds__(256) void union_write_kernel(ListView v, UnionView u, int s,
+                                                          const uint8_t *__restrict__ flags,
+                                                          uint32_t *__restrict__ out_ids,
+                                                          uint32_t *__restrict__ out_freqs, uint32_t cap) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= v.len[s] || !flags[i]) return;
+  const uint32_t x = v.ids[s][i];
+  uint32_t slot = 0, at[kMaxLists];
+  for (int t = 0; t < v.n; t++) {
+    at[t] = t == s ? i : lower_bound(v.ids[t], v.len[t], x);
+    slot += u.prefix[t][at[t]];
+  }
+  if (slot >= cap) return;
+  out_ids[slot] = x;
+  for (int t = 0; t < v.n; t++) {
+    const bool on = at[t] < v.len[t] && v.ids[t][at[t]] == x;
+    out_freqs[(size_t)t * cap + slot] = (on && v.freqs[t]) ? v.freqs[t][at[t]] : 0u;
+  }
+}
+
+// NOT (rqe_iterators/src/not.rs:171-209; not_optimized.rs with a universe list): candidate c is doc id c+1
+// (no universe) or universe[c]; it survives iff the child does not hold it, and then its slot is
+// c - (#child entries below it that are candidates themselves).  Without a universe every child entry
+// <= max_doc is a candidate, so the slot is c - lower_bound(child, doc).  With a universe the count of
+// excluded predecessors comes from the same flag / scan / write triple as the intersection.
+__global__ __launch_bounds__(256) void not_range_kernel(const uint32_t *__restrict__ child, uint32_t child_len,
+                                                        uint32_t max_doc, uint32_t *__restrict__ out_ids,
+                                                        uint32_t *__restrict__ out_freqs, uint32_t cap) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= max_doc) return;
+  const uint32_t doc = c + 1;
+  const uint32_t p = lower_bound(child, child_len, doc);
+  if (p < child_len && child[p] == doc) return;
+  const uint32_t slot = c - p;
+  if (slot < cap) {
+    out_ids[slot] = doc;
+    out_freqs[slot] = 1;  // virtual result: scored as idf = f = 1 (reference src/ext/default.c:289-293)
+  }
+}
+__global__ void count_below_kernel(const uint32_t *__restrict__ list, uint32_t len, uint64_t x, uint32_t *out) {
+  out[0] = x > 0xFFFFFFFFull ? len : lower_bound(list, len, (uint32_t)x);
+}
+__global__ __launch_bounds__(256) void not_universe_flag_kernel(const uint32_t *__restrict__ universe, uint32_t n_u,
+                                                                const uint32_t *__restrict__ child, uint32_t child_len,
+                                                                uint32_t max_doc, uint8_t *__restrict__ flags,
+                                                                uint32_t *__restrict__ block_counts) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  bool keep = i < n_u;
+  if (keep) {
+    const uint32_t doc = universe[i];
+    const uint32_t p = lower_bound(child, child_len, doc);
+    keep = doc <= max_doc && !(p < child_len && child[p] == doc);
+    flags[i] = keep ? 1 : 0;
+  }
+  unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+__global__ __launch_bounds__(256) void not_universe_write_kernel(const uint32_t *__restrict__ universe, uint32_t n_u,
+                                                                 const uint8_t *__restrict__ flags,
+                                                                 const uint32_t *__restrict__ block_off,
+                                                                 uint32_t *__restrict__ out_ids,
+                                                                 uint32_t *__restrict__ out_freqs, uint32_t cap) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool keep = i < n_u && flags[i];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long m = __ballot(keep);
+  if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (!keep) return;
+  uint32_t off = block_off[blockIdx.x];
+  for (uint32_t j = 0; j < w; j++) off += wave_cnt[j];
+  off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (off < cap) {
+    out_ids[off] = universe[i];
+    out_freqs[off] = 1;
+  }
+}
+
 // ---- scorers ---------------------------------------------------------------------------------------
 // orderable image of an fp64: ascending key <=> ascending value, NaN last
 __device__ __forceinline__ uint64_t d2key(double d) {
@@ -202,6 +328,15 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   const uint32_t dlen = known ? doc_len[id] : 0u;
   const uint32_t mfreq = (known && max_freq) ? max_freq[id] : 0u;
   double s = 0.0;
+  // IndexResult_MinOffsetDelta of offset-less children = (children in the aggregate) - 1, at least 1
+  // (reference src/index_result/index_result.c:51-103); a union's aggregate only holds the children that
+  // matched this document (union_flat.rs:297-320)
+  int slop = P.slop;
+  if (P.is_union) {
+    int matched = 0;
+    for (int t = 0; t < P.n_lists; t++) matched += freqs[(size_t)t * cap + h] ? 1 : 0;
+    slop = matched > 1 ? matched - 1 : 1;
+  }
   switch (P.scorer) {
     case 0:    // BM25STD      reference src/ext/default.c:241-316
     case 1: {  // BM25STD.TANH reference src/ext/default.c:329-359
@@ -229,7 +364,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
       ret *= P.root_weight;
       s = (double)dscore * ret;
       if (s < P.min_score) s = 0.0;
-      else s /= (double)P.slop;
+      else s /= (double)slop;
       break;
     }
     case 3:    // TFIDF         reference src/ext/default.c:109-145
@@ -241,7 +376,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
       raw *= P.root_weight;
       s = (double)dscore * raw / (double)norm;
       if (s < P.min_score) s = 0.0;
-      else s /= (double)P.slop;
+      else s /= (double)slop;
       break;
     }
     case 5:  // DOCSCORE reference src/ext/default.c:366-371
@@ -249,7 +384,10 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
       break;
     default: {  // DISMAX reference src/ext/default.c:378-461
       double ret = 0.0;
-      for (int t = 0; t < P.n_lists; t++) ret += P.weight[t] * (double)freqs[(size_t)t * cap + h];
+      for (int t = 0; t < P.n_lists; t++) {  // intersection: sum of the children; union: their maximum
+        const double c = P.weight[t] * (double)freqs[(size_t)t * cap + h];
+        ret = P.is_union ? (c > ret ? c : ret) : ret + c;
+      }
       s = P.root_weight * ret;
       break;
     }
@@ -300,6 +438,37 @@ void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out
 void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
                             uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s) {
   hipLaunchKernelGGL(intersect_write_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_off,
+                     out_ids, out_freqs, cap);
+}
+void launch_union_flag(const ListView &v, int s, uint8_t *flags, uint32_t *block_counts, hipStream_t st) {
+  hipLaunchKernelGGL(union_flag_kernel, dim3(blocks_for(v.len[s])), dim3(256), 0, st, v, s, flags, block_counts);
+}
+void launch_union_prefix(const uint8_t *flags, uint32_t len, const uint32_t *block_off, const uint32_t *total,
+                         uint32_t *prefix, hipStream_t st) {
+  hipLaunchKernelGGL(union_prefix_kernel, dim3(blocks_for(len + 1)), dim3(256), 0, st, flags, len, block_off, total, prefix);
+}
+void launch_union_write(const ListView &v, const UnionView &u, int s, const uint8_t *flags, uint32_t *out_ids,
+                        uint32_t *out_freqs, uint32_t cap, hipStream_t st) {
+  hipLaunchKernelGGL(union_write_kernel, dim3(blocks_for(v.len[s])), dim3(256), 0, st, v, u, s, flags, out_ids,
+                     out_freqs, cap);
+}
+void launch_not_range(const uint32_t *child, uint32_t child_len, uint32_t max_doc, uint32_t *out_ids,
+                      uint32_t *out_freqs, uint32_t cap, hipStream_t st) {
+  if (!max_doc) return;
+  hipLaunchKernelGGL(not_range_kernel, dim3(blocks_for(max_doc)), dim3(256), 0, st, child, child_len, max_doc, out_ids,
+                     out_freqs, cap);
+}
+void launch_count_below(const uint32_t *list, uint32_t len, uint64_t x, uint32_t *out, hipStream_t st) {
+  hipLaunchKernelGGL(count_below_kernel, dim3(1), dim3(1), 0, st, list, len, x, out);
+}
+void launch_not_universe_flag(const uint32_t *universe, uint32_t n_u, const uint32_t *child, uint32_t child_len,
+                              uint32_t max_doc, uint8_t *flags, uint32_t *block_counts, hipStream_t st) {
+  hipLaunchKernelGGL(not_universe_flag_kernel, dim3(blocks_for(n_u)), dim3(256), 0, st, universe, n_u, child, child_len,
+                     max_doc, flags, block_counts);
+}
+void launch_not_universe_write(const uint32_t *universe, uint32_t n_u, const uint8_t *flags, const uint32_t *block_off,
+                               uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st) {
+  hipLaunchKernelGGL(not_universe_write_kernel, dim3(blocks_for(n_u)), dim3(256), 0, st, universe, n_u, flags, block_off,
                      out_ids, out_freqs, cap);
 }
 void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *freqs, uint32_t len, uint32_t cap,

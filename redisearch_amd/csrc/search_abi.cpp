@@ -105,6 +105,7 @@ struct RSGPU_Hits {
   DevBuf<double> scores;
   DevBuf<uint64_t> keys;
   bool scored = false;
+  bool is_union = false;        // built by RSGPU_Union: absent lists have freq 0
   std::vector<uint32_t> h_ids;  // lazily mirrored
   const std::vector<uint32_t> &host_ids() {
     if (h_ids.size() != len) {
@@ -261,6 +262,141 @@ RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
   return guard.release();
   S_CATCH(nullptr)
 }
+// reference src/redisearch_rs/rqe_iterators/src/union_flat.rs:223-257,297-320
+RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
+  if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
+    last_error() = "RSGPU_Union: 1..8 lists";
+    return nullptr;
+  }
+  S_TRY
+  const int device = lists[0]->device;
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  auto *h = new RSGPU_Hits();
+  std::unique_ptr<RSGPU_Hits> guard(h);
+  h->device = device;
+  h->n_lists = (int)n_lists;
+  h->is_union = true;
+  std::iota(h->order, h->order + n_lists, 0);  // caller order: a union has no driving child
+  StageTimer td(c.c, 0);
+  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c.c);
+  td.stop();
+  ListView v;
+  memset(&v, 0, sizeof v);
+  v.n = (int)n_lists;
+  size_t sum = 0, max_len = 0;
+  for (size_t s = 0; s < n_lists; s++) {
+    RSGPU_Postings *p = lists[s];
+    v.ids[s] = p->ids.p;
+    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
+    v.len[s] = p->n_entries;
+    sum += p->n_entries;
+    max_len = std::max<size_t>(max_len, p->n_entries);
+  }
+  if (sum > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_Union: more than 2^32 postings");
+  h->cap = (uint32_t)std::max<size_t>(sum, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc((size_t)h->cap * n_lists);
+  if (!sum) return guard.release();
+  Scratch &sc = scratch(device);
+  // flags of all lists back to back, prefix arrays [len+1] back to back, one block-count array per list
+  sc.flags.ensure(sum);
+  sc.pos.ensure(sum + n_lists);
+  const uint32_t nb_max = (uint32_t)((max_len + 256) / 256 + 1);
+  sc.block_counts.ensure((size_t)nb_max * n_lists);
+  sc.total.ensure(n_lists);
+  UnionView u;
+  memset(&u, 0, sizeof u);
+  StageTimer ti(c.c, 1);
+  size_t foff = 0, poff = 0;
+  std::vector<size_t> flag_at(n_lists);
+  for (size_t s = 0; s < n_lists; s++) {
+    const uint32_t len = v.len[s], nb = (len + 255) / 256;
+    uint32_t *bc = sc.block_counts.p + s * nb_max;
+    flag_at[s] = foff;
+    u.prefix[s] = sc.pos.p + poff;
+    if (len) {
+      launch_union_flag(v, (int)s, sc.flags.p + foff, bc, c->stream);
+      launch_scan_counts(bc, nb, sc.total.p + s, c->stream);
+    } else {
+      HIP_CHECK(hipMemsetAsync(sc.total.p + s, 0, sizeof(uint32_t), c->stream));
+    }
+    launch_union_prefix(sc.flags.p + foff, len, bc, sc.total.p + s, sc.pos.p + poff, c->stream);
+    foff += len;
+    poff += len + 1;
+  }
+  for (size_t s = 0; s < n_lists; s++)
+    if (v.len[s]) launch_union_write(v, u, (int)s, sc.flags.p + flag_at[s], h->ids.p, h->freqs.p, h->cap, c->stream);
+  HIP_CHECK(hipGetLastError());
+  ti.stop();
+  std::vector<uint32_t> totals(n_lists);
+  HIP_CHECK(hipMemcpyAsync(totals.data(), sc.total.p, n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  for (uint32_t t : totals) total += t;
+  h->len = (uint32_t)total;
+  return guard.release();
+  S_CATCH(nullptr)
+}
+
+// reference src/redisearch_rs/rqe_iterators/src/not.rs:171-209 (1..=max_doc_id) and not_optimized.rs (universe)
+RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t max_doc_id) {
+  if (!child) {
+    last_error() = "RSGPU_Not: NULL child";
+    return nullptr;
+  }
+  S_TRY
+  if (max_doc_id > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_Not: doc ids are 32-bit on the device path");
+  if (universe && universe->device != child->device) throw std::runtime_error("RSGPU_Not: lists on different devices");
+  const int device = child->device;
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  auto *h = new RSGPU_Hits();
+  std::unique_ptr<RSGPU_Hits> guard(h);
+  h->device = device;
+  h->n_lists = 1;  // one virtual child: freq 1; the caller scores it with idf = 1 (src/ext/default.c:289-293)
+  h->order[0] = 0;
+  StageTimer td(c.c, 0);
+  decode_on(child, c.c);
+  if (universe) decode_on(universe, c.c);
+  td.stop();
+  const uint32_t max_doc = (uint32_t)max_doc_id;
+  const uint32_t n_cand = universe ? universe->n_entries : max_doc;
+  h->cap = std::max<uint32_t>(n_cand, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc(h->cap);
+  if (!n_cand) return guard.release();
+  Scratch &sc = scratch(device);
+  StageTimer ti(c.c, 1);
+  uint32_t total = 0;
+  if (!universe) {
+    // survivors = max_doc - (child entries <= max_doc); slots are computed per document, no scan needed
+    launch_not_range(child->ids.p, child->n_entries, max_doc, h->ids.p, h->freqs.p, h->cap, c->stream);
+    HIP_CHECK(hipGetLastError());
+    ti.stop();
+    sc.total.ensure(1);
+    launch_count_below(child->ids.p, child->n_entries, max_doc_id + 1, sc.total.p, c->stream);
+    uint32_t below = 0;
+    HIP_CHECK(hipMemcpy(&below, sc.total.p, sizeof below, hipMemcpyDeviceToHost));
+    total = max_doc - below;
+  } else {
+    const uint32_t nb = (n_cand + 255) / 256;
+    sc.flags.ensure(n_cand);
+    sc.block_counts.ensure(nb);
+    sc.total.ensure(1);
+    launch_not_universe_flag(universe->ids.p, n_cand, child->ids.p, child->n_entries, max_doc, sc.flags.p,
+                             sc.block_counts.p, c->stream);
+    launch_scan_counts(sc.block_counts.p, nb, sc.total.p, c->stream);
+    launch_not_universe_write(universe->ids.p, n_cand, sc.flags.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap,
+                              c->stream);
+    HIP_CHECK(hipGetLastError());
+    ti.stop();
+    HIP_CHECK(hipMemcpy(&total, sc.total.p, sizeof total, hipMemcpyDeviceToHost));
+  }
+  h->len = total;
+  return guard.release();
+  S_CATCH(nullptr)
+}
 void RSGPU_Hits_Free(RSGPU_Hits *h) { delete h; }
 size_t RSGPU_Hits_Len(const RSGPU_Hits *h) { return h ? h->len : 0; }
 
@@ -314,6 +450,7 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   // IndexResult_MinOffsetDelta over children without offsets returns num-1 (reference
   // src/index_result/index_result.c:102), 1 for a single child
   P.slop = h->n_lists > 1 ? h->n_lists - 1 : 1;
+  P.is_union = h->is_union ? 1 : 0;
   for (int s = 0; s < h->n_lists; s++) {
     int o = h->order[s];
     P.idf[s] = a->idf ? a->idf[o] : 0.0;

@@ -37,11 +37,31 @@ void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out
 void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
                             uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s);
 
+// union: the lists' emitted-prefix arrays ([len+1] each); see postings_kernels.hip "union / NOT"
+struct UnionView {
+  const uint32_t *prefix[kMaxLists];
+};
+void launch_union_flag(const ListView &v, int s, uint8_t *flags, uint32_t *block_counts, hipStream_t st);
+void launch_union_prefix(const uint8_t *flags, uint32_t len, const uint32_t *block_off, const uint32_t *total,
+                         uint32_t *prefix, hipStream_t st);
+void launch_union_write(const ListView &v, const UnionView &u, int s, const uint8_t *flags, uint32_t *out_ids,
+                        uint32_t *out_freqs, uint32_t cap, hipStream_t st);
+// NOT: doc ids 1..max_doc (or the entries of `universe`) the child does not hold, freq 1 (virtual results)
+void launch_not_range(const uint32_t *child, uint32_t child_len, uint32_t max_doc, uint32_t *out_ids,
+                      uint32_t *out_freqs, uint32_t cap, hipStream_t st);
+// out[0] = number of entries of the sorted list below x
+void launch_count_below(const uint32_t *list, uint32_t len, uint64_t x, uint32_t *out, hipStream_t st);
+void launch_not_universe_flag(const uint32_t *universe, uint32_t n_u, const uint32_t *child, uint32_t child_len,
+                              uint32_t max_doc, uint8_t *flags, uint32_t *block_counts, hipStream_t st);
+void launch_not_universe_write(const uint32_t *universe, uint32_t n_u, const uint8_t *flags, const uint32_t *block_off,
+                               uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st);
+
 struct ScoreParams {
   int scorer, n_lists;
   double avg_doc_len, root_weight, min_score, inv_tanh;
   double idf[kMaxLists], bm25_idf[kMaxLists], weight[kMaxLists];
   int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_lists-1, 1)
+  int is_union;  // hits come from RSGPU_Union: per-hit slop from the matched children, DISMAX takes the maximum
 };
 // scores[h] (fp64) and keys[h] = descending-score orderable u64 (for the top-N select)
 void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *freqs, uint32_t len, uint32_t cap,

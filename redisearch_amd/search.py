@@ -33,6 +33,8 @@ ABI = {
     "RSGPU_Hits_Score": (_i, [_vp, _vp, C.POINTER(ScoreArgs), _vp]),
     "RSGPU_Hits_TopN": (C.c_long, [_vp, _sz, _vp, _vp]),
     "RSGPU_Hits_KnnRerank": (C.c_long, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_Union": (_vp, [_vp, _sz]),
+    "RSGPU_Not": (_vp, [_vp, _vp, C.c_uint64]),
     "RSGPU_HybridFuse": (C.c_long, [_i, _dbl, _vp, _i, _vp, _vp, _sz, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "RSGPU_CalculateIDF": (_dbl, [_sz, _sz]),
     "RSGPU_CalculateIDF_BM25": (_dbl, [_sz, _sz]),
@@ -124,11 +126,17 @@ class DocTable:
 
 
 class Hits:
-    def __init__(self, lists):
+    def __init__(self, lists, op="and", universe=None, max_doc_id=0):
         self.lib = load()
+        if op == "not":
+            self.n_lists = 1
+            self.ptr = _check(self.lib.RSGPU_Not(lists[0].ptr, universe.ptr if universe is not None else None,
+                                                 max_doc_id), "RSGPU_Not")
+            return
         self.n_lists = len(lists)
         arr = (_vp * len(lists))(*[l.ptr for l in lists])
-        self.ptr = _check(self.lib.RSGPU_Intersect(C.cast(arr, _vp), len(lists)), "RSGPU_Intersect")
+        fn = self.lib.RSGPU_Intersect if op == "and" else self.lib.RSGPU_Union
+        self.ptr = _check(fn(C.cast(arr, _vp), len(lists)), "RSGPU_Intersect" if op == "and" else "RSGPU_Union")
 
     def __len__(self):
         return self.lib.RSGPU_Hits_Len(self.ptr)
@@ -175,6 +183,14 @@ class Hits:
 
 def intersect(lists):
     return Hits(lists)
+
+
+def union(lists):
+    return Hits(lists, op="or")
+
+
+def negate(child, max_doc_id, universe=None):
+    return Hits([child], op="not", universe=universe, max_doc_id=max_doc_id)
 
 
 def calculate_idf(total, term):
