@@ -52,6 +52,7 @@ struct ScanTuning {
   int nontemporal = 1;     // stream the corpus with nt loads
   int gemm_dma = 1;        // batched path: 1 LDS-DMA ring KC=8 (default), 0 register-staged, 2/3 experiments
   int filter_select = 1;   // small-K top-K: sample threshold + one filter pass (0 = radix levels only)
+  int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int num_cus = 256;
 };

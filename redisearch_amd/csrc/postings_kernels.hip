@@ -32,22 +32,20 @@ CodecDesc codec_desc(int codec) {
 namespace {
 
 // ---- decode ----------------------------------------------------------------------------------------
+// Records are variable-length and delta-coded, so a block is decoded sequentially by ONE lane -- but the 64
+// blocks of a wavefront are consecutive in the byte stream, so the wavefront first copies its whole byte
+// range into LDS with coalesced 16-byte loads and every lane then parses its block out of LDS (a lane
+// reading its bytes straight from global memory costs one cache-line lookup per byte and lane:
+// 94 GB/s of encoded bytes, profiles/r01_hybrid_config5_stages.json).  A wavefront whose byte range does
+// not fit (huge offset vectors) parses from global memory as before.
 // One kernel per record kind (0 qint, 1 varint delta, 2 raw u32 delta): keeping the three decoders in
 // one body made hipcc (ROCm 7.2) drop the cursor advance of the raw path.
-template <int KIND>
-__global__ __launch_bounds__(256) void decode_blocks_kernel(CodecDesc cd, const uint8_t *__restrict__ bytes,
-                                                            const uint64_t *__restrict__ byte_off,
-                                                            const uint32_t *__restrict__ first,
-                                                            const uint32_t *__restrict__ nent,
-                                                            const uint32_t *__restrict__ entry_off, uint32_t n_blocks,
-                                                            uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
-                                                            uint32_t *__restrict__ masks) {
-  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= n_blocks) return;
-  const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
-  const uint32_t n = nent[b], f0 = first[b];
-  uint32_t out = entry_off[b];
-  uint64_t pos = beg;
+constexpr uint32_t kDecodeLds = 30 * 1024;  // bytes of encoded input staged per wavefront (5 wavefronts per CU)
+
+template <int KIND, typename Bytes>
+__device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes bytes, uint32_t pos, uint32_t fin,
+                                                 uint32_t n, uint32_t f0, uint32_t out, uint32_t *__restrict__ ids,
+                                                 uint32_t *__restrict__ freqs, uint32_t *__restrict__ masks) {
   uint32_t base = f0;
   for (uint32_t e = 0; e < n && pos < fin; e++, out++) {
     uint32_t freq = 0, mask = 0;
@@ -89,6 +87,37 @@ __global__ __launch_bounds__(256) void decode_blocks_kernel(CodecDesc cd, const 
     if (freqs) freqs[out] = freq;
     if (masks) masks[out] = mask;
   }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const uint8_t *__restrict__ bytes,
+                                                           const uint64_t *__restrict__ byte_off,
+                                                           const uint32_t *__restrict__ first,
+                                                           const uint32_t *__restrict__ nent,
+                                                           const uint32_t *__restrict__ entry_off, uint32_t n_blocks,
+                                                           uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
+                                                           uint32_t *__restrict__ masks) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kDecodeLds];
+  const uint32_t b0 = blockIdx.x * 64, lane = threadIdx.x;
+  const uint32_t nb = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
+  const uint64_t w_beg = byte_off[b0] & ~15ull, w_end = byte_off[b0 + nb];  // 16-byte aligned start
+  const bool staged = w_end - w_beg <= kDecodeLds;                           // wave-uniform
+  if (staged) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint32_t span = (uint32_t)(w_end - w_beg);
+    for (uint32_t o = lane * 16; o < span; o += 64 * 16)  // (the byte buffer carries 16 bytes of slack)
+      *reinterpret_cast<u4 *>(stage + o) = *reinterpret_cast<const u4 *>(bytes + w_beg + o);
+  }
+  __syncthreads();
+  const uint32_t b = b0 + lane;
+  if (lane >= nb) return;
+  const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
+  if (staged)
+    decode_one_block<KIND>(cd, (const uint8_t *)stage, (uint32_t)(beg - w_beg), (uint32_t)(fin - w_beg), nent[b],
+                           first[b], entry_off[b], ids, freqs, masks);
+  else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
+    decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), nent[b], first[b], entry_off[b], ids, freqs,
+                           masks);
 }
 
 // ---- intersection ----------------------------------------------------------------------------------
@@ -422,7 +451,7 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           uint32_t *freqs, uint32_t *masks, hipStream_t s) {
   if (!n_blocks) return;
 #define RSGPU_DECODE(K)                                                                                         \
-  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3(blocks_for(n_blocks)), dim3(256), 0, s, cd, bytes, byte_off, first, \
+  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + 63) / 64), dim3(64), 0, s, cd, bytes, byte_off, first, \
                      nent, entry_off, n_blocks, ids, freqs, masks)
   if (cd.kind == 0) RSGPU_DECODE(0);
   else if (cd.kind == 1) RSGPU_DECODE(1);

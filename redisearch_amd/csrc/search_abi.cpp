@@ -15,23 +15,81 @@ namespace {
 
 thread_local double prof_ms[5] = {0, 0, 0, 0, 0};  // decode, intersect, score, topn, knn
 
+// Device buffers of the hit lists come and go with every query: hipMalloc costs tens of microseconds and
+// hipFree synchronises the whole device, so freed buffers are parked in a per-device pool by power-of-two size
+// class (at most kPoolCap bytes parked; beyond that they really are freed).
+class DevPool {
+ public:
+  static DevPool &get() {
+    static DevPool *p = new DevPool();  // leaked on purpose: outlives static destructors
+    return *p;
+  }
+  static size_t size_class(size_t bytes) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  void *take(size_t bytes, size_t *got) {
+    const size_t c = size_class(bytes);
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      auto &v = free_[key(dev, c)];
+      if (!v.empty()) {
+        void *p = v.back();
+        v.pop_back();
+        parked_ -= c;
+        *got = c;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    HIP_CHECK(hipMalloc(&p, c));
+    *got = c;
+    return p;
+  }
+  void give(void *p, size_t cls) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (parked_ + cls <= kPoolCap) {
+        free_[key(dev, cls)].push_back(p);
+        parked_ += cls;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+
+ private:
+  static constexpr size_t kPoolCap = 4ull << 30;
+  static uint64_t key(int dev, size_t c) { return ((uint64_t)dev << 56) | (uint64_t)c; }
+  std::mutex mu_;
+  std::unordered_map<uint64_t, std::vector<void *>> free_;
+  size_t parked_ = 0;
+};
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  size_t cls = 0;  // pool size class in bytes
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { reset(); }
   void reset() {
-    if (p) (void)hipFree(p);
+    if (p) DevPool::get().give(p, cls);
     p = nullptr;
     n = 0;
+    cls = 0;
   }
   void alloc(size_t count) {
     reset();
     if (!count) count = 1;
-    HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    p = static_cast<T *>(DevPool::get().take(count * sizeof(T), &cls));
     n = count;
   }
   void ensure(size_t count) {
@@ -63,11 +121,19 @@ Scratch &scratch(int device) {
   return s;
 }
 
+// per-stage device time; only when profiling is on (RSGPU_SetProfiling): each stop() synchronises the stream
 struct StageTimer {
   QueryCtx *c;
   int slot;
-  StageTimer(QueryCtx *ctx, int s) : c(ctx), slot(s) { HIP_CHECK(hipEventRecord(c->ev0, c->stream)); }
+  bool on;
+  StageTimer(QueryCtx *ctx, int s) : c(ctx), slot(s), on(scan_profile().enabled.load(std::memory_order_relaxed) != 0) {
+    if (on) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  }
   void stop() {
+    if (!on) {  // the stage boundary stays a synchronisation point: results are read on other streams / the host
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      return;
+    }
     HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     HIP_CHECK(hipEventSynchronize(c->ev1));
     float ms = 0;
@@ -95,6 +161,11 @@ struct RSGPU_Postings {
   DevBuf<uint64_t> byte_off;
   DevBuf<uint32_t> first, nent, entry_off;
   DevBuf<uint32_t> ids, freqs, masks;  // decode targets
+  // A list is immutable after upload, so its decoded arrays stay valid: with cache_decoded (default) the
+  // decode kernel runs once, at the first query that touches the list, and HBM keeps both forms
+  // (8-12 B per posting decoded next to ~3 B encoded).
+  std::mutex decode_mu;
+  std::atomic<bool> decoded{false};
 };
 
 struct RSGPU_Hits {
@@ -132,7 +203,18 @@ struct RSGPU_DocTable {
     return failval;                              \
   }
 
-static void decode_on(RSGPU_Postings *p, QueryCtx *c) {
+static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
+  if (scan_tuning().cache_decoded && !force) {
+    if (p->decoded.load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> g(p->decode_mu);
+    if (p->decoded.load(std::memory_order_relaxed)) return;
+    launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
+                         p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));  // other queries read the arrays from their own streams
+    p->decoded.store(true, std::memory_order_release);
+    return;
+  }
   launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
                        p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
   HIP_CHECK(hipGetLastError());
@@ -185,7 +267,12 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
   HIP_CHECK(hipSetDevice(p->device));
   CtxLease c(p->device);
   StageTimer t(c.c, 0);
-  decode_on(p, c.c);
+  {  // an explicit decode request always runs the kernel (it is how the decode stage is measured)
+    std::lock_guard<std::mutex> g(p->decode_mu);
+    decode_on(p, c.c, true);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    p->decoded.store(true, std::memory_order_release);
+  }
   t.stop();
   const uint32_t n = p->n_entries;
   if (doc_ids_out && n) {

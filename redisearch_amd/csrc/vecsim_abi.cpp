@@ -539,6 +539,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_dma")) scan_tuning().gemm_dma = value;
   else if (!strcmp(key, "filter_select")) scan_tuning().filter_select = value;
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
+  else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
   else return -1;
   return 0;
 }
