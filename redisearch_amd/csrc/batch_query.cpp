@@ -87,8 +87,31 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     const bool small = n <= (1u << 19);
     uint32_t n0 = small ? n : std::min<uint32_t>(std::max<uint32_t>(round_up(n / 64, 256), 1u << 16), 1u << 18);
     n0 = std::max<uint32_t>(n0, std::min<uint32_t>(n, (uint32_t)round_up((size_t)kk * 8, 256)));
-    const uint32_t cand_cap =
-        small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, 4ull * kk * ((n + n0 - 1) / n0)));
+    // query-stationary filter pass (gemm_qs_kernels.hip) with PROGRESSIVE thresholds: tau comes from a small
+    // sample first, the pass over the first 1/16 of the corpus re-derives it from the candidates it found
+    // (the exact k-th distance of those rows), the pass over the next 3/16 does it again, and the last
+    // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
+    // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
+    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
+    std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
+    if (use_qs) {
+      n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
+      if (n >= (1u << 23)) phase_end = {(n / 16) & ~31u, (n / 4) & ~31u, n};
+      else if (n >= (1u << 21)) phase_end = {(n / 8) & ~31u, n};
+      else phase_end = {n};
+    }
+    uint64_t expect_total = 4ull * kk * ((n + n0 - 1) / n0);
+    if (use_qs) {
+      expect_total = 0;
+      uint32_t seen = n0, from = 0;
+      for (uint32_t e : phase_end) {
+        expect_total += (uint64_t)kk * (e - from + seen - 1) / seen + kk;
+        seen = std::max(seen, e);
+        from = e;
+      }
+      expect_total *= 6;
+    }
+    const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
     sc.queries.ensure((size_t)kBatch * stride_);
     sc.tau.ensure(kBatch);
     sc.cand_count.ensure(kBatch);
@@ -98,15 +121,20 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     sc.out_keys.ensure((size_t)kBatch * kk);
     sc.out_n.ensure(kBatch);
     sc.cand.ensure((size_t)kBatch * cand_cap);
-    // query-stationary filter pass: per-(workgroup, query, lane half) sub-lists, 8x the expected length
-    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
-    const uint32_t qs_grid = use_qs ? gemm_qs_grid(n) : 0;
-    uint32_t sub_cap = 32;
+    // per-(workgroup, query, lane half) sub-lists of a pass, 8x the expected length of the fullest pass
+    uint32_t sub_cap = 32, qs_grid_max = 0;
     if (use_qs) {
-      const uint64_t expect = (uint64_t)kk * ((n + n0 - 1) / n0) / (2ull * qs_grid) + 1;
-      while (sub_cap < 8 * expect) sub_cap *= 2;
-      sc.sub_count.ensure((size_t)qs_grid * kBatch * 2);
-      sc.sub_cand.ensure((size_t)qs_grid * kBatch * 2 * sub_cap);
+      uint32_t seen = n0, from = 0;
+      for (uint32_t e : phase_end) {
+        const uint32_t grid = gemm_qs_grid(e - from);
+        qs_grid_max = std::max(qs_grid_max, grid);
+        const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
+        while (sub_cap < 8 * expect) sub_cap *= 2;
+        seen = std::max(seen, e);
+        from = e;
+      }
+      sc.sub_count.ensure((size_t)qs_grid_max * kBatch * 2);
+      sc.sub_cand.ensure((size_t)qs_grid_max * kBatch * 2 * sub_cap);
     }
     std::vector<uint8_t> hq((size_t)kBatch * stride_);
     std::vector<uint32_t> h_rows((size_t)kBatch * kk), h_keys((size_t)kBatch * kk), h_n(kBatch), h_over(kBatch);
@@ -134,10 +162,18 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
         if (use_qs) {
-          launch_gemm_qs(ktype, d_rows_, sc.queries.p, stride16, 0, n, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
-                         c->stream);
-          launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, qs_grid, sc.cand_count.p, sc.cand.p, cand_cap,
-                              c->stream);
+          uint32_t from = 0;
+          for (size_t ph = 0; ph < phase_end.size(); ph++) {
+            const uint32_t e = phase_end[ph];
+            launch_gemm_qs(ktype, d_rows_, sc.queries.p, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p,
+                           sub_cap, c->stream);
+            launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
+                                sc.cand.p, cand_cap, ph > 0, c->stream);
+            if (ph + 1 < phase_end.size())
+              launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
+                                          c->stream);
+            from = e;
+          }
         } else {
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);

@@ -417,8 +417,8 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
     uint32_t kk = (k == 0) ? 0u : (uint32_t)(hi >> 32);
     if (q >= s.n_valid) {
       s.tau_out[q] = __uint_as_float(0xff800000u);
-    } else if (take_all) {  // fewer than k elements in the sample: no bound
-      s.tau_out[q] = __uint_as_float(0x7f800000u);
+    } else if (take_all) {  // fewer than k elements: no (new) bound
+      if (!PAIRS) s.tau_out[q] = __uint_as_float(0x7f800000u);
     } else {
       uint32_t u = (kk & 0x80000000u) ? (kk ^ 0x80000000u) : ~kk;
       s.tau_out[q] = __uint_as_float(u);
@@ -484,6 +484,16 @@ void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint3
                             uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride) {
   BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid, stride};
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
+}
+
+// tightening: tau[q] = k-th smallest distance among the candidates collected so far (all of them are <= the
+// old tau, so the new one can only be smaller; a query with fewer than k candidates keeps its bound)
+void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
+                                 uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
+                                 hipStream_t s) {
+  BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, tau_inout, nullptr, nullptr, nullptr, 0, overflow,
+             n_valid, 1};
+  hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,

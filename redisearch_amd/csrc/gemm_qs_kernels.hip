@@ -299,7 +299,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
 __global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__restrict__ sub_count,
                                                            const uint2 *__restrict__ sub_cand, uint32_t sub_cap,
                                                            uint32_t n_wg, uint32_t *__restrict__ cand_count,
-                                                           uint2 *__restrict__ cand, uint32_t cand_cap) {
+                                                           uint2 *__restrict__ cand, uint32_t cand_cap, int append) {
   __shared__ uint32_t offs[513];
   __shared__ uint32_t over;
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -318,8 +318,10 @@ __global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__res
   if (tid == 0)
     for (uint32_t i = 1; i <= 512; i++) offs[i] += offs[i - 1];
   __syncthreads();
+  const uint32_t base = append ? cand_count[q] : 0;  // (every thread reads it before thread 0 rewrites it below)
   const uint32_t total = offs[512];
-  if (total > cand_cap) {
+  __syncthreads();
+  if (base > cand_cap || total > cand_cap - base) {
     if (tid == 0) cand_count[q] = cand_cap + 1;
     return;
   }
@@ -329,10 +331,10 @@ __global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__res
     const uint2 *src = sub_cand + (((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap;
     for (uint32_t i = lane; i < cnt; i += 64) {
       const uint2 e = src[i];
-      cand[(size_t)q * cand_cap + beg + i] = make_uint2(e.x, f2key(__uint_as_float(e.y)));
+      cand[(size_t)q * cand_cap + base + beg + i] = make_uint2(e.x, f2key(__uint_as_float(e.y)));
     }
   }
-  if (tid == 0) cand_count[q] = over ? cand_cap + 1 : total;
+  if (tid == 0) cand_count[q] = over ? cand_cap + 1 : base + total;
 }
 
 template <int DT, int KS, int NS>
@@ -377,9 +379,9 @@ bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t s
 }
 
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
-                         uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s) {
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s) {
   hipLaunchKernelGGL(compact_cand_kernel, dim3(256), dim3(256), 0, s, sub_count, (const uint2 *)sub_cand, sub_cap, n_wg,
-                     cand_count, (uint2 *)cand, cand_cap);
+                     cand_count, (uint2 *)cand, cand_cap, append);
 }
 
 }  // namespace rsgpu

@@ -109,8 +109,9 @@ uint32_t gemm_qs_grid(uint32_t n_rows);
 bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                     uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
                     hipStream_t s);
+// append != 0: the sub-lists are appended behind the cand_count[q] candidates already there
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
-                         uint32_t *cand_count, void *cand, uint32_t cand_cap, hipStream_t s);
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s);
 // per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
 // (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
@@ -123,6 +124,10 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
 // counting in cand_count[0]
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
                         uint32_t cap, hipStream_t s);
+// per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k)
+void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
+                                 uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
+                                 hipStream_t s);
 // per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);

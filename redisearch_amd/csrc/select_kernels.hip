@@ -374,12 +374,38 @@ __global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__rest
       mn = mn < a ? mn : a;
     }
     if (__ballot(mn <= max_key)) {
+      // one atomic per wavefront and step: lanes count their own hits, a shuffle scan hands out the slots
+      uint32_t mine = 0;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const uint32_t idx = b0 + u * 256 + threadIdx.x;
-        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        if (idx < n4)
+          mine += (v[u].x <= max_key ? 1u : 0u) + (v[u].y <= max_key ? 1u : 0u) + (v[u].z <= max_key ? 1u : 0u) +
+                  (v[u].w <= max_key ? 1u : 0u);
+      }
+      uint32_t incl = mine;
 #pragma unroll
-        for (int j = 0; j < 4; j++) append(idx < n4 && w[j] <= max_key, idx * 4 + j, w[j]);
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += t;
+      }
+      const uint32_t total = __shfl(incl, 63, 64);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cand_count, total);
+      base = __shfl(base, 0, 64);
+      if (mine) {
+        uint32_t slot = base + incl - mine;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t idx = b0 + u * 256 + threadIdx.x;
+          const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (idx < n4 && w[j] <= max_key) {
+              if (slot < cap) cand[slot] = make_uint2(idx * 4 + j, w[j]);
+              slot++;
+            }
+        }
       }
     }
   }

@@ -30,7 +30,7 @@ def reference_topk(x, q, k, metric):
 
 
 @pytest.mark.parametrize("n", [262_144, 300_001, 1_000_000])
-@pytest.mark.parametrize("k", [1, 10, 32, 33, 128, 1024])  # 32|33: sample size switch; >128: radix levels only
+@pytest.mark.parametrize("k", [1, 10, 16, 17, 128, 1024])  # <= 16: threshold filter; above: radix levels only
 def test_filter_path_matches_radix_path_and_reference(n, k):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
@@ -52,7 +52,7 @@ def test_filter_path_matches_radix_path_and_reference(n, k):
 
 def test_adversarial_orders_and_overflow_fallback():
     dev = torch.device("cuda", 0)
-    n, dim, k = 400_000, 8, 17
+    n, dim, k = 400_000, 8, 13
     ramp = torch.linspace(0, 1, n, device=dev)[:, None].repeat(1, dim)
     q = np.zeros(dim, dtype=np.float32)
     for x, expect in ((ramp, list(range(1, k + 1))),                       # best rows first
