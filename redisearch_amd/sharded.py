@@ -1,6 +1,6 @@
 """Row-sharded FLAT KNN across the GPUs of one node: one process per GPU, each rank holds a
 contiguous label range of the corpus; a query runs on every shard and the per-shard top-k
-(fp32 score, u64 label) are exchanged with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU
+(fp32 score, u64 label) are exchanged with ONE all-gather of k*(8+8) bytes per rank (RCCL over xGMI on GPUs, gloo in the CPU
 tests) and merged -- the collective analogue of the reference coordinator's per-shard top-K -> heap
 merge (reference src/module.c:3541-3547).  The payload is k*12 bytes per rank, so the
 exchange is latency-bound; nothing is reduced.
@@ -31,13 +31,19 @@ class ShardedTopK:
         self.torch, self.dist = torch, dist
         self.local_topk, self.k, self.group = local_topk, k, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.all_s = torch.empty(k * self.world, dtype=torch.float32, device=device)
-        self.all_l = torch.empty(k * self.world, dtype=torch.int64, device=device)
+        # one collective per query: labels and the fp32 score bits travel in the same int64 buffer
+        self.pack = torch.empty(2 * k, dtype=torch.int64, device=device)
+        self.all_p = torch.empty(2 * k * self.world, dtype=torch.int64, device=device)
 
     def query(self, q):
         s, l = self.local_topk(q, self.k)
-        if self.world > 1:
-            self.dist.all_gather_into_tensor(self.all_s, s, group=self.group)
-            self.dist.all_gather_into_tensor(self.all_l, l, group=self.group)
-            s, l = self.all_s, self.all_l
-        return merge_topk(s.cpu().numpy(), l.cpu().numpy().view(np.uint64), self.k)
+        if self.world == 1:
+            return merge_topk(s.cpu().numpy(), l.cpu().numpy().view(np.uint64), self.k)
+        k = self.k
+        self.pack[:k] = l
+        self.pack[k:] = s.view(self.torch.int32)
+        self.dist.all_gather_into_tensor(self.all_p, self.pack, group=self.group)
+        ap = self.all_p.cpu().numpy().reshape(self.world, 2, k)
+        labels = np.ascontiguousarray(ap[:, 0, :]).ravel().view(np.uint64)
+        scores = np.ascontiguousarray(ap[:, 1, :]).astype(np.int32).ravel().view(np.float32)
+        return merge_topk(scores, labels, k)
