@@ -103,6 +103,7 @@ def main():
     for kv in a.tuning:
         key, val = kv.split("=")
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
+    two_stage = any(kv.replace(" ", "") == "shadow16=1" for kv in a.tuning)
 
     # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
     rows, dim, k = a.rows, a.dim, a.k
@@ -199,16 +200,20 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "scan_kernel<f32,IP,G=64,ITERS=3,U=8> (FLAT scan)", "launches": int(launches),
+                "kernel": ("scan_kernel<f16,IP,G=64,ITERS=2,U=4> over the fp16 shadow (two-stage exact scan)" if two_stage
+                           else "scan_kernel<f32,IP,G=64,ITERS=3,U=8> (FLAT scan)"), "launches": int(launches),
                 "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
+        if two_stage:  # opt-in experiment (--tuning shadow16=1), never the default line
+            out["config"]["two_stage_fp16_shadow"] = ("scan of an fp16 shadow + error-bounded filter + fp32 re-scoring of the "
+                                                      "survivors: results bit-identical to the fp32 scan; roofline bytes = shadow bytes")
         # HBM traffic of the scan kernel from the committed PMC pass (separate rocprofv3 --pmc runs of
         # this same command, corrected as MI355X_MICROARCH.md prescribes); bench.py cannot read PMCs itself
         pmc = os.path.join(ROOT, "profiles", "r01_scan_pmc_hbm_traffic.json")
         if os.path.exists(pmc):
             p = json.load(open(pmc))
-            if p.get("rows") == rows and p.get("dim") == dim:
+            if p.get("rows") == rows and p.get("dim") == dim and not two_stage:
                 out["roofline"]["traffic"] = p["traffic_bytes_per_launch"]
                 out["roofline"]["traffic_source"] = "profiles/r01_scan_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)"
         if world == 1 and not a.no_cpu_baseline:

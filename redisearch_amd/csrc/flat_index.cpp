@@ -275,6 +275,8 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   key_bytes = key_bytes_of(ktype);
   elem_bytes_ = dim * type_size(type);
   stride_ = round_up(elem_bytes_, 16);
+  shadow_ = scan_tuning().shadow16 && type == VecSimType_FLOAT32 && metric == VecSimMetric_Cosine && !multi;
+  sstride_ = shadow_ ? round_up(dim * 2, 16) : 0;
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
   hipDeviceProp_t prop;
@@ -294,12 +296,13 @@ FlatIndex::~FlatIndex() {
   HIP_IGNORE(hipStreamSynchronize(wstream_));
   if (d_rows_) HIP_IGNORE(hipFree(d_rows_));
   if (d_labels_) HIP_IGNORE(hipFree(d_labels_));
+  if (d_shadow_) HIP_IGNORE(hipFree(d_shadow_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
   HIP_IGNORE(hipStreamDestroy(wstream_));
 }
 
 size_t FlatIndex::memory() const {
-  return cap_rows_ * (stride_ + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
+  return cap_rows_ * (stride_ + sstride_ + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
          (single_map_.size() + multi_map_.size()) * 48;
 }
 
@@ -315,6 +318,11 @@ void FlatIndex::grow(size_t min_rows) {
   // 32 rows of slack behind the capacity: the batched filter pass reads its ragged last tile whole
   HIP_CHECK(hipMalloc((void **)&nr, (new_cap + 32) * stride_));
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
+  uint8_t *ns = nullptr;
+  if (shadow_) {
+    HIP_CHECK(hipMalloc((void **)&ns, (new_cap + 32) * sstride_));
+    if (n_rows_) HIP_CHECK(hipMemcpyAsync(ns, d_shadow_, (size_t)n_rows_ * sstride_, hipMemcpyDeviceToDevice, wstream_));
+  }
   if (n_rows_) {
     HIP_CHECK(hipMemcpyAsync(nr, d_rows_, (size_t)n_rows_ * stride_, hipMemcpyDeviceToDevice, wstream_));
     HIP_CHECK(hipMemcpyAsync(nl, d_labels_, (size_t)n_rows_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
@@ -322,6 +330,11 @@ void FlatIndex::grow(size_t min_rows) {
   }
   if (d_rows_) HIP_CHECK(hipFree(d_rows_));
   if (d_labels_) HIP_CHECK(hipFree(d_labels_));
+  if (shadow_) {
+    if (!n_rows_) HIP_CHECK(hipStreamSynchronize(wstream_));
+    if (d_shadow_) HIP_CHECK(hipFree(d_shadow_));
+    d_shadow_ = ns;
+  }
   d_rows_ = nr;
   d_labels_ = nl;
   cap_rows_ = new_cap;
@@ -394,6 +407,8 @@ void FlatIndex::flush() {
   HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)n_rows_ * stride_, h_stage_, stage_n_ * stride_, hipMemcpyHostToDevice, wstream_));
   HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + n_rows_, stage_n_ * sizeof(uint64_t),
                            hipMemcpyHostToDevice, wstream_));
+  if (shadow_)
+    launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, n_rows_, (uint32_t)(n_rows_ + stage_n_), d_shadow_, sstride_, wstream_);
   HIP_CHECK(hipStreamSynchronize(wstream_));
   n_rows_ += (uint32_t)stage_n_;
   stage_n_ = 0;
@@ -441,6 +456,9 @@ int FlatIndex::remove(size_t label) {
       HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)r * stride_, d_rows_ + (size_t)last * stride_, stride_,
                                hipMemcpyDeviceToDevice, wstream_));
       HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
+      if (shadow_)
+        HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
+                                 hipMemcpyDeviceToDevice, wstream_));
       row_label_[r] = moved;
       if (multi) {
         auto &v = multi_map_[moved];
@@ -473,6 +491,8 @@ int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_labe
   }
   if (metric == VecSimMetric_Cosine && kmetric == KM_IP)
     launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
+  if (shadow_)
+    launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, n_rows_, (uint32_t)(n_rows_ + n), d_shadow_, sstride_, wstream_);
   size_t old = row_label_.size();
   row_label_.resize(old + n);
   for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
@@ -513,7 +533,7 @@ VecSimIndexBasicInfo FlatIndex::basic_info() const {
 
 // ---- query building blocks ---------------------------------------------------------------------------
 void FlatIndex::upload_query(QueryCtx *c, const void *blob, bool normalize) {
-  c->ensure_query(stride_ + 16);
+  c->ensure_query(round_up(stride_ + 16, 16) + sstride_);  // (+ room for the fp16 copy of a two-stage scan)
   memset(c->h_query, 0, stride_);
   memcpy(c->h_query, blob, elem_bytes_);
   if (normalize && metric == VecSimMetric_Cosine) normalize_host(c->h_query);
@@ -643,6 +663,63 @@ void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, 
   radix_select(c, c->d_keys, key_bytes, n, k, lower, out, upper);
 }
 
+// Two-stage exact top-K over an fp16 shadow (FLOAT32 cosine indexes created with ScanTuning::shadow16).
+//   1. scan the shadow with the fp16 query: d16(row), half the bytes of the fp32 scan;
+//   2. tau = sampled upper bound of the K-th smallest d16 (sample_threshold_kernel);
+//   3. keep every row with d16 <= tau + 2*eps, where eps bounds |d16 - d32| for unit-norm rows and query:
+//        |q16.x16 - q.x| <= |q16||x16 - x| + |q16 - q||x| <= 2^-12 (1 + 2^-12) + 2^-12        (fp16 RNE)
+//        + 6.1e-5 * sqrt(dim) if the dot unit flushed fp16 subnormals + fp32 accumulation (< 1e-4)
+//      -- 3e-3 covers it up to dim 2048.  The true top-K of d32 is inside that set: a row of the true top-K has
+//      d32 <= K-th d32 <= K-th d16 + eps <= tau + eps, hence d16 <= tau + 2 eps;
+//   4. re-score the survivors from the fp32 rows with the SAME gather kernel arithmetic as the full scan and
+//      select the K best (distance, row): ids and distances are bit-identical to the one-stage path.
+// Returns false (caller runs the full fp32 scan) when the survivors do not fit the candidate buffer.
+bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
+  if (dim > 2048) return false;
+  constexpr float kSlack = 2.0f * 3e-3f;
+  // fp16 copy of the normalised query behind the fp32 one
+  const size_t q16_off = round_up(stride_ + 16, 16);  // upload_query sized the buffers for it
+  const float *qf = reinterpret_cast<const float *>(c->h_query);
+  uint16_t *q16 = reinterpret_cast<uint16_t *>(c->h_query + q16_off);
+  memset(q16, 0, sstride_);
+  for (size_t i = 0; i < dim; i++) q16[i] = f2h(qf[i]);
+  HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q16, sstride_, hipMemcpyHostToDevice, c->stream));
+  c->ensure_keys(n);
+  c->ensure_out(k);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_F16, KM_IP, 0, n, c->d_query + q16_off, c->d_keys, c->stream);
+  if (prof) {
+    HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    c->prof_rows = n;
+    c->prof_bytes_per_row = dim * 2;
+    c->prof_pending = true;
+  }
+  c->h_fcnt[1] = 0;
+  c->h_fcnt[2] = 0;
+  launch_sample_threshold(c->d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
+  launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream, kSlack);
+  HIP_CHECK(hipMemcpyAsync(c->h_fcnt + 3, c->d_fcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  collect_profile(c);
+  const uint32_t m = c->h_fcnt[3];
+  if (m > QueryCtx::kCandCap || m < k) return false;
+  c->ensure_gather(m);
+  launch_cand_rows(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->d_ids, c->stream);
+  launch_gather(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, c->d_ids, m, c->d_query, c->d_dists, c->stream);
+  launch_cand_set_keys(c->d_cand, c->d_dists, m, c->stream);
+  launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys,
+                           c->h_fcnt + 2, k, c->h_fcnt + 1, c->stream);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (c->h_fcnt[1] || c->h_fcnt[2] < k) return false;
+  const uint32_t *k32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
+  out.resize(k);
+  for (uint32_t i = 0; i < k; i++) out[i] = Hit{c->h_out_rows[i], (uint64_t)k32[i]};
+  std::sort(out.begin(), out.end(), [](const Hit &a, const Hit &b) { return a.key != b.key ? a.key < b.key : a.row < b.row; });
+  return true;
+}
+
 static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
   if (order == BY_ID)
     std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
@@ -664,12 +741,14 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   HIP_CHECK(hipSetDevice(device));
   CtxLease c(device);
   upload_query(c.c, query, true);
-  scan_all(c.c, n);
   std::vector<Hit> hits;
+  // fp16 shadow: error-bounded filter + exact fp32 re-scoring of the survivors; falls back to the full scan
+  const bool two_stage = shadow_ && k <= 16 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
+  if (!two_stage) scan_all(c.c, n);
   std::vector<VecSimQueryResult> res;
   if (!multi) {
     uint32_t kk = (uint32_t)std::min<size_t>(k, n);
-    select(c.c, n, kk, Bound(), hits, nullptr);
+    if (!two_stage) select(c.c, n, kk, Bound(), hits, nullptr);
     if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
     res.reserve(hits.size());
     for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], score_of(h.key)});

@@ -193,6 +193,11 @@ class FlatIndex {
   void rows_of(size_t label, std::vector<uint32_t> &out) const;
 
   size_t elem_bytes_, stride_;
+  // optional fp16 shadow of the rows (FLOAT32 cosine, single-value; ScanTuning::shadow16 at creation)
+  bool shadow_ = false;
+  size_t sstride_ = 0;
+  uint8_t *d_shadow_ = nullptr;
+  bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
   uint8_t *d_rows_ = nullptr;
   uint64_t *d_labels_ = nullptr;
   size_t cap_rows_ = 0;

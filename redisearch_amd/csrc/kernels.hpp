@@ -52,6 +52,9 @@ struct ScanTuning {
   int nontemporal = 1;     // stream the corpus with nt loads
   int gemm_dma = 1;        // batched path: 1 LDS-DMA ring KC=8 (default), 0 register-staged, 2/3 experiments
   int filter_select = 1;   // small-K top-K: sample threshold + one filter pass (0 = radix levels only)
+  int shadow16 = 0;        // FLOAT32 cosine indexes created while set keep an fp16 shadow of the rows: the scan
+                           // reads the shadow, an error-bounded filter keeps the few rows that can still be in
+                           // the top-K, and only those are re-scored from the fp32 rows (exact, bit-identical)
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int num_cus = 256;
@@ -71,6 +74,14 @@ void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int 
 // In-place L2 normalisation of rows [row_begin,row_end) (cosine indexes, bulk device loads).
 void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, uint32_t row_begin, uint32_t row_end,
                            hipStream_t s);
+
+// fp16 shadow of fp32 rows [row_begin,row_end): out row stride sstride bytes (multiple of 16, zero padded)
+void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
+                        size_t sstride, hipStream_t s);
+// rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
+void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
+// cand[i].y = orderable key of dists[i]
+void launch_cand_set_keys(void *cand, const float *dists, uint32_t m, hipStream_t s);
 
 // ---- top-K selection over keys[0..n) -------------------------------------------------------------
 // Total order: composite (key, row), key u32 (key_bytes=4) or u64 (key_bytes=8).  Radix select, 8
@@ -122,8 +133,9 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
                              uint32_t *zero4, hipStream_t s);
 // candidates of a single key array: append (row,key) of every key <= orderable(*tau) to cand[0..cap),
 // counting in cand_count[0]
+// (slack is added to *tau first: the two-stage scan's error bound)
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
-                        uint32_t cap, hipStream_t s);
+                        uint32_t cap, hipStream_t s, float slack = 0.0f);
 // per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,

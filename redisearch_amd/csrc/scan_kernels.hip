@@ -581,7 +581,28 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(u4 *rows, uint32_t 
   }
 }
 
+// fp16 (round to nearest even) shadow of fp32 rows, one wavefront per row
+__global__ __launch_bounds__(256) void shadow_rows_kernel(const float *__restrict__ rows, uint32_t stride_f,
+                                                          uint32_t dim, uint32_t row_begin, uint32_t row_end,
+                                                          _Float16 *__restrict__ shadow, uint32_t sstride_h) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
+    const float *src = rows + (size_t)r * stride_f;
+    _Float16 *dst = shadow + (size_t)r * sstride_h;
+    for (uint32_t i = lane; i < sstride_h; i += 64) dst[i] = i < dim ? (_Float16)src[i] : (_Float16)0.0f;
+  }
+}
+
 }  // namespace
+
+void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
+                        size_t sstride, hipStream_t s) {
+  if (row_end <= row_begin) return;
+  uint32_t n = row_end - row_begin;
+  uint32_t need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  hipLaunchKernelGGL(shadow_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const float *)rows,
+                     (uint32_t)(stride / 4), dim, row_begin, row_end, (_Float16 *)shadow, (uint32_t)(sstride / 2));
+}
 
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
                  uint32_t row_end, const void *query, void *keys, hipStream_t s) {

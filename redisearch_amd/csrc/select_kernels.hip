@@ -342,8 +342,8 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
 // thread and step, ONE ballot per step on the minimum of the 16 keys (hits are rare), then the appends.
 __global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                           const float *__restrict__ tau, uint2 *__restrict__ cand,
-                                                          uint32_t *__restrict__ cand_count, uint32_t cap) {
-  const uint32_t max_key = f2key_dev(tau[0]);
+                                                          uint32_t *__restrict__ cand_count, uint32_t cap, float slack) {
+  const uint32_t max_key = f2key_dev(tau[0] + slack);
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t n4 = n / 4;  // whole 16-byte chunks; the 0..3 keys behind them are handled at the end
   const u4 *k4 = (const u4 *)keys;
@@ -456,10 +456,31 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
 }
 
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
-                        uint32_t cap, hipStream_t s) {
+                        uint32_t cap, hipStream_t s, float slack) {
   uint32_t need = (n / 4 + 1023) / 1024, cap_g = (uint32_t)scan_tuning().num_cus * 8;
   uint32_t g = need < cap_g ? need : cap_g;
-  hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap);
+  hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap,
+                     slack);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void cand_rows_kernel(const uint2 *__restrict__ cand, const uint32_t *__restrict__ count,
+                                                        uint32_t cap, uint32_t *__restrict__ rows_out) {
+  const uint32_t m = count[0] < cap ? count[0] : cap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) rows_out[i] = cand[i].x;
+}
+__global__ __launch_bounds__(256) void cand_set_keys_kernel(uint2 *__restrict__ cand, const float *__restrict__ dists,
+                                                            uint32_t m) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) cand[i].y = f2key_dev(dists[i]);
+}
+}  // namespace
+void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s) {
+  hipLaunchKernelGGL(cand_rows_kernel, dim3(64), dim3(256), 0, s, (const uint2 *)cand, count, cap, rows_out);
+}
+void launch_cand_set_keys(void *cand, const float *dists, uint32_t m, hipStream_t s) {
+  if (!m) return;
+  hipLaunchKernelGGL(cand_set_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, s, (uint2 *)cand, dists, m);
 }
 
 void launch_range(const void *keys, int key_bytes, uint32_t n, uint64_t max_key, int collect, uint32_t *counters,

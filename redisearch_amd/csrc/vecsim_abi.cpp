@@ -540,6 +540,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "filter_select")) scan_tuning().filter_select = value;
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
+  else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
   else return -1;
   return 0;
 }
