@@ -62,7 +62,7 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
  *                    pass with 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = tiled GEMM filter
  *   "cache_decoded"  1 (default): a posting list is decoded once and the decoded arrays are kept in HBM
  *   "shadow16"       0 (default); 1: FLOAT32 cosine indexes created from now on keep an fp16 shadow and answer
- *                    K <= 16 queries with the two-stage exact scan */
+ *                    K <= 128 queries with the two-stage exact scan */
 int RSGPU_SetTuning(const char *key, int value);
 /* frees idle per-query workspaces */
 void RSGPU_ReleaseWorkspaces(void);

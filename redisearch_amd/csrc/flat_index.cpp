@@ -743,7 +743,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   upload_query(c.c, query, true);
   std::vector<Hit> hits;
   // fp16 shadow: error-bounded filter + exact fp32 re-scoring of the survivors; falls back to the full scan
-  const bool two_stage = shadow_ && k <= 16 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
+  const bool two_stage = shadow_ && k <= 128 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
   if (!two_stage) scan_all(c.c, n);
   std::vector<VecSimQueryResult> res;
   if (!multi) {

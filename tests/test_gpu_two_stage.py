@@ -41,7 +41,7 @@ def test_random_rows_identical(dim, n):
     x = torch.rand((n, dim), device=dev, generator=gen) * 2 - 1
     plain, shadow = pair(x)
     rng = np.random.default_rng(dim)
-    for k in (1, 10, 16):
+    for k in (1, 10, 16, 100):
         for _ in range(4):
             same(plain, shadow, rng.uniform(-1, 1, dim).astype(np.float32), k)
     # a query that IS a stored row (distance ~0, others far) and its negation
