@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--no-two-stage-extra", action="store_true", help="skip the extra two-stage measurement (N=1)")
     ap.add_argument("--tuning", action="append", default=[], help="engine knob key=value (A/B experiments only)")
     return ap.parse_args()
 
@@ -104,6 +105,12 @@ def main():
         key, val = kv.split("=")
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
     two_stage = any(kv.replace(" ", "") == "shadow16=1" for kv in a.tuning)
+    # N=1: the index also carries the fp16 shadow of the opt-in two-stage exact scan; it is switched OFF for the
+    # timed headline loop (plain fp32 scan) and measured separately afterwards as an extra config entry
+    extra_two_stage = world == 1 and not two_stage and not a.no_two_stage_extra
+    if extra_two_stage:
+        lib.RSGPU_SetTuning(b"shadow16", 1)
+        lib.RSGPU_SetTuning(b"two_stage", 0)
 
     # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
     rows, dim, k = a.rows, a.dim, a.k
@@ -165,6 +172,29 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.RSGPU_SetProfiling(0)
     launches, kern_ms, kern_bytes = V.scan_profile()
+    extra = None
+    if extra_two_stage:  # same index, same queries, two-stage exact scan switched on; results must be identical
+        lib.RSGPU_SetTuning(b"two_stage", 1)
+        for i in range(5):
+            one_query(i)
+        q = queries[7]
+        rep = index.topk_query(q, k)
+        ids2, sc2 = rep.results()
+        lib.RSGPU_SetTuning(b"two_stage", 0)
+        ids1, sc1 = index.topk_query(q, k).results()
+        lib.RSGPU_SetTuning(b"two_stage", 1)
+        same = ids1.tolist() == ids2.tolist() and sc1.tolist() == sc2.tolist()
+        torch.cuda.synchronize()
+        n2 = min(a.steps, 200)
+        t2 = time.perf_counter()
+        for i in range(n2):
+            one_query(a.warmup + i)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        lib.RSGPU_SetTuning(b"two_stage", 0)
+        extra = {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
+                 "what": "opt-in: scan of an fp16 shadow (15.36 GB) + error-bounded filter + fp32 re-scoring of the survivors; "
+                         "NOT the headline value"}
 
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -205,6 +235,8 @@ def main():
                 "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
+        if extra is not None:
+            out["config"]["two_stage_exact_scan_extra"] = extra
         if two_stage:  # opt-in experiment (--tuning shadow16=1), never the default line
             out["config"]["two_stage_fp16_shadow"] = ("scan of an fp16 shadow + error-bounded filter + fp32 re-scoring of the "
                                                       "survivors: results bit-identical to the fp32 scan; roofline bytes = shadow bytes")

@@ -57,12 +57,13 @@ void RSGPU_ResetProfile(void);
 void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes);
 /* Engine knobs (A/B experiments and opt-in modes). Returns 0 if the key is known.
  *   "blocks_per_cu", "rows_per_group", "nontemporal"  launch shape of the FLAT scan kernel
- *   "filter_select"  1 (default): K <= 16 uses sample threshold + one filter pass; 0: radix levels only
+ *   "filter_select"  1 (default): K <= 32 uses sample threshold + one filter pass; 0: radix levels only
  *   "gemm_dma", "gemm_qs"  batched path: staging variant of the tiled GEMM; 1 (default) query-stationary filter
  *                    pass with 8 waves x 32 queries, 2 = 4 waves x 64 queries, 0 = tiled GEMM filter
  *   "cache_decoded"  1 (default): a posting list is decoded once and the decoded arrays are kept in HBM
  *   "shadow16"       0 (default); 1: FLOAT32 cosine indexes created from now on keep an fp16 shadow and answer
- *                    K <= 128 queries with the two-stage exact scan */
+ *                    K <= 128 queries with the two-stage exact scan
+ *   "two_stage"      1 (default): query-time switch of the above for indexes that carry a shadow */
 int RSGPU_SetTuning(const char *key, int value);
 /* frees idle per-query workspaces */
 void RSGPU_ReleaseWorkspaces(void);

@@ -655,9 +655,10 @@ static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> 
 }
 
 void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper) {
-  // measured on 10M keys (post-scan time, filter vs radix levels): k=10 91 vs 118 us, k=32 130 vs 121,
-  // k=100 190 vs 129 -- the single-workgroup final select over ~k*n/64Ki candidates is what grows
-  if (key_bytes == 4 && !lower.valid && !upper && k > 0 && k <= 16 && n >= (1u << 18) && scan_tuning().filter_select) {
+  // measured on 10M keys (post-scan time, filter vs radix levels): k=10 57 vs 118 us, k=16 68 vs 124,
+  // k=32 96 vs 121, k=64 131 vs 128, k=100 158 vs 123 -- the single-workgroup final select over
+  // ~k*n/64Ki candidates is what grows
+  if (key_bytes == 4 && !lower.valid && !upper && k > 0 && k <= 32 && n >= (1u << 18) && scan_tuning().filter_select) {
     if (filter_select(c, n, k, out)) return;
   }
   radix_select(c, c->d_keys, key_bytes, n, k, lower, out, upper);
@@ -743,7 +744,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   upload_query(c.c, query, true);
   std::vector<Hit> hits;
   // fp16 shadow: error-bounded filter + exact fp32 re-scoring of the survivors; falls back to the full scan
-  const bool two_stage = shadow_ && k <= 128 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
+  const bool two_stage = shadow_ && scan_tuning().two_stage && k <= 128 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
   if (!two_stage) scan_all(c.c, n);
   std::vector<VecSimQueryResult> res;
   if (!multi) {

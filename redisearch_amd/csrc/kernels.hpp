@@ -55,6 +55,7 @@ struct ScanTuning {
   int shadow16 = 0;        // FLOAT32 cosine indexes created while set keep an fp16 shadow of the rows: the scan
                            // reads the shadow, an error-bounded filter keeps the few rows that can still be in
                            // the top-K, and only those are re-scored from the fp32 rows (exact, bit-identical)
+  int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int num_cus = 256;

@@ -303,7 +303,6 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
                                                                 uint32_t slab_stride, uint32_t slabs, uint32_t k,
                                                                 float *__restrict__ tau_out,
                                                                 uint32_t *__restrict__ zero4) {
-  __shared__ uint32_t mins[1024];
   const uint32_t t = threadIdx.x;
   if (zero4 && t < 4) zero4[t] = 0;  // the filter pass's counters: saves a memset on the query's critical path
   uint32_t m = 0xFFFFFFFFu;
@@ -321,19 +320,43 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
       m = m < a ? m : a;
     }
   }
-  mins[t] = m;
-  __syncthreads();
-  // rank of this group's minimum among the 1024 (ties by group index): the one of rank k-1 is tau
-  uint32_t rank = 0;
-  for (uint32_t j = 0; j < 1024; j += 4) {
-    const u4 o = *(const u4 *)(mins + j);
-    rank += (o.x < m || (o.x == m && j < t)) ? 1u : 0u;
-    rank += (o.y < m || (o.y == m && j + 1 < t)) ? 1u : 0u;
-    rank += (o.z < m || (o.z == m && j + 2 < t)) ? 1u : 0u;
-    rank += (o.w < m || (o.w == m && j + 3 < t)) ? 1u : 0u;
+  // K-th smallest of the 1024 group minima: four 8-bit radix levels over LDS histograms (a rank-by-counting
+  // pass cost 1M comparisons on this one CU = 40 us; this is ~1 us)
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t sh_prefix, sh_krem;
+  if (t == 0) {
+    sh_prefix = 0;
+    sh_krem = k;
   }
-  if (rank == k - 1) {
-    const uint32_t u = (m & 0x80000000u) ? (m ^ 0x80000000u) : ~m;
+  for (int p = 0; p < 4; p++) {
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    const uint32_t prefix = sh_prefix, krem = sh_krem;
+    const int shift = 24 - 8 * p;
+    if (p == 0 || (m >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(m >> shift) & 255u], 1u);
+    __syncthreads();
+    if (t < 64) {  // wavefront 0: inclusive scan of the 256 bins, 4 per lane
+      const uint32_t h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+      const uint32_t sum = h0 + h1 + h2 + h3;
+      uint32_t inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (t >= (uint32_t)off) inc += o;
+      }
+      const uint32_t exc = inc - sum;
+      if (exc < krem && krem <= inc) {  // exactly one lane owns the digit of the K-th element
+        uint32_t c = exc, d = 0;
+        if (krem > c + h0) { c += h0; d = 1; if (krem > c + h1) { c += h1; d = 2; if (krem > c + h2) { c += h2; d = 3; } } }
+        sh_prefix = prefix | ((4 * t + d) << shift);
+        sh_krem = krem - c;
+      }
+    }
+    __syncthreads();
+  }
+  if (t == 0) {
+    const uint32_t kth = sh_prefix;
+    const uint32_t u = (kth & 0x80000000u) ? (kth ^ 0x80000000u) : ~kth;
     tau_out[0] = __uint_as_float(u);
   }
 }

@@ -541,6 +541,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
+  else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;
   else return -1;
   return 0;
 }

@@ -30,7 +30,7 @@ def reference_topk(x, q, k, metric):
 
 
 @pytest.mark.parametrize("n", [262_144, 300_001, 1_000_000])
-@pytest.mark.parametrize("k", [1, 10, 16, 17, 128, 1024])  # <= 16: threshold filter; above: radix levels only
+@pytest.mark.parametrize("k", [1, 10, 32, 33, 128, 1024])  # <= 32: threshold filter; above: radix levels only
 def test_filter_path_matches_radix_path_and_reference(n, k):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
