@@ -33,7 +33,25 @@ struct Dev {
   }
 };
 
-// grow-only device scratch of the calling thread
+// grow-only device scratch + pinned host mirrors of one pipeline slot of the calling thread
+struct Pinned {
+  void *p = nullptr;
+  size_t bytes = 0;
+  ~Pinned() {
+    if (p) (void)hipHostFree(p);
+  }
+  template <typename T>
+  T *ensure(size_t count) {
+    if (count * sizeof(T) > bytes) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+      bytes = 0;
+      HIP_CHECK(hipHostMalloc(&p, count * sizeof(T), hipHostMallocDefault));
+      bytes = count * sizeof(T);
+    }
+    return static_cast<T *>(p);
+  }
+};
 struct BatchScratch {
   int device = -1;
   Dev<uint8_t> queries;
@@ -41,8 +59,10 @@ struct BatchScratch {
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
   Dev<uint64_t> cand, sub_cand;
   Dev<uint32_t> sub_count;
+  Pinned hq, h_rows, h_keys, h_n, h_over;
 };
-thread_local BatchScratch tls_batch;
+// two slots: the host builds the replies of batch b while the device works on batch b+1
+thread_local BatchScratch tls_batch[2];
 
 }  // namespace
 
@@ -74,12 +94,17 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       return;
     }
     HIP_CHECK(hipSetDevice(device));
-    CtxLease c(device);
-    BatchScratch &sc = tls_batch;
-    if (sc.device != device) {
-      sc.~BatchScratch();
-      new (&sc) BatchScratch();
-      sc.device = device;
+    const size_t n_batches = (n_queries + kBatch - 1) / kBatch;
+    const int n_slots = n_batches > 1 ? 2 : 1;
+    CtxLease lease0(device), lease1(device);
+    QueryCtx *ctxs[2] = {lease0.c, lease1.c};
+    for (int sl = 0; sl < n_slots; sl++) {
+      BatchScratch &sc = tls_batch[sl];
+      if (sc.device != device) {
+        sc.~BatchScratch();
+        new (&sc) BatchScratch();
+        sc.device = device;
+      }
     }
     const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
     const uint32_t stride16 = (uint32_t)(stride_ / 16);
@@ -112,15 +137,23 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       expect_total *= 6;
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
-    sc.queries.ensure((size_t)kBatch * stride_);
-    sc.tau.ensure(kBatch);
-    sc.cand_count.ensure(kBatch);
-    sc.overflow.ensure(kBatch);
-    sc.keys.ensure((size_t)kBatch * n0);
-    sc.out_rows.ensure((size_t)kBatch * kk);
-    sc.out_keys.ensure((size_t)kBatch * kk);
-    sc.out_n.ensure(kBatch);
-    sc.cand.ensure((size_t)kBatch * cand_cap);
+    for (int sl = 0; sl < n_slots; sl++) {
+      BatchScratch &sc = tls_batch[sl];
+      sc.queries.ensure((size_t)kBatch * stride_);
+      sc.tau.ensure(kBatch);
+      sc.cand_count.ensure(kBatch);
+      sc.overflow.ensure(kBatch);
+      sc.keys.ensure((size_t)kBatch * n0);
+      sc.out_rows.ensure((size_t)kBatch * kk);
+      sc.out_keys.ensure((size_t)kBatch * kk);
+      sc.out_n.ensure(kBatch);
+      sc.cand.ensure((size_t)kBatch * cand_cap);
+      sc.hq.ensure<uint8_t>((size_t)kBatch * stride_);
+      sc.h_rows.ensure<uint32_t>((size_t)kBatch * kk);
+      sc.h_keys.ensure<uint32_t>((size_t)kBatch * kk);
+      sc.h_n.ensure<uint32_t>(kBatch);
+      sc.h_over.ensure<uint32_t>(kBatch);
+    }
     // per-(workgroup, query, lane half) sub-lists of a pass, 8x the expected length of the fullest pass
     uint32_t sub_cap = 32, qs_grid_max = 0;
     if (use_qs) {
@@ -133,22 +166,26 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         seen = std::max(seen, e);
         from = e;
       }
-      sc.sub_count.ensure((size_t)qs_grid_max * kBatch * 2);
-      sc.sub_cand.ensure((size_t)qs_grid_max * kBatch * 2 * sub_cap);
+      for (int sl = 0; sl < n_slots; sl++) {
+        tls_batch[sl].sub_count.ensure((size_t)qs_grid_max * kBatch * 2);
+        tls_batch[sl].sub_cand.ensure((size_t)qs_grid_max * kBatch * 2 * sub_cap);
+      }
     }
-    std::vector<uint8_t> hq((size_t)kBatch * stride_);
-    std::vector<uint32_t> h_rows((size_t)kBatch * kk), h_keys((size_t)kBatch * kk), h_n(kBatch), h_over(kBatch);
+    const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
 
-    for (size_t q0 = 0; q0 < n_queries; q0 += kBatch) {
+    // everything of batch q0.. onto the slot's stream, nothing waited for
+    auto enqueue = [&](int sl, size_t q0) {
+      BatchScratch &sc = tls_batch[sl];
+      QueryCtx *c = ctxs[sl];
       const uint32_t nb = (uint32_t)std::min<size_t>(kBatch, n_queries - q0);
-      std::fill(hq.begin(), hq.end(), 0);  // unused query rows stay zero (their results are ignored)
+      uint8_t *hq = static_cast<uint8_t *>(sc.hq.p);
+      memset(hq, 0, (size_t)kBatch * stride_);  // unused query rows stay zero (their results are ignored)
       for (uint32_t i = 0; i < nb; i++) {
-        uint8_t *dst = hq.data() + (size_t)i * stride_;
+        uint8_t *dst = hq + (size_t)i * stride_;
         memcpy(dst, (const uint8_t *)queries + (q0 + i) * elem_bytes_, elem_bytes_);
         if (metric == VecSimMetric_Cosine) normalize_host(dst);
       }
-      HIP_CHECK(hipMemcpyAsync(sc.queries.p, hq.data(), hq.size(), hipMemcpyHostToDevice, c->stream));
-      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+      HIP_CHECK(hipMemcpyAsync(sc.queries.p, hq, (size_t)kBatch * stride_, hipMemcpyHostToDevice, c->stream));
       if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
       if (small) {
         launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
@@ -183,10 +220,19 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
       HIP_CHECK(hipGetLastError());
       if (prof) HIP_CHECK(hipEventRecord(c->ev1, c->stream));
-      HIP_CHECK(hipMemcpyAsync(h_rows.data(), sc.out_rows.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
-      HIP_CHECK(hipMemcpyAsync(h_keys.data(), sc.out_keys.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
-      HIP_CHECK(hipMemcpyAsync(h_n.data(), sc.out_n.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
-      HIP_CHECK(hipMemcpyAsync(h_over.data(), sc.overflow.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(sc.h_rows.p, sc.out_rows.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(sc.h_keys.p, sc.out_keys.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(sc.h_n.p, sc.out_n.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_CHECK(hipMemcpyAsync(sc.h_over.p, sc.overflow.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+    };
+
+    // wait for the slot's batch and build its replies
+    auto finalize = [&](int sl, size_t q0) {
+      BatchScratch &sc = tls_batch[sl];
+      QueryCtx *c = ctxs[sl];
+      const uint32_t nb = (uint32_t)std::min<size_t>(kBatch, n_queries - q0);
+      const uint32_t *h_rows = static_cast<const uint32_t *>(sc.h_rows.p), *h_keys = static_cast<const uint32_t *>(sc.h_keys.p);
+      const uint32_t *h_n = static_cast<const uint32_t *>(sc.h_n.p), *h_over = static_cast<const uint32_t *>(sc.h_over.p);
       HIP_CHECK(hipStreamSynchronize(c->stream));
       if (prof) {
         float ms = 0;
@@ -223,7 +269,13 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           scores_out[qi * k + j] = res[j].score;
         }
       }
+    };
+
+    for (size_t b = 0; b < n_batches; b++) {
+      enqueue((int)(b & 1) % n_slots, b * kBatch);
+      if (b > 0) finalize((int)((b - 1) & 1), (b - 1) * kBatch);
     }
+    finalize((int)((n_batches - 1) & 1) % n_slots, (n_batches - 1) * kBatch);
   }
   for (size_t qi : redo) single(qi);
 }

@@ -55,6 +55,15 @@ for i in (() if int(os.environ.get("GEMM_QS", "1")) in (2, 3, 4, 5, 6, 7) else (
     same = len(set(si.tolist()) & set(ids[i].tolist()))
     assert same >= k - 2 and np.allclose(np.sort(sc[i]), np.sort(ss), atol=2e-3), (i, same)
 out["parity_spot_check"] = "3 queries vs single-query path: top-%d overlap >= %d, distances within 2e-3" % (k, k - 2)
+# many batches per call: the host builds the replies of pass b while the device runs pass b+1
+per_call = int(os.environ.get("QUERIES_PER_CALL", 2560))
+big = np.random.default_rng(50).uniform(-1, 1, (per_call, dim)).astype(np.float16)
+idx.topk_batch(big[:512], k)
+t0 = time.perf_counter()
+idx.topk_batch(big, k)
+el = time.perf_counter() - t0
+out["pipelined_qps_wall"] = per_call / el
+out["pipelined_queries_per_call"] = per_call
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/batch_bench_dma%s_qs%s.json" % (os.environ.get("GEMM_DMA", "1"), os.environ.get("GEMM_QS", "1")), "w"), indent=1)
 print(json.dumps(out))

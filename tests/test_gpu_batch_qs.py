@@ -80,3 +80,20 @@ def test_qs_cosine_and_large_k():
     for i in (0, 77, 255):
         si, ss = g.topk_query(queries[i], k).results()
         assert close(sc[i], ss) and len(set(si.tolist()) ^ set(ids[i].tolist())) <= 6
+
+
+def test_many_batches_are_pipelined_and_identical_to_single_batches():
+    # 700 queries = 3 passes over the corpus on two alternating slots; same answers as batch-by-batch calls
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    n, dim, k = 600_000, 128, 20
+    x = (torch.rand((n, dim), device=dev, generator=gen) * 2 - 1).to(torch.float16)
+    g = V.VecSimIndex(F16, dim, IP)
+    torch.cuda.synchronize()
+    g.add_device_rows(x.data_ptr(), n, 1)
+    queries = np.random.default_rng(12).uniform(-1, 1, (700, dim)).astype(np.float16)
+    ids, sc, cnt = g.topk_batch(queries, k)
+    for lo in (0, 256, 512):
+        i2, s2, c2 = g.topk_batch(queries[lo:lo + 256], k)
+        assert np.array_equal(ids[lo:lo + 256], i2) and np.array_equal(sc[lo:lo + 256], s2) and np.array_equal(cnt[lo:lo + 256], c2)
