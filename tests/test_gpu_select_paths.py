@@ -29,7 +29,7 @@ def reference_topk(x, q, k, metric):
     return ri.cpu().numpy() + 1, rs.cpu().numpy()
 
 
-@pytest.mark.parametrize("n", [262_144, 300_001, 1_000_000])
+@pytest.mark.parametrize("n", [1_000, 20_000, 32_769, 70_001, 262_144, 300_001, 1_000_000])  # single-WG | radix | filter
 @pytest.mark.parametrize("k", [1, 10, 32, 33, 128, 1024])  # <= 32: threshold filter; above: radix levels only
 def test_filter_path_matches_radix_path_and_reference(n, k):
     dev = torch.device("cuda", 0)
