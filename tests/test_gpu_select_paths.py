@@ -25,7 +25,7 @@ def reference_topk(x, q, k, metric):
         d = ((x - qt) ** 2).sum(1)
     else:
         d = 1.0 - x @ qt
-    rs, ri = torch.topk(d, k, largest=False)
+    rs, ri = torch.topk(d, min(k, d.numel()), largest=False)
     return ri.cpu().numpy() + 1, rs.cpu().numpy()
 
 
