@@ -420,6 +420,9 @@ struct Shape {
   int G, ITERS;
 };
 inline Shape pick_shape(uint32_t chunks) {
+  // 96 / 160 / 224 chunks (e.g. 768 halves): half a wavefront per row keeps every lane of every load busy,
+  // a full one would idle 32 lanes in its last pass
+  if (chunks > 64 && chunks % 64 == 32 && chunks <= 224) return {32, (int)(chunks / 32)};
   if (chunks > 64) return {64, (int)((chunks + 63) / 64)};
   int g = 1;
   while ((uint32_t)g < chunks) g <<= 1;
@@ -487,6 +490,13 @@ void launch_shape(const LaunchCtx &c) {
       case 16: return launch_one<TYPE, METRIC, 16, 1, 8, GATHER>(c);
       case 32: return launch_one<TYPE, METRIC, 32, 1, 8, GATHER>(c);
       default: return launch_one<TYPE, METRIC, 64, 1, 8, GATHER>(c);
+    }
+  }
+  if (sh.G == 32) {
+    switch (sh.ITERS) {
+      case 3: return launch_one<TYPE, METRIC, 32, 3, 4, GATHER>(c);
+      case 5: return launch_one<TYPE, METRIC, 32, 5, 2, GATHER>(c);
+      default: return launch_one<TYPE, METRIC, 32, 7, 2, GATHER>(c);
     }
   }
   switch (sh.ITERS) {
