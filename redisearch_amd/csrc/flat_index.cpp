@@ -628,7 +628,7 @@ void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, ui
 // Small-K fast path: K-th smallest group minimum of a spread key sample bounds the answer (tau), one streaming pass
 // keeps the keys <= tau, a single workgroup selects the exact K among them (select_kernels.hip
 // "threshold filter").  ~40 us after the scan instead of ~110 us for the four histogram levels.
-static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
+static bool filter_select(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out) {
   // tau = k-th smallest of 1024 group minima over a 64 Ki key sample: its rank in the whole array is
   // ~ k * n / 64 Ki, below kCandCap up to n = 2^25 at k = 128 (beyond that the overflow fallback decides)
   const uint32_t per = 64;
@@ -637,8 +637,8 @@ static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> 
   // pinned (device-visible, coherent) host buffers: no memset, no D2H copies on the critical path.
   c->h_fcnt[1] = 0;  // overflow flag, only ever set by the kernel
   c->h_fcnt[2] = 0;
-  launch_sample_threshold(c->d_keys, n, per, k, c->d_tau, c->d_fcnt, c->stream);
-  launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
+  launch_sample_threshold(d_keys, n, per, k, c->d_tau, c->d_fcnt, c->stream);
+  launch_filter_keys(d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
   launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys,
                            c->h_fcnt + 2, k, c->h_fcnt + 1, c->stream);
   HIP_CHECK(hipGetLastError());
@@ -657,10 +657,10 @@ static bool filter_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> 
 // Small indexes (n <= 2^15): the whole selection is ONE workgroup's radix select over the keys (they sit in L2),
 // winners written straight into pinned host memory -- one launch and one sync instead of four histogram levels,
 // a collect pass and three copies (10 k rows x 128: 91 -> 59 us per query; at 100 k rows one CU is too slow).
-static bool small_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
+static bool small_select(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out) {
   c->ensure_out(k);
   c->h_fcnt[2] = 0;
-  launch_batch_select_keys(c->d_keys, n, n, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys, c->h_fcnt + 2, k, c->stream);
+  launch_batch_select_keys(d_keys, n, n, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys, c->h_fcnt + 2, k, c->stream);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(c->stream));
   collect_profile(c);
@@ -673,15 +673,21 @@ static bool small_select(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &
   return true;
 }
 
+void select_keys32(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out) {
+  if (k > 0 && k <= 1024 && n <= (1u << 15) && scan_tuning().filter_select && small_select(c, d_keys, n, k, out)) return;
+  if (k > 0 && k <= 32 && n >= (1u << 16) && scan_tuning().filter_select && filter_select(c, d_keys, n, k, out)) return;
+  radix_select(c, d_keys, 4, n, k, Bound(), out, nullptr);
+}
+
 void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper) {
   if (key_bytes == 4 && !lower.valid && !upper && k > 0 && k <= 1024 && n <= (1u << 15) && scan_tuning().filter_select) {
-    if (small_select(c, n, k, out)) return;
+    if (small_select(c, c->d_keys, n, k, out)) return;
   }
   // measured on 10M keys (post-scan time, filter vs radix levels): k=10 57 vs 118 us, k=16 68 vs 124,
   // k=32 96 vs 121, k=64 131 vs 128, k=100 158 vs 123 -- the single-workgroup final select over
   // ~k*n/64Ki candidates is what grows
   if (key_bytes == 4 && !lower.valid && !upper && k > 0 && k <= 32 && n >= (1u << 16) && scan_tuning().filter_select) {
-    if (filter_select(c, n, k, out)) return;
+    if (filter_select(c, c->d_keys, n, k, out)) return;
   }
   radix_select(c, c->d_keys, key_bytes, n, k, lower, out, upper);
 }

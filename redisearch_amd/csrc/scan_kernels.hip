@@ -314,16 +314,18 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
     for (int u = 0; u < U; u++) {
       uint32_t r = r0 + u * u_stride;
       if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      bool present = true;
       if (GATHER) {
         r = row_ids[r];
         rid[u] = r;
-        if (r == 0xFFFFFFFFu) r = 0;  // absent label: any valid row, result replaced by NaN
+        present = r != 0xFFFFFFFFu;  // absent label: nothing is read, the result is NaN
+        if (!present) r = 0;
       }
       const u4 *p = rows + (size_t)r * stride16;
 #pragma unroll
       for (int i = 0; i < ITERS; i++) {
         uint32_t c = lane + i * G;
-        x[u][i] = (EXACT || c < chunks) ? load16<NT>(p + c) : zero4();
+        x[u][i] = ((EXACT || c < chunks) && (!GATHER || present)) ? load16<NT>(p + c) : zero4();
       }
     }
     out_t d[U];

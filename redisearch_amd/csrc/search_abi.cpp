@@ -612,7 +612,7 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   launch_dist_to_keys(sc.dists.p, h->len, sc.keys32.p, c->stream);
   HIP_CHECK(hipGetLastError());
   std::vector<Hit> hits;
-  radix_select(c.c, sc.keys32.p, 4, h->len, (uint32_t)std::min<size_t>(k, h->len), Bound(), hits, nullptr);
+  select_keys32(c.c, sc.keys32.p, h->len, (uint32_t)std::min<size_t>(k, h->len), hits);
   tk.stop();
   const std::vector<uint32_t> &ids = h->host_ids();
   long out = 0;
