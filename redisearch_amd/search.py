@@ -224,29 +224,3 @@ def profile():
     v = [_dbl(0) for _ in range(5)]
     load().RSGPU_SearchProfile(*[C.byref(x) for x in v])
     return dict(zip(("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms"), [x.value for x in v]))
-
-
-def smoke():
-    """Tiny GPU intersection + BM25STD against the CPU oracle (called from __graft_entry__.smoke)."""
-    import oracle as O
-    rng = np.random.default_rng(49)
-    lists_o, lists_g = [], []
-    for n in (700, 1500):
-        docs = np.unique(rng.integers(1, 4000, n)).astype(np.uint64)
-        ii = O.InvertedIndex(O.C_FREQS_ONLY)
-        ii.add_many(docs, rng.integers(1, 9, docs.size).astype(np.uint32))
-        lists_o.append(ii)
-        lists_g.append(Postings.from_flat(ii.flatten()))
-    oi, of, _ = O.intersect(lists_o)
-    h = intersect(lists_g)
-    gi, gf = h.read()
-    assert gi.tolist() == oi.tolist() and gf.tolist() == of.tolist()
-    doc_len = rng.integers(10, 300, 4001).astype(np.uint32)
-    doc_score = np.ones(4001, np.float32)
-    idf = [calculate_idf(4000, l.unique_docs) for l in lists_o]
-    bidf = [calculate_idf_bm25(4000, l.unique_docs) for l in lists_o]
-    gs = h.score(DocTable(doc_len, doc_score), "BM25STD", idf, bidf, [1.0, 1.0], 4000, float(doc_len[1:].mean()))
-    os_ = O.score_flat("BM25STD", of, doc_len[oi.astype(np.int64)], np.ones(len(oi)), doc_score[oi.astype(np.int64)],
-                       idf, bidf, [1.0, 1.0], 1.0, 4000, float(doc_len[1:].mean()))
-    assert np.allclose(gs, os_, rtol=1e-12, atol=0), float(np.max(np.abs(gs - os_)))
-    print("search smoke ok: %d hits" % len(gi))

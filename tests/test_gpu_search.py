@@ -176,4 +176,5 @@ def test_hybrid_prefilter_knn_rerank():
 
 
 def test_search_smoke_entry():
-    S.smoke()
+    import __graft_entry__ as G
+    G._smoke_search(O, np.random.default_rng(49))
