@@ -695,17 +695,19 @@ void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, 
 // Two-stage exact top-K over an fp16 shadow (FLOAT32 cosine indexes created with ScanTuning::shadow16).
 //   1. scan the shadow with the fp16 query: d16(row), half the bytes of the fp32 scan;
 //   2. tau = sampled upper bound of the K-th smallest d16 (sample_threshold_kernel);
-//   3. keep every row with d16 <= tau + 2*eps, where eps bounds |d16 - d32| for unit-norm rows and query:
-//        |q16.x16 - q.x| <= |q16||x16 - x| + |q16 - q||x| <= 2^-12 (1 + 2^-12) + 2^-12        (fp16 RNE)
-//        + 6.1e-5 * sqrt(dim) if the dot unit flushed fp16 subnormals + fp32 accumulation (< 1e-4)
-//      -- 3e-3 covers it up to dim 2048.  The true top-K of d32 is inside that set: a row of the true top-K has
-//      d32 <= K-th d32 <= K-th d16 + eps <= tau + eps, hence d16 <= tau + 2 eps;
+//   3. keep every row with d16 <= tau + 2*eps, where eps bounds |d16 - d32| for unit-norm rows and query
+//      (u = 2^-11, the unit roundoff of fp16):
+//        |q16.x16 - q.x| <= |q16||x16 - x| + |q16 - q||x| <= u (1 + u) + u              = 9.8e-4
+//        + 6.1e-5 * sqrt(dim)  if the dot unit flushes fp16 subnormals (|x_i| < 2^-14)  <= 1.95e-3 at dim 1024
+//        + dim * 2^-24         fp32 accumulation of the products                        <= 6.1e-5
+//      -- eps = 4e-3 covers it up to dim 1024.  The true top-K of d32 is inside that set: a row of the true
+//      top-K has d32 <= K-th d32 <= K-th d16 + eps <= tau + eps, hence d16 <= tau + 2 eps;
 //   4. re-score the survivors from the fp32 rows with the SAME gather kernel arithmetic as the full scan and
 //      select the K best (distance, row): ids and distances are bit-identical to the one-stage path.
 // Returns false (caller runs the full fp32 scan) when the survivors do not fit the candidate buffer.
 bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
-  if (dim > 2048) return false;
-  constexpr float kSlack = 2.0f * 3e-3f;
+  if (dim > 1024) return false;
+  constexpr float kSlack = 2.0f * 4e-3f;
   // fp16 copy of the normalised query behind the fp32 one
   const size_t q16_off = round_up(stride_ + 16, 16);  // upload_query sized the buffers for it
   const float *qf = reinterpret_cast<const float *>(c->h_query);
