@@ -77,9 +77,33 @@ def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0):
         el = time.perf_counter() - t0
         if el >= budget_s or n >= 2000:
             break
+    # (b) eight concurrent queries on eight threads (how a WORKERS 8 deployment runs FLAT queries);
+    # ctypes releases the GIL inside the C scan
+    import threading
+    counts = [0] * 8
+    stop_at = time.perf_counter() + 6.0
+
+    def worker(t):
+        ids_t, sc_t = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+        i = t
+        while time.perf_counter() < stop_at:
+            q = qs[i % len(qs)]
+            lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, ids_t.ctypes.data_as(C.c_void_p), sc_t.ctypes.data_as(C.c_void_p))
+            counts[t] += 1
+            i += 8
+
+    t8 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    el8 = time.perf_counter() - t8
+    qps8 = sum(counts) / el8 * sample_rows / full_rows
     lib.oflat_free(h)
     qps_sample = n / el
     return {"value": qps_sample * sample_rows / full_rows, "unit": "queries/s", "cores": 1, "kind": "port",
+            "eight_threads": {"value": qps8, "cores": 8, "note": "8 concurrent queries, same sample, scaled by rows"},
             "sample": "%d queries over a %d x %d fp32 cosine sample in %.1f s (oracle/flat_oracle.c oflat_topk_heap, %s), "
                       "scaled by rows to %d" % (n, sample_rows, dim, el, flavour, full_rows)}
 
