@@ -63,6 +63,7 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
  *   "cache_decoded"  1 (default): a posting list is decoded once and the decoded arrays are kept in HBM
  *   "shadow16"       0 (default); 1: FLOAT32 cosine indexes created from now on keep an fp16 shadow and answer
  *                    K <= 128 queries with the two-stage exact scan
+ *   "shadow8"        same with an int8 shadow + one fp32 scale per row (a quarter of the fp32 bytes; K <= 32)
  *   "two_stage"      1 (default): query-time switch of the above for indexes that carry a shadow */
 int RSGPU_SetTuning(const char *key, int value);
 /* frees idle per-query workspaces */

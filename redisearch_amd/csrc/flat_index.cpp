@@ -275,14 +275,19 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   key_bytes = key_bytes_of(ktype);
   elem_bytes_ = dim * type_size(type);
   stride_ = round_up(elem_bytes_, 16);
-  shadow_ = scan_tuning().shadow16 && type == VecSimType_FLOAT32 && metric == VecSimMetric_Cosine && !multi;
-  sstride_ = shadow_ ? round_up(dim * 2, 16) : 0;
+  if (type == VecSimType_FLOAT32 && metric == VecSimMetric_Cosine && !multi)
+    shadow_ = scan_tuning().shadow8 ? 2 : (scan_tuning().shadow16 ? 1 : 0);
+  sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ == 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   scan_tuning().num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
+  if (shadow_ == 2) {
+    HIP_CHECK(hipMalloc((void **)&d_smax_, sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d_smax_, 0, sizeof(uint32_t)));
+  }
   // staging block: up to 4096 rows or 8 MiB
   stage_cap_ = std::max<size_t>(1, std::min<size_t>(4096, (8u << 20) / stride_));
   HIP_CHECK(hipHostMalloc((void **)&h_stage_, stage_cap_ * stride_, hipHostMallocDefault));
@@ -297,12 +302,14 @@ FlatIndex::~FlatIndex() {
   if (d_rows_) HIP_IGNORE(hipFree(d_rows_));
   if (d_labels_) HIP_IGNORE(hipFree(d_labels_));
   if (d_shadow_) HIP_IGNORE(hipFree(d_shadow_));
+  if (d_sscale_) HIP_IGNORE(hipFree(d_sscale_));
+  if (d_smax_) HIP_IGNORE(hipFree(d_smax_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
   HIP_IGNORE(hipStreamDestroy(wstream_));
 }
 
 size_t FlatIndex::memory() const {
-  return cap_rows_ * (stride_ + sstride_ + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
+  return cap_rows_ * (stride_ + sstride_ + (shadow_ == 2 ? 4 : 0) + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
          (single_map_.size() + multi_map_.size()) * 48;
 }
 
@@ -319,9 +326,14 @@ void FlatIndex::grow(size_t min_rows) {
   HIP_CHECK(hipMalloc((void **)&nr, (new_cap + 32) * stride_));
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
   uint8_t *ns = nullptr;
+  float *nsc = nullptr;
   if (shadow_) {
     HIP_CHECK(hipMalloc((void **)&ns, (new_cap + 32) * sstride_));
     if (n_rows_) HIP_CHECK(hipMemcpyAsync(ns, d_shadow_, (size_t)n_rows_ * sstride_, hipMemcpyDeviceToDevice, wstream_));
+    if (shadow_ == 2) {
+      HIP_CHECK(hipMalloc((void **)&nsc, new_cap * sizeof(float)));
+      if (n_rows_) HIP_CHECK(hipMemcpyAsync(nsc, d_sscale_, (size_t)n_rows_ * sizeof(float), hipMemcpyDeviceToDevice, wstream_));
+    }
   }
   if (n_rows_) {
     HIP_CHECK(hipMemcpyAsync(nr, d_rows_, (size_t)n_rows_ * stride_, hipMemcpyDeviceToDevice, wstream_));
@@ -334,10 +346,27 @@ void FlatIndex::grow(size_t min_rows) {
     if (!n_rows_) HIP_CHECK(hipStreamSynchronize(wstream_));
     if (d_shadow_) HIP_CHECK(hipFree(d_shadow_));
     d_shadow_ = ns;
+    if (d_sscale_) HIP_CHECK(hipFree(d_sscale_));
+    d_sscale_ = nsc;
   }
   d_rows_ = nr;
   d_labels_ = nl;
   cap_rows_ = new_cap;
+}
+
+// new rows [row_begin,row_end) -> shadow, queued on wstream_ behind the copies / normalisation that produced them;
+// the int8 form also refreshes the host copy of the largest row scale (the caller syncs wstream_ anyway)
+void FlatIndex::shadow_convert(uint32_t row_begin, uint32_t row_end) {
+  if (!shadow_ || row_end <= row_begin) return;
+  if (shadow_ == 1) {
+    launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, row_begin, row_end, d_shadow_, sstride_, wstream_);
+    return;
+  }
+  launch_shadow8_rows(d_rows_, stride_, (uint32_t)dim, row_begin, row_end, d_shadow_, sstride_, d_sscale_, d_smax_, wstream_);
+  uint32_t bits = 0;
+  HIP_CHECK(hipMemcpyAsync(&bits, d_smax_, sizeof bits, hipMemcpyDeviceToHost, wstream_));
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  memcpy(&s_max_, &bits, 4);
 }
 
 void FlatIndex::reserve(size_t rows) {
@@ -407,8 +436,7 @@ void FlatIndex::flush() {
   HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)n_rows_ * stride_, h_stage_, stage_n_ * stride_, hipMemcpyHostToDevice, wstream_));
   HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + n_rows_, stage_n_ * sizeof(uint64_t),
                            hipMemcpyHostToDevice, wstream_));
-  if (shadow_)
-    launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, n_rows_, (uint32_t)(n_rows_ + stage_n_), d_shadow_, sstride_, wstream_);
+  shadow_convert(n_rows_, (uint32_t)(n_rows_ + stage_n_));
   HIP_CHECK(hipStreamSynchronize(wstream_));
   n_rows_ += (uint32_t)stage_n_;
   stage_n_ = 0;
@@ -459,6 +487,8 @@ int FlatIndex::remove(size_t label) {
       if (shadow_)
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
                                  hipMemcpyDeviceToDevice, wstream_));
+      if (shadow_ == 2)
+        HIP_CHECK(hipMemcpyAsync(d_sscale_ + r, d_sscale_ + last, sizeof(float), hipMemcpyDeviceToDevice, wstream_));
       row_label_[r] = moved;
       if (multi) {
         auto &v = multi_map_[moved];
@@ -491,8 +521,7 @@ int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_labe
   }
   if (metric == VecSimMetric_Cosine && kmetric == KM_IP)
     launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
-  if (shadow_)
-    launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, n_rows_, (uint32_t)(n_rows_ + n), d_shadow_, sstride_, wstream_);
+  shadow_convert(n_rows_, (uint32_t)(n_rows_ + n));
   size_t old = row_label_.size();
   row_label_.resize(old + n);
   for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
@@ -533,7 +562,7 @@ VecSimIndexBasicInfo FlatIndex::basic_info() const {
 
 // ---- query building blocks ---------------------------------------------------------------------------
 void FlatIndex::upload_query(QueryCtx *c, const void *blob, bool normalize) {
-  c->ensure_query(round_up(stride_ + 16, 16) + sstride_);  // (+ room for the fp16 copy of a two-stage scan)
+  c->ensure_query(round_up(stride_ + 16, 16) + sstride_ + 16);  // (+ room for the shadow-typed copy of a two-stage scan)
   memset(c->h_query, 0, stride_);
   memcpy(c->h_query, blob, elem_bytes_);
   if (normalize && metric == VecSimMetric_Cosine) normalize_host(c->h_query);
@@ -707,28 +736,60 @@ void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, 
 // Returns false (caller runs the full fp32 scan) when the survivors do not fit the candidate buffer.
 bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
   if (dim > 1024) return false;
-  constexpr float kSlack = 2.0f * 4e-3f;
-  // fp16 copy of the normalised query behind the fp32 one
+  float kSlack = 2.0f * 4e-3f;
+  // shadow-typed copy of the normalised query behind the fp32 one
   const size_t q16_off = round_up(stride_ + 16, 16);  // upload_query sized the buffers for it
   const float *qf = reinterpret_cast<const float *>(c->h_query);
-  uint16_t *q16 = reinterpret_cast<uint16_t *>(c->h_query + q16_off);
-  memset(q16, 0, sstride_);
-  for (size_t i = 0; i < dim; i++) q16[i] = f2h(qf[i]);
-  HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q16, sstride_, hipMemcpyHostToDevice, c->stream));
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
   c->ensure_keys(n);
   c->ensure_out(k);
-  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
-  if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-  launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_F16, KM_IP, 0, n, c->d_query + q16_off, c->d_keys, c->stream);
+  if (shadow_ == 1) {
+    uint16_t *q16 = reinterpret_cast<uint16_t *>(c->h_query + q16_off);
+    memset(q16, 0, sstride_);
+    for (size_t i = 0; i < dim; i++) q16[i] = f2h(qf[i]);
+    HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q16, sstride_, hipMemcpyHostToDevice, c->stream));
+    if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_F16, KM_IP, 0, n, c->d_query + q16_off, c->d_keys, c->stream);
+  } else {
+    // int8 shadow: x = sx (x8 + ex), q = sq (q8 + eq), |ex_i|, |eq_i| <= 1/2, so for unit vectors
+    //   |sx sq x8.q8 - x.q| <= sx (1 + sq sqrt(d)/2) sqrt(d)/2 + sq (1 + sx sqrt(d)/2) sqrt(d)/2 + sx sq d/4
+    //                        = (sx + sq) sqrt(d)/2 + (3/4) sx sq d,   sx <= s_max over all rows
+    float qmax = 0.0f;
+    for (size_t i = 0; i < dim; i++) qmax = std::max(qmax, std::fabs(qf[i]));
+    if (!(qmax > 0.0f) || !(s_max_ > 0.0f)) return false;
+    const float sq = qmax / 127.0f;
+    int8_t *q8 = reinterpret_cast<int8_t *>(c->h_query + q16_off);
+    memset(q8, 0, sstride_ + 16);
+    for (size_t i = 0; i < dim; i++) q8[i] = (int8_t)std::min(127.0f, std::max(-127.0f, std::nearbyintf(qf[i] / sq)));
+    memcpy(q8 + sstride_ + 4, &sq, 4);  // the extra chunk: {0, query scale}
+    HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q8, sstride_ + 16, hipMemcpyHostToDevice, c->stream));
+    const float rd = std::sqrt((float)dim);
+    const float eps = ((s_max_ + sq) * rd * 0.5f + 0.75f * s_max_ * sq * (float)dim) * 1.001f + 1e-6f;
+    kSlack = 2.0f * eps;
+    if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_I8, KM_IPS, 0, n, c->d_query + q16_off, c->d_keys, c->stream, d_sscale_);
+  }
   if (prof) {
     HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     c->prof_rows = n;
-    c->prof_bytes_per_row = dim * 2;
+    c->prof_bytes_per_row = shadow_ == 1 ? dim * 2 : dim + 4;
     c->prof_pending = true;
   }
   c->h_fcnt[1] = 0;
   c->h_fcnt[2] = 0;
-  launch_sample_threshold(c->d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
+  if (shadow_ == 2 && k > 16) {
+    // the int8 band is wide: with a sampled bound the survivors of K > 16 outgrow the candidate buffer, so tau is
+    // the EXACT K-th shadow distance here (radix levels over the shadow keys, ~0.1 ms)
+    std::vector<Hit> tmp;
+    Bound kth;
+    radix_select(c, c->d_keys, 4, n, k, Bound(), tmp, &kth);
+    const float tau = key_to_dist((uint32_t)kth.key);
+    HIP_CHECK(hipMemcpyAsync(c->d_tau, &tau, sizeof tau, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemsetAsync(c->d_fcnt, 0, 4 * sizeof(uint32_t), c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));  // (tau lives on this frame)
+  } else {
+    launch_sample_threshold(c->d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
+  }
   launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream, kSlack);
   HIP_CHECK(hipMemcpyAsync(c->h_fcnt + 3, c->d_fcnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -193,10 +193,15 @@ class FlatIndex {
   void rows_of(size_t label, std::vector<uint32_t> &out) const;
 
   size_t elem_bytes_, stride_;
-  // optional fp16 shadow of the rows (FLOAT32 cosine, single-value; ScanTuning::shadow16 at creation)
-  bool shadow_ = false;
+  // optional low-precision shadow of the rows (FLOAT32 cosine, single-value; chosen at creation by
+  // ScanTuning::shadow16 / shadow8): 0 none, 1 fp16, 2 int8 with one fp32 scale per row
+  int shadow_ = 0;
   size_t sstride_ = 0;
   uint8_t *d_shadow_ = nullptr;
+  float *d_sscale_ = nullptr;   // [cap_rows] (int8 shadow)
+  uint32_t *d_smax_ = nullptr;  // max row scale, f32 bits (atomicMax on the device)
+  float s_max_ = 0.0f;          // its host copy, refreshed by the writers
+  void shadow_convert(uint32_t row_begin, uint32_t row_end);  // on wstream_
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
   uint8_t *d_rows_ = nullptr;
   uint64_t *d_labels_ = nullptr;

@@ -14,7 +14,8 @@ namespace rsgpu {
 enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3, KT_I8 = 4, KT_U8 = 5 };
 // kernel metrics: for the floating-point types cosine is IP over rows/query normalised up front;
 // INT8/UINT8 rows cannot be normalised in place, their cosine divides by the two norms (KM_COS)
-enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2 };
+// KM_IPS (KT_I8 scan only): 1 - dot * row_scale[row] * query_scale, the int8-shadow filter pass
+enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2, KM_IPS = 3 };
 // distances (and keys) of FLOAT64 indexes are 8 bytes wide, everything else computes fp32 distances
 inline int key_bytes_of(int type) { return type == KT_F64 ? 8 : 4; }
 
@@ -55,6 +56,7 @@ struct ScanTuning {
   int shadow16 = 0;        // FLOAT32 cosine indexes created while set keep an fp16 shadow of the rows: the scan
                            // reads the shadow, an error-bounded filter keeps the few rows that can still be in
                            // the top-K, and only those are re-scored from the fp32 rows (exact, bit-identical)
+  int shadow8 = 0;         // same with an int8 shadow (+ per-row scale): a quarter of the bytes, wider error band
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
@@ -65,8 +67,9 @@ ScanTuning &scan_tuning();
 // Distances of rows [row_begin,row_end) to `query`, written as orderable keys keys[row] (u32, or u64
 // for KT_F64).  rows: row-contiguous, `stride` bytes per row (multiple of 16, zero padded), query padded
 // alike; for KT_I8/KT_U8 one more 16-byte chunk follows the padded query: {sum q^2 (i32/u32), |q| (f32)}.
+// KM_IPS: row_scale[row] (fp32) per row; the extra query chunk is {0, query_scale as f32 bits}.
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, void *keys, hipStream_t s);
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_scale = nullptr);
 
 // Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
@@ -79,6 +82,10 @@ void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, ui
 // fp16 shadow of fp32 rows [row_begin,row_end): out row stride sstride bytes (multiple of 16, zero padded)
 void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
                         size_t sstride, hipStream_t s);
+// int8 shadow of unit-norm fp32 rows: shadow[r][i] = rint(x[r][i] / scale[r]), scale[r] = max|x[r]| / 127;
+// smax_bits[0] = max over rows of scale (as f32 bits, atomicMax)
+void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
+                         size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s);
 // rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
 void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
 // cand[i].y = orderable key of dists[i]

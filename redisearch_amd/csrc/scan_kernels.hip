@@ -213,7 +213,7 @@ struct OpInt {
     acc.xq = dot4<TYPE>(x.y, q.y, acc.xq);
     acc.xq = dot4<TYPE>(x.z, q.z, acc.xq);
     acc.xq = dot4<TYPE>(x.w, q.w, acc.xq);
-    if (METRIC != KM_IP) {
+    if (METRIC == KM_L2 || METRIC == KM_COS) {
       acc.xx = dot4<TYPE>(x.x, x.x, acc.xx);
       acc.xx = dot4<TYPE>(x.y, x.y, acc.xx);
       acc.xx = dot4<TYPE>(x.z, x.z, acc.xx);
@@ -266,6 +266,7 @@ __device__ __forceinline__ float finish(I2 acc, u4 qx) {
   const long long qq = TYPE == KT_I8 ? (long long)(int)qx.x : (long long)qx.x;
   if (METRIC == KM_L2) return (float)(xx + qq - 2 * xq);
   if (METRIC == KM_IP) return 1.0f - (float)xq;
+  if (METRIC == KM_IPS) return (float)xq;  // scaled per row where the key is stored
   return 1.0f - (float)xq / (sqrtf((float)xx) * __uint_as_float(qx.y));
 }
 
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
               if (rid[u] == 0xFFFFFFFFu) set_nan(v);
               dists[r] = v;
             } else {
+              if (METRIC == KM_IPS) v = (out_t)(1.0f - (float)v * (reinterpret_cast<const float *>(row_ids)[r] * __uint_as_float(qx.y)));
               keys[r] = to_key(v);
             }
           }
@@ -367,6 +369,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
           if (my_rid == 0xFFFFFFFFu) set_nan(mine);
           dists[r0 + lane] = mine;
         } else {
+          if (METRIC == KM_IPS)
+            mine = (out_t)(1.0f - (float)mine * (reinterpret_cast<const float *>(row_ids)[r0 + lane] * __uint_as_float(qx.y)));
           keys[r0 + lane] = to_key(mine);
         }
       }
@@ -425,6 +429,7 @@ inline Shape pick_shape(uint32_t chunks) {
   // 96 / 160 / 224 chunks (e.g. 768 halves): half a wavefront per row keeps every lane of every load busy,
   // a full one would idle 32 lanes in its last pass
   if (chunks > 64 && chunks % 64 == 32 && chunks <= 224) return {32, (int)(chunks / 32)};
+  if (chunks == 48 || chunks == 80 || chunks == 112) return {16, (int)(chunks / 16)};  // e.g. 768 int8 elements
   if (chunks > 64) return {64, (int)((chunks + 63) / 64)};
   int g = 1;
   while ((uint32_t)g < chunks) g <<= 1;
@@ -494,6 +499,13 @@ void launch_shape(const LaunchCtx &c) {
       default: return launch_one<TYPE, METRIC, 64, 1, 8, GATHER>(c);
     }
   }
+  if (sh.G == 16) {
+    switch (sh.ITERS) {
+      case 3: return launch_one<TYPE, METRIC, 16, 3, 4, GATHER>(c);
+      case 5: return launch_one<TYPE, METRIC, 16, 5, 2, GATHER>(c);
+      default: return launch_one<TYPE, METRIC, 16, 7, 2, GATHER>(c);
+    }
+  }
   if (sh.G == 32) {
     switch (sh.ITERS) {
       case 3: return launch_one<TYPE, METRIC, 32, 3, 4, GATHER>(c);
@@ -534,7 +546,15 @@ void dispatch(int type, int metric, const LaunchCtx &c) {
     RSGPU_CASE(KT_F64)
     RSGPU_CASE(KT_F16)
     RSGPU_CASE(KT_BF16)
-    RSGPU_CASE_INT(KT_I8)
+    case KT_I8:
+      if (metric == KM_IPS) {
+        if (!GATHER) launch_shape<KT_I8, KM_IPS, false>(c);
+        break;
+      }
+      if (metric == KM_L2) launch_shape<KT_I8, KM_L2, GATHER>(c);
+      else if (metric == KM_IP) launch_shape<KT_I8, KM_IP, GATHER>(c);
+      else launch_shape<KT_I8, KM_COS, GATHER>(c);
+      break;
     RSGPU_CASE_INT(KT_U8)
     default: break;
   }
@@ -605,7 +625,42 @@ __global__ __launch_bounds__(256) void shadow_rows_kernel(const float *__restric
   }
 }
 
+// int8 shadow + per-row scale of unit-norm fp32 rows, one wavefront per row
+__global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restrict__ rows, uint32_t stride_f, uint32_t dim,
+                                                           uint32_t row_begin, uint32_t row_end,
+                                                           int8_t *__restrict__ shadow, uint32_t sstride,
+                                                           float *__restrict__ scale, uint32_t *__restrict__ smax_bits) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
+    const float *src = rows + (size_t)r * stride_f;
+    float m = 0.0f;
+    for (uint32_t i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(src[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float sc = m > 0.0f ? m / 127.0f : 1.0f;  // (an all-zero row: every quantised element is 0)
+    int8_t *dst = shadow + (size_t)r * sstride;
+    for (uint32_t i = lane; i < sstride; i += 64) {
+      float v = i < dim ? rintf(src[i] / sc) : 0.0f;
+      v = fminf(fmaxf(v, -127.0f), 127.0f);
+      dst[i] = (int8_t)v;
+    }
+    if (lane == 0) {
+      scale[r] = sc;
+      atomicMax(smax_bits, __float_as_uint(sc));
+    }
+  }
+}
+
 }  // namespace
+
+void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
+                         size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s) {
+  if (row_end <= row_begin) return;
+  uint32_t n = row_end - row_begin;
+  uint32_t need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  hipLaunchKernelGGL(shadow8_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const float *)rows,
+                     (uint32_t)(stride / 4), dim, row_begin, row_end, (int8_t *)shadow, (uint32_t)sstride, scale, smax_bits);
+}
 
 void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
                         size_t sstride, hipStream_t s) {
@@ -617,11 +672,12 @@ void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t 
 }
 
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, void *keys, hipStream_t s) {
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_scale) {
   (void)dim;
   if (row_end <= row_begin) return;
+  // (KM_IPS: the per-row scales travel in the row_ids slot, which a plain scan does not use)
   LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
-              (const u4 *)query, nullptr, keys, nullptr, s};
+              (const u4 *)query, reinterpret_cast<const uint32_t *>(row_scale), keys, nullptr, s};
   dispatch<false>(type, metric, c);
 }
 

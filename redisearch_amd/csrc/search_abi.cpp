@@ -29,10 +29,11 @@ class DevPool {
     while (c < bytes) c <<= 1;
     return c;
   }
-  void *take(size_t bytes, size_t *got) {
+  void *take(size_t bytes, size_t *got, int *dev_out) {
     const size_t c = size_class(bytes);
     int dev = 0;
     HIP_CHECK(hipGetDevice(&dev));
+    *dev_out = dev;
     {
       std::lock_guard<std::mutex> g(mu_);
       auto &v = free_[key(dev, c)];
@@ -49,9 +50,7 @@ class DevPool {
     *got = c;
     return p;
   }
-  void give(void *p, size_t cls) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  void give(void *p, size_t cls, int dev) {  // dev: the device the buffer was allocated on
     {
       std::lock_guard<std::mutex> g(mu_);
       if (parked_ + cls <= kPoolCap) {
@@ -76,12 +75,13 @@ struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
   size_t cls = 0;  // pool size class in bytes
+  int dev = 0;     // device it lives on
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { reset(); }
   void reset() {
-    if (p) DevPool::get().give(p, cls);
+    if (p) DevPool::get().give(p, cls, dev);
     p = nullptr;
     n = 0;
     cls = 0;
@@ -89,7 +89,7 @@ struct DevBuf {
   void alloc(size_t count) {
     reset();
     if (!count) count = 1;
-    p = static_cast<T *>(DevPool::get().take(count * sizeof(T), &cls));
+    p = static_cast<T *>(DevPool::get().take(count * sizeof(T), &cls, &dev));
     n = count;
   }
   void ensure(size_t count) {

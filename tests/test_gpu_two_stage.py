@@ -12,17 +12,20 @@ pytestmark = pytest.mark.gpu
 F32, COS = V.VecSimType_FLOAT32, V.VecSimMetric_Cosine
 
 
-def pair(x):
-    """the same rows in a plain index and in one with the fp16 shadow"""
+MODES = [b"shadow16", b"shadow8"]
+
+
+def pair(x, mode=b"shadow16"):
+    """the same rows in a plain index and in one with a low-precision shadow (fp16 or int8 + row scales)"""
     lib = V.load()
     out = []
     for shadow in (0, 1):
-        lib.RSGPU_SetTuning(b"shadow16", shadow)
+        lib.RSGPU_SetTuning(mode, shadow)
         idx = V.VecSimIndex(F32, x.shape[1], COS)
         torch.cuda.synchronize()
         idx.add_device_rows(x.data_ptr(), x.shape[0], 1)
         out.append(idx)
-    lib.RSGPU_SetTuning(b"shadow16", 0)
+    lib.RSGPU_SetTuning(mode, 0)
     return out
 
 
@@ -33,15 +36,16 @@ def same(plain, shadow, q, k):
     return pi
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("dim,n", [(768, 300_000), (96, 1_000_000), (33, 400_003)])
-def test_random_rows_identical(dim, n):
+def test_random_rows_identical(dim, n, mode):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(dim + n)
     x = torch.rand((n, dim), device=dev, generator=gen) * 2 - 1
-    plain, shadow = pair(x)
+    plain, shadow = pair(x, mode)
     rng = np.random.default_rng(dim)
-    for k in (1, 10, 16, 100):
+    for k in (1, 10, 16, 17, 100):
         for _ in range(4):
             same(plain, shadow, rng.uniform(-1, 1, dim).astype(np.float32), k)
     # a query that IS a stored row (distance ~0, others far) and its negation
@@ -50,34 +54,37 @@ def test_random_rows_identical(dim, n):
     same(plain, shadow, -q, 10)
 
 
-def test_clustered_rows_inside_the_error_band():
+@pytest.mark.parametrize("mode", MODES)
+def test_clustered_rows_inside_the_error_band(mode):
     # 300k rows = 300 tight clusters: thousands of rows within 1e-3 of the k-th distance; still exact
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(5)
     centers = torch.rand((300, 64), device=dev, generator=gen) * 2 - 1
     x = centers.repeat_interleave(1000, 0) + 1e-3 * (torch.rand((300_000, 64), device=dev, generator=gen) - 0.5)
-    plain, shadow = pair(x)
+    plain, shadow = pair(x, mode)
     for c in (0, 7, 299):
         same(plain, shadow, centers[c].cpu().numpy(), 10)
         same(plain, shadow, (centers[c] + 0.01).cpu().numpy(), 16)
 
 
-def test_candidate_overflow_falls_back_to_the_full_scan():
+@pytest.mark.parametrize("mode", MODES)
+def test_candidate_overflow_falls_back_to_the_full_scan(mode):
     # every row identical: all of them pass the filter -> overflow -> one-stage path, ties by storage row
     x = torch.ones((300_000, 16), device="cuda")
-    plain, shadow = pair(x)
+    plain, shadow = pair(x, mode)
     ids, sc = shadow.topk_query(np.ones(16, np.float32), 10).results()
     assert ids.tolist() == list(range(1, 11))
     same(plain, shadow, np.ones(16, np.float32), 10)
 
 
-def test_shadow_follows_deletes_and_appends():
+@pytest.mark.parametrize("mode", MODES)
+def test_shadow_follows_deletes_and_appends(mode):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
     gen.manual_seed(9)
     x = torch.rand((300_000, 48), device=dev, generator=gen) * 2 - 1
-    plain, shadow = pair(x)
+    plain, shadow = pair(x, mode)
     q = x[777].cpu().numpy()
     assert same(plain, shadow, q, 5)[0] == 778
     for idx in (plain, shadow):
@@ -90,3 +97,21 @@ def test_shadow_follows_deletes_and_appends():
     for idx in (plain, shadow):
         idx.add_device_rows(extra.data_ptr(), 50_000, 1_000_000)
     same(plain, shadow, extra[5].cpu().numpy(), 10)
+
+
+def test_spiky_rows_make_the_int8_band_wide_but_results_stay_exact():
+    # a few one-hot rows force the largest row scale to 1/127: the int8 error band swallows most rows, the
+    # candidate buffer overflows and the query is answered by the full scan -- still identical
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(31)
+    x = torch.rand((300_000, 128), device=dev, generator=gen) * 2 - 1
+    x[1000:1010] = 0
+    x[1000:1010, 5] = 1.0
+    plain, shadow = pair(x, b"shadow8")
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        same(plain, shadow, rng.uniform(-1, 1, 128).astype(np.float32), 10)
+    q = np.zeros(128, np.float32)
+    q[5] = 1.0
+    assert set(same(plain, shadow, q, 10).tolist()) == set(range(1001, 1011))
