@@ -247,6 +247,8 @@ std::string &last_error();  // per-thread message behind RSGPU_LastError
 // Drives select_kernels.hip on c->stream and synchronises it.
 void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, uint32_t k, const Bound &lower,
                   std::vector<Hit> &out, Bound *upper);
+// frees the device buffers parked by the search seam's pool (search_abi.cpp)
+void release_search_pool();
 // k smallest (key,index) of a u32 key array: one-workgroup select for short arrays, radix levels otherwise
 void select_keys32(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out);
 VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code);

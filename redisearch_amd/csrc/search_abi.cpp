@@ -50,6 +50,16 @@ class DevPool {
     *got = c;
     return p;
   }
+  void drain() {
+    std::unordered_map<uint64_t, std::vector<void *>> f;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      f.swap(free_);
+      parked_ = 0;
+    }
+    for (auto &kv : f)
+      for (void *p : kv.second) (void)hipFree(p);
+  }
   void give(void *p, size_t cls, int dev) {  // dev: the device the buffer was allocated on
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -219,6 +229,10 @@ static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
                        p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
   HIP_CHECK(hipGetLastError());
 }
+
+namespace rsgpu {
+void release_search_pool() { DevPool::get().drain(); }
+}  // namespace rsgpu
 
 extern "C" {
 

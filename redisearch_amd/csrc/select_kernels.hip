@@ -480,9 +480,9 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
 
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
                         uint32_t cap, hipStream_t s, float slack) {
-  uint32_t need = (n / 4 + 1023) / 1024, cap_g = (uint32_t)scan_tuning().num_cus * 8;
-  uint32_t g = need < cap_g ? need : cap_g;
-  hipLaunchKernelGGL(filter_keys_kernel, dim3(g ? g : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap,
+  // one step per workgroup (a capped grid left ~20 % of the workgroups a second step: 21 us instead of ~12)
+  uint32_t need = (n / 4 + 1023) / 1024;
+  hipLaunchKernelGGL(filter_keys_kernel, dim3(need ? need : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap,
                      slack);
 }
 

@@ -546,6 +546,9 @@ int RSGPU_SetTuning(const char *key, int value) {
   else return -1;
   return 0;
 }
-void RSGPU_ReleaseWorkspaces(void) { CtxPool::get().drain(); }
+void RSGPU_ReleaseWorkspaces(void) {
+  CtxPool::get().drain();
+  rsgpu::release_search_pool();  // parked hit-list buffers of the search seam
+}
 
 }  // extern "C"
