@@ -107,3 +107,42 @@ def test_delete_and_overwrite_at_full_size(big):
     assert idx.add_vector(q, planted[0]) == 1               # exact duplicate of the query: distance ~0, first
     ids, sc = idx.topk_query(q, 3).results()
     assert ids[0] == planted[0] and sc[0] <= 1e-6 and ids[1:].tolist() == planted[1:3]
+
+
+def test_batched_config3_full_size_planted_neighbours():
+    """BASELINE configs[2] at full size: 10M x 768 fp16 IP, 256 queries per pass, top-100.  Planted rows (scaled
+    copies of a query, so their inner product is the largest by far) must lead that query's list in order; all
+    lists are sorted and free of duplicates; a sample of queries matches the single-query path."""
+    import torch
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2 ** 30:
+        pytest.skip("needs an MI355X-class device")
+    rows, dim, k, nq = 10_000_000, 768, 100, 256
+    queries = np.random.default_rng(48).uniform(-1, 1, (nq, dim)).astype(np.float16)
+    idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
+    idx.reserve(rows)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(47)
+    plant = {7: [(123_456, 3.0), (9_999_999, 2.5), (5_000_000, 2.0)], 200: [(0, 4.0), (31, 3.5)]}   # query -> (row, scale)
+    done = 0
+    while done < rows:
+        m = min(1_000_000, rows - done)
+        t = (torch.rand((m, dim), device=dev, generator=gen) * 2 - 1).to(torch.float16)
+        for qi, lst in plant.items():
+            for row, scale in lst:
+                if done <= row < done + m:
+                    t[row - done] = torch.from_numpy(queries[qi].astype(np.float32) * scale).to(dev).to(torch.float16)
+        torch.cuda.synchronize()
+        idx.add_device_rows(t.data_ptr(), m, done + 1)
+        done += m
+        del t
+    ids, sc, cnt = idx.topk_batch(queries, k)
+    assert (cnt == k).all()
+    for qi, lst in plant.items():
+        want = [row + 1 for row, _ in lst]
+        assert ids[qi, :len(want)].tolist() == want
+    assert np.all(np.diff(sc, axis=1) >= 0)
+    assert all(len(set(ids[i].tolist())) == k for i in range(nq))
+    for qi in (0, 7, 200, 255):
+        si, ss = idx.topk_query(queries[qi], k).results()
+        assert len(set(si.tolist()) ^ set(ids[qi].tolist())) <= 2 and np.allclose(ss, sc[qi], rtol=1e-3, atol=2e-3)
