@@ -156,7 +156,10 @@ def main():
     assert index.index_size() == rows
     queries = np.random.default_rng(48).uniform(-1, 1, (1000, dim)).astype(np.float32)
 
-    if world > 1:
+    # RSGPU_BENCH_FORCE_SHARDED=1 (test hook): run the sharded code path -- device-side per-shard top-k, packing,
+    # merge -- on a single rank too (the all-gather itself needs >= 2 ranks)
+    force_sharded = os.environ.get("RSGPU_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         from redisearch_amd.sharded import ShardedTopK
         loc_s = torch.empty(k, device=dev, dtype=torch.float32)
         loc_l = torch.empty(k, device=dev, dtype=torch.int64)
@@ -169,7 +172,7 @@ def main():
 
     def one_query(i):
         q = queries[i % len(queries)]
-        if world == 1:
+        if world == 1 and not force_sharded:
             rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
             n = lib.VecSimQueryReply_Len(rep)
             lib.VecSimQueryReply_Free(rep)

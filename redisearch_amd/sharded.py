@@ -37,12 +37,13 @@ class ShardedTopK:
 
     def query(self, q):
         s, l = self.local_topk(q, self.k)
-        if self.world == 1:
-            return merge_topk(s.cpu().numpy(), l.cpu().numpy().view(np.uint64), self.k)
         k = self.k
         self.pack[:k] = l
         self.pack[k:] = s.view(self.torch.int32)
-        self.dist.all_gather_into_tensor(self.all_p, self.pack, group=self.group)
+        if self.world == 1:
+            self.all_p.copy_(self.pack)
+        else:
+            self.dist.all_gather_into_tensor(self.all_p, self.pack, group=self.group)
         ap = self.all_p.cpu().numpy().reshape(self.world, 2, k)
         labels = np.ascontiguousarray(ap[:, 0, :]).ravel().view(np.uint64)
         scores = np.ascontiguousarray(ap[:, 1, :]).astype(np.int32).ravel().view(np.float32)
