@@ -322,11 +322,22 @@ void FlatIndex::grow(size_t min_rows) {
   new_cap = round_up(new_cap, 64);
   uint8_t *nr = nullptr;
   uint64_t *nl = nullptr;
+  uint8_t *ns = nullptr;
+  float *nsc = nullptr;
+  // an allocation that fails (HBM exhausted) must not leak the ones before it: the index stays usable at its
+  // old capacity and the caller sees the error
+  struct Rollback {
+    void **p[4];
+    bool armed = true;
+    ~Rollback() {
+      if (armed)
+        for (void **q : p)
+          if (*q) HIP_IGNORE(hipFree(*q));
+    }
+  } rollback{{(void **)&nr, (void **)&nl, (void **)&ns, (void **)&nsc}};
   // 32 rows of slack behind the capacity: the batched filter pass reads its ragged last tile whole
   HIP_CHECK(hipMalloc((void **)&nr, (new_cap + 32) * stride_));
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
-  uint8_t *ns = nullptr;
-  float *nsc = nullptr;
   if (shadow_) {
     HIP_CHECK(hipMalloc((void **)&ns, (new_cap + 32) * sstride_));
     if (n_rows_) HIP_CHECK(hipMemcpyAsync(ns, d_shadow_, (size_t)n_rows_ * sstride_, hipMemcpyDeviceToDevice, wstream_));
@@ -340,10 +351,11 @@ void FlatIndex::grow(size_t min_rows) {
     HIP_CHECK(hipMemcpyAsync(nl, d_labels_, (size_t)n_rows_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
     HIP_CHECK(hipStreamSynchronize(wstream_));
   }
+  if (shadow_ && !n_rows_) HIP_CHECK(hipStreamSynchronize(wstream_));
+  rollback.armed = false;
   if (d_rows_) HIP_CHECK(hipFree(d_rows_));
   if (d_labels_) HIP_CHECK(hipFree(d_labels_));
   if (shadow_) {
-    if (!n_rows_) HIP_CHECK(hipStreamSynchronize(wstream_));
     if (d_shadow_) HIP_CHECK(hipFree(d_shadow_));
     d_shadow_ = ns;
     if (d_sscale_) HIP_CHECK(hipFree(d_sscale_));

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "VecSim/vec_sim.h"
@@ -265,7 +266,7 @@ struct BatchIterator {
   uint32_t returned = 0;
   Bound lower;
   bool scanned = false;
-  std::vector<uint64_t> seen_labels;  // multi-value: labels already yielded
+  std::unordered_set<uint64_t> seen_labels;  // multi-value: labels already yielded
 };
 
 struct AdhocCtx {

@@ -234,6 +234,13 @@ namespace rsgpu {
 void release_search_pool() { DevPool::get().drain(); }
 }  // namespace rsgpu
 
+static void check_lists(const char *who, RSGPU_Postings *const *lists, size_t n_lists) {
+  for (size_t l = 0; l < n_lists; l++) {
+    if (!lists[l]) throw std::runtime_error(std::string(who) + ": NULL list");
+    if (lists[l]->device != lists[0]->device) throw std::runtime_error(std::string(who) + ": lists on different devices");
+  }
+}
+
 extern "C" {
 
 RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t *first_doc_id,
@@ -312,6 +319,7 @@ RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
     return nullptr;
   }
   S_TRY
+  check_lists("RSGPU_Intersect", lists, n_lists);
   const int device = lists[0]->device;
   HIP_CHECK(hipSetDevice(device));
   CtxLease c(device);
@@ -370,6 +378,7 @@ RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
     return nullptr;
   }
   S_TRY
+  check_lists("RSGPU_Union", lists, n_lists);
   const int device = lists[0]->device;
   HIP_CHECK(hipSetDevice(device));
   CtxLease c(device);
@@ -478,7 +487,8 @@ RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t 
     sc.total.ensure(1);
     launch_count_below(child->ids.p, child->n_entries, max_doc_id + 1, sc.total.p, c->stream);
     uint32_t below = 0;
-    HIP_CHECK(hipMemcpy(&below, sc.total.p, sizeof below, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpyAsync(&below, sc.total.p, sizeof below, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));  // (the query stream does not synchronise with the null stream)
     total = max_doc - below;
   } else {
     const uint32_t nb = (n_cand + 255) / 256;

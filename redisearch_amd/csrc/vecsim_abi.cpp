@@ -320,8 +320,7 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
     for (const Hit &h : hits) {
       uint64_t lab = f->label_of_row(h.row);
       if (f->multi) {  // a label is yielded once, at its best vector
-        if (std::find(b.seen_labels.begin(), b.seen_labels.end(), lab) != b.seen_labels.end()) continue;
-        b.seen_labels.push_back(lab);
+        if (!b.seen_labels.insert(lab).second) continue;
       }
       res.push_back(VecSimQueryResult{(size_t)lab, f->score_of(h.key)});
     }
