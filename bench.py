@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (default: the BASELINE config)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", choices=["cosine", "l2", "ip"], default="cosine",
+                    help="cosine = BASELINE configs[1] (default); l2 = the metric configs[3] names for the 8-GPU corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-two-stage-extra", action="store_true", help="skip the extra two-stage measurement (N=1)")
@@ -44,7 +46,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0):
+def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0, metric="cosine"):
     """The oracle's FLAT scan (scalar max-heap, one thread = how one RediSearch worker runs one FLAT
     query) timed on a bounded sample of the same workload, scaled linearly in rows to the full size."""
     import oracle as O
@@ -64,7 +66,7 @@ def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0):
         flavour = "portable(avx512/avx2 clones)"
     rng = np.random.default_rng(47)
     data = rng.uniform(-1, 1, (sample_rows, dim)).astype(np.float32)
-    h = lib.oflat_new(O.F32, dim, O.COSINE, 0, 1024)
+    h = lib.oflat_new(O.F32, dim, {"cosine": O.COSINE, "l2": O.L2, "ip": O.IP}[metric], 0, 1024)
     lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), sample_rows, 1)
     qs = np.random.default_rng(48).uniform(-1, 1, (64, dim)).astype(np.float32)
     ids = np.zeros(k, np.uint64)
@@ -104,8 +106,8 @@ def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0):
     qps_sample = n / el
     return {"value": qps_sample * sample_rows / full_rows, "unit": "queries/s", "cores": 1, "kind": "port",
             "eight_threads": {"value": qps8, "cores": 8, "note": "8 concurrent queries, same sample, scaled by rows"},
-            "sample": "%d queries over a %d x %d fp32 cosine sample in %.1f s (oracle/flat_oracle.c oflat_topk_heap, %s), "
-                      "scaled by rows to %d" % (n, sample_rows, dim, el, flavour, full_rows)}
+            "sample": "%d queries over a %d x %d fp32 %s sample in %.1f s (oracle/flat_oracle.c oflat_topk_heap, %s), "
+                      "scaled by rows to %d" % (n, sample_rows, dim, metric, el, flavour, full_rows)}
 
 
 def main():
@@ -132,14 +134,15 @@ def main():
     shadow8 = any(kv.replace(" ", "") == "shadow8=1" for kv in a.tuning)
     # N=1: the index also carries the int8 shadow of the opt-in two-stage exact scan; it is switched OFF for the
     # timed headline loop (plain fp32 scan) and measured separately afterwards as an extra config entry
-    extra_two_stage = world == 1 and not two_stage and not a.no_two_stage_extra
+    extra_two_stage = world == 1 and not two_stage and not a.no_two_stage_extra and a.metric == "cosine"
     if extra_two_stage:
         lib.RSGPU_SetTuning(b"shadow8", 1)
         lib.RSGPU_SetTuning(b"two_stage", 0)
 
     # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
     rows, dim, k = a.rows, a.dim, a.k
-    index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_Cosine)
+    index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, {"cosine": V.VecSimMetric_Cosine, "l2": V.VecSimMetric_L2,
+                                                      "ip": V.VecSimMetric_IP}[a.metric])
     index.reserve(rows)
     gen = torch.Generator(device=dev)
     gen.manual_seed(47 + rank)
@@ -251,11 +254,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d fp32 FLAT COSINE top-%d per GPU, single-query stream via VecSimIndex_TopKQuery"
-                            % (rows, dim, k),
+                "workload": "%dx%d fp32 FLAT %s top-%d per GPU, single-query stream via VecSimIndex_TopKQuery"
+                            % (rows, dim, a.metric.upper(), k),
                 "value_definition": "10M-row shard scans per second summed over the GPUs (= n_gpus x the global QPS on the "
                                     "row-sharded corpus; at n_gpus=1 it IS the QPS); p50/p95 latency below",
-                "rows_per_gpu": rows, "dim": dim, "k": k, "metric": "COSINE",
+                "rows_per_gpu": rows, "dim": dim, "k": k, "metric": a.metric.upper(),
                 "corpus_rows_total": rows * world,
                 "parallelism": "row-sharded x%d, RCCL all-gather of per-shard top-k + merge" % world if world > 1 else "single GPU",
                 "global_qps_on_sharded_corpus": global_qps,
@@ -266,7 +269,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "kernel": ("scan_kernel<i8,IPS,G=16,ITERS=3,U=4> over the int8 shadow (two-stage exact scan)" if two_stage and shadow8
                            else "scan_kernel<f16,IP,G=32,ITERS=3,U=4> over the fp16 shadow (two-stage exact scan)" if two_stage
-                           else "scan_kernel<f32,IP,G=64,ITERS=3,U=8> (FLAT scan)"), "launches": int(launches),
+                           else "scan_kernel<f32,%s,G=64,ITERS=3,U=8> (FLAT scan)" % ("L2" if a.metric == "l2" else "IP")), "launches": int(launches),
                 "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
@@ -285,7 +288,7 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/r01_scan_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)"
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(dim, k, min(a.cpu_sample_rows, rows), rows)
+                out["cpu_baseline"] = cpu_baseline(dim, k, min(a.cpu_sample_rows, rows), rows, metric=a.metric)
             except Exception as e:  # the baseline leg must never cost the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
