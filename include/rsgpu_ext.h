@@ -39,8 +39,10 @@ int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, 
                                uint64_t *dev_labels);
 /* B queries at once: queries = [n_queries][dim] elements of the index type (host). Writes
  * ids_out/scores_out [n_queries][k] ordered by (score,label) and counts_out[n_queries]. FLOAT16 /
- * BFLOAT16 IP or COSINE indexes take the matrix-core GEMM path (256 queries per corpus pass); every
- * other configuration loops over the single-query path. 0 on success. */
+ * BFLOAT16 IP or COSINE indexes take the matrix-core GEMM path (256 queries per corpus pass); so do FLOAT32
+ * COSINE indexes created with the "shadow16" knob (filter pass over the fp16 shadow, survivors re-scored from the
+ * fp32 rows: results bit-identical to single queries); every other configuration loops over the single-query
+ * path. 0 on success. */
 int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_queries, size_t k, size_t *ids_out,
                               double *scores_out, size_t *counts_out);
 /* k best of m (score,label) candidates held in device memory (e.g. after an RCCL all-gather of

@@ -54,7 +54,7 @@ struct Pinned {
 };
 struct BatchScratch {
   int device = -1;
-  Dev<uint8_t> queries;
+  Dev<uint8_t> queries, queries16;  // (queries16: fp16 copy for the pass over an fp16 shadow)
   Dev<float> tau;
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
   Dev<uint64_t> cand, sub_cand;
@@ -68,8 +68,15 @@ thread_local BatchScratch tls_batch[2];
 
 void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
                            size_t *counts_out) {
-  const bool gemm_ok = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 &&
-                       !multi && k > 0 && k <= 4096;
+  // FLOAT32 cosine indexes that carry an fp16 shadow (two-stage exact scan, flat_index.cpp): the MFMA filter pass
+  // runs over the shadow with a 2*eps wider threshold, the survivors are re-scored from the fp32 rows with the
+  // single-query scan's arithmetic -> ids and distances bit-identical to 256 single queries
+  const bool via_shadow = type == VecSimType_FLOAT32 && shadow_ == 1 && metric == VecSimMetric_Cosine && !multi && k > 0 &&
+                          k <= 1024 && dim <= 1024 && dim % 8 == 0 && scan_tuning().two_stage && scan_tuning().gemm_qs &&
+                          gemm_qs_supported((uint32_t)(sstride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
+  const bool gemm_ok = via_shadow || ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) &&
+                                      metric != VecSimMetric_L2 && !multi && k > 0 && k <= 4096);
+  const float slack = via_shadow ? 2.0f * 4e-3f : 0.0f;  // eps: FlatIndex::two_stage_topk
   auto single = [&](size_t qi) {
     VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
     counts_out[qi] = r->len;
@@ -86,6 +93,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   }
   flush_if_needed();
   std::vector<size_t> redo;
+  // the corpus the MFMA passes read
+  const int g_type = via_shadow ? KT_F16 : ktype;
+  const size_t g_stride = via_shadow ? sstride_ : stride_;
   {
     std::shared_lock<std::shared_mutex> g(mu);
     const uint32_t n = n_rows_;
@@ -107,7 +117,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
     }
     const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
-    const uint32_t stride16 = (uint32_t)(stride_ / 16);
+    const uint8_t *g_rows = via_shadow ? d_shadow_ : d_rows_;
+    const uint32_t stride16 = (uint32_t)(g_stride / 16);
     // sample prefix for the thresholds; small corpora take the all-keys path
     const bool small = n <= (1u << 19);
     uint32_t n0 = small ? n : std::min<uint32_t>(std::max<uint32_t>(round_up(n / 64, 256), 1u << 16), 1u << 18);
@@ -118,6 +129,11 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
     const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
+    if (via_shadow && !use_qs) {  // small corpora: the single-query path is already cheap
+      g.unlock();
+      for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+      return;
+    }
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
@@ -134,12 +150,13 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         seen = std::max(seen, e);
         from = e;
       }
-      expect_total *= 6;
+      expect_total *= via_shadow ? 18 : 6;  // (the shadow's error band roughly triples the survivors)
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
     for (int sl = 0; sl < n_slots; sl++) {
       BatchScratch &sc = tls_batch[sl];
       sc.queries.ensure((size_t)kBatch * stride_);
+      if (via_shadow) sc.queries16.ensure((size_t)kBatch * sstride_);
       sc.tau.ensure(kBatch);
       sc.cand_count.ensure(kBatch);
       sc.overflow.ensure(kBatch);
@@ -162,7 +179,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         const uint32_t grid = gemm_qs_grid(e - from);
         qs_grid_max = std::max(qs_grid_max, grid);
         const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
-        while (sub_cap < 8 * expect) sub_cap *= 2;
+        while (sub_cap < (via_shadow ? 24 : 8) * expect) sub_cap *= 2;
         seen = std::max(seen, e);
         from = e;
       }
@@ -186,6 +203,11 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         if (metric == VecSimMetric_Cosine) normalize_host(dst);
       }
       HIP_CHECK(hipMemcpyAsync(sc.queries.p, hq, (size_t)kBatch * stride_, hipMemcpyHostToDevice, c->stream));
+      const uint8_t *g_queries = sc.queries.p;
+      if (via_shadow) {  // fp16 (RNE) copy of the normalised queries, made by the kernel that makes the shadow rows
+        launch_shadow_rows(sc.queries.p, stride_, (uint32_t)dim, 0, kBatch, sc.queries16.p, sstride_, c->stream);
+        g_queries = sc.queries16.p;
+      }
       if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
       if (small) {
         launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
@@ -193,28 +215,31 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         launch_batch_select_keys(sc.keys.p, n0, n, kk, kBatch, sc.out_rows.p, sc.out_keys.p, sc.out_n.p, kk, c->stream);
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
       } else {
-        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
+        launch_gemm_topk(g_type, g_rows, g_queries, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
                          c->stream);
-        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream);
+        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream, 1, slack);
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
         if (use_qs) {
           uint32_t from = 0;
           for (size_t ph = 0; ph < phase_end.size(); ph++) {
             const uint32_t e = phase_end[ph];
-            launch_gemm_qs(ktype, d_rows_, sc.queries.p, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p,
+            launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p,
                            sub_cap, c->stream);
             launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
                                 sc.cand.p, cand_cap, ph > 0, c->stream);
             if (ph + 1 < phase_end.size())
               launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
-                                          c->stream);
+                                          c->stream, slack);
             from = e;
           }
         } else {
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);
         }
+        if (via_shadow)  // shadow keys -> exact fp32 keys, then the usual exact select over (key, row)
+          launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
+                               c->stream);
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);
       }
@@ -239,7 +264,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
           ScanProfile &pf = scan_profile();
           pf.launches++;
-          pf.bytes += (uint64_t)n * elem_bytes_;
+          pf.bytes += (uint64_t)n * (via_shadow ? dim * 2 : elem_bytes_);
           pf.nanos += (uint64_t)((double)ms * 1e6);
         }
       }

@@ -86,6 +86,12 @@ void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t 
 // smax_bits[0] = max over rows of scale (as f32 bits, atomicMax)
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
                          size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s);
+// Batched two-stage scan: cand[q*cand_cap + j].y = orderable key of the fp32 IP distance of row cand[..].x to
+// queries[q] (fp32, qstride bytes apart), j < cand_count[q]; the arithmetic is the single-query scan's, bit for bit.
+// Only row shapes the scan runs without chunk masking (stride/16 == G*ITERS, e.g. dim 128/256/384/512/768/1024 fp32).
+bool batch_rescore_supported(uint32_t stride16);
+bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, hipStream_t s);
 // rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
 void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
 // cand[i].y = orderable key of dists[i]
@@ -133,8 +139,9 @@ void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32
                          uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s);
 // per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
 // (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
+// (slack is added to every finite bound written: the two-stage scan's error band)
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
-                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1);
+                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1, float slack = 0.0f);
 // tau_out[0] = upper bound of the k-th smallest key (k <= 1024) of keys[0..n): k-th smallest of the minima
 // of 1024 groups of `per` sampled keys (per % 4 == 0, n >= 1024*per); also zeroes zero4[0..3] if given
 void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
@@ -147,7 +154,7 @@ void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void
 // per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
-                                 hipStream_t s);
+                                 hipStream_t s, float slack = 0.0f);
 // per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);

@@ -651,7 +651,70 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restri
   }
 }
 
+// Batched two-stage scan: the candidates (row, shadow key) of every query are re-scored from the fp32 rows with the
+// arithmetic of scan_kernel<KT_F32, KM_IP, G, ITERS> (same chunk-to-lane map, same fmaf order, same xor-shuffle
+// reduction), so the keys written here are bit-identical to the ones the single-query scan computes for these rows.
+// grid = (slices, queries); a group of G lanes per candidate.  Lists that overflowed (count > cap) are skipped: the
+// select flags them and the host redoes the query on the single-query path.
+template <int G, int ITERS>
+__global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t n_rows,
+                                                            const u4 *__restrict__ queries, uint32_t qstride16,
+                                                            uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
+                                                            uint32_t cand_cap) {
+  constexpr int GPB = 256 / G;
+  const uint32_t q = blockIdx.y, lane = threadIdx.x % G, grp = threadIdx.x / G;
+  const uint32_t cnt = cand_count[q];
+  if (cnt > cand_cap) return;
+  u4 qv[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; i++) qv[i] = queries[(size_t)q * qstride16 + lane + i * G];
+  uint2 *list = cand + (size_t)q * cand_cap;
+  for (uint32_t j = blockIdx.x * GPB + grp; j < cnt; j += gridDim.x * GPB) {
+    const uint32_t row = list[j].x;
+    if (row >= n_rows) continue;  // (cannot happen; never read outside the corpus)
+    const u4 *p = rows + (size_t)row * stride16;
+    u4 x[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) x[i] = load16<false>(p + lane + i * G);
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) acc = Op<KT_F32, KM_IP>::add(acc, x[i], qv[i]);
+    const float d = finish<KT_F32, KM_IP>(group_reduce<G>(acc), zero4());
+    if (lane == 0) list[j].y = to_key(d);
+  }
+}
+
 }  // namespace
+
+bool batch_rescore_supported(uint32_t stride16) {
+  const Shape sh = pick_shape(stride16);
+  return (sh.G == 64 && sh.ITERS >= 1 && sh.ITERS <= 4) || (sh.G == 32 && (sh.ITERS == 1 || sh.ITERS == 3));
+}
+
+bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, hipStream_t s) {
+  const uint32_t s16 = (uint32_t)(stride / 16);
+  if (!batch_rescore_supported(s16) || !n_queries) return false;
+  const Shape sh = pick_shape(s16);
+  if ((uint32_t)(sh.G * sh.ITERS) != s16) return false;  // exact shapes only (no chunk masking here)
+  const dim3 grid(16, n_queries), block(256);
+#define RSGPU_RESCORE(GG, II)                                                                                      \
+  hipLaunchKernelGGL((batch_rescore_kernel<GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows, (const u4 *)queries, \
+                     (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap)
+  if (sh.G == 32) {
+    if (sh.ITERS == 1) RSGPU_RESCORE(32, 1);
+    else RSGPU_RESCORE(32, 3);
+  } else {
+    switch (sh.ITERS) {
+      case 1: RSGPU_RESCORE(64, 1); break;
+      case 2: RSGPU_RESCORE(64, 2); break;
+      case 3: RSGPU_RESCORE(64, 3); break;
+      default: RSGPU_RESCORE(64, 4); break;
+    }
+  }
+#undef RSGPU_RESCORE
+  return true;
+}
 
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
                          size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s) {
