@@ -237,9 +237,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);
         }
-        if (via_shadow)  // shadow keys -> exact fp32 keys, then the usual exact select over (key, row)
+        if (via_shadow) {
+          // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
+          // their exact fp32 keys, then the usual exact select over (key, row)
+          launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
+                                      c->stream, slack);
           launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                               c->stream);
+                               sc.tau.p, c->stream);
+        }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);
       }

@@ -88,10 +88,11 @@ void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t
                          size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s);
 // Batched two-stage scan: cand[q*cand_cap + j].y = orderable key of the fp32 IP distance of row cand[..].x to
 // queries[q] (fp32, qstride bytes apart), j < cand_count[q]; the arithmetic is the single-query scan's, bit for bit.
+// tau (optional): candidates whose current (shadow) key is above tau[q] are not read; they get the last key instead.
 // Only row shapes the scan runs without chunk masking (stride/16 == G*ITERS, e.g. dim 128/256/384/512/768/1024 fp32).
 bool batch_rescore_supported(uint32_t stride16);
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
-                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, hipStream_t s);
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s);
 // rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
 void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
 // cand[i].y = orderable key of dists[i]

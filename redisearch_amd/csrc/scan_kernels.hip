@@ -660,18 +660,25 @@ template <int G, int ITERS>
 __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t n_rows,
                                                             const u4 *__restrict__ queries, uint32_t qstride16,
                                                             uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
-                                                            uint32_t cand_cap) {
+                                                            uint32_t cand_cap, const float *__restrict__ tau) {
   constexpr int GPB = 256 / G;
   const uint32_t q = blockIdx.y, lane = threadIdx.x % G, grp = threadIdx.x / G;
   const uint32_t cnt = cand_count[q];
   if (cnt > cand_cap) return;
+  // candidates collected under the looser bounds of the earlier passes: only those inside the FINAL band
+  // (shadow distance <= tau[q]) can be in the answer; the others get the last key and are never re-read
+  const uint32_t thr = tau ? f2key(tau[q]) : 0xFFFFFFFFu;
   u4 qv[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; i++) qv[i] = queries[(size_t)q * qstride16 + lane + i * G];
   uint2 *list = cand + (size_t)q * cand_cap;
   for (uint32_t j = blockIdx.x * GPB + grp; j < cnt; j += gridDim.x * GPB) {
-    const uint32_t row = list[j].x;
-    if (row >= n_rows) continue;  // (cannot happen; never read outside the corpus)
+    const uint2 e = list[j];
+    const uint32_t row = e.x;
+    if (e.y > thr || row >= n_rows) {  // (row >= n_rows cannot happen; never read outside the corpus)
+      if (lane == 0) list[j].y = 0xFFFFFFFFu;
+      continue;
+    }
     const u4 *p = rows + (size_t)row * stride16;
     u4 x[ITERS];
 #pragma unroll
@@ -692,7 +699,7 @@ bool batch_rescore_supported(uint32_t stride16) {
 }
 
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
-                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, hipStream_t s) {
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s) {
   const uint32_t s16 = (uint32_t)(stride / 16);
   if (!batch_rescore_supported(s16) || !n_queries) return false;
   const Shape sh = pick_shape(s16);
@@ -700,7 +707,7 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
   const dim3 grid(16, n_queries), block(256);
 #define RSGPU_RESCORE(GG, II)                                                                                      \
   hipLaunchKernelGGL((batch_rescore_kernel<GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows, (const u4 *)queries, \
-                     (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap)
+                     (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau)
   if (sh.G == 32) {
     if (sh.ITERS == 1) RSGPU_RESCORE(32, 1);
     else RSGPU_RESCORE(32, 3);
