@@ -406,6 +406,9 @@ class BatchIterator:
             raise RuntimeError("VecSimBatchIterator_Next failed: " + last_error())
         return QueryReply(r)
 
+    def reset(self):
+        self.lib.VecSimBatchIterator_Reset(self.ptr)
+
     def free(self):
         if getattr(self, "ptr", None):
             self.lib.VecSimBatchIterator_Free(self.ptr)
