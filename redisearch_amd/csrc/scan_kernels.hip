@@ -522,7 +522,10 @@ void launch_shape(const LaunchCtx &c) {
       return launch_one<TYPE, METRIC, 64, 3, 8, GATHER>(c);
     case 4: return launch_one<TYPE, METRIC, 64, 4, 4, GATHER>(c);
     case 5: return launch_one<TYPE, METRIC, 64, 5, 4, GATHER>(c);
-    case 6: return launch_one<TYPE, METRIC, 64, 6, 4, GATHER>(c);
+    case 6:
+      if (u_over == 2) return launch_one<TYPE, METRIC, 64, 6, 2, GATHER>(c);
+      if (u_over == 8) return launch_one<TYPE, METRIC, 64, 6, 8, GATHER>(c);
+      return launch_one<TYPE, METRIC, 64, 6, 4, GATHER>(c);
     case 7: return launch_one<TYPE, METRIC, 64, 7, 2, GATHER>(c);
     default: return launch_one<TYPE, METRIC, 64, 8, 2, GATHER>(c);
   }

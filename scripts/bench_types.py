@@ -19,6 +19,10 @@ TYPES = [("FLOAT32", V.VecSimType_FLOAT32, torch.float32, 4), ("FLOAT64", V.VecS
          ("FLOAT16", V.VecSimType_FLOAT16, torch.float16, 2), ("BFLOAT16", V.VecSimType_BFLOAT16, torch.bfloat16, 2),
          ("INT8", V.VecSimType_INT8, torch.int8, 1), ("UINT8", V.VecSimType_UINT8, torch.uint8, 1)]
 METRICS = [("L2", V.VecSimMetric_L2), ("IP", V.VecSimMetric_IP), ("COSINE", V.VecSimMetric_Cosine)]
+only = os.environ.get("TYPES_ONLY")
+if only:
+    TYPES = [t for t in TYPES if t[0] in only.split(",")]
+rpgs = [int(x) for x in os.environ.get("RPG", "0").split(",")]   # rows_per_group knob values to sweep (0 = default)
 out = []
 for tname, vt, tdt, esz in TYPES:
     gen = torch.Generator(device=dev)
@@ -30,7 +34,8 @@ for tname, vt, tdt, esz in TYPES:
     else:
         x = (torch.rand((rows, dim), device=dev, generator=gen, dtype=torch.float32) * 2 - 1).to(tdt)
         qs = np.random.default_rng(48).uniform(-1, 1, (100, dim)).astype(np.float64 if tdt == torch.float64 else np.float32)
-    for mname, m in METRICS:
+    for mname, m, rpg in [(a, b, r) for a, b in METRICS for r in rpgs]:
+        lib.RSGPU_SetTuning(b"rows_per_group", rpg)
         idx = V.VecSimIndex(vt, dim, m)
         torch.cuda.synchronize()
         idx.add_device_rows(x.data_ptr(), rows, 1)
@@ -44,7 +49,7 @@ for tname, vt, tdt, esz in TYPES:
         el = time.perf_counter() - t0
         lib.RSGPU_SetProfiling(0)
         launches, ms, by = V.scan_profile()
-        r = {"type": tname, "metric": mname, "rows": rows, "dim": dim, "qps": len(qs) / el, "scan_kernel_ms": ms / launches,
+        r = {"type": tname, "metric": mname, "rows_per_group": rpg, "rows": rows, "dim": dim, "qps": len(qs) / el, "scan_kernel_ms": ms / launches,
              "scan_gbs": by / launches / (ms / launches) / 1e6, "frac_of_8TBs": by / launches / (ms / launches) / 1e6 / 8000}
         out.append(r)
         print(json.dumps(r), flush=True)
