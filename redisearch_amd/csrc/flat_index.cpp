@@ -799,6 +799,15 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
     HIP_CHECK(hipMemcpyAsync(c->d_tau, &tau, sizeof tau, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemsetAsync(c->d_fcnt, 0, 4 * sizeof(uint32_t), c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));  // (tau lives on this frame)
+  } else if (shadow_ == 2) {
+    // int8 band (2 eps ~ 0.76 sigma on the bench corpus): filtering with the SAMPLED bound + 2 eps would keep ~16 k rows
+    // and the append path of the filter pass costs 0.1 ms.  Two cheap passes instead: keys <= sampled bound (~1.5 k),
+    // their exact K-th = the K-th shadow distance of the whole index, then keys <= that + 2 eps (~350)
+    launch_sample_threshold(c->d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
+    launch_filter_keys(c->d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
+    // (a list of exactly K candidates keeps the sampled bound, which is then the K-th distance itself)
+    launch_batch_threshold_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, 1, c->d_tau, c->h_fcnt + 1, c->stream);
+    HIP_CHECK(hipMemsetAsync(c->d_fcnt, 0, 4 * sizeof(uint32_t), c->stream));
   } else {
     launch_sample_threshold(c->d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
   }
@@ -807,7 +816,7 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
   HIP_CHECK(hipStreamSynchronize(c->stream));
   collect_profile(c);
   const uint32_t m = c->h_fcnt[3];
-  if (m > QueryCtx::kCandCap || m < k) return false;
+  if (m > QueryCtx::kCandCap || m < k || c->h_fcnt[1]) return false;  // ([1]: the first int8 pass overflowed)
   c->ensure_gather(m);
   launch_cand_rows(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->d_ids, c->stream);
   launch_gather(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, c->d_ids, m, c->d_query, c->d_dists, c->stream);
