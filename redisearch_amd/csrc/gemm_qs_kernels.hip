@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
 // One workgroup per query: concatenate its 2 * n_wg sub-lists (row, distance bits) into
 // cand[q*cand_cap ..] as (row, orderable key) and set cand_count[q] (cand_cap+1 when a sub-list or the
 // list itself overflowed -> the select flags the query and the host redoes it).
-__global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__restrict__ sub_count,
+__global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__restrict__ sub_count,
                                                            const uint2 *__restrict__ sub_cand, uint32_t sub_cap,
                                                            uint32_t n_wg, uint32_t *__restrict__ cand_count,
                                                            uint2 *__restrict__ cand, uint32_t cand_cap, int append) {
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__res
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) over = 0;
   __syncthreads();
-  for (uint32_t sg = tid; sg < 512; sg += 256) {  // segment sg = (workgroup sg/2, lane half sg%2)
+  for (uint32_t sg = tid; sg < 512; sg += blockDim.x) {  // segment sg = (workgroup sg/2, lane half sg%2)
     uint32_t c = sg < 2 * n_wg ? sub_count[((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)] : 0;
     if (c > sub_cap) {
       over = 1;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void compact_cand_kernel(const uint32_t *__res
     return;
   }
   const uint32_t lane = tid & 63, wv = tid >> 6;
-  for (uint32_t sg = wv; sg < 2 * n_wg; sg += 4) {  // wavefront per sub-list: coalesced copies
+  for (uint32_t sg = wv; sg < 2 * n_wg; sg += blockDim.x / 64) {  // wavefront per sub-list: coalesced copies
     const uint32_t beg = offs[sg], cnt = offs[sg + 1] - beg;
     const uint2 *src = sub_cand + (((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap;
     for (uint32_t i = lane; i < cnt; i += 64) {
@@ -380,7 +380,7 @@ bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t s
 
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
                          uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s) {
-  hipLaunchKernelGGL(compact_cand_kernel, dim3(256), dim3(256), 0, s, sub_count, (const uint2 *)sub_cand, sub_cap, n_wg,
+  hipLaunchKernelGGL(compact_cand_kernel, dim3(256), dim3(1024), 0, s, sub_count, (const uint2 *)sub_cand, sub_cap, n_wg,
                      cand_count, (uint2 *)cand, cand_cap, append);
 }
 
