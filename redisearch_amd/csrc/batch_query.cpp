@@ -273,7 +273,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           pf.nanos += (uint64_t)((double)ms * 1e6);
         }
       }
-      std::vector<Hit> hits;
+      std::vector<VecSimQueryResult> res;
       for (uint32_t i = 0; i < nb; i++) {
         const size_t qi = q0 + i;
         if (h_over[i]) {  // candidate list overflowed: redo this query on the single-query path
@@ -281,15 +281,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           continue;
         }
         const uint32_t got = std::min(h_n[i], kk);
-        hits.resize(got);
-        for (uint32_t j = 0; j < got; j++) hits[j] = Hit{h_rows[(size_t)i * kk + j], h_keys[(size_t)i * kk + j]};
-        std::sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) {
-          return a.key != b.key ? a.key < b.key : a.row < b.row;
-        });
-        // reply order: (score, label) ascending
-        std::vector<VecSimQueryResult> res(got);
+        // the device hands back the exact top-k SET (selected by (key, row)); reply order: (score, label) ascending
+        res.resize(got);
         for (uint32_t j = 0; j < got; j++)
-          res[j] = VecSimQueryResult{(size_t)row_label_[hits[j].row], score_of(hits[j].key)};
+          res[j] = VecSimQueryResult{(size_t)row_label_[h_rows[(size_t)i * kk + j]], score_of(h_keys[(size_t)i * kk + j])};
         std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
           return a.score != b.score ? a.score < b.score : a.id < b.id;
         });
