@@ -83,7 +83,7 @@ def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0, metric="cosine")
     # ctypes releases the GIL inside the C scan
     import threading
     counts = [0] * 8
-    stop_at = time.perf_counter() + 6.0
+    stop_at = time.perf_counter() + min(6.0, 0.4 * budget_s)
 
     def worker(t):
         ids_t, sc_t = np.zeros(k, np.uint64), np.zeros(k, np.float64)
