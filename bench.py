@@ -121,7 +121,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # RSGPU_BENCH_FORCE_DIST=1 (test hook): create the RCCL process group and run the real all-gather even with one
+    # rank (under torch.distributed.run --nproc-per-node 1), so the collective code path is exercised on a 1-GPU box
+    force_dist = os.environ.get("RSGPU_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -161,7 +164,7 @@ def main():
 
     # RSGPU_BENCH_FORCE_SHARDED=1 (test hook): run the sharded code path -- device-side per-shard top-k, packing,
     # merge -- on a single rank too (the all-gather itself needs >= 2 ranks)
-    force_sharded = os.environ.get("RSGPU_BENCH_FORCE_SHARDED") == "1"
+    force_sharded = os.environ.get("RSGPU_BENCH_FORCE_SHARDED") == "1" or force_dist
     if world > 1 or force_sharded:
         from redisearch_amd.sharded import ShardedTopK
         loc_s = torch.empty(k, device=dev, dtype=torch.float32)
@@ -184,7 +187,7 @@ def main():
         return len(labels)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +234,7 @@ def main():
         lib.RSGPU_SetTuning(b"two_stage", 0)
         extra = {"error": repr(e)}
 
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -292,7 +295,7 @@ def main():
             except Exception as e:  # the baseline leg must never cost the measured line
                 out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

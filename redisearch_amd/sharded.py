@@ -40,7 +40,7 @@ class ShardedTopK:
         k = self.k
         self.pack[:k] = l
         self.pack[k:] = s.view(self.torch.int32)
-        if self.world == 1:
+        if not self.dist.is_initialized():               # no process group at all: a plain single-GPU caller
             self.all_p.copy_(self.pack)
         else:
             self.dist.all_gather_into_tensor(self.all_p, self.pack, group=self.group)
