@@ -78,7 +78,8 @@ size_t RSGPU_Postings_NumBytes(const RSGPU_Postings *p);
 long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *freqs_out, uint32_t *masks_out);
 
 /* Docs present in ALL lists (decode + intersect on the device). Hits are ascending by doc id and carry
- * the matched frequency of every input list. NULL on failure. */
+ * the matched frequency of every input list. 1..32 lists (the reference's own tests go to 25 children). NULL on
+ * failure. */
 RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists);
 void RSGPU_Hits_Free(RSGPU_Hits *h);
 size_t RSGPU_Hits_Len(const RSGPU_Hits *h);
@@ -113,7 +114,7 @@ long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *sco
 long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
                           double *dist_out);
 
-/* Union of 1..8 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
+/* Union of 1..32 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
  * contributes freq 0 (reference rqe_iterators/src/union_flat.rs:223-257,297-320).  Scoring a union hit list
  * follows the reference's Union node: absent children add nothing, the slop divisor counts the matched
  * children only, DISMAX takes the children's maximum.  Returns NULL on error. */

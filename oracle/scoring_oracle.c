@@ -228,8 +228,12 @@ void oracle_score_flat(int scorer, size_t M, size_t T, const uint32_t *freq, con
                        const uint32_t *max_freq, const float *doc_score, const double *idf,
                        const double *bm25_idf, const double *weight, double root_weight,
                        const OStats *st, double min_score, int slop_const, double *out) {
-  ONode terms[16]; ONode *kids[16]; ONode root;
-  if (T > 16) T = 16;
+  enum { MAX_T = 64 };
+  ONode terms[MAX_T]; ONode *kids[MAX_T]; ONode root;
+  if (T > MAX_T) {  /* not a silent truncation: the caller sees NaN */
+    for (size_t m = 0; m < M; m++) out[m] = NAN;
+    return;
+  }
   for (size_t m = 0; m < M; m++) {
     for (size_t t = 0; t < T; t++) {
       terms[t] = (ONode){R_TERM, weight[t], freq[t * M + m], 1, idf[t], bm25_idf[t], NULL, 0, NULL, 0};

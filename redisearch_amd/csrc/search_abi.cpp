@@ -315,7 +315,7 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
 
 RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
   if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
-    last_error() = "RSGPU_Intersect: 1..8 lists";
+    last_error() = "RSGPU_Intersect: 1..32 lists";
     return nullptr;
   }
   S_TRY
@@ -374,7 +374,7 @@ RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
 // reference src/redisearch_rs/rqe_iterators/src/union_flat.rs:223-257,297-320
 RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
   if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
-    last_error() = "RSGPU_Union: 1..8 lists";
+    last_error() = "RSGPU_Union: 1..32 lists";
     return nullptr;
   }
   S_TRY

@@ -21,7 +21,7 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s);
 
-constexpr int kMaxLists = 8;
+constexpr int kMaxLists = 32;  // children of one intersection / union (the reference's own tests go to 25)
 struct ListView {
   const uint32_t *ids[kMaxLists];
   const uint32_t *freqs[kMaxLists];
