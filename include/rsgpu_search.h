@@ -59,7 +59,10 @@ typedef enum {
   RSGPU_SCORER_TFIDF = 3,
   RSGPU_SCORER_TFIDF_DOCNORM = 4,
   RSGPU_SCORER_DOCSCORE = 5,
-  RSGPU_SCORER_DISMAX = 6
+  RSGPU_SCORER_DISMAX = 6,
+  /* BM25STD followed by the max-score normaliser the reference chains behind it for `SCORER BM25STD.NORM`
+   * (RPMaxScoreNormalizer, src/result_processor.c:1770-1812; pipeline_construction.c:546-547) */
+  RSGPU_SCORER_BM25STD_NORM = 7
 } RSGPU_Scorer;
 
 typedef struct RSGPU_Postings RSGPU_Postings;

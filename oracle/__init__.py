@@ -234,6 +234,7 @@ for _n, _args in (("oracle_tfidf", (_vp, _vp, _dbl, _i)), ("oracle_bm25", (_vp, 
                   ("oracle_dismax", (_vp,))):
     _sig(_n, _dbl, *_args)
 _sig("oracle_slop", _i, _vp)
+_sig("oracle_max_normalize", None, _vp, _sz)
 _sig("oracle_score_flat", None, _i, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _vp, _dbl, _i, _vp)
 
 
@@ -319,6 +320,13 @@ def score_flat(scorer, freq, doc_len, max_freq, doc_score, idf, bm25_idf, weight
     slop_const = 1 if T <= 1 else T - 1
     lib.oracle_score_flat(SCORER_IDS[scorer], M, T, _p(freq), _p(doc_len), _p(max_freq), _p(doc_score), _p(idf),
                           _p(bm25_idf), _p(weight), root_weight, C.addressof(st), min_score, slop_const, _p(out))
+    return out
+
+
+def max_normalize(scores):
+    """BM25STD.NORM epilogue (RPMaxScoreNormalizer): a copy of `scores` divided by max(0, max(scores)) unless that is 0."""
+    out = np.array(scores, dtype=np.float64, copy=True)
+    lib.oracle_max_normalize(_p(out), out.size)
     return out
 
 

@@ -262,6 +262,15 @@ void oracle_score_flat(int scorer, size_t M, size_t T, const uint32_t *freq, con
   }
 }
 
+/* BM25STD.NORM: RPMaxScoreNormalizer (reference src/result_processor.c:1770-1812): accumulates every upstream result,
+ * maxValue = MAX(maxValue, score) starting from 0, then yields score / maxValue -- unless maxValue == 0. */
+void oracle_max_normalize(double *scores, size_t n) {
+  double max_value = 0;
+  for (size_t i = 0; i < n; i++) max_value = max_value > scores[i] ? max_value : scores[i];
+  if (max_value != 0)
+    for (size_t i = 0; i < n; i++) scores[i] = scores[i] / max_value;
+}
+
 /* ---- FT.HYBRID fusion (reference src/hybrid/hybrid_scoring.c:41-84, merger src/result_processor.c:2549-2571,
  * vector-score normalisation src/vector_normalization.h:37-60) -----------------------------------------------
  * Two ranked upstreams: a = search results (score descending), b = vector results (distance ascending, i.e.

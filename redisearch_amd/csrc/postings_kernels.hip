@@ -425,6 +425,41 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   if (keys) keys[h] = ~d2key(s);  // descending score; the select's row tie-break = ascending doc id
 }
 
+// ---- BM25STD.NORM: score / max score over ALL hits (reference RPMaxScoreNormalizer, src/result_processor.c:1770-1812:
+// maxValue starts at 0, MAX() over every upstream score, division only when maxValue != 0) ----------------------------
+__device__ __forceinline__ double key2d(uint64_t k) {
+  const uint64_t u = (k & 0x8000000000000000ull) ? (k ^ 0x8000000000000000ull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+// max_key[0] (zeroed by the caller) <- max over the orderable images of the scores; one atomic per wavefront
+__global__ __launch_bounds__(256) void score_max_kernel(const double *__restrict__ scores, uint32_t n,
+                                                        unsigned long long *__restrict__ max_key) {
+  unsigned long long m = 0;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const unsigned long long k = d2key(scores[i]);
+    m = k > m ? k : m;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(m, off, 64);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(max_key, m);
+}
+__global__ __launch_bounds__(256) void score_normalize_kernel(double *__restrict__ scores, uint64_t *__restrict__ keys,
+                                                              uint32_t n, const unsigned long long *__restrict__ max_key) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long zero = 0x8000000000000000ull;  // d2key(0.0): the accumulator's start value
+  const unsigned long long mk = max_key[0] > zero ? max_key[0] : zero;
+  const double mx = key2d(mk);
+  if (mx != 0.0) {
+    const double s = scores[i] / mx;
+    scores[i] = s;
+    if (keys) keys[i] = ~d2key(s);
+  }
+}
+
 __global__ __launch_bounds__(256) void labels_to_rows_kernel(const uint32_t *__restrict__ ids, uint32_t n,
                                                              uint64_t base, uint32_t n_rows,
                                                              uint32_t *__restrict__ rows) {
@@ -506,6 +541,13 @@ void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *fre
   if (!len) return;
   hipLaunchKernelGGL(score_kernel, dim3(blocks_for(len)), dim3(256), 0, s, p, ids, freqs, len, cap, doc_len,
                      doc_score, max_freq, table_n, scores, keys);
+}
+void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, uint64_t *max_key_zeroed, hipStream_t s) {
+  if (!len) return;
+  const uint32_t need = blocks_for(len), grid = need < 1024 ? need : 1024;
+  hipLaunchKernelGGL(score_max_kernel, dim3(grid), dim3(256), 0, s, scores, len, (unsigned long long *)max_key_zeroed);
+  hipLaunchKernelGGL(score_normalize_kernel, dim3(need), dim3(256), 0, s, scores, keys, len,
+                     (const unsigned long long *)max_key_zeroed);
 }
 void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint32_t n_rows, uint32_t *rows, hipStream_t s) {
   if (!n) return;

@@ -117,7 +117,7 @@ struct Scratch {
   DevBuf<uint8_t> flags;
   DevBuf<uint32_t> pos, block_counts, total, rows, keys32;
   DevBuf<float> dists;
-  DevBuf<uint64_t> fuse;
+  DevBuf<uint64_t> fuse, maxkey;
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -126,6 +126,7 @@ Scratch &scratch(int device) {
     s.flags.reset(); s.pos.reset(); s.block_counts.reset(); s.total.reset(); s.rows.reset(); s.keys32.reset();
     s.dists.reset();
     s.fuse.reset();
+    s.maxkey.reset();
     s.device = device;
   }
   return s;
@@ -552,7 +553,10 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   CtxLease c(h->device);
   ScoreParams P;
   memset(&P, 0, sizeof P);
-  P.scorer = a->scorer;
+  // BM25STD.NORM = BM25STD, then every score divided by the largest one (RPMaxScoreNormalizer sits right behind the
+  // scorer in the reference pipeline, src/pipeline/pipeline_construction.c:546-547)
+  const bool max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
+  P.scorer = max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
   P.n_lists = h->n_lists;
   P.avg_doc_len = a->avg_doc_len;
   P.root_weight = a->root_weight;
@@ -573,6 +577,12 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   StageTimer ts(c.c, 2);
   launch_score(P, h->ids.p, h->freqs.p, h->len, h->cap, t->doc_len.p, t->doc_score.p,
                t->max_freq.p, t->n, h->scores.p, h->keys.p, c->stream);
+  if (max_norm && h->len) {
+    Scratch &sc = scratch(h->device);
+    sc.maxkey.ensure(1);
+    HIP_CHECK(hipMemsetAsync(sc.maxkey.p, 0, sizeof(uint64_t), c->stream));
+    launch_score_max_normalize(h->scores.p, h->keys.p, h->len, sc.maxkey.p, c->stream);
+  }
   HIP_CHECK(hipGetLastError());
   ts.stop();
   h->scored = true;

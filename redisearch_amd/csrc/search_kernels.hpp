@@ -68,6 +68,10 @@ void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *fre
                   const uint32_t *doc_len, const float *doc_score, const uint32_t *max_freq, uint32_t table_n,
                   double *scores, uint64_t *keys, hipStream_t s);
 
+// BM25STD.NORM epilogue: scores[i] /= max(0, max_i scores[i]) unless that maximum is 0; keys rewritten alike.
+// max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream
+void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, uint64_t *max_key_zeroed, hipStream_t s);
+
 // rows[i] = ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
 void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint32_t n_rows, uint32_t *rows, hipStream_t s);
 // keys[i] = orderable(dists[i]) (NaN last)

@@ -11,6 +11,8 @@ _sz, _vp, _dbl, _i = C.c_size_t, C.c_void_p, C.c_double, C.c_int
 (CODEC_FULL, CODEC_FREQS_FIELDS, CODEC_FREQS_ONLY, CODEC_FIELDS_ONLY, CODEC_FIELDS_OFFSETS, CODEC_OFFSETS_ONLY,
  CODEC_FREQS_OFFSETS, CODEC_DOCIDS_ONLY, CODEC_RAW_DOCIDS) = range(9)
 SCORERS = {"BM25STD": 0, "BM25STD.TANH": 1, "BM25": 2, "TFIDF": 3, "TFIDF.DOCNORM": 4, "DOCSCORE": 5, "DISMAX": 6}
+# scorer names that are a registered scorer + a result processor chained behind it in the reference pipeline
+PIPELINE_SCORERS = {"BM25STD.NORM": 7}
 
 
 class ScoreArgs(C.Structure):
@@ -152,7 +154,7 @@ class Hits:
     def score(self, table, scorer, idf, bm25_idf, weight, num_docs, avg_doc_len, root_weight=1.0, min_score=0.0,
               tanh_factor=4, want_scores=True):
         idf, bidf, w = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
-        a = ScoreArgs(SCORERS[scorer], num_docs, avg_doc_len, tanh_factor, root_weight, min_score, _p(idf).value,
+        a = ScoreArgs(SCORERS[scorer] if scorer in SCORERS else PIPELINE_SCORERS[scorer], num_docs, avg_doc_len, tanh_factor, root_weight, min_score, _p(idf).value,
                       _p(bidf).value, _p(w).value)
         out = np.zeros(max(len(self), 1), np.float64) if want_scores else None
         if self.lib.RSGPU_Hits_Score(self.ptr, table.ptr, C.byref(a), _p(out) if want_scores else None) != 0:

@@ -156,3 +156,22 @@ def test_flat_form_matches_tree_form():
             ref = O.score(scorer, tree, doc_score=float(doc_score[m]), max_freq=int(max_freq[m]),
                           doc_len=int(doc_len[m]), num_docs=N, avg_doc_len=180.5)
             assert out[m] == ref, scorer
+
+
+def test_bm25std_norm_explain_kats():
+    # reference tests/pytests/test_scorers.py:244-291: 'Final BM25STD.NORM: 1.00 = Original Score: 0.54 / Max Score: 0.54',
+    # 0.97 = 0.52 / 0.54, 0.95 = 0.51 / 0.54 ; the weighted query: 1.00 / 0.97 / 0.95 of 0.12 / 0.12 / 0.12
+    bidf = O.lib.oracle_idf_bm25(3, 3)
+    avg = (23 + 35 + 45) / 3
+    raw = [O.score("BM25STD", O.intersection([O.term(10, 0, bidf), O.term(10, 0, bidf)]), doc_len=dl, num_docs=3,
+                   avg_doc_len=avg) for dl in (23, 35, 45)]
+    assert [round(x, 2) for x in raw] == [0.54, 0.52, 0.51]
+    assert [round(x, 2) for x in O.max_normalize(raw)] == [1.00, 0.97, 0.95]
+    raw = [O.score("BM25STD", O.union([O.term(10, 0, bidf, weight=0.5), O.term(10, 0, bidf)], weight=0.3), doc_len=dl,
+                   num_docs=3, avg_doc_len=avg) for dl in (23, 35, 45)]
+    assert [round(x, 2) for x in raw] == [0.12, 0.12, 0.12]
+    assert [round(x, 2) for x in O.max_normalize(raw)] == [1.00, 0.97, 0.95]
+    # maxValue starts at 0: all-zero and all-negative score lists pass through unchanged (result_processor.c:1784)
+    assert O.max_normalize([0.0, 0.0]).tolist() == [0.0, 0.0]
+    assert O.max_normalize([-1.0, -2.0]).tolist() == [-1.0, -2.0]
+    assert O.max_normalize([]).tolist() == []
