@@ -164,3 +164,33 @@ def test_fails_loudly_without_gpu(lib, has_gpu):
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError, match="no HIP device|No HIP|device"):
         V.VecSimIndex(V.VecSimType_FLOAT32, 4, V.VecSimMetric_L2)
+
+
+def test_search_seam_argument_errors_are_loud_and_exception_free(lib):
+    """Host-side validation of include/rsgpu_search.h runs before any device work: -1 / NULL plus RSGPU_LastError(),
+    never an exception, never a crash (SURVEY.md 8b "Errors")."""
+    from redisearch_amd import search as S
+    sl = S.load()
+    ids = (C.c_uint64 * 3)(1, 2, 3)
+    sc = (C.c_double * 3)(0.3, 0.2, 0.1)
+    w = (C.c_double * 2)(0.5, 0.5)
+    out_i, out_s = (C.c_uint64 * 8)(), (C.c_double * 8)()
+    fuse = lambda scoring, weights, a_ids, n_a, window: sl.RSGPU_HybridFuse(
+        scoring, 60.0, weights, -1, a_ids, C.cast(sc, C.c_void_p), n_a, C.cast(ids, C.c_void_p), C.cast(sc, C.c_void_p), 3,
+        window, 8, C.cast(out_i, C.c_void_p), C.cast(out_s, C.c_void_p))
+    assert fuse(9, None, C.cast(ids, C.c_void_p), 3, 20) == -1 and "unknown scoring" in V.last_error()
+    assert fuse(S.LINEAR, None, C.cast(ids, C.c_void_p), 3, 20) == -1 and "weights" in V.last_error()
+    assert fuse(S.RRF, None, C.cast(ids, C.c_void_p), 3, 5000) == -1 and "window" in V.last_error()
+    assert fuse(S.RRF, None, None, 3, 20) == -1 and "NULL list" in V.last_error()
+    assert fuse(S.LINEAR, C.cast(w, C.c_void_p), None, 0, 0) == 0          # nothing to fuse: 0 results, no device needed
+    assert not sl.RSGPU_Intersect(None, 2) and "lists" in V.last_error()
+    assert not sl.RSGPU_Union(None, 0)
+    lists33 = (C.c_void_p * 33)()
+    assert not sl.RSGPU_Intersect(C.cast(lists33, C.c_void_p), 33) and "1..32" in V.last_error()
+    assert not sl.RSGPU_Not(None, None, 10) and "NULL child" in V.last_error()
+    assert sl.RSGPU_Hits_TopN(None, 5, None, None) == -1
+    assert sl.RSGPU_Hits_Len(None) == 0 and sl.RSGPU_Postings_NumEntries(None) == 0
+    sl.RSGPU_Hits_Free(None)
+    sl.RSGPU_Postings_Free(None)
+    sl.RSGPU_DocTable_Free(None)
+    assert lib.RSGPU_SetTuning(b"no_such_knob", 1) == -1 and lib.RSGPU_SetTuning(None, 1) == -1
