@@ -1,6 +1,7 @@
 """CPU tests pinning the union / NOT restatements (oracle/postings_oracle.c oracle_union, oracle_not) to the
 reference's own iterator tests."""
 import numpy as np
+import pytest
 
 import oracle as O
 
@@ -38,3 +39,24 @@ def test_union_edge_cases():
     assert len(O.union_lists([ids_list([]), ids_list([])])[0]) == 0
     ids, fr, _ = O.union_lists([ids_list([4, 9], [2, 3])])
     assert ids.tolist() == [4, 9] and fr.tolist() == [[2, 3]]
+
+
+@pytest.mark.parametrize("num_children", [2, 5, 10])
+@pytest.mark.parametrize("base", [[1, 2, 3, 40, 50],
+                                  [5, 6, 7, 24, 25, 46, 47, 48, 49, 50, 51, 234, 2345],
+                                  [9, 25, 30, 40, 50, 60, 70, 80, 90, 100, 110, 120, 130]])
+def test_union_read_fixture_cases(num_children, base):
+    # rqe_iterators/tests/integration/union_common.rs:40-98 with utils/mod.rs:184-197 (create_union_children):
+    # child i holds base * i, i = 1..num_children; reading the union yields the sorted set of all of them
+    children = [[x * i for x in base] for i in range(1, num_children + 1)]
+    expected = sorted(set(x for c in children for x in c))
+    lists = []
+    for c in children:
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(np.asarray(c, dtype=np.uint64), np.full(len(c), 3, dtype=np.uint32))
+        lists.append(ii)
+    ids, fr, _ = O.union_lists(lists)
+    assert ids.tolist() == expected
+    for li, c in enumerate(children):                      # matched children carry their freq, the others 0
+        cs = set(c)
+        assert fr[li].tolist() == [3 if d in cs else 0 for d in expected]
