@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
     ap.add_argument("--no-two-stage-extra", action="store_true", help="skip the extra two-stage measurement (N=1)")
     ap.add_argument("--tuning", action="append", default=[], help="engine knob key=value (A/B experiments only)")
+    ap.add_argument("--cpu-config0", action="store_true",
+                    help="no GPU: time BASELINE configs[0] (100k x 128 fp32 L2 top-10, single query) on the host cores with "
+                         "the cpu_baseline port and print one JSON line")
     return ap.parse_args()
 
 
@@ -110,8 +113,57 @@ def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0, metric="cosine")
                       "scaled by rows to %d" % (n, sample_rows, dim, metric, el, flavour, full_rows)}
 
 
+def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- on host cores with the same port the
+    cpu_baseline leg uses (warm-up 3, 1000 queries, p50 / p95 / QPS).  No GPU involved."""
+    import platform
+    import subprocess
+    import oracle as O
+    lib, flavour = O.lib, "portable(avx512/avx2 clones)"
+    try:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        nat = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle_native.so"))
+        for name in ("oflat_new", "oflat_add_bulk", "oflat_topk_heap", "oflat_free"):
+            getattr(nat, name).restype = getattr(lib, name).restype
+            getattr(nat, name).argtypes = getattr(lib, name).argtypes
+        lib, flavour = nat, "march=native"
+    except Exception:
+        pass
+    data = np.random.default_rng(47).uniform(-1, 1, (n, dim)).astype(np.float32)
+    qs = np.random.default_rng(48).uniform(-1, 1, (nq, dim)).astype(np.float32)
+    h = lib.oflat_new(O.F32, dim, O.L2, 0, 1024)
+    lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), n, 1)
+    ids, sc = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+    lat = np.zeros(nq)
+    run = lambda q: lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, ids.ctypes.data_as(C.c_void_p),
+                                        sc.ctypes.data_as(C.c_void_p))
+    for i in range(3):
+        run(qs[i])
+    t0 = time.perf_counter()
+    for i in range(nq):
+        s = time.perf_counter()
+        run(qs[i])
+        lat[i] = time.perf_counter() - s
+    el = time.perf_counter() - t0
+    lib.oflat_free(h)
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"config": "BASELINE configs[0]: %dx%d fp32 FLAT L2 top-%d, single query, CPU" % (n, dim, k),
+            "kind": "port", "sample": "oracle/flat_oracle.c oflat_topk_heap, %s, 1 thread, %d queries" % (flavour, nq),
+            "cores": 1, "value": nq / el, "unit": "queries/s", "p50_ms": float(np.percentile(lat, 50) * 1e3),
+            "p95_ms": float(np.percentile(lat, 95) * 1e3), "gb_per_s": n * dim * 4 * nq / el / 1e9,
+            "host": {"cpu": cpu, "nproc": os.cpu_count(), "machine": platform.machine()}}
+
+
 def main():
     a = parse()
+    if a.cpu_config0:
+        print(json.dumps(cpu_config0()), flush=True)
+        return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
