@@ -28,6 +28,6 @@ for d in ("prof_pmc", "prof_pmc_w"):
             print(d, k, "n=%d avg=%.1f min=%.1f max=%.1f" % (len(v), sum(v) / len(v), min(v), max(v)))
 PY
 echo "== hybrid"
-timeout 1200 python scripts/bench_hybrid.py 2>&1 | tail -8 | tee gpurun_out/hybrid.txt
+timeout 1200 python tests/bench_hybrid.py 2>&1 | tail -8 | tee gpurun_out/hybrid.txt
 # keep the merged artefacts small
 find gpurun_out -name "*.db" -delete; find gpurun_out -name "*kernel_trace.csv" -size +8M -delete

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import oracle as O  # noqa: E402  (CPU baseline leg + checker only)
+import oracle as O  # noqa: E402  (lives under tests/: the oracle encodes the inputs in the reference's wire format, checks the GPU result and is the CPU baseline)
 from redisearch_amd import search as S  # noqa: E402
 from redisearch_amd import vecsim as V  # noqa: E402
 
