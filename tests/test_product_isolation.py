@@ -28,3 +28,13 @@ def test_allowed_oracle_users_only():
             if re.search(r"^\s*(import|from)\s+oracle\b", open(os.path.join(ROOT, f)).read(), re.M):
                 users.append(f)
     assert sorted(users) == ["__graft_entry__.py", "bench.py"], users
+
+
+def test_scripts_do_not_use_the_oracle():
+    # measurement scripts that need the oracle (as encoder / checker / CPU baseline) live under tests/
+    users = []
+    d = os.path.join(ROOT, "scripts")
+    for f in os.listdir(d):
+        if f.endswith((".py", ".sh")) and re.search(r"(^\s*(import|from)\s+oracle\b|liboracle)", open(os.path.join(d, f)).read(), re.M):
+            users.append(f)
+    assert not users, users
