@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size-2 gloo run of the row-sharded top-k exchange (redisearch_amd/sharded.py).
+"""N>1 path on CPU: world_size-2 and -4 gloo runs of the row-sharded top-k exchange (redisearch_amd/sharded.py).
 Each rank holds a contiguous label range; the merged result must equal the single-index answer."""
 import os
 import socket
@@ -51,10 +51,11 @@ def _worker(rank, world, port, rows, dim, k, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("rows,k", [(500, 10), (7, 10)])
-def test_sharded_topk_matches_single_index(tmp_path, rows, k):
+@pytest.mark.parametrize("world,rows,k", [(2, 500, 10), (2, 7, 10), (4, 300, 10), (4, 3, 10)])
+def test_sharded_topk_matches_single_index(tmp_path, world, rows, k):
+    # (rows < k: shards pad with +inf / UINT64_MAX and the merge returns fewer than world*k real candidates)
     import oracle as O
-    world, dim = 2, 24
+    dim = 24
     mp.spawn(_worker, args=(world, _free_port(), rows, dim, k, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "res.npy", allow_pickle=True)
     sc = np.load(tmp_path / "sc.npy", allow_pickle=True)
