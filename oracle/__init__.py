@@ -43,6 +43,20 @@ def _load():
 
 
 lib = _load()
+
+REFERENCE_ROOT = "/root/reference"
+
+
+def ref_lib(name):
+    """oracle/_ref/<name>.so -- the reference's OWN code for the pieces of the path that compile from their own
+    sources (oracle/ref_wrap.c, `make -C oracle ref`); None where neither a prebuilt file nor the reference tree exists."""
+    path = os.path.join(_HERE, "_ref", name + ".so")
+    if not os.path.exists(path) and os.path.isdir(os.path.join(REFERENCE_ROOT, "src")):
+        subprocess.call(["make", "-s", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        return C.CDLL(path) if os.path.exists(path) else None
+    except OSError:
+        return None
 _vp, _sz, _dbl, _i = C.c_void_p, C.c_size_t, C.c_double, C.c_int
 
 
