@@ -94,7 +94,10 @@ class RefHeap:
 
 
 class PyHeap:
-    """Stand-in with the same interface; exact for tie-free distances (ties are the reference heap's business)."""
+    """Stand-in with the same interface.  It keeps the same SET as the reference heap (the evicted "max" is the highest
+    distance and, among equals, the SMALLEST doc id -- cmpVecSimResByScore's tie rule; checked against traces of the
+    real heap, tests/golden/ref_minmax_heap.json); the order in which equal distances are yielded is the reference
+    heap's internal business and is only reproduced by RefHeap."""
 
     def __init__(self, k):
         self.items, self.count = [], 0
@@ -104,7 +107,7 @@ class PyHeap:
         self.count += 1
 
     def exchange_max(self, doc_id, score):
-        self.items.remove(max(self.items))
+        self.items.remove(max(self.items, key=lambda t: (t[0], -t[1])))
         self.items.append((score, doc_id))
 
     def peek_max_score(self):
