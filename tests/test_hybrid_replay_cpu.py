@@ -78,3 +78,33 @@ def test_policies_agree_on_random_data(batch_size):
     if H.reference_heap_available():                       # the stand-in heap gives the same answer (no ties here)
         py = H.HybridReplay(index, q, k, H.IdListChild(child), policy=H.HYBRID_BATCHES, force_python_heap=True).results()
         assert py == adhoc
+
+
+def test_change_policy_kat():
+    # test_vecsim.py:1583-1643 on `VECTOR FLAT`, d = 2, COSINE, n = 6000 random vectors, the filter passes the first half
+    rng = np.random.default_rng(10)
+    n, dim, k = 6000, 2, 10
+    data = rng.random((n, dim)).astype(np.float32)
+    idx = O.FlatIndex(O.F32, dim, O.COSINE)
+    idx.add_bulk(data)
+    index = H.OracleIndex(idx)
+    q = rng.random(dim).astype(np.float32)
+    half = list(range(1, n // 2 + 1))
+    # (1) 10 results in HYBRID_BATCHES; forcing ad-hoc BF returns the same scores
+    b = H.HybridReplay(index, q, k, H.IdListChild(half))
+    rb = b.results()
+    assert b.mode == H.HYBRID_BATCHES and len(rb) == 10
+    a = H.HybridReplay(index, q, k, H.IdListChild(half), policy=H.HYBRID_ADHOC_BF)
+    assert [s for _, s in a.results()] == [s for _, s in rb] and a.mode == H.HYBRID_ADHOC_BF
+    # (2) an empty child whose ESTIMATE is n/2: the policy changes to ad-hoc BF while running the batches, 0 results
+    e = H.HybridReplay(index, q, k, H.IdListChild([], estimate=n // 2))
+    assert e.results() == [] and e.mode == H.HYBRID_BATCHES_TO_ADHOC_BF and e.num_iterations == 2
+    assert e.batch_sizes == [21, 41]                      # 10 * (6000 / 3000) + 1, then 10 * (6000 / 1500) + 1
+    assert H.HybridReplay(index, q, k, H.IdListChild([], estimate=n // 2), policy=H.HYBRID_ADHOC_BF).results() == []
+    # (3) one valid document (the query itself): found in the first batch, dropped with the heap when the policy
+    # changes, found again by the ad-hoc pass
+    idx.add(q, n + 1)
+    one = H.HybridReplay(index, q, k, H.IdListChild([n + 1], estimate=n // 2))
+    res = one.results()
+    assert one.mode == H.HYBRID_BATCHES_TO_ADHOC_BF and [i for i, _ in res] == [n + 1]
+    assert abs(res[0][1]) < 1e-6
