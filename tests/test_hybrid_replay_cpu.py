@@ -108,3 +108,29 @@ def test_change_policy_kat():
     res = one.results()
     assert one.mode == H.HYBRID_BATCHES_TO_ADHOC_BF and [i for i, _ in res] == [n + 1]
     assert abs(res[0][1]) < 1e-6
+
+
+@pytest.mark.parametrize("vtype", [O.F64, O.F32])
+def test_hybrid_query_cosine_kat(vtype):
+    # test_vecsim.py:1428-1487 on `VECTOR FLAT`: doc i = [i/N, 1, 1, 1], q = [1, 1, 1, 1], COSINE
+    n, dim, k = 6000, 4, 10
+    rows = np.ones((n, dim))
+    rows[:, 0] = np.arange(1, n + 1) / n
+    idx = O.FlatIndex(vtype, dim, O.COSINE)
+    idx.add_bulk(rows)
+    index = H.OracleIndex(idx)
+    q = np.ones(dim)
+    it = H.HybridReplay(index, q, k, H.IdListChild(range(1, n + 1)))
+    ids = [i for i, _ in it.results()]
+    assert it.mode == H.HYBRID_BATCHES                     # LAST_SEARCH_MODE asserted by the reference test
+    if vtype == O.F64:
+        assert ids == [n - i for i in range(10)]
+    else:
+        assert set(ids) <= {n - i for i in range(15)} and len(ids) == 10
+    it = H.HybridReplay(index, q, k, H.IdListChild(range(10, n + 1, 10)))
+    ids = [i for i, _ in it.results()]
+    assert it.mode == H.HYBRID_ADHOC_BF
+    if vtype == O.F64:
+        assert ids == [n - 10 * i for i in range(10)]
+    else:
+        assert set(ids) == {n - 10 * i for i in range(10)}
