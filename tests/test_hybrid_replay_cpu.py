@@ -134,3 +134,30 @@ def test_hybrid_query_cosine_kat(vtype):
         assert ids == [n - 10 * i for i in range(10)]
     else:
         assert set(ids) == {n - 10 * i for i in range(10)}
+
+
+def test_batches_mode_with_tags_middle_query_kat(idx6000):
+    # test_vecsim.py:1040-1093: q = [N/2, N/2]; equal distances on both sides of the query, "closer results will come
+    # before (secondary sorting by id)" -- and at the K boundary the LOWER id of the tied pair mid-5 / mid+5 is the one
+    # that is kept (strict `<` admission, hybrid_reader.c:321, ids arriving in ascending order from the BY_ID batch)
+    n, dim, k = 6000, 2, 10
+    mid = n // 2
+    index = H.OracleIndex(idx6000)
+    q = np.full(dim, float(mid))
+    by_score_then_id = lambda res: sorted(res, key=lambda t: (t[1], t[0]))   # the sorter behind the iterator (SORTBY)
+    exp = [(mid, 0.0)] + [(mid + (-(i + 1) // 2 if i % 2 else i // 2), float(dim * ((i + 1) // 2) ** 2)) for i in range(1, 10)]
+    got = by_score_then_id(H.HybridReplay(index, q, k, H.IdListChild(range(1, n + 1))).results())
+    assert got == exp and got[-1][0] == mid - 5
+    # ids that divide by 5
+    exp5 = [(mid, 0.0)] + [(mid + (-((5 * i + 5) // 2) if i % 2 else (5 * i) // 2), float(dim * (5 * ((i + 1) // 2)) ** 2))
+                           for i in range(1, 10)]
+    got = by_score_then_id(H.HybridReplay(index, q, k, H.IdListChild(range(5, n + 1, 5))).results())
+    assert got == exp5
+    # ids that do not divide by 5
+    expn, i = [], 0
+    while len(expn) < 10:
+        if (mid + (i + 1) // 2) % 5:
+            expn.append((mid + (-((i + 1) // 2) if i % 2 else i // 2), float(dim * ((i + 1) // 2) ** 2)))
+        i += 1
+    got = by_score_then_id(H.HybridReplay(index, q, k, H.IdListChild([d for d in range(1, n + 1) if d % 5])).results())
+    assert got == expn
