@@ -15,6 +15,7 @@
 
 #include "vec_sim_common.h"
 #include "query_results.h"
+#include "info_iterator.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -51,10 +52,7 @@ VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index);
 VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index);
 /* reference src/debug_commands.c:1714 */
 VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index);
-size_t VecSimDebugInfoIterator_NumberOfFields(VecSimDebugInfoIterator *it);
-bool VecSimDebugInfoIterator_HasNextField(VecSimDebugInfoIterator *it);
-VecSim_InfoField *VecSimDebugInfoIterator_NextField(VecSimDebugInfoIterator *it);
-void VecSimDebugInfoIterator_Free(VecSimDebugInfoIterator *it);
+/* the iterator's own accessors: VecSim/info_iterator.h */
 
 /* ---- queries (the hot path) -------------------------------------------------------------------- */
 /* reference src/vector_index.c:744. Fills qparams from raw (name,value) pairs. */
@@ -95,9 +93,7 @@ void VecSimTieredIndex_AcquireSharedLocks(VecSimIndex *index);
 void VecSimTieredIndex_ReleaseSharedLocks(VecSimIndex *index);
 void VecSimTieredIndex_GC(VecSimIndex *index);
 
-/* HNSW-only debug helpers (reference src/debug_commands.c:1814-1830): always BadIndex here. */
-int VecSimDebug_GetElementNeighborsInHNSWGraph(VecSimIndex *index, size_t label, int ***neighborsData);
-void VecSimDebug_ReleaseElementNeighborsInHNSWGraph(int **neighborsData);
+/* HNSW-only debug helpers (reference src/debug_commands.c:1756-1779): VecSim/vec_sim_debug.h. */
 
 /* ---- blob helpers ------------------------------------------------------------------------------ */
 /* reference src/iterators/hybrid_reader.c:304 -- in-place L2 normalisation. */

@@ -34,6 +34,28 @@ extern "C" {
 #define INVALID_JOB_ID UINT_MAX
 #define INVALID_INFO UINT_MAX
 
+/* SVS-Vamana creation defaults.  Not served by this engine; declared because the FT.CREATE parser fills
+ * them in before it knows which algorithm it will get (reference src/spec.c:1227-1237).  Values pinned by
+ * the FT.DEBUG VECSIM_INFO expectation at reference tests/pytests/test_vecsim.py:357-360 (graph degree 32,
+ * construction window 200, leanvec 0, alpha 1.2 / 0.95); the training threshold is 10 blocks
+ * [upstream-memory]. */
+#define SVS_VAMANA_DEFAULT_ALPHA_L2 1.2f
+#define SVS_VAMANA_DEFAULT_ALPHA_IP 0.95f
+#define SVS_VAMANA_DEFAULT_GRAPH_MAX_DEGREE 32
+#define SVS_VAMANA_DEFAULT_CONSTRUCTION_WINDOW_SIZE 200
+#define SVS_VAMANA_DEFAULT_USE_SEARCH_HISTORY true
+#define SVS_VAMANA_DEFAULT_NUM_THREADS 1
+#define SVS_VAMANA_DEFAULT_TRAINING_THRESHOLD (10 * DEFAULT_BLOCK_SIZE)
+#define SVS_VAMANA_DEFAULT_UPDATE_THRESHOLD (1 * DEFAULT_BLOCK_SIZE)
+#define SVS_VAMANA_DEFAULT_SEARCH_WINDOW_SIZE 10
+#define SVS_VAMANA_DEFAULT_LEANVEC_DIM 0
+#define SVS_VAMANA_DEFAULT_EPSILON 0.01f
+
+/* HYBRID_POLICY values as VecSimIndex_ResolveParams accepts them (case-insensitive); the FT.HYBRID FILTER
+ * parser maps its "ADHOC" onto the first (reference src/hybrid/parse/hybrid_callbacks.c:441-443). */
+#define VECSIM_POLICY_ADHOC_BF "adhoc_bf"
+#define VECSIM_POLICY_BATCHES "batches"
+
 /* Element type of stored vectors and query blobs.
  * Names: reference src/vector_index.c:386-393; order [upstream-memory], RDB-persisted (:491). */
 typedef enum {
@@ -213,6 +235,7 @@ typedef struct {
   const char *indexName;
   size_t indexNameLen;
   void *storage;
+  void *userData; /* the owning field index; key of the disk layer (reference src/spec.c:1203,2920) */
   bool rerank;
 } VecSimDiskContext;
 
@@ -284,30 +307,8 @@ typedef struct {
   size_t flatBufferSize;
 } VecSimIndexStatsInfo;
 
-/* Debug-info iterator fields (reference src/debug_commands.c:1664-1687). */
-typedef enum {
-  INFOFIELD_STRING,
-  INFOFIELD_INT64,
-  INFOFIELD_UINT64,
-  INFOFIELD_FLOAT64,
-  INFOFIELD_ITERATOR
-} VecSim_InfoFieldType;
-
+/* Debug-info iterator types live in VecSim/info_iterator.h (reference src/debug_commands.c:49). */
 typedef struct VecSimDebugInfoIterator VecSimDebugInfoIterator;
-
-typedef union {
-  double floatingPointValue;
-  int64_t integerValue;
-  uint64_t uintegerValue;
-  const char *stringValue;
-  VecSimDebugInfoIterator *iteratorValue;
-} FieldValue;
-
-typedef struct {
-  const char *fieldName;
-  VecSim_InfoFieldType fieldType;
-  FieldValue fieldValue;
-} VecSim_InfoField;
 
 /* ---- process-wide hooks (installed at reference src/module-init/module-init.c:147-151) -------- */
 

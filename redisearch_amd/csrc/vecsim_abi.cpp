@@ -9,6 +9,7 @@
 #include <strings.h>
 
 #include "flat_index.hpp"
+#include "VecSim/vec_sim_debug.h"
 #include "rsgpu_ext.h"
 
 using namespace rsgpu;
