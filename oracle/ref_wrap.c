@@ -14,3 +14,14 @@
 double ref_vector_norm(int metric, double value) {
   return getVectorNormalizationFunction((VecSimMetric)metric)(value);
 }
+
+/* src/hybrid/hybrid_scoring.c (HybridRRFScore / HybridLinearScore, :41-84) is compiled as its own object; its
+ * EXPLAINSCORE formatters use hiredis' sds (an empty submodule).  They are not on this path: these stand-ins only
+ * let the library load with RTLD_NOW. */
+#ifdef REF_WRAP_SDS_STUBS
+#include <stdlib.h>
+char *sdsnew(const char *s) { (void)s; abort(); }
+char *sdscat(char *s, const char *t) { (void)s; (void)t; abort(); }
+char *sdscatprintf(char *s, const char *fmt, ...) { (void)s; (void)fmt; abort(); }
+void sdsfree(char *s) { (void)s; abort(); }
+#endif

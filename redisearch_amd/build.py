@@ -67,6 +67,33 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         out.append(target)
+    return out + build_c(force, verbose)
+
+
+# plain-C shared objects (gcc): the scorer plugin a RediSearch module loads with EXTLOAD.  The result-tree accessors
+# stay undefined in it (the module provides them), hence no -Wl,--no-undefined.
+CC = os.environ.get("CC", "gcc")
+C_LIBS = {
+    "librsgpu_scorers.so": (["scorer_plugin.c"],
+                            ["-O2", "-std=gnu11", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall",
+                             "-Wextra", "-I" + os.path.join(ROOT, "include")], ["-ldl", "-lm"]),
+}
+
+
+def build_c(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdr_m = _deps_mtime()
+    out = []
+    for lib, (srcs, flags, libs) in C_LIBS.items():
+        paths = [os.path.join(CSRC, s) for s in srcs]
+        target = os.path.join(LIBDIR, lib)
+        newest = max([os.path.getmtime(x) for x in paths] + [hdr_m])
+        if force or not os.path.exists(target) or os.path.getmtime(target) < newest:
+            cmd = [CC] + flags + paths + ["-o", target] + libs
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        out.append(target)
     return out
 
 
