@@ -32,6 +32,15 @@ int RSGPU_FlatIndex_Reserve(VecSimIndex *index, size_t rows);
  * each), labelled first_label .. first_label+n-1. Cosine rows are normalised on the device.
  * Returns rows added or -1. */
 int RSGPU_FlatIndex_AddDeviceRows(VecSimIndex *index, const void *dev_rows, size_t n, size_t first_label);
+/* Append n SYNTHETIC rows generated in place in HBM (bench / test corpora; nothing crosses PCIe): element j of row i is
+ * Philox4x32-10 keyed by `seed`, counter (first_index + i, j / 4), word j % 4, mapped to [-1, 1) on a 2^-23 grid
+ * (FLOAT16 / BFLOAT16: that fp32 rounded to nearest even; FLOAT64: widened; INT8 / UINT8: the word's top byte).  Any
+ * host can regenerate any row (oracle/flat_oracle.c oracle_philox_rows).  Labels first_label .. first_label+n-1.
+ * Returns rows added or -1. */
+long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t first_index, size_t n, size_t first_label);
+/* Stored rows [row_begin, row_begin+n) in storage order, as they are in HBM (cosine rows: normalised), tightly packed
+ * into host memory (n * dim * sizeof(type) bytes).  Inspection / tests.  0 on success. */
+int RSGPU_FlatIndex_ReadRows(VecSimIndex *index, size_t row_begin, size_t n, void *host_out);
 /* Top-k of one host query written to DEVICE buffers (k fp32 scores, k u64 labels; unused slots get
  * +inf / UINT64_MAX), ordered by (score,label). The call returns after the results are complete.
  * Returns the number of hits or -1. */
@@ -50,6 +59,31 @@ int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_
  * NULL) is synchronised first. Returns the number written or -1. */
 int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
                     double *scores_out, uint64_t *labels_out, void *wait_stream);
+
+/* ---- one index over several GPUs of one process (sharded_index.cpp) ------------------------------
+ * The in-process form of the coordinator's per-shard top-K -> heap merge (reference src/module.c:3541-3547): the corpus
+ * is row-partitioned over n_shards FLAT shards, shard i resident on devices[i] (NULL: i mod the visible devices;
+ * several shards may share a device), a query runs on every shard concurrently and the per-shard top-k lists are merged
+ * by (score, label).  replicas != 0: every shard holds the WHOLE corpus and a query goes to one of them round-robin
+ * (throughput scaling for concurrent callers).  Results equal those of one unsharded index over the same vectors. */
+typedef struct RSGPU_ShardedIndex RSGPU_ShardedIndex;
+RSGPU_ShardedIndex *RSGPU_ShardedIndex_New(const VecSimParams *params, int n_shards, const int *devices, int replicas);
+void RSGPU_ShardedIndex_Free(RSGPU_ShardedIndex *index);
+int RSGPU_ShardedIndex_NumShards(RSGPU_ShardedIndex *index);
+int RSGPU_ShardedIndex_ShardDevice(RSGPU_ShardedIndex *index, int shard);
+/* borrowed handle of one shard, for bulk loads (RSGPU_FlatIndex_AddDeviceRows / _AddPhiloxRows) and inspection; the
+ * caller keeps labels disjoint across shards */
+VecSimIndex *RSGPU_ShardedIndex_Shard(RSGPU_ShardedIndex *index, int shard);
+size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *index);
+/* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
+ * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */
+int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *index, const void *blob, size_t label);
+int RSGPU_ShardedIndex_DeleteVector(RSGPU_ShardedIndex *index, size_t label);
+double RSGPU_ShardedIndex_GetDistanceFrom(RSGPU_ShardedIndex *index, size_t label, const void *normalized_blob);
+VecSimQueryReply *RSGPU_ShardedIndex_TopKQuery(RSGPU_ShardedIndex *index, const void *queryBlob, size_t k,
+                                               VecSimQueryParams *queryParams, VecSimQueryReply_Order order);
+VecSimQueryReply *RSGPU_ShardedIndex_RangeQuery(RSGPU_ShardedIndex *index, const void *queryBlob, double radius,
+                                                VecSimQueryParams *queryParams, VecSimQueryReply_Order order);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* When on, every FLAT scan launch is bracketed by HIP events on its own stream. */

@@ -85,6 +85,7 @@ _sig("oracle_blob_size", _sz, _i, _sz, _i)
 _sig("oracle_distance", _dbl, _vp, _vp, _sz, _i, _i)
 _sig("oracle_distance_f64", _dbl, _vp, _vp, _sz, _i, _i)
 _sig("oracle_prefer_adhoc", _i, _sz, _sz, _sz, _sz, _i, C.POINTER(_i))
+_sig("oracle_prefer_adhoc2", _i, _sz, _sz, _sz, _sz, _sz, _i, C.POINTER(_i))
 _sig("oracle_f32_to_f16", C.c_uint16, C.c_float)
 _sig("oracle_f32_to_bf16", C.c_uint16, C.c_float)
 _sig("oracle_f16_to_f32", C.c_float, C.c_uint16)
@@ -219,9 +220,35 @@ class BatchIterator:
         return ids[:m].copy(), sc[:m].copy()
 
 
-def prefer_adhoc(index_size, dim, subset, k, initial_check=True):
+_sig("oracle_philox_rows", None, C.c_uint64, C.c_uint64, _sz, _sz, _i, _vp)
+
+
+def philox_rows(seed, first_index, n, dim, vtype=F32, threads=None):
+    """Rows first_index .. first_index+n-1 of the keyed synthetic corpus (oracle_philox_rows), as an [n, dim] array;
+    large requests are split over threads (the C function releases the GIL)."""
+    out = np.empty((n, dim), dtype=TYPE_NP[vtype])
+    if n == 0:
+        return out
+    threads = threads or (min(32, os.cpu_count() or 1) if n * dim > (1 << 22) else 1)
+    if threads <= 1:
+        lib.oracle_philox_rows(seed, first_index, n, dim, vtype, _p(out))
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    step = (n + threads - 1) // threads
+
+    def part(t):
+        a, b = t * step, min(n, (t + 1) * step)
+        if a < b:
+            lib.oracle_philox_rows(seed, first_index + a, b - a, dim, vtype, _p(out[a:b]))
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(part, range(threads)))
+    return out
+
+
+def prefer_adhoc(index_size, dim, subset, k, initial_check=True, label_count=None):
     mode = _i(0)
-    r = lib.oracle_prefer_adhoc(index_size, dim, subset, k, int(initial_check), C.byref(mode))
+    r = lib.oracle_prefer_adhoc2(index_size, index_size if label_count is None else label_count, dim, subset, k,
+                                 int(initial_check), C.byref(mode))
     return bool(r), mode.value
 
 

@@ -365,24 +365,74 @@ void obatch_free(OBatch *b) { if (b) { free(b->h); free(b); } }
 /* VecSimIndex_PreferAdHocSearch for BF [upstream-memory D6]; the four decision points the
  * reference pins (tests/pytests/test_vecsim.py:1436-1478,1615-1643,966-968) are checked in
  * tests/test_oracle_flat.py.  Returns 1 for ad-hoc; *mode receives the VecSearchMode recorded. */
-int oracle_prefer_adhoc(size_t index_size, size_t dim, size_t subset, size_t k, int initial_check, int *mode) {
+/* [upstream-memory D6] BruteForceIndex::preferAdHocSearch: the ratio is subset / LABEL count in float, compared
+ * (promoted to double) with double literals; the size cuts use the vector count. */
+int oracle_prefer_adhoc2(size_t index_size, size_t label_count, size_t dim, size_t subset, size_t k, int initial_check,
+                         int *mode) {
   (void)k;
   if (subset > index_size) subset = index_size; /* an estimate may exceed the index */
   int res;
-  float r = index_size ? (float)subset / (float)index_size : 0.0f;
+  float r = index_size ? (float)subset / (float)label_count : 0.0f;
   size_t N = index_size, d = dim;
   if (N <= 5500) res = 1;
   else if (d <= 300) {
-    if (r <= 0.15f) res = 1;
-    else if (r <= 0.35f) { if (d <= 75) res = 0; else res = (N <= 550000); }
+    if (r <= 0.15) res = 1;
+    else if (r <= 0.35) { if (d <= 75) res = 0; else res = (N <= 550000); }
     else res = 0;
   } else {
-    if (r <= 0.55f) res = 1;
+    if (r <= 0.55) res = 1;
     else if (d <= 750) res = 0;
-    else res = (r <= 0.75f);
+    else res = (r <= 0.75);
   }
   if (mode) *mode = res ? (initial_check ? 2 /*HYBRID_ADHOC_BF*/ : 4 /*BATCHES_TO_ADHOC_BF*/) : 3 /*HYBRID_BATCHES*/;
   return res;
+}
+int oracle_prefer_adhoc(size_t index_size, size_t dim, size_t subset, size_t k, int initial_check, int *mode) {
+  return oracle_prefer_adhoc2(index_size, index_size, dim, subset, k, initial_check, mode);
+}
+
+/* ---- keyed synthetic corpus: the CPU twin of redisearch_amd/csrc/corpus_kernels.hip ------------------
+ * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11): ten rounds of
+ * two 32x32->64 multiplies (0xD2511F53, 0xCD9E8D57) with the key bumped by the Weyl constants 0x9E3779B9 / 0xBB67AE85
+ * after each round.  Pinned on the Random123 known answers in tests/test_oracle_flat.py. */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* rows first_index .. first_index+n-1 of the corpus keyed by `seed`, tightly packed (dim elements of `type` each):
+ * element j of row i = word j%4 of Philox(key = seed, counter = (i_lo, i_hi, j/4, 0)); floating types map the word's
+ * top 24 bits to [-1,1) on a 2^-23 grid (exact in fp32; f16/bf16 round that to nearest even; f64 widens it), the
+ * integer types take the top byte. */
+void oracle_philox_rows(uint64_t seed, uint64_t first_index, size_t n, size_t dim, int type, void *out) {
+  const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  const size_t esz = type_size(type);
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t gi = first_index + i;
+    uint8_t *row = (uint8_t *)out + i * dim * esz;
+    for (size_t q = 0; q * 4 < dim; q++) {
+      const uint32_t ctr[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)q, 0u};
+      uint32_t w[4];
+      oracle_philox4x32_10(ctr, key, w);
+      for (size_t e = 0; e < 4 && q * 4 + e < dim; e++) {
+        const size_t j = q * 4 + e;
+        const float v = (float)(w[e] >> 8) * 0x1p-23f - 1.0f;
+        switch (type) {
+          case T_F32: ((float *)row)[j] = v; break;
+          case T_F64: ((double *)row)[j] = (double)v; break;
+          case T_F16: ((uint16_t *)row)[j] = oracle_f32_to_f16(v); break;
+          case T_BF16: ((uint16_t *)row)[j] = oracle_f32_to_bf16(v); break;
+          default: row[j] = (uint8_t)(w[e] >> 24); break;
+        }
+      }
+    }
+  }
 }
 
 /* direct pointer to the stored (normalised) rows, for tests that inspect the layout */

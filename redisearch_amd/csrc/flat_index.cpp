@@ -299,9 +299,9 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
 FlatIndex::~FlatIndex() {
   HIP_IGNORE(hipSetDevice(device));
   HIP_IGNORE(hipStreamSynchronize(wstream_));
-  if (d_rows_) HIP_IGNORE(hipFree(d_rows_));
+  rows_buf_.release();
+  shadow_buf_.release();
   if (d_labels_) HIP_IGNORE(hipFree(d_labels_));
-  if (d_shadow_) HIP_IGNORE(hipFree(d_shadow_));
   if (d_sscale_) HIP_IGNORE(hipFree(d_sscale_));
   if (d_smax_) HIP_IGNORE(hipFree(d_smax_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
@@ -309,60 +309,56 @@ FlatIndex::~FlatIndex() {
 }
 
 size_t FlatIndex::memory() const {
-  return cap_rows_ * (stride_ + sstride_ + (shadow_ == 2 ? 4 : 0) + sizeof(uint64_t)) + row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
+  return rows_buf_.physical() + shadow_buf_.physical() + cap_rows_ * ((shadow_ == 2 ? 4 : 0) + sizeof(uint64_t)) +
+         row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
          (single_map_.size() + multi_map_.size()) * 48;
 }
 
 void FlatIndex::grow(size_t min_rows) {
-  if (min_rows <= cap_rows_) return;
+  // 32 rows of slack behind the rows: the batched filter pass reads its ragged last tile whole
+  const size_t need_row_bytes = (min_rows + 32) * stride_;
+  if (min_rows <= cap_rows_ && need_row_bytes <= rows_buf_.capacity()) return;
   if (min_rows > 0xFFFFFFF0ull) throw std::runtime_error("FLAT index is limited to 2^32 rows per device");
-  size_t cap = cap_rows_ ? cap_rows_ : 0;
-  size_t next = cap < (1u << 22) ? cap * 2 : cap + cap / 2;
-  size_t new_cap = std::max(min_rows, next);
-  new_cap = round_up(new_cap, 64);
-  uint8_t *nr = nullptr;
+  const int mode = scan_tuning().vmm;
+  // Row matrix (+ shadow): no copy once mapped (grow_buffer.hpp), so it grows by what is needed (rounded to a
+  // physical chunk by the buffer); while it is a plain allocation it doubles like the label array below.
+  size_t next = cap_rows_ < (1u << 22) ? cap_rows_ * 2 : cap_rows_ + cap_rows_ / 2;
+  size_t new_cap = round_up(std::max(min_rows, next), 64);
+  const bool rows_mapped = rows_buf_.mapped() || (mode == 1 && need_row_bytes >= GrowBuffer::kVmmThreshold && vmm_supported(device));
+  const size_t row_target = rows_mapped ? min_rows : new_cap;
+  rows_buf_.ensure(device, (row_target + 32) * stride_, (size_t)n_rows_ * stride_, wstream_, mode);
+  d_rows_ = rows_buf_.ptr();
+  if (shadow_) {
+    shadow_buf_.ensure(device, (row_target + 32) * sstride_, (size_t)n_rows_ * sstride_, wstream_, mode);
+    d_shadow_ = shadow_buf_.ptr();
+  }
+  if (min_rows <= cap_rows_) return;
+  // labels (8 B per row) and int8 row scales (4 B): small next to the rows -- allocate, copy, swap
   uint64_t *nl = nullptr;
-  uint8_t *ns = nullptr;
   float *nsc = nullptr;
-  // an allocation that fails (HBM exhausted) must not leak the ones before it: the index stays usable at its
-  // old capacity and the caller sees the error
   struct Rollback {
-    void **p[4];
+    void **p[2];
     bool armed = true;
     ~Rollback() {
       if (armed)
         for (void **q : p)
           if (*q) HIP_IGNORE(hipFree(*q));
     }
-  } rollback{{(void **)&nr, (void **)&nl, (void **)&ns, (void **)&nsc}};
-  // 32 rows of slack behind the capacity: the batched filter pass reads its ragged last tile whole
-  HIP_CHECK(hipMalloc((void **)&nr, (new_cap + 32) * stride_));
+  } rollback{{(void **)&nl, (void **)&nsc}};
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
-  if (shadow_) {
-    HIP_CHECK(hipMalloc((void **)&ns, (new_cap + 32) * sstride_));
-    if (n_rows_) HIP_CHECK(hipMemcpyAsync(ns, d_shadow_, (size_t)n_rows_ * sstride_, hipMemcpyDeviceToDevice, wstream_));
-    if (shadow_ == 2) {
-      HIP_CHECK(hipMalloc((void **)&nsc, new_cap * sizeof(float)));
-      if (n_rows_) HIP_CHECK(hipMemcpyAsync(nsc, d_sscale_, (size_t)n_rows_ * sizeof(float), hipMemcpyDeviceToDevice, wstream_));
-    }
-  }
+  if (shadow_ == 2) HIP_CHECK(hipMalloc((void **)&nsc, new_cap * sizeof(float)));
   if (n_rows_) {
-    HIP_CHECK(hipMemcpyAsync(nr, d_rows_, (size_t)n_rows_ * stride_, hipMemcpyDeviceToDevice, wstream_));
     HIP_CHECK(hipMemcpyAsync(nl, d_labels_, (size_t)n_rows_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
+    if (nsc) HIP_CHECK(hipMemcpyAsync(nsc, d_sscale_, (size_t)n_rows_ * sizeof(float), hipMemcpyDeviceToDevice, wstream_));
     HIP_CHECK(hipStreamSynchronize(wstream_));
   }
-  if (shadow_ && !n_rows_) HIP_CHECK(hipStreamSynchronize(wstream_));
   rollback.armed = false;
-  if (d_rows_) HIP_CHECK(hipFree(d_rows_));
   if (d_labels_) HIP_CHECK(hipFree(d_labels_));
-  if (shadow_) {
-    if (d_shadow_) HIP_CHECK(hipFree(d_shadow_));
-    d_shadow_ = ns;
+  d_labels_ = nl;
+  if (shadow_ == 2) {
     if (d_sscale_) HIP_CHECK(hipFree(d_sscale_));
     d_sscale_ = nsc;
   }
-  d_rows_ = nr;
-  d_labels_ = nl;
   cap_rows_ = new_cap;
 }
 
@@ -515,7 +511,49 @@ int FlatIndex::remove(size_t label) {
   HIP_CHECK(hipStreamSynchronize(wstream_));
   if (multi) multi_map_.erase(label);
   else single_map_.erase(label);
+  layout_epoch++;
   return (int)rows.size();
+}
+
+// a single-value index holds one vector per label: a bulk load may not collide with a stored label
+// (AddVector's overwrite semantics would need a row-by-row path; the caller uses AddVector for that)
+void FlatIndex::check_bulk_labels(size_t n, size_t first_label) const {
+  if (multi) return;
+  if (identity_) {
+    const uint64_t lo = identity_base_, hi = identity_base_ + row_label_.size();  // stored labels [lo,hi)
+    if (!row_label_.empty() && first_label < hi && first_label + n > lo)
+      throw std::runtime_error("bulk load: label range overlaps stored labels");
+  } else {
+    for (size_t i = 0; i < n; i++)
+      if (single_map_.count(first_label + i)) throw std::runtime_error("bulk load: label already stored");
+  }
+}
+
+void FlatIndex::commit_bulk_rows(size_t n, size_t first_label) {
+  if (metric == VecSimMetric_Cosine && kmetric == KM_IP)
+    launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
+  shadow_convert(n_rows_, (uint32_t)(n_rows_ + n));
+  const size_t old = row_label_.size();
+  if (identity_) {
+    if (old == 0) identity_base_ = first_label;
+    // still label == base + row for every row?  otherwise the maps are built now, from the rows stored so far
+    if (first_label != identity_base_ + old) break_identity();
+  }
+  row_label_.resize(old + n);
+  for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
+  if (!identity_) {
+    // maps exist (an earlier delete / out-of-order add / this very call): every new (label,row) goes in
+    if (multi) {
+      for (size_t i = 0; i < n; i++) multi_map_[first_label + i].push_back((uint32_t)(old + i));
+    } else {
+      single_map_.reserve(single_map_.size() + n);
+      for (size_t i = 0; i < n; i++) single_map_[first_label + i] = (uint32_t)(old + i);
+    }
+  }
+  HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + old, n * sizeof(uint64_t), hipMemcpyHostToDevice, wstream_));
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  HIP_CHECK(hipGetLastError());
+  n_rows_ += (uint32_t)n;
 }
 
 int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_label) {
@@ -523,6 +561,7 @@ int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_labe
   HIP_CHECK(hipSetDevice(device));
   flush();
   if (!n) return 0;
+  check_bulk_labels(n, first_label);
   grow((size_t)n_rows_ + n);
   uint8_t *dst = d_rows_ + (size_t)n_rows_ * stride_;
   if (stride_ == elem_bytes_) {
@@ -531,26 +570,41 @@ int FlatIndex::add_device_rows(const void *dev_rows, size_t n, size_t first_labe
     HIP_CHECK(hipMemsetAsync(dst, 0, n * stride_, wstream_));
     HIP_CHECK(hipMemcpy2DAsync(dst, stride_, dev_rows, elem_bytes_, elem_bytes_, n, hipMemcpyDeviceToDevice, wstream_));
   }
-  if (metric == VecSimMetric_Cosine && kmetric == KM_IP)
-    launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
-  shadow_convert(n_rows_, (uint32_t)(n_rows_ + n));
-  size_t old = row_label_.size();
-  row_label_.resize(old + n);
-  for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
-  if (identity_ && old == 0) identity_base_ = first_label;
-  if (!(identity_ && first_label == identity_base_ + old)) {
-    break_identity();  // builds the maps from row_label_, new rows included
-  }
-  HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + old, n * sizeof(uint64_t), hipMemcpyHostToDevice, wstream_));
-  HIP_CHECK(hipStreamSynchronize(wstream_));
-  HIP_CHECK(hipGetLastError());
-  n_rows_ += (uint32_t)n;
+  commit_bulk_rows(n, first_label);
   return (int)n;
+}
+
+int FlatIndex::add_philox_rows(uint64_t seed, uint64_t first_index, size_t n, size_t first_label) {
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  flush();
+  if (!n) return 0;
+  check_bulk_labels(n, first_label);
+  grow((size_t)n_rows_ + n);
+  launch_philox_rows(d_rows_, stride_, (uint32_t)dim, ktype, seed, first_index, n_rows_, (uint32_t)n, wstream_);
+  commit_bulk_rows(n, first_label);
+  return (int)n;
+}
+
+void FlatIndex::read_rows(uint32_t row_begin, size_t n, void *host_out) {
+  flush_if_needed();
+  std::shared_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  if ((size_t)row_begin + n > n_rows_) throw std::runtime_error("read_rows: range beyond the stored rows");
+  if (!n) return;
+  HIP_CHECK(hipMemcpy2D(host_out, elem_bytes_, d_rows_ + (size_t)row_begin * stride_, stride_, elem_bytes_, n,
+                        hipMemcpyDeviceToHost));
 }
 
 size_t FlatIndex::size() {
   std::shared_lock<std::shared_mutex> g(mu);
   return (size_t)n_rows_ + stage_n_;
+}
+bool FlatIndex::contains(size_t label) {
+  std::shared_lock<std::shared_mutex> g(mu);
+  std::vector<uint32_t> rows;
+  rows_of(label, rows);
+  return !rows.empty();
 }
 size_t FlatIndex::label_count() {
   std::shared_lock<std::shared_mutex> g(mu);
@@ -1021,19 +1075,21 @@ double FlatIndex::distance_from(size_t label, const void *blob) {
 // points the reference pins are listed in SURVEY.md 8 a6).
 bool FlatIndex::prefer_adhoc(size_t subset, size_t k, bool initial_check) {
   (void)k;
-  size_t N = size(), d = dim;
+  const size_t N = size(), labels = label_count(), d = dim;
   if (subset > N) subset = N;
-  float r = N ? (float)subset / (float)N : 0.0f;
+  // the ratio is over LABELS (a multi-value index holds more vectors than documents), kept in float and compared
+  // with double literals -- so exactly-on-threshold ratios fall where the float lands
+  const float r = N ? (float)subset / (float)labels : 0.0f;
   bool res;
   if (N <= 5500) res = true;
   else if (d <= 300) {
-    if (r <= 0.15f) res = true;
-    else if (r <= 0.35f) res = d <= 75 ? false : N <= 550000;
+    if (r <= 0.15) res = true;
+    else if (r <= 0.35) res = d <= 75 ? false : N <= 550000;
     else res = false;
   } else {
-    if (r <= 0.55f) res = true;
+    if (r <= 0.55) res = true;
     else if (d <= 750) res = false;
-    else res = r <= 0.75f;
+    else res = r <= 0.75;
   }
   last_mode = res ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
   return res;

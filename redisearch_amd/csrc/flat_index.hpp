@@ -20,6 +20,7 @@
 
 #include "VecSim/vec_sim.h"
 #include "common.hpp"
+#include "grow_buffer.hpp"
 #include "kernels.hpp"
 
 namespace rsgpu {
@@ -128,9 +129,14 @@ class FlatIndex {
   int remove(size_t label);
   void reserve(size_t rows);
   int add_device_rows(const void *dev_rows, size_t n, size_t first_label);
+  // n synthetic rows generated in place (corpus_kernels.hip): row i = Philox(seed; first_index + i)
+  int add_philox_rows(uint64_t seed, uint64_t first_index, size_t n, size_t first_label);
+  // stored rows [row_begin, row_begin+n) as they are in HBM (cosine: normalised), tightly packed, to host memory
+  void read_rows(uint32_t row_begin, size_t n, void *host_out);
 
   size_t size();
   size_t label_count();
+  bool contains(size_t label);  // a vector is stored (committed or staged) under this label
   VecSimIndexBasicInfo basic_info() const;
   size_t memory() const;
 
@@ -184,6 +190,9 @@ class FlatIndex {
   uint64_t uid;
   void *log_ctx;
   std::atomic<int> last_mode{EMPTY_MODE};
+  // bumped whenever a committed row changes place (DeleteVector moves the last row into the hole): per-row state
+  // computed before the bump (a batch iterator's keys) no longer lines up with row -> label
+  std::atomic<uint64_t> layout_epoch{0};
   std::shared_mutex mu;
 
  private:
@@ -191,6 +200,8 @@ class FlatIndex {
   void break_identity();
   void normalize_host(void *blob) const;
   void map_insert(size_t label, uint32_t row);
+  void check_bulk_labels(size_t n, size_t first_label) const;
+  void commit_bulk_rows(size_t n, size_t first_label);  // normalise/shadow/label the n rows written behind n_rows_
   void rows_of(size_t label, std::vector<uint32_t> &out) const;
 
   size_t elem_bytes_, stride_;
@@ -204,6 +215,9 @@ class FlatIndex {
   float s_max_ = 0.0f;          // its host copy, refreshed by the writers
   void shadow_convert(uint32_t row_begin, uint32_t row_end);  // on wstream_
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
+  // rows (and their shadow) grow without copies once they are large: virtual range + mapped chunks (grow_buffer.hpp);
+  // d_rows_ / d_shadow_ cache the buffers' current base addresses
+  GrowBuffer rows_buf_, shadow_buf_;
   uint8_t *d_rows_ = nullptr;
   uint64_t *d_labels_ = nullptr;
   size_t cap_rows_ = 0;
@@ -266,6 +280,7 @@ struct BatchIterator {
   uint32_t returned = 0;
   Bound lower;
   bool scanned = false;
+  uint64_t epoch = 0;          // index->layout_epoch at the scan
   std::unordered_set<uint64_t> seen_labels;  // multi-value: labels already yielded
 };
 

@@ -60,6 +60,8 @@ struct ScanTuning {
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
+  int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
+                           // (no copy, no transient 2x HBM); 0 = hipMalloc + copy on every growth
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();
@@ -74,6 +76,11 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 // Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
                    uint32_t m, const void *query, void *out, hipStream_t s);
+
+// Synthetic corpus rows [row_begin, row_begin+n_rows) written in place: element (i,j) = Philox4x32-10(seed; first_index+i, j)
+// mapped to [-1,1) (corpus_kernels.hip); padding behind dim is zeroed.
+void launch_philox_rows(void *rows, size_t stride, uint32_t dim, int type, uint64_t seed, uint64_t first_index,
+                        uint32_t row_begin, uint32_t n_rows, hipStream_t s);
 
 // In-place L2 normalisation of rows [row_begin,row_end) (cosine indexes, bulk device loads).
 void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, uint32_t row_begin, uint32_t row_end,

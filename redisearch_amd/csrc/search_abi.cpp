@@ -632,6 +632,27 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   f->upload_query(c.c, query, true);
   StageTimer tk(c.c, 4);
   uint64_t base = 0;
+  if (f->multi && !f->identity_labels(nullptr)) {
+    // multi-value index with a real label map: a document's distance is the MINIMUM over its vectors, as
+    // GetDistanceFrom / the ad-hoc gather give it (FlatIndex::gather expands every label to all its rows)
+    const std::vector<uint32_t> &ids = h->host_ids();
+    std::vector<size_t> labels(ids.begin(), ids.end());
+    std::vector<double> d(h->len);
+    f->gather(c.c, labels.data(), h->len, d.data());
+    tk.stop();
+    std::vector<uint32_t> order;
+    order.reserve(h->len);
+    for (uint32_t i = 0; i < h->len; i++)
+      if (!std::isnan(d[i])) order.push_back(i);  // NaN: the doc has no vector (hybrid_reader.c:317-320)
+    const size_t take = std::min<size_t>(k, order.size());
+    std::partial_sort(order.begin(), order.begin() + take, order.end(),
+                      [&](uint32_t a, uint32_t b) { return d[a] != d[b] ? d[a] < d[b] : a < b; });
+    for (size_t i = 0; i < take; i++) {
+      if (doc_ids_out) doc_ids_out[i] = ids[order[i]];
+      if (dist_out) dist_out[i] = d[order[i]];
+    }
+    return (long)take;
+  }
   if (f->identity_labels(&base)) {
     launch_labels_to_rows(h->ids.p, h->len, base, f->committed_rows(), sc.rows.p, c->stream);
   } else {  // general label map lives on the host

@@ -303,10 +303,17 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
   std::shared_lock<std::shared_mutex> g(f->mu);
   HIP_CHECK(hipSetDevice(f->device));
   uint32_t n = std::min<uint32_t>(b.n, f->committed_rows());
-  if (!b.scanned) {
+  // A DeleteVector between two Next() calls moves rows (swap-delete): the keys of the first scan would pair a moved
+  // row's old score with another document's label.  The caller's lock normally excludes that (SURVEY.md 8b
+  // threading contract); if it happened anyway the keys are recomputed for the current layout and the iterator
+  // continues above the same (key,row) bound.
+  if (!b.scanned || b.epoch != f->layout_epoch.load()) {
+    b.n = n;
+    if (b.returned > n) b.returned = n;
     f->upload_query(b.ctx, b.query.data(), true);
     f->scan_all(b.ctx, n);
     b.scanned = true;
+    b.epoch = f->layout_epoch.load();
   }
   std::vector<VecSimQueryResult> res;
   std::vector<Hit> hits;
@@ -467,6 +474,19 @@ int RSGPU_FlatIndex_AddDeviceRows(VecSimIndex *index, const void *dev_rows, size
   return index->flat->add_device_rows(dev_rows, n, first_label);
   ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_AddDeviceRows", -1)
 }
+int RSGPU_FlatIndex_ReadRows(VecSimIndex *index, size_t row_begin, size_t n, void *host_out) {
+  if (!index || (n && !host_out)) return -1;
+  ABI_TRY
+  index->flat->read_rows((uint32_t)row_begin, n, host_out);
+  return 0;
+  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_ReadRows", -1)
+}
+long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t first_index, size_t n, size_t first_label) {
+  if (!index) return -1;
+  ABI_TRY
+  return index->flat->add_philox_rows(seed, first_index, n, first_label);
+  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_AddPhiloxRows", -1)
+}
 int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, float *dev_scores, uint64_t *dev_labels) {
   if (!index || !query || !k) return -1;
   FlatIndex *f = index->flat;
@@ -543,6 +563,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
   else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;
   else if (!strcmp(key, "shadow8")) scan_tuning().shadow8 = value;
+  else if (!strcmp(key, "vmm")) scan_tuning().vmm = value;
   else return -1;
   return 0;
 }

@@ -170,7 +170,20 @@ ABI = {
     "RSGPU_DeviceCount": (_i, []),
     "RSGPU_FlatIndex_Reserve": (_i, [_vp, _sz]),
     "RSGPU_FlatIndex_AddDeviceRows": (_i, [_vp, _vp, _sz, _sz]),
+    "RSGPU_FlatIndex_AddPhiloxRows": (C.c_long, [_vp, C.c_uint64, C.c_uint64, _sz, _sz]),
+    "RSGPU_FlatIndex_ReadRows": (_i, [_vp, _sz, _sz, _vp]),
     "RSGPU_FlatIndex_TopKDevice": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_ShardedIndex_New": (_vp, [C.POINTER(VecSimParams), _i, _vp, _i]),
+    "RSGPU_ShardedIndex_Free": (None, [_vp]),
+    "RSGPU_ShardedIndex_NumShards": (_i, [_vp]),
+    "RSGPU_ShardedIndex_ShardDevice": (_i, [_vp, _i]),
+    "RSGPU_ShardedIndex_Shard": (_vp, [_vp, _i]),
+    "RSGPU_ShardedIndex_IndexSize": (_sz, [_vp]),
+    "RSGPU_ShardedIndex_AddVector": (_i, [_vp, _vp, _sz]),
+    "RSGPU_ShardedIndex_DeleteVector": (_i, [_vp, _sz]),
+    "RSGPU_ShardedIndex_GetDistanceFrom": (_dbl, [_vp, _sz, _vp]),
+    "RSGPU_ShardedIndex_TopKQuery": (_vp, [_vp, _vp, _sz, C.POINTER(VecSimQueryParams), _i]),
+    "RSGPU_ShardedIndex_RangeQuery": (_vp, [_vp, _vp, _dbl, C.POINTER(VecSimQueryParams), _i]),
     "RSGPU_FlatIndex_TopKBatch": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "RSGPU_MergeTopK": (_i, [_i, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "RSGPU_SetProfiling": (None, [_i]),
@@ -302,6 +315,18 @@ class VecSimIndex:
             raise RuntimeError(last_error())
         return r
 
+    def add_philox_rows(self, seed, first_index, n, first_label=1):
+        r = self.lib.RSGPU_FlatIndex_AddPhiloxRows(self.ptr, seed, first_index, n, first_label)
+        if r < 0:
+            raise RuntimeError(last_error())
+        return r
+
+    def read_rows(self, row_begin, n):
+        out = np.zeros((n, self.dim), dtype=TYPE_NP[self.vtype])
+        if self.lib.RSGPU_FlatIndex_ReadRows(self.ptr, row_begin, n, _p(out)) != 0:
+            raise RuntimeError(last_error())
+        return out
+
     # info
     def index_size(self):
         return self.lib.VecSimIndex_IndexSize(self.ptr)
@@ -387,6 +412,78 @@ class VecSimIndex:
         if r < 0:
             raise RuntimeError(last_error())
         return r
+
+
+class _ShardView(VecSimIndex):
+    """Borrowed handle of one shard of a ShardedIndex (never freed on its own)."""
+
+    def __init__(self, parent, ptr):
+        self.lib, self.ptr, self._parent = parent.lib, ptr, parent
+        self.vtype, self.dim, self.metric, self.multi = parent.vtype, parent.dim, parent.metric, parent.multi
+
+    def free(self):
+        self.ptr = None
+
+    __del__ = free
+
+
+class ShardedIndex:
+    """RSGPU_ShardedIndex_*: one FLAT index row-partitioned over several GPUs (or replicas) of this process."""
+
+    def __init__(self, vtype, dim, metric, n_shards, devices=None, replicas=False, multi=False, block_size=1024):
+        self.lib = load()
+        self.vtype, self.dim, self.metric, self.multi = vtype, dim, metric, multi
+        params = flat_params(vtype, dim, metric, multi, 0, block_size)
+        dv = (C.c_int * n_shards)(*devices) if devices is not None else None
+        self.ptr = self.lib.RSGPU_ShardedIndex_New(C.byref(params), n_shards, dv, int(replicas))
+        if not self.ptr:
+            raise RuntimeError("RSGPU_ShardedIndex_New failed: " + last_error())
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.RSGPU_ShardedIndex_Free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+    _q = VecSimIndex._q
+    normalized_query = VecSimIndex.normalized_query
+
+    def num_shards(self):
+        return self.lib.RSGPU_ShardedIndex_NumShards(self.ptr)
+
+    def shard_device(self, i):
+        return self.lib.RSGPU_ShardedIndex_ShardDevice(self.ptr, i)
+
+    def shard(self, i):
+        p = self.lib.RSGPU_ShardedIndex_Shard(self.ptr, i)
+        if not p:
+            raise IndexError(i)
+        return _ShardView(self, p)
+
+    def index_size(self):
+        return self.lib.RSGPU_ShardedIndex_IndexSize(self.ptr)
+
+    def add_vector(self, vec, label):
+        return self.lib.RSGPU_ShardedIndex_AddVector(self.ptr, _p(self._q(vec)), label)
+
+    def delete_vector(self, label):
+        return self.lib.RSGPU_ShardedIndex_DeleteVector(self.ptr, label)
+
+    def get_distance_from_unsafe(self, label, blob):
+        return self.lib.RSGPU_ShardedIndex_GetDistanceFrom(self.ptr, label, _p(blob))
+
+    def topk_query(self, q, k, params=None, order=BY_SCORE):
+        r = self.lib.RSGPU_ShardedIndex_TopKQuery(self.ptr, _p(self._q(q)), k, C.byref(params) if params else None, order)
+        if not r:
+            raise RuntimeError("RSGPU_ShardedIndex_TopKQuery failed: " + last_error())
+        return QueryReply(r)
+
+    def range_query(self, q, radius, params=None, order=BY_ID):
+        r = self.lib.RSGPU_ShardedIndex_RangeQuery(self.ptr, _p(self._q(q)), radius, C.byref(params) if params else None, order)
+        if not r:
+            raise RuntimeError("RSGPU_ShardedIndex_RangeQuery failed: " + last_error())
+        return QueryReply(r)
 
 
 class BatchIterator:

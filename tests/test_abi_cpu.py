@@ -23,8 +23,8 @@ def lib():
 
 def declared_symbols():
     names = set()
-    for h in ("include/VecSim/vec_sim.h", "include/VecSim/query_results.h", "include/rsgpu_ext.h",
-              "include/rsgpu_search.h"):
+    for h in ("include/VecSim/vec_sim.h", "include/VecSim/query_results.h", "include/VecSim/info_iterator.h",
+              "include/VecSim/vec_sim_debug.h", "include/rsgpu_ext.h", "include/rsgpu_search.h"):
         p = os.path.join(ROOT, h)
         if not os.path.exists(p):
             continue

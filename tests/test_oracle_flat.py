@@ -222,3 +222,33 @@ def test_heap_scan_matches_sort():
     q = rng.uniform(-1, 1, 32).astype(np.float32)
     a, b = idx.topk(q, 10), idx.topk(q, 10, heap=True)
     assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_philox4x32_10_random123_known_answers():
+    """The keyed corpus generator is Philox4x32-10; Random123's kat_vectors for it."""
+    import ctypes as C
+
+    def ph(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        O.lib.oracle_philox4x32_10(c, k, o)
+        return list(o)
+    assert ph([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_rows_are_a_pure_function_of_seed_row_column():
+    a = O.philox_rows(11, 0, 64, 37)
+    assert a.dtype == np.float32 and a.min() >= -1.0 and a.max() < 1.0
+    assert np.array_equal(O.philox_rows(11, 10, 5, 37), a[10:15])            # any row can be regenerated alone
+    assert np.array_equal(O.philox_rows(11, 0, 64, 20), a[:, :20])           # columns do not depend on dim
+    assert not np.array_equal(O.philox_rows(12, 0, 64, 37), a)
+    assert np.array_equal(O.philox_rows(11, 2 ** 33, 2, 8), O.philox_rows(11, 2 ** 33, 2, 8, threads=1))
+    assert not np.array_equal(O.philox_rows(11, 2 ** 33, 2, 8), O.philox_rows(11, 0, 2, 8))   # high counter word is used
+    big = O.philox_rows(3, 0, 4096, 256)
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1 / np.sqrt(3)) < 5e-3  # U(-1,1)
+    assert np.array_equal(O.philox_rows(11, 0, 8, 9, O.F16), O.philox_rows(11, 0, 8, 9).astype(np.float16))
+    assert np.array_equal(O.philox_rows(11, 0, 8, 9, O.F64), O.philox_rows(11, 0, 8, 9).astype(np.float64))
+    u8 = O.philox_rows(11, 0, 8, 9, O.U8)
+    assert u8.dtype == np.uint8 and np.array_equal(O.philox_rows(11, 0, 8, 9, O.I8).view(np.uint8), u8)
