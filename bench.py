@@ -2,17 +2,27 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE configs[1] -- 10M x 768 fp32 FLAT, COSINE, top-10, single-query
-stream through the VecSim C ABI (VecSimIndex_TopKQuery -> reply), corpus resident in HBM, synthetic
-U(-1,1) data.  A "step" is one KNN query = one pass over the rank's corpus shard.
-N > 1: the corpus is row-sharded, 10M rows per GPU (weak scaling: 80M rows at N=8, BASELINE
-configs[3]); every query runs on all shards, per-shard top-10 (fp32 score, u64 label) are exchanged
-with an RCCL all-gather over xGMI and merged.  `value` counts 10M-row shard scans per second over all
-ranks (N x the global QPS on the sharded corpus), so that perfect weak scaling reads N x the 1-GPU
-value; the global QPS is in config.
+Workload (config.workload): BASELINE configs[1] -- 10M x 768 fp32 FLAT, COSINE, top-10, single-query stream through
+the VecSim C ABI (VecSimIndex_TopKQuery -> reply), corpus resident in HBM.  A "step" is one KNN query = one pass over
+the corpus.  The corpus is SYNTHETIC and KEYED: element (i, j) = Philox4x32-10(seed; i, j) mapped to
+[-1, 1), generated in place in HBM by RSGPU_FlatIndex_AddPhiloxRows -- any host can regenerate any row, and this file
+does: after the timed loop the rows one timed query returned are regenerated on the host and re-scored in fp64
+(`config.verify`).  tests/test_gpu_fullsize.py checks whole queries of this very corpus against the CPU oracle.
 
-Adds `roofline` (scan kernel, HIP events on its own stream inside the timed region) and
-`cpu_baseline` (the CPU oracle's FLAT scan on a bounded sample, rank 0, N=1 only).
+N > 1 (weak scaling, BASELINE configs[3] at N=8: 80M rows): the corpus is row-sharded, 10M rows per GPU, every query
+runs on all shards and the per-shard top-10 lists are merged by (score, label).
+  * launched by torch.distributed.run (WORLD_SIZE set; how the driver runs it): one rank per GPU, per-shard top-k
+    exchanged with ONE RCCL all-gather over xGMI, merged in C (RSGPU_MergeTopKPacked);
+  * launched as a plain `python bench.py --gpus N` (WORLD_SIZE unset): ONE process drives the N devices through
+    RSGPU_ShardedIndex_* (a worker thread per device, host K-way merge) -- the in-process form a Redis module would use.
+`value` = shard scans per second summed over the GPUs = N x the global QPS on the sharded corpus (at N=1 it is the
+QPS); perfect weak scaling reads N x the 1-GPU value.  The global QPS and p50/p95 latency are in `config`.
+
+The JSON line also carries `roofline` (scan kernel: HIP events on its own stream inside the timed region; kernel name
+reported by the library; PMC traffic from the committed rocprofv3 pass), `cpu_baseline` (the CPU oracle's FLAT scan on
+the host cores -- on the FULL 10M-row corpus when the host has the memory, else on a bounded sample, and it says which)
+and, at N=1, sub-records measured after the headline loop: `config.two_stage_exact_scan_extra`,
+`config.batched_mfma` (BASELINE configs[2]) and `config.hybrid` (BASELINE configs[4]).
 """
 import argparse
 import ctypes as C
@@ -26,7 +36,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak (same guide); never the 2:1-sparsity figure
+SEED = 47
+QUERY_BASE = 1 << 40     # queries are corpus-generator rows far beyond any corpus row
 
 
 def parse():
@@ -41,7 +54,13 @@ def parse():
                     help="cosine = BASELINE configs[1] (default); l2 = the metric configs[3] names for the 8-GPU corpus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
-    ap.add_argument("--no-two-stage-extra", action="store_true", help="skip the extra two-stage measurement (N=1)")
+    ap.add_argument("--cpu-baseline-mode", choices=["auto", "full", "sample"], default="auto")
+    ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-records (two-stage, batched MFMA, hybrid)")
+    ap.add_argument("--no-two-stage-extra", action="store_true")
+    ap.add_argument("--no-batched-extra", action="store_true")
+    ap.add_argument("--no-hybrid-extra", action="store_true")
+    ap.add_argument("--replicas", action="store_true", help="N>1, single process: N full replicas instead of N shards "
+                                                            "(throughput of concurrent callers; reported separately)")
     ap.add_argument("--tuning", action="append", default=[], help="engine knob key=value (A/B experiments only)")
     ap.add_argument("--cpu-config0", action="store_true",
                     help="no GPU: time BASELINE configs[0] (100k x 128 fp32 L2 top-10, single query) on the host cores with "
@@ -49,80 +68,15 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(dim, k, sample_rows, full_rows, budget_s=15.0, metric="cosine"):
-    """The oracle's FLAT scan (scalar max-heap, one thread = how one RediSearch worker runs one FLAT
-    query) timed on a bounded sample of the same workload, scaled linearly in rows to the full size."""
-    import oracle as O
-    import subprocess
-    lib = O.lib
-    native = os.path.join(ROOT, "oracle", "_build", "liboracle_native.so")
-    try:  # prefer a -march=native build made on THIS host
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"],
-                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        nat = C.CDLL(native)
-        for name in ("oflat_new", "oflat_add_bulk", "oflat_topk_heap", "oflat_free"):
-            getattr(nat, name).restype = getattr(lib, name).restype
-            getattr(nat, name).argtypes = getattr(lib, name).argtypes
-        lib = nat
-        flavour = "march=native"
-    except Exception:
-        flavour = "portable(avx512/avx2 clones)"
-    rng = np.random.default_rng(47)
-    data = rng.uniform(-1, 1, (sample_rows, dim)).astype(np.float32)
-    h = lib.oflat_new(O.F32, dim, {"cosine": O.COSINE, "l2": O.L2, "ip": O.IP}[metric], 0, 1024)
-    lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), sample_rows, 1)
-    qs = np.random.default_rng(48).uniform(-1, 1, (64, dim)).astype(np.float32)
-    ids = np.zeros(k, np.uint64)
-    sc = np.zeros(k, np.float64)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        q = qs[n % len(qs)]
-        lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p))
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 2000:
-            break
-    # (b) eight concurrent queries on eight threads (how a WORKERS 8 deployment runs FLAT queries, SURVEY.md 8d);
-    # ctypes releases the GIL inside the C scan
-    import threading
-    counts = [0] * 8
-    stop_at = time.perf_counter() + min(6.0, 0.4 * budget_s)
-
-    def worker(t):
-        ids_t, sc_t = np.zeros(k, np.uint64), np.zeros(k, np.float64)
-        i = t
-        while time.perf_counter() < stop_at:
-            q = qs[i % len(qs)]
-            lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, ids_t.ctypes.data_as(C.c_void_p), sc_t.ctypes.data_as(C.c_void_p))
-            counts[t] += 1
-            i += 8
-
-    t8 = time.perf_counter()
-    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    el8 = time.perf_counter() - t8
-    qps8 = sum(counts) / el8 * sample_rows / full_rows
-    lib.oflat_free(h)
-    qps_sample = n / el
-    return {"value": qps_sample * sample_rows / full_rows, "unit": "queries/s", "cores": 1, "kind": "port",
-            "eight_threads": {"value": qps8, "cores": 8, "note": "8 concurrent queries, same sample, scaled by rows"},
-            "sample": "%d queries over a %d x %d fp32 %s sample in %.1f s (oracle/flat_oracle.c oflat_topk_heap, %s), "
-                      "scaled by rows to %d" % (n, sample_rows, dim, metric, el, flavour, full_rows)}
-
-
-def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
-    """BASELINE configs[0] -- the reference's own CPU-runnable case -- on host cores with the same port the
-    cpu_baseline leg uses (warm-up 3, 1000 queries, p50 / p95 / QPS; SURVEY.md 8d).  No GPU involved."""
-    import platform
+# ---- CPU baseline (oracle; rank 0, N=1 only) -------------------------------------------------------------------------
+def _oracle_lib():
+    """The oracle's scan library: a -march=native build made on THIS host when possible."""
     import subprocess
     import oracle as O
     lib, flavour = O.lib, "portable(avx512/avx2 clones)"
     try:
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
-                              stderr=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         nat = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liboracle_native.so"))
         for name in ("oflat_new", "oflat_add_bulk", "oflat_topk_heap", "oflat_free"):
             getattr(nat, name).restype = getattr(lib, name).restype
@@ -130,8 +84,116 @@ def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
         lib, flavour = nat, "march=native"
     except Exception:
         pass
-    data = np.random.default_rng(47).uniform(-1, 1, (n, dim)).astype(np.float32)
-    qs = np.random.default_rng(48).uniform(-1, 1, (nq, dim)).astype(np.float32)
+    return O, lib, flavour
+
+
+def _mem_available_gb():
+    try:
+        for l in open("/proc/meminfo"):
+            if l.startswith("MemAvailable"):
+                return int(l.split()[1]) / 1e6
+    except Exception:
+        pass
+    return 0.0
+
+
+def _cpus():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(dim, k, rows, sample_rows, metric, mode, gpu_check=None):
+    """The oracle's FLAT scan (scalar K-bounded max-heap over every row, one thread = how one RediSearch worker runs
+    one FLAT query; plus 8 concurrent queries on 8 threads = a WORKERS 8 deployment), on the same keyed corpus.
+    full: all `rows` rows regenerated on the host (warm-up 3, >= 30 queries); sample: `sample_rows` rows,
+    scaled linearly in rows.  gpu_check (query index -> (ids, scores)) lets the full mode double as an oracle check of
+    the timed GPU answers."""
+    import threading
+    O, lib, flavour = _oracle_lib()
+    om = {"cosine": O.COSINE, "l2": O.L2, "ip": O.IP}[metric]
+    need_gb = rows * dim * 4 * 2.2 / 1e9
+    full = mode == "full" or (mode == "auto" and _mem_available_gb() > need_gb + 16 and _cpus() >= 16)
+    n_rows = rows if full else min(sample_rows, rows)
+    t0 = time.perf_counter()
+    if full:  # probe the generator's speed first: a slow host falls back to the sample
+        O.philox_rows(SEED, 0, 100_000, dim)
+        est = (time.perf_counter() - t0) * rows / 100_000
+        if mode == "auto" and est > 90:
+            full, n_rows = False, min(sample_rows, rows)
+    data = O.philox_rows(SEED, 0, n_rows, dim)
+    t_gen = time.perf_counter() - t0
+    h = lib.oflat_new(O.F32, dim, om, 0, 1024)
+    lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), n_rows, 1)
+    del data
+    t_build = time.perf_counter() - t0
+    qs = O.philox_rows(SEED, QUERY_BASE, 64, dim)
+    ids, sc = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+
+    def run(q, i_out=ids, s_out=sc):
+        return lib.oflat_topk_heap(h, q.ctypes.data_as(C.c_void_p), k, i_out.ctypes.data_as(C.c_void_p),
+                                   s_out.ctypes.data_as(C.c_void_p))
+    checked = None
+    if full and gpu_check:
+        checked = {"queries": 0, "ids_identical": True, "max_abs_score_diff": 0.0}
+        for qi, (gi, gs) in gpu_check.items():
+            m = run(qs[qi % 64])
+            checked["queries"] += 1
+            checked["ids_identical"] &= ids[:m].tolist() == list(gi)
+            checked["max_abs_score_diff"] = max(checked["max_abs_score_diff"], float(np.max(np.abs(sc[:m] - np.asarray(gs)))))
+    for i in range(3):
+        run(qs[i])
+    budget = 25.0 if full else 12.0
+    lat = []
+    t1 = time.perf_counter()
+    while True:
+        s = time.perf_counter()
+        run(qs[(3 + len(lat)) % 64])
+        lat.append(time.perf_counter() - s)
+        el = time.perf_counter() - t1
+        if (len(lat) >= 30 and el >= 0.5 * budget) or el >= budget or len(lat) >= 2000:
+            break
+    n1 = len(lat)
+    counts = [0] * 8
+    stop_at = time.perf_counter() + (8.0 if full else 5.0)
+
+    def worker(t):
+        ids_t, sc_t = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+        i = t
+        while time.perf_counter() < stop_at or counts[t] == 0:
+            run(qs[i % 64], ids_t, sc_t)
+            counts[t] += 1
+            i += 8
+    t8 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    el8 = time.perf_counter() - t8
+    lib.oflat_free(h)
+    scale = n_rows / rows
+    out = {"value": n1 / el * scale, "unit": "queries/s", "cores": 1, "kind": "port",
+           "p50_ms": float(np.percentile(lat, 50) * 1e3 / scale),
+           "eight_threads": {"value": sum(counts) / el8 * scale, "cores": 8, "note": "8 concurrent queries on 8 threads"},
+           "host_cpus": _cpus(),
+           "sample": ("FULL corpus: %d queries (after 3 warm-up) over all %d x %d fp32 %s rows regenerated on the host "
+                      "(keyed Philox corpus, %.0f s to generate + load), oracle/flat_oracle.c oflat_topk_heap, %s, 1 thread"
+                      % (n1, rows, dim, metric, t_build, flavour)) if full else
+                     ("%d queries over a %d x %d fp32 %s SAMPLE of the keyed corpus in %.1f s (oracle/flat_oracle.c "
+                      "oflat_topk_heap, %s), scaled by rows to %d (host has %.0f GB free, %d cpus: full mode needs %.0f GB)"
+                      % (n1, n_rows, dim, metric, el, flavour, rows, _mem_available_gb(), _cpus(), need_gb))}
+    if checked is not None:
+        out["gpu_answers_checked_against_oracle_on_full_corpus"] = checked
+    return out
+
+
+def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
+    """BASELINE configs[0] -- the reference's own CPU-runnable case -- on host cores with the same port the
+    cpu_baseline leg uses (warm-up 3, 1000 queries, p50 / p95 / QPS; SURVEY.md 8d).  No GPU involved."""
+    import platform
+    O, lib, flavour = _oracle_lib()
+    data = O.philox_rows(SEED, 0, n, dim)
+    qs = O.philox_rows(SEED, QUERY_BASE, nq, dim)
     h = lib.oflat_new(O.F32, dim, O.L2, 0, 1024)
     lib.oflat_add_bulk(h, data.ctypes.data_as(C.c_void_p), n, 1)
     ids, sc = np.zeros(k, np.uint64), np.zeros(k, np.float64)
@@ -159,89 +221,257 @@ def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
             "host": {"cpu": cpu, "nproc": os.cpu_count(), "machine": platform.machine()}}
 
 
+# ---- N=1 sub-records ---------------------------------------------------------------------------------------------------
+def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
+    """Independent check of timed answers without the oracle's corpus: the rows a query returned are REGENERATED on the
+    host from (seed, label) and re-scored in fp64; the K-th distance must also beat 2048 other regenerated rows."""
+    import oracle as O
+    worst, got = 0.0, {}
+    for qi in which:
+        q = queries[qi].astype(np.float64)
+        ids, sc = index.topk_query(queries[qi], k).results()
+        got[qi] = (ids.tolist(), sc.tolist())
+        rows = np.stack([O.philox_rows(SEED, int(l) - 1, 1, dim)[0] for l in ids]).astype(np.float64)
+        p0 = (12345 + 4096 * qi) % max(total_rows - 2048, 1)
+        probe = O.philox_rows(SEED, p0, min(2048, total_rows), dim).astype(np.float64)
+
+        def dist(x):
+            if metric == "l2":
+                return np.sum((x - q) ** 2, axis=1)
+            dot = x @ q
+            if metric == "cosine":
+                dot = dot / (np.linalg.norm(x, axis=1) * np.linalg.norm(q))
+            return 1.0 - dot
+        d = dist(rows)
+        worst = max(worst, float(np.max(np.abs(d - sc))))
+        assert np.all(np.diff(sc) >= 0), "reply not sorted"
+        others = dist(probe)
+        labels = set(int(l) for l in ids)
+        for j, dj in enumerate(others):
+            lab = p0 + j + 1
+            assert lab in labels or dj >= sc[-1] - 1e-4, ("a regenerated row beats the returned K-th", qi, lab, dj, sc[-1])
+    return worst, got
+
+
+def extra_two_stage(lib, V, index, queries, k, steps, warmup):
+    import torch
+    lib.RSGPU_SetTuning(b"two_stage", 1)
+    try:
+        for i in range(5):
+            index.topk_query(queries[i], k)
+        ids2, sc2 = index.topk_query(queries[7], k).results()
+        lib.RSGPU_SetTuning(b"two_stage", 0)
+        ids1, sc1 = index.topk_query(queries[7], k).results()
+        lib.RSGPU_SetTuning(b"two_stage", 1)
+        same = ids1.tolist() == ids2.tolist() and sc1.tolist() == sc2.tolist()
+        torch.cuda.synchronize()
+        n2 = min(steps, 200)
+        t2 = time.perf_counter()
+        for i in range(n2):
+            q = queries[(warmup + i) % len(queries)]
+            rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
+            lib.VecSimQueryReply_Free(rep)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t2
+        return {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
+                "what": "opt-in: scan of an int8 shadow with per-row scales (7.72 GB) + error-bounded filter + fp32 "
+                        "re-scoring of the survivors; NOT the headline value"}
+    finally:
+        lib.RSGPU_SetTuning(b"two_stage", 0)
+
+
+def extra_batched(lib, V, rows, dim):
+    """BASELINE configs[2]: rows x dim fp16 FLAT IP top-100, 256 queries per corpus pass on the matrix cores."""
+    import oracle as O
+    k, batch, reps = 100, 256, 10
+    idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
+    try:
+        idx.reserve(rows)
+        idx.add_philox_rows(SEED, 0, rows, 1)
+        qs = O.philox_rows(SEED, QUERY_BASE, batch * 4, dim, O.F16).reshape(4, batch, dim)
+        idx.topk_batch(qs[0], k)  # allocations
+        lib.RSGPU_ResetProfile()
+        lib.RSGPU_SetProfiling(1)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            ids, sc, cnt = idx.topk_batch(qs[(i + 1) % 4], k)
+        el = time.perf_counter() - t0
+        lib.RSGPU_SetProfiling(0)
+        launches, ms, _ = V.scan_profile()
+        dev_ms = ms / max(launches, 1)
+        # parity: 4 of the 256 queries against the single-query path of the same index (exact ids up to fp16-sum ties)
+        ok, worst = True, 0.0
+        for i in (0, 85, 170, 255):
+            si, ss = idx.topk_query(qs[reps % 4][i], k).results()
+            ok &= len(set(si.tolist()) & set(ids[i].tolist())) >= k - 2
+            worst = max(worst, float(np.max(np.abs(np.sort(sc[i]) - np.sort(ss)))))
+        flops = 2.0 * batch * dim * rows
+        return {"workload": "%dx%d fp16 FLAT IP top-%d, batch=%d queries per corpus pass (RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
+                "device_ms_per_pass": dev_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": reps * batch / el,
+                "hbm_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac": rows * dim * 2 / dev_ms / 1e6 / HBM_PEAK_GBS,
+                "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
+                "kernel": "gemm_qs_kernel (query-stationary MFMA filter pass) + thresholds + per-query select; HIP events around the whole device pipeline of a pass",
+                "parity": {"ok": bool(ok and worst <= 2e-3), "vs": "single-query path, 4 of 256 queries: top-%d overlap >= %d, |d| <= 2e-3" % (k, k - 2),
+                           "max_abs_dist_diff": worst}}
+    finally:
+        idx.free()
+
+
+def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
+    """BASELINE configs[4]: 2-term intersection over Zipf postings (50M docs) -> FLAT 5M x 768 ad-hoc KNN top-10 + BM25STD."""
+    import oracle as O
+    from redisearch_amd import search as S
+    rng = np.random.default_rng(49)
+    lists = []
+    for r in (2, 4):
+        docs = np.flatnonzero(rng.random(n_docs + 1) < 0.2 / r).astype(np.uint64)
+        docs = docs[docs > 0]
+        freqs = np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32)
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(docs, freqs)
+        lists.append(ii)
+    doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
+    doc_score = np.ones(n_docs + 1, np.float32)
+    avg = float(doc_len[1:].mean())
+    table = S.DocTable(doc_len, doc_score)
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+    try:
+        idx.reserve(n_vec)
+        idx.add_philox_rows(SEED, 0, n_vec, 1)
+        q = O.philox_rows(SEED, QUERY_BASE, 1, dim)[0]
+        g = [S.Postings.from_flat(l.flatten()) for l in lists]
+        idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists]
+        bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists]
+
+        def pipeline():
+            h = S.intersect(g)
+            h.score(table, "BM25STD", idf, bidf, [1.0, 1.0], n_docs, avg, want_scores=False)
+            ti, ts = h.topn(10)
+            ki, kd = h.knn_rerank(idx, q, 10)
+            return h, ti, ts, ki, kd
+        h, ti, ts, ki, kd = pipeline()
+        walls = []
+        for _ in range(8):
+            t0 = time.perf_counter()
+            h2, *_ = pipeline()
+            walls.append((time.perf_counter() - t0) * 1e3)
+            h2.free()
+        # per-stage device times (HIP events; adds a sync per stage, so not the wall figure)
+        lib.RSGPU_SetProfiling(1)
+        h3, *_ = pipeline()
+        prof = S.profile()
+        lib.RSGPU_SetProfiling(0)
+        h3.free()
+        # parity against the CPU oracle on the same inputs
+        t0 = time.perf_counter()
+        oi, of, _ = O.intersect(lists)
+        t_int = (time.perf_counter() - t0) * 1e3
+        sel = oi.astype(np.int64)
+        os_ = O.score_flat("BM25STD", of, doc_len[sel], np.ones(len(sel)), doc_score[sel], idf, bidf, [1.0, 1.0], 1.0, n_docs, avg)
+        gi, gf = h.read()
+        order = np.lexsort((oi, -os_))[:10]
+        ok = gi.tolist() == oi.tolist() and gf.tolist() == of.tolist() and ti.tolist() == oi[order].tolist() and \
+            bool(np.allclose(ts, os_[order], rtol=1e-12, atol=0))
+        adhoc = idx.adhoc_ctx(q)
+        ok &= bool(np.array_equal(adhoc.get_exact_distances(ki), kd))
+        n_cand = int(np.searchsorted(gi, n_vec, side="right"))
+        n_ent = [x.num_entries for x in g]
+        return {"workload": "2-term intersect (Zipf df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD top-10" % (n_docs, n_vec, dim),
+                "wall_ms_per_query": min(walls[1:]), "qps": 1e3 / min(walls[1:]), "postings": n_ent, "hits": len(gi),
+                "candidates_with_vector": n_cand,
+                "stage_device_ms": {k_: prof.get(k_) for k_ in ("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms")},
+                "knn_gather_gbs": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6,
+                "cpu_oracle_intersect_ms": t_int,
+                "parity": {"ok": bool(ok), "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), "
+                                                 "KNN distances equal the per-label ad-hoc seam's"}}
+    finally:
+        idx.free()
+
+
+# ---- main ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
     if a.cpu_config0:
         print(json.dumps(cpu_config0()), flush=True)
         return
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, "launch with --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    env_world = os.environ.get("WORLD_SIZE")
+    ranks_mode = env_world is not None and (int(env_world) > 1 or os.environ.get("RSGPU_BENCH_FORCE_DIST") == "1")
+    world = int(env_world) if ranks_mode else 1
+    if ranks_mode:
+        assert world == a.gpus, "under torch.distributed.run: --nproc-per-node must equal --gpus"
+    inproc = (not ranks_mode) and a.gpus > 1       # plain `python bench.py --gpus N`: one process, N devices
+    n_shards = a.gpus
+    if inproc:
+        assert torch.cuda.device_count() >= a.gpus or os.environ.get("RSGPU_BENCH_OVERSUBSCRIBE") == "1", \
+            "--gpus %d but %d devices visible (RSGPU_BENCH_OVERSUBSCRIBE=1 places several shards per device)" % (a.gpus, torch.cuda.device_count())
+    rank = int(os.environ.get("RANK", "0")) if ranks_mode else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if ranks_mode else 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    # RSGPU_BENCH_FORCE_DIST=1 (test hook): create the RCCL process group and run the real all-gather even with one
-    # rank (under torch.distributed.run --nproc-per-node 1), so the collective code path is exercised on a 1-GPU box
-    force_dist = os.environ.get("RSGPU_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
+    if ranks_mode:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
     from redisearch_amd import vecsim as V
+    import oracle as O   # host-side twin of the corpus generator (queries, verification); never inside the timed loop
     lib = V.load()
     for kv in a.tuning:
         key, val = kv.split("=")
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
     two_stage = any(kv.replace(" ", "") in ("shadow16=1", "shadow8=1") for kv in a.tuning)
-    shadow8 = any(kv.replace(" ", "") == "shadow8=1" for kv in a.tuning)
-    # N=1: the index also carries the int8 shadow of the opt-in two-stage exact scan; it is switched OFF for the
-    # timed headline loop (plain fp32 scan) and measured separately afterwards as an extra config entry
-    extra_two_stage = world == 1 and not two_stage and not a.no_two_stage_extra and a.metric == "cosine"
-    if extra_two_stage:
+    single = a.gpus == 1 and not ranks_mode
+    want_two_stage_extra = single and not two_stage and not a.no_extras and not a.no_two_stage_extra and a.metric == "cosine"
+    if want_two_stage_extra:   # the index also carries the int8 shadow; switched OFF for the timed headline loop
         lib.RSGPU_SetTuning(b"shadow8", 1)
         lib.RSGPU_SetTuning(b"two_stage", 0)
 
-    # ---- corpus: rows_per_gpu x dim fp32 generated in HBM, shard r holds labels r*rows+1 .. (r+1)*rows
     rows, dim, k = a.rows, a.dim, a.k
-    index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, {"cosine": V.VecSimMetric_Cosine, "l2": V.VecSimMetric_L2,
-                                                      "ip": V.VecSimMetric_IP}[a.metric])
-    index.reserve(rows)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(47 + rank)
-    chunk = 1_000_000
-    done = 0
-    while done < rows:
-        m = min(chunk, rows - done)
-        t = torch.rand((m, dim), device=dev, dtype=torch.float32, generator=gen).mul_(2.0).sub_(1.0)
-        torch.cuda.synchronize()
-        index.add_device_rows(t.data_ptr(), m, rank * rows + done + 1)
-        done += m
-        del t
-    torch.cuda.empty_cache()
-    assert index.index_size() == rows
-    queries = np.random.default_rng(48).uniform(-1, 1, (1000, dim)).astype(np.float32)
+    vmetric = {"cosine": V.VecSimMetric_Cosine, "l2": V.VecSimMetric_L2, "ip": V.VecSimMetric_IP}[a.metric]
+    # ---- corpus: global row i (label i+1) = Philox(SEED; i); rank / shard r holds rows [r*rows, (r+1)*rows)
+    if inproc:
+        nd = torch.cuda.device_count()
+        index = V.ShardedIndex(V.VecSimType_FLOAT32, dim, vmetric, n_shards, devices=[i % nd for i in range(n_shards)],
+                               replicas=a.replicas)
+        for s in range(n_shards):
+            sh = index.shard(s)
+            sh.reserve(rows)
+            first = 0 if a.replicas else s * rows
+            sh.add_philox_rows(SEED, first, rows, first + 1)
+        total_rows = rows if a.replicas else rows * n_shards
+        assert index.index_size() == total_rows
+    else:
+        index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, vmetric)
+        index.reserve(rows)
+        index.add_philox_rows(SEED, rank * rows, rows, rank * rows + 1)
+        assert index.index_size() == rows
+        total_rows = rows * world
+    queries = O.philox_rows(SEED, QUERY_BASE, 1000, dim)
 
-    # RSGPU_BENCH_FORCE_SHARDED=1 (test hook): run the sharded code path -- device-side per-shard top-k, packing,
-    # merge -- on a single rank too (the all-gather itself needs >= 2 ranks)
-    force_sharded = os.environ.get("RSGPU_BENCH_FORCE_SHARDED") == "1" or force_dist
-    if world > 1 or force_sharded:
+    if ranks_mode:
         from redisearch_amd.sharded import ShardedTopK
-        loc_s = torch.empty(k, device=dev, dtype=torch.float32)
-        loc_l = torch.empty(k, device=dev, dtype=torch.int64)
-
-        def local_topk(q, kk):
-            index.topk_device(q, kk, loc_s.data_ptr(), loc_l.data_ptr())
-            return loc_s, loc_l
-
-        sharded = ShardedTopK(local_topk, k, dev)
+        sharded = ShardedTopK(index, k, dev)
 
     def one_query(i):
         q = queries[i % len(queries)]
-        if world == 1 and not force_sharded:
+        if ranks_mode:
+            labels, _ = sharded.query(q)   # per-shard top-k -> RCCL all-gather -> merge (C)
+            return len(labels)
+        if inproc:
+            rep = lib.RSGPU_ShardedIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
+        else:
             rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
-            n = lib.VecSimQueryReply_Len(rep)
-            lib.VecSimQueryReply_Free(rep)
-            return n
-        labels, _ = sharded.query(q)   # per-shard top-k -> RCCL all-gather -> merge
-        return len(labels)
+        n = lib.VecSimQueryReply_Len(rep)
+        lib.VecSimQueryReply_Free(rep)
+        return n
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in range(torch.cuda.device_count() if inproc else 1):
+            torch.cuda.synchronize(d if inproc else local_rank)
 
     for i in range(a.warmup):
         assert one_query(i) == k
@@ -258,48 +488,68 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.RSGPU_SetProfiling(0)
     launches, kern_ms, kern_bytes = V.scan_profile()
-    extra = None
-    if extra_two_stage:  # same index, same queries, two-stage exact scan switched on; results must be identical
-      try:
-        lib.RSGPU_SetTuning(b"two_stage", 1)
-        for i in range(5):
-            one_query(i)
-        q = queries[7]
-        rep = index.topk_query(q, k)
-        ids2, sc2 = rep.results()
-        lib.RSGPU_SetTuning(b"two_stage", 0)
-        ids1, sc1 = index.topk_query(q, k).results()
-        lib.RSGPU_SetTuning(b"two_stage", 1)
-        same = ids1.tolist() == ids2.tolist() and sc1.tolist() == sc2.tolist()
-        torch.cuda.synchronize()
-        n2 = min(a.steps, 200)
-        t2 = time.perf_counter()
-        for i in range(n2):
-            one_query(a.warmup + i)
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t2
-        lib.RSGPU_SetTuning(b"two_stage", 0)
-        extra = {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
-                 "what": "opt-in: scan of an int8 shadow with per-row scales (7.72 GB) + error-bounded filter + fp32 "
-                         "re-scoring of the survivors; NOT the headline value"}
-      except Exception as e:  # the extra must never cost the headline line
-        lib.RSGPU_SetTuning(b"two_stage", 0)
-        extra = {"error": repr(e)}
+    kernel_name = V.last_scan_kernel()
 
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- after the timed region: verification and the N=1 sub-records ------------------------------------------------
+    verify, extras, gpu_answers = None, {}, None
     if rank == 0:
+        try:
+            if ranks_mode:
+                verify = {"note": "multi-rank run: answers are checked by tests/test_sharded_cpu.py and the N=1 verification"}
+            else:
+                worst, gpu_answers = verify_answers(index, queries, k, a.metric, dim, total_rows)
+                verify = {"queries": 3, "returned_rows_regenerated_on_host": 3 * k, "max_abs_err_vs_fp64": worst,
+                          "ok": bool(worst <= 1e-4), "kth_beats_regenerated_probe_rows": 3 * 2048}
+        except Exception as e:
+            verify = {"ok": False, "error": repr(e)}
+    if single and rank == 0 and not a.no_extras:
+        if want_two_stage_extra:
+            try:
+                extras["two_stage_exact_scan_extra"] = extra_two_stage(lib, V, index, queries, k, a.steps, a.warmup)
+            except Exception as e:  # an extra must never cost the headline line
+                extras["two_stage_exact_scan_extra"] = {"error": repr(e)}
+    cpu = None
+    if single and rank == 0 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(dim, k, rows, a.cpu_sample_rows, a.metric, a.cpu_baseline_mode, gpu_answers)
+        except Exception as e:  # the baseline leg must never cost the measured line
+            cpu = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+    if single and rank == 0 and not a.no_extras:
+        index.free()
+        lib.RSGPU_SetTuning(b"shadow8", 0)
+        lib.RSGPU_ReleaseWorkspaces()
+        torch.cuda.empty_cache()
+        for name, fn, skip in (("batched_mfma", lambda: extra_batched(lib, V, rows, dim), a.no_batched_extra),
+                               ("hybrid", lambda: extra_hybrid(lib, V), a.no_hybrid_extra)):
+            if skip:
+                continue
+            try:
+                t0 = time.perf_counter()
+                extras[name] = fn()
+                extras[name]["bench_wall_s"] = time.perf_counter() - t0
+            except Exception as e:
+                extras[name] = {"error": repr(e)}
+
+    if rank == 0:
+        n_gpus = a.gpus
         global_qps = a.steps / elapsed
         avg_kernel_s = (kern_ms / 1e3) / max(launches, 1)
         achieved = (kern_bytes / max(launches, 1)) / avg_kernel_s / 1e9 if launches else 0.0
+        scale = 1 if (inproc and a.replicas) else n_gpus
+        par = ("single GPU" if n_gpus == 1 else
+               "%d full replicas in one process, one caller thread (RSGPU_ShardedIndex, replica mode)" % n_gpus if (inproc and a.replicas) else
+               "row-sharded x%d in ONE process: RSGPU_ShardedIndex (worker thread per device, host K-way merge)" % n_gpus if inproc else
+               "row-sharded x%d, one rank per GPU: RCCL all-gather of per-shard top-k + merge in C" % n_gpus)
         out = {
-            "metric": "KNN queries/sec + p50 latency, 10M\u00d7768 fp32 FLAT top-10, 1/2/4/8 GPU",  # BASELINE.json's metric
-            "value": global_qps * world,
-            "unit": "queries/s",
-            "n_gpus": world,
+            "metric": "KNN queries/sec + p50 latency, 10M×768 fp32 FLAT top-10, 1/2/4/8 GPU",  # BASELINE.json's metric
+            "value": global_qps * scale,
+            "unit": "queries/s" if n_gpus == 1 else "shard-scans/s (queries/s x %d shards of %d rows)" % (n_gpus, rows),
+            "n_gpus": n_gpus,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
@@ -307,45 +557,43 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (keyed Philox4x32-10 corpus, seed %d: regenerable row by row)" % SEED,
             "config": {
                 "workload": "%dx%d fp32 FLAT %s top-%d per GPU, single-query stream via VecSimIndex_TopKQuery"
                             % (rows, dim, a.metric.upper(), k),
                 "value_definition": "10M-row shard scans per second summed over the GPUs (= n_gpus x the global QPS on the "
                                     "row-sharded corpus; at n_gpus=1 it IS the QPS); p50/p95 latency below",
                 "rows_per_gpu": rows, "dim": dim, "k": k, "metric": a.metric.upper(),
-                "corpus_rows_total": rows * world,
-                "parallelism": "row-sharded x%d, RCCL all-gather of per-shard top-k + merge" % world if world > 1 else "single GPU",
+                "corpus_rows_total": total_rows,
+                "parallelism": par,
+                "launch": "torch.distributed.run" if ranks_mode else "single process",
                 "global_qps_on_sharded_corpus": global_qps,
                 "p50_ms": float(np.percentile(lat, 50) * 1e3), "p95_ms": float(np.percentile(lat, 95) * 1e3),
+                "verify": verify,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("scan_kernel<i8,IPS,G=16,ITERS=3,U=4> over the int8 shadow (two-stage exact scan)" if two_stage and shadow8
-                           else "scan_kernel<f16,IP,G=32,ITERS=3,U=4> over the fp16 shadow (two-stage exact scan)" if two_stage
-                           else "scan_kernel<f32,%s,G=64,ITERS=3,U=8> (FLAT scan)" % ("L2" if a.metric == "l2" else "IP")), "launches": int(launches),
-                "avg_kernel_ms": avg_kernel_s * 1e3, "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
+                "kernel": kernel_name + (" over the low-precision shadow (two-stage exact scan)" if two_stage else ""),
+                "kernel_source": "RSGPU_GetLastScanKernel (reported by the library at launch)",
+                "launches": int(launches), "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
-        if extra is not None:
-            out["config"]["two_stage_exact_scan_extra"] = extra
-        if two_stage:  # opt-in experiment (--tuning shadow16=1), never the default line
-            out["config"]["two_stage_fp16_shadow"] = ("scan of an fp16 shadow + error-bounded filter + fp32 re-scoring of the "
-                                                      "survivors: results bit-identical to the fp32 scan; roofline bytes = shadow bytes")
-        # HBM traffic of the scan kernel from the committed PMC pass (separate rocprofv3 --pmc runs of
-        # this same command, corrected as MI355X_MICROARCH.md prescribes); bench.py cannot read PMCs itself
-        pmc = os.path.join(ROOT, "profiles", "r01_scan_pmc_hbm_traffic.json")
-        if os.path.exists(pmc):
-            p = json.load(open(pmc))
-            if p.get("rows") == rows and p.get("dim") == dim and not two_stage:
-                out["roofline"]["traffic"] = p["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_scan_pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, KB->B)"
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(dim, k, min(a.cpu_sample_rows, rows), rows, metric=a.metric)
-            except Exception as e:  # the baseline leg must never cost the measured line
-                out["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        out["config"].update(extras)
+        # HBM traffic of the scan kernel: a committed rocprofv3 --pmc pass of this same command (bench.py cannot read
+        # PMCs itself); used only when it was taken for the same shape AND the same kernel instantiation
+        for name in ("r02_scan_pmc_hbm_traffic.json", "r01_scan_pmc_hbm_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc) and not two_stage:
+                p = json.load(open(pmc))
+                same_kernel = p.get("kernel") is None or p.get("kernel", "").split(" grid")[0] == kernel_name.split(" grid")[0]
+                if p.get("rows") == rows and p.get("dim") == dim and same_kernel:
+                    out["roofline"]["traffic"] = p["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB->B)" % name
+                    break
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

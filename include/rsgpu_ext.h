@@ -60,6 +60,11 @@ int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_
 int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
                     double *scores_out, uint64_t *labels_out, void *wait_stream);
 
+/* The same merge over HOST arrays (pure host code; what runs after a collective's result has been brought to the host,
+ * and what the world-size-2 gloo tests exercise on CPU). */
+int RSGPU_MergeTopKHost(const float *scores, const uint64_t *labels, size_t m, size_t k, double *scores_out,
+                        uint64_t *labels_out);
+
 /* ---- one index over several GPUs of one process (sharded_index.cpp) ------------------------------
  * The in-process form of the coordinator's per-shard top-K -> heap merge (reference src/module.c:3541-3547): the corpus
  * is row-partitioned over n_shards FLAT shards, shard i resident on devices[i] (NULL: i mod the visible devices;
@@ -91,6 +96,9 @@ void RSGPU_SetProfiling(int on);
 void RSGPU_ResetProfile(void);
 /* launches, summed kernel milliseconds, algorithmic bytes (rows*dim*sizeof(type)) */
 void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes);
+/* The kernel instantiation the last full FLAT scan of this process launched, e.g.
+ * "scan_kernel<f32,IP,G=64,ITERS=3,U=8,EXACT=1,NT=1> grid=4096x256" (bench.py's roofline.kernel). Returns buf. */
+const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
 /* Engine knobs (A/B experiments and opt-in modes). Returns 0 if the key is known.
  *   "blocks_per_cu", "rows_per_group", "nontemporal"  launch shape of the FLAT scan kernel
  *   "filter_select"  1 (default): K <= 32 uses sample threshold + one filter pass; 0: radix levels only
@@ -100,7 +108,9 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
  *   "shadow16"       0 (default); 1: FLOAT32 cosine indexes created from now on keep an fp16 shadow and answer
  *                    K <= 128 queries with the two-stage exact scan
  *   "shadow8"        same with an int8 shadow + one fp32 scale per row (a quarter of the fp32 bytes; K <= 32)
- *   "two_stage"      1 (default): query-time switch of the above for indexes that carry a shadow */
+ *   "two_stage"      1 (default): query-time switch of the above for indexes that carry a shadow
+ *   "vmm"            1 (default): row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual
+ *                    range (no copy, no transient 2x HBM); 0: hipMalloc + full copy on every growth */
 int RSGPU_SetTuning(const char *key, int value);
 /* frees idle per-query workspaces */
 void RSGPU_ReleaseWorkspaces(void);

@@ -281,6 +281,8 @@ struct BatchIterator {
   Bound lower;
   bool scanned = false;
   uint64_t epoch = 0;          // index->layout_epoch at the scan
+  bool recount = false;        // rows were deleted under the iterator: `returned` no longer says how many rows lie below
+                               // the bound; exhaustion is detected by a selection that comes back short
   std::unordered_set<uint64_t> seen_labels;  // multi-value: labels already yielded
 };
 

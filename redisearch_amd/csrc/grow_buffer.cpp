@@ -31,9 +31,9 @@ static hipMemAllocationProp chunk_prop(int device) {
 void GrowBuffer::release() {
   if (!ptr_) return;
   if (mapped_) {
-    for (size_t i = 0; i < chunks_.size(); i++) {
-      (void)hipMemUnmap(ptr_ + i * chunk_, chunk_);
-      (void)hipMemRelease(chunks_[i]);
+    for (const Chunk &c : chunks_) {
+      (void)hipMemUnmap(ptr_ + c.offset, c.size);
+      (void)hipMemRelease(c.handle);
     }
     (void)hipMemAddressFree(ptr_, va_size_);
     chunks_.clear();
@@ -53,13 +53,13 @@ void GrowBuffer::reserve_va(size_t need) {
   HIP_CHECK(hipMemAddressReserve(&np, want, 0, nullptr, 0));
   uint8_t *nptr = static_cast<uint8_t *>(np);
   if (!chunks_.empty()) {
-    for (size_t i = 0; i < chunks_.size(); i++) HIP_CHECK(hipMemUnmap(ptr_ + i * chunk_, chunk_));
-    for (size_t i = 0; i < chunks_.size(); i++) HIP_CHECK(hipMemMap(nptr + i * chunk_, chunk_, 0, chunks_[i], 0));
+    for (const Chunk &c : chunks_) HIP_CHECK(hipMemUnmap(ptr_ + c.offset, c.size));
+    for (const Chunk &c : chunks_) HIP_CHECK(hipMemMap(nptr + c.offset, c.size, 0, c.handle, 0));
     hipMemAccessDesc acc{};
     acc.location.type = hipMemLocationTypeDevice;
     acc.location.id = device_;
     acc.flags = hipMemAccessFlagsProtReadWrite;
-    HIP_CHECK(hipMemSetAccess(nptr, chunks_.size() * chunk_, &acc, 1));
+    HIP_CHECK(hipMemSetAccess(nptr, cap_, &acc, 1));
   }
   if (ptr_ && va_size_) HIP_CHECK(hipMemAddressFree(ptr_, va_size_));
   ptr_ = nptr;
@@ -72,18 +72,26 @@ void GrowBuffer::map_more(size_t bytes) {
   acc.location.type = hipMemLocationTypeDevice;
   acc.location.id = device_;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  while (chunks_.size() * chunk_ < bytes) {
+  while (cap_ < bytes) {
+    // one physical allocation for the whole step; if the driver cannot find that much in one piece, minimum-size pieces
+    size_t want = round_up(bytes - cap_, chunk_);
     hipMemGenericAllocationHandle_t h;
-    HIP_CHECK(hipMemCreate(&h, chunk_, &prop, 0));  // HBM exhausted: throws, what is mapped stays valid
-    uint8_t *at = ptr_ + chunks_.size() * chunk_;
-    hipError_t e = hipMemMap(at, chunk_, 0, h, 0);
-    if (e == hipSuccess) e = hipMemSetAccess(at, chunk_, &acc, 1);
+    hipError_t e = hipMemCreate(&h, want, &prop, 0);
+    if (e != hipSuccess && want > chunk_) {
+      (void)hipGetLastError();
+      want = chunk_;
+      e = hipMemCreate(&h, want, &prop, 0);
+    }
+    if (e != hipSuccess) throw HipError(e, "hipMemCreate", __FILE__, __LINE__);  // HBM exhausted: what is mapped stays valid
+    uint8_t *at = ptr_ + cap_;
+    e = hipMemMap(at, want, 0, h, 0);
+    if (e == hipSuccess) e = hipMemSetAccess(at, want, &acc, 1);
     if (e != hipSuccess) {
       (void)hipMemRelease(h);
       throw HipError(e, "hipMemMap/hipMemSetAccess", __FILE__, __LINE__);
     }
-    chunks_.push_back(h);
-    cap_ = chunks_.size() * chunk_;
+    chunks_.push_back(Chunk{h, cap_, want});
+    cap_ += want;
   }
 }
 

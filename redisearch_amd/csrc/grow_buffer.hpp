@@ -30,11 +30,13 @@ class GrowBuffer {
 
   uint8_t *ptr() const { return ptr_; }
   size_t capacity() const { return cap_; }    // addressable bytes
-  size_t physical() const { return mapped_ ? chunks_.size() * chunk_ : cap_; }
+  size_t physical() const { return cap_; }
   bool mapped() const { return mapped_; }
 
   static constexpr size_t kVmmThreshold = 256ull << 20;  // buffers below this stay hipMalloc'ed
-  static constexpr size_t kChunk = 256ull << 20;         // physical chunk of a mapped buffer
+  static constexpr size_t kChunk = 256ull << 20;         // smallest physical chunk of a mapped buffer; a growth step maps
+                                                         // ONE chunk of whatever size it needs (a Reserve() of the final
+                                                         // size is a single physical allocation, like hipMalloc)
 
  private:
   void map_more(size_t bytes);
@@ -45,8 +47,12 @@ class GrowBuffer {
   size_t cap_ = 0;
   bool mapped_ = false;
   // mapped mode
-  size_t va_size_ = 0, chunk_ = 0;
-  std::vector<hipMemGenericAllocationHandle_t> chunks_;
+  struct Chunk {
+    hipMemGenericAllocationHandle_t handle;
+    size_t offset, size;
+  };
+  size_t va_size_ = 0, chunk_ = 0;  // chunk_: kChunk rounded to the allocation granularity
+  std::vector<Chunk> chunks_;
 };
 
 // true when the device/driver supports hipMemAddressReserve/hipMemCreate/hipMemMap (probed once per device)

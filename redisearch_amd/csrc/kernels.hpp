@@ -73,6 +73,9 @@ ScanTuning &scan_tuning();
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
                  uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_scale = nullptr);
 
+// name of the kernel instantiation the last full scan of this process launched (template arguments + grid)
+const char *last_scan_kernel_name(char *buf, size_t cap);
+
 // Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
                    uint32_t m, const void *query, void *out, hipStream_t s);

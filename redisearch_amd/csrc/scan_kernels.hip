@@ -25,6 +25,8 @@
 // GEMM path lives in gemm_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdio>
 #include <cstring>
 
 #include "kernels.hpp"
@@ -446,6 +448,9 @@ struct LaunchCtx {
   hipStream_t s;
 };
 
+// what the last full scan (not gather) launched, for bench.py's roofline.kernel (RSGPU_GetLastScanKernel)
+static std::atomic<uint64_t> g_last_scan{0};
+
 template <int TYPE, int METRIC, int G, int ITERS, int U, bool GATHER>
 void launch_one(const LaunchCtx &c) {
   const ScanTuning &t = scan_tuning();
@@ -460,6 +465,9 @@ void launch_one(const LaunchCtx &c) {
   bool nt = TYPE != KT_F32 || t.nontemporal != 0;
   typename Tr<TYPE>::key_t *keys = (typename Tr<TYPE>::key_t *)c.keys;
   typename Tr<TYPE>::out_t *dists = (typename Tr<TYPE>::out_t *)c.dists;
+  if (!GATHER)
+    g_last_scan = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 5) | ((uint64_t)ITERS << 12) | ((uint64_t)U << 16) |
+                  ((uint64_t)exact << 20) | ((uint64_t)nt << 21) | ((uint64_t)grid << 41);
 #define RSGPU_LAUNCH(EX, NTV)                                                                              \
   hipLaunchKernelGGL((scan_kernel<TYPE, METRIC, G, ITERS, U, EX, NTV, GATHER>), dim3(grid), dim3(256), 0, c.s, \
                      c.rows, c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, keys, dists)
@@ -483,6 +491,7 @@ void launch_shape(const LaunchCtx &c) {
     uint32_t need = (n + 3) / 4, cap = (uint32_t)(t.num_cus * t.blocks_per_cu);
     uint32_t grid = need < cap ? need : cap;
     if (!grid) return;
+    if (!GATHER) g_last_scan = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | (1ull << 40) | ((uint64_t)grid << 41);
     hipLaunchKernelGGL((scan_long_kernel<TYPE, METRIC, true, GATHER>), dim3(grid), dim3(256), 0, c.s, c.rows,
                        c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids,
                        (typename Tr<TYPE>::key_t *)c.keys, (typename Tr<TYPE>::out_t *)c.dists);
@@ -695,6 +704,23 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict
 }
 
 }  // namespace
+
+const char *last_scan_kernel_name(char *buf, size_t cap) {
+  static const char *tn[] = {"f32", "f64", "bf16", "f16", "i8", "u8"}, *mn[] = {"L2", "IP", "COS", "IPS"};
+  const uint64_t v = g_last_scan.load();
+  if (!v) {
+    snprintf(buf, cap, "none");
+    return buf;
+  }
+  if ((v >> 40) & 1)
+    snprintf(buf, cap, "scan_long_kernel<%s,%s,NT=1> grid=%ux256", tn[v & 7], mn[(v >> 3) & 3], (unsigned)(v >> 41));
+  else
+    snprintf(buf, cap, "scan_kernel<%s,%s,G=%u,ITERS=%u,U=%u,EXACT=%u,NT=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 3],
+             (unsigned)((v >> 5) & 127), (unsigned)((v >> 12) & 15), (unsigned)((v >> 16) & 15), (unsigned)((v >> 20) & 1),
+             (unsigned)((v >> 21) & 1), (unsigned)(v >> 41));
+  return buf;
+}
+
 
 bool batch_rescore_supported(uint32_t stride16) {
   const Shape sh = pick_shape(stride16);

@@ -308,8 +308,11 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
   // threading contract); if it happened anyway the keys are recomputed for the current layout and the iterator
   // continues above the same (key,row) bound.
   if (!b.scanned || b.epoch != f->layout_epoch.load()) {
+    if (b.scanned) {  // some of the rows already yielded may be gone: count down by short selections from now on
+      b.recount = true;
+      if (n && b.returned >= n) b.returned = n - 1;
+    }
     b.n = n;
-    if (b.returned > n) b.returned = n;
     f->upload_query(b.ctx, b.query.data(), true);
     f->scan_all(b.ctx, n);
     b.scanned = true;
@@ -319,11 +322,12 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
   std::vector<Hit> hits;
   size_t want = n_results;
   while (res.size() < want && b.returned < n) {
-    uint32_t ask = (uint32_t)std::min<size_t>(n - b.returned, want - res.size());
+    uint32_t ask = (uint32_t)std::min<size_t>(b.recount ? n : n - b.returned, want - res.size());
     Bound bound;
     f->select(b.ctx, n, ask, b.lower, hits, &bound);
     if (hits.empty()) { b.returned = n; break; }
-    b.returned += (uint32_t)hits.size();
+    if (b.recount) b.returned = hits.size() < ask ? n : std::min<uint32_t>(b.returned + (uint32_t)hits.size(), n - 1);
+    else b.returned += (uint32_t)hits.size();
     b.lower = bound;
     for (const Hit &h : hits) {
       uint64_t lab = f->label_of_row(h.row);
@@ -350,6 +354,7 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
 void VecSimBatchIterator_Reset(VecSimBatchIterator *iterator) {
   if (!iterator) return;
   iterator->it.returned = 0;
+  iterator->it.recount = false;
   iterator->it.lower = Bound();
   iterator->it.seen_labels.clear();
 }
@@ -514,6 +519,27 @@ int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_
   return 0;
   ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_TopKBatch", -1)
 }
+// the coordinator-style K-way merge of per-shard top-k lists (reference src/module.c:3541-3547): k best of m
+// (score,label) candidates by (score, label) ascending; padding slots carry label == UINT64_MAX.  Pure host code.
+int RSGPU_MergeTopKHost(const float *scores, const uint64_t *labels, size_t m, size_t k, double *scores_out,
+                        uint64_t *labels_out) {
+  if ((m && (!scores || !labels)) || (k && (!scores_out || !labels_out))) return -1;
+  ABI_TRY
+  std::vector<size_t> ord;
+  ord.reserve(m);
+  for (size_t i = 0; i < m; i++)
+    if (labels[i] != UINT64_MAX) ord.push_back(i);
+  size_t kk = std::min(k, ord.size());
+  std::partial_sort(ord.begin(), ord.begin() + (long)kk, ord.end(), [&](size_t a, size_t b) {
+    return scores[a] != scores[b] ? scores[a] < scores[b] : labels[a] < labels[b];
+  });
+  for (size_t i = 0; i < kk; i++) {
+    scores_out[i] = (double)scores[ord[i]];
+    labels_out[i] = labels[ord[i]];
+  }
+  return (int)kk;
+  ABI_CATCH(nullptr, "RSGPU_MergeTopKHost", -1)
+}
 int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_labels, size_t m, size_t k,
                     double *scores_out, uint64_t *labels_out, void *wait_stream) {
   ABI_TRY
@@ -523,20 +549,7 @@ int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_lab
   std::vector<uint64_t> lb(m);
   HIP_CHECK(hipMemcpy(sc.data(), dev_scores, m * sizeof(float), hipMemcpyDeviceToHost));
   HIP_CHECK(hipMemcpy(lb.data(), dev_labels, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  // the coordinator-style K-way merge of per-shard top-k lists (reference src/module.c:3541-3547)
-  std::vector<size_t> ord;
-  ord.reserve(m);
-  for (size_t i = 0; i < m; i++)
-    if (lb[i] != UINT64_MAX) ord.push_back(i);
-  size_t kk = std::min(k, ord.size());
-  std::partial_sort(ord.begin(), ord.begin() + (long)kk, ord.end(), [&](size_t a, size_t b) {
-    return sc[a] != sc[b] ? sc[a] < sc[b] : lb[a] < lb[b];
-  });
-  for (size_t i = 0; i < kk; i++) {
-    scores_out[i] = (double)sc[ord[i]];
-    labels_out[i] = lb[ord[i]];
-  }
-  return (int)kk;
+  return RSGPU_MergeTopKHost(sc.data(), lb.data(), m, k, scores_out, labels_out);
   ABI_CATCH(nullptr, "RSGPU_MergeTopK", -1)
 }
 
@@ -550,6 +563,10 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
   if (launches) *launches = scan_profile().launches.load();
   if (total_ms) *total_ms = (double)scan_profile().nanos.load() / 1e6;
   if (bytes) *bytes = scan_profile().bytes.load();
+}
+const char *RSGPU_GetLastScanKernel(char *buf, size_t cap) {
+  if (!buf || !cap) return "";
+  return last_scan_kernel_name(buf, cap);
 }
 int RSGPU_SetTuning(const char *key, int value) {
   if (!key) return -1;

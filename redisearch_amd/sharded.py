@@ -1,20 +1,41 @@
-"""Row-sharded FLAT KNN across the GPUs of one node: one process per GPU, each rank holds a
-contiguous label range of the corpus; a query runs on every shard and the per-shard top-k
-(fp32 score, u64 label) are exchanged with ONE all-gather of k*(8+8) bytes per rank (RCCL over xGMI on GPUs, gloo in the CPU
-tests) and merged -- the collective analogue of the reference coordinator's per-shard top-K -> heap
-merge (reference src/module.c:3541-3547).  The payload is k*12 bytes per rank, so the
-exchange is latency-bound; nothing is reduced.
+"""Row-sharded FLAT KNN across the GPUs of one node, ONE PROCESS PER GPU (how torch.distributed.run launches bench.py):
+each rank holds a contiguous label range of the corpus; a query runs on every shard and the per-shard top-k
+(fp32 score, u64 label) are exchanged with ONE all-gather of k*(8+8) bytes per rank (RCCL over xGMI on GPUs, gloo in the
+CPU tests) and merged by (score, label) in C (RSGPU_MergeTopKHost) -- the collective analogue of the reference
+coordinator's per-shard top-K -> heap merge (reference src/module.c:3541-3547).  The payload is k*16 bytes
+per rank, so the exchange is latency-bound; nothing is reduced.
+
+(Several GPUs driven by ONE process -- the shape of a Redis module -- need no collective at all: RSGPU_ShardedIndex_* in
+include/rsgpu_ext.h, redisearch_amd/csrc/sharded_index.cpp.)
 """
+import ctypes as C
+
 import numpy as np
 
 UINT64_MAX = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def merge_topk(scores, labels, k):
-    """k best of the gathered candidates by (score, label) ascending; padding slots carry
-    label == UINT64_MAX.  The same order RSGPU_MergeTopK implements in C."""
+    """k best of the gathered candidates by (score, label) ascending; padding slots carry label == UINT64_MAX.
+    Host code stays C: the merge is the library's RSGPU_MergeTopKHost."""
+    from . import vecsim as V
+    lib = V.load()
+    scores = np.ascontiguousarray(np.asarray(scores, dtype=np.float32).ravel())
+    labels = np.asarray(labels).ravel()
+    labels = np.ascontiguousarray(labels.view(np.uint64) if labels.dtype != np.uint64 else labels)
+    out_s, out_l = np.zeros(max(k, 1), np.float64), np.zeros(max(k, 1), np.uint64)
+    m = lib.RSGPU_MergeTopKHost(scores.ctypes.data_as(C.c_void_p), labels.ctypes.data_as(C.c_void_p), scores.size, k,
+                                out_s.ctypes.data_as(C.c_void_p), out_l.ctypes.data_as(C.c_void_p))
+    if m < 0:
+        raise RuntimeError(V.last_error())
+    return out_l[:m], out_s[:m]
+
+
+def merge_topk_numpy(scores, labels, k):
+    """The same order in numpy (cross-check of the C merge in tests)."""
     scores = np.asarray(scores, dtype=np.float64).ravel()
-    labels = np.asarray(labels).ravel().view(np.uint64) if np.asarray(labels).dtype != np.uint64 else np.asarray(labels).ravel()
+    labels = np.asarray(labels).ravel()
+    labels = labels.view(np.uint64) if labels.dtype != np.uint64 else labels
     keep = labels != UINT64_MAX
     scores, labels = scores[keep], labels[keep]
     order = np.lexsort((labels, scores))[:k]
@@ -22,18 +43,28 @@ def merge_topk(scores, labels, k):
 
 
 class ShardedTopK:
-    """local_topk(q, k) -> (scores tensor[k] float32, labels tensor[k] int64) on `device`, padded with
-    +inf / -1 (== UINT64_MAX)."""
+    """`local` is this rank's shard: a redisearch_amd.vecsim.VecSimIndex (GPU) or a callable
+    local_topk(q, k) -> (scores tensor[k] float32, labels tensor[k] int64) padded with +inf / -1 (CPU tests)."""
 
-    def __init__(self, local_topk, k, device, group=None):
+    def __init__(self, local, k, device, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
-        self.local_topk, self.k, self.group = local_topk, k, group
+        self.k, self.group = k, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # one collective per query: labels and the fp32 score bits travel in the same int64 buffer
         self.pack = torch.empty(2 * k, dtype=torch.int64, device=device)
         self.all_p = torch.empty(2 * k * self.world, dtype=torch.int64, device=device)
+        if callable(local):
+            self.local_topk = local
+        else:
+            self._s = torch.empty(k, device=device, dtype=torch.float32)
+            self._l = torch.empty(k, device=device, dtype=torch.int64)
+
+            def local_topk(q, kk):
+                local.topk_device(q, kk, self._s.data_ptr(), self._l.data_ptr())
+                return self._s, self._l
+            self.local_topk = local_topk
 
     def query(self, q):
         s, l = self.local_topk(q, self.k)

@@ -186,9 +186,11 @@ ABI = {
     "RSGPU_ShardedIndex_RangeQuery": (_vp, [_vp, _vp, _dbl, C.POINTER(VecSimQueryParams), _i]),
     "RSGPU_FlatIndex_TopKBatch": (_i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp]),
     "RSGPU_MergeTopK": (_i, [_i, _vp, _vp, _sz, _sz, _vp, _vp, _vp]),
+    "RSGPU_MergeTopKHost": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
     "RSGPU_SetProfiling": (None, [_i]),
     "RSGPU_ResetProfile": (None, []),
     "RSGPU_GetScanProfile": (None, [C.POINTER(C.c_uint64), C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
+    "RSGPU_GetLastScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
     "RSGPU_SetTuning": (_i, [C.c_char_p, _i]),
     "RSGPU_ReleaseWorkspaces": (None, []),
 }
@@ -549,6 +551,11 @@ def set_log_callback(fn):
     cb = LOG_CB(fn) if fn else C.cast(None, LOG_CB)
     load().VecSim_SetLogCallbackFunction(cb)
     return cb
+
+
+def last_scan_kernel():
+    buf = C.create_string_buffer(256)
+    return load().RSGPU_GetLastScanKernel(buf, 256).decode()
 
 
 def scan_profile():

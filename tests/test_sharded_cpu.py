@@ -69,7 +69,16 @@ def test_sharded_topk_matches_single_index(tmp_path, world, rows, k):
 
 
 def test_merge_topk_ties_and_padding():
-    from redisearch_amd.sharded import merge_topk
+    from redisearch_amd.sharded import merge_topk, merge_topk_numpy
+    rng = np.random.default_rng(3)
+    for _ in range(50):                       # the C merge (RSGPU_MergeTopKHost) against the numpy ordering
+        m = int(rng.integers(0, 60))
+        sc = rng.integers(0, 6, m).astype(np.float32)
+        lb = rng.integers(1, 40, m).astype(np.uint64)
+        lb[rng.random(m) < 0.2] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        kk = int(rng.integers(0, 25))
+        a, b = merge_topk(sc, lb, kk), merge_topk_numpy(sc, lb, kk)
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
     s = np.array([0.5, 0.1, np.inf, 0.1, 0.3, np.inf], dtype=np.float32)
     l = np.array([9, 7, -1, 3, 8, -1], dtype=np.int64).view(np.uint64)
     labels, scores = merge_topk(s, l, 3)
