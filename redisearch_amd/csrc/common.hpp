@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 
@@ -70,5 +71,32 @@ T *host_alloc(size_t n) {
 inline void host_free(void *p) {
   if (p) hooks().mem.freeFunction(p);
 }
+
+// std allocator over the installed VecSimMemoryFunctions, counting live bytes into a caller-owned counter: the label
+// maps of an index (hundreds of MB at 10 M labels) are allocated by the module's allocator and show up in FT.INFO
+// memory accounting (SURVEY.md 7.3 "drop-in honesty").
+template <typename T>
+struct HookAlloc {
+  using value_type = T;
+  size_t *live = nullptr;  // bytes currently allocated through this allocator family (guarded by the index lock)
+  HookAlloc() = default;
+  explicit HookAlloc(size_t *counter) : live(counter) {}
+  template <typename U>
+  HookAlloc(const HookAlloc<U> &o) : live(o.live) {}
+  T *allocate(size_t n) {
+    void *p = hooks().mem.allocFunction(n * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    if (live) *live += n * sizeof(T);
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t n) {
+    hooks().mem.freeFunction(p);
+    if (live) *live -= n * sizeof(T);
+  }
+  template <typename U>
+  bool operator==(const HookAlloc<U> &o) const { return live == o.live; }
+  template <typename U>
+  bool operator!=(const HookAlloc<U> &o) const { return live != o.live; }
+};
 
 }  // namespace rsgpu

@@ -310,8 +310,7 @@ FlatIndex::~FlatIndex() {
 
 size_t FlatIndex::memory() const {
   return rows_buf_.physical() + shadow_buf_.physical() + cap_rows_ * ((shadow_ == 2 ? 4 : 0) + sizeof(uint64_t)) +
-         row_label_.capacity() * sizeof(uint64_t) + stage_cap_ * stride_ +
-         (single_map_.size() + multi_map_.size()) * 48;
+         host_bytes_ + stage_cap_ * stride_;
 }
 
 void FlatIndex::grow(size_t min_rows) {
@@ -396,7 +395,7 @@ void FlatIndex::break_identity() {
   size_t total = row_label_.size();
   if (multi) {
     multi_map_.reserve(total);
-    for (size_t r = 0; r < total; r++) multi_map_[row_label_[r]].push_back((uint32_t)r);
+    for (size_t r = 0; r < total; r++) rows_slot(row_label_[r]).push_back((uint32_t)r);
   } else {
     single_map_.reserve(total);
     for (size_t r = 0; r < total; r++) single_map_[row_label_[r]] = (uint32_t)r;
@@ -409,7 +408,7 @@ void FlatIndex::map_insert(size_t label, uint32_t row) {
     if (label == identity_base_ + row) return;
     break_identity();  // row_label_ does not contain `row` yet
   }
-  if (multi) multi_map_[label].push_back(row);
+  if (multi) rows_slot(label).push_back(row);
   else single_map_[label] = row;
 }
 
@@ -421,7 +420,7 @@ void FlatIndex::rows_of(size_t label, std::vector<uint32_t> &out) const {
   }
   if (multi) {
     auto it = multi_map_.find(label);
-    if (it != multi_map_.end()) out = it->second;
+    if (it != multi_map_.end()) out.assign(it->second.begin(), it->second.end());
   } else {
     auto it = single_map_.find(label);
     if (it != single_map_.end()) out.push_back(it->second);
@@ -499,7 +498,7 @@ int FlatIndex::remove(size_t label) {
         HIP_CHECK(hipMemcpyAsync(d_sscale_ + r, d_sscale_ + last, sizeof(float), hipMemcpyDeviceToDevice, wstream_));
       row_label_[r] = moved;
       if (multi) {
-        auto &v = multi_map_[moved];
+        auto &v = rows_slot(moved);
         for (auto &x : v) if (x == last) x = r;
       } else {
         single_map_[moved] = r;
@@ -544,7 +543,7 @@ void FlatIndex::commit_bulk_rows(size_t n, size_t first_label) {
   if (!identity_) {
     // maps exist (an earlier delete / out-of-order add / this very call): every new (label,row) goes in
     if (multi) {
-      for (size_t i = 0; i < n; i++) multi_map_[first_label + i].push_back((uint32_t)(old + i));
+      for (size_t i = 0; i < n; i++) rows_slot(first_label + i).push_back((uint32_t)(old + i));
     } else {
       single_map_.reserve(single_map_.size() + n);
       for (size_t i = 0; i < n; i++) single_map_[first_label + i] = (uint32_t)(old + i);

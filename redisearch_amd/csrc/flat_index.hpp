@@ -227,11 +227,23 @@ class FlatIndex {
   size_t stage_cap_ = 0, stage_n_ = 0;
   hipStream_t wstream_ = nullptr;
   // host maps
-  std::vector<uint64_t> row_label_;  // committed + staged rows
+  // host maps live in memory from the installed VecSimMemoryFunctions and are counted (memory())
+  size_t host_bytes_ = 0;
+  using RowVec = std::vector<uint32_t, HookAlloc<uint32_t>>;
+  using SingleMap = std::unordered_map<uint64_t, uint32_t, std::hash<uint64_t>, std::equal_to<uint64_t>,
+                                       HookAlloc<std::pair<const uint64_t, uint32_t>>>;
+  using MultiMap = std::unordered_map<uint64_t, RowVec, std::hash<uint64_t>, std::equal_to<uint64_t>,
+                                      HookAlloc<std::pair<const uint64_t, RowVec>>>;
+  std::vector<uint64_t, HookAlloc<uint64_t>> row_label_{HookAlloc<uint64_t>(&host_bytes_)};  // committed + staged rows
   bool identity_ = true;             // label == identity_base_ + row for every row, map unused
   uint64_t identity_base_ = 0;
-  std::unordered_map<uint64_t, uint32_t> single_map_;
-  std::unordered_map<uint64_t, std::vector<uint32_t>> multi_map_;
+  SingleMap single_map_{0, std::hash<uint64_t>(), std::equal_to<uint64_t>(), SingleMap::allocator_type(&host_bytes_)};
+  MultiMap multi_map_{0, std::hash<uint64_t>(), std::equal_to<uint64_t>(), MultiMap::allocator_type(&host_bytes_)};
+  RowVec &rows_slot(uint64_t label) {  // multi_map_[label], created with the counting allocator
+    auto it = multi_map_.find(label);
+    if (it == multi_map_.end()) it = multi_map_.emplace(label, RowVec(HookAlloc<uint32_t>(&host_bytes_))).first;
+    return it->second;
+  }
 };
 
 // ---- reply objects (plain C structs behind the opaque ABI types) ----------------------------------

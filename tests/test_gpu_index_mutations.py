@@ -152,3 +152,46 @@ def test_prefer_adhoc_ratio_is_over_labels_not_vectors():
     assert g.prefer_adhoc_search(3000, 10, True) is True       # r = 0.5 <= 0.55
     assert O.prefer_adhoc(12000, 400, 3600, 10, label_count=6000)[0] is False
     assert O.prefer_adhoc(12000, 400, 3000, 10, label_count=6000)[0] is True
+
+
+def test_label_maps_are_allocated_through_the_installed_memory_functions():
+    """VecSim_SetMemoryFunctions (reference src/module-init/module-init.c:147): the label vector and, once identity
+    labelling ends, the label -> row hash map come from the module's allocator and are part of StatsInfo.memory."""
+    import ctypes as C
+    lib = V.load()
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
+    libc.realloc.restype, libc.realloc.argtypes = C.c_void_p, [C.c_void_p, C.c_size_t]
+    libc.free.restype, libc.free.argtypes = None, [C.c_void_p]
+    stats = {"allocs": 0, "bytes": 0, "frees": 0}
+    A, CA, RA, FR = (C.CFUNCTYPE(C.c_void_p, C.c_size_t), C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t),
+                     C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t), C.CFUNCTYPE(None, C.c_void_p))
+
+    def _alloc(n):
+        stats["allocs"] += 1
+        stats["bytes"] += n
+        return libc.malloc(n)
+
+    def _free(p):
+        stats["frees"] += 1
+        libc.free(p)
+    cbs = (A(_alloc), CA(lambda a, b: libc.calloc(a, b)), RA(lambda p, n: libc.realloc(p, n)), FR(_free))
+    plain = V.VecSimMemoryFunctions(*[C.cast(f, C.c_void_p) for f in (libc.malloc, libc.calloc, libc.realloc, libc.free)])
+    lib.VecSim_SetMemoryFunctions(V.VecSimMemoryFunctions(*[C.cast(c, C.c_void_p) for c in cbs]))
+    try:
+        rng = np.random.default_rng(1)
+        g = V.VecSimIndex(F32, 8, L2)
+        x = rng.uniform(-1, 1, (3000, 8)).astype(np.float32)
+        g.add_bulk(x, 1)
+        g.topk_query(x[0], 1)
+        b0, m0 = stats["bytes"], g.stats_info().memory
+        assert b0 >= 3000 * 8                          # the row -> label vector
+        g.delete_vector(17)                            # identity ends: 2 999 hash nodes appear
+        assert stats["allocs"] >= 2999 and stats["bytes"] - b0 >= 2999 * 16
+        assert g.stats_info().memory - m0 >= 2999 * 16
+        f0 = stats["frees"]
+        g.free()
+        assert stats["frees"] - f0 >= 2999
+    finally:
+        lib.VecSim_SetMemoryFunctions(plain)
