@@ -350,18 +350,28 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
             ki, kd = h.knn_rerank(idx, q, 10)
             return h, ti, ts, ki, kd
         h, ti, ts, ki, kd = pipeline()
-        walls = []
-        for _ in range(8):
+        staged = []
+        for _ in range(6):
             t0 = time.perf_counter()
             h2, *_ = pipeline()
-            walls.append((time.perf_counter() - t0) * 1e3)
+            staged.append((time.perf_counter() - t0) * 1e3)
             h2.free()
+
+        def fused():
+            return S.hybrid_query(g, table, "BM25STD", idf, bidf, [1.0, 1.0], n_docs, avg, top_n=10, index=idx, q=q, k=10)
+        r = fused()
+        walls = []
+        for _ in range(12):
+            t0 = time.perf_counter()
+            fused()
+            walls.append((time.perf_counter() - t0) * 1e3)
+        fused_ok = (r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
+                    and r["knn"][0].tolist() == ki.tolist() and r["knn"][1].tolist() == kd.tolist())
         # per-stage device times (HIP events; adds a sync per stage, so not the wall figure)
         lib.RSGPU_SetProfiling(1)
-        h3, *_ = pipeline()
+        fused()
         prof = S.profile()
         lib.RSGPU_SetProfiling(0)
-        h3.free()
         # parity against the CPU oracle on the same inputs
         t0 = time.perf_counter()
         oi, of, _ = O.intersect(lists)
@@ -373,17 +383,21 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
         ok = gi.tolist() == oi.tolist() and gf.tolist() == of.tolist() and ti.tolist() == oi[order].tolist() and \
             bool(np.allclose(ts, os_[order], rtol=1e-12, atol=0))
         adhoc = idx.adhoc_ctx(q)
-        ok &= bool(np.array_equal(adhoc.get_exact_distances(ki), kd))
+        ok &= bool(np.array_equal(adhoc.get_exact_distances(ki), kd)) and fused_ok
         n_cand = int(np.searchsorted(gi, n_vec, side="right"))
         n_ent = [x.num_entries for x in g]
         return {"workload": "2-term intersect (Zipf df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD top-10" % (n_docs, n_vec, dim),
                 "wall_ms_per_query": min(walls[1:]), "qps": 1e3 / min(walls[1:]), "postings": n_ent, "hits": len(gi),
+                "entry_point": "RSGPU_HybridQuery (one call, two stream syncs; score/top-N and KNN branches on two streams)",
+                "wall_ms_stage_by_stage_entry_points": min(staged[1:]),
                 "candidates_with_vector": n_cand,
-                "stage_device_ms": {k_: prof.get(k_) for k_ in ("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms")},
-                "knn_gather_gbs": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6,
+                "stage_device_ms": {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
+                "stage_gbs": {"intersect (4 B per posting of both lists)": sum(n_ent) * 4 / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                              "score (20 B read + 20 B written per hit)": len(gi) * 40 / max(prof.get("score_ms") or 1e-9, 1e-9) / 1e6,
+                              "knn gather (dim*4 B per candidate with a vector)": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6},
                 "cpu_oracle_intersect_ms": t_int,
                 "parity": {"ok": bool(ok), "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), "
-                                                 "KNN distances equal the per-label ad-hoc seam's"}}
+                                                 "KNN distances equal the per-label ad-hoc seam's; fused == stage-by-stage"}}
     finally:
         idx.free()
 

@@ -117,6 +117,29 @@ long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *sco
 long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, size_t k, uint64_t *doc_ids_out,
                           double *dist_out);
 
+/* The whole hybrid query in ONE call (BASELINE configs[4]): intersection of `lists`, then -- both optional, run
+ * concurrently on two streams -- (a) score every hit + the top_n by (score desc, doc id asc), (b) the k nearest hits of
+ * a FLAT index (ad-hoc brute force).  Two stream synchronisations in total, against one per stage (and several inside
+ * the selections) for the stage-by-stage entry points; results are identical to calling
+ * RSGPU_Intersect / _Hits_Score / _Hits_TopN / _Hits_KnnRerank in sequence.  0 on success. */
+typedef struct {
+  RSGPU_Postings *const *lists; /* in: 1..32 intersection children */
+  size_t n_lists;
+  const RSGPU_DocTable *table;  /* in: (a) needs table, score and top_n > 0 */
+  const RSGPU_ScoreArgs *score;
+  size_t top_n;
+  VecSimIndex *index;           /* in: (b) needs index, query and k > 0 */
+  const void *query;
+  size_t k;
+  uint64_t *top_ids;            /* out [top_n] */
+  double *top_scores;           /* out [top_n] */
+  uint64_t *knn_ids;            /* out [k] */
+  double *knn_dists;            /* out [k] */
+  size_t n_hits, n_top, n_knn;  /* out: intersection size, entries written to top_* / knn_* */
+  RSGPU_Hits **hits_out;        /* optional out: the hit list itself (caller frees); NULL = dropped */
+} RSGPU_HybridQueryArgs;
+int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
+
 /* Union of 1..32 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
  * contributes freq 0 (reference rqe_iterators/src/union_flat.rs:223-257,297-320).  Scoring a union hit list
  * follows the reference's Union node: absent children add nothing, the slop divisor counts the matched

@@ -73,8 +73,10 @@ void GrowBuffer::map_more(size_t bytes) {
   acc.location.id = device_;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   while (cap_ < bytes) {
-    // one physical allocation for the whole step; if the driver cannot find that much in one piece, minimum-size pieces
-    size_t want = round_up(bytes - cap_, chunk_);
+    // one physical allocation per step, at most kMaxChunk: this driver maps 1 and 2 GiB handles fine, a 3.75 GiB one
+    // faults on access (scripts/diag/vmm_probe.cpp, ROCm 7.0.2); if even that is not available in one piece,
+    // minimum-size pieces
+    size_t want = std::min<size_t>(round_up(bytes - cap_, chunk_), round_up(kMaxChunk, chunk_));
     hipMemGenericAllocationHandle_t h;
     hipError_t e = hipMemCreate(&h, want, &prop, 0);
     if (e != hipSuccess && want > chunk_) {

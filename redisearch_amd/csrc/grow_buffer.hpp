@@ -34,9 +34,8 @@ class GrowBuffer {
   bool mapped() const { return mapped_; }
 
   static constexpr size_t kVmmThreshold = 256ull << 20;  // buffers below this stay hipMalloc'ed
-  static constexpr size_t kChunk = 256ull << 20;         // smallest physical chunk of a mapped buffer; a growth step maps
-                                                         // ONE chunk of whatever size it needs (a Reserve() of the final
-                                                         // size is a single physical allocation, like hipMalloc)
+  static constexpr size_t kChunk = 256ull << 20;         // smallest physical chunk of a mapped buffer
+  static constexpr size_t kMaxChunk = 1ull << 30;        // largest: a growth step maps ceil(step / 1 GiB) chunks
 
  private:
   void map_more(size_t bytes);

@@ -115,7 +115,7 @@ struct DevBuf {
 struct Scratch {
   int device = -1;
   DevBuf<uint8_t> flags;
-  DevBuf<uint32_t> pos, block_counts, total, rows, keys32;
+  DevBuf<uint32_t> pos, block_counts, total, rows, keys32, skeys32;
   DevBuf<float> dists;
   DevBuf<uint64_t> fuse, maxkey;
 };
@@ -124,6 +124,7 @@ Scratch &scratch(int device) {
   Scratch &s = tls_scratch;
   if (s.device != device) {
     s.flags.reset(); s.pos.reset(); s.block_counts.reset(); s.total.reset(); s.rows.reset(); s.keys32.reset();
+    s.skeys32.reset();
     s.dists.reset();
     s.fuse.reset();
     s.maxkey.reset();
@@ -678,6 +679,249 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
     out++;
   }
   return out;
+  S_CATCH(-1)
+}
+
+
+// ---- the whole hybrid query in one call: one stream per branch, two synchronisations --------------------------------
+// decode (cached) -> intersect ............................ stream A, sync #1 (the hit count decides every later launch)
+//   branch A: score -> 32-bit prefilter -> survivors' 64-bit keys to pinned memory
+//   branch B: labels -> rows -> gather -> keys -> top-k      (runs concurrently on its own stream)
+// sync #2.  The stage-by-stage entry points above remain (each a stream sync of its own: 5 + 3 inside the selects).
+namespace {
+struct FusedEvents {
+  int device = -1;
+  hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void ensure(int dev) {
+    if (device == dev) return;
+    for (auto &x : e) {
+      if (x) (void)hipEventDestroy(x);
+      HIP_CHECK(hipEventCreate(&x));
+    }
+    device = dev;
+  }
+};
+thread_local FusedEvents tls_events;
+constexpr uint32_t kFetchCap = 4096;  // survivors of the score prefilter settled on the host
+}  // namespace
+
+static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t n_lists, QueryCtx *c, Scratch &sc,
+                            uint32_t *total_out) {
+  std::iota(h->order, h->order + n_lists, 0);
+  std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
+  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
+  ListView v;
+  memset(&v, 0, sizeof v);
+  v.n = (int)n_lists;
+  for (size_t s = 0; s < n_lists; s++) {
+    RSGPU_Postings *p = lists[h->order[s]];
+    v.ids[s] = p->ids.p;
+    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
+    v.len[s] = p->n_entries;
+  }
+  const uint32_t n0 = v.len[0];
+  h->cap = std::max<uint32_t>(n0, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc((size_t)h->cap * n_lists);
+  *total_out = 0;
+  if (n0 == 0) return;
+  const uint32_t nb = (n0 + 255) / 256;
+  sc.flags.ensure(n0);
+  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
+  sc.block_counts.ensure(nb);
+  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
+  launch_scan_counts(sc.block_counts.p, nb, total_out, c->stream);  // total_out: pinned host memory
+  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream);
+  HIP_CHECK(hipGetLastError());
+}
+
+static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_ScoreArgs *a, bool *max_norm) {
+  memset(&P, 0, sizeof P);
+  *max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
+  P.scorer = *max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
+  P.n_lists = h->n_lists;
+  P.avg_doc_len = a->avg_doc_len;
+  P.root_weight = a->root_weight;
+  P.min_score = a->min_score;
+  P.inv_tanh = a->tanh_factor ? 1 / (double)a->tanh_factor : 0.0;
+  P.slop = h->n_lists > 1 ? h->n_lists - 1 : 1;
+  P.is_union = h->is_union ? 1 : 0;
+  for (int s = 0; s < h->n_lists; s++) {
+    int o = h->order[s];
+    P.idf[s] = a->idf ? a->idf[o] : 0.0;
+    P.bm25_idf[s] = a->bm25_idf ? a->bm25_idf[o] : 0.0;
+    P.weight[s] = a->weight ? a->weight[o] : 1.0;
+  }
+}
+
+extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
+  if (!a || !a->lists || !a->n_lists || a->n_lists > (size_t)kMaxLists) {
+    last_error() = "RSGPU_HybridQuery: 1..32 lists";
+    return -1;
+  }
+  S_TRY
+  check_lists("RSGPU_HybridQuery", a->lists, a->n_lists);
+  const bool want_score = a->table && a->score && a->top_n;
+  const bool want_knn = a->index && a->query && a->k;
+  const int device = a->lists[0]->device;
+  FlatIndex *f = want_knn ? a->index->flat : nullptr;
+  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridQuery: postings and index live on different devices");
+  if (f && f->key_bytes != 4) throw std::runtime_error("RSGPU_HybridQuery: FLOAT64 indexes are not served by the fused path");
+  a->n_hits = a->n_top = a->n_knn = 0;
+  HIP_CHECK(hipSetDevice(device));
+  if (f) f->flush_if_needed();
+  CtxLease ca(device), cb(device);
+  Scratch &sc = scratch(device);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  FusedEvents &ev = tls_events;
+  if (prof) ev.ensure(device);
+  std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
+  h->device = device;
+  h->n_lists = (int)a->n_lists;
+
+  // ---- intersect (stream A) ----
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
+  uint32_t *h_total = ca->h_counters;  // pinned, device-visible
+  intersect_async(h.get(), a->lists, a->n_lists, ca.c, sc, h_total);
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
+  HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #1
+  const uint32_t len = h_total[0];
+  h->len = len;
+  a->n_hits = len;
+
+  // ---- branch A: score + top-N prefilter (stream A, asynchronous) ----
+  bool prefiltered = false, radix_topn = false;
+  const uint32_t top_n = (uint32_t)std::min<size_t>(a->top_n, len);
+  if (want_score && len) {
+    ScoreParams P;
+    bool max_norm = false;
+    fill_score_params(P, h.get(), a->score, &max_norm);
+    h->scores.ensure(h->cap);
+    h->keys.ensure(h->cap);
+    prefiltered = !max_norm && top_n <= 32 && len >= (1u << 14);
+    if (prefiltered) sc.skeys32.ensure(len + 4);
+    launch_score(P, h->ids.p, h->freqs.p, len, h->cap, a->table->doc_len.p, a->table->doc_score.p, a->table->max_freq.p,
+                 a->table->n, h->scores.p, h->keys.p, ca->stream, prefiltered ? sc.skeys32.p : nullptr);
+    if (max_norm) {
+      sc.maxkey.ensure(1);
+      HIP_CHECK(hipMemsetAsync(sc.maxkey.p, 0, sizeof(uint64_t), ca->stream));
+      launch_score_max_normalize(h->scores.p, h->keys.p, len, sc.maxkey.p, ca->stream);
+    }
+    h->scored = true;
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
+    if (prefiltered) {
+      ca->ensure_out(kFetchCap);
+      ca->ensure_gather(kFetchCap);
+      const uint32_t per = len >= (1u << 16) ? 64 : 16;
+      launch_sample_threshold(sc.skeys32.p, len, per, top_n, ca->d_tau, ca->d_fcnt, ca->stream);
+      launch_filter_keys(sc.skeys32.p, len, ca->d_tau, ca->d_cand, ca->d_fcnt, QueryCtx::kCandCap, ca->stream);
+      ca->h_fcnt[2] = 0;
+      launch_fetch_cand64(ca->d_cand, ca->d_fcnt, kFetchCap, h->keys.p, h->ids.p, ca->h_out_rows, ca->h_out_keys,
+                          ca->h_ids, ca->h_fcnt + 2, ca->stream);
+    } else {
+      radix_topn = true;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
+  }
+
+  // ---- branch B: ad-hoc KNN over the hits (stream B); its select ends with the branch's own synchronisation ----
+  std::vector<Hit> knn_hits;
+  bool knn_on_host_map = false;
+  if (want_knn && len) {
+    std::shared_lock<std::shared_mutex> g(f->mu);
+    uint64_t base = 0;
+    if (f->identity_labels(&base)) {
+      sc.rows.ensure(len);
+      sc.dists.ensure(len);
+      sc.keys32.ensure(len);
+      f->upload_query(cb.c, a->query, true);
+      if (prof) HIP_CHECK(hipEventRecord(ev.e[4], cb->stream));
+      launch_labels_to_rows(h->ids.p, len, base, f->committed_rows(), sc.rows.p, cb->stream);
+      launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, len, cb->d_query,
+                    sc.dists.p, cb->stream);
+      launch_dist_to_keys(sc.dists.p, len, sc.keys32.p, cb->stream);
+      HIP_CHECK(hipGetLastError());
+      select_keys32(cb.c, sc.keys32.p, len, (uint32_t)std::min<size_t>(a->k, len), knn_hits);  // syncs stream B
+      // doc ids of the winners: hit index -> ids[], through pinned memory (one tiny launch, overlapped with branch A)
+      cb->ensure_gather(knn_hits.size() + 1);
+      for (size_t i = 0; i < knn_hits.size(); i++) cb->h_out_rows[i] = knn_hits[i].row;
+      launch_gather_u32(h->ids.p, cb->h_out_rows, (uint32_t)knn_hits.size(), cb->h_ids, cb->stream);
+      if (prof) HIP_CHECK(hipEventRecord(ev.e[5], cb->stream));
+      HIP_CHECK(hipStreamSynchronize(cb->stream));
+    } else {
+      knn_on_host_map = true;  // general label map lives on the host: the staged entry point handles it below
+    }
+  }
+  HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #2 (branch A)
+
+  // ---- results ----
+  if (want_score && len) {
+    std::vector<Hit> top;
+    std::vector<uint32_t> top_doc;
+    if (prefiltered) {
+      const uint32_t n_cand = ca->h_fcnt[2];
+      if (n_cand > kFetchCap || n_cand < top_n) {
+        radix_topn = true;  // too many ties at the threshold for the host to settle: exact radix select on the device
+      } else {
+        std::vector<uint32_t> ord(n_cand);
+        std::iota(ord.begin(), ord.end(), 0u);
+        const uint32_t *rows = ca->h_out_rows;
+        const uint64_t *keys = ca->h_out_keys;
+        std::partial_sort(ord.begin(), ord.begin() + top_n, ord.end(), [&](uint32_t x, uint32_t y) {
+          return keys[x] != keys[y] ? keys[x] < keys[y] : rows[x] < rows[y];
+        });
+        for (uint32_t i = 0; i < top_n; i++) {
+          top.push_back(Hit{rows[ord[i]], keys[ord[i]]});
+          top_doc.push_back(ca->h_ids[ord[i]]);
+        }
+      }
+    }
+    if (radix_topn) {
+      radix_select(ca.c, h->keys.p, 8, len, top_n, Bound(), top, nullptr);
+      ca->ensure_gather(top.size() + 1);
+      for (size_t i = 0; i < top.size(); i++) ca->h_out_rows[i] = top[i].row;
+      launch_gather_u32(h->ids.p, ca->h_out_rows, (uint32_t)top.size(), ca->h_ids, ca->stream);
+      HIP_CHECK(hipStreamSynchronize(ca->stream));
+      top_doc.assign(ca->h_ids, ca->h_ids + top.size());
+    }
+    for (size_t i = 0; i < top.size(); i++) {
+      if (a->top_ids) a->top_ids[i] = top_doc[i];
+      if (a->top_scores) a->top_scores[i] = key2score(top[i].key);
+    }
+    a->n_top = top.size();
+  }
+  if (want_knn && len) {
+    if (knn_on_host_map) {
+      long m = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
+      if (m < 0) return -1;
+      a->n_knn = (size_t)m;
+    } else {
+      size_t out = 0;
+      for (size_t i = 0; i < knn_hits.size(); i++) {
+        const Hit &hit = knn_hits[i];
+        if ((uint32_t)hit.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
+        if (a->knn_ids) a->knn_ids[out] = cb->h_ids[i];
+        if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist((uint32_t)hit.key);
+        out++;
+      }
+      a->n_knn = out;
+    }
+  }
+  if (prof) {
+    float ms = 0;
+    prof_ms[0] = 0;
+    if (hipEventElapsedTime(&ms, ev.e[0], ev.e[1]) == hipSuccess) prof_ms[1] = ms;
+    if (want_score && len) {
+      if (hipEventElapsedTime(&ms, ev.e[1], ev.e[2]) == hipSuccess) prof_ms[2] = ms;
+      if (hipEventElapsedTime(&ms, ev.e[2], ev.e[3]) == hipSuccess) prof_ms[3] = ms;
+    }
+    if (want_knn && len && !knn_on_host_map && hipEventSynchronize(ev.e[5]) == hipSuccess &&
+        hipEventElapsedTime(&ms, ev.e[4], ev.e[5]) == hipSuccess)
+      prof_ms[4] = ms;
+  }
+  if (a->hits_out) *a->hits_out = h.release();
+  return 0;
   S_CATCH(-1)
 }
 

@@ -66,7 +66,14 @@ struct ScoreParams {
 // scores[h] (fp64) and keys[h] = descending-score orderable u64 (for the top-N select)
 void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *freqs, uint32_t len, uint32_t cap,
                   const uint32_t *doc_len, const float *doc_score, const uint32_t *max_freq, uint32_t table_n,
-                  double *scores, uint64_t *keys, hipStream_t s);
+                  double *scores, uint64_t *keys, hipStream_t s, uint32_t *keys32 = nullptr);
+// keys32 (optional): orderable image of (float)(-score), a monotone 4-byte prefilter key for the top-N
+// (row, full key) of the first min(*count, cap) prefilter candidates -> host-visible buffers; out_n[0] = *count
+void launch_fetch_cand64(const void *cand, const uint32_t *count, uint32_t cap, const uint64_t *keys64,
+                         const uint32_t *ids, uint32_t *out_rows, uint64_t *out_keys, uint32_t *out_ids, uint32_t *out_n,
+                         hipStream_t s);
+// out[i] = src[idx[i]], i < n (idx / out may be pinned host memory)
+void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *out, hipStream_t s);
 
 // BM25STD.NORM epilogue: scores[i] /= max(0, max_i scores[i]) unless that maximum is 0; keys rewritten alike.
 // max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream

@@ -20,7 +20,14 @@ class ScoreArgs(C.Structure):
                 ("root_weight", _dbl), ("min_score", _dbl), ("idf", _vp), ("bm25_idf", _vp), ("weight", _vp)]
 
 
+class HybridQueryArgs(C.Structure):
+    _fields_ = [("lists", _vp), ("n_lists", _sz), ("table", _vp), ("score", C.POINTER(ScoreArgs)), ("top_n", _sz),
+                ("index", _vp), ("query", _vp), ("k", _sz), ("top_ids", _vp), ("top_scores", _vp), ("knn_ids", _vp),
+                ("knn_dists", _vp), ("n_hits", _sz), ("n_top", _sz), ("n_knn", _sz), ("hits_out", _vp)]
+
+
 ABI = {
+    "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
     "RSGPU_Postings_NumEntries": (_sz, [_vp]),
@@ -181,6 +188,33 @@ class Hits:
             self.ptr = None
 
     __del__ = free
+
+
+def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,
+                 top_n=0, index=None, q=None, k=0, root_weight=1.0, min_score=0.0, tanh_factor=4):
+    """RSGPU_HybridQuery: intersection -> (score + top_n) || (ad-hoc KNN top-k), two stream syncs in total.
+    Returns dict(n_hits, top=(ids, scores), knn=(ids, dists))."""
+    lib = load()
+    arr = (_vp * len(lists))(*[l.ptr for l in lists])
+    a = HybridQueryArgs()
+    a.lists, a.n_lists = C.cast(arr, _vp), len(lists)
+    keep = []
+    if table is not None and scorer is not None and top_n:
+        idf_, bidf_, w_ = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
+        sa = ScoreArgs(SCORERS[scorer] if scorer in SCORERS else PIPELINE_SCORERS[scorer], num_docs, avg_doc_len, tanh_factor,
+                       root_weight, min_score, _p(idf_).value, _p(bidf_).value, _p(w_).value)
+        keep += [idf_, bidf_, w_, sa]
+        a.table, a.score, a.top_n = table.ptr, C.pointer(sa), top_n
+    ti, ts = np.zeros(max(top_n, 1), np.uint64), np.zeros(max(top_n, 1), np.float64)
+    ki, kd = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64)
+    a.top_ids, a.top_scores, a.knn_ids, a.knn_dists = _p(ti).value, _p(ts).value, _p(ki).value, _p(kd).value
+    if index is not None and q is not None and k:
+        qb = index._q(q)
+        keep.append(qb)
+        a.index, a.query, a.k = index.ptr, _p(qb).value, k
+    if lib.RSGPU_HybridQuery(C.byref(a)) != 0:
+        raise RuntimeError(V.last_error())
+    return dict(n_hits=a.n_hits, top=(ti[:a.n_top], ts[:a.n_top]), knn=(ki[:a.n_knn], kd[:a.n_knn]))
 
 
 def intersect(lists):
