@@ -451,6 +451,46 @@ def intersect(lists, cap=None):
     return ids[:h].copy(), fr[:, :h].copy(), mk[:, :h].copy()
 
 
+_sig("oracle_intersect_ex", _sz, _vp, _sz, _sz, C.c_long, _i, _vp, _vp, _vp, _vp)
+_sig("oracle_within_range", _i, _sz, _vp, _vp, _vp, _vp, C.c_long, _i)
+_sig("oracle_min_offset_delta", _i, _sz, _vp, _vp, _vp, _vp)
+
+
+def intersect_ex(lists, max_slop=None, in_order=False, cap=None):
+    """Intersection with max_slop / in_order (oracle_intersect_ex) -> (ids[H], freqs[N,H], slops[H])."""
+    n = len(lists)
+    cap = cap or max(min(l.unique_docs for l in lists), 1)
+    arr = (_vp * n)(*[l.h for l in lists])
+    ids, fr, sl = np.zeros(cap, np.uint64), np.zeros((n, cap), np.uint32), np.zeros(cap, np.int32)
+    m = lib.oracle_intersect_ex(arr, n, cap, -1 if max_slop is None else int(max_slop), int(in_order), _p(ids), _p(fr),
+                                None, _p(sl))
+    return ids[:m], fr[:, :m], sl[:m]
+
+
+def _prox_args(children):
+    """children: list of (is_agg, [offset byte strings of the leaves])"""
+    first, agg, bufs, lens = [0], [], [], []
+    for is_agg, leaves in children:
+        agg.append(int(is_agg))
+        for b in leaves:
+            bufs.append(np.frombuffer(bytes(b), np.uint8) if len(b) else np.zeros(1, np.uint8))
+            lens.append(len(b))
+        first.append(len(bufs))
+    ptrs = (_vp * max(len(bufs), 1))(*[x.ctypes.data for x in bufs])
+    return (len(children), _p(np.asarray(first, np.uint64)), _p(np.asarray(agg, np.int32)), ptrs,
+            _p(np.asarray(lens + [0], np.uint32))), bufs
+
+
+def within_range(children, max_slop=None, in_order=False):
+    a, keep = _prox_args(children)
+    return bool(lib.oracle_within_range(*a, -1 if max_slop is None else int(max_slop), int(in_order)))
+
+
+def min_offset_delta(children):
+    a, keep = _prox_args(children)
+    return lib.oracle_min_offset_delta(*a)
+
+
 def qint_encode(vals):
     v = np.asarray(vals, dtype=np.uint32)
     out = np.zeros(17, np.uint8)

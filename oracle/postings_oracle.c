@@ -21,6 +21,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 enum {
@@ -272,6 +273,185 @@ size_t oracle_intersect(const OInv **lists, size_t nl, size_t cap, uint64_t *ids
   }
   for (size_t i = 0; i < nl; i++) oreader_free(c[i].r);
   free(c);
+  return hits;
+}
+
+/* ---- proximity: max_slop / in_order (reference src/redisearch_rs/index_result/src/core/proximity.rs:134-298) and the
+ * slop a scorer divides by (reference src/index_result/index_result.c:51-103 IndexResult_MinOffsetDelta), over the
+ * varint-delta offset bytes of the children's current records.  A child is one term (`n_leaves` = 1) or a union /
+ * intersection of terms whose positions are merged in ascending order (proximity.rs OffsetIter::Merge). -------------- */
+#define P_EOF 0xFFFFFFFFu
+typedef struct { const uint8_t *p; size_t len, pos; uint32_t last; } PTerm;
+static uint32_t pterm_next(PTerm *t) {
+  if (t->pos >= t->len) return P_EOF;
+  uint64_t d; size_t k = oracle_varint_decode(t->p + t->pos, t->len - t->pos, &d);
+  if (!k) { t->pos = t->len; return P_EOF; }
+  t->pos += k; t->last += (uint32_t)d;
+  return t->last;
+}
+typedef struct { PTerm *leaf; uint32_t *look; size_t n; int merged; } PChild;
+static void pchild_prime(PChild *c) { if (c->merged) for (size_t i = 0; i < c->n; i++) c->look[i] = pterm_next(&c->leaf[i]); }
+static uint32_t pchild_next(PChild *c) {
+  if (!c->merged) return c->n ? pterm_next(&c->leaf[0]) : P_EOF;
+  size_t best = c->n; uint32_t mv = P_EOF;
+  for (size_t i = 0; i < c->n; i++) if (c->look[i] != P_EOF && c->look[i] < mv) { mv = c->look[i]; best = i; }
+  if (best == c->n) return P_EOF;
+  c->look[best] = pterm_next(&c->leaf[best]);
+  return mv;
+}
+static int prox_in_order(PChild *it, size_t n, uint32_t max_slop) {
+  uint32_t *positions = calloc(n, sizeof *positions);
+  int result = -1;
+  while (result < 0) {
+    int32_t span = 0; int over = 0;
+    for (size_t i = 0; i < n; i++) {
+      uint32_t pos;
+      if (i == 0) { pos = pchild_next(&it[0]); if (pos == P_EOF) { result = 0; break; } }
+      else pos = positions[i];
+      uint32_t last_pos = i == 0 ? 0u : positions[i - 1];
+      while (pos < last_pos) { pos = pchild_next(&it[i]); if (pos == P_EOF) { result = 0; break; } }
+      if (result == 0) break;
+      positions[i] = pos;
+      if (i > 0) {
+        span += (int32_t)pos - (int32_t)last_pos - 1;
+        if (span > 0 && (uint32_t)span > max_slop) { over = 1; break; }
+      }
+    }
+    if (result < 0 && !over) result = 1;
+  }
+  free(positions);
+  return result;
+}
+static int prox_unordered(PChild *it, size_t n, uint32_t max_slop) {
+  uint32_t *positions = calloc(n, sizeof *positions);
+  for (size_t i = 0; i < n; i++) { positions[i] = pchild_next(&it[i]); if (positions[i] == P_EOF) { free(positions); return 0; } }
+  uint32_t max_pos = 0;
+  for (size_t i = 0; i < n; i++) if (positions[i] >= max_pos) max_pos = positions[i];
+  int result = 0;
+  for (;;) {
+    uint32_t min_pos = P_EOF; size_t min_idx = 0;
+    for (size_t i = 0; i < n; i++) if (positions[i] < min_pos) { min_pos = positions[i]; min_idx = i; }
+    if (min_pos != max_pos) {
+      int32_t span = (int32_t)max_pos - (int32_t)min_pos - ((int32_t)n - 1);
+      if (span < 0 || (uint32_t)span <= max_slop) { result = 1; break; }
+    }
+    uint32_t np = pchild_next(&it[min_idx]);
+    if (np == P_EOF) break;
+    positions[min_idx] = np;
+    if (np > max_pos) max_pos = np;
+  }
+  free(positions);
+  return result;
+}
+/* children in aggregate order: child c owns leaves [child_first[c], child_first[c+1]); is_agg[c] != 0 marks a union /
+ * intersection child (it "has offsets" whatever its leaves hold, proximity.rs:72-90).  off/len: the offset bytes of
+ * every leaf's current record (len 0 = none / leaf absent).  max_slop < 0: no slop constraint. */
+int oracle_within_range(size_t n_children, const size_t *child_first, const int *is_agg, const uint8_t *const *off,
+                        const uint32_t *len, long max_slop, int in_order) {
+  if (n_children <= 1) return 1;
+  size_t n_leaves = child_first[n_children];
+  PTerm *leaf = calloc(n_leaves ? n_leaves : 1, sizeof *leaf);
+  uint32_t *look = calloc(n_leaves ? n_leaves : 1, sizeof *look);
+  PChild *it = calloc(n_children, sizeof *it);
+  size_t m = 0;
+  for (size_t c = 0; c < n_children; c++) {
+    size_t a = child_first[c], b = child_first[c + 1];
+    int has = is_agg[c] ? 1 : (b > a && len[a] > 0);
+    if (!has) continue;
+    for (size_t l = a; l < b; l++) { leaf[l].p = off[l]; leaf[l].len = len[l]; }
+    it[m].leaf = leaf + a; it[m].look = look + a; it[m].n = b - a; it[m].merged = is_agg[c] && (b - a) != 1;
+    pchild_prime(&it[m]);
+    m++;
+  }
+  int r = 1;
+  if (m > 1) {
+    uint32_t ms = max_slop < 0 ? 0xFFFFFFFFu : (uint32_t)max_slop;
+    r = in_order ? prox_in_order(it, m, ms) : prox_unordered(it, m, ms);
+  }
+  free(leaf); free(look); free(it);
+  return r;
+}
+int oracle_min_offset_delta(size_t n_children, const size_t *child_first, const int *is_agg, const uint8_t *const *off,
+                            const uint32_t *len) {
+  if (n_children <= 1) return 1;
+  size_t n_leaves = child_first[n_children];
+  int dist = 0; size_t i = 0, num = n_children;
+#define HAS(c) (is_agg[c] ? 1 : (child_first[(c) + 1] > child_first[c] && len[child_first[c]] > 0))
+  while (i < num) {
+    while (i < num && !HAS(i)) i++;
+    if (i == num) break;
+    size_t c1 = i++;
+    while (i < num && !HAS(i)) i++;
+    if (i == num) break;
+    size_t c2 = i;
+    PTerm *leaf = calloc(n_leaves, sizeof *leaf); uint32_t *look = calloc(n_leaves, sizeof *look);
+    PChild v[2]; size_t cs[2] = {c1, c2};
+    for (int k = 0; k < 2; k++) {
+      size_t a = child_first[cs[k]], b = child_first[cs[k] + 1];
+      for (size_t l = a; l < b; l++) { leaf[l].p = off[l]; leaf[l].len = len[l]; leaf[l].pos = 0; leaf[l].last = 0; }
+      v[k].leaf = leaf + a; v[k].look = look + a; v[k].n = b - a; v[k].merged = is_agg[cs[k]] && (b - a) != 1;
+      pchild_prime(&v[k]);
+    }
+    uint32_t p1 = pchild_next(&v[0]), p2 = pchild_next(&v[1]);
+    int cd = (int)(p2 > p1 ? p2 - p1 : p1 - p2);
+    while (cd > 1 && p1 != P_EOF && p2 != P_EOF) {
+      uint32_t a = p2 > p1 ? p2 - p1 : p1 - p2;
+      if (a < (uint32_t)cd) cd = (int)a;
+      if (p2 > p1) p1 = pchild_next(&v[0]); else p2 = pchild_next(&v[1]);
+    }
+    dist += cd * cd;
+    free(leaf); free(look);
+  }
+#undef HAS
+  return dist ? (int)sqrt((double)dist) : (int)(num - 1);
+}
+
+/* Intersection with proximity constraints (Intersection::new_with_slop_order, reference
+ * rqe_iterators/src/intersection.rs:94-119,200-245): in_order keeps the children in the caller's order (they are not
+ * sorted by estimate), a consensus document that is not within range is skipped.  slops_out[hit] (optional) =
+ * IndexResult_MinOffsetDelta of the hit in aggregate (iteration) order. */
+size_t oracle_intersect_ex(const OInv **lists, size_t nl, size_t cap, long max_slop, int in_order, uint64_t *ids,
+                           uint32_t *freqs, uint32_t *masks, int32_t *slops_out) {
+  if (!nl) return 0;
+  Child *c = malloc(nl * sizeof *c);
+  for (size_t i = 0; i < nl; i++) { c[i].r = oreader_new(lists[i]); c[i].orig = i; c[i].cur = 0; }
+  if (!in_order)
+    for (size_t i = 1; i < nl; i++) {
+      Child t = c[i]; size_t j = i;
+      while (j && c[j - 1].r->ii->n_unique > t.r->ii->n_unique) { c[j] = c[j - 1]; j--; }
+      c[j] = t;
+    }
+  const int check = max_slop >= 0 || in_order;
+  size_t *first = malloc((nl + 1) * sizeof *first); int *agg = calloc(nl, sizeof *agg);
+  const uint8_t **off = malloc(nl * sizeof *off); uint32_t *len = malloc(nl * sizeof *len);
+  for (size_t i = 0; i <= nl; i++) first[i] = i;
+  size_t hits = 0; int eof = 0;
+  while (!eof && hits < cap) {
+    if (!oreader_next(c[0].r)) break;
+    uint64_t target = c[0].cur = c[0].r->doc;
+    for (;;) {
+      int agreed = 1;
+      for (size_t i = 0; i < nl; i++) {
+        if (c[i].cur == target) continue;
+        if (!oreader_seek(c[i].r, target)) { eof = 1; agreed = 0; break; }
+        c[i].cur = c[i].r->doc;
+        if (c[i].cur != target) { target = c[i].cur; agreed = 0; break; }
+      }
+      if (eof || agreed) break;
+    }
+    if (eof) break;
+    for (size_t i = 0; i < nl; i++) { off[i] = c[i].r->offs; len[i] = c[i].r->osz; }
+    if (check && !oracle_within_range(nl, first, agg, off, len, max_slop, in_order)) continue;
+    ids[hits] = target;
+    for (size_t i = 0; i < nl; i++) {
+      if (freqs) freqs[c[i].orig * cap + hits] = c[i].r->freq;
+      if (masks) masks[c[i].orig * cap + hits] = c[i].r->mask;
+    }
+    if (slops_out) slops_out[hits] = oracle_min_offset_delta(nl, first, agg, off, len);
+    hits++;
+  }
+  for (size_t i = 0; i < nl; i++) oreader_free(c[i].r);
+  free(c); free(first); free(agg); free(off); free(len);
   return hits;
 }
 
