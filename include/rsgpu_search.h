@@ -24,7 +24,8 @@
  * NewMetricIteratorSortedByScore (headers/iterators_ffi.h:574,480).
  *
  * The posting bytes are uploaded AS-IS in the reference's block format; decoding happens on the
- * device.  Doc ids must be < 2^32 (they are monotonically assigned from 1).
+ * device.  Doc ids must be < 2^32 (they are monotonically assigned from 1).  Term offsets stay where they are -- in
+ * the encoded bytes -- and are read in place by the proximity kernels (max_slop / in_order, the scorers' slop).
  */
 #ifndef RSGPU_SEARCH_H
 #define RSGPU_SEARCH_H
@@ -48,7 +49,13 @@ typedef enum {
   RSGPU_CODEC_OFFSETS_ONLY = 5,   /* qint[delta,offsetsLen] + offsets */
   RSGPU_CODEC_FREQS_OFFSETS = 6,  /* qint[delta,freq,offsetsLen] + offsets */
   RSGPU_CODEC_DOCIDS_ONLY = 7,    /* varint delta */
-  RSGPU_CODEC_RAW_DOCIDS = 8      /* u32 delta from the block's first doc id */
+  RSGPU_CODEC_RAW_DOCIDS = 8,     /* u32 delta from the block's first doc id */
+  /* the *Wide variants for schemas with more than 32 text fields: the field mask (up to 128 bits) is a varint
+   * behind the qint fields (reference codec/full.rs:195, freqs_fields.rs:112, fields_only.rs:107, fields_offsets.rs:137) */
+  RSGPU_CODEC_FULL_WIDE = 9,           /* qint[delta,freq,offsetsLen] + varint mask + offsets */
+  RSGPU_CODEC_FREQS_FIELDS_WIDE = 10,  /* qint[delta,freq] + varint mask */
+  RSGPU_CODEC_FIELDS_ONLY_WIDE = 11,   /* varint delta + varint mask */
+  RSGPU_CODEC_FIELDS_OFFSETS_WIDE = 12 /* qint[delta,offsetsLen] + varint mask + offsets */
 } RSGPU_Codec;
 
 /* scorers registered by DefaultExtensionInit (reference src/ext/default.c:737-) */
@@ -80,10 +87,22 @@ size_t RSGPU_Postings_NumBytes(const RSGPU_Postings *p);
 /* Decode every record on the device; any host output may be NULL. Returns #records or -1. */
 long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *freqs_out, uint32_t *masks_out);
 
+/* Wide codecs: the 128-bit field mask of every record (low / high 64 bits; either may be NULL; masks_out of
+ * RSGPU_Postings_Decode carries the low 32 bits).  Returns #records or -1. */
+long RSGPU_Postings_DecodeWideMasks(RSGPU_Postings *p, uint64_t *masks_lo_out, uint64_t *masks_hi_out);
+
 /* Docs present in ALL lists (decode + intersect on the device). Hits are ascending by doc id and carry
  * the matched frequency of every input list. 1..32 lists (the reference's own tests go to 25 children). NULL on
  * failure. */
 RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists);
+/* The same with the proximity constraints of NewIntersectionIterator(its, num, max_slop, in_order, weight)
+ * (reference headers/iterators_ffi.h:309; Intersection::new_with_slop_order, rqe_iterators/src/intersection.rs:94-119;
+ * the check is RSIndexResult::is_within_range, index_result/src/core/proximity.rs:262-298): a document in all lists
+ * is kept only if the terms' positions (decoded from the lists' offset bytes on the device) fit a window with at most
+ * max_slop foreign tokens -- max_slop < 0: no slop constraint -- and, with in_order, appear in the order of `lists`
+ * (which are then NOT re-ordered by size).  Lists whose codec stores no offsets do not take part in the check.
+ * The hit list borrows the posting lists (slop-aware scoring reads their offset bytes): free the hits first. */
+RSGPU_Hits *RSGPU_IntersectEx(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order);
 void RSGPU_Hits_Free(RSGPU_Hits *h);
 size_t RSGPU_Hits_Len(const RSGPU_Hits *h);
 /* doc_ids[len]; freqs[n_lists][len] in the order the lists were given. Either may be NULL. */

@@ -20,7 +20,10 @@ BY_SCORE, BY_ID = 0, 1
 TYPE_NP = {F32: np.float32, F64: np.float64, F16: np.float16, BF16: np.uint16, I8: np.int8, U8: np.uint8}
 
 (C_FULL, C_FREQS_FIELDS, C_FREQS_ONLY, C_FIELDS_ONLY, C_FIELDS_OFFSETS, C_OFFSETS_ONLY,
- C_FREQS_OFFSETS, C_DOCIDS_ONLY, C_RAW_DOCIDS) = range(9)
+ C_FREQS_OFFSETS, C_DOCIDS_ONLY, C_RAW_DOCIDS, C_FULL_WIDE, C_FREQS_FIELDS_WIDE, C_FIELDS_ONLY_WIDE,
+ C_FIELDS_OFFSETS_WIDE) = range(13)
+WIDE_CODECS = (C_FULL_WIDE, C_FREQS_FIELDS_WIDE, C_FIELDS_ONLY_WIDE, C_FIELDS_OFFSETS_WIDE)
+OFFSET_CODECS = (C_FULL, C_FIELDS_OFFSETS, C_OFFSETS_ONLY, C_FREQS_OFFSETS, C_FULL_WIDE, C_FIELDS_OFFSETS_WIDE)
 
 R_UNION, R_INTERSECTION, R_TERM, R_VIRTUAL, R_NUMERIC, R_METRIC, R_HYBRID = 1, 2, 4, 8, 16, 32, 64
 
@@ -101,6 +104,10 @@ _sig("oracle_varint_decode", _sz, _vp, _sz, C.POINTER(C.c_uint64))
 _sig("oinv_new", _vp, _i)
 _sig("oinv_free", None, _vp)
 _sig("oinv_add", _i, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp, C.c_uint32)
+_sig("oreader_offsets", C.c_uint32, _vp, C.POINTER(C.c_void_p))
+_sig("oracle_decode_offsets", _sz, _vp, _sz, _vp, _sz)
+_sig("oinv_add_wide", _i, _vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _vp, C.c_uint32)
+_sig("oinv_decode_masks128", _sz, _vp, _vp, _vp)
 _sig("oinv_add_many", None, _vp, _vp, _vp, _sz)
 _sig("oinv_num_blocks", _sz, _vp)
 _sig("oinv_unique_docs", C.c_uint32, _vp)
@@ -388,6 +395,17 @@ class InvertedIndex:
         ob = np.frombuffer(bytes(offsets), dtype=np.uint8) if len(offsets) else np.zeros(1, dtype=np.uint8)
         return lib.oinv_add(self.h, doc, freq, mask, _p(ob), len(offsets))
 
+    def add_wide(self, doc, freq=1, mask=1, offsets=b""):
+        """mask: a Python int of up to 128 bits"""
+        ob = np.frombuffer(bytes(offsets), dtype=np.uint8) if len(offsets) else np.zeros(1, dtype=np.uint8)
+        return lib.oinv_add_wide(self.h, doc, freq, mask & 0xFFFFFFFFFFFFFFFF, mask >> 64, _p(ob), len(offsets))
+
+    def decode_masks128(self):
+        n = self.unique_docs
+        lo, hi = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+        m = lib.oinv_decode_masks128(self.h, _p(lo), _p(hi))
+        return [int(a) | (int(b) << 64) for a, b in zip(lo[:m].tolist(), hi[:m].tolist())]
+
     def add_many(self, docs, freqs=None):
         d = np.ascontiguousarray(docs, dtype=np.uint64)
         f = np.ascontiguousarray(freqs, dtype=np.uint32) if freqs is not None else None
@@ -438,6 +456,17 @@ class Reader:
 
     def rewind(self):
         lib.oreader_rewind(self.h)
+
+    def offsets(self):
+        """absolute token positions of the current record"""
+        pp = C.c_void_p()
+        n = lib.oreader_offsets(self.h, C.byref(pp))
+        if not n:
+            return []
+        buf = (C.c_uint8 * n).from_address(pp.value)
+        out = np.zeros(n, np.uint32)
+        m = lib.oracle_decode_offsets(buf, n, _p(out), n)
+        return out[:m].tolist()
 
 
 def intersect(lists, cap=None):

@@ -26,14 +26,20 @@
 
 enum {
   C_FULL = 0, C_FREQS_FIELDS = 1, C_FREQS_ONLY = 2, C_FIELDS_ONLY = 3, C_FIELDS_OFFSETS = 4,
-  C_OFFSETS_ONLY = 5, C_FREQS_OFFSETS = 6, C_DOCIDS_ONLY = 7, C_RAW_DOCIDS = 8, C_NUM = 9
+  C_OFFSETS_ONLY = 5, C_FREQS_OFFSETS = 6, C_DOCIDS_ONLY = 7, C_RAW_DOCIDS = 8,
+  /* wide field masks (u128 as a varint behind the qint fields / the varint delta): reference codec/full.rs:181-213,
+   * freqs_fields.rs:100-140, fields_only.rs:95-130, fields_offsets.rs:125-175 */
+  C_FULL_WIDE = 9, C_FREQS_FIELDS_WIDE = 10, C_FIELDS_ONLY_WIDE = 11, C_FIELDS_OFFSETS_WIDE = 12, C_NUM = 13
 };
-/* qint arity and which slot holds what (-1 = absent). slot 0 is always the delta. */
-typedef struct { int n, freq, mask, osz; uint16_t block_entries; } CodecDesc;
+/* qint arity and which slot holds what (-1 = absent). slot 0 is always the delta. wide: a varint u128 mask follows;
+ * n == 0 with wide: the delta is a varint too (FieldsOnlyWide). */
+typedef struct { int n, freq, mask, osz; uint16_t block_entries; int wide; } CodecDesc;
 static const CodecDesc CODECS[C_NUM] = {
-  {4, 1, 2, 3, 100}, {3, 1, 2, -1, 100}, {2, 1, -1, -1, 100}, {2, -1, 1, -1, 100}, {3, -1, 1, 2, 100},
-  {2, -1, -1, 1, 100}, {3, 1, -1, 2, 100}, {0, -1, -1, -1, 1000}, {0, -1, -1, -1, 1000},
+  {4, 1, 2, 3, 100, 0}, {3, 1, 2, -1, 100, 0}, {2, 1, -1, -1, 100, 0}, {2, -1, 1, -1, 100, 0}, {3, -1, 1, 2, 100, 0},
+  {2, -1, -1, 1, 100, 0}, {3, 1, -1, 2, 100, 0}, {0, -1, -1, -1, 1000, 0}, {0, -1, -1, -1, 1000, 0},
+  {3, 1, -1, 2, 100, 1}, {2, 1, -1, -1, 100, 1}, {0, -1, -1, -1, 100, 1}, {2, -1, -1, 1, 100, 1},
 };
+typedef unsigned __int128 u128;
 
 /* ---- qint ---------------------------------------------------------------------------------------- */
 /* Encodes n (2..4) u32 values; returns bytes written. Header byte: 2 bits per value = len-1. */
@@ -79,6 +85,24 @@ size_t oracle_varint_decode(const uint8_t *in, size_t avail, uint64_t *v) {
   *v = val; return pos;
 }
 
+size_t oracle_varint128_encode(uint8_t *out, uint64_t lo, uint64_t hi) {
+  u128 v = ((u128)hi << 64) | lo;
+  uint8_t buf[24]; int pos = 23;
+  buf[pos] = (uint8_t)(v & 0x7f); v >>= 7;
+  while (v) { v--; buf[--pos] = (uint8_t)(0x80 | (uint8_t)(v & 0x7f)); v >>= 7; }
+  memcpy(out, buf + pos, (size_t)(24 - pos));
+  return (size_t)(24 - pos);
+}
+size_t oracle_varint128_decode(const uint8_t *in, size_t avail, uint64_t *lo, uint64_t *hi) {
+  if (!avail) return 0;
+  size_t pos = 0; uint8_t c = in[pos++]; u128 val = c & 0x7f;
+  while (c & 0x80) {
+    if (pos >= avail) return 0;
+    val++; c = in[pos++]; val = (val << 7) | (c & 0x7f);
+  }
+  *lo = (uint64_t)val; *hi = (uint64_t)(val >> 64); return pos;
+}
+
 /* ---- inverted index ------------------------------------------------------------------------------ */
 typedef struct { uint64_t first, last; uint16_t n; uint8_t *buf; size_t len, cap; } OBlock;
 typedef struct { int codec; OBlock *b; size_t nb, capb; uint32_t n_unique; } OInv;
@@ -100,24 +124,34 @@ static OBlock *new_block(OInv *ii, uint64_t doc) {
 }
 /* add_entry: same-doc duplicates are skipped; a full block or a >u32 delta opens a new block whose
  * first entry has delta 0. Returns 1 if a record was written. */
+int oinv_add_wide(OInv *ii, uint64_t doc, uint32_t freq, uint64_t mask_lo, uint64_t mask_hi, const uint8_t *offs, uint32_t osz);
 int oinv_add(OInv *ii, uint64_t doc, uint32_t freq, uint32_t mask, const uint8_t *offs, uint32_t osz) {
+  return oinv_add_wide(ii, doc, freq, mask, 0, offs, osz);
+}
+int oinv_add_wide(OInv *ii, uint64_t doc, uint32_t freq, uint64_t mask_lo, uint64_t mask_hi, const uint8_t *offs, uint32_t osz) {
   const CodecDesc *cd = &CODECS[ii->codec];
+  const uint32_t mask = (uint32_t)mask_lo;
   if (ii->nb && ii->b[ii->nb - 1].last == doc && ii->b[ii->nb - 1].n) return 0;
   OBlock *bl = (ii->nb && ii->b[ii->nb - 1].n < cd->block_entries) ? &ii->b[ii->nb - 1] : new_block(ii, doc);
   uint64_t base = (ii->codec == C_RAW_DOCIDS) ? bl->first : bl->last;
   uint64_t delta = doc - base;
   if (delta > 0xFFFFFFFFull) { bl = new_block(ii, doc); delta = 0; }
-  size_t need = bl->len + 32 + (cd->osz >= 0 ? osz : 0);
+  size_t need = bl->len + 64 + (cd->osz >= 0 ? osz : 0);
   if (need > bl->cap) { bl->cap = need * 2; bl->buf = realloc(bl->buf, bl->cap); }
   uint8_t *w = bl->buf + bl->len;
   if (ii->codec == C_DOCIDS_ONLY) bl->len += oracle_varint_encode(w, delta);
   else if (ii->codec == C_RAW_DOCIDS) { uint32_t d = (uint32_t)delta; memcpy(w, &d, 4); bl->len += 4; }
-  else {
+  else if (ii->codec == C_FIELDS_ONLY_WIDE) {
+    size_t k = oracle_varint_encode(w, delta);
+    k += oracle_varint128_encode(w + k, mask_lo, mask_hi);
+    bl->len += k;
+  } else {
     uint32_t v[4]; v[0] = (uint32_t)delta;
     if (cd->freq >= 0) v[cd->freq] = freq;
     if (cd->mask >= 0) v[cd->mask] = mask;
     if (cd->osz >= 0) v[cd->osz] = osz;
     size_t k = oracle_qint_encode(w, v, cd->n);
+    if (cd->wide) k += oracle_varint128_encode(w + k, mask_lo, mask_hi);
     if (cd->osz >= 0 && osz) { memcpy(w + k, offs, osz); k += osz; }
     bl->len += k;
   }
@@ -145,6 +179,7 @@ typedef struct {
   const OInv *ii; size_t blk; size_t pos; uint64_t last_doc;
   /* current record */
   uint64_t doc; uint32_t freq, mask; const uint8_t *offs; uint32_t osz;
+  uint64_t mask_lo, mask_hi;
   int eof;
 } OReader;
 
@@ -161,7 +196,12 @@ void oreader_rewind(OReader *r) { r->eof = 0; r->doc = 0; if (r->ii->nb) set_blo
 static int decode_one(OReader *r, uint64_t base) {
   const OBlock *bl = &r->ii->b[r->blk]; const CodecDesc *cd = &CODECS[r->ii->codec];
   const uint8_t *p = bl->buf + r->pos; size_t avail = bl->len - r->pos;
-  r->freq = 0; r->mask = 0; r->offs = NULL; r->osz = 0;
+  r->freq = 0; r->mask = 0; r->offs = NULL; r->osz = 0; r->mask_lo = r->mask_hi = 0;
+  if (r->ii->codec == C_FIELDS_ONLY_WIDE) {
+    uint64_t d; size_t k = oracle_varint_decode(p, avail, &d); if (!k) return 0;
+    size_t k2 = oracle_varint128_decode(p + k, avail - k, &r->mask_lo, &r->mask_hi); if (!k2) return 0;
+    r->doc = base + (uint32_t)d; r->mask = (uint32_t)r->mask_lo; r->pos += k + k2; return 1;
+  }
   if (r->ii->codec == C_DOCIDS_ONLY) {
     uint64_t d; size_t k = oracle_varint_decode(p, avail, &d); if (!k) return 0;
     r->doc = base + (uint32_t)d; r->pos += k; return 1;
@@ -172,10 +212,14 @@ static int decode_one(OReader *r, uint64_t base) {
   }
   uint32_t v[4]; size_t k = oracle_qint_decode(p, avail, v, cd->n); if (!k) return 0;
   uint32_t osz = cd->osz >= 0 ? v[cd->osz] : 0;
+  if (cd->wide) {
+    size_t k2 = oracle_varint128_decode(p + k, avail - k, &r->mask_lo, &r->mask_hi); if (!k2) return 0;
+    k += k2; r->mask = (uint32_t)r->mask_lo;
+  }
   if (k + osz > avail) return 0;
   r->doc = base + v[0];
   if (cd->freq >= 0) r->freq = v[cd->freq];
-  if (cd->mask >= 0) r->mask = v[cd->mask];
+  if (cd->mask >= 0) { r->mask = v[cd->mask]; r->mask_lo = r->mask; }
   if (cd->osz >= 0) { r->offs = p + k; r->osz = osz; }
   r->pos += k + osz;
   return 1;
@@ -220,6 +264,9 @@ int oreader_seek(OReader *r, uint64_t target) {
 uint64_t oreader_doc(const OReader *r) { return r->doc; }
 uint32_t oreader_freq(const OReader *r) { return r->freq; }
 uint32_t oreader_mask(const OReader *r) { return r->mask; }
+void oreader_mask128(const OReader *r, uint64_t *lo, uint64_t *hi) { *lo = r->mask_lo; *hi = r->mask_hi; }
+/* all records' 128-bit masks (wide codecs) */
+size_t oinv_decode_masks128(const OInv *ii, uint64_t *lo, uint64_t *hi);
 uint32_t oreader_offsets(const OReader *r, const uint8_t **p) { *p = r->offs; return r->osz; }
 
 /* decode everything (ids/freqs/masks may be NULL); returns the number of records */
@@ -229,6 +276,13 @@ size_t oinv_decode_all(const OInv *ii, uint64_t *ids, uint32_t *freqs, uint32_t 
     if (ids) ids[n] = r->doc; if (freqs) freqs[n] = r->freq; if (masks) masks[n] = r->mask;
     n++;
   }
+  oreader_free(r);
+  return n;
+}
+
+size_t oinv_decode_masks128(const OInv *ii, uint64_t *lo, uint64_t *hi) {
+  OReader *r = oreader_new(ii); size_t n = 0;
+  while (oreader_next(r)) { lo[n] = r->mask_lo; hi[n] = r->mask_hi; n++; }
   oreader_free(r);
   return n;
 }

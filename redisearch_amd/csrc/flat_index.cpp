@@ -325,6 +325,8 @@ void FlatIndex::grow(size_t min_rows) {
   size_t new_cap = round_up(std::max(min_rows, next), 64);
   const bool rows_mapped = rows_buf_.mapped() || (mode == 1 && need_row_bytes >= GrowBuffer::kVmmThreshold && vmm_supported(device));
   const size_t row_target = rows_mapped ? min_rows : new_cap;
+  rows_buf_.reserve_factor = shadow_buf_.reserve_factor = scan_tuning().vmm_reserve_factor;
+  rows_buf_.chunk_override = shadow_buf_.chunk_override = (size_t)scan_tuning().vmm_chunk_mib << 20;
   rows_buf_.ensure(device, (row_target + 32) * stride_, (size_t)n_rows_ * stride_, wstream_, mode);
   d_rows_ = rows_buf_.ptr();
   if (shadow_) {

@@ -62,6 +62,8 @@ struct ScanTuning {
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
                            // (no copy, no transient 2x HBM); 0 = hipMalloc + copy on every growth
+  int vmm_chunk_mib = 0;        // 0 = automatic (256 MiB, or 1 GiB for corpora reserved large); A/B knob
+  int vmm_reserve_factor = 64;  // virtual range of a mapped row matrix = factor x its size at mapping time (>= 64 GiB)
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();

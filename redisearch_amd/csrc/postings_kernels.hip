@@ -22,10 +22,13 @@
 namespace rsgpu {
 
 CodecDesc codec_desc(int codec) {
-  static const CodecDesc T[9] = {
-      {0, 4, 1, 2, 3},  {0, 3, 1, 2, -1}, {0, 2, 1, -1, -1}, {0, 2, -1, 1, -1}, {0, 3, -1, 1, 2},
-      {0, 2, -1, -1, 1}, {0, 3, 1, -1, 2}, {1, 0, -1, -1, -1}, {2, 0, -1, -1, -1}};
-  if (codec < 0 || codec > 8) return CodecDesc{-1, 0, -1, -1, -1};
+  static const CodecDesc T[13] = {
+      {0, 4, 1, 2, 3, 0},  {0, 3, 1, 2, -1, 0}, {0, 2, 1, -1, -1, 0}, {0, 2, -1, 1, -1, 0}, {0, 3, -1, 1, 2, 0},
+      {0, 2, -1, -1, 1, 0}, {0, 3, 1, -1, 2, 0}, {1, 0, -1, -1, -1, 0}, {2, 0, -1, -1, -1, 0},
+      // wide: FullWide qint[delta,freq,offsetsLen] + varint mask + offsets; FreqsFieldsWide qint[delta,freq] + varint mask;
+      // FieldsOnlyWide varint delta + varint mask; FieldsOffsetsWide qint[delta,offsetsLen] + varint mask + offsets
+      {0, 3, 1, -1, 2, 1}, {0, 2, 1, -1, -1, 1}, {1, 0, -1, -1, -1, 1}, {0, 2, -1, -1, 1, 1}};
+  if (codec < 0 || codec > 12) return CodecDesc{-1, 0, -1, -1, -1, 0};
   return T[codec];
 }
 
@@ -42,13 +45,32 @@ namespace {
 // one body made hipcc (ROCm 7.2) drop the cursor advance of the raw path.
 constexpr uint32_t kDecodeLds = 30 * 1024;  // bytes of encoded input staged per wavefront (5 wavefronts per CU)
 
+// 7-bit groups, most significant first, +1 per continuation (reference varint/src/lib.rs); 128-bit accumulator
+template <typename Bytes>
+__device__ __forceinline__ uint32_t read_varint128(Bytes bytes, uint32_t pos, uint64_t &lo, uint64_t &hi) {
+  uint32_t c = bytes[pos++];
+  lo = c & 0x7fu;
+  hi = 0;
+  while (c & 0x80u) {
+    lo++;
+    if (lo == 0) hi++;
+    c = bytes[pos++];
+    hi = (hi << 7) | (lo >> 57);
+    lo = (lo << 7) | (uint64_t)(c & 0x7fu);
+  }
+  return pos;
+}
+
 template <int KIND, typename Bytes>
 __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes bytes, uint32_t pos, uint32_t fin,
                                                  uint32_t n, uint32_t f0, uint32_t out, uint32_t *__restrict__ ids,
-                                                 uint32_t *__restrict__ freqs, uint32_t *__restrict__ masks) {
+                                                 uint32_t *__restrict__ freqs, uint32_t *__restrict__ masks,
+                                                 uint32_t *__restrict__ wmasks, uint32_t *__restrict__ off_pos,
+                                                 uint32_t *__restrict__ off_len, uint32_t abs_base) {
   uint32_t base = f0;
   for (uint32_t e = 0; e < n && pos < fin; e++, out++) {
-    uint32_t freq = 0, mask = 0;
+    uint32_t freq = 0, mask = 0, osz = 0;
+    uint64_t mlo = 0, mhi = 0;
     if (KIND == 0) {
       const uint32_t hdr = bytes[pos++];
       uint32_t v[4] = {0, 0, 0, 0};
@@ -67,7 +89,7 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
       base += v[0];
       if (cd.freq >= 0) freq = cd.freq == 1 ? v[1] : (cd.freq == 2 ? v[2] : v[3]);
       if (cd.mask >= 0) mask = cd.mask == 1 ? v[1] : (cd.mask == 2 ? v[2] : v[3]);
-      if (cd.osz >= 0) pos += cd.osz == 1 ? v[1] : (cd.osz == 2 ? v[2] : v[3]);  // offsets bytes skipped
+      if (cd.osz >= 0) osz = cd.osz == 1 ? v[1] : (cd.osz == 2 ? v[2] : v[3]);
     } else if (KIND == 1) {
       uint32_t c = bytes[pos++];
       uint32_t val = c & 0x7fu;
@@ -83,9 +105,24 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
       pos += 4;
       base = f0 + d;
     }
+    if (cd.wide) {
+      pos = read_varint128(bytes, pos, mlo, mhi);
+      mask = (uint32_t)mlo;
+    }
     ids[out] = base;
     if (freqs) freqs[out] = freq;
     if (masks) masks[out] = mask;
+    if (wmasks) {
+      wmasks[4 * (size_t)out] = (uint32_t)mlo;
+      wmasks[4 * (size_t)out + 1] = (uint32_t)(mlo >> 32);
+      wmasks[4 * (size_t)out + 2] = (uint32_t)mhi;
+      wmasks[4 * (size_t)out + 3] = (uint32_t)(mhi >> 32);
+    }
+    if (off_pos) {  // where the offsets blob of this record sits in the list's byte buffer
+      off_pos[out] = abs_base + pos;
+      off_len[out] = osz;
+    }
+    pos += osz;  // offsets bytes are not parsed here: the proximity kernels read them in place
   }
 }
 
@@ -96,7 +133,9 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
                                                            const uint32_t *__restrict__ nent,
                                                            const uint32_t *__restrict__ entry_off, uint32_t n_blocks,
                                                            uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
-                                                           uint32_t *__restrict__ masks) {
+                                                           uint32_t *__restrict__ masks, uint32_t *__restrict__ wmasks,
+                                                           uint32_t *__restrict__ off_pos,
+                                                           uint32_t *__restrict__ off_len) {
   __shared__ __attribute__((aligned(16))) uint8_t stage[kDecodeLds];
   const uint32_t b0 = blockIdx.x * 64, lane = threadIdx.x;
   const uint32_t nb = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
@@ -114,10 +153,10 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
   const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
   if (staged)
     decode_one_block<KIND>(cd, (const uint8_t *)stage, (uint32_t)(beg - w_beg), (uint32_t)(fin - w_beg), nent[b],
-                           first[b], entry_off[b], ids, freqs, masks);
+                           first[b], entry_off[b], ids, freqs, masks, wmasks, off_pos, off_len, (uint32_t)w_beg);
   else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
     decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), nent[b], first[b], entry_off[b], ids, freqs,
-                           masks);
+                           masks, wmasks, off_pos, off_len, (uint32_t)beg);
 }
 
 // ---- intersection ----------------------------------------------------------------------------------
@@ -254,7 +293,8 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, const 
                                                               const uint32_t *__restrict__ pos,
                                                               const uint32_t *__restrict__ block_off,
                                                               uint32_t *__restrict__ out_ids,
-                                                              uint32_t *__restrict__ out_freqs, uint32_t cap) {
+                                                              uint32_t *__restrict__ out_freqs, uint32_t cap,
+                                                              uint32_t *__restrict__ out_epos) {
   __shared__ uint32_t wave_cnt[4];
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   const uint32_t n0 = v.len[0];
@@ -272,6 +312,10 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, const 
     out_freqs[off] = v.freqs[0] ? v.freqs[0][i] : 0;
     for (int l = 1; l < v.n; l++)
       out_freqs[(size_t)l * cap + off] = v.freqs[l] ? v.freqs[l][pos[(size_t)(l - 1) * n0 + i]] : 0;
+  }
+  if (out_epos) {
+    out_epos[off] = i;
+    for (int l = 1; l < v.n; l++) out_epos[(size_t)l * cap + off] = pos[(size_t)(l - 1) * n0 + i];
   }
 }
 
@@ -401,6 +445,201 @@ __global__ __launch_bounds__(256) void not_universe_write_kernel(const uint32_t 
   }
 }
 
+// ---- proximity: max_slop / in_order and the scorers' slop, over the offset bytes in place ---------------------------------
+// Reference: index_result/src/core/proximity.rs:134-298 (within_range_in_order / _unordered, OffsetIter::Merge) and
+// src/index_result/index_result.c:51-103 (IndexResult_MinOffsetDelta).  One thread per candidate / hit; a term's
+// positions are read straight out of the list's byte buffer (varint deltas), nothing is materialised.
+constexpr uint32_t kPosEof = 0xFFFFFFFFu;
+struct TermIt {
+  const uint8_t *p;
+  uint32_t len, pos, last;
+};
+__device__ __forceinline__ uint32_t term_next(TermIt &t) {
+  if (t.pos >= t.len) return kPosEof;
+  uint32_t c = t.p[t.pos++];
+  uint32_t val = c & 0x7fu;
+  while (c & 0x80u) {
+    if (t.pos >= t.len) return kPosEof;  // truncated varint: the reference's reader errors -> EOF
+    val++;
+    c = t.p[t.pos++];
+    val = (val << 7) | (c & 0x7fu);
+  }
+  t.last += val;
+  return t.last;
+}
+
+template <int MAXL>
+struct ProxCtx {
+  TermIt leaf[MAXL];
+  uint32_t look[MAXL];
+
+  __device__ __forceinline__ bool merged(const ProxParams &P, int c) const {
+    return P.is_agg[c] && (P.child_first[c + 1] - P.child_first[c]) != 1;
+  }
+  // proximity.rs:72-90: a term takes part iff it has offsets, an aggregate of terms always does
+  __device__ __forceinline__ bool has(const ProxParams &P, int c) const {
+    return P.is_agg[c] ? true : (P.child_first[c + 1] > P.child_first[c] && leaf[P.child_first[c]].len > 0);
+  }
+  __device__ __forceinline__ void reset(const ProxParams &P, int c) {
+    for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) {
+      leaf[l].pos = 0;
+      leaf[l].last = 0;
+    }
+    if (merged(P, c))
+      for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) look[l] = term_next(leaf[l]);
+  }
+  __device__ __forceinline__ uint32_t next(const ProxParams &P, int c) {
+    const int a = P.child_first[c], b = P.child_first[c + 1];
+    if (!merged(P, c)) return b > a ? term_next(leaf[a]) : kPosEof;
+    int best = -1;
+    uint32_t mv = kPosEof;
+    for (int l = a; l < b; l++)
+      if (look[l] != kPosEof && look[l] < mv) {
+        mv = look[l];
+        best = l;
+      }
+    if (best < 0) return kPosEof;
+    look[best] = term_next(leaf[best]);
+    return mv;
+  }
+};
+
+template <int MAXL>
+__device__ bool prox_within_range(const ProxParams &P, ProxCtx<MAXL> &x) {
+  if (P.n_children <= 1) return true;
+  int m[MAXL], n = 0;
+  for (int c = 0; c < P.n_children; c++)
+    if (x.has(P, c)) {
+      x.reset(P, c);
+      m[n++] = c;
+    }
+  if (n <= 1) return true;
+  const uint32_t max_slop = P.max_slop < 0 ? 0xFFFFFFFFu : (uint32_t)P.max_slop;
+  uint32_t positions[MAXL];
+  if (P.in_order) {
+    for (int i = 0; i < n; i++) positions[i] = 0;
+    for (;;) {
+      int span = 0;
+      bool over = false;
+      for (int i = 0; i < n; i++) {
+        uint32_t pos;
+        if (i == 0) {
+          pos = x.next(P, m[0]);
+          if (pos == kPosEof) return false;
+        } else {
+          pos = positions[i];
+        }
+        const uint32_t last_pos = i == 0 ? 0u : positions[i - 1];
+        while (pos < last_pos) {
+          pos = x.next(P, m[i]);
+          if (pos == kPosEof) return false;
+        }
+        positions[i] = pos;
+        if (i > 0) {
+          span += (int)pos - (int)last_pos - 1;
+          if (span > 0 && (uint32_t)span > max_slop) {
+            over = true;
+            break;
+          }
+        }
+      }
+      if (!over) return true;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    positions[i] = x.next(P, m[i]);
+    if (positions[i] == kPosEof) return false;
+  }
+  uint32_t max_pos = 0;
+  for (int i = 0; i < n; i++)
+    if (positions[i] >= max_pos) max_pos = positions[i];
+  for (;;) {
+    uint32_t min_pos = kPosEof;
+    int min_idx = 0;
+    for (int i = 0; i < n; i++)
+      if (positions[i] < min_pos) {
+        min_pos = positions[i];
+        min_idx = i;
+      }
+    if (min_pos != max_pos) {
+      const int span = (int)max_pos - (int)min_pos - (n - 1);
+      if (span < 0 || (uint32_t)span <= max_slop) return true;
+    }
+    const uint32_t np = x.next(P, m[min_idx]);
+    if (np == kPosEof) return false;
+    positions[min_idx] = np;
+    if (np > max_pos) max_pos = np;
+  }
+}
+
+template <int MAXL>
+__device__ int prox_min_offset_delta(const ProxParams &P, ProxCtx<MAXL> &x) {
+  const int num = P.n_children;
+  if (num <= 1) return 1;
+  int dist = 0, i = 0;
+  while (i < num) {
+    while (i < num && !x.has(P, i)) i++;
+    if (i == num) break;
+    const int c1 = i++;
+    while (i < num && !x.has(P, i)) i++;
+    if (i == num) break;
+    const int c2 = i;  // (not consumed: it is the first of the next pair)
+    x.reset(P, c1);
+    x.reset(P, c2);
+    uint32_t p1 = x.next(P, c1), p2 = x.next(P, c2);
+    int cd = (int)(p2 > p1 ? p2 - p1 : p1 - p2);
+    while (cd > 1 && p1 != kPosEof && p2 != kPosEof) {
+      const uint32_t a = p2 > p1 ? p2 - p1 : p1 - p2;
+      if (a < (uint32_t)cd) cd = (int)a;
+      if (p2 > p1) p1 = x.next(P, c1);
+      else p2 = x.next(P, c2);
+    }
+    dist += cd * cd;
+  }
+  return dist ? (int)sqrt((double)dist) : num - 1;
+}
+
+template <int MAXL, typename EntryOf>
+__device__ __forceinline__ void prox_load(const ProxParams &P, const OffsetView &o, ProxCtx<MAXL> &x, EntryOf entry_of) {
+  for (int l = 0; l < P.n_leaves; l++) {
+    const uint32_t e = entry_of(l);
+    const bool on = o.off_pos[l] != nullptr && e != 0xFFFFFFFFu;
+    x.leaf[l].p = on ? o.bytes[l] + o.off_pos[l][e] : nullptr;
+    x.leaf[l].len = on ? o.off_len[l][e] : 0u;
+    x.leaf[l].pos = 0;
+    x.leaf[l].last = 0;
+  }
+}
+
+template <int MAXL>
+__global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetView o, uint32_t n0,
+                                                          const uint32_t *__restrict__ pos, uint8_t *__restrict__ flags,
+                                                          uint32_t *__restrict__ block_counts) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  bool keep = i < n0 && flags[i];
+  if (keep) {
+    ProxCtx<MAXL> x;
+    prox_load<MAXL>(P, o, x, [&](int l) { return l == 0 ? i : pos[(size_t)(l - 1) * n0 + i]; });
+    keep = prox_within_range<MAXL>(P, x);
+    flags[i] = keep ? 1 : 0;
+  }
+  unsigned long long m = __ballot(keep);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+}
+
+template <int MAXL>
+__global__ __launch_bounds__(256) void prox_slop_kernel(ProxParams P, OffsetView o, const uint32_t *__restrict__ epos,
+                                                        uint32_t len, uint32_t cap, int32_t *__restrict__ slops) {
+  const uint32_t h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= len) return;
+  ProxCtx<MAXL> x;
+  prox_load<MAXL>(P, o, x, [&](int l) { return epos[(size_t)l * cap + h]; });
+  slops[h] = prox_min_offset_delta<MAXL>(P, x);
+}
+
 // ---- scorers ---------------------------------------------------------------------------------------
 // orderable image of an fp64: ascending key <=> ascending value, NaN last
 __device__ __forceinline__ uint64_t d2key(double d) {
@@ -427,8 +666,8 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   // IndexResult_MinOffsetDelta of offset-less children = (children in the aggregate) - 1, at least 1
   // (reference src/index_result/index_result.c:51-103); a union's aggregate only holds the children that
   // matched this document (union_flat.rs:297-320)
-  int slop = P.slop;
-  if (P.is_union) {
+  int slop = P.slops ? P.slops[h] : P.slop;
+  if (P.is_union && !P.slops) {
     int matched = 0;
     for (int t = 0; t < P.n_lists; t++) matched += freqs[(size_t)t * cap + h] ? 1 : 0;
     slop = matched > 1 ? matched - 1 : 1;
@@ -582,11 +821,12 @@ inline uint32_t blocks_for(uint32_t n) { return n ? (n + 255) / 256 : 1; }
 
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
-                          uint32_t *freqs, uint32_t *masks, hipStream_t s) {
+                          uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
+                          uint32_t *off_len) {
   if (!n_blocks) return;
 #define RSGPU_DECODE(K)                                                                                         \
   hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + 63) / 64), dim3(64), 0, s, cd, bytes, byte_off, first, \
-                     nent, entry_off, n_blocks, ids, freqs, masks)
+                     nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len)
   if (cd.kind == 0) RSGPU_DECODE(0);
   else if (cd.kind == 1) RSGPU_DECODE(1);
   else RSGPU_DECODE(2);
@@ -599,9 +839,25 @@ void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total_out);
 }
 void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
-                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s) {
+                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s, uint32_t *out_epos) {
   hipLaunchKernelGGL(intersect_write_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_off,
-                     out_ids, out_freqs, cap);
+                     out_ids, out_freqs, cap, out_epos);
+}
+void launch_prox_filter(const ProxParams &p, const OffsetView &o, uint32_t n0, const uint32_t *pos, uint8_t *flags,
+                        uint32_t *block_counts, hipStream_t s) {
+  if (!n0) return;
+  const dim3 g(blocks_for(n0)), b(256);
+  if (p.n_leaves <= 4) hipLaunchKernelGGL(prox_filter_kernel<4>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
+  else if (p.n_leaves <= 8) hipLaunchKernelGGL(prox_filter_kernel<8>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
+  else hipLaunchKernelGGL(prox_filter_kernel<kMaxLists>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
+}
+void launch_prox_slop(const ProxParams &p, const OffsetView &o, const uint32_t *epos, uint32_t len, uint32_t cap,
+                      int32_t *slops, hipStream_t s) {
+  if (!len) return;
+  const dim3 g(blocks_for(len)), b(256);
+  if (p.n_leaves <= 4) hipLaunchKernelGGL(prox_slop_kernel<4>, g, b, 0, s, p, o, epos, len, cap, slops);
+  else if (p.n_leaves <= 8) hipLaunchKernelGGL(prox_slop_kernel<8>, g, b, 0, s, p, o, epos, len, cap, slops);
+  else hipLaunchKernelGGL(prox_slop_kernel<kMaxLists>, g, b, 0, s, p, o, epos, len, cap, slops);
 }
 void launch_union_flag(const ListView &v, int s, uint8_t *flags, uint32_t *block_counts, hipStream_t st) {
   hipLaunchKernelGGL(union_flag_kernel, dim3(blocks_for(v.len[s])), dim3(256), 0, st, v, s, flags, block_counts);

@@ -173,6 +173,9 @@ struct RSGPU_Postings {
   DevBuf<uint64_t> byte_off;
   DevBuf<uint32_t> first, nent, entry_off;
   DevBuf<uint32_t> ids, freqs, masks;  // decode targets
+  DevBuf<uint32_t> wmasks;             // wide codecs: 128-bit field masks, 4 words per entry
+  DevBuf<uint32_t> off_pos, off_len;   // codecs with offsets: where each entry's offsets blob sits in `bytes`
+  bool has_offsets() const { return cd.osz >= 0; }
   // A list is immutable after upload, so its decoded arrays stay valid: with cache_decoded (default) the
   // decode kernel runs once, at the first query that touches the list, and HBM keeps both forms
   // (8-12 B per posting decoded next to ~3 B encoded).
@@ -189,6 +192,13 @@ struct RSGPU_Hits {
   DevBuf<uint64_t> keys;
   bool scored = false;
   bool is_union = false;        // built by RSGPU_Union: absent lists have freq 0
+  // term offsets: entry index of every hit in every list (slot order) + the lists themselves, so that the scorers'
+  // slop (IndexResult_MinOffsetDelta) can be computed from the offset bytes; the lists must outlive the hits
+  bool with_offsets = false;
+  DevBuf<uint32_t> epos;
+  DevBuf<int32_t> slops;
+  bool slops_ready = false;
+  const RSGPU_Postings *src[kMaxLists] = {};
   std::vector<uint32_t> h_ids;  // lazily mirrored
   const std::vector<uint32_t> &host_ids() {
     if (h_ids.size() != len) {
@@ -221,14 +231,18 @@ static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
     std::lock_guard<std::mutex> g(p->decode_mu);
     if (p->decoded.load(std::memory_order_relaxed)) return;
     launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
-                         p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
+                         p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
+                         c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
+                         p->has_offsets() ? p->off_len.p : nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(c->stream));  // other queries read the arrays from their own streams
     p->decoded.store(true, std::memory_order_release);
     return;
   }
   launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
-                       p->cd.freq >= 0 ? p->freqs.p : nullptr, p->cd.mask >= 0 ? p->masks.p : nullptr, c->stream);
+                       p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
+                       c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
+                       p->has_offsets() ? p->off_len.p : nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -241,6 +255,88 @@ static void check_lists(const char *who, RSGPU_Postings *const *lists, size_t n_
     if (!lists[l]) throw std::runtime_error(std::string(who) + ": NULL list");
     if (lists[l]->device != lists[0]->device) throw std::runtime_error(std::string(who) + ": lists on different devices");
   }
+}
+
+// helpers shared by RSGPU_Intersect(Ex) and the fused query ----------------------------------------------------------------
+static OffsetView offset_view(const RSGPU_Hits *h) {
+  OffsetView o;
+  memset(&o, 0, sizeof o);
+  for (int s = 0; s < h->n_lists; s++) {
+    const RSGPU_Postings *p = h->src[s];
+    o.bytes[s] = p->bytes.p;
+    o.off_pos[s] = p->has_offsets() ? p->off_pos.p : nullptr;
+    o.off_len[s] = p->has_offsets() ? p->off_len.p : nullptr;
+  }
+  return o;
+}
+static ProxParams flat_prox(const RSGPU_Hits *h, long max_slop, int in_order) {
+  ProxParams P;
+  memset(&P, 0, sizeof P);
+  P.n_children = P.n_leaves = h->n_lists;
+  for (int c = 0; c <= h->n_lists; c++) P.child_first[c] = (uint8_t)c;
+  P.max_slop = max_slop < 0 ? -1 : (int)std::min<long>(max_slop, 0x7FFFFFFF);
+  P.in_order = in_order;
+  return P;
+}
+
+// Enqueues decode (cached) + probe [+ proximity filter] + scan + write on c->stream; *total_out (pinned host memory)
+// receives the hit count once the stream has been synchronised.  max_slop < 0: no slop constraint.
+static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t n_lists, QueryCtx *c, Scratch &sc,
+                            uint32_t *total_out, long max_slop = -1, int in_order = 0) {
+  std::iota(h->order, h->order + n_lists, 0);
+  // children ordered by estimated size, ascending and stable (reference intersection.rs:94-119); in_order keeps the
+  // caller's order -- it is the order the terms must appear in
+  if (!in_order)
+    std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
+  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
+  ListView v;
+  memset(&v, 0, sizeof v);
+  v.n = (int)n_lists;
+  h->with_offsets = false;
+  for (size_t s = 0; s < n_lists; s++) {
+    RSGPU_Postings *p = lists[h->order[s]];
+    v.ids[s] = p->ids.p;
+    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
+    v.len[s] = p->n_entries;
+    h->src[s] = p;
+    h->with_offsets |= p->has_offsets();
+  }
+  const uint32_t n0 = v.len[0];
+  h->cap = std::max<uint32_t>(n0, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc((size_t)h->cap * n_lists);
+  if (h->with_offsets) h->epos.alloc((size_t)h->cap * n_lists);
+  *total_out = 0;
+  if (n0 == 0) return;
+  const uint32_t nb = (n0 + 255) / 256;
+  sc.flags.ensure(n0);
+  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
+  sc.block_counts.ensure(nb);
+  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
+  if ((max_slop >= 0 || in_order) && n_lists > 1 && h->with_offsets) {
+    // Intersection::current_is_relevant (intersection.rs:205-215): a consensus document outside the window is dropped
+    const ProxParams P = flat_prox(h, max_slop, in_order);
+    launch_prox_filter(P, offset_view(h), n0, sc.pos.p, sc.flags.p, sc.block_counts.p, c->stream);
+  }
+  launch_scan_counts(sc.block_counts.p, nb, total_out, c->stream);  // total_out: pinned host memory
+  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream,
+                         h->with_offsets ? h->epos.p : nullptr);
+  HIP_CHECK(hipGetLastError());
+}
+
+// per-hit slop from the term offsets, once per hit list (a no-op for lists without offsets)
+static const int32_t *hit_slops(RSGPU_Hits *h, QueryCtx *c) {
+  if (!h->with_offsets || h->is_union || h->n_lists < 2 || !h->len) return nullptr;
+  if (!h->slops_ready) {
+    h->slops.ensure(h->cap);
+    launch_prox_slop(flat_prox(h, -1, 0), offset_view(h), h->epos.p, h->len, h->cap, h->slops.p, c->stream);
+    HIP_CHECK(hipGetLastError());
+    h->slops_ready = true;
+  }
+  return h->slops.p;
+}
+static bool slop_dependent(int scorer) {
+  return scorer == RSGPU_SCORER_TFIDF || scorer == RSGPU_SCORER_TFIDF_DOCNORM || scorer == RSGPU_SCORER_BM25;
 }
 
 extern "C" {
@@ -276,7 +372,14 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
   p->entry_off.upload(eoff.data(), n_blocks + 1);
   p->ids.alloc(p->n_entries);
   p->freqs.alloc(p->n_entries);
-  p->masks.alloc(cd.mask >= 0 ? p->n_entries : 1);
+  p->masks.alloc((cd.mask >= 0 || cd.wide) ? p->n_entries : 1);
+  if (cd.wide) p->wmasks.alloc((size_t)p->n_entries * 4);
+  if (cd.osz >= 0) {
+    // the decoded offsets index addresses the byte buffer with 32 bits
+    if (p->n_bytes >= 0xFFFFFFF0ull) throw std::runtime_error("posting lists with offsets are limited to 4 GiB of encoded bytes");
+    p->off_pos.alloc(p->n_entries);
+    p->off_len.alloc(p->n_entries);
+  }
   return guard.release();
   S_CATCH(nullptr)
 }
@@ -308,14 +411,31 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
     else memset(freqs_out, 0, n * sizeof(uint32_t));
   }
   if (masks_out && n) {
-    if (p->cd.mask >= 0) HIP_CHECK(hipMemcpy(masks_out, p->masks.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (p->cd.mask >= 0 || p->cd.wide) HIP_CHECK(hipMemcpy(masks_out, p->masks.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     else memset(masks_out, 0, n * sizeof(uint32_t));
   }
   return (long)n;
   S_CATCH(-1)
 }
 
-RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
+long RSGPU_Postings_DecodeWideMasks(RSGPU_Postings *p, uint64_t *masks_lo_out, uint64_t *masks_hi_out) {
+  if (!p) return -1;
+  S_TRY
+  if (!p->cd.wide) throw std::runtime_error("RSGPU_Postings_DecodeWideMasks: not a wide codec");
+  if (RSGPU_Postings_Decode(p, nullptr, nullptr, nullptr) < 0) return -1;
+  HIP_CHECK(hipSetDevice(p->device));
+  const uint32_t n = p->n_entries;
+  std::vector<uint32_t> w((size_t)n * 4);
+  if (n) HIP_CHECK(hipMemcpy(w.data(), p->wmasks.p, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; i++) {
+    if (masks_lo_out) masks_lo_out[i] = (uint64_t)w[4 * (size_t)i] | ((uint64_t)w[4 * (size_t)i + 1] << 32);
+    if (masks_hi_out) masks_hi_out[i] = (uint64_t)w[4 * (size_t)i + 2] | ((uint64_t)w[4 * (size_t)i + 3] << 32);
+  }
+  return (long)n;
+  S_CATCH(-1)
+}
+
+RSGPU_Hits *RSGPU_IntersectEx(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order) {
   if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
     last_error() = "RSGPU_Intersect: 1..32 lists";
     return nullptr;
@@ -329,49 +449,22 @@ RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
   std::unique_ptr<RSGPU_Hits> guard(h);
   h->device = device;
   h->n_lists = (int)n_lists;
-  // children ordered by estimated size, ascending and stable (reference intersection.rs:60-119);
-  // the first one drives
-  std::iota(h->order, h->order + n_lists, 0);
-  std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
-
-  StageTimer td(c.c, 0);
-  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c.c);
-  td.stop();
-
-  ListView v;
-  memset(&v, 0, sizeof v);
-  v.n = (int)n_lists;
-  for (size_t s = 0; s < n_lists; s++) {
-    RSGPU_Postings *p = lists[h->order[s]];
-    v.ids[s] = p->ids.p;
-    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
-    v.len[s] = p->n_entries;
-  }
-  const uint32_t n0 = v.len[0];
-  h->cap = std::max<uint32_t>(n0, 1);
-  h->ids.alloc(h->cap);
-  h->freqs.alloc((size_t)h->cap * n_lists);
-  if (n0 == 0) {
-    h->len = 0;
-    return guard.release();
-  }
   Scratch &sc = scratch(device);
-  const uint32_t nb = (n0 + 255) / 256;
-  sc.flags.ensure(n0);
-  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
-  sc.block_counts.ensure(nb);
-  sc.total.ensure(1);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  if (prof) {  // the decode stage on its own (a stream sync), as the per-stage profile reports it
+    StageTimer td(c.c, 0);
+    for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c.c);
+    td.stop();
+  }
   StageTimer ti(c.c, 1);
-  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
-  launch_scan_counts(sc.block_counts.p, nb, sc.total.p, c->stream);
-  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream);
-  HIP_CHECK(hipGetLastError());
-  ti.stop();
-  uint32_t total = 0;
-  HIP_CHECK(hipMemcpy(&total, sc.total.p, sizeof total, hipMemcpyDeviceToHost));
-  h->len = total;
+  intersect_async(h, lists, n_lists, c.c, sc, c->h_counters, max_slop, in_order);
+  ti.stop();  // synchronises the stream: the count below is final
+  h->len = c->h_counters[0];
   return guard.release();
   S_CATCH(nullptr)
+}
+RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists) {
+  return RSGPU_IntersectEx(lists, n_lists, -1, 0);
 }
 // reference src/redisearch_rs/rqe_iterators/src/union_flat.rs:223-257,297-320
 RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
@@ -402,6 +495,7 @@ RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
     v.ids[s] = p->ids.p;
     v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
     v.len[s] = p->n_entries;
+    h->src[s] = p;
     sum += p->n_entries;
     max_len = std::max<size_t>(max_len, p->n_entries);
   }
@@ -575,6 +669,14 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   }
   h->scores.ensure(h->cap);
   h->keys.ensure(h->cap);
+  if (slop_dependent(P.scorer)) {
+    if (h->is_union)
+      for (int s2 = 0; s2 < h->n_lists; s2++)
+        if (h->src[s2] && h->src[s2]->has_offsets())
+          throw std::runtime_error("slop-dependent scorers (TFIDF, TFIDF.DOCNORM, BM25) over a union of lists that carry "
+                                   "term offsets are not served: the union keeps no per-term positions");
+    P.slops = hit_slops(h, c.c);  // IndexResult_MinOffsetDelta from the term offsets where the lists carry them
+  }
   StageTimer ts(c.c, 2);
   launch_score(P, h->ids.p, h->freqs.p, h->len, h->cap, t->doc_len.p, t->doc_score.p,
                t->max_freq.p, t->n, h->scores.p, h->keys.p, c->stream);
@@ -705,36 +807,6 @@ thread_local FusedEvents tls_events;
 constexpr uint32_t kFetchCap = 4096;  // survivors of the score prefilter settled on the host
 }  // namespace
 
-static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t n_lists, QueryCtx *c, Scratch &sc,
-                            uint32_t *total_out) {
-  std::iota(h->order, h->order + n_lists, 0);
-  std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
-  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
-  ListView v;
-  memset(&v, 0, sizeof v);
-  v.n = (int)n_lists;
-  for (size_t s = 0; s < n_lists; s++) {
-    RSGPU_Postings *p = lists[h->order[s]];
-    v.ids[s] = p->ids.p;
-    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
-    v.len[s] = p->n_entries;
-  }
-  const uint32_t n0 = v.len[0];
-  h->cap = std::max<uint32_t>(n0, 1);
-  h->ids.alloc(h->cap);
-  h->freqs.alloc((size_t)h->cap * n_lists);
-  *total_out = 0;
-  if (n0 == 0) return;
-  const uint32_t nb = (n0 + 255) / 256;
-  sc.flags.ensure(n0);
-  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
-  sc.block_counts.ensure(nb);
-  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
-  launch_scan_counts(sc.block_counts.p, nb, total_out, c->stream);  // total_out: pinned host memory
-  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream);
-  HIP_CHECK(hipGetLastError());
-}
-
 static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_ScoreArgs *a, bool *max_norm) {
   memset(&P, 0, sizeof P);
   *max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
@@ -798,6 +870,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     fill_score_params(P, h.get(), a->score, &max_norm);
     h->scores.ensure(h->cap);
     h->keys.ensure(h->cap);
+    if (slop_dependent(P.scorer)) P.slops = hit_slops(h.get(), ca.c);
     prefiltered = !max_norm && top_n <= 32 && len >= (1u << 14);
     if (prefiltered) sc.skeys32.ensure(len + 4);
     launch_score(P, h->ids.p, h->freqs.p, len, h->cap, a->table->doc_len.p, a->table->doc_score.p, a->table->max_freq.p,

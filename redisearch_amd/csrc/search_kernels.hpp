@@ -10,16 +10,21 @@ namespace rsgpu {
 
 // record layout of a codec: qint arity and slot of each field (-1 = absent); kind 0 qint, 1 varint
 // delta, 2 raw u32 delta from the block's first doc id
+// wide != 0: a varint-coded field mask of up to 128 bits follows the qint fields (or the varint delta) -- the *Wide
+// codecs of reference inverted_index/src/codec/{full,freqs_fields,fields_only,fields_offsets}.rs
 struct CodecDesc {
-  int kind, n, freq, mask, osz;
+  int kind, n, freq, mask, osz, wide;
 };
 CodecDesc codec_desc(int codec);
 
 // One thread per IndexBlock, sequential inside the block (records are variable-length and
 // delta-coded), blocks in parallel.  ids/freqs/masks receive entry_off[b] + e.
+// Optional outputs (NULL = skipped): wmasks[4*e .. 4*e+3] the 128-bit field mask (little-endian words) of wide codecs;
+// off_pos[e] / off_len[e] byte position (into `bytes`) and length of the record's offsets blob.
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
-                          uint32_t *freqs, uint32_t *masks, hipStream_t s);
+                          uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks = nullptr,
+                          uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr);
 
 constexpr int kMaxLists = 32;  // children of one intersection / union (the reference's own tests go to 25)
 struct ListView {
@@ -33,9 +38,34 @@ struct ListView {
 void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s);
 // exclusive scan of block_counts[0..nb) in place, total -> total_out[0]
 void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s);
-// ordered compaction: out_ids[h], out_freqs[l*cap + h]
+// ordered compaction: out_ids[h], out_freqs[l*cap + h]; out_epos[l*cap + h] (optional) = the hit's entry index in list l
 void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
-                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s);
+                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
+                            uint32_t *out_epos = nullptr);
+
+// ---- proximity over the term offsets (reference index_result/src/core/proximity.rs, index_result.c:51-103) ----------
+// Leaves are the hit list's term columns; a child of the aggregate is one leaf, or -- is_agg -- a union / intersection
+// of consecutive leaves whose positions are merged.  bytes/off_pos/off_len: per leaf, the list's byte buffer and the
+// decoded offsets index (NULL off_pos: the codec stores no offsets).
+struct OffsetView {
+  const uint8_t *bytes[kMaxLists];
+  const uint32_t *off_pos[kMaxLists];
+  const uint32_t *off_len[kMaxLists];
+};
+struct ProxParams {
+  int n_children, n_leaves;
+  uint8_t child_first[kMaxLists + 1];
+  uint8_t is_agg[kMaxLists];
+  int max_slop;  // < 0: no slop constraint
+  int in_order;
+};
+// filter the candidates of the probe: flags[i] &= within_range(candidate i); block_counts recomputed.
+// candidate i's entry index is i in leaf 0 and pos[(l-1)*n0 + i] in leaf l.
+void launch_prox_filter(const ProxParams &p, const OffsetView &o, uint32_t n0, const uint32_t *pos, uint8_t *flags,
+                        uint32_t *block_counts, hipStream_t s);
+// slops[h] = IndexResult_MinOffsetDelta of hit h (entry indices epos[l*cap + h], 0xFFFFFFFF = leaf absent)
+void launch_prox_slop(const ProxParams &p, const OffsetView &o, const uint32_t *epos, uint32_t len, uint32_t cap,
+                      int32_t *slops, hipStream_t s);
 
 // union: the lists' emitted-prefix arrays ([len+1] each); see postings_kernels.hip "union / NOT"
 struct UnionView {
@@ -61,6 +91,7 @@ struct ScoreParams {
   double avg_doc_len, root_weight, min_score, inv_tanh;
   double idf[kMaxLists], bm25_idf[kMaxLists], weight[kMaxLists];
   int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_lists-1, 1)
+  const int32_t *slops;  // per-hit slop computed from the term offsets (launch_prox_slop); NULL: the constant above
   int is_union;  // hits come from RSGPU_Union: per-hit slop from the matched children, DISMAX takes the maximum
 };
 // scores[h] (fp64) and keys[h] = descending-score orderable u64 (for the top-N select)

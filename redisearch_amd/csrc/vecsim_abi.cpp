@@ -581,6 +581,8 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;
   else if (!strcmp(key, "shadow8")) scan_tuning().shadow8 = value;
   else if (!strcmp(key, "vmm")) scan_tuning().vmm = value;
+  else if (!strcmp(key, "vmm_chunk_mib")) scan_tuning().vmm_chunk_mib = value;
+  else if (!strcmp(key, "vmm_reserve_factor")) scan_tuning().vmm_reserve_factor = value > 0 ? value : 64;
   else return -1;
   return 0;
 }

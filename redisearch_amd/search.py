@@ -9,7 +9,8 @@ from . import vecsim as V
 _sz, _vp, _dbl, _i = C.c_size_t, C.c_void_p, C.c_double, C.c_int
 
 (CODEC_FULL, CODEC_FREQS_FIELDS, CODEC_FREQS_ONLY, CODEC_FIELDS_ONLY, CODEC_FIELDS_OFFSETS, CODEC_OFFSETS_ONLY,
- CODEC_FREQS_OFFSETS, CODEC_DOCIDS_ONLY, CODEC_RAW_DOCIDS) = range(9)
+ CODEC_FREQS_OFFSETS, CODEC_DOCIDS_ONLY, CODEC_RAW_DOCIDS, CODEC_FULL_WIDE, CODEC_FREQS_FIELDS_WIDE,
+ CODEC_FIELDS_ONLY_WIDE, CODEC_FIELDS_OFFSETS_WIDE) = range(13)
 SCORERS = {"BM25STD": 0, "BM25STD.TANH": 1, "BM25": 2, "TFIDF": 3, "TFIDF.DOCNORM": 4, "DOCSCORE": 5, "DISMAX": 6}
 # scorer names that are a registered scorer + a result processor chained behind it in the reference pipeline
 PIPELINE_SCORERS = {"BM25STD.NORM": 7}
@@ -34,6 +35,8 @@ ABI = {
     "RSGPU_Postings_NumBytes": (_sz, [_vp]),
     "RSGPU_Postings_Decode": (C.c_long, [_vp, _vp, _vp, _vp]),
     "RSGPU_Intersect": (_vp, [_vp, _sz]),
+    "RSGPU_IntersectEx": (_vp, [_vp, _sz, C.c_long, _i]),
+    "RSGPU_Postings_DecodeWideMasks": (C.c_long, [_vp, _vp, _vp]),
     "RSGPU_Hits_Free": (None, [_vp]),
     "RSGPU_Hits_Len": (_sz, [_vp]),
     "RSGPU_Hits_Read": (_i, [_vp, _vp, _vp]),
@@ -110,6 +113,14 @@ class Postings:
             raise RuntimeError(V.last_error())
         return ids[:m], fr[:m], mk[:m]
 
+    def decode_wide_masks(self):
+        n = self.num_entries
+        lo, hi = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
+        m = self.lib.RSGPU_Postings_DecodeWideMasks(self.ptr, _p(lo), _p(hi))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return [int(a) | (int(b) << 64) for a, b in zip(lo[:m].tolist(), hi[:m].tolist())]
+
     def free(self):
         if getattr(self, "ptr", None):
             self.lib.RSGPU_Postings_Free(self.ptr)
@@ -135,8 +146,9 @@ class DocTable:
 
 
 class Hits:
-    def __init__(self, lists, op="and", universe=None, max_doc_id=0):
+    def __init__(self, lists, op="and", universe=None, max_doc_id=0, max_slop=None, in_order=False):
         self.lib = load()
+        self._lists = list(lists)   # the hit list borrows the postings (offset bytes): keep them alive
         if op == "not":
             self.n_lists = 1
             self.ptr = _check(self.lib.RSGPU_Not(lists[0].ptr, universe.ptr if universe is not None else None,
@@ -144,8 +156,11 @@ class Hits:
             return
         self.n_lists = len(lists)
         arr = (_vp * len(lists))(*[l.ptr for l in lists])
-        fn = self.lib.RSGPU_Intersect if op == "and" else self.lib.RSGPU_Union
-        self.ptr = _check(fn(C.cast(arr, _vp), len(lists)), "RSGPU_Intersect" if op == "and" else "RSGPU_Union")
+        if op == "and":
+            self.ptr = _check(self.lib.RSGPU_IntersectEx(C.cast(arr, _vp), len(lists), -1 if max_slop is None else int(max_slop),
+                                                         int(in_order)), "RSGPU_IntersectEx")
+        else:
+            self.ptr = _check(self.lib.RSGPU_Union(C.cast(arr, _vp), len(lists)), "RSGPU_Union")
 
     def __len__(self):
         return self.lib.RSGPU_Hits_Len(self.ptr)
@@ -217,8 +232,8 @@ def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight
     return dict(n_hits=a.n_hits, top=(ti[:a.n_top], ts[:a.n_top]), knn=(ki[:a.n_knn], kd[:a.n_knn]))
 
 
-def intersect(lists):
-    return Hits(lists)
+def intersect(lists, max_slop=None, in_order=False):
+    return Hits(lists, "and", max_slop=max_slop, in_order=in_order)
 
 
 def union(lists):

@@ -45,15 +45,21 @@ def test_rows_survive_growth_steps(vmm):
         lib.RSGPU_SetTuning(b"vmm", 1)
 
 
-def test_virtual_range_is_re_reserved_when_it_runs_out():
-    """The first reservation is max(4 x size, 4 GiB); growing past it reserves a larger range and re-maps the SAME
-    physical chunks there (no copy): contents and results survive."""
-    dim, seed = 1024, 78
-    g = V.VecSimIndex(F32, dim, V.VecSimMetric_L2)
-    n = 0
-    for step in (70_000, 1_000_000):                # 273 MiB (reservation 4 GiB) -> 4.08 GiB: beyond the reservation
-        assert g.add_philox_rows(seed, n, step, n + 1) == step
-        n += step
-        _check(g, seed, n, dim, [0, 69_999, 70_000, 500_000, n - 1])
-    mem = g.stats_info().memory
-    assert n * dim * 4 <= mem <= n * dim * 4 + (600 << 20)
+def test_a_buffer_that_outgrows_its_virtual_range_is_rebuilt():
+    """The virtual range is 64 x the size at mapping time (>= 64 GiB); with the test knob vmm_reserve_factor = 2 the
+    range is 2 GiB and growing to 4 GiB rebuilds the buffer in a larger one (the one copying step): contents and
+    results survive."""
+    lib = V.load()
+    assert lib.RSGPU_SetTuning(b"vmm_reserve_factor", 2) == 0
+    try:
+        dim, seed = 1024, 78
+        g = V.VecSimIndex(F32, dim, V.VecSimMetric_L2)
+        n = 0
+        for step in (70_000, 1_000_000, 300_000):       # 273 MiB (range 2 GiB) -> 4.08 GiB (rebuilt, range 8 GiB) -> 5.2 GiB
+            assert g.add_philox_rows(seed, n, step, n + 1) == step
+            n += step
+            _check(g, seed, n, dim, [0, 69_999, 70_000, 500_000, 1_069_999, 1_070_000, n - 1])
+        mem = g.stats_info().memory
+        assert n * dim * 4 <= mem <= n * dim * 4 + (1200 << 20)
+    finally:
+        lib.RSGPU_SetTuning(b"vmm_reserve_factor", 64)
