@@ -112,6 +112,62 @@ HOT static float l2_f32(const float *a, const float *b, size_t d) {
   return reduce16(s);
 }
 
+/* fp16 rows: the same 16-lane accumulation over elements widened to fp32.  half -> float is exact, so the F16C
+ * hardware conversion (picked at run time where the CPU has it) and the bit-level f16_to_f32 give the same values; lane j
+ * still sums the elements i = j (mod 16) in order, products and sums stay separate (no FMA). */
+static float dot_or_l2_f16_scalar(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+  float s[16] = {0};
+  for (size_t i = 0; i < d; i++) {
+    float x = f16_to_f32(a[i]), y = f16_to_f32(b[i]);
+    if (l2) { float t = x - y; s[i & 15] += t * t; } else s[i & 15] += x * y;
+  }
+  return reduce16(s);
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,f16c"))) static float dot_or_l2_f16_f16c(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+  __m256 s0 = _mm256_setzero_ps(), s1 = _mm256_setzero_ps();
+  size_t i = 0;
+  for (; i + 16 <= d; i += 16) {
+    __m256 a0 = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(a + i))), a1 = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(a + i + 8)));
+    __m256 b0 = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(b + i))), b1 = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i *)(b + i + 8)));
+    if (l2) {
+      __m256 t0 = _mm256_sub_ps(a0, b0), t1 = _mm256_sub_ps(a1, b1);
+      s0 = _mm256_add_ps(s0, _mm256_mul_ps(t0, t0));
+      s1 = _mm256_add_ps(s1, _mm256_mul_ps(t1, t1));
+    } else {
+      s0 = _mm256_add_ps(s0, _mm256_mul_ps(a0, b0));
+      s1 = _mm256_add_ps(s1, _mm256_mul_ps(a1, b1));
+    }
+  }
+  float s[16];
+  _mm256_storeu_ps(s, s0);
+  _mm256_storeu_ps(s + 8, s1);
+  for (int j = 0; i < d; i++, j++) {
+    float x = f16_to_f32(a[i]), y = f16_to_f32(b[i]);
+    if (l2) { float t = x - y; s[j] += t * t; } else s[j] += x * y;
+  }
+  return reduce16(s);
+}
+#endif
+static float dot_or_l2_f16(const uint16_t *a, const uint16_t *b, size_t d, int l2) {
+#if defined(__x86_64__)
+  static int have = -1;
+  if (have < 0) have = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
+  if (have) return dot_or_l2_f16_f16c(a, b, d, l2);
+#endif
+  return dot_or_l2_f16_scalar(a, b, d, l2);
+}
+
+/* test hook: 1 when the dispatched fp16 loop and the scalar one agree bit for bit on (a, b) for both metrics */
+int oracle_f16_paths_agree(const uint16_t *a, const uint16_t *b, size_t d) {
+  for (int l2 = 0; l2 < 2; l2++) {
+    float x = dot_or_l2_f16(a, b, d, l2), y = dot_or_l2_f16_scalar(a, b, d, l2);
+    if (memcmp(&x, &y, 4) != 0) return 0;
+  }
+  return 1;
+}
+
 /* element i of a blob widened to float (f16/bf16 are up-converted, fp32 accumulate [D5]) */
 static inline float elem_f(const void *p, int type, size_t i) {
   switch (type) {
@@ -148,7 +204,11 @@ double oracle_distance(const void *x, const void *q, size_t d, int type, int met
     float na, nb; memcpy(&na, (const char *)x + d, 4); memcpy(&nb, (const char *)q + d, 4);
     return (double)(1.0f - (float)s / (na * nb));
   }
-  /* f16 / bf16 */
+  if (type == T_F16) {
+    float r = dot_or_l2_f16((const uint16_t *)x, (const uint16_t *)q, d, metric == M_L2);
+    return (double)(metric == M_L2 ? r : 1.0f - r);
+  }
+  /* bf16 */
   float s[16] = {0};
   for (size_t i = 0; i < d; i++) {
     float a = elem_f(x, type, i), b = elem_f(q, type, i);

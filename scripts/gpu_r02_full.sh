@@ -1,0 +1,8 @@
+#!/bin/bash
+# the whole GPU suite + smoke, as the driver runs them at round end
+mkdir -p gpurun_out
+T0=$(date +%s)
+timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=8 > gpurun_out/r02_full_tests.txt 2>&1
+echo "tests rc=$? t=$(( $(date +%s) - T0 ))s" >> gpurun_out/r02_full_tests.txt
+tail -25 gpurun_out/r02_full_tests.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3

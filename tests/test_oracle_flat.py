@@ -252,3 +252,16 @@ def test_philox_rows_are_a_pure_function_of_seed_row_column():
     assert np.array_equal(O.philox_rows(11, 0, 8, 9, O.F64), O.philox_rows(11, 0, 8, 9).astype(np.float64))
     u8 = O.philox_rows(11, 0, 8, 9, O.U8)
     assert u8.dtype == np.uint8 and np.array_equal(O.philox_rows(11, 0, 8, 9, O.I8).view(np.uint8), u8)
+
+
+def test_fp16_hardware_conversion_path_equals_the_bit_level_one():
+    """oracle/flat_oracle.c dot_or_l2_f16: the F16C loop (picked at run time) and the scalar loop over f16_to_f32 must give
+    the same float for every length, incl. subnormals, infinities and ragged tails."""
+    rng = np.random.default_rng(2)
+    O.lib.oracle_f16_paths_agree.restype = int
+    for d in (1, 7, 15, 16, 17, 33, 100, 768, 1000):
+        for _ in range(20):
+            a = rng.standard_normal(d).astype(np.float16)
+            b = (rng.standard_normal(d) * rng.choice([1e-6, 1.0, 200.0])).astype(np.float16)
+            a[rng.integers(0, d)] = np.float16(6e-8)        # subnormal
+            assert O.lib.oracle_f16_paths_agree(O._p(a), O._p(b), d) == 1
