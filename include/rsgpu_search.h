@@ -164,6 +164,28 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * follows the reference's Union node: absent children add nothing, the slop divisor counts the matched
  * children only, DISMAX takes the children's maximum.  Returns NULL on error. */
 RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists);
+/* Two-level query tree: the root (AND / OR) over `n_groups` children, child g being the single list group_first[g]
+ * (RSGPU_OP_TERM) or the OR / AND of lists[group_first[g] .. group_first[g+1]) with weight group_weight[g] -- e.g. the
+ * stemmer's (run|running|ran) (shoe|shoes), or (a b) | (c d).  The hit list carries every term's frequency (0 where a
+ * union child did not match), so RSGPU_Hits_Score evaluates the reference's result tree Intersection{Union{..},..}
+ * (src/ext/default.c recursions: an aggregate sums its children and multiplies by its weight, DISMAX takes a union's
+ * maximum) and its slop merges a union child's term positions (proximity.rs OffsetIter::Merge).  max_slop / in_order
+ * apply to a root intersection.  idf / bm25_idf / weight of RSGPU_ScoreArgs are per LIST, in the order of `lists`. */
+#define RSGPU_OP_TERM 0
+#define RSGPU_OP_UNION 1
+#define RSGPU_OP_INTERSECT 2
+typedef struct {
+  int root_op;                 /* RSGPU_OP_INTERSECT or RSGPU_OP_UNION */
+  size_t n_groups;
+  const size_t *group_first;   /* [n_groups + 1] */
+  const int *group_op;         /* [n_groups], NULL: all RSGPU_OP_TERM */
+  const double *group_weight;  /* [n_groups], NULL: all 1.0 (a term's own weight stays in RSGPU_ScoreArgs.weight) */
+  RSGPU_Postings *const *lists;
+  long max_slop;               /* < 0: none */
+  int in_order;
+} RSGPU_TreeQuery;
+RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q);
+
 /* NOT: doc ids 1..max_doc_id the child does not hold (rqe_iterators/src/not.rs:171-209), or -- with a
  * `universe` list of existing documents -- the universe's entries <= max_doc_id the child does not hold
  * (not_optimized.rs).  The hits are virtual results: one child with freq 1; score them with idf = 1

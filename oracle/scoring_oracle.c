@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 
 /* result-tree node kinds (same meaning as RSResultData_* in the reference) */
 enum { R_UNION = 1, R_INTERSECTION = 2, R_TERM = 4, R_VIRTUAL = 8, R_NUMERIC = 16, R_METRIC = 32, R_HYBRID = 64 };
@@ -80,11 +81,36 @@ static int has_offsets(const ONode *r) {
     default: return 0;
   }
 }
-/* offsets iteration for slop: only direct Term children carry explicit positions in this
- * restatement (nested aggregates would merge their children's; not needed by the pinned cases). */
+/* offsets iteration for slop: a Term child yields its positions; an aggregate child yields the ascending merge of its
+ * descendants' positions (reference index_result/src/core/proximity.rs OffsetIter::Merge, pinned by the merge KATs at
+ * :410-466 in tests/test_oracle_proximity.py through the byte-level restatement) */
 #define OFF_EOF 0xFFFFFFFFu
-typedef struct { const ONode *n; size_t i; } OffIt;
-static uint32_t off_next(OffIt *it) { return (it->n->offsets && it->i < it->n->n_offsets) ? it->n->offsets[it->i++] : OFF_EOF; }
+typedef struct { uint32_t *pos; size_t n, i; int owned; } OffIt;
+static size_t count_pos(const ONode *n) {
+  if (n->tag == R_TERM) return n->n_offsets;
+  size_t c = 0;
+  if (IS_AGG(n->tag)) for (size_t k = 0; k < n->n_children; k++) c += count_pos(n->children[k]);
+  return c;
+}
+static size_t gather_pos(const ONode *n, uint32_t *out) {
+  if (n->tag == R_TERM) { if (n->n_offsets) memcpy(out, n->offsets, n->n_offsets * 4); return n->n_offsets; }
+  size_t c = 0;
+  if (IS_AGG(n->tag)) for (size_t k = 0; k < n->n_children; k++) c += gather_pos(n->children[k], out + c);
+  return c;
+}
+static int cmp_u32(const void *a, const void *b) { uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b; return x < y ? -1 : x > y; }
+static OffIt off_iter(const ONode *n) {
+  OffIt it = {NULL, 0, 0, 0};
+  if (n->tag == R_TERM) { it.pos = (uint32_t *)n->offsets; it.n = n->n_offsets; return it; }
+  it.n = count_pos(n);
+  it.pos = malloc((it.n ? it.n : 1) * 4);
+  it.owned = 1;
+  gather_pos(n, it.pos);
+  qsort(it.pos, it.n, 4, cmp_u32);
+  return it;
+}
+static void off_free(OffIt *it) { if (it->owned) free(it->pos); }
+static uint32_t off_next(OffIt *it) { return it->i < it->n ? it->pos[it->i++] : OFF_EOF; }
 #define ABSDELTA(x, y) ((x) > (y) ? (x) - (y) : (y) - (x))
 
 int oracle_slop(const ONode *r) {
@@ -95,11 +121,11 @@ int oracle_slop(const ONode *r) {
   while (i < num) {
     while (i < num && !has_offsets(r->children[i])) i++;
     if (i == num) break;
-    OffIt v1 = {r->children[i], 0};
+    OffIt v1 = off_iter(r->children[i]);
     i++;
     while (i < num && !has_offsets(r->children[i])) i++;
-    if (i == num) break;
-    OffIt v2 = {r->children[i], 0};
+    if (i == num) { off_free(&v1); break; }
+    OffIt v2 = off_iter(r->children[i]);
     uint32_t p1 = off_next(&v1), p2 = off_next(&v2);
     int cd = (int)ABSDELTA(p2, p1);
     while (cd > 1 && p1 != OFF_EOF && p2 != OFF_EOF) {
@@ -108,6 +134,7 @@ int oracle_slop(const ONode *r) {
       if (p2 > p1) p1 = off_next(&v1); else p2 = off_next(&v2);
     }
     dist += cd * cd;
+    off_free(&v1); off_free(&v2);
   }
   return dist ? (int)sqrt((double)dist) : (int)(num - 1);
 }

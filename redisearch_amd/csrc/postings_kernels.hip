@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(uint32_t *__restrict_
   if (threadIdx.x == 0) total_out[0] = carry;
 }
 
-__global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, const uint8_t *__restrict__ flags,
+__global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, LeafMap lm, const uint8_t *__restrict__ flags,
                                                               const uint32_t *__restrict__ pos,
                                                               const uint32_t *__restrict__ block_off,
                                                               uint32_t *__restrict__ out_ids,
@@ -308,14 +308,11 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, const 
   for (uint32_t j = 0; j < w; j++) off += wave_cnt[j];
   off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   out_ids[off] = v.ids[0][i];
-  if (out_freqs) {
-    out_freqs[off] = v.freqs[0] ? v.freqs[0][i] : 0;
-    for (int l = 1; l < v.n; l++)
-      out_freqs[(size_t)l * cap + off] = v.freqs[l] ? v.freqs[l][pos[(size_t)(l - 1) * n0 + i]] : 0;
-  }
-  if (out_epos) {
-    out_epos[off] = i;
-    for (int l = 1; l < v.n; l++) out_epos[(size_t)l * cap + off] = pos[(size_t)(l - 1) * n0 + i];
+  for (int l = 0; l < lm.n_leaves; l++) {
+    const uint32_t t = lm.leaf_list[l];
+    const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];  // the hit's position in list t
+    if (out_freqs) out_freqs[(size_t)l * cap + off] = lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 0u;
+    if (out_epos) out_epos[(size_t)l * cap + off] = lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
   }
 }
 
@@ -363,10 +360,11 @@ __global__ __launch_bounds__(256) void union_prefix_kernel(const uint8_t *__rest
   if (i == len) prefix[len] = total[0];  // (the grid covers len + 1 slots)
 }
 
-__global__ __launch_bounds__(256) void union_write_kernel(ListView v, UnionView u, int s,
+__global__ __launch_bounds__(256) void union_write_kernel(ListView v, LeafMap lm, UnionView u, int s,
                                                           const uint8_t *__restrict__ flags,
                                                           uint32_t *__restrict__ out_ids,
-                                                          uint32_t *__restrict__ out_freqs, uint32_t cap) {
+                                                          uint32_t *__restrict__ out_freqs, uint32_t cap,
+                                                          uint32_t *__restrict__ out_epos) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= v.len[s] || !flags[i]) return;
   const uint32_t x = v.ids[s][i];
@@ -377,9 +375,11 @@ __global__ __launch_bounds__(256) void union_write_kernel(ListView v, UnionView 
   }
   if (slot >= cap) return;
   out_ids[slot] = x;
-  for (int t = 0; t < v.n; t++) {
-    const bool on = at[t] < v.len[t] && v.ids[t][at[t]] == x;
-    out_freqs[(size_t)t * cap + slot] = (on && v.freqs[t]) ? v.freqs[t][at[t]] : 0u;
+  for (int l = 0; l < lm.n_leaves; l++) {
+    const uint32_t t = lm.leaf_list[l], p = at[t];
+    const bool on = p < v.len[t] && v.ids[t][p] == x;
+    out_freqs[(size_t)l * cap + slot] = (on && lm.leaf_freq[l]) ? lm.leaf_freq[l][p] : 0u;
+    if (out_epos) out_epos[(size_t)l * cap + slot] = on ? (lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p) : 0xFFFFFFFFu;
   }
 }
 
@@ -472,13 +472,20 @@ template <int MAXL>
 struct ProxCtx {
   TermIt leaf[MAXL];
   uint32_t look[MAXL];
+  uint32_t present;  // bit l: leaf l matched this document (union children may be absent)
+
+  __device__ __forceinline__ bool child_present(const ProxParams &P, int c) const {
+    uint32_t m = 0;
+    for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) m |= (present >> l) & 1u;
+    return m != 0;
+  }
 
   __device__ __forceinline__ bool merged(const ProxParams &P, int c) const {
     return P.is_agg[c] && (P.child_first[c + 1] - P.child_first[c]) != 1;
   }
   // proximity.rs:72-90: a term takes part iff it has offsets, an aggregate of terms always does
   __device__ __forceinline__ bool has(const ProxParams &P, int c) const {
-    return P.is_agg[c] ? true : (P.child_first[c + 1] > P.child_first[c] && leaf[P.child_first[c]].len > 0);
+    return P.is_agg[c] ? child_present(P, c) : (P.child_first[c + 1] > P.child_first[c] && leaf[P.child_first[c]].len > 0);
   }
   __device__ __forceinline__ void reset(const ProxParams &P, int c) {
     for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) {
@@ -574,15 +581,21 @@ __device__ bool prox_within_range(const ProxParams &P, ProxCtx<MAXL> &x) {
 
 template <int MAXL>
 __device__ int prox_min_offset_delta(const ProxParams &P, ProxCtx<MAXL> &x) {
-  const int num = P.n_children;
+  const int nc = P.n_children;
+  // a union's aggregate only holds the children that matched this document (union_flat.rs:297-320)
+  int num = nc;
+  if (P.count_present) {
+    num = 0;
+    for (int c = 0; c < nc; c++) num += x.child_present(P, c) ? 1 : 0;
+  }
   if (num <= 1) return 1;
   int dist = 0, i = 0;
-  while (i < num) {
-    while (i < num && !x.has(P, i)) i++;
-    if (i == num) break;
+  while (i < nc) {
+    while (i < nc && !x.has(P, i)) i++;
+    if (i == nc) break;
     const int c1 = i++;
-    while (i < num && !x.has(P, i)) i++;
-    if (i == num) break;
+    while (i < nc && !x.has(P, i)) i++;
+    if (i == nc) break;
     const int c2 = i;  // (not consumed: it is the first of the next pair)
     x.reset(P, c1);
     x.reset(P, c2);
@@ -601,8 +614,10 @@ __device__ int prox_min_offset_delta(const ProxParams &P, ProxCtx<MAXL> &x) {
 
 template <int MAXL, typename EntryOf>
 __device__ __forceinline__ void prox_load(const ProxParams &P, const OffsetView &o, ProxCtx<MAXL> &x, EntryOf entry_of) {
+  x.present = 0;
   for (int l = 0; l < P.n_leaves; l++) {
     const uint32_t e = entry_of(l);
+    if (e != 0xFFFFFFFFu) x.present |= 1u << l;
     const bool on = o.off_pos[l] != nullptr && e != 0xFFFFFFFFu;
     x.leaf[l].p = on ? o.bytes[l] + o.off_pos[l][e] : nullptr;
     x.leaf[l].len = on ? o.off_len[l][e] : 0u;
@@ -612,7 +627,7 @@ __device__ __forceinline__ void prox_load(const ProxParams &P, const OffsetView 
 }
 
 template <int MAXL>
-__global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetView o, uint32_t n0,
+__global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetView o, LeafMap lm, uint32_t n0,
                                                           const uint32_t *__restrict__ pos, uint8_t *__restrict__ flags,
                                                           uint32_t *__restrict__ block_counts) {
   __shared__ uint32_t wave_cnt[4];
@@ -620,7 +635,11 @@ __global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetVi
   bool keep = i < n0 && flags[i];
   if (keep) {
     ProxCtx<MAXL> x;
-    prox_load<MAXL>(P, o, x, [&](int l) { return l == 0 ? i : pos[(size_t)(l - 1) * n0 + i]; });
+    prox_load<MAXL>(P, o, x, [&](int l) {
+      const uint32_t t = lm.leaf_list[l];
+      const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];
+      return lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
+    });
     keep = prox_within_range<MAXL>(P, x);
     flags[i] = keep ? 1 : 0;
   }
@@ -663,27 +682,54 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   const uint32_t dlen = known ? doc_len[id] : 0u;
   const uint32_t mfreq = (known && max_freq) ? max_freq[id] : 0u;
   double s = 0.0;
+  // The result tree (ScoreParams): root -> groups -> leaves.  fold(leaf) evaluates it the way the reference's
+  // recursions do (src/ext/default.c:68-106,164-209,262-302,378-455): an aggregate sums its children and multiplies by
+  // its weight; DISMAX takes the maximum over a UNION's children instead.  A leaf that did not match this document
+  // (union children) carries frequency 0 and contributes exactly 0.
+  auto fold = [&](auto leaf, bool dismax) {
+    double ret = 0.0;
+    for (int g = 0; g < P.n_groups; g++) {
+      const int a = P.group_first[g], b = P.group_first[g + 1];
+      double child;
+      if (P.group_op[g] == 0) {
+        child = leaf(a);
+      } else {
+        double acc = 0.0;
+        for (int t = a; t < b; t++) {
+          const double v = leaf(t);
+          acc = (dismax && P.group_op[g] == 1) ? (v > acc ? v : acc) : acc + v;
+        }
+        child = P.group_weight[g] * acc;
+      }
+      ret = (dismax && P.is_union) ? (child > ret ? child : ret) : ret + child;
+    }
+    return ret;
+  };
+  auto F = [&](int t) { return (double)freqs[(size_t)t * cap + h]; };
   // IndexResult_MinOffsetDelta of offset-less children = (children in the aggregate) - 1, at least 1
   // (reference src/index_result/index_result.c:51-103); a union's aggregate only holds the children that
   // matched this document (union_flat.rs:297-320)
   int slop = P.slops ? P.slops[h] : P.slop;
   if (P.is_union && !P.slops) {
     int matched = 0;
-    for (int t = 0; t < P.n_lists; t++) matched += freqs[(size_t)t * cap + h] ? 1 : 0;
+    for (int g = 0; g < P.n_groups; g++) {
+      bool any = false;
+      for (int t = P.group_first[g]; t < P.group_first[g + 1]; t++) any |= freqs[(size_t)t * cap + h] != 0;
+      matched += any ? 1 : 0;
+    }
     slop = matched > 1 ? matched - 1 : 1;
   }
   switch (P.scorer) {
     case 0:    // BM25STD      reference src/ext/default.c:241-316
     case 1: {  // BM25STD.TANH reference src/ext/default.c:329-359
       const float b = 0.75f, k1 = 1.2f;
-      double ret = 0.0;
-      for (int t = 0; t < P.n_lists; t++) {
-        const double f = (double)freqs[(size_t)t * cap + h];
+      double ret = fold([&](int t) {
+        const double f = F(t);
         // weight * idf * f * (k1 + 1) / (f + k1 * (1.0f - b + b * (float)doc_len/avg_doc_len))
         const double num = P.weight[t] * P.bm25_idf[t] * f * (double)(k1 + 1);
         const double den = f + (double)k1 * ((double)(1.0f - b) + (double)(b * (float)(int)dlen) / P.avg_doc_len);
-        ret += num / den;
-      }
+        return num / den;
+      }, false);
       ret *= P.root_weight;
       s = (double)dscore * ret;
       if (P.scorer == 1) s = tanh(P.inv_tanh * s);
@@ -691,11 +737,10 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
     }
     case 2: {  // legacy BM25 reference src/ext/default.c:164-233
       const float b = 0.5f, k1 = 1.2f;
-      double ret = 0.0;
-      for (int t = 0; t < P.n_lists; t++) {
-        const double f = (double)freqs[(size_t)t * cap + h];
-        ret += P.weight[t] * P.idf[t] * f / (f + (double)k1 * ((double)(1.0f - b) + (double)b * P.avg_doc_len));
-      }
+      double ret = fold([&](int t) {
+        const double f = F(t);
+        return P.weight[t] * P.idf[t] * f / (f + (double)k1 * ((double)(1.0f - b) + (double)b * P.avg_doc_len));
+      }, false);
       ret *= P.root_weight;
       s = (double)dscore * ret;
       if (s < P.min_score) s = 0.0;
@@ -706,8 +751,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
     case 4: {  // TFIDF.DOCNORM reference src/ext/default.c:149-153
       const uint32_t norm = P.scorer == 3 ? mfreq : dlen;
       if (dscore == 0.0f || norm == 0) { s = 0.0; break; }
-      double raw = 0.0;
-      for (int t = 0; t < P.n_lists; t++) raw += P.weight[t] * (double)freqs[(size_t)t * cap + h] * P.idf[t];
+      double raw = fold([&](int t) { return P.weight[t] * F(t) * P.idf[t]; }, false);
       raw *= P.root_weight;
       s = (double)dscore * raw / (double)norm;
       if (s < P.min_score) s = 0.0;
@@ -717,13 +761,8 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
     case 5:  // DOCSCORE reference src/ext/default.c:366-371
       s = (double)dscore;
       break;
-    default: {  // DISMAX reference src/ext/default.c:378-461
-      double ret = 0.0;
-      for (int t = 0; t < P.n_lists; t++) {  // intersection: sum of the children; union: their maximum
-        const double c = P.weight[t] * (double)freqs[(size_t)t * cap + h];
-        ret = P.is_union ? (c > ret ? c : ret) : ret + c;
-      }
-      s = P.root_weight * ret;
+    default: {  // DISMAX reference src/ext/default.c:378-461: an intersection sums its children, a union takes their maximum
+      s = P.root_weight * fold([&](int t) { return P.weight[t] * F(t); }, true);
       break;
     }
   }
@@ -838,18 +877,19 @@ void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, ui
 void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s) {
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total_out);
 }
-void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
-                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s, uint32_t *out_epos) {
-  hipLaunchKernelGGL(intersect_write_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_off,
+void launch_intersect_write(const ListView &v, const LeafMap &m, const uint8_t *flags, const uint32_t *pos,
+                            const uint32_t *block_off, uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
+                            uint32_t *out_epos) {
+  hipLaunchKernelGGL(intersect_write_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, m, flags, pos, block_off,
                      out_ids, out_freqs, cap, out_epos);
 }
-void launch_prox_filter(const ProxParams &p, const OffsetView &o, uint32_t n0, const uint32_t *pos, uint8_t *flags,
-                        uint32_t *block_counts, hipStream_t s) {
+void launch_prox_filter(const ProxParams &p, const OffsetView &o, const LeafMap &m, uint32_t n0, const uint32_t *pos,
+                        uint8_t *flags, uint32_t *block_counts, hipStream_t s) {
   if (!n0) return;
   const dim3 g(blocks_for(n0)), b(256);
-  if (p.n_leaves <= 4) hipLaunchKernelGGL(prox_filter_kernel<4>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
-  else if (p.n_leaves <= 8) hipLaunchKernelGGL(prox_filter_kernel<8>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
-  else hipLaunchKernelGGL(prox_filter_kernel<kMaxLists>, g, b, 0, s, p, o, n0, pos, flags, block_counts);
+  if (p.n_leaves <= 4) hipLaunchKernelGGL(prox_filter_kernel<4>, g, b, 0, s, p, o, m, n0, pos, flags, block_counts);
+  else if (p.n_leaves <= 8) hipLaunchKernelGGL(prox_filter_kernel<8>, g, b, 0, s, p, o, m, n0, pos, flags, block_counts);
+  else hipLaunchKernelGGL(prox_filter_kernel<kMaxLists>, g, b, 0, s, p, o, m, n0, pos, flags, block_counts);
 }
 void launch_prox_slop(const ProxParams &p, const OffsetView &o, const uint32_t *epos, uint32_t len, uint32_t cap,
                       int32_t *slops, hipStream_t s) {
@@ -866,10 +906,10 @@ void launch_union_prefix(const uint8_t *flags, uint32_t len, const uint32_t *blo
                          uint32_t *prefix, hipStream_t st) {
   hipLaunchKernelGGL(union_prefix_kernel, dim3(blocks_for(len + 1)), dim3(256), 0, st, flags, len, block_off, total, prefix);
 }
-void launch_union_write(const ListView &v, const UnionView &u, int s, const uint8_t *flags, uint32_t *out_ids,
-                        uint32_t *out_freqs, uint32_t cap, hipStream_t st) {
-  hipLaunchKernelGGL(union_write_kernel, dim3(blocks_for(v.len[s])), dim3(256), 0, st, v, u, s, flags, out_ids,
-                     out_freqs, cap);
+void launch_union_write(const ListView &v, const LeafMap &m, const UnionView &u, int s, const uint8_t *flags,
+                        uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st, uint32_t *out_epos) {
+  hipLaunchKernelGGL(union_write_kernel, dim3(blocks_for(v.len[s])), dim3(256), 0, st, v, m, u, s, flags, out_ids,
+                     out_freqs, cap, out_epos);
 }
 void launch_not_range(const uint32_t *child, uint32_t child_len, uint32_t max_doc, uint32_t *out_ids,
                       uint32_t *out_freqs, uint32_t cap, hipStream_t st) {

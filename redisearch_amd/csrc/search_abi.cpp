@@ -199,6 +199,13 @@ struct RSGPU_Hits {
   DevBuf<int32_t> slops;
   bool slops_ready = false;
   const RSGPU_Postings *src[kMaxLists] = {};
+  // result-tree shape for the scorers: the root's children ("groups") over the leaf columns; a flat list has one
+  // term group per leaf
+  int n_groups = 0;
+  uint8_t group_first[kMaxLists + 1] = {};
+  uint8_t group_op[kMaxLists] = {};  // 0 term, 1 union, 2 intersection
+  double group_weight[kMaxLists] = {};
+  std::vector<std::unique_ptr<RSGPU_Hits>> nested;  // the groups' own hit lists (their columns are borrowed)
   std::vector<uint32_t> h_ids;  // lazily mirrored
   const std::vector<uint32_t> &host_ids() {
     if (h_ids.size() != len) {
@@ -257,7 +264,46 @@ static void check_lists(const char *who, RSGPU_Postings *const *lists, size_t n_
   }
 }
 
-// helpers shared by RSGPU_Intersect(Ex) and the fused query ----------------------------------------------------------------
+// helpers shared by RSGPU_Intersect(Ex) / RSGPU_Union / RSGPU_EvalTree and the fused query --------------------------------
+// One child of the aggregate being built: a term's posting list, or the hit list of a nested union / intersection.
+struct Source {
+  const uint32_t *ids = nullptr;
+  uint32_t len = 0;
+  int n_leaves = 0;
+  const uint32_t *freq[kMaxLists] = {};
+  const uint32_t *epos[kMaxLists] = {};
+  const RSGPU_Postings *src[kMaxLists] = {};
+  int orig[kMaxLists] = {};  // the caller's list index of every leaf
+  int op = 0;                // 0 term, 1 union, 2 intersection
+  double weight = 1.0;
+};
+static Source term_source(RSGPU_Postings *p, int orig) {
+  Source s;
+  s.ids = p->ids.p;
+  s.len = p->n_entries;
+  s.n_leaves = 1;
+  s.freq[0] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
+  s.epos[0] = nullptr;  // the position IS the entry index
+  s.src[0] = p;
+  s.orig[0] = orig;
+  return s;
+}
+static Source hits_source(const RSGPU_Hits *g, int op, double weight) {
+  Source s;
+  s.ids = g->ids.p;
+  s.len = g->len;
+  s.n_leaves = g->n_lists;
+  for (int l = 0; l < g->n_lists; l++) {
+    s.freq[l] = g->freqs.p + (size_t)l * g->cap;
+    s.epos[l] = g->with_offsets ? g->epos.p + (size_t)l * g->cap : nullptr;
+    s.src[l] = g->src[l];
+    s.orig[l] = g->order[l];
+  }
+  s.op = op;
+  s.weight = weight;
+  return s;
+}
+
 static OffsetView offset_view(const RSGPU_Hits *h) {
   OffsetView o;
   memset(&o, 0, sizeof o);
@@ -269,67 +315,158 @@ static OffsetView offset_view(const RSGPU_Hits *h) {
   }
   return o;
 }
-static ProxParams flat_prox(const RSGPU_Hits *h, long max_slop, int in_order) {
+// proximity parameters of the hit list's own tree
+static ProxParams tree_prox(const RSGPU_Hits *h, long max_slop, int in_order) {
   ProxParams P;
   memset(&P, 0, sizeof P);
-  P.n_children = P.n_leaves = h->n_lists;
-  for (int c = 0; c <= h->n_lists; c++) P.child_first[c] = (uint8_t)c;
+  P.n_children = h->n_groups;
+  P.n_leaves = h->n_lists;
+  for (int g = 0; g <= h->n_groups; g++) P.child_first[g] = h->group_first[g];
+  for (int g = 0; g < h->n_groups; g++) P.is_agg[g] = h->group_op[g] != 0;
   P.max_slop = max_slop < 0 ? -1 : (int)std::min<long>(max_slop, 0x7FFFFFFF);
   P.in_order = in_order;
+  P.count_present = h->is_union ? 1 : 0;
   return P;
 }
 
-// Enqueues decode (cached) + probe [+ proximity filter] + scan + write on c->stream; *total_out (pinned host memory)
-// receives the hit count once the stream has been synchronised.  max_slop < 0: no slop constraint.
-static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t n_lists, QueryCtx *c, Scratch &sc,
-                            uint32_t *total_out, long max_slop = -1, int in_order = 0) {
-  std::iota(h->order, h->order + n_lists, 0);
-  // children ordered by estimated size, ascending and stable (reference intersection.rs:94-119); in_order keeps the
-  // caller's order -- it is the order the terms must appear in
-  if (!in_order)
-    std::stable_sort(h->order, h->order + n_lists, [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
-  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
-  ListView v;
+// Lays the sources out as the aggregate's children (ListView slot = group, leaves flattened in order) and records the
+// tree shape in the hit list.  Returns the leaf map for the write / proximity kernels.
+static LeafMap adopt_sources(RSGPU_Hits *h, const std::vector<Source> &srcs, ListView &v) {
   memset(&v, 0, sizeof v);
-  v.n = (int)n_lists;
+  LeafMap m;
+  memset(&m, 0, sizeof m);
+  v.n = (int)srcs.size();
+  h->n_groups = (int)srcs.size();
   h->with_offsets = false;
-  for (size_t s = 0; s < n_lists; s++) {
-    RSGPU_Postings *p = lists[h->order[s]];
-    v.ids[s] = p->ids.p;
-    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
-    v.len[s] = p->n_entries;
-    h->src[s] = p;
-    h->with_offsets |= p->has_offsets();
+  int leaf = 0;
+  for (size_t g = 0; g < srcs.size(); g++) {
+    const Source &s = srcs[g];
+    v.ids[g] = s.ids;
+    v.len[g] = s.len;
+    h->group_first[g] = (uint8_t)leaf;
+    h->group_op[g] = (uint8_t)s.op;
+    h->group_weight[g] = s.weight;
+    for (int l = 0; l < s.n_leaves; l++, leaf++) {
+      m.leaf_list[leaf] = (uint8_t)g;
+      m.leaf_freq[leaf] = s.freq[l];
+      m.leaf_epos[leaf] = s.epos[l];
+      h->src[leaf] = s.src[l];
+      h->order[leaf] = s.orig[l];
+      h->with_offsets |= s.src[l]->has_offsets();
+    }
   }
+  h->group_first[srcs.size()] = (uint8_t)leaf;
+  h->n_lists = m.n_leaves = leaf;
+  return m;
+}
+
+// AND of the sources (already in iteration order; source 0 drives).  Enqueues probe [+ proximity filter] + scan + write
+// on c->stream; *total_out (pinned host memory) receives the hit count once the stream has been synchronised.
+static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx *c, Scratch &sc, uint32_t *total_out,
+                        long max_slop, int in_order) {
+  ListView v;
+  const LeafMap m = adopt_sources(h, srcs, v);
+  h->is_union = false;
   const uint32_t n0 = v.len[0];
   h->cap = std::max<uint32_t>(n0, 1);
   h->ids.alloc(h->cap);
-  h->freqs.alloc((size_t)h->cap * n_lists);
-  if (h->with_offsets) h->epos.alloc((size_t)h->cap * n_lists);
+  h->freqs.alloc((size_t)h->cap * h->n_lists);
+  if (h->with_offsets) h->epos.alloc((size_t)h->cap * h->n_lists);
   *total_out = 0;
   if (n0 == 0) return;
   const uint32_t nb = (n0 + 255) / 256;
   sc.flags.ensure(n0);
-  sc.pos.ensure((size_t)n0 * std::max<size_t>(n_lists - 1, 1));
+  sc.pos.ensure((size_t)n0 * std::max<size_t>(srcs.size() - 1, 1));
   sc.block_counts.ensure(nb);
   launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
-  if ((max_slop >= 0 || in_order) && n_lists > 1 && h->with_offsets) {
+  if ((max_slop >= 0 || in_order) && srcs.size() > 1 && h->with_offsets) {
     // Intersection::current_is_relevant (intersection.rs:205-215): a consensus document outside the window is dropped
-    const ProxParams P = flat_prox(h, max_slop, in_order);
-    launch_prox_filter(P, offset_view(h), n0, sc.pos.p, sc.flags.p, sc.block_counts.p, c->stream);
+    launch_prox_filter(tree_prox(h, max_slop, in_order), offset_view(h), m, n0, sc.pos.p, sc.flags.p, sc.block_counts.p,
+                       c->stream);
   }
   launch_scan_counts(sc.block_counts.p, nb, total_out, c->stream);  // total_out: pinned host memory
-  launch_intersect_write(v, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream,
+  launch_intersect_write(v, m, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream,
                          h->with_offsets ? h->epos.p : nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
+// OR of the sources (union_flat.rs:223-257,297-320); synchronises the stream (the total comes from per-source counts)
+static void combine_or(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx *c, Scratch &sc) {
+  ListView v;
+  const LeafMap m = adopt_sources(h, srcs, v);
+  h->is_union = true;
+  const size_t n = srcs.size();
+  size_t sum = 0, max_len = 0;
+  for (size_t s = 0; s < n; s++) {
+    sum += v.len[s];
+    max_len = std::max<size_t>(max_len, v.len[s]);
+  }
+  if (sum > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_Union: more than 2^32 postings");
+  h->cap = (uint32_t)std::max<size_t>(sum, 1);
+  h->ids.alloc(h->cap);
+  h->freqs.alloc((size_t)h->cap * h->n_lists);
+  if (h->with_offsets) h->epos.alloc((size_t)h->cap * h->n_lists);
+  h->len = 0;
+  if (!sum) return;
+  // flags of all sources back to back, prefix arrays [len+1] back to back, one block-count array per source
+  sc.flags.ensure(sum);
+  sc.pos.ensure(sum + n);
+  const uint32_t nb_max = (uint32_t)((max_len + 256) / 256 + 1);
+  sc.block_counts.ensure((size_t)nb_max * n);
+  sc.total.ensure(n);
+  UnionView u;
+  memset(&u, 0, sizeof u);
+  size_t foff = 0, poff = 0;
+  std::vector<size_t> flag_at(n);
+  for (size_t s = 0; s < n; s++) {
+    const uint32_t len = v.len[s], nb = (len + 255) / 256;
+    uint32_t *bc = sc.block_counts.p + s * nb_max;
+    flag_at[s] = foff;
+    u.prefix[s] = sc.pos.p + poff;
+    if (len) {
+      launch_union_flag(v, (int)s, sc.flags.p + foff, bc, c->stream);
+      launch_scan_counts(bc, nb, sc.total.p + s, c->stream);
+    } else {
+      HIP_CHECK(hipMemsetAsync(sc.total.p + s, 0, sizeof(uint32_t), c->stream));
+    }
+    launch_union_prefix(sc.flags.p + foff, len, bc, sc.total.p + s, sc.pos.p + poff, c->stream);
+    foff += len;
+    poff += len + 1;
+  }
+  for (size_t s = 0; s < n; s++)
+    if (v.len[s])
+      launch_union_write(v, m, u, (int)s, sc.flags.p + flag_at[s], h->ids.p, h->freqs.p, h->cap, c->stream,
+                         h->with_offsets ? h->epos.p : nullptr);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> totals(n);
+  HIP_CHECK(hipMemcpyAsync(totals.data(), sc.total.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  for (uint32_t t : totals) total += t;
+  h->len = (uint32_t)total;
+}
+
+// flat AND of posting lists: decode (cached) + combine_and over term sources
+static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t n_lists, QueryCtx *c, Scratch &sc,
+                            uint32_t *total_out, long max_slop = -1, int in_order = 0) {
+  std::vector<int> order(n_lists);
+  std::iota(order.begin(), order.end(), 0);
+  // children ordered by estimated size, ascending and stable (reference intersection.rs:94-119); in_order keeps the
+  // caller's order -- it is the order the terms must appear in
+  if (!in_order)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
+  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
+  std::vector<Source> srcs;
+  for (size_t s = 0; s < n_lists; s++) srcs.push_back(term_source(lists[order[s]], order[s]));
+  combine_and(h, srcs, c, sc, total_out, max_slop, in_order);
+}
+
 // per-hit slop from the term offsets, once per hit list (a no-op for lists without offsets)
 static const int32_t *hit_slops(RSGPU_Hits *h, QueryCtx *c) {
-  if (!h->with_offsets || h->is_union || h->n_lists < 2 || !h->len) return nullptr;
+  if (!h->with_offsets || h->n_groups < 2 || !h->len) return nullptr;
   if (!h->slops_ready) {
     h->slops.ensure(h->cap);
-    launch_prox_slop(flat_prox(h, -1, 0), offset_view(h), h->epos.p, h->len, h->cap, h->slops.p, c->stream);
+    launch_prox_slop(tree_prox(h, -1, 0), offset_view(h), h->epos.p, h->len, h->cap, h->slops.p, c->stream);
     HIP_CHECK(hipGetLastError());
     h->slops_ready = true;
   }
@@ -337,6 +474,19 @@ static const int32_t *hit_slops(RSGPU_Hits *h, QueryCtx *c) {
 }
 static bool slop_dependent(int scorer) {
   return scorer == RSGPU_SCORER_TFIDF || scorer == RSGPU_SCORER_TFIDF_DOCNORM || scorer == RSGPU_SCORER_BM25;
+}
+static void tree_score_params(ScoreParams &P, const RSGPU_Hits *h) {
+  P.n_lists = h->n_lists;
+  P.n_groups = h->n_groups;
+  for (int g = 0; g <= h->n_groups; g++) P.group_first[g] = h->group_first[g];
+  for (int g = 0; g < h->n_groups; g++) {
+    P.group_op[g] = h->group_op[g];
+    P.group_weight[g] = h->group_weight[g];
+  }
+  // IndexResult_MinOffsetDelta over children without offsets returns num-1 (reference
+  // src/index_result/index_result.c:102), 1 for a single child
+  P.slop = h->n_groups > 1 ? h->n_groups - 1 : 1;
+  P.is_union = h->is_union ? 1 : 0;
 }
 
 extern "C" {
@@ -480,67 +630,95 @@ RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
   auto *h = new RSGPU_Hits();
   std::unique_ptr<RSGPU_Hits> guard(h);
   h->device = device;
-  h->n_lists = (int)n_lists;
-  h->is_union = true;
-  std::iota(h->order, h->order + n_lists, 0);  // caller order: a union has no driving child
   StageTimer td(c.c, 0);
   for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c.c);
   td.stop();
-  ListView v;
-  memset(&v, 0, sizeof v);
-  v.n = (int)n_lists;
-  size_t sum = 0, max_len = 0;
-  for (size_t s = 0; s < n_lists; s++) {
-    RSGPU_Postings *p = lists[s];
-    v.ids[s] = p->ids.p;
-    v.freqs[s] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
-    v.len[s] = p->n_entries;
-    h->src[s] = p;
-    sum += p->n_entries;
-    max_len = std::max<size_t>(max_len, p->n_entries);
-  }
-  if (sum > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_Union: more than 2^32 postings");
-  h->cap = (uint32_t)std::max<size_t>(sum, 1);
-  h->ids.alloc(h->cap);
-  h->freqs.alloc((size_t)h->cap * n_lists);
-  if (!sum) return guard.release();
-  Scratch &sc = scratch(device);
-  // flags of all lists back to back, prefix arrays [len+1] back to back, one block-count array per list
-  sc.flags.ensure(sum);
-  sc.pos.ensure(sum + n_lists);
-  const uint32_t nb_max = (uint32_t)((max_len + 256) / 256 + 1);
-  sc.block_counts.ensure((size_t)nb_max * n_lists);
-  sc.total.ensure(n_lists);
-  UnionView u;
-  memset(&u, 0, sizeof u);
+  std::vector<Source> srcs;  // caller order: a union has no driving child
+  for (size_t s = 0; s < n_lists; s++) srcs.push_back(term_source(lists[s], (int)s));
   StageTimer ti(c.c, 1);
-  size_t foff = 0, poff = 0;
-  std::vector<size_t> flag_at(n_lists);
-  for (size_t s = 0; s < n_lists; s++) {
-    const uint32_t len = v.len[s], nb = (len + 255) / 256;
-    uint32_t *bc = sc.block_counts.p + s * nb_max;
-    flag_at[s] = foff;
-    u.prefix[s] = sc.pos.p + poff;
-    if (len) {
-      launch_union_flag(v, (int)s, sc.flags.p + foff, bc, c->stream);
-      launch_scan_counts(bc, nb, sc.total.p + s, c->stream);
-    } else {
-      HIP_CHECK(hipMemsetAsync(sc.total.p + s, 0, sizeof(uint32_t), c->stream));
-    }
-    launch_union_prefix(sc.flags.p + foff, len, bc, sc.total.p + s, sc.pos.p + poff, c->stream);
-    foff += len;
-    poff += len + 1;
-  }
-  for (size_t s = 0; s < n_lists; s++)
-    if (v.len[s]) launch_union_write(v, u, (int)s, sc.flags.p + flag_at[s], h->ids.p, h->freqs.p, h->cap, c->stream);
-  HIP_CHECK(hipGetLastError());
+  combine_or(h, srcs, c.c, scratch(device));
   ti.stop();
-  std::vector<uint32_t> totals(n_lists);
-  HIP_CHECK(hipMemcpyAsync(totals.data(), sc.total.p, n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_CHECK(hipStreamSynchronize(c->stream));
-  uint64_t total = 0;
-  for (uint32_t t : totals) total += t;
-  h->len = (uint32_t)total;
+  return guard.release();
+  S_CATCH(nullptr)
+}
+
+/* Two-level query tree: root (AND / OR) over groups, each a term or an OR / AND of terms -- e.g. the stemmer's
+ * (run|running|ran) (shoe|shoes), or (a b) | (c d).  Nested groups are evaluated first (their hit lists stay alive
+ * inside the result), the root then combines the groups' id lists and carries every term's frequency and entry index
+ * along, so that scoring sees the reference's result tree (Intersection{Union{..},Union{..}} etc.). */
+RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
+  if (!q || !q->lists || !q->n_groups || !q->group_first) {
+    last_error() = "RSGPU_EvalTree: empty tree";
+    return nullptr;
+  }
+  S_TRY
+  const size_t n_lists = q->group_first[q->n_groups];
+  if (q->n_groups > (size_t)kMaxLists || n_lists > (size_t)kMaxLists || !n_lists)
+    throw std::runtime_error("RSGPU_EvalTree: at most 32 groups and 32 terms");
+  if (q->root_op != RSGPU_OP_INTERSECT && q->root_op != RSGPU_OP_UNION) throw std::runtime_error("RSGPU_EvalTree: bad root_op");
+  check_lists("RSGPU_EvalTree", q->lists, n_lists);
+  const int device = q->lists[0]->device;
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  Scratch &sc = scratch(device);
+  auto *h = new RSGPU_Hits();
+  std::unique_ptr<RSGPU_Hits> guard(h);
+  h->device = device;
+  for (size_t l = 0; l < n_lists; l++) decode_on(q->lists[l], c.c);
+  struct Grp {
+    Source s;
+    size_t estimate;
+    int index;
+  };
+  std::vector<Grp> groups;
+  for (size_t g = 0; g < q->n_groups; g++) {
+    const size_t a = q->group_first[g], b = q->group_first[g + 1];
+    if (b <= a || b > n_lists) throw std::runtime_error("RSGPU_EvalTree: bad group_first");
+    const int op = q->group_op ? q->group_op[g] : RSGPU_OP_TERM;
+    const double w = q->group_weight ? q->group_weight[g] : 1.0;
+    if (op == RSGPU_OP_TERM || b - a == 1) {
+      if (b - a != 1) throw std::runtime_error("RSGPU_EvalTree: a term group holds exactly one list");
+      if (op == RSGPU_OP_TERM) {
+        groups.push_back(Grp{term_source(q->lists[a], (int)a), q->lists[a]->n_entries, (int)g});
+        continue;
+      }
+    }
+    // nested aggregate: its own hit list first
+    std::unique_ptr<RSGPU_Hits> sub(new RSGPU_Hits());
+    sub->device = device;
+    std::vector<int> order(b - a);
+    std::iota(order.begin(), order.end(), (int)a);
+    if (op == RSGPU_OP_INTERSECT)
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return q->lists[x]->n_entries < q->lists[y]->n_entries; });
+    std::vector<Source> srcs;
+    for (int li : order) srcs.push_back(term_source(q->lists[li], li));
+    size_t est = 0;
+    if (op == RSGPU_OP_INTERSECT) {
+      combine_and(sub.get(), srcs, c.c, sc, c->h_counters, -1, 0);
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      sub->len = c->h_counters[0];
+      est = q->lists[order[0]]->n_entries;  // num_estimated of an intersection: its smallest child
+    } else if (op == RSGPU_OP_UNION) {
+      combine_or(sub.get(), srcs, c.c, sc);
+      for (int li : order) est += q->lists[li]->n_entries;  // ... of a union: the sum
+    } else {
+      throw std::runtime_error("RSGPU_EvalTree: bad group_op");
+    }
+    groups.push_back(Grp{hits_source(sub.get(), op == RSGPU_OP_UNION ? 1 : 2, w), est, (int)g});
+    h->nested.push_back(std::move(sub));
+  }
+  std::vector<Source> srcs;
+  if (q->root_op == RSGPU_OP_INTERSECT) {
+    // children sorted by estimate, ascending and stable, unless in_order pins the caller's order
+    if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const Grp &x, const Grp &y) { return x.estimate < y.estimate; });
+    for (auto &g : groups) srcs.push_back(g.s);
+    combine_and(h, srcs, c.c, sc, c->h_counters, q->max_slop, q->in_order);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    h->len = c->h_counters[0];
+  } else {
+    for (auto &g : groups) srcs.push_back(g.s);
+    combine_or(h, srcs, c.c, sc);
+  }
   return guard.release();
   S_CATCH(nullptr)
 }
@@ -562,6 +740,12 @@ RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t 
   h->device = device;
   h->n_lists = 1;  // one virtual child: freq 1; the caller scores it with idf = 1 (src/ext/default.c:289-293)
   h->order[0] = 0;
+  h->n_groups = 1;
+  h->group_first[0] = 0;
+  h->group_first[1] = 1;
+  h->group_op[0] = 0;
+  h->group_weight[0] = 1.0;
+  h->src[0] = child;
   StageTimer td(c.c, 0);
   decode_on(child, c.c);
   if (universe) decode_on(universe, c.c);
@@ -652,15 +836,11 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   // scorer in the reference pipeline, src/pipeline/pipeline_construction.c:546-547)
   const bool max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
   P.scorer = max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
-  P.n_lists = h->n_lists;
+  tree_score_params(P, h);
   P.avg_doc_len = a->avg_doc_len;
   P.root_weight = a->root_weight;
   P.min_score = a->min_score;
   P.inv_tanh = a->tanh_factor ? 1 / (double)a->tanh_factor : 0.0;
-  // IndexResult_MinOffsetDelta over children without offsets returns num-1 (reference
-  // src/index_result/index_result.c:102), 1 for a single child
-  P.slop = h->n_lists > 1 ? h->n_lists - 1 : 1;
-  P.is_union = h->is_union ? 1 : 0;
   for (int s = 0; s < h->n_lists; s++) {
     int o = h->order[s];
     P.idf[s] = a->idf ? a->idf[o] : 0.0;
@@ -669,14 +849,7 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   }
   h->scores.ensure(h->cap);
   h->keys.ensure(h->cap);
-  if (slop_dependent(P.scorer)) {
-    if (h->is_union)
-      for (int s2 = 0; s2 < h->n_lists; s2++)
-        if (h->src[s2] && h->src[s2]->has_offsets())
-          throw std::runtime_error("slop-dependent scorers (TFIDF, TFIDF.DOCNORM, BM25) over a union of lists that carry "
-                                   "term offsets are not served: the union keeps no per-term positions");
-    P.slops = hit_slops(h, c.c);  // IndexResult_MinOffsetDelta from the term offsets where the lists carry them
-  }
+  if (slop_dependent(P.scorer)) P.slops = hit_slops(h, c.c);  // IndexResult_MinOffsetDelta from the term offsets
   StageTimer ts(c.c, 2);
   launch_score(P, h->ids.p, h->freqs.p, h->len, h->cap, t->doc_len.p, t->doc_score.p,
                t->max_freq.p, t->n, h->scores.p, h->keys.p, c->stream);
@@ -811,13 +984,11 @@ static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_S
   memset(&P, 0, sizeof P);
   *max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
   P.scorer = *max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
-  P.n_lists = h->n_lists;
+  tree_score_params(P, h);
   P.avg_doc_len = a->avg_doc_len;
   P.root_weight = a->root_weight;
   P.min_score = a->min_score;
   P.inv_tanh = a->tanh_factor ? 1 / (double)a->tanh_factor : 0.0;
-  P.slop = h->n_lists > 1 ? h->n_lists - 1 : 1;
-  P.is_union = h->is_union ? 1 : 0;
   for (int s = 0; s < h->n_lists; s++) {
     int o = h->order[s];
     P.idf[s] = a->idf ? a->idf[o] : 0.0;

@@ -33,14 +33,25 @@ struct ListView {
   uint32_t len[kMaxLists];
   int n;  // lists; list 0 drives (the shortest)
 };
+// How the term ("leaf") columns of a hit list hang off the lists of a ListView: a list is a term's posting list (one
+// leaf, its own freq column, entry index = position) or the hit list of a nested union / intersection (several
+// leaves, each with a freq column and an entry-index column indexed by the position in that hit list).
+struct LeafMap {
+  int n_leaves;
+  uint8_t leaf_list[kMaxLists];          // ListView slot the leaf belongs to
+  const uint32_t *leaf_freq[kMaxLists];  // [position in that list] -> frequency (NULL: 0)
+  const uint32_t *leaf_epos[kMaxLists];  // [position in that list] -> entry index in the term's posting list
+                                         // (NULL: the position itself; 0xFFFFFFFF: the leaf did not match)
+};
 // probe: for every element of list 0, binary-search the other lists; flags[i]=1 on consensus,
 // pos[(l-1)*len0 + i] = match position in list l; block_counts[b] = hits in block b
 void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s);
 // exclusive scan of block_counts[0..nb) in place, total -> total_out[0]
 void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s);
-// ordered compaction: out_ids[h], out_freqs[l*cap + h]; out_epos[l*cap + h] (optional) = the hit's entry index in list l
-void launch_intersect_write(const ListView &v, const uint8_t *flags, const uint32_t *pos, const uint32_t *block_off,
-                            uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
+// ordered compaction: out_ids[h], out_freqs[leaf*cap + h]; out_epos[leaf*cap + h] (optional) = the hit's entry index in
+// the leaf's posting list
+void launch_intersect_write(const ListView &v, const LeafMap &m, const uint8_t *flags, const uint32_t *pos,
+                            const uint32_t *block_off, uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
                             uint32_t *out_epos = nullptr);
 
 // ---- proximity over the term offsets (reference index_result/src/core/proximity.rs, index_result.c:51-103) ----------
@@ -58,11 +69,12 @@ struct ProxParams {
   uint8_t is_agg[kMaxLists];
   int max_slop;  // < 0: no slop constraint
   int in_order;
+  int count_present;  // the aggregate is a UNION: children that did not match this document are not part of it
 };
 // filter the candidates of the probe: flags[i] &= within_range(candidate i); block_counts recomputed.
 // candidate i's entry index is i in leaf 0 and pos[(l-1)*n0 + i] in leaf l.
-void launch_prox_filter(const ProxParams &p, const OffsetView &o, uint32_t n0, const uint32_t *pos, uint8_t *flags,
-                        uint32_t *block_counts, hipStream_t s);
+void launch_prox_filter(const ProxParams &p, const OffsetView &o, const LeafMap &m, uint32_t n0, const uint32_t *pos,
+                        uint8_t *flags, uint32_t *block_counts, hipStream_t s);
 // slops[h] = IndexResult_MinOffsetDelta of hit h (entry indices epos[l*cap + h], 0xFFFFFFFF = leaf absent)
 void launch_prox_slop(const ProxParams &p, const OffsetView &o, const uint32_t *epos, uint32_t len, uint32_t cap,
                       int32_t *slops, hipStream_t s);
@@ -74,8 +86,9 @@ struct UnionView {
 void launch_union_flag(const ListView &v, int s, uint8_t *flags, uint32_t *block_counts, hipStream_t st);
 void launch_union_prefix(const uint8_t *flags, uint32_t len, const uint32_t *block_off, const uint32_t *total,
                          uint32_t *prefix, hipStream_t st);
-void launch_union_write(const ListView &v, const UnionView &u, int s, const uint8_t *flags, uint32_t *out_ids,
-                        uint32_t *out_freqs, uint32_t cap, hipStream_t st);
+// out_epos (optional): entry index per leaf, 0xFFFFFFFF where the leaf's list does not hold the document
+void launch_union_write(const ListView &v, const LeafMap &m, const UnionView &u, int s, const uint8_t *flags,
+                        uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st, uint32_t *out_epos = nullptr);
 // NOT: doc ids 1..max_doc (or the entries of `universe`) the child does not hold, freq 1 (virtual results)
 void launch_not_range(const uint32_t *child, uint32_t child_len, uint32_t max_doc, uint32_t *out_ids,
                       uint32_t *out_freqs, uint32_t cap, hipStream_t st);
@@ -90,7 +103,14 @@ struct ScoreParams {
   int scorer, n_lists;
   double avg_doc_len, root_weight, min_score, inv_tanh;
   double idf[kMaxLists], bm25_idf[kMaxLists], weight[kMaxLists];
-  int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_lists-1, 1)
+  // result tree: the root (intersection, or union when is_union) has n_groups children; child g is leaf
+  // group_first[g] alone (group_op 0) or a union (1) / intersection (2) of the leaves [group_first[g], group_first[g+1])
+  // with weight group_weight[g].  Flat hit lists: one term group per leaf.
+  int n_groups;
+  uint8_t group_first[kMaxLists + 1];
+  uint8_t group_op[kMaxLists];
+  double group_weight[kMaxLists];
+  int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_groups-1, 1)
   const int32_t *slops;  // per-hit slop computed from the term offsets (launch_prox_slop); NULL: the constant above
   int is_union;  // hits come from RSGPU_Union: per-hit slop from the matched children, DISMAX takes the maximum
 };

@@ -27,7 +27,15 @@ class HybridQueryArgs(C.Structure):
                 ("knn_dists", _vp), ("n_hits", _sz), ("n_top", _sz), ("n_knn", _sz), ("hits_out", _vp)]
 
 
+class TreeQuery(C.Structure):
+    _fields_ = [("root_op", _i), ("n_groups", _sz), ("group_first", _vp), ("group_op", _vp), ("group_weight", _vp),
+                ("lists", _vp), ("max_slop", C.c_long), ("in_order", _i)]
+
+
+OP_TERM, OP_UNION, OP_INTERSECT = 0, 1, 2
+
 ABI = {
+    "RSGPU_EvalTree": (_vp, [C.POINTER(TreeQuery)]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
@@ -230,6 +238,29 @@ def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight
     if lib.RSGPU_HybridQuery(C.byref(a)) != 0:
         raise RuntimeError(V.last_error())
     return dict(n_hits=a.n_hits, top=(ti[:a.n_top], ts[:a.n_top]), knn=(ki[:a.n_knn], kd[:a.n_knn]))
+
+
+class TreeHits(Hits):
+    """RSGPU_EvalTree: root_op over groups; groups = [(op, weight, [Postings...]), ...] (op OP_TERM takes one list).
+    Scoring arrays (idf, bm25_idf, weight) are per list in the flattened order of `groups`."""
+
+    def __init__(self, root_op, groups, max_slop=None, in_order=False):
+        self.lib = load()
+        flat, first, ops, ws = [], [0], [], []
+        for op, w, ls in groups:
+            flat += list(ls)
+            first.append(len(flat))
+            ops.append(op)
+            ws.append(w)
+        self._lists = flat
+        self.n_lists = len(flat)
+        arr = (_vp * len(flat))(*[l.ptr for l in flat])
+        gf = np.asarray(first, np.uint64)
+        go = np.asarray(ops, np.int32)
+        gw = np.asarray(ws, np.float64)
+        q = TreeQuery(root_op, len(groups), _p(gf).value, _p(go).value, _p(gw).value, C.cast(arr, _vp).value,
+                      -1 if max_slop is None else int(max_slop), int(in_order))
+        self.ptr = _check(self.lib.RSGPU_EvalTree(C.byref(q)), "RSGPU_EvalTree")
 
 
 def intersect(lists, max_slop=None, in_order=False):
