@@ -275,8 +275,10 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   key_bytes = key_bytes_of(ktype);
   elem_bytes_ = dim * type_size(type);
   stride_ = round_up(elem_bytes_, 16);
-  if (type == VecSimType_FLOAT32 && metric == VecSimMetric_Cosine && !multi)
-    shadow_ = scan_tuning().shadow8 ? 2 : (scan_tuning().shadow16 ? 1 : 0);
+  if (type == VecSimType_FLOAT32 && !multi) {
+    if (scan_tuning().shadow8) shadow_ = 2;  // every metric (the error band carries the norms)
+    else if (scan_tuning().shadow16 && metric == VecSimMetric_Cosine) shadow_ = 1;
+  }
   sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ == 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
@@ -285,8 +287,8 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   scan_tuning().num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&wstream_, hipStreamNonBlocking));
   if (shadow_ == 2) {
-    HIP_CHECK(hipMalloc((void **)&d_smax_, sizeof(uint32_t)));
-    HIP_CHECK(hipMemset(d_smax_, 0, sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc((void **)&d_smax_, 4 * sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d_smax_, 0, 4 * sizeof(uint32_t)));
   }
   // staging block: up to 4096 rows or 8 MiB
   stage_cap_ = std::max<size_t>(1, std::min<size_t>(4096, (8u << 20) / stride_));
@@ -309,7 +311,7 @@ FlatIndex::~FlatIndex() {
 }
 
 size_t FlatIndex::memory() const {
-  return rows_buf_.physical() + shadow_buf_.physical() + cap_rows_ * ((shadow_ == 2 ? 4 : 0) + sizeof(uint64_t)) +
+  return rows_buf_.physical() + shadow_buf_.physical() + cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
          host_bytes_ + stage_cap_ * stride_;
 }
 
@@ -347,10 +349,10 @@ void FlatIndex::grow(size_t min_rows) {
     }
   } rollback{{(void **)&nl, (void **)&nsc}};
   HIP_CHECK(hipMalloc((void **)&nl, new_cap * sizeof(uint64_t)));
-  if (shadow_ == 2) HIP_CHECK(hipMalloc((void **)&nsc, new_cap * sizeof(float)));
+  if (shadow_ == 2) HIP_CHECK(hipMalloc((void **)&nsc, new_cap * 2 * sizeof(float)));
   if (n_rows_) {
     HIP_CHECK(hipMemcpyAsync(nl, d_labels_, (size_t)n_rows_ * sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
-    if (nsc) HIP_CHECK(hipMemcpyAsync(nsc, d_sscale_, (size_t)n_rows_ * sizeof(float), hipMemcpyDeviceToDevice, wstream_));
+    if (nsc) HIP_CHECK(hipMemcpyAsync(nsc, d_sscale_, (size_t)n_rows_ * 2 * sizeof(float), hipMemcpyDeviceToDevice, wstream_));
     HIP_CHECK(hipStreamSynchronize(wstream_));
   }
   rollback.armed = false;
@@ -372,10 +374,12 @@ void FlatIndex::shadow_convert(uint32_t row_begin, uint32_t row_end) {
     return;
   }
   launch_shadow8_rows(d_rows_, stride_, (uint32_t)dim, row_begin, row_end, d_shadow_, sstride_, d_sscale_, d_smax_, wstream_);
-  uint32_t bits = 0;
-  HIP_CHECK(hipMemcpyAsync(&bits, d_smax_, sizeof bits, hipMemcpyDeviceToHost, wstream_));
+  uint32_t bits[4] = {0, 0, 0, 0};
+  HIP_CHECK(hipMemcpyAsync(bits, d_smax_, sizeof bits, hipMemcpyDeviceToHost, wstream_));
   HIP_CHECK(hipStreamSynchronize(wstream_));
-  memcpy(&s_max_, &bits, 4);
+  memcpy(&s_max_, &bits[0], 4);
+  memcpy(&n2_max_, &bits[1], 4);
+  s_bad_ = bits[2] != 0;
 }
 
 void FlatIndex::reserve(size_t rows) {
@@ -497,7 +501,8 @@ int FlatIndex::remove(size_t label) {
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
                                  hipMemcpyDeviceToDevice, wstream_));
       if (shadow_ == 2)
-        HIP_CHECK(hipMemcpyAsync(d_sscale_ + r, d_sscale_ + last, sizeof(float), hipMemcpyDeviceToDevice, wstream_));
+        HIP_CHECK(hipMemcpyAsync(d_sscale_ + 2 * (size_t)r, d_sscale_ + 2 * (size_t)last, 2 * sizeof(float), hipMemcpyDeviceToDevice,
+                                 wstream_));
       row_label_[r] = moved;
       if (multi) {
         auto &v = rows_slot(moved);
@@ -818,35 +823,50 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
     if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_F16, KM_IP, 0, n, c->d_query + q16_off, c->d_keys, c->stream);
   } else {
-    // int8 shadow: x = sx (x8 + ex), q = sq (q8 + eq), |ex_i|, |eq_i| <= 1/2, so for unit vectors
-    //   |sx sq x8.q8 - x.q| <= sx (1 + sq sqrt(d)/2) sqrt(d)/2 + sq (1 + sx sqrt(d)/2) sqrt(d)/2 + sx sq d/4
-    //                        = (sx + sq) sqrt(d)/2 + (3/4) sx sq d,   sx <= s_max over all rows
+    // int8 shadow: x = sx (x8 + ex), q = sq (q8 + eq), |ex_i|, |eq_i| <= 1/2, so
+    //   |sx sq x8.q8 - x.q| <= sx (|q| + sq sqrt(d)/2) sqrt(d)/2 + sq (|x| + sx sqrt(d)/2) sqrt(d)/2 + sx sq d/4
+    //                        = (sx |q| + sq |x|) sqrt(d)/2 + (3/4) sx sq d,   sx <= s_max, |x| <= n_max over all rows
+    // (unit vectors: (sx + sq) sqrt(d)/2 + ...).  IP / cosine distance 1 - x.q: that band; L2 = |q|^2 + |x|^2 - 2 x.q:
+    // twice the band, |x|^2 taken from the fp32 row at add time.
     float qmax = 0.0f;
-    for (size_t i = 0; i < dim; i++) qmax = std::max(qmax, std::fabs(qf[i]));
-    if (!(qmax > 0.0f) || !(s_max_ > 0.0f)) return false;
+    double qn2 = 0.0;
+    for (size_t i = 0; i < dim; i++) {
+      qmax = std::max(qmax, std::fabs(qf[i]));
+      qn2 += (double)qf[i] * (double)qf[i];
+    }
+    if (!(qmax > 0.0f) || !(s_max_ > 0.0f) || s_bad_ || !std::isfinite(qn2) || !std::isfinite(n2_max_)) return false;
     const float sq = qmax / 127.0f;
+    const float qn = (float)std::sqrt(qn2) * 1.000001f, xn = std::sqrt(n2_max_) * 1.0001f, qn2f = (float)qn2;
     int8_t *q8 = reinterpret_cast<int8_t *>(c->h_query + q16_off);
     memset(q8, 0, sstride_ + 16);
     for (size_t i = 0; i < dim; i++) q8[i] = (int8_t)std::min(127.0f, std::max(-127.0f, std::nearbyintf(qf[i] / sq)));
-    memcpy(q8 + sstride_ + 4, &sq, 4);  // the extra chunk: {0, query scale}
+    memcpy(q8 + sstride_ + 4, &sq, 4);  // the extra chunk: {0, query scale, |q|^2, 0}
+    memcpy(q8 + sstride_ + 8, &qn2f, 4);
     HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q8, sstride_ + 16, hipMemcpyHostToDevice, c->stream));
     const float rd = std::sqrt((float)dim);
-    const float eps = ((s_max_ + sq) * rd * 0.5f + 0.75f * s_max_ * sq * (float)dim) * 1.001f + 1e-6f;
+    const float eps_dot = ((s_max_ * qn + sq * xn) * rd * 0.5f + 0.75f * s_max_ * sq * (float)dim) * 1.001f;
+    const bool l2 = kmetric == KM_L2;
+    // fp32 rounding on both sides (d-term accumulations, |x|^2 of the row, the final sums): d 2^-23 of the largest magnitude
+    const float mag = l2 ? (qn + xn) * (qn + xn) : 1.0f + qn * xn;
+    const float eps = (l2 ? 2.0f * eps_dot : eps_dot) + (float)dim * 1.2e-7f * mag + 1e-6f;
+    if (!std::isfinite(eps)) return false;
     kSlack = 2.0f * eps;
     if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-    launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_I8, KM_IPS, 0, n, c->d_query + q16_off, c->d_keys, c->stream, d_sscale_);
+    launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_I8, l2 ? KM_L2S : KM_IPS, 0, n, c->d_query + q16_off, c->d_keys, c->stream,
+                d_sscale_);
   }
   if (prof) {
     HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     c->prof_rows = n;
-    c->prof_bytes_per_row = shadow_ == 1 ? dim * 2 : dim + 4;
+    c->prof_bytes_per_row = shadow_ == 1 ? dim * 2 : dim + 8;
     c->prof_pending = true;
   }
   c->h_fcnt[1] = 0;
   c->h_fcnt[2] = 0;
-  if (shadow_ == 2 && k > 16) {
-    // the int8 band is wide: with a sampled bound the survivors of K > 16 outgrow the candidate buffer, so tau is
-    // the EXACT K-th shadow distance here (radix levels over the shadow keys, ~0.1 ms)
+  if ((shadow_ == 2 && k > 16) || k > 128) {
+    // the int8 band is wide: with a sampled bound the survivors of K > 16 outgrow the candidate buffer (and so do those
+    // of the fp16 band for K > 128), so tau is the EXACT K-th shadow distance here (radix levels over the shadow
+    // keys, ~0.1 ms)
     std::vector<Hit> tmp;
     Bound kth;
     radix_select(c, c->d_keys, 4, n, k, Bound(), tmp, &kth);
@@ -911,7 +931,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   upload_query(c.c, query, true);
   std::vector<Hit> hits;
   // fp16 shadow: error-bounded filter + exact fp32 re-scoring of the survivors; falls back to the full scan
-  const bool two_stage = shadow_ && scan_tuning().two_stage && k <= 128 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
+  const bool two_stage = shadow_ && scan_tuning().two_stage && k <= 1024 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
   if (!two_stage) scan_all(c.c, n);
   std::vector<VecSimQueryResult> res;
   if (!multi) {

@@ -205,14 +205,15 @@ class FlatIndex {
   void rows_of(size_t label, std::vector<uint32_t> &out) const;
 
   size_t elem_bytes_, stride_;
-  // optional low-precision shadow of the rows (FLOAT32 cosine, single-value; chosen at creation by
-  // ScanTuning::shadow16 / shadow8): 0 none, 1 fp16, 2 int8 with one fp32 scale per row
+  // optional low-precision shadow of the rows (FLOAT32, single-value; chosen at creation by ScanTuning::shadow16 --
+  // cosine only -- / shadow8 -- cosine, IP, L2): 0 none, 1 fp16, 2 int8 with {fp32 scale, |x|^2} per row
   int shadow_ = 0;
   size_t sstride_ = 0;
   uint8_t *d_shadow_ = nullptr;
-  float *d_sscale_ = nullptr;   // [cap_rows] (int8 shadow)
-  uint32_t *d_smax_ = nullptr;  // max row scale, f32 bits (atomicMax on the device)
-  float s_max_ = 0.0f;          // its host copy, refreshed by the writers
+  float *d_sscale_ = nullptr;   // [cap_rows][2] (int8 shadow): row scale, |x|^2 of the fp32 row
+  uint32_t *d_smax_ = nullptr;  // [4]: max row scale, max |x|^2 (f32 bits, atomicMax on the device), non-finite-row flag
+  float s_max_ = 0.0f, n2_max_ = 0.0f;  // their host copies, refreshed by the writers
+  bool s_bad_ = false;                  // a row holds inf / NaN: the shadow bounds nothing, queries take the fp32 scan
   void shadow_convert(uint32_t row_begin, uint32_t row_end);  // on wstream_
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
   // rows (and their shadow) grow without copies once they are large: virtual range + mapped chunks (grow_buffer.hpp);

@@ -15,7 +15,8 @@ enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3, KT_I8 = 4, KT_U8 =
 // kernel metrics: for the floating-point types cosine is IP over rows/query normalised up front;
 // INT8/UINT8 rows cannot be normalised in place, their cosine divides by the two norms (KM_COS)
 // KM_IPS (KT_I8 scan only): 1 - dot * row_scale[row] * query_scale, the int8-shadow filter pass
-enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2, KM_IPS = 3 };
+// KM_L2S (KT_I8 scan only): |q|^2 + |x|^2[row] - 2 * dot * row_scale[row] * query_scale, the same for L2 indexes
+enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2, KM_IPS = 3, KM_L2S = 4 };
 // distances (and keys) of FLOAT64 indexes are 8 bytes wide, everything else computes fp32 distances
 inline int key_bytes_of(int type) { return type == KT_F64 ? 8 : 4; }
 
@@ -71,9 +72,10 @@ ScanTuning &scan_tuning();
 // Distances of rows [row_begin,row_end) to `query`, written as orderable keys keys[row] (u32, or u64
 // for KT_F64).  rows: row-contiguous, `stride` bytes per row (multiple of 16, zero padded), query padded
 // alike; for KT_I8/KT_U8 one more 16-byte chunk follows the padded query: {sum q^2 (i32/u32), |q| (f32)}.
-// KM_IPS: row_scale[row] (fp32) per row; the extra query chunk is {0, query_scale as f32 bits}.
+// KM_IPS / KM_L2S: row_meta[row] = {scale, |x|^2 of the fp32 row} per row; the extra query chunk is
+// {0, query_scale, |q|^2, 0} as f32 bits.
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_scale = nullptr);
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_meta = nullptr);
 
 // name of the kernel instantiation the last full scan of this process launched (template arguments + grid)
 const char *last_scan_kernel_name(char *buf, size_t cap);
@@ -94,10 +96,11 @@ void launch_normalize_rows(void *rows, size_t stride, uint32_t dim, int type, ui
 // fp16 shadow of fp32 rows [row_begin,row_end): out row stride sstride bytes (multiple of 16, zero padded)
 void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
                         size_t sstride, hipStream_t s);
-// int8 shadow of unit-norm fp32 rows: shadow[r][i] = rint(x[r][i] / scale[r]), scale[r] = max|x[r]| / 127;
-// smax_bits[0] = max over rows of scale (as f32 bits, atomicMax)
+// int8 shadow of fp32 rows: shadow[r][i] = rint(x[r][i] / scale[r]), scale[r] = max|x[r]| / 127;
+// meta[r] = {scale[r], |x[r]|^2}; max_bits[0] / [1] = max over rows of scale / |x|^2 (f32 bits, atomicMax);
+// max_bits[2] is set when a row holds a non-finite element (the shadow cannot bound such an index)
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
-                         size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s);
+                         size_t sstride, float *meta, uint32_t *max_bits, hipStream_t s);
 // Batched two-stage scan: cand[q*cand_cap + j].y = orderable key of the fp32 IP distance of row cand[..].x to
 // queries[q] (fp32, qstride bytes apart), j < cand_count[q]; the arithmetic is the single-query scan's, bit for bit.
 // tau (optional): candidates whose current (shadow) key is above tau[q] are not read; they get the last key instead.

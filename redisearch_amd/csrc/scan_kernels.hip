@@ -268,8 +268,15 @@ __device__ __forceinline__ float finish(I2 acc, u4 qx) {
   const long long qq = TYPE == KT_I8 ? (long long)(int)qx.x : (long long)qx.x;
   if (METRIC == KM_L2) return (float)(xx + qq - 2 * xq);
   if (METRIC == KM_IP) return 1.0f - (float)xq;
-  if (METRIC == KM_IPS) return (float)xq;  // scaled per row where the key is stored
+  if (METRIC == KM_IPS || METRIC == KM_L2S) return (float)xq;  // scaled per row where the key is stored
   return 1.0f - (float)xq / (sqrtf((float)xx) * __uint_as_float(qx.y));
+}
+
+// int8-shadow distance of a row from its integer dot: meta = {row scale, |x|^2}, qx = {0, query scale, |q|^2, 0}
+template <int METRIC>
+__device__ __forceinline__ float shadow8_distance(float dot, float2 meta, u4 qx) {
+  const float xq = dot * (meta.x * __uint_as_float(qx.y));
+  return METRIC == KM_L2S ? (__uint_as_float(qx.z) + meta.y) - 2.0f * xq : 1.0f - xq;
 }
 
 // ---- the scan -------------------------------------------------------------------------------------
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
               if (rid[u] == 0xFFFFFFFFu) set_nan(v);
               dists[r] = v;
             } else {
-              if (METRIC == KM_IPS) v = (out_t)(1.0f - (float)v * (reinterpret_cast<const float *>(row_ids)[r] * __uint_as_float(qx.y)));
+              if (METRIC == KM_IPS || METRIC == KM_L2S) v = (out_t)shadow8_distance<METRIC>((float)v, reinterpret_cast<const float2 *>(row_ids)[r], qx);
               keys[r] = to_key(v);
             }
           }
@@ -371,8 +378,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
           if (my_rid == 0xFFFFFFFFu) set_nan(mine);
           dists[r0 + lane] = mine;
         } else {
-          if (METRIC == KM_IPS)
-            mine = (out_t)(1.0f - (float)mine * (reinterpret_cast<const float *>(row_ids)[r0 + lane] * __uint_as_float(qx.y)));
+          if (METRIC == KM_IPS || METRIC == KM_L2S)
+            mine = (out_t)shadow8_distance<METRIC>((float)mine, reinterpret_cast<const float2 *>(row_ids)[r0 + lane], qx);
           keys[r0 + lane] = to_key(mine);
         }
       }
@@ -466,8 +473,8 @@ void launch_one(const LaunchCtx &c) {
   typename Tr<TYPE>::key_t *keys = (typename Tr<TYPE>::key_t *)c.keys;
   typename Tr<TYPE>::out_t *dists = (typename Tr<TYPE>::out_t *)c.dists;
   if (!GATHER)
-    g_last_scan = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 5) | ((uint64_t)ITERS << 12) | ((uint64_t)U << 16) |
-                  ((uint64_t)exact << 20) | ((uint64_t)nt << 21) | ((uint64_t)grid << 41);
+    g_last_scan = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
+                  ((uint64_t)exact << 21) | ((uint64_t)nt << 22) | ((uint64_t)grid << 41);
 #define RSGPU_LAUNCH(EX, NTV)                                                                              \
   hipLaunchKernelGGL((scan_kernel<TYPE, METRIC, G, ITERS, U, EX, NTV, GATHER>), dim3(grid), dim3(256), 0, c.s, \
                      c.rows, c.stride16, c.chunks, c.row_begin, c.row_end, c.query, c.row_ids, keys, dists)
@@ -559,8 +566,11 @@ void dispatch(int type, int metric, const LaunchCtx &c) {
     RSGPU_CASE(KT_F16)
     RSGPU_CASE(KT_BF16)
     case KT_I8:
-      if (metric == KM_IPS) {
-        if (!GATHER) launch_shape<KT_I8, KM_IPS, false>(c);
+      if (metric == KM_IPS || metric == KM_L2S) {
+        if (!GATHER) {
+          if (metric == KM_IPS) launch_shape<KT_I8, KM_IPS, false>(c);
+          else launch_shape<KT_I8, KM_L2S, false>(c);
+        }
         break;
       }
       if (metric == KM_L2) launch_shape<KT_I8, KM_L2, GATHER>(c);
@@ -637,18 +647,25 @@ __global__ __launch_bounds__(256) void shadow_rows_kernel(const float *__restric
   }
 }
 
-// int8 shadow + per-row scale of unit-norm fp32 rows, one wavefront per row
+// int8 shadow + per-row {scale, |x|^2} of fp32 rows, one wavefront per row
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restrict__ rows, uint32_t stride_f, uint32_t dim,
                                                            uint32_t row_begin, uint32_t row_end,
                                                            int8_t *__restrict__ shadow, uint32_t sstride,
-                                                           float *__restrict__ scale, uint32_t *__restrict__ smax_bits) {
+                                                           float2 *__restrict__ meta, uint32_t *__restrict__ max_bits) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
     const float *src = rows + (size_t)r * stride_f;
-    float m = 0.0f;
-    for (uint32_t i = lane; i < dim; i += 64) m = fmaxf(m, fabsf(src[i]));
+    float m = 0.0f, n2 = 0.0f;
+    for (uint32_t i = lane; i < dim; i += 64) {
+      const float v = src[i];
+      m = fmaxf(m, fabsf(v));
+      n2 = fmaf(v, v, n2);
+    }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    for (int o = 32; o >= 1; o >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, o, 64));
+      n2 += __shfl_xor(n2, o, 64);
+    }
     const float sc = m > 0.0f ? m / 127.0f : 1.0f;  // (an all-zero row: every quantised element is 0)
     int8_t *dst = shadow + (size_t)r * sstride;
     for (uint32_t i = lane; i < sstride; i += 64) {
@@ -657,8 +674,10 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restri
       dst[i] = (int8_t)v;
     }
     if (lane == 0) {
-      scale[r] = sc;
-      atomicMax(smax_bits, __float_as_uint(sc));
+      meta[r] = make_float2(sc, n2);
+      atomicMax(max_bits, __float_as_uint(sc));
+      atomicMax(max_bits + 1, __float_as_uint(n2));
+      if (!(n2 < __builtin_inff())) max_bits[2] = 1;  // inf / NaN element (fmaxf would have hidden a NaN)
     }
   }
 }
@@ -706,18 +725,18 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict
 }  // namespace
 
 const char *last_scan_kernel_name(char *buf, size_t cap) {
-  static const char *tn[] = {"f32", "f64", "bf16", "f16", "i8", "u8"}, *mn[] = {"L2", "IP", "COS", "IPS"};
+  static const char *tn[] = {"f32", "f64", "bf16", "f16", "i8", "u8"}, *mn[] = {"L2", "IP", "COS", "IPS", "L2S", "?", "?", "?"};
   const uint64_t v = g_last_scan.load();
   if (!v) {
     snprintf(buf, cap, "none");
     return buf;
   }
   if ((v >> 40) & 1)
-    snprintf(buf, cap, "scan_long_kernel<%s,%s,NT=1> grid=%ux256", tn[v & 7], mn[(v >> 3) & 3], (unsigned)(v >> 41));
+    snprintf(buf, cap, "scan_long_kernel<%s,%s,NT=1> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7], (unsigned)(v >> 41));
   else
-    snprintf(buf, cap, "scan_kernel<%s,%s,G=%u,ITERS=%u,U=%u,EXACT=%u,NT=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 3],
-             (unsigned)((v >> 5) & 127), (unsigned)((v >> 12) & 15), (unsigned)((v >> 16) & 15), (unsigned)((v >> 20) & 1),
-             (unsigned)((v >> 21) & 1), (unsigned)(v >> 41));
+    snprintf(buf, cap, "scan_kernel<%s,%s,G=%u,ITERS=%u,U=%u,EXACT=%u,NT=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7],
+             (unsigned)((v >> 6) & 127), (unsigned)((v >> 13) & 15), (unsigned)((v >> 17) & 15), (unsigned)((v >> 21) & 1),
+             (unsigned)((v >> 22) & 1), (unsigned)(v >> 41));
   return buf;
 }
 
@@ -753,12 +772,12 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
 }
 
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
-                         size_t sstride, float *scale, uint32_t *smax_bits, hipStream_t s) {
+                         size_t sstride, float *meta, uint32_t *max_bits, hipStream_t s) {
   if (row_end <= row_begin) return;
   uint32_t n = row_end - row_begin;
   uint32_t need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
   hipLaunchKernelGGL(shadow8_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const float *)rows,
-                     (uint32_t)(stride / 4), dim, row_begin, row_end, (int8_t *)shadow, (uint32_t)sstride, scale, smax_bits);
+                     (uint32_t)(stride / 4), dim, row_begin, row_end, (int8_t *)shadow, (uint32_t)sstride, (float2 *)meta, max_bits);
 }
 
 void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,
@@ -771,12 +790,12 @@ void launch_shadow_rows(const void *rows, size_t stride, uint32_t dim, uint32_t 
 }
 
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
-                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_scale) {
+                 uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_meta) {
   (void)dim;
   if (row_end <= row_begin) return;
-  // (KM_IPS: the per-row scales travel in the row_ids slot, which a plain scan does not use)
+  // (KM_IPS / KM_L2S: the per-row {scale, |x|^2} travel in the row_ids slot, which a plain scan does not use)
   LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
-              (const u4 *)query, reinterpret_cast<const uint32_t *>(row_scale), keys, nullptr, s};
+              (const u4 *)query, reinterpret_cast<const uint32_t *>(row_meta), keys, nullptr, s};
   dispatch<false>(type, metric, c);
 }
 
