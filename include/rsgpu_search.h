@@ -24,8 +24,11 @@
  * NewMetricIteratorSortedByScore (headers/iterators_ffi.h:574,480).
  *
  * The posting bytes are uploaded AS-IS in the reference's block format; decoding happens on the
- * device.  Doc ids must be < 2^32 (they are monotonically assigned from 1).  Term offsets stay where they are -- in
- * the encoded bytes -- and are read in place by the proximity kernels (max_slop / in_order, the scorers' slop).
+ * device.  Doc ids are 64-bit (t_docId) at this interface.  On the device a list holds 32-bit offsets from its own
+ * base -- 0 while every id of the list fits 32 bits, else the list's first doc id -- and the lists of one query are
+ * re-based on the fly onto the smallest doc id among them: a list, and the lists combined in one query, must span fewer
+ * than 2^32 doc ids (ids are assigned monotonically, so the live window of an index does).  Term offsets stay where they
+ * are -- in the encoded bytes -- and are read in place by the proximity kernels (max_slop / in_order, the scorers' slop).
  */
 #ifndef RSGPU_SEARCH_H
 #define RSGPU_SEARCH_H
@@ -112,6 +115,10 @@ int RSGPU_Hits_Read(const RSGPU_Hits *h, uint64_t *doc_ids, uint32_t *freqs);
  * src/redisearch.h:97-132), arrays indexed by doc id, n = max doc id + 1. */
 RSGPU_DocTable *RSGPU_DocTable_Upload(size_t n, const uint32_t *doc_len, const float *doc_score,
                                       const uint32_t *max_term_freq);
+/* The same for a window of doc ids: entry j describes doc id first_doc_id + j (indexes whose ids have grown past 2^32
+ * keep a table of the live window only).  Hits outside the window score as unknown documents. */
+RSGPU_DocTable *RSGPU_DocTable_UploadWindow(uint64_t first_doc_id, size_t n, const uint32_t *doc_len,
+                                            const float *doc_score, const uint32_t *max_term_freq);
 void RSGPU_DocTable_Free(RSGPU_DocTable *t);
 
 typedef struct {

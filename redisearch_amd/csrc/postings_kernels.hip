@@ -191,6 +191,18 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
   return lo + (uint32_t)__popcll(__ballot(less));
 }
 
+// id i of list l in the frame the lists of a query share
+__device__ __forceinline__ uint32_t shared_id(const ListView &v, int l, uint32_t i) {
+  return (uint32_t)((long long)v.ids[l][i] + v.add[l]);
+}
+// x (shared frame) -> the frame of a list stored `add` away from it; *out: x lies outside the 32-bit range that list
+// can hold -- it cannot match, and the value returned keeps its lower bound right (0 below, the list's end above)
+__device__ __forceinline__ uint32_t to_list_frame(uint32_t x, long long add, bool *out) {
+  const long long t = (long long)x - add;
+  *out = t < 0 || t > 0xFFFFFFFFll;
+  return t < 0 ? 0u : (t > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)t);
+}
+
 // Intersection probe.  The 256 candidates of a workgroup are consecutive in the (sorted) driving list, so their
 // matches in another list lie in ONE window [lower_bound(first), lower_bound(first of the next workgroup)): the
 // window's ends are found by wavefront-wide 64-ary searches, the window is staged in LDS with coalesced loads and
@@ -209,15 +221,19 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
   const uint32_t n0 = v.len[0];
   const uint32_t i_first = blockIdx.x * 256, i_next = i_first + 256;
   bool hit = i < n0;
-  const uint32_t x = hit ? v.ids[0][i] : 0u;
+  const uint32_t xc = hit ? shared_id(v, 0, i) : 0u;  // shared frame
   for (int l = 1; l < v.n; l++) {
     const uint32_t *__restrict__ a = v.ids[l];
     const uint32_t nl = v.len[l];
+    bool under;
+    const uint32_t x = to_list_frame(xc, v.add[l], &under);  // this list's frame
     if (wave == 0) {
-      const uint32_t r = wave_lower_bound(a, nl, v.ids[0][i_first], lane);
+      bool u0;
+      const uint32_t r = wave_lower_bound(a, nl, to_list_frame(shared_id(v, 0, i_first), v.add[l], &u0), lane);
       if (lane == 0) w_lo = r;
     } else if (wave == 1) {
-      const uint32_t r = i_next < n0 ? wave_lower_bound(a, nl, v.ids[0][i_next], lane) : nl;
+      bool u1;
+      const uint32_t r = i_next < n0 ? wave_lower_bound(a, nl, to_list_frame(shared_id(v, 0, i_next), v.add[l], &u1), lane) : nl;
       if (lane == 0) w_hi = r;
     }
     __syncthreads();
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
         else e = mid;
       }
       p = lo + b;
-      const bool m = hit && b < span && win[b] == x;
+      const bool m = hit && !under && b < span && win[b] == x;
       if (hit) pos[(size_t)(l - 1) * n0 + i] = p;
       hit = m;
     } else {
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
           else e = mid;
         }
         pos[(size_t)(l - 1) * n0 + i] = b;
-        hit = b < nl && a[b] == x;
+        hit = !under && b < nl && a[b] == x;
       }
     }
     __syncthreads();  // win / w_lo / w_hi are reused by the next list
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, LeafMa
   uint32_t off = block_off[blockIdx.x];
   for (uint32_t j = 0; j < w; j++) off += wave_cnt[j];
   off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  out_ids[off] = v.ids[0][i];
+  out_ids[off] = shared_id(v, 0, i);
   for (int l = 0; l < lm.n_leaves; l++) {
     const uint32_t t = lm.leaf_list[l];
     const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];  // the hit's position in list t
@@ -328,8 +344,11 @@ __global__ __launch_bounds__(256) void union_flag_kernel(ListView v, int s, uint
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   bool emit = i < v.len[s];
   if (emit) {
-    const uint32_t x = v.ids[s][i];
+    const uint32_t xc = shared_id(v, s, i);
     for (int t = 0; t < s; t++) {
+      bool under;
+      const uint32_t x = to_list_frame(xc, v.add[t], &under);
+      if (under) continue;
       const uint32_t p = lower_bound(v.ids[t], v.len[t], x);
       if (p < v.len[t] && v.ids[t][p] == x) { emit = false; break; }
     }
@@ -367,17 +386,21 @@ __global__ __launch_bounds__(256) void union_write_kernel(ListView v, LeafMap lm
                                                           uint32_t *__restrict__ out_epos) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= v.len[s] || !flags[i]) return;
-  const uint32_t x = v.ids[s][i];
+  const uint32_t xc = shared_id(v, s, i);
   uint32_t slot = 0, at[kMaxLists];
+  bool outside[kMaxLists];
   for (int t = 0; t < v.n; t++) {
-    at[t] = t == s ? i : lower_bound(v.ids[t], v.len[t], x);
+    const uint32_t x = to_list_frame(xc, v.add[t], &outside[t]);
+    // (outside above the list's range: every entry is smaller, unless one sits exactly at the clamp -- lower_bound
+    // would stop in front of it, so the end is taken explicitly)
+    at[t] = t == s ? i : (outside[t] ? (x ? v.len[t] : 0u) : lower_bound(v.ids[t], v.len[t], x));
     slot += u.prefix[t][at[t]];
   }
   if (slot >= cap) return;
-  out_ids[slot] = x;
+  out_ids[slot] = xc;
   for (int l = 0; l < lm.n_leaves; l++) {
     const uint32_t t = lm.leaf_list[l], p = at[t];
-    const bool on = p < v.len[t] && v.ids[t][p] == x;
+    const bool on = p < v.len[t] && !outside[t] && shared_id(v, (int)t, p) == xc;
     out_freqs[(size_t)l * cap + slot] = (on && lm.leaf_freq[l]) ? lm.leaf_freq[l][p] : 0u;
     if (out_epos) out_epos[(size_t)l * cap + slot] = on ? (lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p) : 0xFFFFFFFFu;
   }
@@ -407,15 +430,18 @@ __global__ void count_below_kernel(const uint32_t *__restrict__ list, uint32_t l
 }
 __global__ __launch_bounds__(256) void not_universe_flag_kernel(const uint32_t *__restrict__ universe, uint32_t n_u,
                                                                 const uint32_t *__restrict__ child, uint32_t child_len,
-                                                                uint32_t max_doc, uint8_t *__restrict__ flags,
+                                                                long long child_shift, uint32_t max_doc,
+                                                                uint8_t *__restrict__ flags,
                                                                 uint32_t *__restrict__ block_counts) {
   __shared__ uint32_t wave_cnt[4];
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   bool keep = i < n_u;
   if (keep) {
     const uint32_t doc = universe[i];
-    const uint32_t p = lower_bound(child, child_len, doc);
-    keep = doc <= max_doc && !(p < child_len && child[p] == doc);
+    bool outside;  // the child stores ids relative to its own base: child frame = universe frame + child_shift
+    const uint32_t cdoc = to_list_frame(doc, -child_shift, &outside);
+    const uint32_t p = outside ? child_len : lower_bound(child, child_len, cdoc);
+    keep = doc <= max_doc && !(p < child_len && child[p] == cdoc);
     flags[i] = keep ? 1 : 0;
   }
   unsigned long long m = __ballot(keep);
@@ -676,8 +702,9 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
                                                     uint32_t *__restrict__ keys32) {
   const uint32_t h = blockIdx.x * 256 + threadIdx.x;
   if (h >= len) return;
-  const uint32_t id = ids[h];
-  const bool known = id < table_n;
+  const long long tid = (long long)ids[h] + P.table_off;
+  const bool known = tid >= 0 && tid < (long long)table_n;
+  const uint32_t id = known ? (uint32_t)tid : 0u;
   const float dscore = known ? doc_score[id] : 0.0f;
   const uint32_t dlen = known ? doc_len[id] : 0u;
   const uint32_t mfreq = (known && max_freq) ? max_freq[id] : 0u;
@@ -831,11 +858,11 @@ __global__ __launch_bounds__(256) void score_normalize_kernel(double *__restrict
 }
 
 __global__ __launch_bounds__(256) void labels_to_rows_kernel(const uint32_t *__restrict__ ids, uint32_t n,
-                                                             uint64_t base, uint32_t n_rows,
+                                                             uint64_t ids_base, uint64_t base, uint32_t n_rows,
                                                              uint32_t *__restrict__ rows) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t id = ids[i];
+  const uint64_t id = ids_base + ids[i];
   rows[i] = (id >= base && id - base < n_rows) ? (uint32_t)(id - base) : 0xFFFFFFFFu;
 }
 
@@ -921,9 +948,10 @@ void launch_count_below(const uint32_t *list, uint32_t len, uint64_t x, uint32_t
   hipLaunchKernelGGL(count_below_kernel, dim3(1), dim3(1), 0, st, list, len, x, out);
 }
 void launch_not_universe_flag(const uint32_t *universe, uint32_t n_u, const uint32_t *child, uint32_t child_len,
-                              uint32_t max_doc, uint8_t *flags, uint32_t *block_counts, hipStream_t st) {
+                              long long child_shift, uint32_t max_doc, uint8_t *flags, uint32_t *block_counts,
+                              hipStream_t st) {
   hipLaunchKernelGGL(not_universe_flag_kernel, dim3(blocks_for(n_u)), dim3(256), 0, st, universe, n_u, child, child_len,
-                     max_doc, flags, block_counts);
+                     child_shift, max_doc, flags, block_counts);
 }
 void launch_not_universe_write(const uint32_t *universe, uint32_t n_u, const uint8_t *flags, const uint32_t *block_off,
                                uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st) {
@@ -954,9 +982,10 @@ void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, ui
   hipLaunchKernelGGL(score_normalize_kernel, dim3(need), dim3(256), 0, s, scores, keys, len,
                      (const unsigned long long *)max_key_zeroed);
 }
-void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint32_t n_rows, uint32_t *rows, hipStream_t s) {
+void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows, uint32_t *rows,
+                           hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(labels_to_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, base, n_rows, rows);
+  hipLaunchKernelGGL(labels_to_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, base, n_rows, rows);
 }
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s) {
   if (!n) return;

@@ -169,6 +169,9 @@ struct RSGPU_Postings {
   CodecDesc cd{};
   uint32_t n_blocks = 0, n_entries = 0;
   size_t n_bytes = 0;
+  // 64-bit doc ids: the device arrays hold id - base (u32); base = 0 for lists whose ids all fit 32 bits, else the
+  // list's first doc id.  first / last = the list's smallest / largest doc id (absolute).
+  uint64_t base = 0, first_id = 0, last = 0;
   DevBuf<uint8_t> bytes;
   DevBuf<uint64_t> byte_off;
   DevBuf<uint32_t> first, nent, entry_off;
@@ -186,6 +189,7 @@ struct RSGPU_Postings {
 struct RSGPU_Hits {
   int device = 0, n_lists = 0;
   uint32_t len = 0, cap = 0;
+  uint64_t base = 0, last = 0;  // ids[] hold doc id - base (base <= every id); last: an upper bound of the largest doc id
   int order[kMaxLists];  // internal list slot -> index in the caller's list array
   DevBuf<uint32_t> ids, freqs;
   DevBuf<double> scores;
@@ -219,6 +223,7 @@ struct RSGPU_Hits {
 struct RSGPU_DocTable {
   int device = 0;
   uint32_t n = 0;
+  uint64_t first = 0;  // doc id of entry 0
   DevBuf<uint32_t> doc_len, max_freq;
   DevBuf<float> doc_score;
 };
@@ -276,11 +281,15 @@ struct Source {
   int orig[kMaxLists] = {};  // the caller's list index of every leaf
   int op = 0;                // 0 term, 1 union, 2 intersection
   double weight = 1.0;
+  uint64_t base = 0, first = 0, last = 0;  // ids[] are relative to base; first / last bound the doc ids from below / above
 };
 static Source term_source(RSGPU_Postings *p, int orig) {
   Source s;
   s.ids = p->ids.p;
   s.len = p->n_entries;
+  s.base = p->base;
+  s.first = p->first_id;
+  s.last = p->last;
   s.n_leaves = 1;
   s.freq[0] = p->cd.freq >= 0 ? p->freqs.p : nullptr;
   s.epos[0] = nullptr;  // the position IS the entry index
@@ -292,6 +301,9 @@ static Source hits_source(const RSGPU_Hits *g, int op, double weight) {
   Source s;
   s.ids = g->ids.p;
   s.len = g->len;
+  s.base = g->base;
+  s.first = g->base;
+  s.last = g->last;
   s.n_leaves = g->n_lists;
   for (int l = 0; l < g->n_lists; l++) {
     s.freq[l] = g->freqs.p + (size_t)l * g->cap;
@@ -338,11 +350,25 @@ static LeafMap adopt_sources(RSGPU_Hits *h, const std::vector<Source> &srcs, Lis
   v.n = (int)srcs.size();
   h->n_groups = (int)srcs.size();
   h->with_offsets = false;
+  // the frame the children share: offsets from the smallest doc id among them; every child's ids must fit 32 bits
+  // above it (a child's own base may lie below -- lists whose ids fit 32 bits keep base 0 -- or above it)
+  uint64_t base = ~0ull, last = 0;
+  for (const Source &s : srcs)
+    if (s.len) {
+      base = std::min(base, s.first);
+      last = std::max(last, s.last);
+    }
+  if (base == ~0ull) base = 0;
+  if (last >= base && last - base > 0xFFFFFFFEull)
+    throw std::runtime_error("the posting lists of one query span 2^32 doc ids or more (device ids are 32-bit offsets from the smallest doc id)");
+  h->base = base;
+  h->last = last;
   int leaf = 0;
   for (size_t g = 0; g < srcs.size(); g++) {
     const Source &s = srcs[g];
     v.ids[g] = s.ids;
     v.len[g] = s.len;
+    v.add[g] = s.len ? (long long)(s.base - base) : 0ll;  // (two's complement: negative when the child's base lies below)
     h->group_first[g] = (uint8_t)leaf;
     h->group_op[g] = (uint8_t)s.op;
     h->group_weight[g] = s.weight;
@@ -475,7 +501,9 @@ static const int32_t *hit_slops(RSGPU_Hits *h, QueryCtx *c) {
 static bool slop_dependent(int scorer) {
   return scorer == RSGPU_SCORER_TFIDF || scorer == RSGPU_SCORER_TFIDF_DOCNORM || scorer == RSGPU_SCORER_BM25;
 }
-static void tree_score_params(ScoreParams &P, const RSGPU_Hits *h) {
+static void tree_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_DocTable *t) {
+  // table entry of hit id x (relative to the hits' base): x + (hits base - table first); may be negative
+  P.table_off = (long long)(h->base - t->first);
   P.n_lists = h->n_lists;
   P.n_groups = h->n_groups;
   for (int g = 0; g <= h->n_groups; g++) P.group_first[g] = h->group_first[g];
@@ -506,9 +534,18 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
   p->cd = cd;
   p->n_blocks = (uint32_t)n_blocks;
   std::vector<uint32_t> first(n_blocks), eoff(n_blocks + 1, 0);
+  uint64_t lo = ~0ull, hi = 0;
   for (size_t b = 0; b < n_blocks; b++) {
-    if (last_doc_id[b] > 0xFFFFFFFFull) throw std::runtime_error("doc ids >= 2^32 are not supported on the device path");
-    first[b] = (uint32_t)first_doc_id[b];
+    lo = std::min(lo, first_doc_id[b]);
+    hi = std::max(hi, std::max(first_doc_id[b], last_doc_id[b]));
+  }
+  // t_docId is 64-bit; the device holds 32-bit offsets from a per-list base (0 while every id fits 32 bits)
+  p->base = (n_blocks && hi > 0xFFFFFFFEull) ? lo : 0;
+  p->first_id = n_blocks ? lo : 0;
+  p->last = hi;
+  if (n_blocks && hi - p->base > 0xFFFFFFFEull) throw std::runtime_error("a posting list spanning 2^32 doc ids or more is not supported on the device path");
+  for (size_t b = 0; b < n_blocks; b++) {
+    first[b] = (uint32_t)(first_doc_id[b] - p->base);
     eoff[b + 1] = eoff[b] + num_entries[b];
   }
   p->n_entries = eoff[n_blocks];
@@ -554,7 +591,7 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
   if (doc_ids_out && n) {
     std::vector<uint32_t> tmp(n);
     HIP_CHECK(hipMemcpy(tmp.data(), p->ids.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; i++) doc_ids_out[i] = tmp[i];
+    for (uint32_t i = 0; i < n; i++) doc_ids_out[i] = p->base + tmp[i];
   }
   if (freqs_out && n) {
     if (p->cd.freq >= 0) HIP_CHECK(hipMemcpy(freqs_out, p->freqs.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -730,8 +767,18 @@ RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t 
     return nullptr;
   }
   S_TRY
-  if (max_doc_id > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_Not: doc ids are 32-bit on the device path");
   if (universe && universe->device != child->device) throw std::runtime_error("RSGPU_Not: lists on different devices");
+  // one frame for the child, the universe and max_doc_id: the universe's base (the plain NOT enumerates 1..max_doc_id
+  // and needs all of it below 2^32)
+  const uint64_t frame = universe ? universe->base : 0;
+  if (!universe && child->n_entries && child->base != 0)
+    throw std::runtime_error("RSGPU_Not: 1..max_doc_id must stay below 2^32 without a universe list");
+  if (max_doc_id < frame) max_doc_id = frame;  // nothing qualifies
+  max_doc_id -= frame;
+  if (max_doc_id > 0xFFFFFFF0ull) {
+    if (!universe) throw std::runtime_error("RSGPU_Not: 1..max_doc_id must stay below 2^32 without a universe list");
+    max_doc_id = 0xFFFFFFF0ull;  // every id of the frame
+  }
   const int device = child->device;
   HIP_CHECK(hipSetDevice(device));
   CtxLease c(device);
@@ -746,6 +793,8 @@ RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t 
   h->group_op[0] = 0;
   h->group_weight[0] = 1.0;
   h->src[0] = child;
+  h->base = frame;
+  h->last = frame + max_doc_id;
   StageTimer td(c.c, 0);
   decode_on(child, c.c);
   if (universe) decode_on(universe, c.c);
@@ -775,7 +824,7 @@ RSGPU_Hits *RSGPU_Not(RSGPU_Postings *child, RSGPU_Postings *universe, uint64_t 
     sc.flags.ensure(n_cand);
     sc.block_counts.ensure(nb);
     sc.total.ensure(1);
-    launch_not_universe_flag(universe->ids.p, n_cand, child->ids.p, child->n_entries, max_doc, sc.flags.p,
+    launch_not_universe_flag(universe->ids.p, n_cand, child->ids.p, child->n_entries, (long long)(frame - child->base), max_doc, sc.flags.p,
                              sc.block_counts.p, c->stream);
     launch_scan_counts(sc.block_counts.p, nb, sc.total.p, c->stream);
     launch_not_universe_write(universe->ids.p, n_cand, sc.flags.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap,
@@ -798,7 +847,7 @@ int RSGPU_Hits_Read(const RSGPU_Hits *hc, uint64_t *doc_ids, uint32_t *freqs) {
   HIP_CHECK(hipSetDevice(h->device));
   if (doc_ids) {
     const std::vector<uint32_t> &ids = h->host_ids();
-    for (uint32_t i = 0; i < h->len; i++) doc_ids[i] = ids[i];
+    for (uint32_t i = 0; i < h->len; i++) doc_ids[i] = h->base + ids[i];
   }
   if (freqs && h->len)
     for (int s = 0; s < h->n_lists; s++)  // back to the caller's list order
@@ -808,15 +857,23 @@ int RSGPU_Hits_Read(const RSGPU_Hits *hc, uint64_t *doc_ids, uint32_t *freqs) {
   S_CATCH(-1)
 }
 
+RSGPU_DocTable *RSGPU_DocTable_UploadWindow(uint64_t first_doc_id, size_t n, const uint32_t *doc_len,
+                                            const float *doc_score, const uint32_t *max_term_freq);
 RSGPU_DocTable *RSGPU_DocTable_Upload(size_t n, const uint32_t *doc_len, const float *doc_score,
                                       const uint32_t *max_term_freq) {
+  return RSGPU_DocTable_UploadWindow(0, n, doc_len, doc_score, max_term_freq);
+}
+RSGPU_DocTable *RSGPU_DocTable_UploadWindow(uint64_t first_doc_id, size_t n, const uint32_t *doc_len,
+                                            const float *doc_score, const uint32_t *max_term_freq) {
   S_TRY
+  if (n > 0xFFFFFFF0ull) throw std::runtime_error("RSGPU_DocTable_Upload: at most 2^32 entries");
   std::string why;
   if (!device_available(&why)) throw std::runtime_error(why);
   auto *t = new RSGPU_DocTable();
   std::unique_ptr<RSGPU_DocTable> guard(t);
   HIP_CHECK(hipGetDevice(&t->device));
   t->n = (uint32_t)n;
+  t->first = first_doc_id;
   t->doc_len.upload(doc_len, n);
   t->doc_score.upload(doc_score, n);
   if (max_term_freq) t->max_freq.upload(max_term_freq, n);
@@ -836,7 +893,7 @@ int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreAr
   // scorer in the reference pipeline, src/pipeline/pipeline_construction.c:546-547)
   const bool max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
   P.scorer = max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
-  tree_score_params(P, h);
+  tree_score_params(P, h, t);
   P.avg_doc_len = a->avg_doc_len;
   P.root_weight = a->root_weight;
   P.min_score = a->min_score;
@@ -882,7 +939,7 @@ long RSGPU_Hits_TopN(RSGPU_Hits *h, size_t n, uint64_t *doc_ids_out, double *sco
   tt.stop();
   const std::vector<uint32_t> &ids = h->host_ids();
   for (size_t i = 0; i < hits.size(); i++) {
-    if (doc_ids_out) doc_ids_out[i] = ids[hits[i].row];
+    if (doc_ids_out) doc_ids_out[i] = h->base + ids[hits[i].row];
     if (scores_out) scores_out[i] = key2score(hits[i].key);
   }
   return (long)hits.size();
@@ -912,7 +969,8 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
     // multi-value index with a real label map: a document's distance is the MINIMUM over its vectors, as
     // GetDistanceFrom / the ad-hoc gather give it (FlatIndex::gather expands every label to all its rows)
     const std::vector<uint32_t> &ids = h->host_ids();
-    std::vector<size_t> labels(ids.begin(), ids.end());
+    std::vector<size_t> labels(ids.size());
+    for (size_t i = 0; i < ids.size(); i++) labels[i] = (size_t)(h->base + ids[i]);
     std::vector<double> d(h->len);
     f->gather(c.c, labels.data(), h->len, d.data());
     tk.stop();
@@ -924,17 +982,17 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
     std::partial_sort(order.begin(), order.begin() + take, order.end(),
                       [&](uint32_t a, uint32_t b) { return d[a] != d[b] ? d[a] < d[b] : a < b; });
     for (size_t i = 0; i < take; i++) {
-      if (doc_ids_out) doc_ids_out[i] = ids[order[i]];
+      if (doc_ids_out) doc_ids_out[i] = h->base + ids[order[i]];
       if (dist_out) dist_out[i] = d[order[i]];
     }
     return (long)take;
   }
   if (f->identity_labels(&base)) {
-    launch_labels_to_rows(h->ids.p, h->len, base, f->committed_rows(), sc.rows.p, c->stream);
+    launch_labels_to_rows(h->ids.p, h->len, h->base, base, f->committed_rows(), sc.rows.p, c->stream);
   } else {  // general label map lives on the host
     const std::vector<uint32_t> &ids = h->host_ids();
     std::vector<uint32_t> rows(h->len);
-    for (uint32_t i = 0; i < h->len; i++) rows[i] = f->first_row_of(ids[i]);
+    for (uint32_t i = 0; i < h->len; i++) rows[i] = f->first_row_of(h->base + ids[i]);
     HIP_CHECK(hipMemcpyAsync(sc.rows.p, rows.data(), h->len * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
   }
@@ -949,7 +1007,7 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   long out = 0;
   for (const Hit &hit : hits) {
     if ((uint32_t)hit.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
-    if (doc_ids_out) doc_ids_out[out] = ids[hit.row];
+    if (doc_ids_out) doc_ids_out[out] = h->base + ids[hit.row];
     if (dist_out) dist_out[out] = (double)key_to_dist((uint32_t)hit.key);
     out++;
   }
@@ -980,11 +1038,12 @@ thread_local FusedEvents tls_events;
 constexpr uint32_t kFetchCap = 4096;  // survivors of the score prefilter settled on the host
 }  // namespace
 
-static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_ScoreArgs *a, bool *max_norm) {
+static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreArgs *a,
+                              bool *max_norm) {
   memset(&P, 0, sizeof P);
   *max_norm = a->scorer == RSGPU_SCORER_BM25STD_NORM;
   P.scorer = *max_norm ? (int)RSGPU_SCORER_BM25STD : a->scorer;
-  tree_score_params(P, h);
+  tree_score_params(P, h, t);
   P.avg_doc_len = a->avg_doc_len;
   P.root_weight = a->root_weight;
   P.min_score = a->min_score;
@@ -1038,7 +1097,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   if (want_score && len) {
     ScoreParams P;
     bool max_norm = false;
-    fill_score_params(P, h.get(), a->score, &max_norm);
+    fill_score_params(P, h.get(), a->table, a->score, &max_norm);
     h->scores.ensure(h->cap);
     h->keys.ensure(h->cap);
     if (slop_dependent(P.scorer)) P.slops = hit_slops(h.get(), ca.c);
@@ -1081,7 +1140,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
       sc.keys32.ensure(len);
       f->upload_query(cb.c, a->query, true);
       if (prof) HIP_CHECK(hipEventRecord(ev.e[4], cb->stream));
-      launch_labels_to_rows(h->ids.p, len, base, f->committed_rows(), sc.rows.p, cb->stream);
+      launch_labels_to_rows(h->ids.p, len, h->base, base, f->committed_rows(), sc.rows.p, cb->stream);
       launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, len, cb->d_query,
                     sc.dists.p, cb->stream);
       launch_dist_to_keys(sc.dists.p, len, sc.keys32.p, cb->stream);
@@ -1130,7 +1189,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
       top_doc.assign(ca->h_ids, ca->h_ids + top.size());
     }
     for (size_t i = 0; i < top.size(); i++) {
-      if (a->top_ids) a->top_ids[i] = top_doc[i];
+      if (a->top_ids) a->top_ids[i] = h->base + top_doc[i];
       if (a->top_scores) a->top_scores[i] = key2score(top[i].key);
     }
     a->n_top = top.size();
@@ -1145,7 +1204,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
       for (size_t i = 0; i < knn_hits.size(); i++) {
         const Hit &hit = knn_hits[i];
         if ((uint32_t)hit.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
-        if (a->knn_ids) a->knn_ids[out] = cb->h_ids[i];
+        if (a->knn_ids) a->knn_ids[out] = h->base + cb->h_ids[i];
         if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist((uint32_t)hit.key);
         out++;
       }

@@ -31,6 +31,10 @@ struct ListView {
   const uint32_t *ids[kMaxLists];
   const uint32_t *freqs[kMaxLists];
   uint32_t len[kMaxLists];
+  // 64-bit doc ids: a list stores ids relative to its own base; add[l] = base_l - B, B = the smallest doc id among the
+  // lists of the query, so ids[l][i] + add[l] is the document's id in the frame the lists share (add may be negative;
+  // the sum fits 32 bits: the caller checks that the lists span fewer than 2^32 ids)
+  long long add[kMaxLists];
   int n;  // lists; list 0 drives (the shortest)
 };
 // How the term ("leaf") columns of a hit list hang off the lists of a ListView: a list is a term's posting list (one
@@ -94,8 +98,10 @@ void launch_not_range(const uint32_t *child, uint32_t child_len, uint32_t max_do
                       uint32_t *out_freqs, uint32_t cap, hipStream_t st);
 // out[0] = number of entries of the sorted list below x
 void launch_count_below(const uint32_t *list, uint32_t len, uint64_t x, uint32_t *out, hipStream_t st);
+// child_shift: (the universe's base) - (the child's base): a universe id u is child id u + child_shift
 void launch_not_universe_flag(const uint32_t *universe, uint32_t n_u, const uint32_t *child, uint32_t child_len,
-                              uint32_t max_doc, uint8_t *flags, uint32_t *block_counts, hipStream_t st);
+                              long long child_shift, uint32_t max_doc, uint8_t *flags, uint32_t *block_counts,
+                              hipStream_t st);
 void launch_not_universe_write(const uint32_t *universe, uint32_t n_u, const uint8_t *flags, const uint32_t *block_off,
                                uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t st);
 
@@ -113,6 +119,7 @@ struct ScoreParams {
   int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_groups-1, 1)
   const int32_t *slops;  // per-hit slop computed from the term offsets (launch_prox_slop); NULL: the constant above
   int is_union;  // hits come from RSGPU_Union: per-hit slop from the matched children, DISMAX takes the maximum
+  long long table_off;  // doc-table entry of hit id x = x + table_off (64-bit doc ids: hits base - table first id)
 };
 // scores[h] (fp64) and keys[h] = descending-score orderable u64 (for the top-N select)
 void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *freqs, uint32_t len, uint32_t cap,
@@ -130,8 +137,9 @@ void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uin
 // max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream
 void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, uint64_t *max_key_zeroed, hipStream_t s);
 
-// rows[i] = ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
-void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t base, uint32_t n_rows, uint32_t *rows, hipStream_t s);
+// rows[i] = ids_base + ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
+void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows, uint32_t *rows,
+                           hipStream_t s);
 // keys[i] = orderable(dists[i]) (NaN last)
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s);
 

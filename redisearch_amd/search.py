@@ -49,6 +49,7 @@ ABI = {
     "RSGPU_Hits_Len": (_sz, [_vp]),
     "RSGPU_Hits_Read": (_i, [_vp, _vp, _vp]),
     "RSGPU_DocTable_Upload": (_vp, [_sz, _vp, _vp, _vp]),
+    "RSGPU_DocTable_UploadWindow": (_vp, [C.c_uint64, _sz, _vp, _vp, _vp]),
     "RSGPU_DocTable_Free": (None, [_vp]),
     "RSGPU_Hits_Score": (_i, [_vp, _vp, C.POINTER(ScoreArgs), _vp]),
     "RSGPU_Hits_TopN": (C.c_long, [_vp, _sz, _vp, _vp]),
@@ -138,12 +139,14 @@ class Postings:
 
 
 class DocTable:
-    def __init__(self, doc_len, doc_score, max_freq=None):
+    def __init__(self, doc_len, doc_score, max_freq=None, first_doc_id=0):
+        """entry j describes doc id first_doc_id + j"""
         self.lib = load()
         dl, ds = np.ascontiguousarray(doc_len, np.uint32), np.ascontiguousarray(doc_score, np.float32)
         mf = np.ascontiguousarray(max_freq, np.uint32) if max_freq is not None else None
-        self.ptr = _check(self.lib.RSGPU_DocTable_Upload(len(dl), _p(dl), _p(ds), _p(mf) if mf is not None else None),
-                          "RSGPU_DocTable_Upload")
+        self.ptr = _check(self.lib.RSGPU_DocTable_UploadWindow(int(first_doc_id), len(dl), _p(dl), _p(ds),
+                                                               _p(mf) if mf is not None else None),
+                          "RSGPU_DocTable_UploadWindow")
 
     def free(self):
         if getattr(self, "ptr", None):
