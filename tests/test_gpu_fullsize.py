@@ -5,7 +5,8 @@ regenerates the same 10M rows (oracle.philox_rows, threads), loads them into the
 own first queries among them -- are compared id for id and distance for distance (`assert_topk_parity`): the oracle pins
 the headline configuration itself, not a scaled-down stand-in.  On top of that, size-independent properties: planted
 near-duplicates come back first and in order, results are sorted, deterministic, consistent between TopK / batches /
-range / ad-hoc distances, and a row-sharded merge equals the single-index answer.
+range / ad-hoc distances, and a row-sharded merge equals the single-index answer.  The opt-in two-stage exact scan
+(int8 shadow) is held to the same oracle at the same size.
 Needs ~31 GB of HBM and ~65 GB of host memory; skipped when the device is smaller."""
 import numpy as np
 import pytest
@@ -81,6 +82,57 @@ def test_oracle_parity_at_the_baseline_size(big, big_oracle):
     onq = big_oracle.normalized_query(qs[2])
     for lab in (1, 5_000_000, ROWS, ROWS + 3):
         assert abs(idx.get_distance_from_unsafe(lab, nq) - big_oracle.distance_from(lab, onq)) <= 1e-4
+
+
+def test_two_stage_int8_shadow_at_the_baseline_size(big, big_oracle):
+    """The opt-in two-stage exact scan at full size: a second index over the same 10M keyed rows, created with the
+    int8 shadow (+25 % HBM), answers the same queries -- checked against the CPU oracle like the plain index, and
+    bit-identical to the plain index (ids and distances), K = 10 / 100 / 1000; then the same pair under L2 (plain vs
+    shadow, bit-identical)."""
+    idx, q, planted, planted_vecs = big
+    lib = V.load()
+
+    def shadowed(metric, with_planted):
+        lib.RSGPU_SetTuning(b"shadow8", 1)
+        try:
+            s = V.VecSimIndex(V.VecSimType_FLOAT32, DIM, metric)
+        finally:
+            lib.RSGPU_SetTuning(b"shadow8", 0)
+        s.reserve(ROWS + 64)
+        assert s.add_philox_rows(SEED, 0, ROWS, 1) == ROWS
+        if with_planted:
+            for v, lab in zip(planted_vecs, planted):
+                assert s.add_vector(v, lab) == 1
+        return s
+
+    sh = shadowed(V.VecSimMetric_Cosine, True)
+    qs = list(O.philox_rows(SEED, QUERY_BASE, 3, DIM)) + [O.philox_rows(SEED, 4_242_424, 1, DIM)[0] * 1.5, q]
+    lib.RSGPU_ResetProfile()
+    lib.RSGPU_SetProfiling(1)
+    for qq in qs:
+        assert_topk_parity(sh, big_oracle, qq, K)
+    lib.RSGPU_SetProfiling(0)
+    launches, _, by = V.scan_profile()
+    assert launches == len(qs) and by == launches * (ROWS + K + 2) * (DIM + 8)      # every query ran the shadow scan
+    for qq in qs[:3]:
+        for k in (K, 100, 1000):
+            pi, ps = idx.topk_query(qq, k).results()
+            si, ss = sh.topk_query(qq, k).results()
+            assert si.tolist() == pi.tolist() and ss.tolist() == ps.tolist()
+    assert_topk_parity(sh, big_oracle, qs[1], 100)
+    del sh
+    plain = V.VecSimIndex(V.VecSimType_FLOAT32, DIM, V.VecSimMetric_L2)
+    plain.reserve(ROWS + 64)
+    assert plain.add_philox_rows(SEED, 0, ROWS, 1) == ROWS
+    sh = shadowed(V.VecSimMetric_L2, False)
+    for qq in qs[:3]:
+        for k in (K, 100):
+            pi, ps = plain.topk_query(qq, k).results()
+            si, ss = sh.topk_query(qq, k).results()
+            assert si.tolist() == pi.tolist() and ss.tolist() == ps.tolist()
+    # a stored row as the query: L2 distance 0 comes first
+    si, ss = sh.topk_query(O.philox_rows(SEED, 777_777, 1, DIM)[0], 3).results()
+    assert si[0] == 777_778 and ss[0] == 0.0
 
 
 def test_planted_neighbours_found_in_order(big):
