@@ -14,7 +14,8 @@ runs on all shards and the per-shard top-10 lists are merged by (score, label).
   * launched by torch.distributed.run (WORLD_SIZE set; how the driver runs it): one rank per GPU, per-shard top-k
     exchanged with ONE RCCL all-gather over xGMI, merged in C (RSGPU_MergeTopKPacked);
   * launched as a plain `python bench.py --gpus N` (WORLD_SIZE unset): ONE process drives the N devices through
-    RSGPU_ShardedIndex_* (a worker thread per device, host K-way merge) -- the in-process form a Redis module would use.
+    the ordinary VecSimIndex handle over N device shards (RSGPU_SetTuning("shards", N): a worker thread per device, host
+    K-way merge behind VecSimIndex_TopKQuery) -- the in-process form a Redis module would use.
 `value` = shard scans per second summed over the GPUs = N x the global QPS on the sharded corpus (at N=1 it is the
 QPS); perfect weak scaling reads N x the 1-GPU value.  The global QPS and p50/p95 latency are in `config`.
 
@@ -446,16 +447,18 @@ def main():
     vmetric = {"cosine": V.VecSimMetric_Cosine, "l2": V.VecSimMetric_L2, "ip": V.VecSimMetric_IP}[a.metric]
     # ---- corpus: global row i (label i+1) = Philox(SEED; i); rank / shard r holds rows [r*rows, (r+1)*rows)
     if inproc:
-        nd = torch.cuda.device_count()
-        index = V.ShardedIndex(V.VecSimType_FLOAT32, dim, vmetric, n_shards, devices=[i % nd for i in range(n_shards)],
-                               replicas=a.replicas)
-        for s in range(n_shards):
-            sh = index.shard(s)
-            sh.reserve(rows)
-            first = 0 if a.replicas else s * rows
-            sh.add_philox_rows(SEED, first, rows, first + 1)
+        # the ordinary VecSim handle over N device shards ("shards" knob): everything below -- VecSimIndex_TopKQuery
+        # included -- is the code a single-GPU run executes; the library fans out and merges (sharded_index.cpp)
+        lib.RSGPU_SetTuning(b"shards", n_shards)
+        lib.RSGPU_SetTuning(b"shard_replicas", int(a.replicas))
+        index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, vmetric)
+        lib.RSGPU_SetTuning(b"shards", 0)
+        lib.RSGPU_SetTuning(b"shard_replicas", 0)
         total_rows = rows if a.replicas else rows * n_shards
+        index.reserve(total_rows)
+        assert index.add_philox_rows(SEED, 0, total_rows, 1) == total_rows   # split in contiguous runs over the shards
         assert index.index_size() == total_rows
+        assert lib.RSGPU_ShardedIndex_NumShards(lib.RSGPU_ShardedIndex_FromHandle(index.ptr)) == n_shards
     else:
         index = V.VecSimIndex(V.VecSimType_FLOAT32, dim, vmetric)
         index.reserve(rows)
@@ -473,10 +476,7 @@ def main():
         if ranks_mode:
             labels, _ = sharded.query(q)   # per-shard top-k -> RCCL all-gather -> merge (C)
             return len(labels)
-        if inproc:
-            rep = lib.RSGPU_ShardedIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
-        else:
-            rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
+        rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
         n = lib.VecSimQueryReply_Len(rep)
         lib.VecSimQueryReply_Free(rep)
         return n
@@ -556,13 +556,13 @@ def main():
         achieved = (kern_bytes / max(launches, 1)) / avg_kernel_s / 1e9 if launches else 0.0
         scale = 1 if (inproc and a.replicas) else n_gpus
         par = ("single GPU" if n_gpus == 1 else
-               "%d full replicas in one process, one caller thread (RSGPU_ShardedIndex, replica mode)" % n_gpus if (inproc and a.replicas) else
-               "row-sharded x%d in ONE process: RSGPU_ShardedIndex (worker thread per device, host K-way merge)" % n_gpus if inproc else
+               "%d full replicas in one process behind the plain VecSim handle, one caller thread (replica mode)" % n_gpus if (inproc and a.replicas) else
+               "row-sharded x%d in ONE process behind the plain VecSim handle (\"shards\" knob: worker thread per device, host K-way merge)" % n_gpus if inproc else
                "row-sharded x%d, one rank per GPU: RCCL all-gather of per-shard top-k + merge in C" % n_gpus)
         out = {
             "metric": "KNN queries/sec + p50 latency, 10M×768 fp32 FLAT top-10, 1/2/4/8 GPU",  # BASELINE.json's metric
             "value": global_qps * scale,
-            "unit": "queries/s" if n_gpus == 1 else "shard-scans/s (queries/s x %d shards of %d rows)" % (n_gpus, rows),
+            "unit": "queries/s" if (n_gpus == 1 or (inproc and a.replicas)) else "shard-scans/s (queries/s x %d shards of %d rows)" % (n_gpus, rows),
             "n_gpus": n_gpus,
             "steps": a.steps,
             "warmup": a.warmup,

@@ -79,6 +79,14 @@ int RSGPU_ShardedIndex_ShardDevice(RSGPU_ShardedIndex *index, int shard);
 /* borrowed handle of one shard, for bulk loads (RSGPU_FlatIndex_AddDeviceRows / _AddPhiloxRows) and inspection; the
  * caller keeps labels disjoint across shards */
 VecSimIndex *RSGPU_ShardedIndex_Shard(RSGPU_ShardedIndex *index, int shard);
+/* Drop-in form: after RSGPU_SetTuning("shards", N) (and "shard_replicas", 0 | 1), VecSimIndex_New itself returns a handle
+ * over N device shards and the WHOLE VecSim C ABI works on it unchanged -- AddVector / DeleteVector (routed to the owning
+ * shard), TopKQuery / RangeQuery (fan-out + merge), VecSimBatchIterator_* (per-shard iterators with look-ahead buffers
+ * merged by (score, label)), VecSimIndex_AdhocBfCtx_* and GetDistanceFrom_Unsafe (labels routed to their shards),
+ * PreferAdHocSearch / info over the summed sizes -- so the reference's hybrid reader and vector_index.c run on several
+ * GPUs without a source change.  This returns the shards behind such a handle (NULL for a single-device handle); the
+ * handle owns them. */
+RSGPU_ShardedIndex *RSGPU_ShardedIndex_FromHandle(VecSimIndex *index);
 size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *index);
 /* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
  * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */
@@ -109,6 +117,9 @@ const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
  *                    K <= 128 queries with the two-stage exact scan
  *   "shadow8"        same with an int8 shadow + one fp32 scale per row (a quarter of the fp32 bytes; K <= 32)
  *   "two_stage"      1 (default): query-time switch of the above for indexes that carry a shadow
+ *   "shards"         0 (default); N > 1: VecSimIndex_New builds ONE index over N device shards (shard i on device
+ *                    i mod the visible devices) behind the ordinary handle -- see RSGPU_ShardedIndex_FromHandle
+ *   "shard_replicas" with "shards": every shard holds the whole corpus, queries go to one of them round-robin
  *   "vmm"            1 (default): row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual
  *                    range (no copy, no transient 2x HBM); 0: hipMalloc + full copy on every growth */
 int RSGPU_SetTuning(const char *key, int value);

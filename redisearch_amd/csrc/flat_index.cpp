@@ -1094,24 +1094,25 @@ double FlatIndex::distance_from(size_t label, const void *blob) {
 
 // VecSimIndex_PreferAdHocSearch for a brute-force index ([upstream-memory D6]; the four decision
 // points the reference pins are listed in SURVEY.md 8 a6).
-bool FlatIndex::prefer_adhoc(size_t subset, size_t k, bool initial_check) {
-  (void)k;
-  const size_t N = size(), labels = label_count(), d = dim;
+bool FlatIndex::prefer_adhoc_rule(size_t N, size_t labels, size_t d, size_t subset) {
   if (subset > N) subset = N;
   // the ratio is over LABELS (a multi-value index holds more vectors than documents), kept in float and compared
   // with double literals -- so exactly-on-threshold ratios fall where the float lands
   const float r = N ? (float)subset / (float)labels : 0.0f;
-  bool res;
-  if (N <= 5500) res = true;
-  else if (d <= 300) {
-    if (r <= 0.15) res = true;
-    else if (r <= 0.35) res = d <= 75 ? false : N <= 550000;
-    else res = false;
-  } else {
-    if (r <= 0.55) res = true;
-    else if (d <= 750) res = false;
-    else res = r <= 0.75;
+  if (N <= 5500) return true;
+  if (d <= 300) {
+    if (r <= 0.15) return true;
+    if (r <= 0.35) return d <= 75 ? false : N <= 550000;
+    return false;
   }
+  if (r <= 0.55) return true;
+  if (d <= 750) return false;
+  return r <= 0.75;
+}
+
+bool FlatIndex::prefer_adhoc(size_t subset, size_t k, bool initial_check) {
+  (void)k;
+  const bool res = prefer_adhoc_rule(size(), label_count(), dim, subset);
   last_mode = res ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
   return res;
 }

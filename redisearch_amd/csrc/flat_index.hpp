@@ -150,6 +150,8 @@ class FlatIndex {
   void topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
                   size_t *counts_out);
   bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
+  // the decision itself: N vectors under `labels` labels, `subset` of them pass the filter
+  static bool prefer_adhoc_rule(size_t N, size_t labels, size_t dim, size_t subset);
 
   // building blocks shared with the batch iterator / adhoc ctx / device-output extension
   void flush();                                                 // staged adds -> HBM (unique lock held)
@@ -264,9 +266,12 @@ struct VecSimQueryReply_Iterator {
   size_t pos;
 };
 
-// the opaque ABI handle
+// the opaque ABI handle: one FLAT index on one device, or -- created with the "shards" knob -- the same interface over
+// several device shards (sharded_index.hpp); exactly one of the two is set
+struct RSGPU_ShardedIndex;
 struct VecSimIndex {
   rsgpu::FlatIndex *flat;
+  RSGPU_ShardedIndex *sharded = nullptr;
 };
 
 namespace rsgpu {

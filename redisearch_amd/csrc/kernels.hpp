@@ -65,6 +65,8 @@ struct ScanTuning {
                            // (no copy, no transient 2x HBM); 0 = hipMalloc + copy on every growth
   int vmm_chunk_mib = 0;        // 0 = automatic (256 MiB, or 1 GiB for corpora reserved large); A/B knob
   int vmm_reserve_factor = 64;  // virtual range of a mapped row matrix = factor x its size at mapping time (>= 64 GiB)
+  int shards = 0;          // > 1: VecSimIndex_New builds one index over this many device shards (sharded_index.hpp)
+  int shard_replicas = 0;  // with shards: every shard holds the whole corpus, queries go round-robin
   int num_cus = 256;
 };
 ScanTuning &scan_tuning();

@@ -951,6 +951,31 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   if (!h || !index || !query) return -1;
   FlatIndex *f = index->flat;
   S_TRY
+  if (!f) {
+    // a sharded handle (VecSimIndex_New under the "shards" knob): the candidates go through the ad-hoc context of the
+    // VecSim ABI, which routes every label to the shard that owns it
+    if (!h->len || !k) return 0;
+    HIP_CHECK(hipSetDevice(h->device));
+    const std::vector<uint32_t> &ids = h->host_ids();
+    std::vector<size_t> labels(ids.size());
+    for (size_t i = 0; i < ids.size(); i++) labels[i] = (size_t)(h->base + ids[i]);
+    std::vector<double> d(h->len);
+    VecSimAdhocBfCtx *actx = VecSimIndex_AdhocBfCtx_New(index, query);
+    if (!actx) throw std::runtime_error(last_error());
+    VecSimIndex_AdhocBfCtx_GetExactDistances(actx, labels.data(), d.data(), h->len);
+    VecSimIndex_AdhocBfCtx_Free(actx);
+    std::vector<uint32_t> order;
+    for (uint32_t i = 0; i < h->len; i++)
+      if (!std::isnan(d[i])) order.push_back(i);  // NaN: the doc has no vector (hybrid_reader.c:317-320)
+    const size_t take = std::min<size_t>(k, order.size());
+    std::partial_sort(order.begin(), order.begin() + take, order.end(),
+                      [&](uint32_t a, uint32_t b) { return d[a] != d[b] ? d[a] < d[b] : a < b; });
+    for (size_t i = 0; i < take; i++) {
+      if (doc_ids_out) doc_ids_out[i] = labels[order[i]];
+      if (dist_out) dist_out[i] = d[order[i]];
+    }
+    return (long)take;
+  }
   if (f->device != h->device) throw std::runtime_error("hits and index live on different devices");
   if (f->key_bytes != 4) throw std::runtime_error("RSGPU_Hits_KnnRerank: FLOAT64 indexes are served by VecSimIndex_AdhocBfCtx_GetExactDistances");
   f->flush_if_needed();
@@ -1132,9 +1157,10 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   std::vector<Hit> knn_hits;
   bool knn_on_host_map = false;
   if (want_knn && len) {
-    std::shared_lock<std::shared_mutex> g(f->mu);
+    std::shared_lock<std::shared_mutex> g;
+    if (f) g = std::shared_lock<std::shared_mutex>(f->mu);
     uint64_t base = 0;
-    if (f->identity_labels(&base)) {
+    if (f && f->identity_labels(&base)) {
       sc.rows.ensure(len);
       sc.dists.ensure(len);
       sc.keys32.ensure(len);

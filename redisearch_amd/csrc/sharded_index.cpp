@@ -15,23 +15,17 @@
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
 
-#include "flat_index.hpp"
 #include "rsgpu_ext.h"
+#include "sharded_index.hpp"
 
 using namespace rsgpu;
 
 namespace {
-
-struct Job {
-  enum Kind { NONE, TOPK, RANGE, STOP } kind = NONE;
-  const void *query = nullptr;
-  size_t k = 0;
-  double radius = 0;
-  VecSimQueryParams *qp = nullptr;
-};
 
 struct Shard {
   FlatIndex *flat = nullptr;
@@ -39,9 +33,9 @@ struct Shard {
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
-  Job job;
+  std::function<void()> job;  // empty + stop: leave
+  bool stop = false;
   uint64_t posted = 0, done = 0;  // generation counters
-  VecSimQueryReply *reply = nullptr;
   std::string error;
 };
 
@@ -56,26 +50,27 @@ struct RSGPU_ShardedIndex {
   std::condition_variable done_cv;
   std::mutex query_mu;  // one fan-out at a time (the workers hold one job slot each)
   std::atomic<uint64_t> rr{0};
-  std::vector<VecSimIndex> handles;  // borrowed views for RSGPU_ShardedIndex_Shard
+  std::atomic<int> last_mode{EMPTY_MODE};
+  std::vector<VecSimIndex> handles;  // per-shard ABI handles (RSGPU_ShardedIndex_Shard; per-shard iterators / contexts)
+  size_t n() const { return shards.size(); }
+  Shard *pick() { return shards[rr++ % shards.size()].get(); }  // replica mode: round-robin
 };
 
 static void worker_main(RSGPU_ShardedIndex *si, Shard *s) {
   (void)hipSetDevice(s->device);
   uint64_t seen = 0;
   for (;;) {
-    Job job;
+    std::function<void()> job;
     {
       std::unique_lock<std::mutex> g(s->mu);
       s->cv.wait(g, [&] { return s->posted != seen; });
       seen = s->posted;
+      if (s->stop) return;
       job = s->job;
     }
-    if (job.kind == Job::STOP) return;
-    VecSimQueryReply *r = nullptr;
     std::string err;
     try {
-      if (job.kind == Job::TOPK) r = s->flat->topk(job.query, job.k, job.qp, BY_SCORE);
-      else if (job.kind == Job::RANGE) r = s->flat->range(job.query, job.radius, job.qp, BY_SCORE);
+      if (job) job();
     } catch (const std::exception &e) {
       err = e.what();
     } catch (...) {
@@ -83,7 +78,6 @@ static void worker_main(RSGPU_ShardedIndex *si, Shard *s) {
     }
     {
       std::lock_guard<std::mutex> g(si->done_mu);
-      s->reply = r;
       s->error = err;
       s->done = seen;
     }
@@ -91,67 +85,459 @@ static void worker_main(RSGPU_ShardedIndex *si, Shard *s) {
   }
 }
 
-static void post_all(RSGPU_ShardedIndex *si, const Job &job) {
-  for (auto &s : si->shards) {
+// Runs jobs[i] on shard i's worker (its device is current there), all at once; returns when every one has finished.
+// Throws the first error.  The caller holds query_mu.
+static void run_on_shards(RSGPU_ShardedIndex *si, const std::vector<std::function<void()>> &jobs) {
+  for (size_t i = 0; i < si->n(); i++) {
+    Shard *s = si->shards[i].get();
     {
       std::lock_guard<std::mutex> g(s->mu);
-      s->job = job;
+      s->job = jobs[i];
       s->posted++;
     }
     s->cv.notify_one();
   }
-  std::unique_lock<std::mutex> g(si->done_mu);
-  si->done_cv.wait(g, [&] {
-    for (auto &s : si->shards)
-      if (s->done != s->posted) return false;
-    return true;
-  });
+  std::string err;
+  {
+    std::unique_lock<std::mutex> g(si->done_mu);
+    si->done_cv.wait(g, [&] {
+      for (auto &s : si->shards)
+        if (s->done != s->posted) return false;
+      return true;
+    });
+    for (auto &s : si->shards) {
+      if (!s->error.empty() && err.empty()) err = s->error;
+      s->error.clear();
+    }
+  }
+  if (!err.empty()) throw std::runtime_error(err);
+}
+
+// shard code that runs on the CALLER's thread selects the shard's device there: put the caller's device back afterwards
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+static bool by_score_then_id(const VecSimQueryResult &a, const VecSimQueryResult &b) {
+  return a.score != b.score ? a.score < b.score : a.id < b.id;
 }
 
 // K-way merge of per-shard replies (each ascending by (score, id)); frees them.
-static VecSimQueryReply *merge_replies(RSGPU_ShardedIndex *si, size_t k, bool cut, VecSimQueryReply_Order order) {
+static VecSimQueryReply *merge_replies(std::vector<VecSimQueryReply *> &replies, size_t k, bool cut,
+                                       VecSimQueryReply_Order order) {
   size_t total = 0;
   bool timed_out_any = false;
-  std::string err;
-  for (auto &s : si->shards) {
-    if (!s->error.empty()) err = s->error;
-    if (s->reply) {
-      total += s->reply->len;
-      timed_out_any |= s->reply->code == VecSim_QueryReply_TimedOut;
+  for (VecSimQueryReply *r : replies)
+    if (r) {
+      total += r->len;
+      timed_out_any |= r->code == VecSim_QueryReply_TimedOut;
     }
-  }
   VecSimQueryReply *out = nullptr;
-  if (err.empty()) {
-    if (timed_out_any) {
-      out = new_reply(0, VecSim_QueryReply_TimedOut);
-    } else {
-      const size_t take = cut ? std::min(k, total) : total;
-      out = new_reply(take, VecSim_QueryReply_OK);
-      std::vector<size_t> pos(si->shards.size(), 0);
-      for (size_t n = 0; n < take; n++) {
-        int best = -1;
-        for (size_t i = 0; i < si->shards.size(); i++) {
-          VecSimQueryReply *r = si->shards[i]->reply;
-          if (!r || pos[i] >= r->len) continue;
-          if (best < 0) { best = (int)i; continue; }
-          const VecSimQueryResult &a = r->results[pos[i]], &b = si->shards[best]->reply->results[pos[best]];
-          if (a.score != b.score ? a.score < b.score : a.id < b.id) best = (int)i;
-        }
-        out->results[n] = si->shards[best]->reply->results[pos[best]++];
+  if (timed_out_any) {
+    out = new_reply(0, VecSim_QueryReply_TimedOut);
+  } else {
+    const size_t take = cut ? std::min(k, total) : total;
+    out = new_reply(take, VecSim_QueryReply_OK);
+    std::vector<size_t> pos(replies.size(), 0);
+    for (size_t n = 0; n < take; n++) {
+      int best = -1;
+      for (size_t i = 0; i < replies.size(); i++) {
+        VecSimQueryReply *r = replies[i];
+        if (!r || pos[i] >= r->len) continue;
+        if (best < 0 || by_score_then_id(r->results[pos[i]], replies[best]->results[pos[best]])) best = (int)i;
       }
-      if (order == BY_ID)
-        std::sort(out->results, out->results + out->len,
-                  [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
+      out->results[n] = replies[best]->results[pos[best]++];
     }
+    if (order == BY_ID)
+      std::sort(out->results, out->results + out->len,
+                [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
   }
-  for (auto &s : si->shards) {
-    VecSimQueryReply_Free(s->reply);
-    s->reply = nullptr;
-    s->error.clear();
+  for (VecSimQueryReply *&r : replies) {
+    VecSimQueryReply_Free(r);
+    r = nullptr;
   }
-  if (!err.empty()) throw std::runtime_error(err);
   return out;
 }
+
+namespace rsgpu {
+
+RSGPU_ShardedIndex *sharded_new(const BFParams &p, void *log_ctx, int n_shards, const int *devices, bool replicas) {
+  if (n_shards < 1 || n_shards > 64) throw std::runtime_error("1..64 shards");
+  std::string why;
+  if (!device_available(&why)) throw std::runtime_error(why);
+  int ndev = 0;
+  HIP_CHECK(hipGetDeviceCount(&ndev));
+  int prev = 0;
+  HIP_CHECK(hipGetDevice(&prev));
+  std::unique_ptr<RSGPU_ShardedIndex> si(new RSGPU_ShardedIndex());
+  si->replicas = replicas;
+  si->multi = p.multi;
+  si->log_ctx = log_ctx;
+  try {
+    for (int i = 0; i < n_shards; i++) {
+      const int dev = devices ? devices[i] : i % ndev;
+      if (dev < 0 || dev >= ndev) throw std::runtime_error("no such device");
+      HIP_CHECK(hipSetDevice(dev));
+      std::unique_ptr<Shard> s(new Shard());
+      s->device = dev;
+      s->flat = new FlatIndex(p, log_ctx);
+      si->shards.push_back(std::move(s));
+    }
+  } catch (...) {
+    for (auto &s : si->shards) delete s->flat;
+    (void)hipSetDevice(prev);
+    throw;
+  }
+  HIP_CHECK(hipSetDevice(prev));
+  si->handles.resize(si->n());
+  for (size_t i = 0; i < si->n(); i++) {
+    si->handles[i].flat = si->shards[i]->flat;
+    if (!si->replicas && si->n() > 1) si->shards[i]->worker = std::thread(worker_main, si.get(), si->shards[i].get());
+  }
+  return si.release();
+}
+
+void sharded_free(RSGPU_ShardedIndex *si) {
+  if (!si) return;
+  for (auto &s : si->shards) {
+    if (s->worker.joinable()) {
+      {
+        std::lock_guard<std::mutex> g(s->mu);
+        s->stop = true;
+        s->posted++;
+      }
+      s->cv.notify_one();
+      s->worker.join();
+    }
+    try {
+      delete s->flat;
+    } catch (...) {
+    }
+  }
+  delete si;
+}
+
+void *sharded_log_ctx(RSGPU_ShardedIndex *si) { return si->log_ctx; }
+FlatIndex *sharded_first(RSGPU_ShardedIndex *si) { return si->shards[0]->flat; }
+int sharded_last_mode(RSGPU_ShardedIndex *si) { return si->last_mode.load(); }
+
+size_t sharded_size(RSGPU_ShardedIndex *si) {
+  if (si->replicas) return si->shards[0]->flat->size();
+  size_t n = 0;
+  for (auto &s : si->shards) n += s->flat->size();
+  return n;
+}
+size_t sharded_label_count(RSGPU_ShardedIndex *si) {
+  if (si->replicas) return si->shards[0]->flat->label_count();
+  size_t n = 0;  // a label lives on exactly one shard
+  for (auto &s : si->shards) n += s->flat->label_count();
+  return n;
+}
+size_t sharded_memory(RSGPU_ShardedIndex *si) {
+  size_t n = 0;
+  for (auto &s : si->shards) n += s->flat->memory();
+  return n;
+}
+
+// A label lives on exactly one shard: an existing label is overwritten (single-value) or extended (multi-value) where
+// it is, a new one goes to the emptiest shard.  Replicas: every shard gets the vector.
+int sharded_add(RSGPU_ShardedIndex *si, const void *blob, size_t label) {
+  DeviceGuard dg;
+  if (si->replicas) {
+    int r = 0;
+    for (auto &s : si->shards) r = s->flat->add(blob, label);
+    return r;
+  }
+  Shard *target = nullptr;
+  for (auto &s : si->shards)
+    if (s->flat->contains(label)) { target = s.get(); break; }
+  if (!target) {
+    size_t best = SIZE_MAX;
+    for (auto &s : si->shards) {
+      const size_t n = s->flat->size();
+      if (n < best) { best = n; target = s.get(); }
+    }
+  }
+  return target->flat->add(blob, label);
+}
+
+int sharded_remove(RSGPU_ShardedIndex *si, size_t label) {
+  DeviceGuard dg;
+  int removed = 0;
+  for (auto &s : si->shards) {
+    const int r = s->flat->remove(label);
+    removed = si->replicas ? r : removed + r;
+  }
+  return removed;
+}
+
+double sharded_distance_from(RSGPU_ShardedIndex *si, size_t label, const void *normalized_blob) {
+  DeviceGuard dg;
+  if (si->replicas) return si->pick()->flat->distance_from(label, normalized_blob);
+  for (auto &s : si->shards) {
+    if (!s->flat->contains(label)) continue;
+    return s->flat->distance_from(label, normalized_blob);
+  }
+  return NAN;
+}
+
+VecSimQueryReply *sharded_topk(RSGPU_ShardedIndex *si, const void *query, size_t k, VecSimQueryParams *qp,
+                               VecSimQueryReply_Order order) {
+  DeviceGuard dg;
+  si->last_mode = STANDARD_KNN;
+  if (si->replicas) return si->pick()->flat->topk(query, k, qp, order);
+  if (si->n() == 1) return si->shards[0]->flat->topk(query, k, qp, order);
+  std::lock_guard<std::mutex> q(si->query_mu);
+  std::vector<VecSimQueryReply *> replies(si->n(), nullptr);
+  std::vector<std::function<void()>> jobs;
+  for (size_t i = 0; i < si->n(); i++) {
+    FlatIndex *f = si->shards[i]->flat;
+    VecSimQueryReply **slot = &replies[i];
+    jobs.push_back([=] { *slot = f->topk(query, k, qp, BY_SCORE); });
+  }
+  try {
+    run_on_shards(si, jobs);
+  } catch (...) {
+    for (VecSimQueryReply *r : replies) VecSimQueryReply_Free(r);
+    throw;
+  }
+  return merge_replies(replies, k, true, order);
+}
+
+VecSimQueryReply *sharded_range(RSGPU_ShardedIndex *si, const void *query, double radius, VecSimQueryParams *qp,
+                                VecSimQueryReply_Order order) {
+  DeviceGuard dg;
+  si->last_mode = RANGE_QUERY;
+  if (si->replicas) return si->pick()->flat->range(query, radius, qp, order);
+  if (si->n() == 1) return si->shards[0]->flat->range(query, radius, qp, order);
+  std::lock_guard<std::mutex> q(si->query_mu);
+  std::vector<VecSimQueryReply *> replies(si->n(), nullptr);
+  std::vector<std::function<void()>> jobs;
+  for (size_t i = 0; i < si->n(); i++) {
+    FlatIndex *f = si->shards[i]->flat;
+    VecSimQueryReply **slot = &replies[i];
+    jobs.push_back([=] { *slot = f->range(query, radius, qp, BY_SCORE); });
+  }
+  try {
+    run_on_shards(si, jobs);
+  } catch (...) {
+    for (VecSimQueryReply *r : replies) VecSimQueryReply_Free(r);
+    throw;
+  }
+  return merge_replies(replies, 0, false, order);
+}
+
+// the reference's decision tree over the WHOLE index (vectors and labels summed over the shards)
+bool sharded_prefer_adhoc(RSGPU_ShardedIndex *si, size_t subset, size_t k, bool initial_check) {
+  (void)k;
+  const bool res = FlatIndex::prefer_adhoc_rule(sharded_size(si), sharded_label_count(si), si->shards[0]->flat->dim, subset);
+  si->last_mode = res ? (initial_check ? HYBRID_ADHOC_BF : HYBRID_BATCHES_TO_ADHOC_BF) : HYBRID_BATCHES;
+  return res;
+}
+
+void sharded_reserve(RSGPU_ShardedIndex *si, size_t rows) {
+  DeviceGuard dg;
+  const size_t per = si->replicas ? rows : (rows + si->n() - 1) / si->n();
+  for (auto &s : si->shards) s->flat->reserve(per);
+}
+
+long sharded_add_philox_rows(RSGPU_ShardedIndex *si, uint64_t seed, uint64_t first_index, size_t n, size_t first_label) {
+  DeviceGuard dg;
+  long added = 0;
+  if (si->replicas) {
+    for (auto &s : si->shards) added = s->flat->add_philox_rows(seed, first_index, n, first_label);
+    return added;
+  }
+  const size_t per = (n + si->n() - 1) / si->n();
+  for (size_t i = 0; i < si->n(); i++) {
+    const size_t a = std::min(n, i * per), b = std::min(n, a + per);
+    if (b > a) added += si->shards[i]->flat->add_philox_rows(seed, first_index + a, b - a, first_label + a);
+  }
+  return added;
+}
+
+// ---- batch iterator ---------------------------------------------------------------------------------------------------
+// Every shard has its own iterator (keys of its rows, resumable select).  Next(n): every shard whose look-ahead buffer
+// holds fewer than n results is asked for the difference -- all shards at once, the first call is the scan itself --
+// then the n best of the buffers' fronts are taken by (score, label).  What stays in the buffers is the head start of
+// the next call.  A label lives on one shard, so multi-value de-duplication stays inside the shard iterators.
+struct ShardedBatchIterator {
+  RSGPU_ShardedIndex *si = nullptr;
+  std::vector<VecSimBatchIterator *> its;
+  std::vector<std::deque<VecSimQueryResult>> buf;
+};
+
+ShardedBatchIterator *sharded_batch_new(RSGPU_ShardedIndex *si, const void *query, VecSimQueryParams *qp) {
+  DeviceGuard dg;
+  std::unique_ptr<ShardedBatchIterator> it(new ShardedBatchIterator());
+  it->si = si;
+  const size_t m = si->replicas ? 1 : si->n();
+  const size_t first = si->replicas ? (size_t)(si->rr++ % si->n()) : 0;
+  for (size_t i = 0; i < m; i++) {
+    VecSimBatchIterator *b = VecSimBatchIterator_New(&si->handles[first + i], query, qp);
+    if (!b) {
+      for (VecSimBatchIterator *x : it->its) VecSimBatchIterator_Free(x);
+      throw std::runtime_error(last_error());
+    }
+    it->its.push_back(b);
+  }
+  it->buf.resize(m);
+  return it.release();
+}
+
+bool sharded_batch_has_next(ShardedBatchIterator *it) {
+  for (size_t i = 0; i < it->its.size(); i++)
+    if (!it->buf[i].empty() || VecSimBatchIterator_HasNext(it->its[i])) return true;
+  return false;
+}
+
+VecSimQueryReply *sharded_batch_next(ShardedBatchIterator *it, size_t n, VecSimQueryReply_Order order) {
+  DeviceGuard dg;
+  RSGPU_ShardedIndex *si = it->si;
+  si->last_mode = HYBRID_BATCHES;
+  if (it->its.size() == 1) return VecSimBatchIterator_Next(it->its[0], n, order);
+  std::vector<VecSimQueryReply *> replies(it->its.size(), nullptr);
+  {
+    std::lock_guard<std::mutex> q(si->query_mu);
+    std::vector<std::function<void()>> jobs;
+    for (size_t i = 0; i < it->its.size(); i++) {
+      const size_t have = it->buf[i].size();
+      VecSimBatchIterator *b = it->its[i];
+      VecSimQueryReply **slot = &replies[i];
+      if (have >= n || !VecSimBatchIterator_HasNext(b)) {
+        jobs.push_back(nullptr);
+        continue;
+      }
+      const size_t need = n - have;
+      jobs.push_back([=] {
+        *slot = VecSimBatchIterator_Next(b, need, BY_SCORE);
+        if (!*slot) throw std::runtime_error(last_error());
+      });
+    }
+    try {
+      run_on_shards(si, jobs);
+    } catch (...) {
+      for (VecSimQueryReply *r : replies) VecSimQueryReply_Free(r);
+      throw;
+    }
+  }
+  bool timed = false;
+  for (size_t i = 0; i < replies.size(); i++) {
+    VecSimQueryReply *r = replies[i];
+    if (!r) continue;
+    timed |= r->code == VecSim_QueryReply_TimedOut;
+    for (size_t j = 0; j < r->len; j++) it->buf[i].push_back(r->results[j]);
+    VecSimQueryReply_Free(r);
+  }
+  if (timed) return new_reply(0, VecSim_QueryReply_TimedOut);
+  std::vector<VecSimQueryResult> out;
+  while (out.size() < n) {
+    int best = -1;
+    for (size_t i = 0; i < it->buf.size(); i++)
+      if (!it->buf[i].empty() && (best < 0 || by_score_then_id(it->buf[i].front(), it->buf[best].front()))) best = (int)i;
+    if (best < 0) break;
+    out.push_back(it->buf[best].front());
+    it->buf[best].pop_front();
+  }
+  VecSimQueryReply *r = new_reply(out.size(), VecSim_QueryReply_OK);
+  if (!out.empty()) memcpy(r->results, out.data(), out.size() * sizeof(VecSimQueryResult));
+  if (order == BY_ID)
+    std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
+  return r;
+}
+
+void sharded_batch_reset(ShardedBatchIterator *it) {
+  DeviceGuard dg;
+  for (size_t i = 0; i < it->its.size(); i++) {
+    VecSimBatchIterator_Reset(it->its[i]);
+    it->buf[i].clear();
+  }
+}
+
+void sharded_batch_free(ShardedBatchIterator *it) {
+  DeviceGuard dg;
+  if (!it) return;
+  for (VecSimBatchIterator *b : it->its) VecSimBatchIterator_Free(b);
+  delete it;
+}
+
+// ---- ad-hoc context -----------------------------------------------------------------------------------------------------
+struct ShardedAdhoc {
+  RSGPU_ShardedIndex *si = nullptr;
+  std::vector<VecSimAdhocBfCtx *> ctx;
+  size_t first = 0;  // replica mode: the replica this context reads
+};
+
+ShardedAdhoc *sharded_adhoc_new(RSGPU_ShardedIndex *si, const void *query) {
+  DeviceGuard dg;
+  std::unique_ptr<ShardedAdhoc> a(new ShardedAdhoc());
+  a->si = si;
+  const size_t m = si->replicas ? 1 : si->n();
+  a->first = si->replicas ? (size_t)(si->rr++ % si->n()) : 0;
+  for (size_t i = 0; i < m; i++) {
+    VecSimAdhocBfCtx *c = VecSimIndex_AdhocBfCtx_New(&si->handles[a->first + i], query);
+    if (!c) {
+      for (VecSimAdhocBfCtx *x : a->ctx) VecSimIndex_AdhocBfCtx_Free(x);
+      throw std::runtime_error(last_error());
+    }
+    a->ctx.push_back(c);
+  }
+  return a.release();
+}
+
+void sharded_adhoc_distances(ShardedAdhoc *a, const size_t *labels, double *out, size_t count) {
+  DeviceGuard dg;
+  RSGPU_ShardedIndex *si = a->si;
+  si->last_mode = HYBRID_ADHOC_BF;
+  if (a->ctx.size() == 1) {
+    VecSimIndex_AdhocBfCtx_GetExactDistances(a->ctx[0], labels, out, count);
+    return;
+  }
+  const size_t m = a->ctx.size();
+  std::vector<std::vector<size_t>> lab(m), at(m);
+  for (size_t i = 0; i < count; i++) {
+    out[i] = NAN;  // a label no shard holds
+    for (size_t s = 0; s < m; s++)
+      if (si->shards[s]->flat->contains(labels[i])) {
+        lab[s].push_back(labels[i]);
+        at[s].push_back(i);
+        break;
+      }
+  }
+  std::vector<std::vector<double>> d(m);
+  std::lock_guard<std::mutex> q(si->query_mu);
+  std::vector<std::function<void()>> jobs;
+  for (size_t s = 0; s < m; s++) {
+    if (lab[s].empty()) {
+      jobs.push_back(nullptr);
+      continue;
+    }
+    d[s].resize(lab[s].size());
+    VecSimAdhocBfCtx *c = a->ctx[s];
+    const size_t *lp = lab[s].data();
+    double *dp = d[s].data();
+    const size_t cnt = lab[s].size();
+    jobs.push_back([=] { VecSimIndex_AdhocBfCtx_GetExactDistances(c, lp, dp, cnt); });
+  }
+  run_on_shards(si, jobs);
+  for (size_t s = 0; s < m; s++)
+    for (size_t j = 0; j < at[s].size(); j++) out[at[s][j]] = d[s][j];
+}
+
+void sharded_adhoc_free(ShardedAdhoc *a) {
+  DeviceGuard dg;
+  if (!a) return;
+  for (VecSimAdhocBfCtx *c : a->ctx) VecSimIndex_AdhocBfCtx_Free(c);
+  delete a;
+}
+
+}  // namespace rsgpu
 
 #define SH_TRY try {
 #define SH_CATCH(si, where, ret)                                      \
@@ -170,66 +556,17 @@ extern "C" {
 
 RSGPU_ShardedIndex *RSGPU_ShardedIndex_New(const VecSimParams *params, int n_shards, const int *devices, int replicas) {
   if (!params || n_shards < 1 || n_shards > 64) return nullptr;
-  RSGPU_ShardedIndex *si = nullptr;
-  SH_TRY
-  if (params->algo != VecSimAlgo_BF) throw std::runtime_error("only VecSimAlgo_BF (FLAT) is served");
-  std::string why;
-  if (!device_available(&why)) throw std::runtime_error(why);
-  int ndev = 0;
-  HIP_CHECK(hipGetDeviceCount(&ndev));
-  int prev = 0;
-  HIP_CHECK(hipGetDevice(&prev));
-  si = new RSGPU_ShardedIndex();
-  si->replicas = replicas != 0;
-  si->multi = params->algoParams.bfParams.multi;
-  si->log_ctx = params->logCtx;
-  for (int i = 0; i < n_shards; i++) {
-    const int dev = devices ? devices[i] : i % ndev;
-    if (dev < 0 || dev >= ndev) throw std::runtime_error("RSGPU_ShardedIndex_New: no such device");
-    HIP_CHECK(hipSetDevice(dev));
-    std::unique_ptr<Shard> s(new Shard());
-    s->device = dev;
-    s->flat = new FlatIndex(params->algoParams.bfParams, params->logCtx);
-    si->shards.push_back(std::move(s));
-  }
-  HIP_CHECK(hipSetDevice(prev));
-  si->handles.resize(si->shards.size());
-  for (size_t i = 0; i < si->shards.size(); i++) {
-    si->handles[i].flat = si->shards[i]->flat;
-    if (!si->replicas) si->shards[i]->worker = std::thread(worker_main, si, si->shards[i].get());
-  }
-  return si;
-  }
-  catch (const std::exception &e) {
+  try {
+    if (params->algo != VecSimAlgo_BF) throw std::runtime_error("only VecSimAlgo_BF (FLAT) is served");
+    return sharded_new(params->algoParams.bfParams, params->logCtx, n_shards, devices, replicas != 0);
+  } catch (const std::exception &e) {
     last_error() = std::string("RSGPU_ShardedIndex_New: ") + e.what();
     logf(params->logCtx, "warning", "%s", last_error().c_str());
-    if (si) {
-      for (auto &s : si->shards) delete s->flat;
-      delete si;
-    }
     return nullptr;
   }
 }
 
-void RSGPU_ShardedIndex_Free(RSGPU_ShardedIndex *si) {
-  if (!si) return;
-  for (auto &s : si->shards) {
-    if (s->worker.joinable()) {
-      {
-        std::lock_guard<std::mutex> g(s->mu);
-        s->job.kind = Job::STOP;
-        s->posted++;
-      }
-      s->cv.notify_one();
-      s->worker.join();
-    }
-    try {
-      delete s->flat;
-    } catch (...) {
-    }
-  }
-  delete si;
-}
+void RSGPU_ShardedIndex_Free(RSGPU_ShardedIndex *si) { sharded_free(si); }
 
 int RSGPU_ShardedIndex_NumShards(RSGPU_ShardedIndex *si) { return si ? (int)si->shards.size() : 0; }
 int RSGPU_ShardedIndex_ShardDevice(RSGPU_ShardedIndex *si, int shard) {
@@ -238,59 +575,29 @@ int RSGPU_ShardedIndex_ShardDevice(RSGPU_ShardedIndex *si, int shard) {
 VecSimIndex *RSGPU_ShardedIndex_Shard(RSGPU_ShardedIndex *si, int shard) {
   return (si && shard >= 0 && shard < (int)si->shards.size()) ? &si->handles[shard] : nullptr;
 }
+/* the ABI handle's shards, when the handle came from VecSimIndex_New under the "shards" knob (NULL otherwise) */
+RSGPU_ShardedIndex *RSGPU_ShardedIndex_FromHandle(VecSimIndex *index) { return index ? index->sharded : nullptr; }
 
-size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *si) {
-  if (!si) return 0;
-  if (si->replicas) return si->shards[0]->flat->size();
-  size_t n = 0;
-  for (auto &s : si->shards) n += s->flat->size();
-  return n;
-}
+size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *si) { return si ? sharded_size(si) : 0; }
 
-// A label lives on exactly one shard: an existing label is overwritten (single-value) or extended (multi-value) where
-// it is, a new one goes to the emptiest shard.  Replicas: every shard gets the vector.
 int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *si, const void *blob, size_t label) {
   if (!si || !blob) return 0;
   SH_TRY
-  if (si->replicas) {
-    int r = 0;
-    for (auto &s : si->shards) r = s->flat->add(blob, label);
-    return r;
-  }
-  Shard *target = nullptr;
-  for (auto &s : si->shards)
-    if (s->flat->contains(label)) { target = s.get(); break; }
-  if (!target) {
-    size_t best = SIZE_MAX;
-    for (auto &s : si->shards) {
-      const size_t n = s->flat->size();
-      if (n < best) { best = n; target = s.get(); }
-    }
-  }
-  return target->flat->add(blob, label);
+  return sharded_add(si, blob, label);
   SH_CATCH(si, "RSGPU_ShardedIndex_AddVector", 0)
 }
 
 int RSGPU_ShardedIndex_DeleteVector(RSGPU_ShardedIndex *si, size_t label) {
   if (!si) return 0;
   SH_TRY
-  int removed = 0;
-  for (auto &s : si->shards) {
-    const int r = s->flat->remove(label);
-    removed = si->replicas ? r : removed + r;
-  }
-  return removed;
+  return sharded_remove(si, label);
   SH_CATCH(si, "RSGPU_ShardedIndex_DeleteVector", 0)
 }
 
 double RSGPU_ShardedIndex_GetDistanceFrom(RSGPU_ShardedIndex *si, size_t label, const void *normalized_blob) {
   if (!si || !normalized_blob) return NAN;
   SH_TRY
-  for (auto &s : si->shards) {
-    if (!s->flat->contains(label)) continue;
-    return s->flat->distance_from(label, normalized_blob);
-  }
-  return NAN;
+  return sharded_distance_from(si, label, normalized_blob);
   SH_CATCH(si, "RSGPU_ShardedIndex_GetDistanceFrom", NAN)
 }
 
@@ -298,19 +605,7 @@ VecSimQueryReply *RSGPU_ShardedIndex_TopKQuery(RSGPU_ShardedIndex *si, const voi
                                                VecSimQueryParams *qp, VecSimQueryReply_Order order) {
   if (!si || !query) return nullptr;
   SH_TRY
-  if (si->replicas) {
-    Shard *s = si->shards[si->rr++ % si->shards.size()].get();
-    return s->flat->topk(query, k, qp, order);
-  }
-  if (si->shards.size() == 1) return si->shards[0]->flat->topk(query, k, qp, order);
-  std::lock_guard<std::mutex> q(si->query_mu);
-  Job job;
-  job.kind = Job::TOPK;
-  job.query = query;
-  job.k = k;
-  job.qp = qp;
-  post_all(si, job);
-  return merge_replies(si, k, true, order);
+  return sharded_topk(si, query, k, qp, order);
   SH_CATCH(si, "RSGPU_ShardedIndex_TopKQuery", nullptr)
 }
 
@@ -318,19 +613,7 @@ VecSimQueryReply *RSGPU_ShardedIndex_RangeQuery(RSGPU_ShardedIndex *si, const vo
                                                 VecSimQueryParams *qp, VecSimQueryReply_Order order) {
   if (!si || !query) return nullptr;
   SH_TRY
-  if (si->replicas) {
-    Shard *s = si->shards[si->rr++ % si->shards.size()].get();
-    return s->flat->range(query, radius, qp, order);
-  }
-  if (si->shards.size() == 1) return si->shards[0]->flat->range(query, radius, qp, order);
-  std::lock_guard<std::mutex> q(si->query_mu);
-  Job job;
-  job.kind = Job::RANGE;
-  job.query = query;
-  job.radius = radius;
-  job.qp = qp;
-  post_all(si, job);
-  return merge_replies(si, 0, false, order);
+  return sharded_range(si, query, radius, qp, order);
   SH_CATCH(si, "RSGPU_ShardedIndex_RangeQuery", nullptr)
 }
 

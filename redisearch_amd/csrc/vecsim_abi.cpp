@@ -9,6 +9,7 @@
 #include <strings.h>
 
 #include "flat_index.hpp"
+#include "sharded_index.hpp"
 #include "VecSim/vec_sim_debug.h"
 #include "rsgpu_ext.h"
 
@@ -20,10 +21,13 @@ void normalize_blob(void *blob, size_t dim, VecSimType type);
 
 struct VecSimBatchIterator {
   BatchIterator it;
+  ShardedBatchIterator *sh = nullptr;  // the iterator of a sharded handle (then `it` is unused)
 };
 struct VecSimAdhocBfCtx {
   AdhocCtx a;
+  ShardedAdhoc *sh = nullptr;
 };
+static void *log_ctx_of(VecSimIndex *index) { return index->sharded ? sharded_log_ctx(index->sharded) : index->flat->log_ctx; }
 struct VecSimDebugInfoIterator {
   std::vector<VecSim_InfoField> fields;
   std::vector<std::string> strings;
@@ -76,6 +80,9 @@ VecSimIndex *VecSimIndex_New(const VecSimParams *params) {
     set_error(lctx, "VecSimIndex_New", why.c_str());
     return nullptr;
   }
+  // "shards" knob: the same handle over several device shards -- every entry point below dispatches on it
+  if (scan_tuning().shards > 1)
+    return new VecSimIndex{nullptr, sharded_new(bf, lctx, scan_tuning().shards, nullptr, scan_tuning().shard_replicas != 0)};
   VecSimIndex *idx = new VecSimIndex{new FlatIndex(bf, lctx)};
   return idx;
   ABI_CATCH(lctx, "VecSimIndex_New", nullptr)
@@ -86,6 +93,7 @@ VecSimIndex *VecSimIndex_NewDisk(const VecSimParamsDisk *) { return nullptr; }
 void VecSimIndex_Free(VecSimIndex *index) {
   if (!index) return;
   try {
+    if (index->sharded) sharded_free(index->sharded);
     delete index->flat;
   } catch (...) {
   }
@@ -107,20 +115,25 @@ size_t VecSimIndex_EstimateInitialSize(const VecSimParams *params) {
 int VecSimIndex_AddVector(VecSimIndex *index, const void *blob, size_t label) {
   if (!index || !blob) return 0;
   ABI_TRY
+  if (index->sharded) return sharded_add(index->sharded, blob, label);
   return index->flat->add(blob, label);
-  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_AddVector", 0)
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_AddVector", 0)
 }
 int VecSimIndex_DeleteVector(VecSimIndex *index, size_t label) {
   if (!index) return 0;
   ABI_TRY
+  if (index->sharded) return sharded_remove(index->sharded, label);
   return index->flat->remove(label);
-  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_DeleteVector", 0)
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_DeleteVector", 0)
 }
 
 // ---- info ----------------------------------------------------------------------------------------
-size_t VecSimIndex_IndexSize(VecSimIndex *index) { return index ? index->flat->size() : 0; }
+size_t VecSimIndex_IndexSize(VecSimIndex *index) {
+  if (!index) return 0;
+  return index->sharded ? sharded_size(index->sharded) : index->flat->size();
+}
 VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index) {
-  if (index) return index->flat->basic_info();
+  if (index) return (index->sharded ? sharded_first(index->sharded) : index->flat)->basic_info();
   VecSimIndexBasicInfo i;
   memset(&i, 0, sizeof i);
   return i;
@@ -128,7 +141,7 @@ VecSimIndexBasicInfo VecSimIndex_BasicInfo(VecSimIndex *index) {
 VecSimIndexStatsInfo VecSimIndex_StatsInfo(VecSimIndex *index) {
   VecSimIndexStatsInfo s;
   memset(&s, 0, sizeof s);
-  if (index) s.memory = index->flat->memory();
+  if (index) s.memory = index->sharded ? sharded_memory(index->sharded) : index->flat->memory();
   return s;
 }
 
@@ -162,7 +175,8 @@ static const char *mode_str(int m) {
 // tests/pytests/test_vecsim.py:342, the FRONTEND_INDEX part).
 VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
   if (!index) return nullptr;
-  FlatIndex *f = index->flat;
+  RSGPU_ShardedIndex *sh = index->sharded;
+  FlatIndex *f = sh ? sharded_first(sh) : index->flat;  // (a sharded handle: type / metric / dim from shard 0, sizes summed)
   auto *it = new VecSimDebugInfoIterator();
   auto add_s = [&](const char *n, const char *v) {
     VecSim_InfoField fld; fld.fieldName = n; fld.fieldType = INFOFIELD_STRING; fld.fieldValue.stringValue = v;
@@ -178,10 +192,10 @@ VecSimDebugInfoIterator *VecSimIndex_DebugInfoIterator(VecSimIndex *index) {
   add_s("METRIC", metric_str(f->metric));
   add_u("IS_MULTI_VALUE", f->multi);
   add_u("IS_DISK", 0);
-  add_u("INDEX_SIZE", f->size());
-  add_u("INDEX_LABEL_COUNT", f->label_count());
-  add_u("MEMORY", f->memory());
-  add_s("LAST_SEARCH_MODE", mode_str(f->last_mode.load()));
+  add_u("INDEX_SIZE", sh ? sharded_size(sh) : f->size());
+  add_u("INDEX_LABEL_COUNT", sh ? sharded_label_count(sh) : f->label_count());
+  add_u("MEMORY", sh ? sharded_memory(sh) : f->memory());
+  add_s("LAST_SEARCH_MODE", mode_str(sh ? sharded_last_mode(sh) : f->last_mode.load()));
   add_u("BLOCK_SIZE", f->block_size);
   return it;
 }
@@ -248,32 +262,49 @@ VecSimQueryReply *VecSimIndex_TopKQuery(VecSimIndex *index, const void *queryBlo
                                         VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
   if (!index || !queryBlob) return nullptr;
   ABI_TRY
+  if (index->sharded) return sharded_topk(index->sharded, queryBlob, k, queryParams, order);
   return index->flat->topk(queryBlob, k, queryParams, order);
-  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_TopKQuery", nullptr)
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_TopKQuery", nullptr)
 }
 
 VecSimQueryReply *VecSimIndex_RangeQuery(VecSimIndex *index, const void *queryBlob, double radius,
                                          VecSimQueryParams *queryParams, VecSimQueryReply_Order order) {
   if (!index || !queryBlob) return nullptr;
   ABI_TRY
+  if (index->sharded) return sharded_range(index->sharded, queryBlob, radius, queryParams, order);
   return index->flat->range(queryBlob, radius, queryParams, order);
-  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_RangeQuery", nullptr)
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_RangeQuery", nullptr)
 }
 
 double VecSimIndex_GetDistanceFrom_Unsafe(VecSimIndex *index, size_t label, const void *blob) {
   if (!index || !blob) return NAN;
   ABI_TRY
+  if (index->sharded) return sharded_distance_from(index->sharded, label, blob);
   return index->flat->distance_from(label, blob);
-  ABI_CATCH(index->flat->log_ctx, "VecSimIndex_GetDistanceFrom_Unsafe", NAN)
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_GetDistanceFrom_Unsafe", NAN)
 }
 
 bool VecSimIndex_PreferAdHocSearch(VecSimIndex *index, size_t subsetSize, size_t k, bool initialCheck) {
-  return index ? index->flat->prefer_adhoc(subsetSize, k, initialCheck) : true;
+  if (!index) return true;
+  if (index->sharded) return sharded_prefer_adhoc(index->sharded, subsetSize, k, initialCheck);
+  return index->flat->prefer_adhoc(subsetSize, k, initialCheck);
 }
 
 // ---- batch iterator ------------------------------------------------------------------------------
 VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *queryBlob, VecSimQueryParams *queryParams) {
   if (!index || !queryBlob) return nullptr;
+  if (index->sharded) {
+    try {
+      auto *b = new VecSimBatchIterator();
+      b->it.index = nullptr;
+      b->it.ctx = nullptr;
+      b->sh = sharded_batch_new(index->sharded, queryBlob, queryParams);
+      return b;
+    } catch (const std::exception &e) {
+      set_error(log_ctx_of(index), "VecSimBatchIterator_New", e.what());
+      return nullptr;
+    }
+  }
   FlatIndex *f = index->flat;
   ABI_TRY
   f->flush_if_needed();
@@ -290,11 +321,21 @@ VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *que
 }
 
 bool VecSimBatchIterator_HasNext(VecSimBatchIterator *iterator) {
-  return iterator && iterator->it.returned < iterator->it.n;
+  if (!iterator) return false;
+  if (iterator->sh) return sharded_batch_has_next(iterator->sh);
+  return iterator->it.returned < iterator->it.n;
 }
 
 VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t n_results, VecSimQueryReply_Order order) {
   if (!iterator) return nullptr;
+  if (iterator->sh) {
+    try {
+      return sharded_batch_next(iterator->sh, n_results, order);
+    } catch (const std::exception &e) {
+      set_error(nullptr, "VecSimBatchIterator_Next", e.what());
+      return nullptr;
+    }
+  }
   BatchIterator &b = iterator->it;
   FlatIndex *f = b.index;
   ABI_TRY
@@ -353,6 +394,10 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
 
 void VecSimBatchIterator_Reset(VecSimBatchIterator *iterator) {
   if (!iterator) return;
+  if (iterator->sh) {
+    sharded_batch_reset(iterator->sh);
+    return;
+  }
   iterator->it.returned = 0;
   iterator->it.recount = false;
   iterator->it.lower = Bound();
@@ -361,6 +406,7 @@ void VecSimBatchIterator_Reset(VecSimBatchIterator *iterator) {
 
 void VecSimBatchIterator_Free(VecSimBatchIterator *iterator) {
   if (!iterator) return;
+  if (iterator->sh) sharded_batch_free(iterator->sh);
   if (iterator->it.ctx) CtxPool::get().release(iterator->it.ctx);
   delete iterator;
 }
@@ -368,6 +414,18 @@ void VecSimBatchIterator_Free(VecSimBatchIterator *iterator) {
 // ---- ad-hoc brute-force context (batched GPU gather) -----------------------------------------------
 VecSimAdhocBfCtx *VecSimIndex_AdhocBfCtx_New(VecSimIndex *index, const void *queryBlob) {
   if (!index || !queryBlob) return nullptr;
+  if (index->sharded) {
+    try {
+      auto *a = new VecSimAdhocBfCtx();
+      a->a.index = nullptr;
+      a->a.ctx = nullptr;
+      a->sh = sharded_adhoc_new(index->sharded, queryBlob);
+      return a;
+    } catch (const std::exception &e) {
+      set_error(log_ctx_of(index), "VecSimIndex_AdhocBfCtx_New", e.what());
+      return nullptr;
+    }
+  }
   FlatIndex *f = index->flat;
   ABI_TRY
   f->flush_if_needed();
@@ -381,6 +439,15 @@ VecSimAdhocBfCtx *VecSimIndex_AdhocBfCtx_New(VecSimIndex *index, const void *que
 }
 void VecSimIndex_AdhocBfCtx_GetExactDistances(VecSimAdhocBfCtx *ctx, const size_t *labels, double *out, size_t count) {
   if (!ctx || !count) return;
+  if (ctx->sh) {
+    try {
+      sharded_adhoc_distances(ctx->sh, labels, out, count);
+    } catch (const std::exception &e) {
+      set_error(nullptr, "VecSimIndex_AdhocBfCtx_GetExactDistances", e.what());
+      for (size_t i = 0; i < count; i++) out[i] = NAN;
+    }
+    return;
+  }
   FlatIndex *f = ctx->a.index;
   try {
     std::shared_lock<std::shared_mutex> g(f->mu);
@@ -398,6 +465,7 @@ double VecSimIndex_AdhocBfCtx_GetDistanceFrom(VecSimAdhocBfCtx *ctx, size_t labe
 }
 void VecSimIndex_AdhocBfCtx_Free(VecSimAdhocBfCtx *ctx) {
   if (!ctx) return;
+  if (ctx->sh) sharded_adhoc_free(ctx->sh);
   if (ctx->a.ctx) CtxPool::get().release(ctx->a.ctx);
   delete ctx;
 }
@@ -469,31 +537,39 @@ int RSGPU_DeviceCount(void) {
 int RSGPU_FlatIndex_Reserve(VecSimIndex *index, size_t rows) {
   if (!index) return -1;
   ABI_TRY
-  index->flat->reserve(rows);
+  if (index->sharded) sharded_reserve(index->sharded, rows);
+  else index->flat->reserve(rows);
   return 0;
-  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_Reserve", -1)
+  ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_Reserve", -1)
 }
 int RSGPU_FlatIndex_AddDeviceRows(VecSimIndex *index, const void *dev_rows, size_t n, size_t first_label) {
   if (!index) return -1;
   ABI_TRY
+  if (index->sharded) throw std::runtime_error("device rows belong to one device: load the shards one by one (RSGPU_ShardedIndex_Shard)");
   return index->flat->add_device_rows(dev_rows, n, first_label);
-  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_AddDeviceRows", -1)
+  ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_AddDeviceRows", -1)
 }
 int RSGPU_FlatIndex_ReadRows(VecSimIndex *index, size_t row_begin, size_t n, void *host_out) {
   if (!index || (n && !host_out)) return -1;
   ABI_TRY
+  if (index->sharded) throw std::runtime_error("storage rows are per shard (RSGPU_ShardedIndex_Shard)");
   index->flat->read_rows((uint32_t)row_begin, n, host_out);
   return 0;
-  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_ReadRows", -1)
+  ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_ReadRows", -1)
 }
 long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t first_index, size_t n, size_t first_label) {
   if (!index) return -1;
   ABI_TRY
+  if (index->sharded) return sharded_add_philox_rows(index->sharded, seed, first_index, n, first_label);
   return index->flat->add_philox_rows(seed, first_index, n, first_label);
-  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_AddPhiloxRows", -1)
+  ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_AddPhiloxRows", -1)
 }
 int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, float *dev_scores, uint64_t *dev_labels) {
   if (!index || !query || !k) return -1;
+  if (index->sharded) {
+    set_error(log_ctx_of(index), "RSGPU_FlatIndex_TopKDevice", "a sharded handle has no single device to write to");
+    return -1;
+  }
   FlatIndex *f = index->flat;
   ABI_TRY
   VecSimQueryReply *r = f->topk(query, k, nullptr, BY_SCORE);
@@ -515,9 +591,10 @@ int RSGPU_FlatIndex_TopKBatch(VecSimIndex *index, const void *queries, size_t n_
                               double *scores_out, size_t *counts_out) {
   if (!index || !queries || !ids_out || !scores_out || !counts_out) return -1;
   ABI_TRY
+  if (index->sharded) throw std::runtime_error("batched queries run per shard (RSGPU_ShardedIndex_Shard) and merge on the caller's side");
   index->flat->topk_batch(queries, n_queries, k, ids_out, scores_out, counts_out);
   return 0;
-  ABI_CATCH(index->flat->log_ctx, "RSGPU_FlatIndex_TopKBatch", -1)
+  ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_TopKBatch", -1)
 }
 // the coordinator-style K-way merge of per-shard top-k lists (reference src/module.c:3541-3547): k best of m
 // (score,label) candidates by (score, label) ascending; padding slots carry label == UINT64_MAX.  Pure host code.
@@ -576,6 +653,8 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_dma")) scan_tuning().gemm_dma = value;
   else if (!strcmp(key, "filter_select")) scan_tuning().filter_select = value;
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
+  else if (!strcmp(key, "shards")) scan_tuning().shards = value;
+  else if (!strcmp(key, "shard_replicas")) scan_tuning().shard_replicas = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
   else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;

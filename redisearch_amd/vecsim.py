@@ -176,6 +176,7 @@ ABI = {
     "RSGPU_ShardedIndex_New": (_vp, [C.POINTER(VecSimParams), _i, _vp, _i]),
     "RSGPU_ShardedIndex_Free": (None, [_vp]),
     "RSGPU_ShardedIndex_NumShards": (_i, [_vp]),
+    "RSGPU_ShardedIndex_FromHandle": (_vp, [_vp]),
     "RSGPU_ShardedIndex_ShardDevice": (_i, [_vp, _i]),
     "RSGPU_ShardedIndex_Shard": (_vp, [_vp, _i]),
     "RSGPU_ShardedIndex_IndexSize": (_sz, [_vp]),

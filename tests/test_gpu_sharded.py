@@ -142,3 +142,131 @@ def test_concurrent_callers_on_a_sharded_index():
     [t.start() for t in th]
     [t.join() for t in th]
     assert not bad
+
+
+# ---- the VecSim ABI handle itself over several shards ("shards" knob): multi-GPU behind the reference's unchanged seam ----
+def abi_sharded(vtype, dim, metric, shards, multi=False, replicas=False):
+    lib = V.load()
+    lib.RSGPU_SetTuning(b"shards", shards)
+    lib.RSGPU_SetTuning(b"shard_replicas", int(replicas))
+    try:
+        return V.VecSimIndex(vtype, dim, metric, multi=multi)
+    finally:
+        lib.RSGPU_SetTuning(b"shards", 0)
+        lib.RSGPU_SetTuning(b"shard_replicas", 0)
+
+
+@pytest.mark.parametrize("shards,replicas", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("metric", [V.VecSimMetric_L2, V.VecSimMetric_Cosine])
+def test_abi_handle_over_shards_is_a_drop_in(shards, replicas, metric):
+    rng = np.random.default_rng(100 + shards)
+    n, dim = 7000, 32
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    g = abi_sharded(F32, dim, metric, shards, replicas=replicas)
+    one = V.VecSimIndex(F32, dim, metric)
+    labels = rng.permutation(n * 3)[:n] + 1                 # arbitrary labels: AddVector routes them to the emptiest shard
+    for row, lab in zip(data, labels):
+        assert g.add_vector(row, int(lab)) == 1 and one.add_vector(row, int(lab)) == 1
+    assert g.index_size() == one.index_size() == n
+    flat_info = g.debug_info()
+    info = dict(zip(flat_info[0::2], flat_info[1::2]))
+    assert info["ALGORITHM"] == "FLAT" and info["INDEX_SIZE"] == n and info["INDEX_LABEL_COUNT"] == n
+    for subset in (10, 500, 2000, 6999):
+        assert g.prefer_adhoc_search(subset, 10) == one.prefer_adhoc_search(subset, 10)
+    for qi in range(4):
+        q = rng.standard_normal(dim).astype(np.float32)
+        for k in (1, 10, 333):
+            a, b = g.topk_query(q, k).results(), one.topk_query(q, k).results()
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+        a, b = g.topk_query(q, 25, order=V.BY_ID).results(), one.topk_query(q, 25, order=V.BY_ID).results()
+        assert a[0].tolist() == b[0].tolist()
+        radius = float(one.topk_query(q, 60).results()[1][-1])
+        a, b = g.range_query(q, radius, order=V.BY_SCORE).results(), one.range_query(q, radius, order=V.BY_SCORE).results()
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+        # the batch iterator: the same sequence of batches, whatever their sizes; Reset starts over
+        ig, io = g.batch_iterator(q), one.batch_iterator(q)
+        for size, order in ((7, V.BY_SCORE), (1, V.BY_ID), (300, V.BY_ID), (64, V.BY_SCORE), (5000, V.BY_SCORE)):
+            assert ig.has_next() == io.has_next()
+            a, b = ig.next(size, order).results(), io.next(size, order).results()
+            assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+        ig.reset()
+        io.reset()
+        a, b = ig.next(12, V.BY_SCORE).results(), io.next(12, V.BY_SCORE).results()
+        assert a[0].tolist() == b[0].tolist()
+        while io.has_next():                                  # drain: both end together
+            assert ig.has_next()
+            a, b = ig.next(3000, V.BY_SCORE).results(), io.next(3000, V.BY_SCORE).results()
+            assert a[0].tolist() == b[0].tolist()
+        assert not ig.has_next()
+        ig.free()
+        io.free()
+        # ad-hoc: labels of every shard and labels nobody holds, in one call
+        probe = np.concatenate([labels[:200], [n * 3 + 5, n * 3 + 6]]).astype(np.uint64)
+        cg, co = g.adhoc_ctx(q), one.adhoc_ctx(q)
+        dg, do = cg.get_exact_distances(probe), co.get_exact_distances(probe)
+        assert np.array_equal(dg, do, equal_nan=True) and np.isnan(dg[-1])
+        cg.free()
+        co.free()
+        nq = one.normalized_query(q)
+        for lab in labels[:5]:
+            assert g.get_distance_from_unsafe(int(lab), nq) == one.get_distance_from_unsafe(int(lab), nq)
+    # deletes and overwrites land on the owning shard
+    for lab in labels[:50]:
+        assert g.delete_vector(int(lab)) == one.delete_vector(int(lab)) == 1
+    assert g.delete_vector(int(labels[0])) == 0
+    assert g.add_vector(data[0] * 2, int(labels[100])) == one.add_vector(data[0] * 2, int(labels[100]))
+    assert g.index_size() == one.index_size() == n - 50
+    q = data[0]
+    a, b = g.topk_query(q, 20).results(), one.topk_query(q, 20).results()
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_reference_hybrid_iterator_on_a_sharded_handle():
+    """The reference's own compiled HybridIterator (oracle/_ref, tests/test_gpu_reference_hybrid_reader.py) driving a
+    2-shard handle through the unchanged VecSim ABI: same results, same modes, same iteration counts as on one index."""
+    from tests import test_gpu_reference_hybrid_reader as R
+    from tests import hybrid_replay as H
+    rng = np.random.default_rng(1583)
+    n, dim, k = 6000, 24, 10
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    g = abi_sharded(F32, dim, V.VecSimMetric_L2, 2)
+    one = V.VecSimIndex(F32, dim, V.VecSimMetric_L2)
+    for i, row in enumerate(data):
+        g.add_vector(row, i + 1)
+        one.add_vector(row, i + 1)
+    for trial in range(3):
+        qv = rng.standard_normal(dim).astype(np.float32)
+        child = sorted(rng.choice(np.arange(1, n + 300), int(rng.choice([40, 700, 4000])), replace=False).tolist())
+        for kind in ("reference", "batched"):
+            for policy, bs in ((0, 0), (H.HYBRID_BATCHES, 7), (H.HYBRID_ADHOC_BF, 0)):
+                a, ao = R.run(kind, g, qv, k, child, policy=policy, batch_size=bs)
+                b, bo = R.run(kind, one, qv, k, child, policy=policy, batch_size=bs)
+                assert a == b and ao.search_mode_out == bo.search_mode_out and ao.num_iterations == bo.num_iterations
+    a, ao = R.run("reference", g, data[5], k, None)             # no child: STANDARD_KNN
+    assert a[0][0] == 6 and ao.search_mode_out == H.STANDARD_KNN
+
+
+def test_abi_handle_philox_rows_split_over_shards_and_multi_value():
+    g = abi_sharded(F32, 48, V.VecSimMetric_Cosine, 3)
+    one = V.VecSimIndex(F32, 48, V.VecSimMetric_Cosine)
+    assert g.add_philox_rows(9, 0, 100_000, 1) == 100_000 and one.add_philox_rows(9, 0, 100_000, 1) == 100_000
+    sh = V.load().RSGPU_ShardedIndex_FromHandle(g.ptr)
+    assert sh and V.load().RSGPU_ShardedIndex_NumShards(sh) == 3
+    for qi in range(3):
+        q = O.philox_rows(9, 200_000 + qi, 1, 48)[0]
+        a, b = g.topk_query(q, 50).results(), one.topk_query(q, 50).results()
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+    # multi-value labels: a label's vectors stay together on the shard that got the first one
+    rng = np.random.default_rng(2)
+    gm, om = abi_sharded(F32, 16, V.VecSimMetric_L2, 2, multi=True), V.VecSimIndex(F32, 16, V.VecSimMetric_L2, multi=True)
+    for i in range(3000):
+        v = rng.standard_normal(16).astype(np.float32)
+        lab = int(rng.integers(1, 800))
+        assert gm.add_vector(v, lab) == om.add_vector(v, lab)
+    q = rng.standard_normal(16).astype(np.float32)
+    a, b = gm.topk_query(q, 30).results(), om.topk_query(q, 30).results()
+    assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+    ig, io = gm.batch_iterator(q), om.batch_iterator(q)
+    for _ in range(4):
+        a, b = ig.next(40, V.BY_SCORE).results(), io.next(40, V.BY_SCORE).results()
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
