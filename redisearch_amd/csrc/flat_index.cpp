@@ -774,6 +774,37 @@ static bool small_select(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32
   return true;
 }
 
+// The two one-sync paths above, split in halves for callers that keep several streams busy (the fused hybrid query):
+// enqueue launches the selection on c->stream and returns which path it took (0: none applies -- use select_keys32);
+// nothing is synchronised.  Once the caller has synchronised the stream, the winners sit UNSORTED in c->h_out_rows /
+// c->h_out_keys (u32 keys) and collect says how many -- or false when the path has to be redone by select_keys32
+// (candidate overflow).
+int select_keys32_enqueue(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k) {
+  if (!scan_tuning().filter_select || k == 0) return 0;
+  if (k <= 1024 && n <= (1u << 15)) {
+    c->ensure_out(k);
+    c->h_fcnt[2] = 0;
+    launch_batch_select_keys(d_keys, n, n, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys, c->h_fcnt + 2, k, c->stream);
+    return 1;
+  }
+  if (k <= 32 && n >= (1u << 16)) {
+    c->ensure_out(k);
+    c->h_fcnt[1] = 0;
+    c->h_fcnt[2] = 0;
+    launch_sample_threshold(d_keys, n, 64, k, c->d_tau, c->d_fcnt, c->stream);
+    launch_filter_keys(d_keys, n, c->d_tau, c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->stream);
+    launch_batch_select_cand(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, k, 1, c->h_out_rows, (uint32_t *)c->h_out_keys,
+                             c->h_fcnt + 2, k, c->h_fcnt + 1, c->stream);
+    return 2;
+  }
+  return 0;
+}
+bool select_keys32_collect(QueryCtx *c, int mode, uint32_t n, uint32_t k, uint32_t *got) {
+  if (mode == 2 && c->h_fcnt[1]) return false;
+  *got = std::min<uint32_t>(c->h_fcnt[2], k);
+  return *got >= std::min<uint32_t>(k, n);
+}
+
 void select_keys32(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out) {
   if (k > 0 && k <= 1024 && n <= (1u << 15) && scan_tuning().filter_select && small_select(c, d_keys, n, k, out)) return;
   if (k > 0 && k <= 32 && n >= (1u << 16) && scan_tuning().filter_select && filter_select(c, d_keys, n, k, out)) return;

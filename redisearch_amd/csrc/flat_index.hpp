@@ -284,6 +284,9 @@ void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, ui
 void release_search_pool();
 // k smallest (key,index) of a u32 key array: one-workgroup select for short arrays, radix levels otherwise
 void select_keys32(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out);
+// asynchronous halves of its one-sync paths (flat_index.cpp): enqueue -> [caller synchronises c->stream] -> collect
+int select_keys32_enqueue(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k);
+bool select_keys32_collect(QueryCtx *c, int mode, uint32_t n, uint32_t k, uint32_t *got);
 VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code);
 bool timed_out(void *timeout_ctx);
 

@@ -83,8 +83,9 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 const char *last_scan_kernel_name(char *buf, size_t cap);
 
 // Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
+// m_dev (optional, device memory): the actual candidate count when the host only knows the upper bound m
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
-                   uint32_t m, const void *query, void *out, hipStream_t s);
+                   uint32_t m, const void *query, void *out, hipStream_t s, const uint32_t *m_dev = nullptr);
 
 // Synthetic corpus rows [row_begin, row_begin+n_rows) written in place: element (i,j) = Philox4x32-10(seed; first_index+i, j)
 // mapped to [-1,1) (corpus_kernels.hip); padding behind dim is zeroed.

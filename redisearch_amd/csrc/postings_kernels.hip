@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
 
-// single workgroup: exclusive scan of nb counters, 1024 threads, chunked
+// single workgroup: exclusive scan of nb counters.  1024 threads x 8 consecutive counters per step (two 16-byte loads
+// each, all in flight before the first use), thread-local scan, shuffle scan across the wave, 16 wave totals through LDS.
 __global__ __launch_bounds__(1024) void scan_counts_kernel(uint32_t *__restrict__ c, uint32_t nb,
                                                            uint32_t *__restrict__ total_out) {
   __shared__ uint32_t wsum[16];
@@ -283,23 +284,37 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(uint32_t *__restrict_
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t x = i < nb ? c[i] : 0;
-    uint32_t inc = x;
+  for (uint32_t base = 0; base < nb; base += 8192) {
+    const uint32_t i0 = base + threadIdx.x * 8;
+    uint32_t x[8];
+    if (i0 + 8 <= nb && (reinterpret_cast<uintptr_t>(c + i0) & 15u) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4 *>(c + i0), b = *reinterpret_cast<const uint4 *>(c + i0 + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) x[j] = i0 + j < nb ? c[i0 + j] : 0u;
+    }
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) sum += x[j];
+    uint32_t inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      uint32_t t = __shfl_up(inc, off, 64);
+      const uint32_t t = __shfl_up(inc, off, 64);
       if (lane >= (uint32_t)off) inc += t;
     }
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (uint32_t j = 0; j < w; j++) woff += wsum[j];
-    const uint32_t excl = carry + woff + inc - x;
-    if (i < nb) c[i] = excl;
+    uint32_t run = carry + woff + inc - sum;  // exclusive prefix of this thread's first counter
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (i0 + j < nb) c[i0 + j] = run;
+      run += x[j];
+    }
     __syncthreads();
-    if (threadIdx.x == 1023) carry = excl + x;
+    if (threadIdx.x == 1023) carry = run;
     __syncthreads();
   }
   if (threadIdx.x == 0) total_out[0] = carry;
@@ -866,6 +881,164 @@ __global__ __launch_bounds__(256) void labels_to_rows_kernel(const uint32_t *__r
   rows[i] = (id >= base && id - base < n_rows) ? (uint32_t)(id - base) : 0xFFFFFFFFu;
 }
 
+// The hits that have a vector, compacted (order does not matter: the selection that follows ranks by (distance, hit
+// index)): rows_out[slot] = storage row, cand[slot] = (hit index, 0); count[0] = how many (slots >= cap are dropped and
+// the caller sees count > cap).  One atomic per wavefront.
+__global__ __launch_bounds__(256) void labels_to_cand_kernel(const uint32_t *__restrict__ ids, uint32_t n, uint64_t ids_base,
+                                                             uint64_t base, uint32_t n_rows, uint32_t *__restrict__ rows_out,
+                                                             uint2 *__restrict__ cand, uint32_t *__restrict__ count,
+                                                             uint32_t cap) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  uint64_t id = 0;
+  bool has = false;
+  if (i < n) {
+    id = ids_base + ids[i];
+    has = id >= base && id - base < n_rows;
+  }
+  const unsigned long long m = __ballot(has);
+  if (!m) return;
+  uint32_t first = 0;
+  if (lane == (uint32_t)__builtin_ctzll(m)) first = atomicAdd(count, (uint32_t)__popcll(m));
+  first = __shfl(first, __builtin_ctzll(m), 64);
+  if (!has) return;
+  const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (slot < cap) {
+    rows_out[slot] = (uint32_t)(id - base);
+    cand[slot] = make_uint2(i, 0u);
+  }
+}
+
+// k (<= 32) nearest of the compacted candidates in ONE launch: block b ranks its share of the candidates by the composite
+// (distance key, hit index) with k rounds of a block-wide arg-min and parks its k best in `part`; the block that finishes
+// last (a ticket) ranks the blocks' lists the same way and writes the winners -- hit index, key, doc id -- into pinned
+// host memory.  It also puts the two counters back to zero, so the stream needs no memset before the next query.
+constexpr int kKnnTopkBlocks = 64, kKnnTopkPerThread = 4, kKnnTopkMaxK = 32;
+__device__ __forceinline__ uint32_t f2key(float f) {  // orderable image of a distance, NaN last
+  const uint32_t u = __float_as_uint(f);
+  return ((u & 0x7fffffffu) > 0x7f800000u) ? 0xFFFFFFFFu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));
+}
+// wave-wide minimum, the same value in every lane.  Four DPP steps (xor 1, xor 2 inside a quad, half-row mirror, row
+// mirror: min is idempotent, so mirrors do as well as butterflies) leave every lane with the minimum of its row of 16;
+// four v_readlane pairs and scalar compares finish it -- ~40 instructions instead of twelve dependent ds_bpermute round
+// trips (the k rounds of wave_topk are a serial chain of these).
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_min_step(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+  const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+  const uint64_t o = ((uint64_t)ohi << 32) | olo;
+  return o < v ? o : v;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+  v = dpp_min_step<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_min_step<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_min_step<0x141>(v);  // row_half_mirror
+  v = dpp_min_step<0x140>(v);  // row_mirror
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int row = 0; row < 4; row++) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, row * 16);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), row * 16);
+    const uint64_t r = ((uint64_t)hi << 32) | lo;
+    m = r < m ? r : m;
+  }
+  return m;
+}
+// the k (<= 64) smallest of the N composites each lane holds: lane r returns the r-th smallest (~0 when there are
+// fewer).  k rounds of a wave-wide arg-min -- shuffles only, no barrier, no LDS.  Composites are unique.
+template <int N>
+__device__ __forceinline__ uint64_t wave_topk(uint64_t (&mine)[N], uint32_t k, uint32_t lane) {
+  uint64_t res = ~0ull;
+  for (uint32_t r = 0; r < k; r++) {
+    uint64_t v = mine[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) v = mine[j] < v ? mine[j] : v;
+    const uint64_t m = wave_min_u64(v);
+    if (m == ~0ull) break;
+    if (lane == r) res = m;
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (mine[j] == m) mine[j] = ~0ull;
+  }
+  return res;
+}
+__global__ __launch_bounds__(256) void knn_topk_kernel(const float *__restrict__ dists, const uint2 *__restrict__ cand,
+                                                       uint32_t *__restrict__ count, uint32_t cap, uint32_t k,
+                                                       const uint32_t *__restrict__ ids, uint64_t *__restrict__ part,
+                                                       uint32_t *__restrict__ ticket, uint32_t *__restrict__ out_rows,
+                                                       uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_ids,
+                                                       uint32_t *__restrict__ out_n, uint32_t *__restrict__ overflow) {
+  __shared__ uint64_t wl[4][kKnnTopkMaxK];  // the four waves' lists
+  __shared__ uint32_t sh_last;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t total = *count;
+  const uint32_t n = total < cap ? total : cap;
+  const uint32_t per = (n + kKnnTopkBlocks - 1) / kKnnTopkBlocks;  // <= 256 * kKnnTopkPerThread (cap = 64 Ki)
+  const uint32_t beg = blockIdx.x * per, end = beg + per < n ? beg + per : n;
+  uint64_t mine[kKnnTopkPerThread];
+#pragma unroll
+  for (int j = 0; j < kKnnTopkPerThread; j++) {
+    const uint32_t i = beg + j * 256 + threadIdx.x;
+    mine[j] = i < end ? (((uint64_t)f2key(dists[i]) << 32) | cand[i].x) : ~0ull;
+  }
+  {
+    const uint64_t r = wave_topk(mine, k, lane);
+    if (lane < kKnnTopkMaxK) wl[w][lane] = r;
+  }
+  __syncthreads();
+  if (w == 0) {  // merge the four lists: 4 * k <= 128 composites, two per lane
+    uint64_t two[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const uint32_t i = j * 64 + lane;
+      two[j] = (i % kKnnTopkMaxK) < k ? wl[i / kKnnTopkMaxK][i % kKnnTopkMaxK] : ~0ull;
+    }
+    const uint64_t r = wave_topk(two, k, lane);
+    if (lane < kKnnTopkMaxK) part[(size_t)blockIdx.x * kKnnTopkMaxK + lane] = r;
+    __threadfence();
+    if (lane == 0) sh_last = atomicAdd(ticket, 1u) == (uint32_t)kKnnTopkBlocks - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  // the last block: the kKnnTopkBlocks lists (<= 2048 composites, 8 per thread), per wave first, then merged
+  constexpr int PT = kKnnTopkBlocks * kKnnTopkMaxK / 256;
+  uint64_t all[PT];
+#pragma unroll
+  for (int j = 0; j < PT; j++) {
+    const uint32_t i = j * 256 + threadIdx.x, t = i % kKnnTopkMaxK;
+    all[j] = t < k ? part[i] : ~0ull;
+  }
+  {
+    const uint64_t r = wave_topk(all, k, lane);
+    if (lane < kKnnTopkMaxK) wl[w][lane] = r;  // (wave 0 finished reading wl before the barrier above)
+  }
+  __syncthreads();
+  if (w != 0) return;
+  uint64_t two[2];
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const uint32_t i = j * 64 + lane;
+    two[j] = (i % kKnnTopkMaxK) < k ? wl[i / kKnnTopkMaxK][i % kKnnTopkMaxK] : ~0ull;
+  }
+  const uint64_t m = wave_topk(two, k, lane);
+  uint32_t got = 0;
+  if (lane < k && m != ~0ull) {
+    const uint32_t hit = (uint32_t)m;
+    out_rows[lane] = hit;
+    out_keys[lane] = (uint32_t)(m >> 32);
+    out_ids[lane] = ids[hit];
+    got = 1;
+  }
+  const uint32_t n_got = (uint32_t)__popcll(__ballot(got != 0));  // the valid entries are a prefix (ascending, ~0 last)
+  if (lane == 0) {
+    *out_n = n_got;
+    if (total > cap) *overflow = 1;  // more candidates than the list holds: the caller redoes the query the long way
+    *count = 0;
+    *ticket = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void dist_to_keys_kernel(const float *__restrict__ d, uint32_t n,
                                                            uint32_t *__restrict__ keys) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -875,6 +1048,17 @@ __global__ __launch_bounds__(256) void dist_to_keys_kernel(const float *__restri
 }
 
 // out[i] = src[idx[i]] (idx / out may be host-visible pinned memory)
+__global__ __launch_bounds__(256) void gather_u32_counted_kernel(const uint32_t *__restrict__ src, uint32_t src_len,
+                                                                 const uint32_t *__restrict__ idx,
+                                                                 const uint32_t *__restrict__ count, uint32_t cap,
+                                                                 uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n = *count < cap ? *count : cap;
+  if (i >= n) return;
+  const uint32_t j = idx[i];
+  if (j < src_len) out[i] = src[j];
+}
+
 __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
                                                          uint32_t n, uint32_t *__restrict__ out) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -971,6 +1155,11 @@ void launch_fetch_cand64(const void *cand, const uint32_t *count, uint32_t cap, 
   hipLaunchKernelGGL(fetch_cand64_kernel, dim3(8), dim3(256), 0, s, (const uint2 *)cand, count, cap, keys64, ids,
                      out_rows, out_keys, out_ids, out_n);
 }
+void launch_gather_u32_counted(const uint32_t *src, uint32_t src_len, const uint32_t *idx, const uint32_t *count,
+                               uint32_t cap, uint32_t *out, hipStream_t s) {
+  if (!cap) return;
+  hipLaunchKernelGGL(gather_u32_counted_kernel, dim3(blocks_for(cap)), dim3(256), 0, s, src, src_len, idx, count, cap, out);
+}
 void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *out, hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(gather_u32_kernel, dim3(blocks_for(n)), dim3(256), 0, s, src, idx, n, out);
@@ -986,6 +1175,20 @@ void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, u
                            hipStream_t s) {
   if (!n) return;
   hipLaunchKernelGGL(labels_to_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, base, n_rows, rows);
+}
+void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows,
+                           uint32_t *rows_out, void *cand, uint32_t *count, uint32_t cap, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(labels_to_cand_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, base, n_rows, rows_out,
+                     (uint2 *)cand, count, cap);
+}
+uint32_t knn_topk_max_k() { return kKnnTopkMaxK; }
+size_t knn_topk_scratch_bytes() { return (size_t)kKnnTopkBlocks * kKnnTopkMaxK * sizeof(uint64_t); }
+void launch_knn_topk(const float *dists, const void *cand, uint32_t *count, uint32_t cap, uint32_t k, const uint32_t *ids,
+                     void *part, uint32_t *ticket, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_ids, uint32_t *out_n,
+                     uint32_t *overflow, hipStream_t s) {
+  hipLaunchKernelGGL(knn_topk_kernel, dim3(kKnnTopkBlocks), dim3(256), 0, s, dists, (const uint2 *)cand, count, cap, k, ids,
+                     (uint64_t *)part, ticket, out_rows, out_keys, out_ids, out_n, overflow);
 }
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s) {
   if (!n) return;

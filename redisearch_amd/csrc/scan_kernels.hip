@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256) void scan_kernel(const u4 *__restrict__ rows, 
   // base + u*GPB + grp goes to group grp, so that for a fixed u neighbouring groups read
   // neighbouring rows and every load instruction stays contiguous across the wavefront.
   constexpr bool INTERLEAVE = G < 64;
+  // GATHER: the keys slot is unused; a non-NULL pointer there is the DEVICE-side candidate count (the host only knows an
+  // upper bound when it enqueues the launch), which then bounds the loop
+  if (GATHER && keys) {
+    const uint32_t m = *reinterpret_cast<const uint32_t *>(keys);
+    if (m < row_end - row_begin) row_end = row_begin + m;
+    if (row_end == row_begin) return;
+  }
   const uint32_t n = row_end - row_begin;
   const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
   const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
@@ -404,6 +411,10 @@ __global__ __launch_bounds__(256) void scan_long_kernel(const u4 *__restrict__ r
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = gridDim.x * 4;
   const u4 qx = Tr<TYPE>::kExtra ? query[chunks] : zero4();
+  if (GATHER && keys) {  // device-side candidate count (see scan_kernel)
+    const uint32_t m = *reinterpret_cast<const uint32_t *>(keys);
+    if (m < row_end - row_begin) row_end = row_begin + m;
+  }
   for (uint32_t t = blockIdx.x * 4 + wave; t < row_end - row_begin; t += total) {
     uint32_t r = row_begin + t, rid = 0;
     if (GATHER) {
@@ -800,11 +811,11 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 }
 
 void launch_gather(const void *rows, size_t stride, uint32_t dim, int type, int metric, const uint32_t *row_ids,
-                   uint32_t m, const void *query, void *out, hipStream_t s) {
+                   uint32_t m, const void *query, void *out, hipStream_t s, const uint32_t *m_dev) {
   (void)dim;
   if (!m) return;
   LaunchCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), 0, m,
-              (const u4 *)query, row_ids, nullptr, out, s};
+              (const u4 *)query, row_ids, const_cast<uint32_t *>(m_dev), out, s};
   dispatch<true>(type, metric, c);
 }
 

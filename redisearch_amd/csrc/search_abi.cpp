@@ -118,6 +118,11 @@ struct Scratch {
   DevBuf<uint32_t> pos, block_counts, total, rows, keys32, skeys32;
   DevBuf<float> dists;
   DevBuf<uint64_t> fuse, maxkey;
+  // fused hybrid query, KNN branch: {candidate count, ticket} -- zero at rest, the last kernel of the branch puts them
+  // back -- and the per-block partial lists of knn_topk_kernel
+  DevBuf<uint32_t> knn_cnt;
+  DevBuf<uint64_t> knn_part;
+  bool knn_dirty = true;  // the counters may be non-zero (first use, or a query that failed half-way)
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -128,6 +133,9 @@ Scratch &scratch(int device) {
     s.dists.reset();
     s.fuse.reset();
     s.maxkey.reset();
+    s.knn_cnt.reset();
+    s.knn_part.reset();
+    s.knn_dirty = true;
     s.device = device;
   }
   return s;
@@ -386,6 +394,7 @@ static LeafMap adopt_sources(RSGPU_Hits *h, const std::vector<Source> &srcs, Lis
   return m;
 }
 
+constexpr uint32_t kCountPending = 0xFFFFFFFFu;  // (a hit count cannot reach it: n0 < 2^32 - 16)
 // AND of the sources (already in iteration order; source 0 drives).  Enqueues probe [+ proximity filter] + scan + write
 // on c->stream; *total_out (pinned host memory) receives the hit count once the stream has been synchronised.
 static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx *c, Scratch &sc, uint32_t *total_out,
@@ -400,6 +409,7 @@ static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx
   if (h->with_offsets) h->epos.alloc((size_t)h->cap * h->n_lists);
   *total_out = 0;
   if (n0 == 0) return;
+  *total_out = kCountPending;  // until scan_counts_kernel has written the real count (callers that poll instead of synchronising)
   const uint32_t nb = (n0 + 255) / 256;
   sc.flags.ensure(n0);
   sc.pos.ensure((size_t)n0 * std::max<size_t>(srcs.size() - 1, 1));
@@ -1106,15 +1116,87 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   h->device = device;
   h->n_lists = (int)a->n_lists;
 
+  // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
+  uint64_t knn_base = 0;
+  bool knn_identity = false;
+  std::shared_lock<std::shared_mutex> index_lock;
+  if (f) {
+    index_lock = std::shared_lock<std::shared_mutex>(f->mu);
+    knn_identity = f->identity_labels(&knn_base);
+    if (knn_identity) f->upload_query(cb.c, a->query, true);
+  }
+
   // ---- intersect (stream A) ----
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
   uint32_t *h_total = ca->h_counters;  // pinned, device-visible
   intersect_async(h.get(), a->lists, a->n_lists, ca.c, sc, h_total);
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
-  HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #1
+  // The hit count decides every later launch.  It is written into pinned memory by the scan kernel, one kernel BEFORE
+  // the intersection's last (the ordered write): polling it instead of synchronising lets the host enqueue both
+  // branches while that kernel still runs -- stream A orders itself, stream B waits for the event recorded here.
+  HIP_CHECK(hipEventRecord(ca->ev1, ca->stream));
+  if (!prof) {
+    volatile uint32_t *pending = h_total;
+    for (int spin = 0; spin < 200000 && *pending == kCountPending; spin++) __builtin_ia32_pause();
+  }
+  if (prof || h_total[0] == kCountPending) HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #1 (profiling / a very slow query)
+  HIP_CHECK(hipStreamWaitEvent(cb->stream, ca->ev1, 0));
   const uint32_t len = h_total[0];
   h->len = len;
   a->n_hits = len;
+
+  // ---- branch B: ad-hoc KNN over the hits (stream B, asynchronous; enqueued FIRST -- it is the longer branch) ----
+  int knn_mode = 0;       // which asynchronous select was enqueued (0: none -- the synchronous select runs after sync #2)
+  uint32_t knn_k = 0;
+  bool knn_on_host_map = false;
+  if (want_knn && len) {
+    if (knn_identity) {
+      knn_k = (uint32_t)std::min<size_t>(a->k, len);
+      if (prof) HIP_CHECK(hipEventRecord(ev.e[4], cb->stream));
+      // Most hits of a text filter have no vector (configs[4]: one in ten): compact the ones that do -- in any order, a
+      // wave-aggregated append -- so that the gather runs dense (U rows in flight per wave instead of mostly skipped
+      // slots) and the selection is ONE workgroup's pass over (distance key, hit index) pairs: the hit index breaks ties
+      // the way the reference does (ascending doc id), whatever order the append produced.
+      const uint32_t m_up = std::min<uint32_t>(len, QueryCtx::kCandCap);
+      cb->ensure_gather(std::max<uint32_t>(m_up, knn_k + 1));
+      cb->ensure_out(knn_k);
+      cb->h_fcnt[1] = 0;
+      cb->h_fcnt[2] = 0;
+      if (knn_k <= knn_topk_max_k()) {
+        // three launches, no memset, no host round trip: append -> dense gather bounded by the device-side count ->
+        // one top-k kernel that also fetches the winners' doc ids and re-arms the counters
+        sc.knn_cnt.ensure(4);
+        sc.knn_part.ensure(knn_topk_scratch_bytes() / sizeof(uint64_t));
+        if (sc.knn_dirty) HIP_CHECK(hipMemsetAsync(sc.knn_cnt.p, 0, 4 * sizeof(uint32_t), cb->stream));
+        sc.knn_dirty = true;
+        launch_labels_to_cand(h->ids.p, len, h->base, knn_base, f->committed_rows(), cb->d_ids, cb->d_cand, sc.knn_cnt.p,
+                              QueryCtx::kCandCap, cb->stream);
+        launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, cb->d_ids, m_up, cb->d_query,
+                      cb->d_dists, cb->stream, sc.knn_cnt.p);
+        launch_knn_topk(cb->d_dists, cb->d_cand, sc.knn_cnt.p, QueryCtx::kCandCap, knn_k, h->ids.p, sc.knn_part.p,
+                        sc.knn_cnt.p + 1, cb->h_out_rows, (uint32_t *)cb->h_out_keys, cb->h_ids, cb->h_fcnt + 2,
+                        cb->h_fcnt + 1, cb->stream);
+        knn_mode = 2;
+      } else {
+      HIP_CHECK(hipMemsetAsync(cb->d_fcnt, 0, 4 * sizeof(uint32_t), cb->stream));
+      HIP_CHECK(hipMemsetAsync(cb->d_ids, 0xFF, (size_t)m_up * sizeof(uint32_t), cb->stream));  // unused slots: "no vector"
+      launch_labels_to_cand(h->ids.p, len, h->base, knn_base, f->committed_rows(), cb->d_ids, cb->d_cand, cb->d_fcnt,
+                            QueryCtx::kCandCap, cb->stream);
+      launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, cb->d_ids, m_up, cb->d_query,
+                    cb->d_dists, cb->stream);
+      launch_cand_set_keys(cb->d_cand, cb->d_dists, m_up, cb->stream);
+      launch_batch_select_cand(cb->d_cand, cb->d_fcnt, QueryCtx::kCandCap, knn_k, 1, cb->h_out_rows, (uint32_t *)cb->h_out_keys,
+                               cb->h_fcnt + 2, knn_k, cb->h_fcnt + 1, cb->stream);
+      // doc ids of the winners: hit index -> ids[], straight behind the select (no host round trip in between)
+      launch_gather_u32_counted(h->ids.p, len, cb->h_out_rows, cb->h_fcnt + 2, knn_k, cb->h_ids, cb->stream);
+      knn_mode = 1;
+      }
+      HIP_CHECK(hipGetLastError());
+      if (prof) HIP_CHECK(hipEventRecord(ev.e[5], cb->stream));
+    } else {
+      knn_on_host_map = true;  // general label map lives on the host: the staged entry point handles it below
+    }
+  }
 
   // ---- branch A: score + top-N prefilter (stream A, asynchronous) ----
   bool prefiltered = false, radix_topn = false;
@@ -1153,34 +1235,9 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
   }
 
-  // ---- branch B: ad-hoc KNN over the hits (stream B); its select ends with the branch's own synchronisation ----
-  std::vector<Hit> knn_hits;
-  bool knn_on_host_map = false;
-  if (want_knn && len) {
-    std::shared_lock<std::shared_mutex> g;
-    if (f) g = std::shared_lock<std::shared_mutex>(f->mu);
-    uint64_t base = 0;
-    if (f && f->identity_labels(&base)) {
-      sc.rows.ensure(len);
-      sc.dists.ensure(len);
-      sc.keys32.ensure(len);
-      f->upload_query(cb.c, a->query, true);
-      if (prof) HIP_CHECK(hipEventRecord(ev.e[4], cb->stream));
-      launch_labels_to_rows(h->ids.p, len, h->base, base, f->committed_rows(), sc.rows.p, cb->stream);
-      launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, len, cb->d_query,
-                    sc.dists.p, cb->stream);
-      launch_dist_to_keys(sc.dists.p, len, sc.keys32.p, cb->stream);
-      HIP_CHECK(hipGetLastError());
-      select_keys32(cb.c, sc.keys32.p, len, (uint32_t)std::min<size_t>(a->k, len), knn_hits);  // syncs stream B
-      // doc ids of the winners: hit index -> ids[], through pinned memory (one tiny launch, overlapped with branch A)
-      cb->ensure_gather(knn_hits.size() + 1);
-      for (size_t i = 0; i < knn_hits.size(); i++) cb->h_out_rows[i] = knn_hits[i].row;
-      launch_gather_u32(h->ids.p, cb->h_out_rows, (uint32_t)knn_hits.size(), cb->h_ids, cb->stream);
-      if (prof) HIP_CHECK(hipEventRecord(ev.e[5], cb->stream));
-      HIP_CHECK(hipStreamSynchronize(cb->stream));
-    } else {
-      knn_on_host_map = true;  // general label map lives on the host: the staged entry point handles it below
-    }
+  if (want_knn && len && knn_identity) {
+    HIP_CHECK(hipStreamSynchronize(cb->stream));  // sync #2a (branch B)
+    if (knn_mode == 2) sc.knn_dirty = false;      // knn_topk_kernel ran to its end: the counters are back at zero
   }
   HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #2 (branch A)
 
@@ -1222,16 +1279,42 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   }
   if (want_knn && len) {
     if (knn_on_host_map) {
+      if (index_lock.owns_lock()) index_lock.unlock();  // (the staged entry point takes the index's locks itself)
       long m = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
       if (m < 0) return -1;
       a->n_knn = (size_t)m;
     } else {
+      struct Win {
+        uint32_t key, row, id;
+      };
+      std::vector<Win> win;
+      uint32_t got = 0;
+      if (knn_mode && !cb->h_fcnt[1]) {  // ([1]: more than kCandCap hits have a vector -- the list overflowed)
+        got = std::min<uint32_t>(cb->h_fcnt[2], knn_k);
+        const uint32_t *k32 = reinterpret_cast<const uint32_t *>(cb->h_out_keys);
+        for (uint32_t i = 0; i < got; i++) win.push_back(Win{k32[i], cb->h_out_rows[i], cb->h_ids[i]});
+      } else {  // the general form: every hit keeps its slot (absent rows -> NaN), keys selected by (key, hit index)
+        sc.rows.ensure(len);
+        sc.dists.ensure(len);
+        sc.keys32.ensure(len);
+        launch_labels_to_rows(h->ids.p, len, h->base, knn_base, f->committed_rows(), sc.rows.p, cb->stream);
+        launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, len, cb->d_query,
+                      sc.dists.p, cb->stream);
+        launch_dist_to_keys(sc.dists.p, len, sc.keys32.p, cb->stream);
+        std::vector<Hit> knn_hits;
+        select_keys32(cb.c, sc.keys32.p, len, knn_k, knn_hits);
+        cb->ensure_gather(knn_hits.size() + 1);
+        for (size_t i = 0; i < knn_hits.size(); i++) cb->h_out_rows[i] = knn_hits[i].row;
+        launch_gather_u32(h->ids.p, cb->h_out_rows, (uint32_t)knn_hits.size(), cb->h_ids, cb->stream);
+        HIP_CHECK(hipStreamSynchronize(cb->stream));
+        for (size_t i = 0; i < knn_hits.size(); i++) win.push_back(Win{(uint32_t)knn_hits[i].key, knn_hits[i].row, cb->h_ids[i]});
+      }
+      std::sort(win.begin(), win.end(), [](const Win &x, const Win &y) { return x.key != y.key ? x.key < y.key : x.row < y.row; });
       size_t out = 0;
-      for (size_t i = 0; i < knn_hits.size(); i++) {
-        const Hit &hit = knn_hits[i];
-        if ((uint32_t)hit.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
-        if (a->knn_ids) a->knn_ids[out] = h->base + cb->h_ids[i];
-        if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist((uint32_t)hit.key);
+      for (const Win &w : win) {
+        if (w.key == 0xFFFFFFFFu) continue;  // NaN: the doc has no vector (hybrid_reader.c:317-320)
+        if (a->knn_ids) a->knn_ids[out] = h->base + w.id;
+        if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist(w.key);
         out++;
       }
       a->n_knn = out;

@@ -132,6 +132,10 @@ void launch_fetch_cand64(const void *cand, const uint32_t *count, uint32_t cap, 
                          hipStream_t s);
 // out[i] = src[idx[i]], i < n (idx / out may be pinned host memory)
 void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *out, hipStream_t s);
+// the same for an index list whose length the device knows: out[i] = src[idx[i]] for i < min(*count, cap), indices
+// >= src_len are skipped (idx / count / out may be pinned host memory written by the previous kernel of the stream)
+void launch_gather_u32_counted(const uint32_t *src, uint32_t src_len, const uint32_t *idx, const uint32_t *count,
+                               uint32_t cap, uint32_t *out, hipStream_t s);
 
 // BM25STD.NORM epilogue: scores[i] /= max(0, max_i scores[i]) unless that maximum is 0; keys rewritten alike.
 // max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream
@@ -140,6 +144,19 @@ void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, ui
 // rows[i] = ids_base + ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
 void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows, uint32_t *rows,
                            hipStream_t s);
+// the hits with a vector, compacted in any order: rows_out[slot] = row, cand[slot] = (hit index, 0) (uint2), count[0] += 1
+// per hit; slots >= cap are dropped (count[0] > cap tells).  count must be zeroed by the caller on the same stream.
+void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows,
+                           uint32_t *rows_out, void *cand, uint32_t *count, uint32_t cap, hipStream_t s);
+// k (<= knn_topk_max_k()) best of the compacted candidates by (key of dists[slot], hit index cand[slot].x), one launch:
+// winners' hit indices / u32 keys / doc ids (ids[hit]) and their number go to out_* (pinned host memory), *overflow is
+// set when *count > cap.  `part`: knn_topk_scratch_bytes() of device scratch; `count` and `ticket` (device, zero on
+// entry) are zero again when the kernel ends.
+uint32_t knn_topk_max_k();
+size_t knn_topk_scratch_bytes();
+void launch_knn_topk(const float *dists, const void *cand, uint32_t *count, uint32_t cap, uint32_t k, const uint32_t *ids,
+                     void *part, uint32_t *ticket, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_ids, uint32_t *out_n,
+                     uint32_t *overflow, hipStream_t s);
 // keys[i] = orderable(dists[i]) (NaN last)
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s);
 

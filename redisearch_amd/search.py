@@ -216,31 +216,51 @@ class Hits:
     __del__ = free
 
 
+class HybridQuery:
+    """RSGPU_HybridQuery with its argument block prepared once: intersection -> (score + top_n) || (ad-hoc KNN top-k).
+    run() is the bare C call (what a C caller pays); results() reads the outputs of the last run."""
+
+    def __init__(self, lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,
+                 top_n=0, index=None, q=None, k=0, root_weight=1.0, min_score=0.0, tanh_factor=4):
+        self.lib = load()
+        self._fn = self.lib.RSGPU_HybridQuery
+        self._arr = (_vp * len(lists))(*[l.ptr for l in lists])
+        a = self.args = HybridQueryArgs()
+        a.lists, a.n_lists = C.cast(self._arr, _vp), len(lists)
+        self._keep = [lists, table, index]
+        if table is not None and scorer is not None and top_n:
+            idf_, bidf_, w_ = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
+            sa = ScoreArgs(SCORERS[scorer] if scorer in SCORERS else PIPELINE_SCORERS[scorer], num_docs, avg_doc_len, tanh_factor,
+                           root_weight, min_score, _p(idf_).value, _p(bidf_).value, _p(w_).value)
+            self._keep += [idf_, bidf_, w_, sa]
+            a.table, a.score, a.top_n = table.ptr, C.pointer(sa), top_n
+        self.ti, self.ts = np.zeros(max(top_n, 1), np.uint64), np.zeros(max(top_n, 1), np.float64)
+        self.ki, self.kd = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64)
+        a.top_ids, a.top_scores = _p(self.ti).value, _p(self.ts).value
+        a.knn_ids, a.knn_dists = _p(self.ki).value, _p(self.kd).value
+        if index is not None and q is not None and k:
+            qb = index._q(q)
+            self._keep.append(qb)
+            a.index, a.query, a.k = index.ptr, _p(qb).value, k
+        self._ref = C.byref(a)
+
+    def run(self):
+        if self._fn(self._ref) != 0:
+            raise RuntimeError(V.last_error())
+
+    def results(self):
+        a = self.args
+        return dict(n_hits=a.n_hits, top=(self.ti[:a.n_top].copy(), self.ts[:a.n_top].copy()),
+                    knn=(self.ki[:a.n_knn].copy(), self.kd[:a.n_knn].copy()))
+
+
 def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,
                  top_n=0, index=None, q=None, k=0, root_weight=1.0, min_score=0.0, tanh_factor=4):
-    """RSGPU_HybridQuery: intersection -> (score + top_n) || (ad-hoc KNN top-k), two stream syncs in total.
-    Returns dict(n_hits, top=(ids, scores), knn=(ids, dists))."""
-    lib = load()
-    arr = (_vp * len(lists))(*[l.ptr for l in lists])
-    a = HybridQueryArgs()
-    a.lists, a.n_lists = C.cast(arr, _vp), len(lists)
-    keep = []
-    if table is not None and scorer is not None and top_n:
-        idf_, bidf_, w_ = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
-        sa = ScoreArgs(SCORERS[scorer] if scorer in SCORERS else PIPELINE_SCORERS[scorer], num_docs, avg_doc_len, tanh_factor,
-                       root_weight, min_score, _p(idf_).value, _p(bidf_).value, _p(w_).value)
-        keep += [idf_, bidf_, w_, sa]
-        a.table, a.score, a.top_n = table.ptr, C.pointer(sa), top_n
-    ti, ts = np.zeros(max(top_n, 1), np.uint64), np.zeros(max(top_n, 1), np.float64)
-    ki, kd = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64)
-    a.top_ids, a.top_scores, a.knn_ids, a.knn_dists = _p(ti).value, _p(ts).value, _p(ki).value, _p(kd).value
-    if index is not None and q is not None and k:
-        qb = index._q(q)
-        keep.append(qb)
-        a.index, a.query, a.k = index.ptr, _p(qb).value, k
-    if lib.RSGPU_HybridQuery(C.byref(a)) != 0:
-        raise RuntimeError(V.last_error())
-    return dict(n_hits=a.n_hits, top=(ti[:a.n_top], ts[:a.n_top]), knn=(ki[:a.n_knn], kd[:a.n_knn]))
+    """One-shot form of HybridQuery.  Returns dict(n_hits, top=(ids, scores), knn=(ids, dists))."""
+    hq = HybridQuery(lists, table, scorer, idf, bm25_idf, weight, num_docs, avg_doc_len, top_n, index, q, k, root_weight,
+                     min_score, tanh_factor)
+    hq.run()
+    return hq.results()
 
 
 class TreeHits(Hits):
