@@ -2,8 +2,8 @@
 # per-kernel times and launch gaps of the fused hybrid query (configs[4])
 export TMPDIR=/tmp
 R=$(pwd); mkdir -p gpurun_out
-timeout 600 python scripts/hybrid_fused_prof.py 2>&1 | tail -1 | tee gpurun_out/hybrid_fused_wall.txt
-(cd /tmp && REPS=60 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/hybrid_prof" -o h -- python "$R/scripts/hybrid_fused_prof.py" > "$R/gpurun_out/hybrid_prof.log" 2>&1)
+timeout 600 python tests/hybrid_fused_prof.py 2>&1 | tail -1 | tee gpurun_out/hybrid_fused_wall.txt
+(cd /tmp && REPS=60 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/hybrid_prof" -o h -- python "$R/tests/hybrid_fused_prof.py" > "$R/gpurun_out/hybrid_prof.log" 2>&1)
 tail -1 gpurun_out/hybrid_prof.log
 python - <<'PY'
 import csv, glob

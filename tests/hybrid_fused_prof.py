@@ -1,4 +1,4 @@
-"""BASELINE configs[4] through RSGPU_HybridQuery in a loop (for rocprofv3 --kernel-trace: per-kernel times and the gaps
+"""BASELINE configs[4] through RSGPU_HybridQuery in a loop (the oracle encodes the posting lists; for rocprofv3 --kernel-trace: per-kernel times and the gaps
 between them).  Prints the wall time per query."""
 import os
 import sys
