@@ -111,6 +111,27 @@ size_t RSGPU_Hits_Len(const RSGPU_Hits *h);
 /* doc_ids[len]; freqs[n_lists][len] in the order the lists were given. Either may be NULL. */
 int RSGPU_Hits_Read(const RSGPU_Hits *h, uint64_t *doc_ids, uint32_t *freqs);
 
+/* ---- record access: what the iterator seam (include/rs_iterator.h) needs to rebuild, per hit, the RSIndexResult the
+ * reference's own iterators would hold in `current` ------------------------------------------------------------------ */
+/* Number of term columns ("leaves") of the hit list and, for child slot s of the aggregate, the index of its list in the
+ * caller's array: an intersection iterates its children by ascending size unless in_order (reference
+ * rqe_iterators/src/intersection.rs:94-119), and the result's children come in THAT order.  Returns #leaves or -1. */
+int RSGPU_Postings_Codec(const RSGPU_Postings *p); /* RSGPU_Codec of the list, -1 for NULL */
+size_t RSGPU_Hits_NumLeaves(const RSGPU_Hits *h);
+int RSGPU_Hits_IsUnion(const RSGPU_Hits *h); /* 1: built by RSGPU_Union (a child may be absent from a hit) */
+int RSGPU_Hits_LeafOrder(const RSGPU_Hits *h, int *list_of_child);
+/* doc ids of hits [first, first+count) (clamped to the hit list); returns #written or -1. */
+long RSGPU_Hits_ReadRange(const RSGPU_Hits *h, size_t first, size_t count, uint64_t *doc_ids);
+/* For hits [first, first+count) and one list (index in the caller's array): the record the term's reader would have
+ * yielded -- entry index in the posting list (0xFFFFFFFF: the list does not hold the document, i.e. a union child that
+ * did not match), frequency, field mask (low / high 64 bits), and where the record's term-offsets blob lies in the
+ * uploaded bytes (position, length; RSGPU_Postings_ReadBytes fetches them).  Any output may be NULL.  The lists must
+ * still be alive.  Returns #written or -1. */
+long RSGPU_Hits_ReadRecords(const RSGPU_Hits *h, size_t list, size_t first, size_t count, uint32_t *entry, uint32_t *freqs,
+                            uint64_t *mask_lo, uint64_t *mask_hi, uint64_t *offsets_pos, uint32_t *offsets_len);
+/* bytes [pos, pos+len) of the list as uploaded (device -> host).  0 on success. */
+int RSGPU_Postings_ReadBytes(const RSGPU_Postings *p, size_t pos, size_t len, uint8_t *out);
+
 /* Per-document scorer inputs (RSDocumentMetadata: score, maxTermFreq, docLen -- reference
  * src/redisearch.h:97-132), arrays indexed by doc id, n = max doc id + 1. */
 RSGPU_DocTable *RSGPU_DocTable_Upload(size_t n, const uint32_t *doc_len, const float *doc_score,

@@ -59,6 +59,13 @@ def lib():
         L.xh_has_ref_slop.restype = i
         L.xh_ref_slop.restype, L.xh_ref_slop.argtypes = i, [vp]
         L.xh_score.restype, L.xh_score.argtypes = dbl, [C.c_char_p, vp, C.POINTER(_Args), vp, sz]
+        # module-side stand-ins for iterators written in C + the drivers (Boundary 3)
+        L.xh_new_term.restype, L.xh_new_term.argtypes = vp, [dbl, dbl, C.c_char_p]
+        L.xh_iter_drain.restype, L.xh_iter_drain.argtypes = C.c_long, [vp, sz, sz] + [vp] * 11
+        L.xh_iter_script.restype, L.xh_iter_script.argtypes = None, [vp, sz, vp, vp, vp, vp, vp, vp]
+        L.xh_iter_score_all.restype = C.c_long
+        L.xh_iter_score_all.argtypes = [vp, C.c_char_p, C.POINTER(_Args), vp, vp, vp, sz, sz, vp, vp]
+        L.xh_iter_free.restype, L.xh_iter_free.argtypes = None, [vp]
         _lib = L
     return _lib
 
@@ -148,3 +155,74 @@ class Host:
             if err.startswith("no "):
                 raise KeyError(err)
         return (v, buf.value.decode()) if explain else v
+
+
+# ---- drivers for iterators with the reference's QueryIterator vtable (oracle/ext_harness.c, end of file) -------------------
+OP_READ, OP_SKIP, OP_REWIND, OP_ESTIMATE = 0, 1, 2, 3
+
+
+def handle():
+    """dlopen handle of the harness: the library that implements the module's RSIndexResult constructors here"""
+    return lib()._handle
+
+
+def new_term(idf=0.0, bm25_idf=0.0, name=""):
+    return lib().xh_new_term(idf, bm25_idf, name.encode())
+
+
+def _vpp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def iter_drain(it, cap, max_children):
+    """Reads `it` to EOF -> dict of per-hit arrays (ids, freq, mask, n_children) and per-child planes [max_children, n]"""
+    c = max(cap, 1)
+    ids, lo, hi = np.zeros(c, np.uint64), np.zeros(c, np.uint64), np.zeros(c, np.uint64)
+    fr, nc = np.zeros(c, np.uint32), np.zeros(c, np.uint32)
+    cf, cn = np.zeros((max_children, c), np.uint32), np.zeros((max_children, c), np.uint32)
+    clo, chi, ch = (np.zeros((max_children, c), np.uint64) for _ in range(3))
+    same = np.zeros((max_children, c), np.uint8)
+    n = lib().xh_iter_drain(it, c, max_children, _vpp(ids), _vpp(fr), _vpp(lo), _vpp(hi), _vpp(nc), _vpp(cf), _vpp(clo),
+                            _vpp(chi), _vpp(cn), _vpp(ch), _vpp(same))
+    if n < 0:
+        raise RuntimeError("iterator protocol violation while draining")
+    m = min(n, cap)
+    return dict(n=n, ids=ids[:m], freq=fr[:m], mask=[int(a) | (int(b) << 64) for a, b in zip(lo[:m].tolist(), hi[:m].tolist())],
+                n_children=nc[:m], c_freq=cf[:, :m], c_mask_lo=clo[:, :m], c_mask_hi=chi[:, :m], c_npos=cn[:, :m],
+                c_hash=ch[:, :m], c_same_doc=same[:, :m])
+
+
+def positions_hash(positions):
+    h = 1469598103934665603
+    for p in positions:
+        h = ((h ^ int(p)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def iter_script(it, ops):
+    """ops: list of (OP_*, arg) -> list of (status, lastDocId, atEOF, doc id of current or 0)"""
+    n = len(ops)
+    o = np.asarray([a for a, _ in ops], np.int32)
+    g = np.asarray([b for _, b in ops], np.uint64)
+    st, last, cur = np.zeros(n, np.int64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    eof = np.zeros(n, np.uint8)
+    lib().xh_iter_script(it, n, _vpp(o), _vpp(g), _vpp(st), _vpp(last), _vpp(eof), _vpp(cur))
+    return [(int(st[i]), int(last[i]), bool(eof[i]), int(cur[i])) for i in range(n)]
+
+
+def iter_score_all(it, alias, doc_len, doc_score, max_freq, cap, num_docs=1, avg_doc_len=1.0, min_score=0.0, tanh_factor=4,
+                   slop=0):
+    a = _Args()
+    a.num_docs, a.avg_doc_len, a.tanh_factor, a.min_score, a.slop = num_docs, avg_doc_len, tanh_factor, min_score, slop
+    dl = np.ascontiguousarray(doc_len, np.uint32)
+    ds = np.ascontiguousarray(doc_score, np.float32)
+    mf = np.ascontiguousarray(max_freq, np.uint32)
+    ids, sc = np.zeros(max(cap, 1), np.uint64), np.zeros(max(cap, 1), np.float64)
+    n = lib().xh_iter_score_all(it, alias.encode(), C.byref(a), _vpp(dl), _vpp(ds), _vpp(mf), dl.size, cap, _vpp(ids), _vpp(sc))
+    if n < 0:
+        raise RuntimeError("xh_iter_score_all: " + lib().xh_last_error().decode())
+    return ids[: min(n, cap)], sc[: min(n, cap)]
+
+
+def iter_free(it):
+    lib().xh_iter_free(it)

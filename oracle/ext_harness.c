@@ -27,6 +27,7 @@
 #include <string.h>
 
 #include "rs_extension.h"
+#include "rs_iterator.h" /* QueryIterator: the iterator drivers at the end of this file */
 
 #define XH_API __attribute__((visibility("default")))
 
@@ -38,9 +39,10 @@ struct RSQueryTerm {
 };
 
 typedef struct {
-  size_t len;
+  size_t len, cap;
   RSIndexResult *items[];
 } XVec;
+enum { XAGG_BORROWED = 0, XAGG_OWNED = 1 }; /* RSAggregateResult_Borrowed / _Owned, index_result_rs.h:486-487 */
 
 static char g_err[512];
 XH_API const char *xh_last_error(void) { return g_err; }
@@ -187,6 +189,8 @@ XH_API RSIndexResult *xh_agg(int tag, double weight, RSIndexResult **kids, size_
   RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r);
   XVec *v = (XVec *)calloc(1, sizeof *v + (n ? n : 1) * sizeof(RSIndexResult *));
   v->len = n;
+  v->cap = n ? n : 1;
+  r->data.agg.tag = XAGG_OWNED;
   r->data.tag = (uint8_t)tag;
   r->weight = weight;
   for (size_t i = 0; i < n; i++) {
@@ -209,10 +213,102 @@ XH_API void xh_free(RSIndexResult *r) {
     free((void *)r->data.term.offsets.data);
   } else if (IndexResult_AggregateRef(r)) {
     XVec *v = (XVec *)r->data.agg.records;
-    for (size_t i = 0; i < v->len; i++) xh_free(v->items[i]);
+    if (r->data.agg.tag == XAGG_OWNED)
+      for (size_t i = 0; i < v->len; i++) xh_free(v->items[i]);
     free(v);
   }
   free(r);
+}
+
+/* ---- the module's RSIndexResult constructors (src/redisearch_rs/headers/types_ffi.h:89,233,263,331,352,358,364,444):
+ * what an iterator implemented in C builds its `current` with.  Aggregates made here BORROW their children
+ * (RSIndexResult::build_intersect / build_union), exactly like the reference's. ------------------------------------------ */
+static RSIndexResult *new_agg(int tag, size_t cap, double weight) {
+  RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r);
+  XVec *v = (XVec *)calloc(1, sizeof *v + (cap ? cap : 1) * sizeof(RSIndexResult *));
+  v->cap = cap ? cap : 1;
+  r->data.tag = (uint8_t)tag;
+  r->data.agg.tag = XAGG_BORROWED;
+  r->data.agg.records = v;
+  r->weight = weight;
+  return r;
+}
+XH_API RSIndexResult *NewIntersectResult(size_t cap, double weight) { return new_agg(RSResultData_Intersection, cap, weight); }
+XH_API RSIndexResult *NewUnionResult(size_t cap, double weight) { return new_agg(RSResultData_Union, cap, weight); }
+XH_API RSIndexResult *NewVirtualResult(double weight, t_fieldMask field_mask) {
+  RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r); /* RawIndexResultBuilder::virt: doc 0, freq 0 */
+  r->data.tag = RSResultData_Virtual;
+  r->weight = weight;
+  r->fieldMask = field_mask;
+  return r;
+}
+/* types_ffi/src/lib.rs:105-122: a term record with frequency 0, field mask 0, the term owned by the record */
+XH_API RSIndexResult *NewTokenRecord(RSQueryTerm *term, double weight) {
+  RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r);
+  r->data.tag = RSResultData_Term;
+  r->data.term.term = term;
+  r->weight = weight;
+  return r;
+}
+/* RSIndexResult::push_borrowed (index_result/src/core/mod.rs:985-1010): the parent takes the child's doc id, adds its
+ * frequency, ORs its field mask; an owned parent takes the child itself */
+XH_API void AggregateResult_AddChild(RSIndexResult *parent, RSIndexResult *child) {
+  if (!IndexResult_AggregateRef(parent)) return;
+  XVec *v = (XVec *)parent->data.agg.records;
+  if (v->len == v->cap) {
+    v->cap *= 2;
+    v = (XVec *)realloc(v, sizeof *v + v->cap * sizeof(RSIndexResult *));
+    parent->data.agg.records = v;
+  }
+  v->items[v->len++] = child;
+  parent->docId = child->docId;
+  parent->freq += child->freq;
+  parent->fieldMask |= child->fieldMask;
+  parent->data.agg.kind_mask |= child->data.tag;
+}
+XH_API void IndexResult_AggregateReset(RSIndexResult *r) { /* types_ffi.h:233: children vector and kind mask */
+  if (!IndexResult_AggregateRef(r)) return;
+  XVec *v = (XVec *)r->data.agg.records;
+  if (r->data.agg.tag == XAGG_OWNED)
+    for (size_t i = 0; i < v->len; i++) xh_free(v->items[i]);
+  v->len = 0;
+  r->data.agg.kind_mask = 0;
+}
+XH_API void IndexResult_Free(RSIndexResult *r) { xh_free(r); }
+/* RSOffsetVector_SetData(offsets, data, len), types_ffi.h:444: `data` is the ENCODED offsets blob of a posting record
+ * (varint deltas, reference src/redisearch_rs/varint/src/lib.rs; src/varint.h ReadVarint).  In this harness a term's
+ * offsets are the decoded positions (the header of this file), so the blob is decoded here -- which is what the
+ * module's offset iterator does lazily. */
+XH_API void RSOffsetVector_SetData(void *offsets, const char *data, uint32_t len) {
+  XOffsetSlice *s = (XOffsetSlice *)offsets;
+  free((void *)s->data);
+  s->data = NULL;
+  s->len = 0;
+  if (!data || !len) return;
+  uint32_t *pos = (uint32_t *)malloc((size_t)len * 4); /* at most one position per byte */
+  uint32_t n = 0, at = 0, last = 0;
+  while (at < len) {
+    unsigned char c = (unsigned char)data[at++];
+    uint32_t val = c & 127;
+    while ((c >> 7) && at < len) {
+      ++val;
+      c = (unsigned char)data[at++];
+      val = (val << 7) | (c & 127);
+    }
+    last += val;
+    pos[n++] = last;
+  }
+  s->data = (const uint8_t *)pos;
+  s->len = n;
+}
+/* a query term for NewTokenRecord (NewQueryTerm + the idf pair Term::new computes, term.rs:91) */
+XH_API RSQueryTerm *xh_new_term(double idf, double bm25_idf, const char *str) {
+  RSQueryTerm *t = (RSQueryTerm *)calloc(1, sizeof *t);
+  t->idf = idf;
+  t->bm25_idf = bm25_idf;
+  t->str = strdup(str ? str : "");
+  t->len = strlen(t->str);
+  return t;
 }
 
 /* ---- registry + loader (src/extension.c) ----------------------------------------------------------------------------- */
@@ -359,4 +455,100 @@ XH_API double xh_score(const char *alias, const RSIndexResult *res, const XScore
     free(root);
   }
   return v;
+}
+
+/* ---- iterator drivers: what the query pipeline does with a QueryIterator (src/result_processor.c rpQueryItNext reads,
+ * composite iterators skip) -- here over any iterator with the reference's vtable, i.e. the product's
+ * librsgpu_iterators.so --------------------------------------------------------------------------------------------- */
+static uint64_t pos_hash(const RSIndexResult *t) { /* order-sensitive digest of a term record's positions */
+  uint64_t h = 1469598103934665603ull;
+  const uint32_t *p = (const uint32_t *)t->data.term.offsets.data;
+  for (uint32_t i = 0; i < t->data.term.offsets.len; i++) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
+}
+/* Read to EOF.  Per hit: doc id, the aggregate's frequency and field mask, its number of children; per hit and child
+ * slot c < max_children (planes of `cap`): the child's doc id == the hit's (1/0), frequency, field mask (lo/hi),
+ * number of positions and their digest.  Returns the number of hits (may exceed cap: the rest is counted only),
+ * -1 on a status other than OK / EOF. */
+XH_API long xh_iter_drain(QueryIterator *it, size_t cap, size_t max_children, uint64_t *ids, uint32_t *freq,
+                          uint64_t *mask_lo, uint64_t *mask_hi, uint32_t *n_children, uint32_t *c_freq, uint64_t *c_mask_lo,
+                          uint64_t *c_mask_hi, uint32_t *c_npos, uint64_t *c_hash, uint8_t *c_same_doc) {
+  size_t n = 0;
+  for (;;) {
+    const IteratorStatus st = it->Read(it);
+    if (st == ITERATOR_EOF) break;
+    if (st != ITERATOR_OK || !it->current || it->current->docId != it->lastDocId) return -1;
+    const RSIndexResult *r = it->current;
+    if (n < cap) {
+      ids[n] = r->docId;
+      freq[n] = r->freq;
+      mask_lo[n] = (uint64_t)r->fieldMask;
+      mask_hi[n] = (uint64_t)(r->fieldMask >> 64);
+      size_t k = 0;
+      if (IndexResult_AggregateRef(r)) {
+        const XVec *v = (const XVec *)r->data.agg.records;
+        k = v->len;
+        for (size_t c = 0; c < k && c < max_children; c++) {
+          const RSIndexResult *t = v->items[c];
+          c_freq[c * cap + n] = t->freq;
+          c_mask_lo[c * cap + n] = (uint64_t)t->fieldMask;
+          c_mask_hi[c * cap + n] = (uint64_t)(t->fieldMask >> 64);
+          c_npos[c * cap + n] = t->data.tag == RSResultData_Term ? t->data.term.offsets.len : 0;
+          c_hash[c * cap + n] = t->data.tag == RSResultData_Term ? pos_hash(t) : 0;
+          c_same_doc[c * cap + n] = t->docId == r->docId;
+        }
+      }
+      n_children[n] = (uint32_t)k;
+    }
+    n++;
+  }
+  if (!it->atEOF || it->current) return -1; /* iterator_api.h:96-99 */
+  return (long)n;
+}
+/* ops: 0 Read, 1 SkipTo(arg), 2 Rewind, 3 NumEstimated (status_out receives the estimate).  After every op: the
+ * status, lastDocId, atEOF and the doc id of `current` (0 when NULL). */
+XH_API void xh_iter_script(QueryIterator *it, size_t n_ops, const int *ops, const uint64_t *args, long *status_out,
+                           uint64_t *last_out, uint8_t *eof_out, uint64_t *cur_out) {
+  for (size_t i = 0; i < n_ops; i++) {
+    switch (ops[i]) {
+      case 0: status_out[i] = it->Read(it); break;
+      case 1: status_out[i] = it->SkipTo(it, args[i]); break;
+      case 2:
+        it->Rewind(it);
+        status_out[i] = 0;
+        break;
+      default: status_out[i] = (long)it->NumEstimated(it); break;
+    }
+    last_out[i] = it->lastDocId;
+    eof_out[i] = it->atEOF;
+    cur_out[i] = it->current ? it->current->docId : 0;
+  }
+}
+/* rpscoreNext over the whole iterator: every result scored by `alias` with the document's metadata taken from arrays
+ * indexed by doc id (entries beyond table_n: doc_len 0, score 1, max_freq 1).  Returns #hits or -1. */
+XH_API long xh_iter_score_all(QueryIterator *it, const char *alias, const XScoreArgs *common, const uint32_t *doc_len,
+                              const float *doc_score, const uint32_t *max_freq, size_t table_n, size_t cap, uint64_t *ids,
+                              double *scores) {
+  size_t n = 0;
+  for (;;) {
+    const IteratorStatus st = it->Read(it);
+    if (st == ITERATOR_EOF) break;
+    if (st != ITERATOR_OK) return -1;
+    XScoreArgs a = *common;
+    const uint64_t d = it->lastDocId;
+    a.doc_len = d < table_n ? doc_len[d] : 0;
+    a.doc_score = d < table_n ? doc_score[d] : 1.0f;
+    a.max_term_freq = d < table_n ? max_freq[d] : 1;
+    const double v = xh_score(alias, it->current, &a, NULL, 0);
+    if (g_err[0]) return -1;
+    if (n < cap) {
+      ids[n] = d;
+      scores[n] = v;
+    }
+    n++;
+  }
+  return (long)n;
+}
+XH_API void xh_iter_free(QueryIterator *it) {
+  if (it) it->Free(it);
 }

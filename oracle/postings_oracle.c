@@ -196,7 +196,9 @@ void oreader_rewind(OReader *r) { r->eof = 0; r->doc = 0; if (r->ii->nb) set_blo
 static int decode_one(OReader *r, uint64_t base) {
   const OBlock *bl = &r->ii->b[r->blk]; const CodecDesc *cd = &CODECS[r->ii->codec];
   const uint8_t *p = bl->buf + r->pos; size_t avail = bl->len - r->pos;
-  r->freq = 0; r->mask = 0; r->offs = NULL; r->osz = 0; r->mask_lo = r->mask_hi = 0;
+  /* a record keeps what its codec does not store from the reader's base result: frequency 1
+   * (RawTermResultBuilder::new, index_result/src/core/mod.rs:192-197; rqe_iterators/src/inverted_index/term.rs:93) */
+  r->freq = cd->freq >= 0 ? 0 : 1; r->mask = 0; r->offs = NULL; r->osz = 0; r->mask_lo = r->mask_hi = 0;
   if (r->ii->codec == C_FIELDS_ONLY_WIDE) {
     uint64_t d; size_t k = oracle_varint_decode(p, avail, &d); if (!k) return 0;
     size_t k2 = oracle_varint128_decode(p + k, avail - k, &r->mask_lo, &r->mask_hi); if (!k2) return 0;

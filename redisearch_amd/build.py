@@ -77,6 +77,12 @@ C_LIBS = {
     "librsgpu_scorers.so": (["scorer_plugin.c"],
                             ["-O2", "-std=gnu11", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-Wall",
                              "-Wextra", "-I" + os.path.join(ROOT, "include")], ["-ldl", "-lm"]),
+    # Boundary 3: the reference's QueryIterator vtable over device hit lists.  Needs the engine (RSGPU_* symbols) next to
+    # it; the RSIndexResult constructors are looked up in the process (or installed) at run time.
+    "librsgpu_iterators.so": (["query_iterators.c"],
+                              ["-O2", "-std=gnu11", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
+                               "-I" + os.path.join(ROOT, "include")],
+                              ["-L" + LIBDIR, "-lVectorSimilarity", "-Wl,-rpath,$ORIGIN", "-ldl"]),
 }
 
 

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, LeafMa
   for (int l = 0; l < lm.n_leaves; l++) {
     const uint32_t t = lm.leaf_list[l];
     const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];  // the hit's position in list t
-    if (out_freqs) out_freqs[(size_t)l * cap + off] = lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 0u;
+    // (a codec that stores no frequency yields the term record's default, 1: reference index_result/src/core/mod.rs:192-197)
+    if (out_freqs) out_freqs[(size_t)l * cap + off] = lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 1u;
     if (out_epos) out_epos[(size_t)l * cap + off] = lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
   }
 }
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void union_write_kernel(ListView v, LeafMap lm
   for (int l = 0; l < lm.n_leaves; l++) {
     const uint32_t t = lm.leaf_list[l], p = at[t];
     const bool on = p < v.len[t] && !outside[t] && shared_id(v, (int)t, p) == xc;
-    out_freqs[(size_t)l * cap + slot] = (on && lm.leaf_freq[l]) ? lm.leaf_freq[l][p] : 0u;
+    out_freqs[(size_t)l * cap + slot] = on ? (lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 1u) : 0u;
     if (out_epos) out_epos[(size_t)l * cap + slot] = on ? (lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p) : 0xFFFFFFFFu;
   }
 }
@@ -1154,6 +1155,61 @@ void launch_fetch_cand64(const void *cand, const uint32_t *count, uint32_t cap, 
                          hipStream_t s) {
   hipLaunchKernelGGL(fetch_cand64_kernel, dim3(8), dim3(256), 0, s, (const uint2 *)cand, count, cap, keys64, ids,
                      out_rows, out_keys, out_ids, out_n);
+}
+// ---- per-hit term records for the iterator seam (query_iterators.c) ----------------------------------------------------
+// What the term's own reader would have yielded for hit first+i: out[0] entry index in the term's posting list
+// (0xFFFFFFFF: the list does not hold the document -- a union child that did not match), out[1..4] field mask (128 bits),
+// out[5] / out[6] position (into the list's bytes) and length of the record's offsets blob; planes of `count` words.
+// The entry index comes from the hit list's own column when it has one, else from a binary search of the hit's doc id
+// (hit_ids + shift = the id in the list's frame).
+__global__ __launch_bounds__(256) void hit_records_kernel(const uint32_t *__restrict__ hit_ids, uint32_t first, uint32_t count,
+                                                          const uint32_t *__restrict__ hit_epos,
+                                                          const uint32_t *__restrict__ list_ids, uint32_t list_len,
+                                                          long long shift, const uint32_t *__restrict__ masks,
+                                                          const uint32_t *__restrict__ wmasks,
+                                                          const uint32_t *__restrict__ off_pos,
+                                                          const uint32_t *__restrict__ off_len, uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  uint32_t e = 0xFFFFFFFFu;
+  if (hit_epos) {
+    e = hit_epos[first + i];
+  } else {
+    const long long want = (long long)hit_ids[first + i] + shift;
+    if (want >= 0 && want <= 0xFFFFFFFFll) {
+      uint32_t lo = 0, hi = list_len;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((long long)list_ids[mid] < want) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < list_len && (long long)list_ids[lo] == want) e = lo;
+    }
+  }
+  const bool have = e != 0xFFFFFFFFu && e < list_len;
+  out[i] = have ? e : 0xFFFFFFFFu;
+  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+  if (have) {
+    if (wmasks) {
+      m0 = wmasks[4 * (size_t)e], m1 = wmasks[4 * (size_t)e + 1], m2 = wmasks[4 * (size_t)e + 2], m3 = wmasks[4 * (size_t)e + 3];
+    } else if (masks) {
+      m0 = masks[e];
+    }
+  }
+  out[(size_t)count + i] = m0;
+  out[2 * (size_t)count + i] = m1;
+  out[3 * (size_t)count + i] = m2;
+  out[4 * (size_t)count + i] = m3;
+  out[5 * (size_t)count + i] = have && off_pos ? off_pos[e] : 0;
+  out[6 * (size_t)count + i] = have && off_len ? off_len[e] : 0;
+}
+
+void launch_hit_records(const uint32_t *hit_ids, uint32_t first, uint32_t count, const uint32_t *hit_epos,
+                        const uint32_t *list_ids, uint32_t list_len, long long shift, const uint32_t *masks,
+                        const uint32_t *wmasks, const uint32_t *off_pos, const uint32_t *off_len, uint32_t *out, hipStream_t s) {
+  if (!count) return;
+  hipLaunchKernelGGL(hit_records_kernel, dim3(blocks_for(count)), dim3(256), 0, s, hit_ids, first, count, hit_epos, list_ids,
+                     list_len, shift, masks, wmasks, off_pos, off_len, out);
 }
 void launch_gather_u32_counted(const uint32_t *src, uint32_t src_len, const uint32_t *idx, const uint32_t *count,
                                uint32_t cap, uint32_t *out, hipStream_t s) {

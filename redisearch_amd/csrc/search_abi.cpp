@@ -605,7 +605,7 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
   }
   if (freqs_out && n) {
     if (p->cd.freq >= 0) HIP_CHECK(hipMemcpy(freqs_out, p->freqs.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    else memset(freqs_out, 0, n * sizeof(uint32_t));
+    else std::fill(freqs_out, freqs_out + n, 1u);  // the term record's default (index_result/src/core/mod.rs:192-197)
   }
   if (masks_out && n) {
     if (p->cd.mask >= 0 || p->cd.wide) HIP_CHECK(hipMemcpy(masks_out, p->masks.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -863,6 +863,88 @@ int RSGPU_Hits_Read(const RSGPU_Hits *hc, uint64_t *doc_ids, uint32_t *freqs) {
     for (int s = 0; s < h->n_lists; s++)  // back to the caller's list order
       HIP_CHECK(hipMemcpy(freqs + (size_t)h->order[s] * h->len, h->freqs.p + (size_t)s * h->cap,
                           h->len * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return 0;
+  S_CATCH(-1)
+}
+
+// ---- the iterator seam's view of a hit list (include/rsgpu_search.h "record access"; query_iterators.c) -----------------
+int RSGPU_Postings_Codec(const RSGPU_Postings *p) { return p ? p->codec : -1; }
+int RSGPU_Hits_IsUnion(const RSGPU_Hits *h) { return h && h->is_union ? 1 : 0; }
+size_t RSGPU_Hits_NumLeaves(const RSGPU_Hits *h) { return h ? (size_t)h->n_lists : 0; }
+
+int RSGPU_Hits_LeafOrder(const RSGPU_Hits *h, int *list_of_child) {
+  if (!h || !list_of_child) return -1;
+  for (int s = 0; s < h->n_lists; s++) list_of_child[s] = h->order[s];
+  return h->n_lists;
+}
+
+long RSGPU_Hits_ReadRange(const RSGPU_Hits *hc, size_t first, size_t count, uint64_t *doc_ids) {
+  if (!hc || !doc_ids) return -1;
+  RSGPU_Hits *h = const_cast<RSGPU_Hits *>(hc);
+  S_TRY
+  if (first >= h->len) return 0;
+  count = std::min<size_t>(count, h->len - first);
+  HIP_CHECK(hipSetDevice(h->device));
+  std::vector<uint32_t> tmp(count);
+  if (count) HIP_CHECK(hipMemcpy(tmp.data(), h->ids.p + first, count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < count; i++) doc_ids[i] = h->base + tmp[i];
+  return (long)count;
+  S_CATCH(-1)
+}
+
+long RSGPU_Hits_ReadRecords(const RSGPU_Hits *hc, size_t list, size_t first, size_t count, uint32_t *entry, uint32_t *freqs,
+                            uint64_t *mask_lo, uint64_t *mask_hi, uint64_t *offsets_pos, uint32_t *offsets_len) {
+  if (!hc) return -1;
+  RSGPU_Hits *h = const_cast<RSGPU_Hits *>(hc);
+  S_TRY
+  int slot = -1;
+  for (int s = 0; s < h->n_lists; s++)
+    if ((size_t)h->order[s] == list) slot = s;
+  if (slot < 0) throw std::runtime_error("RSGPU_Hits_ReadRecords: no such list in this hit list");
+  if (first >= h->len) return 0;
+  count = std::min<size_t>(count, h->len - first);
+  if (!count) return 0;
+  RSGPU_Postings *p = const_cast<RSGPU_Postings *>(h->src[slot]);
+  if (!p) throw std::runtime_error("RSGPU_Hits_ReadRecords: the hit list does not know its posting lists");
+  HIP_CHECK(hipSetDevice(h->device));
+  CtxLease c(h->device);
+  decode_on(p, c.c);
+  DevBuf<uint32_t> out;
+  out.alloc(7 * count);
+  // the hit's id in the list's frame = hits base + id - list base
+  const long long shift = (long long)(h->base - p->base);
+  launch_hit_records(h->ids.p, (uint32_t)first, (uint32_t)count,
+                     h->with_offsets && h->epos.p ? h->epos.p + (size_t)slot * h->cap : nullptr, p->ids.p, p->n_entries, shift,
+                     (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr, p->cd.wide ? p->wmasks.p : nullptr,
+                     p->has_offsets() ? p->off_pos.p : nullptr, p->has_offsets() ? p->off_len.p : nullptr, out.p, c->stream);
+  HIP_CHECK(hipGetLastError());
+  std::vector<uint32_t> host(7 * count), hf;
+  HIP_CHECK(hipMemcpyAsync(host.data(), out.p, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  if (freqs) {
+    hf.resize(count);
+    HIP_CHECK(hipMemcpyAsync(hf.data(), h->freqs.p + (size_t)slot * h->cap + first, count * sizeof(uint32_t),
+                             hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < count; i++) {
+    const uint32_t e = host[i];
+    if (entry) entry[i] = e;
+    if (freqs) freqs[i] = e == 0xFFFFFFFFu ? 0 : hf[i];
+    if (mask_lo) mask_lo[i] = (uint64_t)host[count + i] | ((uint64_t)host[2 * count + i] << 32);
+    if (mask_hi) mask_hi[i] = (uint64_t)host[3 * count + i] | ((uint64_t)host[4 * count + i] << 32);
+    if (offsets_pos) offsets_pos[i] = host[5 * count + i];
+    if (offsets_len) offsets_len[i] = host[6 * count + i];
+  }
+  return (long)count;
+  S_CATCH(-1)
+}
+
+int RSGPU_Postings_ReadBytes(const RSGPU_Postings *p, size_t pos, size_t len, uint8_t *out) {
+  if (!p || (!out && len)) return -1;
+  S_TRY
+  if (pos > p->n_bytes || len > p->n_bytes - pos) throw std::runtime_error("RSGPU_Postings_ReadBytes: range outside the list's bytes");
+  HIP_CHECK(hipSetDevice(p->device));
+  if (len) HIP_CHECK(hipMemcpy(out, p->bytes.p + pos, len, hipMemcpyDeviceToHost));
   return 0;
   S_CATCH(-1)
 }

@@ -137,6 +137,12 @@ void launch_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uin
 void launch_gather_u32_counted(const uint32_t *src, uint32_t src_len, const uint32_t *idx, const uint32_t *count,
                                uint32_t cap, uint32_t *out, hipStream_t s);
 
+// per-hit term records of hits [first, first+count) for one leaf: out = 7 planes of `count` words -- entry index in the
+// leaf's posting list (0xFFFFFFFF absent), field mask words 0..3, offsets position / length (postings_kernels.hip)
+void launch_hit_records(const uint32_t *hit_ids, uint32_t first, uint32_t count, const uint32_t *hit_epos,
+                        const uint32_t *list_ids, uint32_t list_len, long long shift, const uint32_t *masks,
+                        const uint32_t *wmasks, const uint32_t *off_pos, const uint32_t *off_len, uint32_t *out, hipStream_t s);
+
 // BM25STD.NORM epilogue: scores[i] /= max(0, max_i scores[i]) unless that maximum is 0; keys rewritten alike.
 // max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream
 void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, uint64_t *max_key_zeroed, hipStream_t s);

@@ -60,6 +60,14 @@ ABI = {
     "RSGPU_CalculateIDF": (_dbl, [_sz, _sz]),
     "RSGPU_CalculateIDF_BM25": (_dbl, [_sz, _sz]),
     "RSGPU_SearchProfile": (None, [C.POINTER(_dbl)] * 5),
+    # record access for the iterator seam (include/rsgpu_search.h)
+    "RSGPU_Postings_Codec": (_i, [_vp]),
+    "RSGPU_Hits_NumLeaves": (_sz, [_vp]),
+    "RSGPU_Hits_IsUnion": (_i, [_vp]),
+    "RSGPU_Hits_LeafOrder": (_i, [_vp, _vp]),
+    "RSGPU_Hits_ReadRange": (C.c_long, [_vp, _sz, _sz, _vp]),
+    "RSGPU_Hits_ReadRecords": (C.c_long, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "RSGPU_Postings_ReadBytes": (_i, [_vp, _sz, _sz, _vp]),
 }
 V.EXTRA_ABI = ABI
 
@@ -129,6 +137,12 @@ class Postings:
         if m < 0:
             raise RuntimeError(V.last_error())
         return [int(a) | (int(b) << 64) for a, b in zip(lo[:m].tolist(), hi[:m].tolist())]
+
+    def read_bytes(self, pos, length):
+        out = np.zeros(max(length, 1), np.uint8)
+        if self.lib.RSGPU_Postings_ReadBytes(self.ptr, pos, length, _p(out)) != 0:
+            raise RuntimeError(V.last_error())
+        return out[:length]
 
     def free(self):
         if getattr(self, "ptr", None):
@@ -207,6 +221,31 @@ class Hits:
         if m < 0:
             raise RuntimeError(V.last_error())
         return ids[:m], d[:m]
+
+    def leaf_order(self):
+        """list index (in the caller's array) of every child slot of the aggregate, in iteration order"""
+        o = np.zeros(32, np.int32)
+        n = self.lib.RSGPU_Hits_LeafOrder(self.ptr, _p(o))
+        return o[:n].tolist()
+
+    def read_range(self, first, count):
+        ids = np.zeros(max(count, 1), np.uint64)
+        m = self.lib.RSGPU_Hits_ReadRange(self.ptr, first, count, _p(ids))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return ids[:m]
+
+    def read_records(self, lst, first=0, count=None):
+        """-> dict(entry, freq, mask (Python ints, 128 bit), off_pos, off_len) of hits [first, first+count) for list `lst`"""
+        count = len(self) - first if count is None else count
+        c = max(count, 1)
+        e, f, ol = np.zeros(c, np.uint32), np.zeros(c, np.uint32), np.zeros(c, np.uint32)
+        lo, hi, op = np.zeros(c, np.uint64), np.zeros(c, np.uint64), np.zeros(c, np.uint64)
+        m = self.lib.RSGPU_Hits_ReadRecords(self.ptr, lst, first, count, _p(e), _p(f), _p(lo), _p(hi), _p(op), _p(ol))
+        if m < 0:
+            raise RuntimeError(V.last_error())
+        return dict(entry=e[:m], freq=f[:m], mask=[int(a) | (int(b) << 64) for a, b in zip(lo[:m].tolist(), hi[:m].tolist())],
+                    off_pos=op[:m], off_len=ol[:m])
 
     def free(self):
         if getattr(self, "ptr", None):
@@ -329,3 +368,70 @@ def profile():
     v = [_dbl(0) for _ in range(5)]
     load().RSGPU_SearchProfile(*[C.byref(x) for x in v])
     return dict(zip(("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms"), [x.value for x in v]))
+
+
+# ---- Boundary 3: librsgpu_iterators.so, the reference's QueryIterator vtable over device hit lists (include/rs_iterator.h) --
+class TermArg(C.Structure):
+    _fields_ = [("postings", _vp), ("term", _vp), ("weight", _dbl)]
+
+
+class QueryIteratorStruct(C.Structure):
+    """reference src/iterators/iterator_api.h:46-151"""
+    _fields_ = [("type", C.c_uint32), ("atEOF", C.c_bool), ("lastDocId", C.c_uint64), ("current", _vp),
+                ("NumEstimated", _vp), ("Read", _vp), ("SkipTo", _vp), ("Revalidate", _vp), ("Free", _vp), ("Rewind", _vp),
+                ("ProfileChildren", _vp), ("PrintProfile", _vp)]
+
+
+IT_OK, IT_NOTFOUND, IT_EOF, IT_TIMEOUT = 0, 1, 2, 3
+_itlib = None
+
+
+def load_iterators(result_api_handle=None):
+    """Loads librsgpu_iterators.so next to the engine.  result_api_handle: dlopen handle (ctypes CDLL._handle) of the
+    library that implements the module's RSIndexResult constructors; None = look them up in the whole process."""
+    global _itlib
+    if _itlib is None:
+        load()
+        from . import build as B
+        L = C.CDLL(B.lib_path("librsgpu_iterators.so"))
+        L.RSGPU_Iterators_SetResultAPI.restype, L.RSGPU_Iterators_SetResultAPI.argtypes = _i, [_vp, _vp]
+        L.RSGPU_Iterators_LastError.restype = C.c_char_p
+        L.RSGPU_Iterators_SetBlock.restype, L.RSGPU_Iterators_SetBlock.argtypes = None, [_sz]
+        L.RSGPU_NewIntersectionIterator.restype = _vp
+        L.RSGPU_NewIntersectionIterator.argtypes = [_vp, _sz, C.c_int32, C.c_bool, _dbl]
+        L.RSGPU_NewUnionIterator.restype, L.RSGPU_NewUnionIterator.argtypes = _vp, [_vp, _sz, _dbl]
+        L.RSGPU_NewNotIterator.restype, L.RSGPU_NewNotIterator.argtypes = _vp, [_vp, _vp, C.c_uint64, _dbl]
+        L.RSGPU_NewHitsIterator.restype, L.RSGPU_NewHitsIterator.argtypes = _vp, [_vp, _vp, _sz, _dbl, C.c_bool]
+        L.RSGPU_Iterator_Hits.restype, L.RSGPU_Iterator_Hits.argtypes = _vp, [_vp]
+        _itlib = L
+    if result_api_handle is not None:
+        if _itlib.RSGPU_Iterators_SetResultAPI(None, _vp(result_api_handle)) != 0:
+            raise RuntimeError(_itlib.RSGPU_Iterators_LastError().decode())
+    return _itlib
+
+
+def term_args(lists, terms=None, weights=None):
+    """RSGPU_TermArg array for posting lists `lists`; terms: RSQueryTerm pointers (ints) or None"""
+    n = len(lists)
+    arr = (TermArg * n)()
+    for i, l in enumerate(lists):
+        arr[i].postings = l.ptr
+        arr[i].term = terms[i] if terms is not None else None
+        arr[i].weight = 1.0 if weights is None else float(weights[i])
+    return arr
+
+
+def new_iterator(kind, lists, terms=None, weights=None, weight=1.0, max_slop=-1, in_order=False, universe=None, max_doc_id=0):
+    """-> QueryIterator* (int).  kind: "and" | "or" | "not".  Free it through its own vtable (Free)."""
+    L = load_iterators()
+    if kind == "not":
+        it = L.RSGPU_NewNotIterator(lists[0].ptr, universe.ptr if universe is not None else None, max_doc_id, weight)
+    else:
+        arr = term_args(lists, terms, weights)
+        if kind == "and":
+            it = L.RSGPU_NewIntersectionIterator(C.cast(arr, _vp), len(lists), max_slop, in_order, weight)
+        else:
+            it = L.RSGPU_NewUnionIterator(C.cast(arr, _vp), len(lists), weight)
+    if not it:
+        raise RuntimeError("iterator: " + L.RSGPU_Iterators_LastError().decode())
+    return it
