@@ -180,7 +180,8 @@ def test_reference_fixture_read_skip_rewind_scripts(num_children, case):
     S.load_iterators().RSGPU_Iterators_SetBlock(65536)
     try:
         ops = []
-        for d in range(1, max(result) + 3):          # skip_to every doc id up to past the end (intersection.rs skip_to tests)
+        targets = sorted({t for r in result for t in (r - 1, r, r + 1) if t > 0} | set(range(1, 60)) | {max(result) + 2})
+        for d in targets:     # skip_to every expected id, its neighbours and a dense prefix (intersection.rs skip_to tests)
             ops += [(X.OP_REWIND, 0), (X.OP_SKIP, d), (X.OP_READ, 0)]
         ops += [(X.OP_REWIND, 0)] + [(X.OP_READ, 0)] * (len(result) + 2)
         ops += [(X.OP_REWIND, 0), (X.OP_READ, 0), (X.OP_SKIP, result[2]), (X.OP_SKIP, result[2] + 1), (X.OP_READ, 0),

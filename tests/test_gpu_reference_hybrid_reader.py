@@ -163,3 +163,58 @@ def test_batching_shim_issues_one_gather_per_chunk():
         out[kind + "_s"] = time.perf_counter() - t0
     assert out["batched"] == out["reference"]
     assert out["batched_s"] * 5 < out["reference_s"], out
+
+
+# ---- Boundary 3 under the reference's iterator: childIt = the GPU-backed intersection (include/rs_iterator.h) -------------
+def run_with_gpu_child(kind, g, q, k, lists, policy=0, batch_size=0, can_trim=False, max_slop=-1, in_order=False):
+    """The whole reference pipeline of `(@t:a @t:b)=>[KNN k @v $blob]` with both halves on the device: the reference's
+    compiled HybridIterator pulls its filter through librsgpu_iterators.so's vtable and its vectors through the VecSim
+    seam.  The harness library supplies the module's RSIndexResult constructors (oracle/hybrid_harness.c)."""
+    from redisearch_amd import search as S
+    L = harness(kind)
+    if not hasattr(L, "_child_ready"):
+        L.xhr_run_child.restype = C.c_long
+        L.xhr_run_child.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                    C.POINTER(Opts), C.c_void_p, C.c_void_p, C.c_size_t]
+        L._child_ready = True
+    S.load_iterators(L._handle)          # results are built with THIS harness's constructors
+    child = S.new_iterator("and", lists, max_slop=max_slop, in_order=in_order)
+    blob = V.to_blob(q, g.vtype)
+    o = Opts(search_mode_in=policy, batch_size=batch_size, can_trim=int(can_trim))
+    ids, sc = np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.float64)
+    n = L.xhr_run_child(g.ptr, g.vtype, g.metric, g.dim, blob.ctypes.data_as(C.c_void_p), k, child, C.byref(o),
+                        ids.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p), max(k, 1))
+    assert n >= 0 and not o.timed_out
+    return list(zip(ids[:n].tolist(), sc[:n].tolist())), o
+
+
+@pytest.mark.parametrize("kind", ["reference", "batched"])
+def test_reference_hybrid_iterator_over_the_gpu_intersection_iterator(kind):
+    from redisearch_amd import search as S
+    from tests.test_gpu_proximity import gpu, rand_list
+    rng = np.random.default_rng(2024)
+    n, dim, k = 9000, 24, 10
+    data = rng.standard_normal((n, dim)).astype(np.float32)
+    g = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+    t = torch.from_numpy(data).cuda()
+    torch.cuda.synchronize()
+    g.add_device_rows(t.data_ptr(), n, 1)
+    try:
+        for sizes, slop in (((6000, 5000), -1), ((900, 700), -1), ((6000, 5500), 3)):
+            lists = [rand_list(rng, O.C_FULL, m, n + 300, max_pos=15) for m in sizes]     # some ids have no vector
+            gl = [gpu(l) for l in lists]
+            want_child = (O.intersect_ex(lists, max_slop=slop)[0] if slop >= 0 else O.intersect(lists)[0]).tolist()
+            assert len(want_child) > 30
+            qv = rng.standard_normal(dim).astype(np.float32)
+            for policy, bs, trim in ((0, 0, False), (H.HYBRID_BATCHES, 7, False), (H.HYBRID_ADHOC_BF, 0, True),
+                                     (H.HYBRID_BATCHES, 0, True)):
+                got, go = run_with_gpu_child(kind, g, qv, k, gl, policy=policy, batch_size=bs, can_trim=trim, max_slop=slop)
+                # the same iterator over the harness's own sorted-id-list child holding the oracle's intersection; the
+                # GPU child estimates like the reference's intersection does (its smallest list), so hand that over
+                ref, ro = run(kind, g, qv, k, want_child, policy=policy, batch_size=bs, can_trim=trim,
+                              estimate=min(l.unique_docs for l in lists))
+                assert got == ref, (sizes, slop, policy, bs)
+                assert (go.search_mode_out, go.num_iterations, go.max_batch_size) == (ro.search_mode_out, ro.num_iterations,
+                                                                                      ro.max_batch_size)
+    finally:
+        S.load_iterators()   # (binding stays; test_gpu_iterators re-binds to its own harness at module start)
