@@ -123,18 +123,23 @@ struct Op<KT_F32, KM_L2> {
   }
 };
 // fp64: two elements per chunk, fp64 accumulate
+typedef double d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double as_d(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
 template <>
 struct Op<KT_F64, KM_IP> {
   static __device__ __forceinline__ double add(double acc, u4 x, u4 q) {
-    acc = fma(as_d(x.x, x.y), as_d(q.x, q.y), acc);
-    return fma(as_d(x.z, x.w), as_d(q.z, q.w), acc);
+    // (one 16-byte value -> two doubles in ONE bit cast: building each double from two words let the compiler narrow
+    // the chunk load into a dwordx4 + a second dwordx2 of the same address and wait for every load separately)
+    const d2 xv = __builtin_bit_cast(d2, x), qv = __builtin_bit_cast(d2, q);
+    acc = fma(xv.x, qv.x, acc);
+    return fma(xv.y, qv.y, acc);
   }
 };
 template <>
 struct Op<KT_F64, KM_L2> {
   static __device__ __forceinline__ double add(double acc, u4 x, u4 q) {
-    double d0 = as_d(x.x, x.y) - as_d(q.x, q.y), d1 = as_d(x.z, x.w) - as_d(q.z, q.w);
+    const d2 xv = __builtin_bit_cast(d2, x), qv = __builtin_bit_cast(d2, q);
+    double d0 = xv.x - qv.x, d1 = xv.y - qv.y;
     acc = fma(d0, d0, acc);
     return fma(d1, d1, acc);
   }
