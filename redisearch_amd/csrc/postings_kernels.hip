@@ -61,6 +61,21 @@ __device__ __forceinline__ uint32_t read_varint128(Bytes bytes, uint32_t pos, ui
   return pos;
 }
 
+// Four bytes at an arbitrary position.  From LDS: two aligned dword reads + v_alignbyte_b32 -- ONE LDS round trip per
+// value instead of one per byte (a lane's byte reads are dependent ds_read_u8's: ~9 round trips per qint record was what
+// bounded this kernel, 140 GB/s of encoded bytes).  From global memory: byte loads as before (rare fallback).
+struct LdsBytes {
+  const uint8_t *p;  // 4-byte aligned, 8 readable bytes behind the last record
+  __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return p[i]; }
+};
+__device__ __forceinline__ uint32_t peek32(LdsBytes b, uint32_t pos) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(b.p) + (pos >> 2);
+  return __builtin_amdgcn_alignbyte(w[1], w[0], pos & 3u);
+}
+__device__ __forceinline__ uint32_t peek32(const uint8_t *b, uint32_t pos) {
+  return (uint32_t)b[pos] | ((uint32_t)b[pos + 1] << 8) | ((uint32_t)b[pos + 2] << 16) | ((uint32_t)b[pos + 3] << 24);
+}
+
 template <int KIND, typename Bytes>
 __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes bytes, uint32_t pos, uint32_t fin,
                                                  uint32_t n, uint32_t f0, uint32_t out, uint32_t *__restrict__ ids,
@@ -68,22 +83,29 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
                                                  uint32_t *__restrict__ wmasks, uint32_t *__restrict__ off_pos,
                                                  uint32_t *__restrict__ off_len, uint32_t abs_base) {
   uint32_t base = f0;
+  // Decoded fields are collected four records at a time and written with one 16-byte store per array: a lane's entries
+  // are consecutive in the output arrays, those of its neighbours ~100 entries away, so a scalar store per record is 64
+  // separate 4-byte write transactions per instruction -- it was the stores, not the parsing, that bounded this kernel.
+  typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+  uint32_t b_id[4], b_fr[4], b_mk[4], b_op[4], b_ol[4];
   for (uint32_t e = 0; e < n && pos < fin; e++, out++) {
     uint32_t freq = 0, mask = 0, osz = 0;
     uint64_t mlo = 0, mhi = 0;
     if (KIND == 0) {
-      const uint32_t hdr = bytes[pos++];
+      // the control byte fixes where every field starts, so the fields are fetched independently of each other:
+      // two dependent round trips per record (control byte, then all fields)
+      const uint32_t head = peek32(bytes, pos);
+      const uint32_t hdr = head & 0xffu;
+      pos++;
       uint32_t v[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         if (i < cd.n) {
           const uint32_t len = ((hdr >> (2 * i)) & 3u) + 1u;
-          uint32_t x = bytes[pos];
-          if (len > 1) x |= (uint32_t)bytes[pos + 1] << 8;
-          if (len > 2) x |= (uint32_t)bytes[pos + 2] << 16;
-          if (len > 3) x |= (uint32_t)bytes[pos + 3] << 24;
+          // field 0 of a record that is at most 4 bytes long came with the control byte
+          const uint32_t raw = i == 0 && len < 4 ? head >> 8 : peek32(bytes, pos);
+          v[i] = len == 4 ? raw : raw & ((1u << (8 * len)) - 1u);
           pos += len;
-          v[i] = x;
         }
       }
       base += v[0];
@@ -91,17 +113,21 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
       if (cd.mask >= 0) mask = cd.mask == 1 ? v[1] : (cd.mask == 2 ? v[2] : v[3]);
       if (cd.osz >= 0) osz = cd.osz == 1 ? v[1] : (cd.osz == 2 ? v[2] : v[3]);
     } else if (KIND == 1) {
-      uint32_t c = bytes[pos++];
+      // a 32-bit delta takes at most five bytes: parsed out of two fetched words, no memory access inside the loop
+      uint64_t win = (uint64_t)peek32(bytes, pos) | ((uint64_t)peek32(bytes, pos + 4) << 32);
+      uint32_t c = (uint32_t)win & 0xffu;
       uint32_t val = c & 0x7fu;
+      pos++;
       while (c & 0x80u) {
         val++;
-        c = bytes[pos++];
+        win >>= 8;
+        c = (uint32_t)win & 0xffu;
+        pos++;
         val = (val << 7) | (c & 0x7fu);
       }
       base += val;
     } else {
-      const uint32_t d = (uint32_t)bytes[pos] | ((uint32_t)bytes[pos + 1] << 8) | ((uint32_t)bytes[pos + 2] << 16) |
-                         ((uint32_t)bytes[pos + 3] << 24);
+      const uint32_t d = peek32(bytes, pos);
       pos += 4;
       base = f0 + d;
     }
@@ -109,18 +135,45 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
       pos = read_varint128(bytes, pos, mlo, mhi);
       mask = (uint32_t)mlo;
     }
-    ids[out] = base;
-    if (freqs) freqs[out] = freq;
-    if (masks) masks[out] = mask;
+    const uint32_t slot = e & 3u;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++)
+      if (slot == j) {
+        b_id[j] = base;
+        b_fr[j] = freq;
+        b_mk[j] = mask;
+        b_op[j] = abs_base + pos;
+        b_ol[j] = osz;
+      }
+    const bool last = e + 1 == n || pos + osz >= fin;
+    if (slot == 3u) {  // records e-3 .. e -> entries out-3 .. out
+      const uint32_t o = out - 3u;
+      *reinterpret_cast<u4u *>(ids + o) = (u4u){b_id[0], b_id[1], b_id[2], b_id[3]};
+      if (freqs) *reinterpret_cast<u4u *>(freqs + o) = (u4u){b_fr[0], b_fr[1], b_fr[2], b_fr[3]};
+      if (masks) *reinterpret_cast<u4u *>(masks + o) = (u4u){b_mk[0], b_mk[1], b_mk[2], b_mk[3]};
+      if (off_pos) {  // where the offsets blob of each record sits in the list's byte buffer
+        *reinterpret_cast<u4u *>(off_pos + o) = (u4u){b_op[0], b_op[1], b_op[2], b_op[3]};
+        *reinterpret_cast<u4u *>(off_len + o) = (u4u){b_ol[0], b_ol[1], b_ol[2], b_ol[3]};
+      }
+    } else if (last) {  // the block's last one to three records
+#pragma unroll
+      for (uint32_t j = 0; j < 3; j++)
+        if (j <= slot) {
+          const uint32_t o = out - slot + j;
+          ids[o] = b_id[j];
+          if (freqs) freqs[o] = b_fr[j];
+          if (masks) masks[o] = b_mk[j];
+          if (off_pos) {
+            off_pos[o] = b_op[j];
+            off_len[o] = b_ol[j];
+          }
+        }
+    }
     if (wmasks) {
       wmasks[4 * (size_t)out] = (uint32_t)mlo;
       wmasks[4 * (size_t)out + 1] = (uint32_t)(mlo >> 32);
       wmasks[4 * (size_t)out + 2] = (uint32_t)mhi;
       wmasks[4 * (size_t)out + 3] = (uint32_t)(mhi >> 32);
-    }
-    if (off_pos) {  // where the offsets blob of this record sits in the list's byte buffer
-      off_pos[out] = abs_base + pos;
-      off_len[out] = osz;
     }
     pos += osz;  // offsets bytes are not parsed here: the proximity kernels read them in place
   }
@@ -136,7 +189,7 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
                                                            uint32_t *__restrict__ masks, uint32_t *__restrict__ wmasks,
                                                            uint32_t *__restrict__ off_pos,
                                                            uint32_t *__restrict__ off_len) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[kDecodeLds];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[kDecodeLds + 16];  // (+ slack: peek32 reads up to 8 bytes ahead)
   const uint32_t b0 = blockIdx.x * 64, lane = threadIdx.x;
   const uint32_t nb = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
   const uint64_t w_beg = byte_off[b0] & ~15ull, w_end = byte_off[b0 + nb];  // 16-byte aligned start
@@ -152,11 +205,87 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
   if (lane >= nb) return;
   const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
   if (staged)
-    decode_one_block<KIND>(cd, (const uint8_t *)stage, (uint32_t)(beg - w_beg), (uint32_t)(fin - w_beg), nent[b],
+    decode_one_block<KIND>(cd, LdsBytes{stage}, (uint32_t)(beg - w_beg), (uint32_t)(fin - w_beg), nent[b],
                            first[b], entry_off[b], ids, freqs, masks, wmasks, off_pos, off_len, (uint32_t)w_beg);
   else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
     decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), nent[b], first[b], entry_off[b], ids, freqs,
                            masks, wmasks, off_pos, off_len, (uint32_t)beg);
+}
+
+// One WAVEFRONT per block for the two record kinds whose boundaries need no parse from the block start: a varint delta
+// ends at the byte without the continuation bit (DocIdsOnly: 1000 records per block, so lane-per-block left 5 000 lanes
+// for a 5 M-entry list), a raw delta is four bytes.  Lane i takes byte i of a 64-byte chunk; a lane on a terminator
+// byte assembles its varint from the up to four continuation bytes before it, the record index is the count of
+// terminators before it (ballot), the doc id the running sum of the deltas (wavefront scan): ids are written in order,
+// coalesced.  Bit-for-bit the sequential decoder's output (reference inverted_index/src/codec/doc_ids_only.rs:38-49,
+// raw_doc_ids_only.rs; varint/src/lib.rs).
+template <int KIND>
+__global__ __launch_bounds__(256) void decode_blocks_wave_kernel(const uint8_t *__restrict__ bytes,
+                                                                const uint64_t *__restrict__ byte_off,
+                                                                const uint32_t *__restrict__ first,
+                                                                const uint32_t *__restrict__ nent,
+                                                                const uint32_t *__restrict__ entry_off, uint32_t n_blocks,
+                                                                uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
+                                                                uint32_t *__restrict__ masks) {
+  const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= n_blocks) return;
+  const uint64_t beg = byte_off[b];
+  const uint32_t len = (uint32_t)(byte_off[b + 1] - beg), n = nent[b], f0 = first[b], out0 = entry_off[b];
+  const uint8_t *__restrict__ p = bytes + beg;
+  if (KIND == 2) {  // raw: id = block's first doc id + u32
+    for (uint32_t e = lane; e < n && 4u * e + 4u <= len; e += 64u) {
+      const uint32_t d = (uint32_t)p[4 * e] | ((uint32_t)p[4 * e + 1] << 8) | ((uint32_t)p[4 * e + 2] << 16) |
+                         ((uint32_t)p[4 * e + 3] << 24);
+      ids[out0 + e] = f0 + d;
+      if (freqs) freqs[out0 + e] = 0;
+      if (masks) masks[out0 + e] = 0;
+    }
+    return;
+  }
+  uint32_t base = f0, done = 0;  // wave-uniform: doc id and number of the records emitted so far
+  for (uint32_t c0 = 0; c0 < len && done < n; c0 += 64u) {
+    const uint32_t i = c0 + lane;
+    const bool in = i < len;
+    const uint32_t c = in ? p[i] : 0x80u;
+    const bool term = in && !(c & 0x80u);
+    uint32_t val = 0;
+    if (term) {
+      // continuation bytes right before this one (at most four for a 32-bit value), oldest first
+      uint32_t k = 0;
+      uint32_t pb[4];
+#pragma unroll
+      for (uint32_t j = 1; j <= 4; j++) {
+        pb[j - 1] = (i >= j && k == j - 1) ? p[i - j] : 0u;
+        if (k == j - 1 && i >= j && (pb[j - 1] & 0x80u)) k = j;
+      }
+      // val = c_first & 0x7f; then val = ((val + 1) << 7) | (next & 0x7f) for every following byte
+      bool open = false;
+#pragma unroll
+      for (int j = 3; j >= 0; j--)
+        if ((uint32_t)j < k) {
+          val = open ? (((val + 1u) << 7) | (pb[j] & 0x7fu)) : (pb[j] & 0x7fu);
+          open = true;
+        }
+      val = open ? (((val + 1u) << 7) | (c & 0x7fu)) : (c & 0x7fu);
+    }
+    const unsigned long long tm = __ballot(term);
+    const uint32_t before = (uint32_t)__popcll(tm & ((1ull << lane) - 1ull));
+    // inclusive scan of the deltas over the wavefront (non-terminators carry 0)
+    uint32_t sum = val;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+      const uint32_t o = __shfl_up(sum, d);
+      if (lane >= d) sum += o;
+    }
+    const uint32_t idx = done + before;
+    if (term && idx < n) {
+      ids[out0 + idx] = base + sum;
+      if (freqs) freqs[out0 + idx] = 0;
+      if (masks) masks[out0 + idx] = 0;
+    }
+    base += __shfl(sum, 63);
+    done += (uint32_t)__popcll(tm);
+  }
 }
 
 // ---- intersection ----------------------------------------------------------------------------------
@@ -1078,7 +1207,15 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
 #define RSGPU_DECODE(K)                                                                                         \
   hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + 63) / 64), dim3(64), 0, s, cd, bytes, byte_off, first, \
                      nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len)
-  if (cd.kind == 0) RSGPU_DECODE(0);
+  // varint / raw deltas without a wide mask: one wavefront per block (decode_blocks_wave_kernel)
+  const bool wave = (cd.kind == 1 || cd.kind == 2) && !cd.wide && !wmasks && !off_pos;
+  if (wave && cd.kind == 1)
+    hipLaunchKernelGGL(decode_blocks_wave_kernel<1>, dim3((n_blocks + 3) / 4), dim3(256), 0, s, bytes, byte_off, first, nent,
+                       entry_off, n_blocks, ids, freqs, masks);
+  else if (wave)
+    hipLaunchKernelGGL(decode_blocks_wave_kernel<2>, dim3((n_blocks + 3) / 4), dim3(256), 0, s, bytes, byte_off, first, nent,
+                       entry_off, n_blocks, ids, freqs, masks);
+  else if (cd.kind == 0) RSGPU_DECODE(0);
   else if (cd.kind == 1) RSGPU_DECODE(1);
   else RSGPU_DECODE(2);
 #undef RSGPU_DECODE
