@@ -307,7 +307,43 @@ def extra_batched(lib, V, rows, dim):
             ok &= len(set(si.tolist()) & set(ids[i].tolist())) >= k - 2
             worst = max(worst, float(np.max(np.abs(np.sort(sc[i]) - np.sort(ss)))))
         flops = 2.0 * batch * dim * rows
+        # opt-in int8 shadow of the same corpus (RSGPU_SetTuning("shadow8") before VecSimIndex_New): the filter passes run
+        # on the int8 matrix cores over half the bytes, survivors are re-scored from the fp16 rows -- the replies must be
+        # BIT-IDENTICAL to single queries on the fp16 index
+        i8 = None
+        try:
+            idx.free()
+            lib.RSGPU_SetTuning(b"shadow8", 1)
+            idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
+            lib.RSGPU_SetTuning(b"shadow8", 0)
+            idx.reserve(rows)
+            idx.add_philox_rows(SEED, 0, rows, 1)
+            t0 = time.perf_counter()
+            idx.topk_batch(qs[0], k)  # builds the shadow
+            build_s = time.perf_counter() - t0
+            lib.RSGPU_ResetProfile()
+            lib.RSGPU_SetProfiling(1)
+            t0 = time.perf_counter()
+            for i in range(reps):
+                ids8, sc8, cnt8 = idx.topk_batch(qs[(i + 1) % 4], k)
+            el8 = time.perf_counter() - t0
+            lib.RSGPU_SetProfiling(0)
+            l8, ms8, by8 = V.scan_profile()
+            d8 = ms8 / max(l8, 1)
+            same = True
+            for i in (0, 85, 170, 255):
+                si, ss = idx.topk_query(qs[reps % 4][i], k).results()
+                same &= si.tolist() == ids8[i].tolist() and ss.tolist() == sc8[i].tolist()
+            i8 = {"device_ms_per_pass": d8, "qps_device": batch / d8 * 1e3, "qps_wall": reps * batch / el8,
+                  "shadow_bytes_read_per_pass": by8 / max(l8, 1), "hbm_gbs_of_shadow_bytes": by8 / max(l8, 1) / d8 / 1e6,
+                  "int8_tops": flops / d8 / 1e9, "int8_frac_of_5000_TOPS": flops / d8 / 1e9 / 5000.0,
+                  "first_call_incl_shadow_build_s": build_s,
+                  "bit_identical_to_single_queries": bool(same),
+                  "note": "opt-in (+50 % HBM for an fp16 index); exact: Cauchy-Schwarz band from the actual quantisation-error norms"}
+        except Exception as e:  # the extra must never take the headline down
+            i8 = {"error": str(e)[:200]}
         return {"workload": "%dx%d fp16 FLAT IP top-%d, batch=%d queries per corpus pass (RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
+                "int8_shadow_extra": i8,
                 "device_ms_per_pass": dev_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": reps * batch / el,
                 "hbm_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac": rows * dim * 2 / dev_ms / 1e6 / HBM_PEAK_GBS,
                 "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,

@@ -54,8 +54,8 @@ struct Pinned {
 };
 struct BatchScratch {
   int device = -1;
-  Dev<uint8_t> queries, queries16;  // (queries16: fp16 copy for the pass over an fp16 shadow)
-  Dev<float> tau;
+  Dev<uint8_t> queries, queries16;  // (queries16: fp16 copy for the pass over an fp16 shadow; int8 copy for an int8 shadow)
+  Dev<float> tau, qscale, slack_q;  // (qscale / slack_q: int8 shadow -- per-query scale product and error band)
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
   Dev<uint64_t> cand, sub_cand;
   Dev<uint32_t> sub_count;
@@ -76,6 +76,12 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                           gemm_qs_supported((uint32_t)(sstride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
   const bool gemm_ok = via_shadow || ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) &&
                                       metric != VecSimMetric_L2 && !multi && k > 0 && k <= 4096);
+  // FLOAT16 IP / cosine indexes that carry the int8 shadow (shadow_ == 3): the filter passes run on the int8 matrix
+  // cores over half the bytes, every threshold is widened by the query's own error band, the survivors are re-scored
+  // from the fp16 rows with the single-query scan's arithmetic -> ids and distances bit-identical to single queries
+  bool via_shadow8 = gemm_ok && !via_shadow && shadow_ == 3 && k <= 1024 && scan_tuning().two_stage && scan_tuning().gemm_qs &&
+                     gemm_qs_supported((uint32_t)(sstride_ / 16)) && sstride_ / 16 <= 64 &&  // (int8 rows up to 1024 bytes)
+                     batch_rescore_supported((uint32_t)(stride_ / 16)) && ensure_shadow8g();
   const float slack = via_shadow ? 2.0f * 4e-3f : 0.0f;  // eps: FlatIndex::two_stage_topk
   auto single = [&](size_t qi) {
     VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
@@ -93,12 +99,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   }
   flush_if_needed();
   std::vector<size_t> redo;
-  // the corpus the MFMA passes read
-  const int g_type = via_shadow ? KT_F16 : ktype;
-  const size_t g_stride = via_shadow ? sstride_ : stride_;
   {
     std::shared_lock<std::shared_mutex> g(mu);
     const uint32_t n = n_rows_;
+    // (rows added since ensure_shadow8g, or a corpus the single-query path serves anyway: the plain fp16 passes)
+    if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
+    // the corpus the MFMA passes read
+    const int g_type = via_shadow ? KT_F16 : (via_shadow8 ? KT_I8 : ktype);
+    const size_t g_stride = (via_shadow || via_shadow8) ? sstride_ : stride_;
     if (!n) {
       for (size_t qi = 0; qi < n_queries; qi++) counts_out[qi] = 0;
       return;
@@ -117,7 +125,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
     }
     const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
-    const uint8_t *g_rows = via_shadow ? d_shadow_ : d_rows_;
+    const uint8_t *g_rows = (via_shadow || via_shadow8) ? d_shadow_ : d_rows_;
     const uint32_t stride16 = (uint32_t)(g_stride / 16);
     // sample prefix for the thresholds; small corpora take the all-keys path
     const bool small = n <= (1u << 19);
@@ -129,7 +137,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
     const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
-    if (via_shadow && !use_qs) {  // small corpora: the single-query path is already cheap
+    if ((via_shadow || via_shadow8) && !use_qs) {  // small corpora: the single-query path is already cheap
       g.unlock();
       for (size_t qi = 0; qi < n_queries; qi++) single(qi);
       return;
@@ -137,7 +145,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
-      if (n >= (1u << 23)) phase_end = {(n / 16) & ~31u, (n / 4) & ~31u, n};
+      // (the int8 filter's wider band makes the sample's loose bound expensive: one more, shorter first phase)
+      if (n >= (1u << 23) && (scan_tuning().qs_phases == 4 || (via_shadow8 && scan_tuning().qs_phases == 0))) phase_end = {(n / 64) & ~31u, (n / 16) & ~31u, (n / 4) & ~31u, n};
+      else if (n >= (1u << 23)) phase_end = {(n / 16) & ~31u, (n / 4) & ~31u, n};
       else if (n >= (1u << 21)) phase_end = {(n / 8) & ~31u, n};
       else phase_end = {n};
     }
@@ -150,14 +160,18 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         seen = std::max(seen, e);
         from = e;
       }
-      expect_total *= via_shadow ? 18 : 6;  // (the shadow's error band roughly triples the survivors)
+      expect_total *= via_shadow ? 18 : (via_shadow8 ? 48 : 6);  // (a shadow's error band multiplies the survivors)
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
     for (int sl = 0; sl < n_slots; sl++) {
       BatchScratch &sc = tls_batch[sl];
       sc.queries.ensure((size_t)kBatch * stride_);
-      if (via_shadow) sc.queries16.ensure((size_t)kBatch * sstride_);
+      if (via_shadow || via_shadow8) sc.queries16.ensure((size_t)kBatch * sstride_);
       sc.tau.ensure(kBatch);
+      if (via_shadow8) {
+        sc.qscale.ensure(kBatch);
+        sc.slack_q.ensure(kBatch);
+      }
       sc.cand_count.ensure(kBatch);
       sc.overflow.ensure(kBatch);
       sc.keys.ensure((size_t)kBatch * n0);
@@ -179,7 +193,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         const uint32_t grid = gemm_qs_grid(e - from);
         qs_grid_max = std::max(qs_grid_max, grid);
         const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
-        while (sub_cap < (via_shadow ? 24 : 8) * expect) sub_cap *= 2;
+        while (sub_cap < (via_shadow ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
         seen = std::max(seen, e);
         from = e;
       }
@@ -208,6 +222,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         launch_shadow_rows(sc.queries.p, stride_, (uint32_t)dim, 0, kBatch, sc.queries16.p, sstride_, c->stream);
         g_queries = sc.queries16.p;
       }
+      const float *slack_q = nullptr, *qscale = nullptr;
+      if (via_shadow8) {  // int8 copies of the queries with their own scales + the per-query error band
+        launch_quantize_queries_f16(sc.queries.p, stride_, (uint32_t)dim, kBatch, s8g_scale_, d_s8g_stats_, sc.queries16.p, sstride_,
+                                    sc.qscale.p, sc.slack_q.p, c->stream);
+        g_queries = sc.queries16.p;
+        slack_q = sc.slack_q.p;
+        qscale = sc.qscale.p;
+      }
       if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
       if (small) {
         launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
@@ -215,9 +237,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         launch_batch_select_keys(sc.keys.p, n0, n, kk, kBatch, sc.out_rows.p, sc.out_keys.p, sc.out_n.p, kk, c->stream);
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
       } else {
-        launch_gemm_topk(g_type, g_rows, g_queries, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
-                         c->stream);
-        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream, 1, slack);
+        // the sample's bound: from the exact rows when the filter runs on the int8 shadow (the tiled GEMM has no int8 form;
+        // an exact bound widened by the band is as good as a shadow bound widened by it)
+        if (via_shadow8)
+          launch_gemm_topk(ktype, d_rows_, sc.queries.p, (uint32_t)(stride_ / 16), 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr,
+                           0, c->stream);
+        else
+          launch_gemm_topk(g_type, g_rows, g_queries, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0, c->stream);
+        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream, 1, slack, slack_q);
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
         if (use_qs) {
@@ -225,25 +252,25 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           for (size_t ph = 0; ph < phase_end.size(); ph++) {
             const uint32_t e = phase_end[ph];
             launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p,
-                           sub_cap, c->stream);
+                           sub_cap, c->stream, qscale);
             launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
                                 sc.cand.p, cand_cap, ph > 0, c->stream);
             if (ph + 1 < phase_end.size())
               launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
-                                          c->stream, slack);
+                                          c->stream, slack, slack_q);
             from = e;
           }
         } else {
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);
         }
-        if (via_shadow) {
+        if (via_shadow || via_shadow8) {
           // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
-          // their exact fp32 keys, then the usual exact select over (key, row)
+          // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
-                                      c->stream, slack);
+                                      c->stream, slack, slack_q);
           launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                               sc.tau.p, c->stream);
+                               sc.tau.p, c->stream, via_shadow8 ? KT_F16 : KT_F32);
         }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);
@@ -269,7 +296,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
           ScanProfile &pf = scan_profile();
           pf.launches++;
-          pf.bytes += (uint64_t)n * (via_shadow ? dim * 2 : elem_bytes_);
+          pf.bytes += (uint64_t)n * (via_shadow ? dim * 2 : (via_shadow8 ? dim : elem_bytes_));
           pf.nanos += (uint64_t)((double)ms * 1e6);
         }
       }

@@ -279,7 +279,9 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     if (scan_tuning().shadow8) shadow_ = 2;  // every metric (the error band carries the norms)
     else if (scan_tuning().shadow16 && metric == VecSimMetric_Cosine) shadow_ = 1;
   }
-  sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ == 2 ? round_up(dim, 16) : 0);
+  // FLOAT16 IP / cosine: an int8 shadow with one index-wide scale for the batched MFMA pass (batch_query.cpp)
+  if (type == VecSimType_FLOAT16 && !multi && metric != VecSimMetric_L2 && scan_tuning().shadow8) shadow_ = 3;
+  sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ >= 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
   hipDeviceProp_t prop;
@@ -289,6 +291,10 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   if (shadow_ == 2) {
     HIP_CHECK(hipMalloc((void **)&d_smax_, 4 * sizeof(uint32_t)));
     HIP_CHECK(hipMemset(d_smax_, 0, 4 * sizeof(uint32_t)));
+  }
+  if (shadow_ == 3) {
+    HIP_CHECK(hipMalloc((void **)&d_s8g_stats_, 4 * sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d_s8g_stats_, 0, 4 * sizeof(uint32_t)));
   }
   // staging block: up to 4096 rows or 8 MiB
   stage_cap_ = std::max<size_t>(1, std::min<size_t>(4096, (8u << 20) / stride_));
@@ -306,6 +312,7 @@ FlatIndex::~FlatIndex() {
   if (d_labels_) HIP_IGNORE(hipFree(d_labels_));
   if (d_sscale_) HIP_IGNORE(hipFree(d_sscale_));
   if (d_smax_) HIP_IGNORE(hipFree(d_smax_));
+  if (d_s8g_stats_) HIP_IGNORE(hipFree(d_s8g_stats_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
   HIP_IGNORE(hipStreamDestroy(wstream_));
 }
@@ -368,7 +375,7 @@ void FlatIndex::grow(size_t min_rows) {
 // new rows [row_begin,row_end) -> shadow, queued on wstream_ behind the copies / normalisation that produced them;
 // the int8 form also refreshes the host copy of the largest row scale (the caller syncs wstream_ anyway)
 void FlatIndex::shadow_convert(uint32_t row_begin, uint32_t row_end) {
-  if (!shadow_ || row_end <= row_begin) return;
+  if (!shadow_ || shadow_ == 3 || row_end <= row_begin) return;  // (3: built lazily, ensure_shadow8g)
   if (shadow_ == 1) {
     launch_shadow_rows(d_rows_, stride_, (uint32_t)dim, row_begin, row_end, d_shadow_, sstride_, wstream_);
     return;
@@ -431,6 +438,50 @@ void FlatIndex::rows_of(size_t label, std::vector<uint32_t> &out) const {
     auto it = single_map_.find(label);
     if (it != single_map_.end()) out.push_back(it->second);
   }
+}
+
+// int8 shadow with one index-wide scale (shadow_ == 3), brought up to date with the rows: see flat_index.hpp.
+bool FlatIndex::ensure_shadow8g() {
+  if (shadow_ != 3) return false;
+  flush_if_needed();
+  {
+    std::shared_lock<std::shared_mutex> g(mu);
+    if (s_bad_) return false;
+    if (s8g_built_ >= n_rows_ && s8g_seen_ >= n_rows_ && s8g_scale_ > 0.0f) return true;
+  }
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  const uint32_t n = n_rows_;
+  if (!n) return false;
+  s8g_built_ = std::min(s8g_built_, n);
+  s8g_seen_ = std::min(s8g_seen_, n);
+  uint32_t st[4] = {0, 0, 0, 0};
+  if (s8g_seen_ < n) {  // the largest |x_i| of the rows not looked at yet
+    launch_absmax_f16_rows(d_rows_, stride_, (uint32_t)dim, s8g_seen_, n, d_s8g_stats_, wstream_);
+    s8g_seen_ = n;
+  }
+  HIP_CHECK(hipMemcpyAsync(st, d_s8g_stats_, sizeof st, hipMemcpyDeviceToHost, wstream_));
+  HIP_CHECK(hipStreamSynchronize(wstream_));
+  float gmax;
+  memcpy(&gmax, &st[0], 4);
+  if (st[3] || !(gmax <= 65504.0f)) {  // inf / NaN element: no scale bounds such an index
+    s_bad_ = true;
+    return false;
+  }
+  const float want = gmax > 0.0f ? gmax / 127.0f : 1.0f;
+  if (!(s8g_scale_ > 0.0f) || want > s8g_scale_) {  // first build, or a row outgrew the scale: every row again
+    s8g_scale_ = want;
+    s8g_built_ = 0;
+    const uint32_t zero2[2] = {0, 0};  // the error maxima belong to the scale
+    HIP_CHECK(hipMemcpyAsync(d_s8g_stats_ + 1, zero2, sizeof zero2, hipMemcpyHostToDevice, wstream_));
+  }
+  if (s8g_built_ < n) {
+    launch_shadow8g_f16_rows(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, s8g_scale_, d_shadow_, sstride_, d_s8g_stats_, wstream_);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(wstream_));
+    s8g_built_ = n;
+  }
+  return true;
 }
 
 void FlatIndex::flush_if_needed() {
@@ -497,7 +548,8 @@ int FlatIndex::remove(size_t label) {
       HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)r * stride_, d_rows_ + (size_t)last * stride_, stride_,
                                hipMemcpyDeviceToDevice, wstream_));
       HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
-      if (shadow_)
+      if (shadow_ == 3) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
+      else if (shadow_)
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
                                  hipMemcpyDeviceToDevice, wstream_));
       if (shadow_ == 2)
@@ -962,7 +1014,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   upload_query(c.c, query, true);
   std::vector<Hit> hits;
   // fp16 shadow: error-bounded filter + exact fp32 re-scoring of the survivors; falls back to the full scan
-  const bool two_stage = shadow_ && scan_tuning().two_stage && k <= 1024 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
+  const bool two_stage = (shadow_ == 1 || shadow_ == 2) && scan_tuning().two_stage && k <= 1024 && n >= (1u << 18) && two_stage_topk(c.c, n, (uint32_t)std::min<size_t>(k, n), hits);
   if (!two_stage) scan_all(c.c, n);
   std::vector<VecSimQueryResult> res;
   if (!multi) {

@@ -217,6 +217,13 @@ class FlatIndex {
   float s_max_ = 0.0f, n2_max_ = 0.0f;  // their host copies, refreshed by the writers
   bool s_bad_ = false;                  // a row holds inf / NaN: the shadow bounds nothing, queries take the fp32 scan
   void shadow_convert(uint32_t row_begin, uint32_t row_end);  // on wstream_
+  // shadow_ == 3: int8 rows with ONE index-wide scale, for the batched int8 MFMA pass over FLOAT16 (IP / cosine) indexes
+  // created with ScanTuning::shadow8 (batch_query.cpp).  Built lazily -- and incrementally -- by the first batched query
+  // that finds rows it does not cover; a row that outgrows the scale, or a delete below the built prefix, re-quantises.
+  uint32_t *d_s8g_stats_ = nullptr;  // {max |x_i| (f32 bits), max |x8|^2, max |ex|^2 (f32 bits), non-finite flag}
+  float s8g_scale_ = 0.0f;           // the scale the built rows were quantised with (0: nothing built)
+  uint32_t s8g_built_ = 0, s8g_seen_ = 0;  // rows [0, built) are quantised; rows [0, seen) went into max |x_i|
+  bool ensure_shadow8g();            // true: d_shadow_ covers every row and bounds them
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
   // rows (and their shadow) grow without copies once they are large: virtual range + mapped chunks (grow_buffer.hpp);
   // d_rows_ / d_shadow_ cache the buffers' current base addresses

@@ -332,6 +332,7 @@ struct BatchSel {
   uint32_t n_valid;    // queries >= n_valid are padding: tau = -inf so that they never collect candidates
   uint32_t stride;     // PAIRS=false: element i is keys[q*ld + i*stride] (strided sample of a key array)
   float slack;         // added to the bound written to tau_out (error band of a low-precision filter pass)
+  const float *slack_q;  // per-query band (overrides slack)
 };
 
 template <bool PAIRS>
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
       if (!PAIRS) s.tau_out[q] = __uint_as_float(0x7f800000u);
     } else {
       uint32_t u = (kk & 0x80000000u) ? (kk ^ 0x80000000u) : ~kk;
-      s.tau_out[q] = __uint_as_float(u) + s.slack;
+      s.tau_out[q] = __uint_as_float(u) + (s.slack_q ? s.slack_q[q] : s.slack);
     }
   }
   if (s.out_rows) {
@@ -482,8 +483,9 @@ void launch_gemm_topk(int dtype, const void *rows, const void *queries, uint32_t
 }
 
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
-                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride, float slack) {
-  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid, stride, slack};
+                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride, float slack,
+                            const float *slack_q) {
+  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid, stride, slack, slack_q};
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
@@ -491,22 +493,22 @@ void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint3
 // old tau, so the new one can only be smaller; a query with fewer than k candidates keeps its bound)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
-                                 hipStream_t s, float slack) {
+                                 hipStream_t s, float slack, const float *slack_q) {
   BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, tau_inout, nullptr, nullptr, nullptr, 0, overflow,
-             n_valid, 1, slack};
+             n_valid, 1, slack, slack_q};
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s) {
-  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries, 1, 0.0f};
+  BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries, 1, 0.0f, nullptr};
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                               uint32_t n_queries, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n,
                               uint32_t k_ld, uint32_t *overflow, hipStream_t s) {
-  BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries, 1, 0.0f};
+  BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries, 1, 0.0f, nullptr};
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 

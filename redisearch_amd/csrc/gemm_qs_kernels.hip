@@ -38,6 +38,18 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// accumulator of the pass: fp32 for the half types, exact 32-bit integers for the int8 shadow (KT_I8)
+template <int DT>
+struct AccT {
+  typedef f32x16 t;
+};
+template <>
+struct AccT<KT_I8> {
+  typedef i32x16 t;
+};
 
 __device__ __forceinline__ uint32_t f2key(float f) {
   uint32_t u = __float_as_uint(f);
@@ -46,12 +58,17 @@ __device__ __forceinline__ uint32_t f2key(float f) {
 }
 
 template <int DT>
-__device__ __forceinline__ f32x16 mfma(u4 a, u4 b, f32x16 c) {
-  if (DT == KT_F16) {
+__device__ __forceinline__ typename AccT<DT>::t mfma(u4 a, u4 b, typename AccT<DT>::t c) {
+  if constexpr (DT == KT_F16) {
     half8 x, y;
     __builtin_memcpy(&x, &a, 16);
     __builtin_memcpy(&y, &b, 16);
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+  } else if constexpr (DT == KT_I8) {  // 32 int8 of K per instruction: the same 16 bytes per lane, twice the rate
+    i32x4 x, y;
+    __builtin_memcpy(&x, &a, 16);
+    __builtin_memcpy(&y, &b, 16);
+    return __builtin_amdgcn_mfma_i32_32x32x32_i8(x, y, c, 0, 0, 0);
   } else {
     bf16x8 x, y;
     __builtin_memcpy(&x, &a, 16);
@@ -68,6 +85,7 @@ struct QsArgs {
   uint32_t *sub_count;  // [gridDim.x][256][2]
   uint2 *sub_cand;      // [gridDim.x][256][2][sub_cap] (row, distance bits): one list per (workgroup, query, lane half)
   uint32_t sub_cap;
+  const float *qscale;  // KT_I8: [256] distance = 1 - qscale[q] * (integer dot); row scale x query scale
 };
 
 // same for a wave-uniform value: pinned to an SGPR (otherwise kernel arguments and gridDim are re-loaded with
@@ -94,6 +112,12 @@ __device__ __forceinline__ uint32_t opaque(uint32_t v) {
 __device__ __forceinline__ float max3(float a, float b, float c) {
   float m;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+  return m;
+}
+
+__device__ __forceinline__ int max3i(int a, int b, int c) {
+  int m;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
   return m;
 }
 
@@ -158,6 +182,8 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     }
   // distance d = 1 - s <= tau, tested first on s with a margin that covers the rounding of both subtractions
   float tau[QB], thr[QB];
+  float qsc[QB];   // KT_I8 only
+  int ithr[QB];    // KT_I8 only: the same test on the integer dot product
   uint32_t cur[QB];
 #pragma unroll
   for (int nb = 0; nb < QB; nb++) {
@@ -165,6 +191,16 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     tau[nb] = g.tau[32 * QB * w + 32 * nb + r];
     const float u = 1.0f - tau[nb];
     thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : u - (fabsf(tau[nb]) + fabsf(u)) * 2.4e-7f;
+    qsc[nb] = 1.0f;
+    ithr[nb] = 0x7fffffff;
+    if constexpr (DT == KT_I8) {
+      qsc[nb] = g.qscale[32 * QB * w + 32 * nb + r];
+      // 1 - qsc * acc <= tau  <=>  acc >= (1 - tau) / qsc; taken one unit (and the float roundings) lower: the exact
+      // test on the distance follows for the lanes that pass
+      const float lim = thr[nb] / qsc[nb] - 1.0f - fabsf(thr[nb] / qsc[nb]) * 2.4e-7f;
+      ithr[nb] = !(qsc[nb] > 0.0f) || thr[nb] == __builtin_inff() || lim >= 2147483520.0f ? 0x7fffffff
+                 : (lim <= -2147483520.0f ? (int)0x80000000 : (int)floorf(lim));
+    }
   }
 
   const uint32_t n = g.row_end - g.row_begin;
@@ -236,11 +272,11 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     // chunk (2ks+h)^x = 16(ks>>3) + (2(ks&7) ^ (h^x)): one v_xad_u32 per read, nothing held in registers
     const uint32_t t16 = 16u * ((lr >> 5) ^ (lr & 15u));
     auto frag_addr = [&](int ks) { return tbase + ((32u * (uint32_t)(ks & 7)) ^ t16); };
-    f32x16 acc[QB];
+    typename AccT<DT>::t acc[QB];
 #pragma unroll
     for (int e = 0; e < 16; e++)
 #pragma unroll
-      for (int nb = 0; nb < QB; nb++) acc[nb][e] = 0.0f;
+      for (int nb = 0; nb < QB; nb++) acc[nb][e] = 0;
     // Software pipeline, PF fragments ahead: with one wave per SIMD nothing else hides the LDS latency.
     // The reads and their counted waits are inline asm (hipcc waits lgkmcnt(0) before every use once LDS
     // DMAs are pending, and would drain vmcnt for an LDS load it can see); sched_barrier pins the order.
@@ -264,23 +300,48 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     const uint32_t xr0 = row_first + i * row_step + 4 * (lr >> 5);
 #pragma unroll
     for (int nb = 0; nb < QB; nb++) {
-      float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+      if constexpr (DT == KT_I8) {
+        int m = max3i(acc[nb][0], acc[nb][1], acc[nb][2]);
 #pragma unroll
-      for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
-      m = max3(m, acc[nb][15], acc[nb][15]);
-      if (m >= thr[nb]) {  // rare: a few hits per tile over the whole wave
-        uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+        for (int e = 3; e < 15; e += 2) m = max3i(m, acc[nb][e], acc[nb][e + 1]);
+        m = max3i(m, acc[nb][15], acc[nb][15]);
+        if (m >= ithr[nb]) {  // a few lanes per tile (the int8 band is wide: ~20 % of a wavefront's tiles at K = 100)
+          uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
 #pragma unroll
-        for (int eg = 0; eg < 4; eg++) {
-          const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
-          if (gm >= thr[nb]) {
+          for (int eg = 0; eg < 4; eg++) {
+            const int gm = max3i(max3i(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+            if (gm >= ithr[nb]) {
 #pragma unroll
-            for (int el = 0; el < 4; el++) {
-              const float d = 1.0f - acc[nb][4 * eg + el];
-              const uint32_t xr = xr0 + 8 * eg + el;
-              if (d <= tau[nb] && xr < row_end) {
-                if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
-                cur[nb]++;
+              for (int el = 0; el < 4; el++) {
+                const float d = 1.0f - qsc[nb] * (float)acc[nb][4 * eg + el];
+                const uint32_t xr = xr0 + 8 * eg + el;
+                if (acc[nb][4 * eg + el] >= ithr[nb] && d <= tau[nb] && xr < row_end) {
+                  if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                  cur[nb]++;
+                }
+              }
+            }
+          }
+        }
+      } else {
+        float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
+        m = max3(m, acc[nb][15], acc[nb][15]);
+        if (m >= thr[nb]) {  // rare: a few hits per tile over the whole wave
+          uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+#pragma unroll
+          for (int eg = 0; eg < 4; eg++) {
+            const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+            if (gm >= thr[nb]) {
+#pragma unroll
+              for (int el = 0; el < 4; el++) {
+                const float d = 1.0f - acc[nb][4 * eg + el];
+                const uint32_t xr = xr0 + 8 * eg + el;
+                if (d <= tau[nb] && xr < row_end) {
+                  if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                  cur[nb]++;
+                }
               }
             }
           }
@@ -348,7 +409,13 @@ void launch_qs_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
 template <int DT>
 bool launch_qs_dt(const QsArgs &g, uint32_t stride16, uint32_t grid, hipStream_t s) {
   switch (stride16) {  // chunks per row = 2 * KS; the ring is as deep as ~144 KiB of LDS allows
-    case 96: launch_qs_shape<DT, 48, 3>(g, grid, s); return true;
+    case 96:
+      // (int8 rows of 1536 bytes are not offered: untested shape)
+      if constexpr (DT == KT_I8) return false;
+      else {
+        launch_qs_shape<DT, 48, 3>(g, grid, s);
+        return true;
+      }
     case 64: launch_qs_shape<DT, 32, 4>(g, grid, s); return true;
     case 48: launch_qs_shape<DT, 24, 6>(g, grid, s); return true;
     case 32: launch_qs_shape<DT, 16, 8>(g, grid, s); return true;
@@ -371,10 +438,14 @@ uint32_t gemm_qs_grid(uint32_t n_rows) {
 
 bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                     uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
-                    hipStream_t s) {
+                    hipStream_t s, const float *qscale) {
   if (row_end <= row_begin || !gemm_qs_supported(stride16)) return false;
-  QsArgs g{(const u4 *)rows, (const u4 *)queries, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap};
+  QsArgs g{(const u4 *)rows, (const u4 *)queries, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, qscale};
   const uint32_t grid = gemm_qs_grid(row_end - row_begin);
+  if (dtype == KT_I8 || scan_tuning().qs_force_i8) {  // (qs_force_i8: timing experiment over bytes that are not int8 data)
+    if (!g.qscale) g.qscale = tau;
+    return launch_qs_dt<KT_I8>(g, stride16, grid, s);
+  }
   return dtype == KT_F16 ? launch_qs_dt<KT_F16>(g, stride16, grid, s) : launch_qs_dt<KT_BF16>(g, stride16, grid, s);
 }
 

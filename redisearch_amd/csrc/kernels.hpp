@@ -61,6 +61,8 @@ struct ScanTuning {
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
+  int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
+  int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
                            // (no copy, no transient 2x HBM); 0 = hipMalloc + copy on every growth
   int vmm_chunk_mib = 0;        // 0 = automatic (256 MiB, or 1 GiB for corpora reserved large); A/B knob
@@ -110,7 +112,17 @@ void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t
 // Only row shapes the scan runs without chunk masking (stride/16 == G*ITERS, e.g. dim 128/256/384/512/768/1024 fp32).
 bool batch_rescore_supported(uint32_t stride16);
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
-                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s);
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
+                          int type = KT_F32);  // KT_F16: fp16 rows / queries, the fp16 scan's arithmetic
+// int8 shadow of FLOAT16 rows with ONE index-wide scale (the batched int8 MFMA pass, scan_kernels.hip "int8 shadow with
+// ONE index-wide scale"): stats = {max |x_i| (f32 bits), max |x8|^2 (u32), max |ex|^2 (f32 bits), non-finite flag}
+void launch_absmax_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint32_t *stats,
+                            hipStream_t s);
+void launch_shadow8g_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float scale,
+                              void *shadow, size_t sstride, uint32_t *stats, hipStream_t s);
+// queries (fp16) -> int8 rows q8 + qscale[q] = scale * sq + slack[q] = twice the error band of query q
+void launch_quantize_queries_f16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
+                                 const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s);
 // rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
 void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
 // cand[i].y = orderable key of dists[i]
@@ -152,7 +164,7 @@ bool gemm_qs_supported(uint32_t stride16);
 uint32_t gemm_qs_grid(uint32_t n_rows);
 bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                     uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
-                    hipStream_t s);
+                    hipStream_t s, const float *qscale = nullptr);
 // append != 0: the sub-lists are appended behind the cand_count[q] candidates already there
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
                          uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s);
@@ -160,7 +172,8 @@ void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32
 // (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
 // (slack is added to every finite bound written: the two-stage scan's error band)
 void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
-                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1, float slack = 0.0f);
+                            uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride = 1, float slack = 0.0f,
+                            const float *slack_q = nullptr);  // slack_q: per-query band (device), overrides slack
 // tau_out[0] = upper bound of the k-th smallest key (k <= 1024) of keys[0..n): k-th smallest of the minima
 // of 1024 groups of `per` sampled keys (per % 4 == 0, n >= 1024*per); also zeroes zero4[0..3] if given
 void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
@@ -173,7 +186,7 @@ void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void
 // per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
-                                 hipStream_t s, float slack = 0.0f);
+                                 hipStream_t s, float slack = 0.0f, const float *slack_q = nullptr);
 // per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);

@@ -698,12 +698,130 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restri
   }
 }
 
+// ---- int8 shadow with ONE index-wide scale, for the batched pass over FLOAT16 indexes (gemm_qs_kernels.hip, KT_I8) ------
+// x = s (x8 + ex), q = sq (q8 + eq): the integer dot product s sq (x8 . q8) misses x . q by
+//   s sq (x8 . eq + q8 . ex + ex . eq)  <=  s sq (|x8| |eq| + |q8| |ex| + |ex| |eq|)            (Cauchy-Schwarz)
+// with the ACTUAL error norms: |eq|, |q8| are the query's own, |x8|, |ex| are bounded by their maxima over the index
+// (stats[1], stats[2], atomicMax while the rows are quantised).  One scale for every row keeps the filter an integer
+// compare per query.  stats: [0] max |x_i| (f32 bits), [1] max |x8|^2 (u32), [2] max |ex|^2 (f32 bits), [3] non-finite flag.
+__global__ __launch_bounds__(256) void absmax_f16_rows_kernel(const _Float16 *__restrict__ rows, uint32_t stride_h, uint32_t dim,
+                                                              uint32_t row_begin, uint32_t row_end,
+                                                              uint32_t *__restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float m = 0.0f;
+  bool bad = false;
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
+    const _Float16 *src = rows + (size_t)r * stride_h;
+    for (uint32_t i = lane; i < dim; i += 64) {
+      const float v = fabsf((float)src[i]);
+      bad |= !(v <= 65504.0f);
+      m = fmaxf(m, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) atomicMax(stats, __float_as_uint(m));
+  if (bad) stats[3] = 1;
+}
+
+__global__ __launch_bounds__(256) void shadow8g_f16_rows_kernel(const _Float16 *__restrict__ rows, uint32_t stride_h, uint32_t dim,
+                                                                uint32_t row_begin, uint32_t row_end, float scale,
+                                                                int8_t *__restrict__ shadow, uint32_t sstride,
+                                                                uint32_t *__restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv = 1.0f / scale;
+  uint32_t n8_max = 0;
+  float ne_max = 0.0f;
+  // eight elements per lane and step: one 16-byte load, one 8-byte store (rows are zero padded to whole 16-byte chunks)
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
+    const u4 *src = reinterpret_cast<const u4 *>(rows + (size_t)r * stride_h);
+    uint2 *dst = reinterpret_cast<uint2 *>(shadow + (size_t)r * sstride);
+    uint32_t n8 = 0;
+    float ne = 0.0f;
+    for (uint32_t c = lane; c < sstride / 8; c += 64) {
+      const u4 x = 8 * c < stride_h ? src[c] : zero4();
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+      uint32_t o[2] = {0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const half2_t h = as_h2(w[j >> 1]);
+        const float xf = (8 * c + j < dim) ? (float)((j & 1) ? h.y : h.x) : 0.0f;
+        const float t = xf * inv;
+        const float v = fminf(fmaxf(rintf(t), -127.0f), 127.0f);
+        const float e = t - v;
+        const int vi = (int)v;
+        o[j >> 2] |= ((uint32_t)vi & 0xffu) << (8 * (j & 3));
+        n8 += (uint32_t)(vi * vi);
+        ne = fmaf(e, e, ne);
+      }
+      dst[c] = make_uint2(o[0], o[1]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      n8 += __shfl_xor(n8, o, 64);
+      ne += __shfl_xor(ne, o, 64);
+    }
+    n8_max = n8 > n8_max ? n8 : n8_max;
+    ne_max = fmaxf(ne_max, ne);
+  }
+  if (lane == 0) {
+    atomicMax(stats + 1, n8_max);
+    atomicMax(stats + 2, __float_as_uint(ne_max));
+  }
+}
+
+// The 256 queries of a pass (fp16, already normalised for cosine) -> int8 with their own scales; qscale[q] = s sq
+// (distance = 1 - qscale * integer dot) and slack[q] >= 2 E_q, E_q >= |shadow distance - fp32 distance of the fp16 row|:
+// the Cauchy-Schwarz band above (x 1.001 for the fp32 arithmetic that computes it) plus the rounding of both distance
+// computations, dim 2^-24 |x||q| for the fp32 accumulation of the exact row and a few ulps of the shadow's.
+__global__ __launch_bounds__(64) void quantize_queries_f16_kernel(const _Float16 *__restrict__ queries, uint32_t qstride_h,
+                                                                  uint32_t dim, float scale, const uint32_t *__restrict__ stats,
+                                                                  int8_t *__restrict__ q8, uint32_t sstride,
+                                                                  float *__restrict__ qscale, float *__restrict__ slack) {
+  const uint32_t q = blockIdx.x, lane = threadIdx.x;
+  const _Float16 *src = queries + (size_t)q * qstride_h;
+  float m = 0.0f;
+  for (uint32_t i = lane; i < dim; i += 64) m = fmaxf(m, fabsf((float)src[i]));
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const bool finite = m <= 65504.0f;
+  const float sq = (m > 0.0f && finite) ? m / 127.0f : 1.0f, inv = 1.0f / sq;
+  uint32_t n8 = 0;
+  float ne = 0.0f;
+  for (uint32_t i = lane; i < sstride; i += 64) {
+    float t = (i < dim && finite) ? (float)src[i] * inv : 0.0f;
+    float v = fminf(fmaxf(rintf(t), -127.0f), 127.0f);
+    const float e = t - v;
+    q8[(size_t)q * sstride + i] = (int8_t)v;
+    n8 += (uint32_t)((int)v * (int)v);
+    ne = fmaf(e, e, ne);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    n8 += __shfl_xor(n8, o, 64);
+    ne += __shfl_xor(ne, o, 64);
+  }
+  if (lane == 0) {
+    const float X8 = sqrtf((float)stats[1]) * 1.0001f, EX = sqrtf(__uint_as_float(stats[2])) * 1.0001f + 1e-3f;
+    const float Q8 = sqrtf((float)n8) * 1.0001f, EQ = sqrtf(ne) * 1.0001f + 1e-3f;
+    const float ss = scale * sq;
+    const float band = ss * (X8 * EQ + Q8 * EX + EX * EQ) * 1.001f;
+    const float xq = ss * (X8 + EX) * (Q8 + EQ);  // >= |x| |q| >= |x . q|
+    const float round = ((float)dim * 6.0e-8f + 6.0e-7f) * (xq + 1.0f);
+    qscale[q] = ss;
+    // a query with a non-finite element: an infinite band keeps every row (the exact re-scoring decides)
+    // (2 band + 2 round for the shadow-derived bounds; the sample's bound comes from exact rows through the MFMA
+    // summation order -- one band and three roundings away -- so four roundings cover both even when the band is 0)
+    slack[q] = finite ? 2.0f * band + 4.0f * round : __builtin_inff();
+  }
+}
+
 // Batched two-stage scan: the candidates (row, shadow key) of every query are re-scored from the fp32 rows with the
 // arithmetic of scan_kernel<KT_F32, KM_IP, G, ITERS> (same chunk-to-lane map, same fmaf order, same xor-shuffle
 // reduction), so the keys written here are bit-identical to the ones the single-query scan computes for these rows.
 // grid = (slices, queries); a group of G lanes per candidate.  Lists that overflowed (count > cap) are skipped: the
 // select flags them and the host redoes the query on the single-query path.
-template <int G, int ITERS>
+template <int TYPE, int G, int ITERS>
 __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t n_rows,
                                                             const u4 *__restrict__ queries, uint32_t qstride16,
                                                             uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
@@ -732,8 +850,8 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict
     for (int i = 0; i < ITERS; i++) x[i] = load16<false>(p + lane + i * G);
     float acc = 0.0f;
 #pragma unroll
-    for (int i = 0; i < ITERS; i++) acc = Op<KT_F32, KM_IP>::add(acc, x[i], qv[i]);
-    const float d = finish<KT_F32, KM_IP>(group_reduce<G>(acc), zero4());
+    for (int i = 0; i < ITERS; i++) acc = Op<TYPE, KM_IP>::add(acc, x[i], qv[i]);
+    const float d = finish<TYPE, KM_IP>(group_reduce<G>(acc), zero4());
     if (lane == 0) list[j].y = to_key(d);
   }
 }
@@ -763,15 +881,24 @@ bool batch_rescore_supported(uint32_t stride16) {
 }
 
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
-                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s) {
+                          const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
+                          int type) {
   const uint32_t s16 = (uint32_t)(stride / 16);
-  if (!batch_rescore_supported(s16) || !n_queries) return false;
+  if (!batch_rescore_supported(s16) || !n_queries || (type != KT_F32 && type != KT_F16)) return false;
   const Shape sh = pick_shape(s16);
   if ((uint32_t)(sh.G * sh.ITERS) != s16) return false;  // exact shapes only (no chunk masking here)
-  const dim3 grid(16, n_queries), block(256);
-#define RSGPU_RESCORE(GG, II)                                                                                      \
-  hipLaunchKernelGGL((batch_rescore_kernel<GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows, (const u4 *)queries, \
-                     (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau)
+  // (64 slices per query: a slice walks its share of the list with one dependent load per candidate, most of which it
+  // skips -- the int8 band leaves ~10 k collected candidates per query of which a few hundred are inside the final band)
+  const dim3 grid(64, n_queries), block(256);
+#define RSGPU_RESCORE(GG, II)                                                                                              \
+  do {                                                                                                                     \
+    if (type == KT_F16)                                                                                                    \
+      hipLaunchKernelGGL((batch_rescore_kernel<KT_F16, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
+                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((batch_rescore_kernel<KT_F32, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
+                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
+  } while (0)
   if (sh.G == 32) {
     if (sh.ITERS == 1) RSGPU_RESCORE(32, 1);
     else RSGPU_RESCORE(32, 3);
@@ -785,6 +912,27 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
   }
 #undef RSGPU_RESCORE
   return true;
+}
+
+void launch_absmax_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint32_t *stats,
+                            hipStream_t s) {
+  if (row_end <= row_begin) return;
+  const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  hipLaunchKernelGGL(absmax_f16_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const _Float16 *)rows,
+                     (uint32_t)(stride / 2), dim, row_begin, row_end, stats);
+}
+void launch_shadow8g_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float scale,
+                              void *shadow, size_t sstride, uint32_t *stats, hipStream_t s) {
+  if (row_end <= row_begin) return;
+  const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  hipLaunchKernelGGL(shadow8g_f16_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const _Float16 *)rows,
+                     (uint32_t)(stride / 2), dim, row_begin, row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
+}
+void launch_quantize_queries_f16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
+                                 const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s) {
+  if (!n_queries) return;
+  hipLaunchKernelGGL(quantize_queries_f16_kernel, dim3(n_queries), dim3(64), 0, s, (const _Float16 *)queries,
+                     (uint32_t)(qstride / 2), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
 }
 
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,

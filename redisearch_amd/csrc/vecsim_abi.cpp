@@ -653,6 +653,8 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_dma")) scan_tuning().gemm_dma = value;
   else if (!strcmp(key, "filter_select")) scan_tuning().filter_select = value;
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
+  else if (!strcmp(key, "qs_phases")) scan_tuning().qs_phases = value;
+  else if (!strcmp(key, "qs_force_i8")) scan_tuning().qs_force_i8 = value;
   else if (!strcmp(key, "shards")) scan_tuning().shards = value;
   else if (!strcmp(key, "shard_replicas")) scan_tuning().shard_replicas = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;

@@ -255,3 +255,42 @@ def test_batched_config3_full_size_against_the_oracle():
         god = dict(zip(ids[qi].tolist(), sc[qi].tolist()))
         ood = dict(zip(oi.tolist(), os_.tolist()))
         assert max(abs(god[x] - ood[x]) for x in common) <= tol
+
+
+def test_batched_config3_int8_shadow_full_size():
+    """BASELINE configs[2] through the opt-in int8 shadow (one index-wide scale, int8 MFMA filter passes, fp16 re-scoring):
+    at 10M x 768 the 256 replies must be BIT-IDENTICAL to single queries on the same fp16 index -- 16 of them are compared
+    id for id and distance for distance -- planted rows lead their query's list, and the passes must have read the int8
+    shadow (one byte per element)."""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2 ** 30:
+        pytest.skip("needs an MI355X-class device")
+    rows, dim, k, nq = 10_000_000, 768, 100, 256
+    lib = V.load()
+    queries = O.philox_rows(SEED, QUERY_BASE, nq, dim, O.F16)
+    lib.RSGPU_SetTuning(b"shadow8", 1)
+    try:
+        idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
+    finally:
+        lib.RSGPU_SetTuning(b"shadow8", 0)
+    idx.reserve(rows + 64)
+    assert idx.add_philox_rows(SEED, 0, rows, 1) == rows
+    lab, want = rows + 1, {}
+    for qi, scales in {7: [0.99, 0.97], 200: [0.98]}.items():          # (below 1: the index-wide scale stays put)
+        want[qi] = []
+        for sc_ in scales:
+            assert idx.add_vector((queries[qi].astype(np.float32) * sc_).astype(np.float16), lab) == 1
+            want[qi].append(lab)
+            lab += 1
+    lib.RSGPU_ResetProfile()
+    lib.RSGPU_SetProfiling(1)
+    ids, sc, cnt = idx.topk_batch(queries, k)
+    lib.RSGPU_SetProfiling(0)
+    launches, _, by = V.scan_profile()
+    assert launches == 1 and by == (rows + 3) * dim                      # one pass over the int8 shadow
+    assert (cnt == k).all() and np.all(np.diff(sc, axis=1) >= 0)
+    for qi, labs in want.items():
+        assert ids[qi, :len(labs)].tolist() == labs
+    for qi in list(range(0, 256, 17)) + [255]:
+        si, ss = idx.topk_query(queries[qi], k).results()
+        assert si.tolist() == ids[qi].tolist() and ss.tolist() == sc[qi].tolist(), qi
