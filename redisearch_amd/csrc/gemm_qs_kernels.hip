@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     // Software pipeline, PF fragments ahead: with one wave per SIMD nothing else hides the LDS latency.
     // The reads and their counted waits are inline asm (hipcc waits lgkmcnt(0) before every use once LDS
     // DMAs are pending, and would drain vmcnt for an LDS load it can see); sched_barrier pins the order.
-    constexpr int PF = QB == 1 ? 3 : 6;  // (PFV: deeper prefetch where registers allow -- the int8 variant)
+    constexpr int PF = QB == 1 ? 3 : 6;
     u4 xb[PF];
 #pragma unroll
     for (int ks = 0; ks < PF; ks++) xb[ks] = lds_read16(frag_addr(ks), ks >> 3);
