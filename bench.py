@@ -314,6 +314,7 @@ def extra_batched(lib, V, rows, dim):
         try:
             idx.free()
             lib.RSGPU_SetTuning(b"shadow8", 1)
+            lib.RSGPU_SetTuning(b"two_stage", 1)   # (query-time switch of every shadow; the headline loop keeps it off)
             idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
             lib.RSGPU_SetTuning(b"shadow8", 0)
             idx.reserve(rows)
@@ -342,6 +343,8 @@ def extra_batched(lib, V, rows, dim):
                   "note": "opt-in (+50 % HBM for an fp16 index); exact: Cauchy-Schwarz band from the actual quantisation-error norms"}
         except Exception as e:  # the extra must never take the headline down
             i8 = {"error": str(e)[:200]}
+        finally:
+            lib.RSGPU_SetTuning(b"two_stage", 0)
         return {"workload": "%dx%d fp16 FLAT IP top-%d, batch=%d queries per corpus pass (RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
                 "int8_shadow_extra": i8,
                 "device_ms_per_pass": dev_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": reps * batch / el,

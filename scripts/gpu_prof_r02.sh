@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$(pwd); mkdir -p gpurun_out
 timeout 600 python bench.py > gpurun_out/r02_bench_1gpu.json 2> gpurun_out/r02_bench_1gpu.err
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r02_prof_stats" -o b -- python "$R/bench.py" > "$R/gpurun_out/r02_prof_stats.log" 2>&1)
-tail -1 gpurun_out/r02_prof_stats.log | cut -c1-300 > gpurun_out/r02_bench_under_rocprof.json
+grep "^{\"metric\"" gpurun_out/r02_prof_stats.log | tail -1 > gpurun_out/r02_bench_under_rocprof.json
 f=$(find gpurun_out/r02_prof_stats -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/r02_bench_kernel_stats.csv; cut -c1-200 "$f" | head -30
 for grp in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$R/gpurun_out/r02_prof_$grp" -o b -- python "$R/bench.py" --steps 60 --warmup 5 --no-cpu-baseline --no-extras > "$R/gpurun_out/r02_prof_$grp.log" 2>&1)
