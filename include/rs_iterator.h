@@ -133,6 +133,12 @@ QueryIterator *RSGPU_NewNotIterator(RSGPU_Postings *child, RSGPU_Postings *unive
  * of the call that built the hits.  With own_hits the iterator frees the hit list. */
 QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_TermArg *terms, size_t num, double weight,
                                      bool own_hits);
+/* A two-level query tree behind one iterator (RSGPU_EvalTree, include/rsgpu_search.h): the root AND / OR over groups that
+ * are a term, or the OR / AND of several terms -- e.g. the stemmer's (run|running|ran) (shoe|shoes).  `terms[i]` belongs
+ * to q->lists[i] (q->lists itself is ignored: the posting lists are taken from `terms`).  `current` is the tree the
+ * reference's nested iterators build: Intersection{Union{Term..}, Term, ..} with the groups in iteration order and, under
+ * a union, only the children that matched the document. */
+QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const RSGPU_TermArg *terms, double weight);
 /* The hit list behind an iterator made here (score it in one batch with RSGPU_Hits_Score, re-rank with
  * RSGPU_Hits_KnnRerank, ...); NULL for foreign iterators. */
 RSGPU_Hits *RSGPU_Iterator_Hits(QueryIterator *it);

@@ -120,6 +120,11 @@ int RSGPU_Postings_Codec(const RSGPU_Postings *p); /* RSGPU_Codec of the list, -
 size_t RSGPU_Hits_NumLeaves(const RSGPU_Hits *h);
 int RSGPU_Hits_IsUnion(const RSGPU_Hits *h); /* 1: built by RSGPU_Union (a child may be absent from a hit) */
 int RSGPU_Hits_LeafOrder(const RSGPU_Hits *h, int *list_of_child);
+/* Shape of the result tree behind the hits: the root (union or intersection) has n_groups children, child g being leaf
+ * group_first[g] alone (group_op 0) or a union (1) / intersection (2) of the leaves [group_first[g], group_first[g+1])
+ * with weight group_weight[g]; leaves are the child slots of RSGPU_Hits_LeafOrder.  group_first has n_groups + 1
+ * entries.  Any output may be NULL.  Returns n_groups or -1. */
+int RSGPU_Hits_Tree(const RSGPU_Hits *h, int *root_is_union, int *group_first, int *group_op, double *group_weight);
 /* doc ids of hits [first, first+count) (clamped to the hit list); returns #written or -1. */
 long RSGPU_Hits_ReadRange(const RSGPU_Hits *h, size_t first, size_t count, uint64_t *doc_ids);
 /* For hits [first, first+count) and one list (index in the caller's array): the record the term's reader would have

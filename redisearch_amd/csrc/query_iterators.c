@@ -83,6 +83,7 @@ static int codec_has_mask(int c) {
 
 /* ---- the iterator ----------------------------------------------------------------------------------------------------- */
 enum { K_AND = 0, K_OR = 1, K_NOT = 2 };
+enum { G_TERM = 0, G_UNION = 1, G_INTERSECT = 2 }; /* RSGPU_OP_* of a root child */
 
 typedef struct {
   int list;                /* index of the child's list in the hit list's lists */
@@ -109,6 +110,11 @@ typedef struct {
   Child child[MAX_CHILDREN];
   size_t block, blk_first, blk_count;  /* records of hits [blk_first, blk_first + blk_count) are loaded */
   RSIndexResult *result;   /* the aggregate / virtual result `current` points at */
+  /* two-level trees (RSGPU_NewTreeIterator): the root's children are groups of consecutive child slots; a group that is
+   * a union / intersection has its own aggregate between the root and its term records */
+  int n_groups;            /* 0: flat (every child hangs off the root) */
+  int group_first[MAX_CHILDREN + 1], group_op[MAX_CHILDREN];
+  RSIndexResult *group_rec[MAX_CHILDREN];
 } GpuIt;
 
 static size_t it_num_estimated(const QueryIterator *self) { return ((const GpuIt *)self)->est; }
@@ -190,16 +196,31 @@ static void build_current(GpuIt *it, size_t i) {
     r->fieldMask = 0;
     g_api.IndexResult_AggregateReset(r);
     const size_t j = i - it->blk_first;
-    for (size_t c = 0; c < it->n_children; c++) {
-      Child *ch = &it->child[c];
-      if (ch->entry[j] == 0xFFFFFFFFu) continue; /* a union child that does not hold the document */
-      RSIndexResult *t = ch->rec;
-      t->docId = id;
-      t->freq = ch->has_freq ? ch->freq[j] : 1; /* RawTermResultBuilder::new: frequency 1 unless the codec decodes one */
-      t->fieldMask = ch->has_mask ? ((t_fieldMask)ch->mhi[j] << 64) | (t_fieldMask)ch->mlo[j] : RS_FIELDMASK_ALL; /* term.rs:95 */
-      const char *ob = ch->olen[j] ? (const char *)ch->obytes + (ch->opos[j] - ch->obase) : NULL;
-      g_api.RSOffsetVector_SetData(&t->data.term.offsets, ob, ch->olen[j]);
-      g_api.AggregateResult_AddChild(r, t);
+    const int ng = it->n_groups ? it->n_groups : (int)it->n_children;
+    for (int g = 0; g < ng; g++) {
+      const size_t c0 = it->n_groups ? (size_t)it->group_first[g] : (size_t)g;
+      const size_t c1 = it->n_groups ? (size_t)it->group_first[g + 1] : (size_t)g + 1;
+      RSIndexResult *parent = r;
+      if (it->n_groups && it->group_op[g] != G_TERM) { /* a nested Union / Intersection: rebuilt like the root */
+        parent = it->group_rec[g];
+        parent->freq = 0;
+        parent->fieldMask = 0;
+        g_api.IndexResult_AggregateReset(parent);
+      }
+      size_t added = 0;
+      for (size_t c = c0; c < c1; c++) {
+        Child *ch = &it->child[c];
+        if (ch->entry[j] == 0xFFFFFFFFu) continue; /* a union child (or a whole group) that does not hold the document */
+        RSIndexResult *t = ch->rec;
+        t->docId = id;
+        t->freq = ch->has_freq ? ch->freq[j] : 1; /* RawTermResultBuilder::new: frequency 1 unless the codec decodes one */
+        t->fieldMask = ch->has_mask ? ((t_fieldMask)ch->mhi[j] << 64) | (t_fieldMask)ch->mlo[j] : RS_FIELDMASK_ALL; /* term.rs:95 */
+        const char *ob = ch->olen[j] ? (const char *)ch->obytes + (ch->opos[j] - ch->obase) : NULL;
+        g_api.RSOffsetVector_SetData(&t->data.term.offsets, ob, ch->olen[j]);
+        g_api.AggregateResult_AddChild(parent, t);
+        added++;
+      }
+      if (parent != r && added) g_api.AggregateResult_AddChild(r, parent); /* takes the group's doc id, frequency, mask */
     }
     r->docId = id;
   }
@@ -272,6 +293,11 @@ static void it_free(QueryIterator *self) {
     if (it->kind != K_NOT) g_api.IndexResult_AggregateReset(it->result); /* the children were borrowed */
     g_api.IndexResult_Free(it->result);
   }
+  for (int g = 0; g < it->n_groups; g++)
+    if (it->group_rec[g]) {
+      g_api.IndexResult_AggregateReset(it->group_rec[g]);
+      g_api.IndexResult_Free(it->group_rec[g]);
+    }
   if (it->own_hits && it->hits) RSGPU_Hits_Free(it->hits);
   free(it->ids);
   free(it);
@@ -419,6 +445,58 @@ RSGPU_API QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_Ter
   const int is_union = RSGPU_Hits_IsUnion(hits);
   GpuIt *it = make(is_union ? K_OR : K_AND, hits, own_hits, terms, num, weight, is_union ? sum : mn);
   return it ? &it->base : NULL;
+}
+
+RSGPU_API QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const RSGPU_TermArg *terms, double weight) {
+  if (!q || !q->n_groups || !q->group_first || q->n_groups > MAX_CHILDREN) {
+    set_err("an empty tree", NULL);
+    return NULL;
+  }
+  const size_t num = q->group_first[q->n_groups];
+  if (check_terms(terms, num)) return NULL;
+  RSGPU_Postings *lists[MAX_CHILDREN];
+  for (size_t i = 0; i < num; i++) lists[i] = terms[i].postings;
+  RSGPU_TreeQuery tq = *q;
+  tq.lists = lists;
+  /* estimates as the reference's constructors compute them: a term its unique docs, a union the sum, an intersection
+   * the smallest child (union_flat.rs:102, intersection.rs:144-146) */
+  size_t est = q->root_op == RSGPU_OP_INTERSECT ? (size_t)-1 : 0;
+  for (size_t g = 0; g < q->n_groups; g++) {
+    const int op = q->group_op ? q->group_op[g] : RSGPU_OP_TERM;
+    size_t e = op == RSGPU_OP_INTERSECT ? (size_t)-1 : 0;
+    for (size_t l = q->group_first[g]; l < q->group_first[g + 1]; l++) {
+      const size_t n = RSGPU_Postings_NumEntries(lists[l]);
+      if (op == RSGPU_OP_INTERSECT) e = n < e ? n : e;
+      else e += n;
+    }
+    if (q->root_op == RSGPU_OP_INTERSECT) est = e < est ? e : est;
+    else est += e;
+  }
+  RSGPU_Hits *h = RSGPU_EvalTree(&tq);
+  if (!h) {
+    set_err("RSGPU_EvalTree", RSGPU_LastError());
+    return NULL;
+  }
+  int is_union = 0, gf[MAX_CHILDREN + 1], gop[MAX_CHILDREN];
+  double gw[MAX_CHILDREN];
+  const int ng = RSGPU_Hits_Tree(h, &is_union, gf, gop, gw);
+  GpuIt *it = ng > 0 ? make(is_union ? K_OR : K_AND, h, true, terms, num, weight, est) : NULL;
+  if (!it) {
+    RSGPU_Hits_Free(h);
+    return NULL;
+  }
+  /* make() hung every term off the root; re-root: the root holds one child per group */
+  g_api.IndexResult_AggregateReset(it->result);
+  g_api.IndexResult_Free(it->result);
+  it->result = is_union ? g_api.NewUnionResult((size_t)ng, weight) : g_api.NewIntersectResult((size_t)ng, weight);
+  it->n_groups = ng;
+  for (int g = 0; g <= ng; g++) it->group_first[g] = gf[g];
+  for (int g = 0; g < ng; g++) {
+    it->group_op[g] = gop[g];
+    const size_t n = (size_t)(gf[g + 1] - gf[g]);
+    it->group_rec[g] = gop[g] == G_UNION ? g_api.NewUnionResult(n, gw[g]) : gop[g] == G_INTERSECT ? g_api.NewIntersectResult(n, gw[g]) : NULL;
+  }
+  return &it->base;
 }
 
 RSGPU_API RSGPU_Hits *RSGPU_Iterator_Hits(QueryIterator *it) {

@@ -872,6 +872,18 @@ int RSGPU_Postings_Codec(const RSGPU_Postings *p) { return p ? p->codec : -1; }
 int RSGPU_Hits_IsUnion(const RSGPU_Hits *h) { return h && h->is_union ? 1 : 0; }
 size_t RSGPU_Hits_NumLeaves(const RSGPU_Hits *h) { return h ? (size_t)h->n_lists : 0; }
 
+int RSGPU_Hits_Tree(const RSGPU_Hits *h, int *root_is_union, int *group_first, int *group_op, double *group_weight) {
+  if (!h) return -1;
+  if (root_is_union) *root_is_union = h->is_union ? 1 : 0;
+  for (int g = 0; g < h->n_groups; g++) {
+    if (group_first) group_first[g] = h->group_first[g];
+    if (group_op) group_op[g] = h->group_op[g];
+    if (group_weight) group_weight[g] = h->group_weight[g];
+  }
+  if (group_first) group_first[h->n_groups] = h->group_first[h->n_groups];
+  return h->n_groups;
+}
+
 int RSGPU_Hits_LeafOrder(const RSGPU_Hits *h, int *list_of_child) {
   if (!h || !list_of_child) return -1;
   for (int s = 0; s < h->n_lists; s++) list_of_child[s] = h->order[s];
@@ -920,14 +932,14 @@ long RSGPU_Hits_ReadRecords(const RSGPU_Hits *hc, size_t list, size_t first, siz
   HIP_CHECK(hipGetLastError());
   std::vector<uint32_t> host(7 * count), hf;
   HIP_CHECK(hipMemcpyAsync(host.data(), out.p, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-  if (freqs) {
-    hf.resize(count);
-    HIP_CHECK(hipMemcpyAsync(hf.data(), h->freqs.p + (size_t)slot * h->cap + first, count * sizeof(uint32_t),
-                             hipMemcpyDeviceToHost, c->stream));
-  }
+  // (always: a hit's frequency column also says whether the leaf is part of the match -- 0 = a union child, or a
+  // nested group, that did not match this document; every record that matched carries a frequency >= 1)
+  hf.resize(count);
+  HIP_CHECK(hipMemcpyAsync(hf.data(), h->freqs.p + (size_t)slot * h->cap + first, count * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, c->stream));
   HIP_CHECK(hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < count; i++) {
-    const uint32_t e = host[i];
+    const uint32_t e = hf[i] == 0 ? 0xFFFFFFFFu : host[i];
     if (entry) entry[i] = e;
     if (freqs) freqs[i] = e == 0xFFFFFFFFu ? 0 : hf[i];
     if (mask_lo) mask_lo[i] = (uint64_t)host[count + i] | ((uint64_t)host[2 * count + i] << 32);

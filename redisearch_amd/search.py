@@ -403,6 +403,7 @@ def load_iterators(result_api_handle=None):
         L.RSGPU_NewNotIterator.restype, L.RSGPU_NewNotIterator.argtypes = _vp, [_vp, _vp, C.c_uint64, _dbl]
         L.RSGPU_NewHitsIterator.restype, L.RSGPU_NewHitsIterator.argtypes = _vp, [_vp, _vp, _sz, _dbl, C.c_bool]
         L.RSGPU_Iterator_Hits.restype, L.RSGPU_Iterator_Hits.argtypes = _vp, [_vp]
+        L.RSGPU_NewTreeIterator.restype, L.RSGPU_NewTreeIterator.argtypes = _vp, [C.POINTER(TreeQuery), _vp, _dbl]
         _itlib = L
     if result_api_handle is not None:
         if _itlib.RSGPU_Iterators_SetResultAPI(None, _vp(result_api_handle)) != 0:
@@ -434,4 +435,24 @@ def new_iterator(kind, lists, terms=None, weights=None, weight=1.0, max_slop=-1,
             it = L.RSGPU_NewUnionIterator(C.cast(arr, _vp), len(lists), weight)
     if not it:
         raise RuntimeError("iterator: " + L.RSGPU_Iterators_LastError().decode())
+    return it
+
+
+def new_tree_iterator(root_op, groups, terms=None, weights=None, weight=1.0, max_slop=None, in_order=False):
+    """-> QueryIterator* over a two-level tree; groups = [(op, group_weight, [Postings...]), ...] as for TreeHits;
+    terms / weights are per list in the flattened order of `groups`."""
+    L = load_iterators()
+    flat, first, ops, ws = [], [0], [], []
+    for op, w, ls in groups:
+        flat += list(ls)
+        first.append(len(flat))
+        ops.append(op)
+        ws.append(w)
+    gf, go, gw = np.asarray(first, np.uint64), np.asarray(ops, np.int32), np.asarray(ws, np.float64)
+    q = TreeQuery(root_op, len(groups), _p(gf).value, _p(go).value, _p(gw).value, None,
+                  -1 if max_slop is None else int(max_slop), int(in_order))
+    arr = term_args(flat, terms, weights)
+    it = L.RSGPU_NewTreeIterator(C.byref(q), C.cast(arr, _vp), weight)
+    if not it:
+        raise RuntimeError("tree iterator: " + L.RSGPU_Iterators_LastError().decode())
     return it

@@ -314,3 +314,68 @@ def test_results_scored_one_by_one_equal_the_batched_scorer(scorer):
             assert np.array_equal(sc, gsc) or scorer == "BM25STD.TANH"
     finally:
         X.iter_free(it)
+
+
+# ---- two-level trees: Intersection{Union{..}, Term, ..} behind one iterator ------------------------------------------------
+from tests.test_gpu_tree import I as OP_I, T as OP_T, U as OP_U, OracleTree, rand_list as tree_rand_list  # noqa: E402
+
+
+@pytest.mark.parametrize("name,root,shape,slop,in_order", [
+    ("and_of_ors", OP_I, [(OP_U, 1.0, [0, 1, 2]), (OP_U, 0.5, [3, 4])], None, False),          # (a|a'|a'') (b|b')
+    ("or_of_ands", OP_U, [(OP_I, 1.0, [0, 1]), (OP_I, 2.0, [2, 3])], None, False),              # (a b) | (c d)
+    ("term_and_or", OP_I, [(OP_T, 1.0, [0]), (OP_U, 1.0, [1, 2, 3]), (OP_T, 1.0, [4])], None, False),
+    ("or_of_term_and_and", OP_U, [(OP_T, 1.0, [0]), (OP_I, 0.7, [1, 2, 3])], None, False),      # a | (b c d)
+    ("phrase_over_a_union", OP_I, [(OP_T, 1.0, [0]), (OP_U, 1.0, [1, 2, 3]), (OP_T, 1.0, [4])], 3, True),
+])
+def test_tree_iterator_results_score_like_the_batched_tree_scorer(name, root, shape, slop, in_order):
+    """The iterator's `current` for a two-level tree, scored one by one by the reference's compiled scorers (which walk
+    the nested aggregates and ask IndexResult_MinOffsetDelta for the slop) == RSGPU_Hits_Score over the tree's hit list;
+    doc ids, the number of root children per document and the aggregate frequency follow the oracle's set algebra."""
+    rng = np.random.default_rng(abs(hash(name)) % 1000 + 17)
+    n_lists = sum(len(g[2]) for g in shape)
+    built = [tree_rand_list(rng, O.C_FULL, int(rng.integers(300, 1500)), 2500, True) for _ in range(n_lists)]
+    lists, recs = [b[0] for b in built], [b[1] for b in built]
+    sizes = [l.unique_docs for l in lists]
+    g = [gpu(l) for l in lists]
+    groups = [(op, w, [g[i] for i in idx]) for op, w, idx in shape]
+    ot = OracleTree(root, shape, recs, sizes, slop, in_order)
+    assert len(ot.docs) > 5
+    n_docs = 2500
+    doc_len = rng.integers(5, 200, n_docs + 1).astype(np.uint32)
+    doc_score = rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32)
+    max_freq = rng.integers(1, 40, n_docs + 1).astype(np.uint32)
+    idf = [S.calculate_idf(n_docs, s) for s in sizes]
+    bidf = [S.calculate_idf_bm25(n_docs, s) for s in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    avg = float(doc_len[1:].mean())
+    host = X.Host()
+    if not X.have_ref():
+        pytest.skip("needs oracle/_ref/libref_default_ext.so (the reference's scorers and IndexResult_MinOffsetDelta)")
+    host.load_ref()
+    S.load_iterators().RSGPU_Iterators_SetBlock(37)
+    h = S.TreeHits(root, groups, max_slop=slop, in_order=in_order)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    try:
+        for scorer in ("BM25STD", "TFIDF", "BM25", "DISMAX", "TFIDF.DOCNORM"):
+            terms = [X.new_term(idf[i], bidf[i], "t%d" % i) for i in range(n_lists)]
+            it = S.new_tree_iterator(root, groups, terms=terms, weights=w, weight=1.5, max_slop=slop, in_order=in_order)
+            try:
+                (est,) = X.iter_script(it, [(X.OP_ESTIMATE, 0)])
+                ge = [min(sizes[i] for i in idx) if op == OP_I else sum(sizes[i] for i in idx) for op, _, idx in shape]
+                assert est[0] == (min(ge) if root == OP_I else sum(ge))
+                ids, sc = X.iter_score_all(it, scorer, doc_len, doc_score, max_freq, len(ot.docs) + 8, num_docs=n_docs,
+                                           avg_doc_len=avg, slop=0)
+                assert ids.tolist() == ot.docs
+                gs = h.score(table, scorer, idf, bidf, w, n_docs, avg, root_weight=1.5)
+                assert np.array_equal(sc, gs), (scorer, np.max(np.abs(sc - gs)))
+                if scorer == "BM25STD":
+                    X.iter_script(it, [(X.OP_REWIND, 0)])
+                    d = X.iter_drain(it, len(ot.docs) + 8, len(shape))
+                    for j, doc in enumerate(ot.docs):
+                        matched = [gr for gr in ot.groups if doc in gr["docs"]]
+                        assert d["n_children"][j] == len(matched)
+                        assert d["freq"][j] == sum(recs[i][doc][0] for gr in matched for i in gr["idx"] if doc in recs[i])
+            finally:
+                X.iter_free(it)
+    finally:
+        S.load_iterators().RSGPU_Iterators_SetBlock(65536)
