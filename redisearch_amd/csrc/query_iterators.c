@@ -442,6 +442,13 @@ RSGPU_API QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_Ter
     if (n < mn) mn = n;
     sum += n;
   }
+  int gop[MAX_CHILDREN];
+  const int ng = RSGPU_Hits_Tree(hits, NULL, NULL, gop, NULL);
+  for (int g = 0; g < ng; g++)
+    if (gop[g] != G_TERM) { /* nested groups need the tree's shape and weights: RSGPU_NewTreeIterator builds those */
+      set_err("the hit list comes from a two-level tree", "use RSGPU_NewTreeIterator");
+      return NULL;
+    }
   const int is_union = RSGPU_Hits_IsUnion(hits);
   GpuIt *it = make(is_union ? K_OR : K_AND, hits, own_hits, terms, num, weight, is_union ? sum : mn);
   return it ? &it->base : NULL;
