@@ -59,7 +59,7 @@ struct BatchScratch {
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
   Dev<uint64_t> cand, sub_cand;
   Dev<uint32_t> sub_count;
-  Pinned hq, h_rows, h_keys, h_n, h_over;
+  Pinned hq, h_rows, h_keys, h_n, h_over, h_tau;
 };
 // two slots: the host builds the replies of batch b while the device works on batch b+1
 thread_local BatchScratch tls_batch[2];
@@ -74,14 +74,21 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   const bool via_shadow = type == VecSimType_FLOAT32 && shadow_ == 1 && metric == VecSimMetric_Cosine && !multi && k > 0 &&
                           k <= 1024 && dim <= 1024 && dim % 8 == 0 && scan_tuning().two_stage && scan_tuning().gemm_qs &&
                           gemm_qs_supported((uint32_t)(sstride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
-  const bool gemm_ok = via_shadow || ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) &&
-                                      metric != VecSimMetric_L2 && !multi && k > 0 && k <= 4096);
+  // int8 rows with one index-wide scale (FLOAT16 indexes: shadow_ == 3; FLOAT32 indexes created with shadow8: next to
+  // their per-row shadow): the filter passes of the batch run on the int8 matrix cores
+  const bool s8g_shape = s8g_enabled() && metric != VecSimMetric_L2 && !multi && k > 0 && k <= 1024 && scan_tuning().two_stage &&
+                         scan_tuning().gemm_qs && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) &&
+                         s8g_stride() / 16 <= 64 &&  // (int8 rows up to 1024 bytes)
+                         batch_rescore_supported((uint32_t)(stride_ / 16));
+  const bool gemm_ok = via_shadow || (s8g_shape && type == VecSimType_FLOAT32) ||
+                       ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi &&
+                        k > 0 && k <= 4096);
   // FLOAT16 IP / cosine indexes that carry the int8 shadow (shadow_ == 3): the filter passes run on the int8 matrix
   // cores over half the bytes, every threshold is widened by the query's own error band, the survivors are re-scored
   // from the fp16 rows with the single-query scan's arithmetic -> ids and distances bit-identical to single queries
-  bool via_shadow8 = gemm_ok && !via_shadow && shadow_ == 3 && k <= 1024 && scan_tuning().two_stage && scan_tuning().gemm_qs &&
-                     gemm_qs_supported((uint32_t)(sstride_ / 16)) && sstride_ / 16 <= 64 &&  // (int8 rows up to 1024 bytes)
-                     batch_rescore_supported((uint32_t)(stride_ / 16)) && ensure_shadow8g();
+  bool via_shadow8 = !via_shadow && s8g_shape && ensure_shadow8g();
+  // a FLOAT32 index has no MFMA form of its own: without the int8 rows (too small, a non-finite row, ...) -> single queries
+  const bool f32_needs_s8g = type == VecSimType_FLOAT32 && !via_shadow;
   const float slack = via_shadow ? 2.0f * 4e-3f : 0.0f;  // eps: FlatIndex::two_stage_topk
   auto single = [&](size_t qi) {
     VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
@@ -104,9 +111,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     const uint32_t n = n_rows_;
     // (rows added since ensure_shadow8g, or a corpus the single-query path serves anyway: the plain fp16 passes)
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
+    if (f32_needs_s8g && !via_shadow8) {
+      g.unlock();
+      for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+      return;
+    }
     // the corpus the MFMA passes read
     const int g_type = via_shadow ? KT_F16 : (via_shadow8 ? KT_I8 : ktype);
-    const size_t g_stride = (via_shadow || via_shadow8) ? sstride_ : stride_;
+    const size_t g_stride = via_shadow ? sstride_ : (via_shadow8 ? s8g_stride() : stride_);
     if (!n) {
       for (size_t qi = 0; qi < n_queries; qi++) counts_out[qi] = 0;
       return;
@@ -125,7 +137,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
     }
     const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
-    const uint8_t *g_rows = (via_shadow || via_shadow8) ? d_shadow_ : d_rows_;
+    const uint8_t *g_rows = via_shadow ? d_shadow_ : (via_shadow8 ? s8g_rows() : d_rows_);
     const uint32_t stride16 = (uint32_t)(g_stride / 16);
     // sample prefix for the thresholds; small corpora take the all-keys path
     const bool small = n <= (1u << 19);
@@ -142,14 +154,19 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       for (size_t qi = 0; qi < n_queries; qi++) single(qi);
       return;
     }
+    // FLOAT32 rows have no tiled GEMM for the sample bound: the first int8 phase runs over n0 rows with tau = +inf -- every
+    // (row, query) pair becomes a candidate -- and the first bound is the K-th shadow distance among them + the band
+    const bool phase0 = via_shadow8 && type == VecSimType_FLOAT32;
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
+      if (phase0) n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 14, (uint32_t)round_up((size_t)kk * 16, 256)));
       // (the int8 filter's wider band makes the sample's loose bound expensive: one more, shorter first phase)
       if (n >= (1u << 23) && (scan_tuning().qs_phases == 4 || (via_shadow8 && scan_tuning().qs_phases == 0))) phase_end = {(n / 64) & ~31u, (n / 16) & ~31u, (n / 4) & ~31u, n};
       else if (n >= (1u << 23)) phase_end = {(n / 16) & ~31u, (n / 4) & ~31u, n};
       else if (n >= (1u << 21)) phase_end = {(n / 8) & ~31u, n};
       else phase_end = {n};
+      if (phase0) phase_end.insert(phase_end.begin(), n0 & ~31u);
     }
     uint64_t expect_total = 4ull * kk * ((n + n0 - 1) / n0);
     if (use_qs) {
@@ -161,12 +178,13 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         from = e;
       }
       expect_total *= via_shadow ? 18 : (via_shadow8 ? 48 : 6);  // (a shadow's error band multiplies the survivors)
+      if (phase0) expect_total += n0;
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
     for (int sl = 0; sl < n_slots; sl++) {
       BatchScratch &sc = tls_batch[sl];
       sc.queries.ensure((size_t)kBatch * stride_);
-      if (via_shadow || via_shadow8) sc.queries16.ensure((size_t)kBatch * sstride_);
+      if (via_shadow || via_shadow8) sc.queries16.ensure((size_t)kBatch * (via_shadow ? sstride_ : s8g_stride()));
       sc.tau.ensure(kBatch);
       if (via_shadow8) {
         sc.qscale.ensure(kBatch);
@@ -194,6 +212,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         qs_grid_max = std::max(qs_grid_max, grid);
         const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
         while (sub_cap < (via_shadow ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
+        if (phase0 && from == 0)  // every row of the first phase lands in a sub-list: 16 per lane and tile
+          while (sub_cap < 16u * (((e + 31) / 32 + grid - 1) / grid)) sub_cap *= 2;
         seen = std::max(seen, e);
         from = e;
       }
@@ -224,8 +244,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
       const float *slack_q = nullptr, *qscale = nullptr;
       if (via_shadow8) {  // int8 copies of the queries with their own scales + the per-query error band
-        launch_quantize_queries_f16(sc.queries.p, stride_, (uint32_t)dim, kBatch, s8g_scale_, d_s8g_stats_, sc.queries16.p, sstride_,
-                                    sc.qscale.p, sc.slack_q.p, c->stream);
+        launch_quantize_queries(ktype, sc.queries.p, stride_, (uint32_t)dim, kBatch, s8g_scale_, d_s8g_stats_, sc.queries16.p,
+                                s8g_stride(), sc.qscale.p, sc.slack_q.p, c->stream);
         g_queries = sc.queries16.p;
         slack_q = sc.slack_q.p;
         qscale = sc.qscale.p;
@@ -239,12 +259,18 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       } else {
         // the sample's bound: from the exact rows when the filter runs on the int8 shadow (the tiled GEMM has no int8 form;
         // an exact bound widened by the band is as good as a shadow bound widened by it)
-        if (via_shadow8)
-          launch_gemm_topk(ktype, d_rows_, sc.queries.p, (uint32_t)(stride_ / 16), 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr,
-                           0, c->stream);
-        else
-          launch_gemm_topk(g_type, g_rows, g_queries, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0, c->stream);
-        launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream, 1, slack, slack_q);
+        if (phase0) {  // tau = +inf for the queries of the batch, -inf for the padding
+          float *ht = sc.h_tau.ensure<float>(kBatch);  // (pinned, one per slot: free again once the slot's batch is finalized)
+          for (uint32_t i = 0; i < kBatch; i++) ht[i] = i < nb ? __builtin_inff() : -__builtin_inff();
+          HIP_CHECK(hipMemcpyAsync(sc.tau.p, ht, kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        } else {
+          if (via_shadow8)
+            launch_gemm_topk(ktype, d_rows_, sc.queries.p, (uint32_t)(stride_ / 16), 0, n0, 0, sc.keys.p, n0, nullptr, nullptr,
+                             nullptr, 0, c->stream);
+          else
+            launch_gemm_topk(g_type, g_rows, g_queries, stride16, 0, n0, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0, c->stream);
+          launch_batch_threshold(sc.keys.p, n0, n0, kk, kBatch, nb, sc.tau.p, c->stream, 1, slack, slack_q);
+        }
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
         if (use_qs) {
@@ -270,7 +296,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                       c->stream, slack, slack_q);
           launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                               sc.tau.p, c->stream, via_shadow8 ? KT_F16 : KT_F32);
+                               sc.tau.p, c->stream, via_shadow8 ? ktype : KT_F32);
         }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);

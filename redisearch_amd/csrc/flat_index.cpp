@@ -292,7 +292,7 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     HIP_CHECK(hipMalloc((void **)&d_smax_, 4 * sizeof(uint32_t)));
     HIP_CHECK(hipMemset(d_smax_, 0, 4 * sizeof(uint32_t)));
   }
-  if (shadow_ == 3) {
+  if (shadow_ == 3 || (shadow_ == 2 && metric != VecSimMetric_L2)) {  // (FLOAT16, or FLOAT32 next to its per-row shadow)
     HIP_CHECK(hipMalloc((void **)&d_s8g_stats_, 4 * sizeof(uint32_t)));
     HIP_CHECK(hipMemset(d_s8g_stats_, 0, 4 * sizeof(uint32_t)));
   }
@@ -313,12 +313,13 @@ FlatIndex::~FlatIndex() {
   if (d_sscale_) HIP_IGNORE(hipFree(d_sscale_));
   if (d_smax_) HIP_IGNORE(hipFree(d_smax_));
   if (d_s8g_stats_) HIP_IGNORE(hipFree(d_s8g_stats_));
+  if (d_s8g_f32_) HIP_IGNORE(hipFree(d_s8g_f32_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
   HIP_IGNORE(hipStreamDestroy(wstream_));
 }
 
 size_t FlatIndex::memory() const {
-  return rows_buf_.physical() + shadow_buf_.physical() + cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
+  return rows_buf_.physical() + shadow_buf_.physical() + s8g_f32_cap_rows_ * round_up(dim, 16) + cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
          host_bytes_ + stage_cap_ * stride_;
 }
 
@@ -442,7 +443,7 @@ void FlatIndex::rows_of(size_t label, std::vector<uint32_t> &out) const {
 
 // int8 shadow with one index-wide scale (shadow_ == 3), brought up to date with the rows: see flat_index.hpp.
 bool FlatIndex::ensure_shadow8g() {
-  if (shadow_ != 3) return false;
+  if (!s8g_enabled()) return false;
   flush_if_needed();
   {
     std::shared_lock<std::shared_mutex> g(mu);
@@ -455,16 +456,25 @@ bool FlatIndex::ensure_shadow8g() {
   if (!n) return false;
   s8g_built_ = std::min(s8g_built_, n);
   s8g_seen_ = std::min(s8g_seen_, n);
+  if (shadow_ != 3 && (size_t)n + 32 > s8g_f32_cap_rows_) {  // FLOAT32: the int8 rows live in their own allocation
+    if (d_s8g_f32_) HIP_IGNORE(hipFree(d_s8g_f32_));
+    d_s8g_f32_ = nullptr;
+    s8g_f32_cap_rows_ = 0;
+    const size_t cap = (size_t)n + n / 8 + 64;
+    HIP_CHECK(hipMalloc((void **)&d_s8g_f32_, cap * s8g_stride()));
+    s8g_f32_cap_rows_ = cap;
+    s8g_built_ = 0;
+  }
   uint32_t st[4] = {0, 0, 0, 0};
   if (s8g_seen_ < n) {  // the largest |x_i| of the rows not looked at yet
-    launch_absmax_f16_rows(d_rows_, stride_, (uint32_t)dim, s8g_seen_, n, d_s8g_stats_, wstream_);
+    launch_absmax_rows(ktype, d_rows_, stride_, (uint32_t)dim, s8g_seen_, n, d_s8g_stats_, wstream_);
     s8g_seen_ = n;
   }
   HIP_CHECK(hipMemcpyAsync(st, d_s8g_stats_, sizeof st, hipMemcpyDeviceToHost, wstream_));
   HIP_CHECK(hipStreamSynchronize(wstream_));
   float gmax;
   memcpy(&gmax, &st[0], 4);
-  if (st[3] || !(gmax <= 65504.0f)) {  // inf / NaN element: no scale bounds such an index
+  if (st[3] || !(gmax <= 3.0e38f)) {  // inf / NaN element: no scale bounds such an index
     s_bad_ = true;
     return false;
   }
@@ -476,7 +486,8 @@ bool FlatIndex::ensure_shadow8g() {
     HIP_CHECK(hipMemcpyAsync(d_s8g_stats_ + 1, zero2, sizeof zero2, hipMemcpyHostToDevice, wstream_));
   }
   if (s8g_built_ < n) {
-    launch_shadow8g_f16_rows(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, s8g_scale_, d_shadow_, sstride_, d_s8g_stats_, wstream_);
+    launch_shadow8g_rows(ktype, d_rows_, stride_, (uint32_t)dim, s8g_built_, n, s8g_scale_, const_cast<uint8_t *>(s8g_rows()),
+                         s8g_stride(), d_s8g_stats_, wstream_);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(wstream_));
     s8g_built_ = n;
@@ -548,8 +559,8 @@ int FlatIndex::remove(size_t label) {
       HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)r * stride_, d_rows_ + (size_t)last * stride_, stride_,
                                hipMemcpyDeviceToDevice, wstream_));
       HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
-      if (shadow_ == 3) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
-      else if (shadow_)
+      if (s8g_enabled()) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
+      if (shadow_ && shadow_ != 3)
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
                                  hipMemcpyDeviceToDevice, wstream_));
       if (shadow_ == 2)

@@ -220,6 +220,13 @@ class FlatIndex {
   // shadow_ == 3: int8 rows with ONE index-wide scale, for the batched int8 MFMA pass over FLOAT16 (IP / cosine) indexes
   // created with ScanTuning::shadow8 (batch_query.cpp).  Built lazily -- and incrementally -- by the first batched query
   // that finds rows it does not cover; a row that outgrows the scale, or a delete below the built prefix, re-quantises.
+  // FLOAT32 indexes created with shadow8 (shadow_ == 2: per-row scales for the single-query two-stage scan) get the same
+  // index-wide-scale int8 rows for THEIR batched queries, in a buffer of their own (d_s8g_f32_), built on demand.
+  uint8_t *d_s8g_f32_ = nullptr;
+  size_t s8g_f32_cap_rows_ = 0;
+  bool s8g_enabled() const { return d_s8g_stats_ != nullptr; }
+  const uint8_t *s8g_rows() const { return shadow_ == 3 ? d_shadow_ : d_s8g_f32_; }
+  size_t s8g_stride() const { return round_up(dim, 16); }
   uint32_t *d_s8g_stats_ = nullptr;  // {max |x_i| (f32 bits), max |x8|^2, max |ex|^2 (f32 bits), non-finite flag}
   float s8g_scale_ = 0.0f;           // the scale the built rows were quantised with (0: nothing built)
   uint32_t s8g_built_ = 0, s8g_seen_ = 0;  // rows [0, built) are quantised; rows [0, seen) went into max |x_i|

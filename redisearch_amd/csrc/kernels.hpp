@@ -114,15 +114,15 @@ bool batch_rescore_supported(uint32_t stride16);
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
                           int type = KT_F32);  // KT_F16: fp16 rows / queries, the fp16 scan's arithmetic
-// int8 shadow of FLOAT16 rows with ONE index-wide scale (the batched int8 MFMA pass, scan_kernels.hip "int8 shadow with
+// int8 shadow of FLOAT16 / FLOAT32 rows with ONE index-wide scale (the batched int8 MFMA pass, scan_kernels.hip "int8 shadow with
 // ONE index-wide scale"): stats = {max |x_i| (f32 bits), max |x8|^2 (u32), max |ex|^2 (f32 bits), non-finite flag}
-void launch_absmax_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint32_t *stats,
-                            hipStream_t s);
-void launch_shadow8g_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float scale,
-                              void *shadow, size_t sstride, uint32_t *stats, hipStream_t s);
-// queries (fp16) -> int8 rows q8 + qscale[q] = scale * sq + slack[q] = twice the error band of query q
-void launch_quantize_queries_f16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
-                                 const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s);
+void launch_absmax_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,
+                        uint32_t *stats, hipStream_t s);  // type: KT_F16 or KT_F32 rows
+void launch_shadow8g_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,
+                          float scale, void *shadow, size_t sstride, uint32_t *stats, hipStream_t s);
+// queries (fp16 / fp32) -> int8 rows q8 + qscale[q] = scale * sq + slack[q] = twice the error band of query q
+void launch_quantize_queries(int type, const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
+                             const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s);
 // rows_out[i] = cand[i].x (row ids of a candidate list, i < count[0] clamped to cap)
 void launch_cand_rows(const void *cand, const uint32_t *count, uint32_t cap, uint32_t *rows_out, hipStream_t s);
 // cand[i].y = orderable key of dists[i]

@@ -704,17 +704,25 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restri
 // with the ACTUAL error norms: |eq|, |q8| are the query's own, |x8|, |ex| are bounded by their maxima over the index
 // (stats[1], stats[2], atomicMax while the rows are quantised).  One scale for every row keeps the filter an integer
 // compare per query.  stats: [0] max |x_i| (f32 bits), [1] max |x8|^2 (u32), [2] max |ex|^2 (f32 bits), [3] non-finite flag.
-__global__ __launch_bounds__(256) void absmax_f16_rows_kernel(const _Float16 *__restrict__ rows, uint32_t stride_h, uint32_t dim,
-                                                              uint32_t row_begin, uint32_t row_end,
-                                                              uint32_t *__restrict__ stats) {
+template <typename T>
+struct FiniteMax {  // the largest finite value of the row element type
+  static constexpr float v = 65504.0f;
+};
+template <>
+struct FiniteMax<float> {
+  static constexpr float v = 3.4028234e38f;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const T *__restrict__ rows, uint32_t stride_h, uint32_t dim,
+                                                          uint32_t row_begin, uint32_t row_end, uint32_t *__restrict__ stats) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float m = 0.0f;
   bool bad = false;
   for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
-    const _Float16 *src = rows + (size_t)r * stride_h;
+    const T *src = rows + (size_t)r * stride_h;
     for (uint32_t i = lane; i < dim; i += 64) {
       const float v = fabsf((float)src[i]);
-      bad |= !(v <= 65504.0f);
+      bad |= !(v <= FiniteMax<T>::v);
       m = fmaxf(m, v);
     }
   }
@@ -724,29 +732,44 @@ __global__ __launch_bounds__(256) void absmax_f16_rows_kernel(const _Float16 *__
   if (bad) stats[3] = 1;
 }
 
-__global__ __launch_bounds__(256) void shadow8g_f16_rows_kernel(const _Float16 *__restrict__ rows, uint32_t stride_h, uint32_t dim,
-                                                                uint32_t row_begin, uint32_t row_end, float scale,
-                                                                int8_t *__restrict__ shadow, uint32_t sstride,
-                                                                uint32_t *__restrict__ stats) {
+// eight consecutive elements of a row (rows are zero padded to whole 16-byte chunks)
+__device__ __forceinline__ void load8(const _Float16 *row, uint32_t c, uint32_t stride_e, float out[8]) {
+  const u4 x = 8 * c < stride_e ? reinterpret_cast<const u4 *>(row)[c] : zero4();
+  const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const half2_t h = as_h2(w[j >> 1]);
+    out[j] = (float)((j & 1) ? h.y : h.x);
+  }
+}
+__device__ __forceinline__ void load8(const float *row, uint32_t c, uint32_t stride_e, float out[8]) {
+  const bool in = 8 * c < stride_e;
+  const u4 a = in ? reinterpret_cast<const u4 *>(row)[2 * c] : zero4(), b = in ? reinterpret_cast<const u4 *>(row)[2 * c + 1] : zero4();
+  out[0] = __uint_as_float(a.x), out[1] = __uint_as_float(a.y), out[2] = __uint_as_float(a.z), out[3] = __uint_as_float(a.w);
+  out[4] = __uint_as_float(b.x), out[5] = __uint_as_float(b.y), out[6] = __uint_as_float(b.z), out[7] = __uint_as_float(b.w);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void shadow8g_rows_kernel(const T *__restrict__ rows, uint32_t stride_e, uint32_t dim,
+                                                            uint32_t row_begin, uint32_t row_end, float scale,
+                                                            int8_t *__restrict__ shadow, uint32_t sstride,
+                                                            uint32_t *__restrict__ stats) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float inv = 1.0f / scale;
   uint32_t n8_max = 0;
   float ne_max = 0.0f;
-  // eight elements per lane and step: one 16-byte load, one 8-byte store (rows are zero padded to whole 16-byte chunks)
+  // eight elements per lane and step: 16 (32) bytes loaded, 8 bytes stored
   for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
-    const u4 *src = reinterpret_cast<const u4 *>(rows + (size_t)r * stride_h);
+    const T *src = rows + (size_t)r * stride_e;
     uint2 *dst = reinterpret_cast<uint2 *>(shadow + (size_t)r * sstride);
     uint32_t n8 = 0;
     float ne = 0.0f;
     for (uint32_t c = lane; c < sstride / 8; c += 64) {
-      const u4 x = 8 * c < stride_h ? src[c] : zero4();
-      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+      float xf[8];
+      load8(src, c, stride_e, xf);
       uint32_t o[2] = {0, 0};
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const half2_t h = as_h2(w[j >> 1]);
-        const float xf = (8 * c + j < dim) ? (float)((j & 1) ? h.y : h.x) : 0.0f;
-        const float t = xf * inv;
+        const float t = (8 * c + j < dim) ? xf[j] * inv : 0.0f;
         const float v = fminf(fmaxf(rintf(t), -127.0f), 127.0f);
         const float e = t - v;
         const int vi = (int)v;
@@ -774,17 +797,18 @@ __global__ __launch_bounds__(256) void shadow8g_f16_rows_kernel(const _Float16 *
 // (distance = 1 - qscale * integer dot) and slack[q] >= 2 E_q, E_q >= |shadow distance - fp32 distance of the fp16 row|:
 // the Cauchy-Schwarz band above (x 1.001 for the fp32 arithmetic that computes it) plus the rounding of both distance
 // computations, dim 2^-24 |x||q| for the fp32 accumulation of the exact row and a few ulps of the shadow's.
-__global__ __launch_bounds__(64) void quantize_queries_f16_kernel(const _Float16 *__restrict__ queries, uint32_t qstride_h,
-                                                                  uint32_t dim, float scale, const uint32_t *__restrict__ stats,
-                                                                  int8_t *__restrict__ q8, uint32_t sstride,
-                                                                  float *__restrict__ qscale, float *__restrict__ slack) {
+template <typename T>
+__global__ __launch_bounds__(64) void quantize_queries_kernel(const T *__restrict__ queries, uint32_t qstride_h, uint32_t dim,
+                                                              float scale, const uint32_t *__restrict__ stats,
+                                                              int8_t *__restrict__ q8, uint32_t sstride,
+                                                              float *__restrict__ qscale, float *__restrict__ slack) {
   const uint32_t q = blockIdx.x, lane = threadIdx.x;
-  const _Float16 *src = queries + (size_t)q * qstride_h;
+  const T *src = queries + (size_t)q * qstride_h;
   float m = 0.0f;
   for (uint32_t i = lane; i < dim; i += 64) m = fmaxf(m, fabsf((float)src[i]));
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  const bool finite = m <= 65504.0f;
+  const bool finite = m <= FiniteMax<T>::v;
   const float sq = (m > 0.0f && finite) ? m / 127.0f : 1.0f, inv = 1.0f / sq;
   uint32_t n8 = 0;
   float ne = 0.0f;
@@ -914,25 +938,39 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
   return true;
 }
 
-void launch_absmax_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint32_t *stats,
-                            hipStream_t s) {
+void launch_absmax_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,
+                        uint32_t *stats, hipStream_t s) {
   if (row_end <= row_begin) return;
   const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
-  hipLaunchKernelGGL(absmax_f16_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const _Float16 *)rows,
-                     (uint32_t)(stride / 2), dim, row_begin, row_end, stats);
+  const dim3 grid(need < cap ? need : cap), block(256);
+  if (type == KT_F32)
+    hipLaunchKernelGGL(absmax_rows_kernel<float>, grid, block, 0, s, (const float *)rows, (uint32_t)(stride / 4), dim, row_begin,
+                       row_end, stats);
+  else
+    hipLaunchKernelGGL(absmax_rows_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)rows, (uint32_t)(stride / 2), dim,
+                       row_begin, row_end, stats);
 }
-void launch_shadow8g_f16_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float scale,
-                              void *shadow, size_t sstride, uint32_t *stats, hipStream_t s) {
+void launch_shadow8g_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,
+                          float scale, void *shadow, size_t sstride, uint32_t *stats, hipStream_t s) {
   if (row_end <= row_begin) return;
   const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
-  hipLaunchKernelGGL(shadow8g_f16_rows_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const _Float16 *)rows,
-                     (uint32_t)(stride / 2), dim, row_begin, row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
+  const dim3 grid(need < cap ? need : cap), block(256);
+  if (type == KT_F32)
+    hipLaunchKernelGGL(shadow8g_rows_kernel<float>, grid, block, 0, s, (const float *)rows, (uint32_t)(stride / 4), dim, row_begin,
+                       row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
+  else
+    hipLaunchKernelGGL(shadow8g_rows_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)rows, (uint32_t)(stride / 2), dim,
+                       row_begin, row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
 }
-void launch_quantize_queries_f16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
-                                 const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s) {
+void launch_quantize_queries(int type, const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, float scale,
+                             const uint32_t *stats, void *q8, size_t sstride, float *qscale, float *slack, hipStream_t s) {
   if (!n_queries) return;
-  hipLaunchKernelGGL(quantize_queries_f16_kernel, dim3(n_queries), dim3(64), 0, s, (const _Float16 *)queries,
-                     (uint32_t)(qstride / 2), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
+  if (type == KT_F32)
+    hipLaunchKernelGGL(quantize_queries_kernel<float>, dim3(n_queries), dim3(64), 0, s, (const float *)queries,
+                       (uint32_t)(qstride / 4), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
+  else
+    hipLaunchKernelGGL(quantize_queries_kernel<_Float16>, dim3(n_queries), dim3(64), 0, s, (const _Float16 *)queries,
+                       (uint32_t)(qstride / 2), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
 }
 
 void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, void *shadow,

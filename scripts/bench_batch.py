@@ -31,6 +31,10 @@ if f32s:
 i8s = os.environ.get("I8_SHADOW") == "1" and not f32s
 if i8s:
     lib.RSGPU_SetTuning(b"shadow8", 1)
+# I8_SHADOW=1 F32_ROWS=1: a FLOAT32 cosine index created with shadow8 -- the same int8 passes, re-scored from the fp32 rows
+f32i8 = i8s and os.environ.get("F32_ROWS") == "1"
+if f32i8:
+    f32s = True   # (fp32 rows / queries below; shadow16 stays off)
 idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_Cosine) if f32s else V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
 npdt = np.float32 if f32s else np.float16
 idx.reserve(rows)

@@ -153,3 +153,64 @@ def test_zero_query_and_small_corpus(shadow8):
         wi, ws = small.topk_query(q, k).results()
         assert len(set(ids[i].tolist()) & set(wi.tolist())) >= k - 1 or i == 2
         assert np.allclose(np.sort(sc[i]), np.sort(ws), atol=2e-3)
+
+
+# ---- FLOAT32 indexes created with shadow8: the same int8 passes for THEIR batches (re-scored from the fp32 rows) -----------
+F32 = V.VecSimType_FLOAT32
+
+
+def build_f32(x, dim, metric):
+    g = V.VecSimIndex(F32, dim, metric)
+    torch.cuda.synchronize()
+    g.add_device_rows(x.data_ptr(), x.shape[0], 1)
+    return g
+
+
+@pytest.mark.parametrize("metric", [IP, COS])
+@pytest.mark.parametrize("dim,n,k", [(768, 530_001, 10), (256, 700_000, 100), (512, 540_000, 1000)])
+def test_f32_index_batches_through_the_int8_rows(shadow8, metric, dim, n, k):
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(dim * 13 + k)
+    x = torch.rand((n, dim), device=dev, generator=gen) * 2 - 1
+    b = 300
+    queries = np.random.default_rng(dim + k + 1).uniform(-1, 1, (b, dim)).astype(np.float32)
+    shadow8.RSGPU_SetTuning(b"shadow8", 0)                 # plain fp32 index: the exact answers
+    p = build_f32(x.clone(), dim, metric)
+    want = [p.topk_query(q, k).results() for q in queries]
+    p.free()
+    shadow8.RSGPU_SetTuning(b"shadow8", 1)
+    g = build_f32(x, dim, metric)
+    launches, by = check(shadow8, g, queries, k, want, expect_launches=2)
+    assert by == 2 * n * dim                               # both passes read one byte per element
+    # its single queries (two-stage over the per-row int8 shadow) give the same answers
+    for i in (0, 150, 299):
+        si, ss = g.topk_query(queries[i], k).results()
+        assert si.tolist() == want[i][0].tolist() and ss.tolist() == want[i][1].tolist()
+
+
+def test_f32_index_appends_deletes_and_growth(shadow8):
+    dev = torch.device("cuda", 0)
+    dim, n, k = 256, 560_000, 10
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(21)
+    x = torch.rand((n, dim), device=dev, generator=gen) * 2 - 1
+    queries = np.random.default_rng(22).uniform(-1, 1, (9, dim)).astype(np.float32)
+    g = build_f32(x, dim, IP)
+    shadow8.RSGPU_SetTuning(b"two_stage", 0)               # single queries as the plain fp32 scan: the reference answers
+    single = lambda: [g.topk_query(q, k).results() for q in queries]
+    want = single()
+    shadow8.RSGPU_SetTuning(b"two_stage", 1)
+    check(shadow8, g, queries, k, want, expect_launches=1)
+    extra = np.random.default_rng(23).uniform(-1, 1, (40, dim)).astype(np.float32)
+    extra[5] = queries[1]
+    for i in range(40):
+        g.add_vector(extra[i], n + 1 + i)
+    for lbl in (9, 100_000, n + 3):
+        g.delete_vector(lbl)
+    g.add_vector(queries[2] * 3, 8_000_000)                # outgrows the scale
+    shadow8.RSGPU_SetTuning(b"two_stage", 0)
+    want = single()
+    shadow8.RSGPU_SetTuning(b"two_stage", 1)
+    assert want[1][0][0] == n + 6 and want[2][0][0] == 8_000_000
+    check(shadow8, g, queries, k, want, expect_launches=1)
