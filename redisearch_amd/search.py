@@ -65,6 +65,7 @@ ABI = {
     "RSGPU_Hits_NumLeaves": (_sz, [_vp]),
     "RSGPU_Hits_IsUnion": (_i, [_vp]),
     "RSGPU_Hits_LeafOrder": (_i, [_vp, _vp]),
+    "RSGPU_Hits_Tree": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Hits_ReadRange": (C.c_long, [_vp, _sz, _sz, _vp]),
     "RSGPU_Hits_ReadRecords": (C.c_long, [_vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_ReadBytes": (_i, [_vp, _sz, _sz, _vp]),
