@@ -341,6 +341,12 @@ static GpuIt *make(int kind, RSGPU_Hits *hits, bool own, const RSGPU_TermArg *te
   it->own_hits = own;
   if (kind == K_NOT) {
     it->result = g_api.NewVirtualResult(weight, RS_FIELDMASK_ALL); /* not.rs:112-115 */
+    if (!it->result) {
+      set_err("the module could not allocate a result", NULL);
+      it->own_hits = false;
+      it_free(&it->base);
+      return NULL;
+    }
     return it;
   }
   it->n_children = num;
@@ -354,6 +360,16 @@ static GpuIt *make(int kind, RSGPU_Hits *hits, bool own, const RSGPU_TermArg *te
     ch->has_freq = codec_has_freq(codec);
     ch->has_mask = codec_has_mask(codec);
     ch->rec = g_api.NewTokenRecord(t->term, t->weight);
+  }
+  /* the module's allocator failing is the one thing that can go wrong after the terms have been handed over: the records
+   * made so far (and their terms) are released with the iterator */
+  bool ok = it->result != NULL;
+  for (size_t c = 0; c < num; c++) ok = ok && it->child[c].rec != NULL;
+  if (!ok) {
+    set_err("the module could not allocate a result", NULL);
+    it->own_hits = false; /* the caller frees the hit list on a NULL return */
+    it_free(&it->base);
+    return NULL;
   }
   return it;
 }
