@@ -5,9 +5,15 @@
 Workload (config.workload): BASELINE configs[1] -- 10M x 768 fp32 FLAT, COSINE, top-10, single-query stream through
 the VecSim C ABI (VecSimIndex_TopKQuery -> reply), corpus resident in HBM.  A "step" is one KNN query = one pass over
 the corpus.  The corpus is SYNTHETIC and KEYED: element (i, j) = Philox4x32-10(seed; i, j) mapped to
-[-1, 1), generated in place in HBM by RSGPU_FlatIndex_AddPhiloxRows -- any host can regenerate any row, and this file
-does: after the timed loop the rows one timed query returned are regenerated on the host and re-scored in fp64
-(`config.verify`).  tests/test_gpu_fullsize.py checks whole queries of this very corpus against the CPU oracle.
+[-1, 1), generated in place in HBM by RSGPU_FlatIndex_AddPhiloxRows -- any host can regenerate any row, and the
+cpu_baseline leg does: after the timed loop the rows one timed query returned are regenerated on the host and re-scored
+in fp64 (`config.verify`).  tests/test_gpu_fullsize.py checks whole queries of this very corpus against the CPU oracle.
+
+Every input of the timed regions comes from the product or from numpy: the corpus and the queries from the library's
+Philox kernel (queries read back through a scratch index), the hybrid extra's posting lists from encode_freqs_only
+below.  oracle/ is imported in the cpu_baseline leg only -- the CPU timing, the verification of the timed answers
+(`config.verify`, `cpu_baseline.gpu_answers_checked_...`) and the oracle check of the hybrid extra -- never with
+--no-cpu-baseline (tests/test_bench_contract_cpu.py::test_bench_imports_the_oracle_only_in_its_cpu_leg).
 
 N > 1 (weak scaling, BASELINE configs[3] at N=8: 80M rows): the corpus is row-sharded, 10M rows per GPU, every query
 runs on all shards and the per-shard top-10 lists are merged by (score, label).
@@ -223,6 +229,53 @@ def cpu_config0(n=100_000, dim=128, k=10, nq=1000):
 
 
 # ---- N=1 sub-records ---------------------------------------------------------------------------------------------------
+def philox_host_rows(V, first_index, n, dim, vtype=None):
+    """Rows first_index .. first_index+n of the keyed Philox corpus as a host array, produced by the PRODUCT's own generator
+    (corpus_kernels.hip through a scratch L2 index: no normalisation) -- bench inputs never come from oracle/."""
+    vtype = V.VecSimType_FLOAT32 if vtype is None else vtype
+    s = V.VecSimIndex(vtype, dim, V.VecSimMetric_L2)
+    try:
+        assert s.add_philox_rows(SEED, first_index, n, 1) == n
+        return s.read_rows(0, n)
+    finally:
+        s.free()
+
+
+def encode_freqs_only(docs, freqs, block_entries=100):
+    """Synthetic posting list in the reference's FreqsOnly block format (inverted_index/src/codec/freqs_only.rs: qint2
+    [delta, freq]; qint/src/lib.rs: one control byte, 2 bits per field = byte length - 1, little-endian minimal bytes; a
+    block holds 100 entries, the delta of its first entry is 0).  Pure numpy: the bench's input generator.  Returns the
+    upload dict of redisearch_amd.search.Postings.from_flat (tests/test_bench_contract_cpu.py holds it to the oracle's
+    block writer byte for byte)."""
+    docs = np.ascontiguousarray(docs, np.uint64)
+    freqs = np.ascontiguousarray(freqs, np.uint64)
+    n = docs.size
+    idx = np.arange(n)
+    delta = np.zeros(n, np.uint64)
+    delta[1:] = docs[1:] - docs[:-1]
+    delta[idx % block_entries == 0] = 0
+    assert n == 0 or int(delta.max()) <= 0xFFFFFFFF
+
+    def nbytes(v):
+        return (1 + (v > 0xFF) + (v > 0xFFFF) + (v > 0xFFFFFF)).astype(np.int64)
+    ld, lf = nbytes(delta), nbytes(freqs)
+    rec = 1 + ld + lf
+    off = np.cumsum(rec) - rec
+    total = int(off[-1] + rec[-1]) if n else 0
+    out = np.zeros(max(total, 1), np.uint8)
+    out[off] = ((ld - 1) | ((lf - 1) << 2)).astype(np.uint8)
+    for b in range(4):
+        m = ld > b
+        out[off[m] + 1 + b] = ((delta[m] >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+        m = lf > b
+        out[off[m] + 1 + ld[m] + b] = ((freqs[m] >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+    starts = np.arange(0, n, block_entries)
+    ends = np.minimum(starts + block_entries, n)
+    byte_off = np.concatenate([off[starts], [total]]).astype(np.uint64) if n else np.zeros(1, np.uint64)
+    return dict(first=docs[starts], last=docs[ends - 1] if n else docs[:0], num_entries=(ends - starts).astype(np.uint32),
+                offset=byte_off, bytes=out[:total], codec=2)   # RSGPU_CODEC_FREQS_ONLY
+
+
 def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
     """Independent check of timed answers without the oracle's corpus: the rows a query returned are REGENERATED on the
     host from (seed, label) and re-scored in fp64; the K-th distance must also beat 2048 other regenerated rows."""
@@ -283,13 +336,12 @@ def extra_two_stage(lib, V, index, queries, k, steps, warmup):
 
 def extra_batched(lib, V, rows, dim):
     """BASELINE configs[2]: rows x dim fp16 FLAT IP top-100, 256 queries per corpus pass on the matrix cores."""
-    import oracle as O
     k, batch, reps = 100, 256, 10
     idx = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
     try:
         idx.reserve(rows)
         idx.add_philox_rows(SEED, 0, rows, 1)
-        qs = O.philox_rows(SEED, QUERY_BASE, batch * 4, dim, O.F16).reshape(4, batch, dim)
+        qs = philox_host_rows(V, QUERY_BASE, batch * 4, dim, V.VecSimType_FLOAT16).reshape(4, batch, dim)
         idx.topk_batch(qs[0], k)  # allocations
         lib.RSGPU_ResetProfile()
         lib.RSGPU_SetProfiling(1)
@@ -358,18 +410,17 @@ def extra_batched(lib, V, rows, dim):
 
 
 def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
-    """BASELINE configs[4]: 2-term intersection over Zipf postings (50M docs) -> FLAT 5M x 768 ad-hoc KNN top-10 + BM25STD."""
-    import oracle as O
+    """BASELINE configs[4]: 2-term intersection over Zipf postings (50M docs) -> FLAT 5M x 768 ad-hoc KNN top-10 + BM25STD.
+    Returns (record, payload): the payload holds what the cpu-baseline leg needs to hold the answers to the CPU oracle
+    (check_hybrid_with_oracle); nothing here touches oracle/."""
     from redisearch_amd import search as S
     rng = np.random.default_rng(49)
-    lists = []
+    raw = []
     for r in (2, 4):
         docs = np.flatnonzero(rng.random(n_docs + 1) < 0.2 / r).astype(np.uint64)
         docs = docs[docs > 0]
         freqs = np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32)
-        ii = O.InvertedIndex(O.C_FREQS_ONLY)
-        ii.add_many(docs, freqs)
-        lists.append(ii)
+        raw.append((docs, freqs))
     doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
     doc_score = np.ones(n_docs + 1, np.float32)
     avg = float(doc_len[1:].mean())
@@ -378,10 +429,10 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
     try:
         idx.reserve(n_vec)
         idx.add_philox_rows(SEED, 0, n_vec, 1)
-        q = O.philox_rows(SEED, QUERY_BASE, 1, dim)[0]
-        g = [S.Postings.from_flat(l.flatten()) for l in lists]
-        idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists]
-        bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists]
+        q = philox_host_rows(V, QUERY_BASE, 1, dim)[0]
+        g = [S.Postings.from_flat(encode_freqs_only(d, f)) for d, f in raw]
+        idf = [S.calculate_idf(n_docs, d.size) for d, _ in raw]
+        bidf = [S.calculate_idf_bm25(n_docs, d.size) for d, _ in raw]
 
         def pipeline():
             h = S.intersect(g)
@@ -415,34 +466,50 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
         fused()
         prof = S.profile()
         lib.RSGPU_SetProfiling(0)
-        # parity against the CPU oracle on the same inputs
-        t0 = time.perf_counter()
-        oi, of, _ = O.intersect(lists)
-        t_int = (time.perf_counter() - t0) * 1e3
-        sel = oi.astype(np.int64)
-        os_ = O.score_flat("BM25STD", of, doc_len[sel], np.ones(len(sel)), doc_score[sel], idf, bidf, [1.0, 1.0], 1.0, n_docs, avg)
         gi, gf = h.read()
-        order = np.lexsort((oi, -os_))[:10]
-        ok = gi.tolist() == oi.tolist() and gf.tolist() == of.tolist() and ti.tolist() == oi[order].tolist() and \
-            bool(np.allclose(ts, os_[order], rtol=1e-12, atol=0))
         adhoc = idx.adhoc_ctx(q)
-        ok &= bool(np.array_equal(adhoc.get_exact_distances(ki), kd)) and fused_ok
+        seam_ok = bool(np.array_equal(adhoc.get_exact_distances(ki), kd))   # the per-label ad-hoc seam gives the same distances
         n_cand = int(np.searchsorted(gi, n_vec, side="right"))
         n_ent = [x.num_entries for x in g]
-        return {"workload": "2-term intersect (Zipf df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD top-10" % (n_docs, n_vec, dim),
-                "wall_ms_per_query": min(walls[1:]), "qps": 1e3 / min(walls[1:]), "postings": n_ent, "hits": len(gi),
-                "entry_point": "RSGPU_HybridQuery (one call, two stream syncs; score/top-N and KNN branches on two streams)",
-                "wall_ms_stage_by_stage_entry_points": min(staged[1:]),
-                "candidates_with_vector": n_cand,
-                "stage_device_ms": {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
-                "stage_gbs": {"intersect (4 B per posting of both lists)": sum(n_ent) * 4 / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
-                              "score (20 B read + 20 B written per hit)": len(gi) * 40 / max(prof.get("score_ms") or 1e-9, 1e-9) / 1e6,
-                              "knn gather (dim*4 B per candidate with a vector)": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6},
-                "cpu_oracle_intersect_ms": t_int,
-                "parity": {"ok": bool(ok), "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), "
-                                                 "KNN distances equal the per-label ad-hoc seam's; fused == stage-by-stage"}}
+        rec = {"workload": "2-term intersect (Zipf df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD top-10" % (n_docs, n_vec, dim),
+               "wall_ms_per_query": min(walls[1:]), "qps": 1e3 / min(walls[1:]), "postings": n_ent, "hits": len(gi),
+               "entry_point": "RSGPU_HybridQuery (one call, two stream syncs; score/top-N and KNN branches on two streams)",
+               "wall_ms_stage_by_stage_entry_points": min(staged[1:]),
+               "candidates_with_vector": n_cand,
+               "stage_device_ms": {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
+               "stage_gbs": {"intersect (4 B per posting of both lists)": sum(n_ent) * 4 / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                             "score (20 B read + 20 B written per hit)": len(gi) * 40 / max(prof.get("score_ms") or 1e-9, 1e-9) / 1e6,
+                             "knn gather (dim*4 B per candidate with a vector)": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6},
+               "parity": {"ok": bool(fused_ok and seam_ok), "vs": "fused == stage-by-stage entry points; KNN distances equal the per-label ad-hoc "
+                                                                 "seam's (the CPU-oracle check runs in the cpu_baseline leg)"}}
+        payload = dict(raw=raw, doc_len=doc_len, doc_score=doc_score, idf=idf, bidf=bidf, n_docs=n_docs, avg=avg,
+                       gi=gi, gf=gf, ti=ti, ts=ts, ok=bool(fused_ok and seam_ok))
+        return rec, payload
     finally:
         idx.free()
+
+
+def check_hybrid_with_oracle(p):
+    """cpu_baseline leg: the hybrid extra's answers against the CPU oracle on the same inputs (the oracle's own block
+    writer re-encodes the lists from the raw (doc, freq) arrays: an independent path to the same postings)."""
+    import oracle as O
+    lists = []
+    for docs, freqs in p["raw"]:
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(docs, freqs)
+        lists.append(ii)
+    t0 = time.perf_counter()
+    oi, of, _ = O.intersect(lists)
+    t_int = (time.perf_counter() - t0) * 1e3
+    sel = oi.astype(np.int64)
+    os_ = O.score_flat("BM25STD", of, p["doc_len"][sel], np.ones(len(sel)), p["doc_score"][sel], p["idf"], p["bidf"], [1.0, 1.0], 1.0,
+                       p["n_docs"], p["avg"])
+    order = np.lexsort((oi, -os_))[:10]
+    ok = (p["gi"].tolist() == oi.tolist() and p["gf"].tolist() == of.tolist() and p["ti"].tolist() == oi[order].tolist()
+          and bool(np.allclose(p["ts"], os_[order], rtol=1e-12, atol=0)))
+    return {"ok": bool(ok and p["ok"]), "cpu_oracle_intersect_ms": t_int,
+            "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), KNN distances equal "
+                  "the per-label ad-hoc seam's; fused == stage-by-stage"}
 
 
 # ---- main ------------------------------------------------------------------------------------------------------------------
@@ -473,8 +540,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from redisearch_amd import vecsim as V
-    import oracle as O   # host-side twin of the corpus generator (queries, verification); never inside the timed loop
-    lib = V.load()
+    lib = V.load()   # (oracle/ is imported by the cpu_baseline leg only: verification of the answers + the CPU timing)
     for kv in a.tuning:
         key, val = kv.split("=")
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
@@ -507,7 +573,7 @@ def main():
         index.add_philox_rows(SEED, rank * rows, rows, rank * rows + 1)
         assert index.index_size() == rows
         total_rows = rows * world
-    queries = O.philox_rows(SEED, QUERY_BASE, 1000, dim)
+    queries = philox_host_rows(V, QUERY_BASE, 1000, dim)   # the product's own generator, read back to the host
 
     if ranks_mode:
         from redisearch_amd.sharded import ShardedTopK
@@ -557,6 +623,8 @@ def main():
         try:
             if ranks_mode:
                 verify = {"note": "multi-rank run: answers are checked by tests/test_sharded_cpu.py and the N=1 verification"}
+            elif a.no_cpu_baseline:   # the host-side regeneration is the oracle's Philox twin: part of the CPU leg
+                verify = {"skipped": "--no-cpu-baseline (the verification uses the CPU twin of the corpus generator)"}
             else:
                 worst, gpu_answers = verify_answers(index, queries, k, a.metric, dim, total_rows)
                 verify = {"queries": 3, "returned_rows_regenerated_on_host": 3 * k, "max_abs_err_vs_fp64": worst,
@@ -586,8 +654,19 @@ def main():
                 continue
             try:
                 t0 = time.perf_counter()
-                extras[name] = fn()
+                res = fn()
+                payload = None
+                if isinstance(res, tuple):
+                    res, payload = res
+                extras[name] = res
                 extras[name]["bench_wall_s"] = time.perf_counter() - t0
+                if payload is not None and cpu is not None:   # cpu_baseline leg: the extra's answers vs the CPU oracle
+                    try:
+                        chk = check_hybrid_with_oracle(payload)
+                        extras[name]["cpu_oracle_intersect_ms"] = chk.pop("cpu_oracle_intersect_ms")
+                        extras[name]["parity"] = chk
+                    except Exception as e:
+                        extras[name]["parity"] = {"ok": False, "error": repr(e)}
             except Exception as e:
                 extras[name] = {"error": repr(e)}
 

@@ -2,7 +2,10 @@
 bench.py touches oracle/) returns the object the bench line carries.  The timed GPU region itself is exercised on
 the MI355X (bench.py asserts a device)."""
 import importlib
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load_bench(argv):
@@ -57,3 +60,43 @@ def test_cpu_baseline_full_mode_checks_gpu_answers_against_the_oracle():
     bad = dict(answers)
     bad[1] = ([999] + answers[1][0][1:], answers[1][1])
     assert b.cpu_baseline(dim, k, rows, 100, "cosine", "full", bad)["gpu_answers_checked_against_oracle_on_full_corpus"]["ids_identical"] is False
+
+
+def test_bench_posting_encoder_matches_the_oracle_block_writer():
+    """bench.py encodes its synthetic FreqsOnly posting lists itself (numpy: the bench's inputs never come from oracle/);
+    the bytes, block headers and offsets must equal the oracle's block writer for the same (doc, freq) pairs."""
+    import numpy as np
+    import oracle as O
+    b = load_bench([])
+    rng = np.random.default_rng(5)
+    for n, max_gap, max_freq in ((0, 5, 5), (1, 5, 5), (99, 3, 300), (100, 70000, 70000), (101, 300, 2), (1234, 20_000_000, 1 << 30)):
+        docs = np.cumsum(rng.integers(1, max_gap + 1, n)).astype(np.uint64)
+        freqs = rng.integers(1, max_freq + 1, n).astype(np.uint32)
+        mine = b.encode_freqs_only(docs, freqs)
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        if n:
+            ii.add_many(docs, freqs)
+        ref = ii.flatten()
+        assert mine["codec"] == ref["codec"] == O.C_FREQS_ONLY
+        for key in ("first", "last", "num_entries", "offset"):
+            assert np.array_equal(np.asarray(mine[key], np.uint64), np.asarray(ref[key], np.uint64)), (n, key)
+        assert bytes(mine["bytes"]) == bytes(ref["bytes"]), n
+
+
+def test_bench_imports_the_oracle_only_in_its_cpu_leg():
+    """bench.py may use oracle/ only as the checker / CPU baseline: every import of it sits inside cpu_baseline's helpers,
+    the host-side verification and the extras' oracle check, all of which run only when the cpu_baseline leg runs."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    allowed = {"_oracle_lib", "verify_answers", "check_hybrid_with_oracle"}
+    users = set()
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Import) and any(al.name == "oracle" for al in node.names):
+                users.add(fn.name)
+            if isinstance(node, ast.ImportFrom) and (node.module or "").startswith("oracle"):
+                users.add(fn.name)
+    top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any(getattr(n, "module", None) == "oracle" or any(al.name == "oracle" for al in getattr(n, "names", [])) for n in top)
+    assert users <= allowed, users
