@@ -87,7 +87,9 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
 void RSGPU_Postings_Free(RSGPU_Postings *p);
 size_t RSGPU_Postings_NumEntries(const RSGPU_Postings *p);
 size_t RSGPU_Postings_NumBytes(const RSGPU_Postings *p);
-/* Decode every record on the device; any host output may be NULL. Returns #records or -1. */
+/* Decode every record on the device; any host output may be NULL. Returns #records or -1.  A codec that stores no
+ * frequency yields 1 for every record -- the term record's default the reference's reader leaves in place
+ * (index_result/src/core/mod.rs:192-197) -- and that is also what such a list contributes to a hit's frequencies. */
 long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *freqs_out, uint32_t *masks_out);
 
 /* Wide codecs: the 128-bit field mask of every record (low / high 64 bits; either may be NULL; masks_out of
