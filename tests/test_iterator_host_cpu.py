@@ -51,10 +51,14 @@ class TreeQuery(C.Structure):
 def lib():
     os.makedirs(BUILD, exist_ok=True)
     srcs = [os.path.join(ROOT, "redisearch_amd", "csrc", "query_iterators.c"), os.path.join(ROOT, "tests", "mock_hits.c")]
-    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+    prebuilt = os.environ.get("RSGPU_ITER_MOCK_LIB")        # e.g. an -fsanitize=address,undefined build (scripts/asan_iterators.sh)
+    if prebuilt:
+        pass
+    elif not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.check_call(["gcc", "-O1", "-g", "-std=gnu11", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wextra",
-                               "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", LIB, "-ldl", "-Wl,-Bsymbolic"])   # (bind the mock's RSGPU_* inside: the real engine may be loaded too)
-    L = C.CDLL(LIB)
+                               "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", LIB, "-ldl",
+                               "-Wl,-Bsymbolic"])           # (binds the mock's RSGPU_* inside: the real engine may be loaded too)
+    L = C.CDLL(prebuilt or LIB)
     L.RSGPU_Iterators_SetResultAPI.restype, L.RSGPU_Iterators_SetResultAPI.argtypes = C.c_int, [_vp, _vp]
     L.RSGPU_Iterators_SetBlock.restype, L.RSGPU_Iterators_SetBlock.argtypes = None, [C.c_size_t]
     L.RSGPU_Iterators_LastError.restype = C.c_char_p
