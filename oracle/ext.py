@@ -66,6 +66,7 @@ def lib():
         L.xh_iter_score_all.restype = C.c_long
         L.xh_iter_score_all.argtypes = [vp, C.c_char_p, C.POINTER(_Args), vp, vp, vp, sz, sz, vp, vp]
         L.xh_iter_free.restype, L.xh_iter_free.argtypes = None, [vp]
+        L.xh_fail_constructor_after.restype, L.xh_fail_constructor_after.argtypes = None, [C.c_long]
         _lib = L
     return _lib
 
@@ -222,6 +223,11 @@ def iter_score_all(it, alias, doc_len, doc_score, max_freq, cap, num_docs=1, avg
     if n < 0:
         raise RuntimeError("xh_iter_score_all: " + lib().xh_last_error().decode())
     return ids[: min(n, cap)], sc[: min(n, cap)]
+
+
+def fail_constructor_after(n):
+    """the (n+1)-th RSIndexResult constructor call from now on returns NULL once (n < 0: off) -- error-path tests"""
+    lib().xh_fail_constructor_after(n)
 
 
 def iter_free(it):

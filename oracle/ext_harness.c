@@ -223,7 +223,14 @@ XH_API void xh_free(RSIndexResult *r) {
 /* ---- the module's RSIndexResult constructors (src/redisearch_rs/headers/types_ffi.h:89,233,263,331,352,358,364,444):
  * what an iterator implemented in C builds its `current` with.  Aggregates made here BORROW their children
  * (RSIndexResult::build_intersect / build_union), exactly like the reference's. ------------------------------------------ */
+/* fault injection for the iterator library's error paths: the (n+1)-th constructor call from now on returns NULL once
+ * (the module's allocator never does -- RedisModule_Alloc aborts -- but a library must not crash or leak if it did) */
+static long g_fail_after = -1;
+XH_API void xh_fail_constructor_after(long n) { g_fail_after = n; }
+static int failing(void) { return g_fail_after >= 0 && g_fail_after-- == 0; }
+
 static RSIndexResult *new_agg(int tag, size_t cap, double weight) {
+  if (failing()) return NULL;
   RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r);
   XVec *v = (XVec *)calloc(1, sizeof *v + (cap ? cap : 1) * sizeof(RSIndexResult *));
   v->cap = cap ? cap : 1;
@@ -236,6 +243,7 @@ static RSIndexResult *new_agg(int tag, size_t cap, double weight) {
 XH_API RSIndexResult *NewIntersectResult(size_t cap, double weight) { return new_agg(RSResultData_Intersection, cap, weight); }
 XH_API RSIndexResult *NewUnionResult(size_t cap, double weight) { return new_agg(RSResultData_Union, cap, weight); }
 XH_API RSIndexResult *NewVirtualResult(double weight, t_fieldMask field_mask) {
+  if (failing()) return NULL;
   RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r); /* RawIndexResultBuilder::virt: doc 0, freq 0 */
   r->data.tag = RSResultData_Virtual;
   r->weight = weight;
@@ -244,6 +252,10 @@ XH_API RSIndexResult *NewVirtualResult(double weight, t_fieldMask field_mask) {
 }
 /* types_ffi/src/lib.rs:105-122: a term record with frequency 0, field mask 0, the term owned by the record */
 XH_API RSIndexResult *NewTokenRecord(RSQueryTerm *term, double weight) {
+  if (failing()) { /* the term was handed over: it goes with the failed record */
+    if (term) free(term->str), free(term);
+    return NULL;
+  }
   RSIndexResult *r = (RSIndexResult *)calloc(1, sizeof *r);
   r->data.tag = RSResultData_Term;
   r->data.term.term = term;

@@ -142,7 +142,11 @@ static int load_block(GpuIt *it, size_t i) {
       ch->mlo = malloc(it->block * sizeof *ch->mlo);
       ch->mhi = malloc(it->block * sizeof *ch->mhi);
       ch->opos = malloc(it->block * sizeof *ch->opos);
-      if (!ch->entry || !ch->freq || !ch->olen || !ch->mlo || !ch->mhi || !ch->opos) return -1;
+      if (!ch->entry || !ch->freq || !ch->olen || !ch->mlo || !ch->mhi || !ch->opos) {
+        free_child_block(ch); /* all or nothing: the next attempt starts from scratch */
+        set_err("out of memory", "a block of term records");
+        return -1;
+      }
     }
     if (RSGPU_Hits_ReadRecords(it->hits, (size_t)ch->list, first, count, ch->entry, ch->freq, ch->mlo, ch->mhi, ch->opos, ch->olen) !=
         (long)count) {
@@ -162,7 +166,11 @@ static int load_block(GpuIt *it, size_t i) {
         free(ch->obytes);
         ch->obytes_cap = (size_t)(hi - lo);
         ch->obytes = malloc(ch->obytes_cap);
-        if (!ch->obytes) return -1;
+        if (!ch->obytes) {
+          ch->obytes_cap = 0;
+          set_err("out of memory", "a block of term offsets");
+          return -1;
+        }
       }
       if (RSGPU_Postings_ReadBytes(ch->postings, (size_t)lo, (size_t)(hi - lo), ch->obytes)) {
         set_err("RSGPU_Postings_ReadBytes", RSGPU_LastError());
@@ -518,6 +526,13 @@ RSGPU_API QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const R
     it->group_op[g] = gop[g];
     const size_t n = (size_t)(gf[g + 1] - gf[g]);
     it->group_rec[g] = gop[g] == G_UNION ? g_api.NewUnionResult(n, gw[g]) : gop[g] == G_INTERSECT ? g_api.NewIntersectResult(n, gw[g]) : NULL;
+  }
+  bool ok = it->result != NULL;
+  for (int g = 0; g < ng; g++) ok = ok && (gop[g] == G_TERM || it->group_rec[g] != NULL);
+  if (!ok) { /* the module's allocator failed (see make()): everything made so far goes with the iterator */
+    set_err("the module could not allocate a result", NULL);
+    it_free(&it->base); /* (owns the hit list) */
+    return NULL;
   }
   return &it->base;
 }

@@ -317,3 +317,46 @@ def test_constructor_errors_and_foreign_iterators(lib):
         assert lib.RSGPU_Iterator_Hits(it) == C.addressof(m.hits)
     finally:
         X.iter_free(it)
+
+
+def test_module_allocation_failures_neither_crash_nor_leak(lib):
+    """Every RSIndexResult constructor the library calls is made to fail once (oracle/ext_harness.c fault injection): the
+    constructor returns NULL with a message, the hit list it made is released exactly once, nothing is used after free
+    (run under scripts/asan_iterators.sh) -- for flat AND / NOT and for a two-level tree."""
+    rng = np.random.default_rng(2)
+    lists = [rand_list(rng, O.C_FULL, 80, 200) for _ in range(3)]
+    want = O.intersect(lists)[0].tolist()
+    try:
+        for n in range(4):                                          # root + 3 term records
+            m = Mock(lists, want, size_order(lists))
+            terms = [X.new_term(1.0, 1.0, "t%d" % i) for i in range(3)]
+            lib.mock_set_next_hits(C.addressof(m.hits))
+            X.fail_constructor_after(n)
+            it = lib.RSGPU_NewIntersectionIterator(C.cast(m.term_args(terms), _vp), 3, -1, False, 1.0)
+            assert it is None and b"allocate" in lib.RSGPU_Iterators_LastError(), n
+            assert m.hits.freed == 1, n
+        m = Mock([lists[0]], [1, 2, 3], [0], present=lambda li, d: False)
+        lib.mock_set_next_hits(C.addressof(m.hits))
+        X.fail_constructor_after(0)
+        assert lib.RSGPU_NewNotIterator(C.addressof(m.posts[0][0]), None, 10, 1.0) is None and m.hits.freed == 1
+        # tree: make() builds root + 3 terms, then the root again and one aggregate per non-term group
+        ids = sorted(set(records(lists[0])) & (set(records(lists[1])) | set(records(lists[2]))))
+        gf, go = np.asarray([0, 1, 3], np.uint64), np.asarray([OP_T, OP_U], np.int32)
+        tq = TreeQuery(OP_I, 2, gf.ctypes.data, go.ctypes.data, None, None, -1, 0)
+        for n in range(6):
+            m = Mock(lists, ids, [0, 1, 2], groups=[(OP_T, 1.0, 1), (OP_U, 1.0, 2)])
+            terms = [X.new_term(1.0, 1.0, "t%d" % i) for i in range(3)]
+            lib.mock_set_next_hits(C.addressof(m.hits))
+            X.fail_constructor_after(n)
+            it = lib.RSGPU_NewTreeIterator(C.byref(tq), C.cast(m.term_args(terms), _vp), 1.0)
+            assert it is None and b"allocate" in lib.RSGPU_Iterators_LastError(), n
+            assert m.hits.freed == 1, n
+        X.fail_constructor_after(-1)
+        m = Mock(lists, ids, [0, 1, 2], groups=[(OP_T, 1.0, 1), (OP_U, 1.0, 2)])
+        lib.mock_set_next_hits(C.addressof(m.hits))
+        it = lib.RSGPU_NewTreeIterator(C.byref(tq), C.cast(m.term_args(), _vp), 1.0)    # (and it works once nothing fails)
+        assert it
+        assert X.iter_drain(it, len(ids) + 2, 2)["ids"].tolist() == ids
+        X.iter_free(it)
+    finally:
+        X.fail_constructor_after(-1)
