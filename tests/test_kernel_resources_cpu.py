@@ -1,0 +1,74 @@
+"""CPU: the register / LDS / scratch budgets the design relies on, read from the built gfx950 code objects
+(scripts/kernel_resources.py; no GPU).  A spill or a lost occupancy step does not fail any parity test -- it only makes a
+kernel slower -- so the budgets are asserted here:
+  * no kernel spills registers, except the one experiment variant behind a knob;
+  * scratch memory only where per-thread cursor arrays are the design (the proximity kernels);
+  * the query-stationary MFMA pass keeps two wavefronts per SIMD in its default shape (8 waves x 32 queries) and fits its
+    LDS ring into the CU's 160 KiB; the tiled GEMM's default ring variant likewise;
+  * the single-query scan (scan_kernel<TYPE, METRIC, G, ITERS, U, ...>) never needs more than the 512 registers one wave
+    can have; only the deepest unrolling (U = 8 rows in flight per row group) may drop to one wave per SIMD -- its loads in
+    flight are what hides the HBM latency then -- every other variant keeps two or more."""
+import importlib.util
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "scripts", "kernel_resources.py"))
+KR = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(KR)
+
+LDS_PER_CU = 160 * 1024
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not os.path.isdir(KR.OBJDIR) or not any(f.endswith(".hip.o") for f in os.listdir(KR.OBJDIR)):
+        pytest.skip("objects not built (python -m redisearch_amd.build)")
+    ks = KR.all_kernels()
+    assert len(ks) > 1000                 # every .hip file contributed (the scan alone has ~1600 instantiations)
+    return ks
+
+
+def test_no_spills_on_any_default_path(kernels):
+    spilling = [k["name"] for k in kernels if k["vgpr_spill"] or k["sgpr_spill"]]
+    # gemm_dma = 2 (24 KiB stages, two workgroups per CU) in filter mode: an A/B knob, never the default (kernels.hpp)
+    assert all(re.match(r"gemm_topk_ring_kernel<\d+, 4, 3, 4, 1>", n) for n in spilling), spilling
+
+
+def test_scratch_only_for_the_proximity_cursors(kernels):
+    scratch = {re.sub(r"<.*", "", k["name"]) for k in kernels if k["scratch"] and not k["vgpr_spill"]}
+    assert scratch <= {"prox_filter_kernel", "prox_slop_kernel"}, scratch
+
+
+def test_lds_fits_the_cu(kernels):
+    assert max(k["lds"] for k in kernels) <= LDS_PER_CU
+    for k in kernels:
+        assert k["vgpr"] <= 512, k["name"]
+
+
+def test_query_stationary_pass_budget(kernels):
+    qs = [k for k in kernels if k["name"].startswith("gemm_qs_kernel<")]
+    assert len(qs) >= 20
+    for k in qs:
+        qb = int(re.match(r"gemm_qs_kernel<\d+, \d+, \d+, (\d+)", k["name"]).group(1))
+        assert k["wg"] == 512 // qb
+        if qb == 1:                       # the default: 8 waves per workgroup = two per SIMD
+            assert k["vgpr"] <= 256, (k["name"], k["vgpr"])
+        assert k["lds"] <= 147456         # the ring (~144 KiB), nothing else
+
+
+def test_tiled_gemm_default_variant_budget(kernels):
+    ring = [k for k in kernels if re.match(r"gemm_topk_ring_kernel<\d+, 8, 3, 2, \d>", k["name"])]
+    assert len(ring) == 4                 # f16 / bf16 x all-keys / filter
+    for k in ring:
+        assert k["vgpr"] <= 256 and not k["scratch"], k
+
+
+def test_single_query_scan_budget(kernels):
+    scan = [k for k in kernels if k["name"].startswith("scan_kernel<")]
+    assert len(scan) > 1000
+    for k in scan:
+        u = int(re.match(r"scan_kernel<\d+, \d+, \d+, \d+, (\d+)", k["name"]).group(1))
+        assert k["vgpr"] <= (512 if u >= 8 else 256), (k["name"], k["vgpr"])
