@@ -142,6 +142,10 @@ QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const RSGPU_TermA
 /* The hit list behind an iterator made here (score it in one batch with RSGPU_Hits_Score, re-rank with
  * RSGPU_Hits_KnnRerank, ...); NULL for foreign iterators. */
 RSGPU_Hits *RSGPU_Iterator_Hits(QueryIterator *it);
+/* Failure behaviour: a constructor returns NULL (RSGPU_Iterators_LastError says why; the hit list it made is released, and so
+ * are the Term records -- with their terms -- if the module's allocator failed after they were handed over).  Read / SkipTo
+ * return ITERATOR_TIMEOUT -- the one status that leaves an iterator where it was (iterator_api.h:100-102) -- when paging a
+ * block of records from the device fails or the host runs out of memory; the same call may be repeated. */
 /* Block size (hits) of the paging between device and host; default 65536.  Applies to iterators created later. */
 void RSGPU_Iterators_SetBlock(size_t hits);
 
