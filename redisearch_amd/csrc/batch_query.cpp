@@ -339,7 +339,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         for (uint32_t j = 0; j < got; j++)
           res[j] = VecSimQueryResult{(size_t)row_label_[h_rows[(size_t)i * kk + j]], score_of(h_keys[(size_t)i * kk + j])};
         std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
-          return a.score != b.score ? a.score < b.score : a.id < b.id;
+          return score_id_before(a.score, a.id, b.score, b.id);
         });
         counts_out[qi] = got;
         for (uint32_t j = 0; j < got; j++) {

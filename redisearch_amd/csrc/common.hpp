@@ -48,6 +48,22 @@ bool device_available(std::string *why = nullptr);
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+// `a` before `b` in score order -- a STRICT WEAK order even when a score is NaN (a NaN element stored in the index, a NaN
+// query): NaN sorts after every number and NaNs tie among themselves.  `a != b ? a < b : tie` is not one with NaNs around,
+// and std::sort / std::partial_sort may then walk out of the range they were given.
+inline bool score_before(double a, double b) {
+  const bool an = a != a, bn = b != b;
+  if (an || bn) return !an && bn;
+  return a < b;
+}
+// (score, id) ascending with that order
+template <typename S, typename I>
+inline bool score_id_before(S sa, I ia, S sb, I ib) {
+  if (score_before((double)sa, (double)sb)) return true;
+  if (score_before((double)sb, (double)sa)) return false;
+  return ia < ib;
+}
+
 inline size_t type_size(VecSimType t) {
   switch (t) {
     case VecSimType_FLOAT32: return 4;

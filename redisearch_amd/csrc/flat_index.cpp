@@ -1007,7 +1007,7 @@ static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
     std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
   else
     std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
-      return a.score != b.score ? a.score < b.score : a.id < b.id;
+      return score_id_before(a.score, a.id, b.score, b.id);
     });
 }
 

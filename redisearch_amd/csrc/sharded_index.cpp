@@ -125,7 +125,7 @@ struct DeviceGuard {
 };
 
 static bool by_score_then_id(const VecSimQueryResult &a, const VecSimQueryResult &b) {
-  return a.score != b.score ? a.score < b.score : a.id < b.id;
+  return score_id_before(a.score, a.id, b.score, b.id);  // (the order the shards' replies are in: NaN scores last)
 }
 
 // K-way merge of per-shard replies (each ascending by (score, id)); frees them.

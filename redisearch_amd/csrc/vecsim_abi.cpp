@@ -386,7 +386,7 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
     std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &c) { return a.id < c.id; });
   else
     std::sort(r->results, r->results + r->len, [](const VecSimQueryResult &a, const VecSimQueryResult &c) {
-      return a.score != c.score ? a.score < c.score : a.id < c.id;
+      return score_id_before(a.score, a.id, c.score, c.id);
     });
   return r;
   ABI_CATCH(f->log_ctx, "VecSimBatchIterator_Next", nullptr)
@@ -608,7 +608,7 @@ int RSGPU_MergeTopKHost(const float *scores, const uint64_t *labels, size_t m, s
     if (labels[i] != UINT64_MAX) ord.push_back(i);
   size_t kk = std::min(k, ord.size());
   std::partial_sort(ord.begin(), ord.begin() + (long)kk, ord.end(), [&](size_t a, size_t b) {
-    return scores[a] != scores[b] ? scores[a] < scores[b] : labels[a] < labels[b];
+    return score_id_before(scores[a], labels[a], scores[b], labels[b]);
   });
   for (size_t i = 0; i < kk; i++) {
     scores_out[i] = (double)scores[ord[i]];

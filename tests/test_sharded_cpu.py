@@ -85,3 +85,22 @@ def test_merge_topk_ties_and_padding():
     assert labels.tolist() == [3, 7, 8] and np.allclose(scores, [0.1, 0.1, 0.3])
     labels, _ = merge_topk(s, l, 10)
     assert labels.tolist() == [3, 7, 8, 9]
+
+
+def test_merge_topk_is_a_total_order_with_nan_scores():
+    """Scores can be NaN (a NaN element stored in an index): the merge's comparator must stay a strict weak order -- NaN after
+    every number, ties by label -- or std::partial_sort may leave its range.  Many random draws with a third of the scores
+    NaN, checked against the same order in numpy (lexsort puts NaN last as well)."""
+    from redisearch_amd.sharded import merge_topk
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        m = int(rng.integers(1, 400))
+        sc = rng.integers(0, 5, m).astype(np.float32)
+        sc[rng.random(m) < 0.33] = np.nan
+        sc[rng.random(m) < 0.05] = np.inf
+        lb = rng.permutation(m).astype(np.uint64) + 1
+        kk = int(rng.integers(1, m + 3))
+        labels, scores = merge_topk(sc, lb, kk)
+        order = np.lexsort((lb, sc))[:kk]                 # (NaN sorts last in numpy too)
+        assert labels.tolist() == lb[order].tolist()
+        assert np.array_equal(scores, sc[order].astype(np.float64), equal_nan=True)
