@@ -18,6 +18,9 @@ run() {  # name, env...
 run plain
 run blocking HIP_LAUNCH_BLOCKING=1 AMD_SERIALIZE_KERNEL=3
 run logged AMD_LOG_LEVEL=3 HIP_LAUNCH_BLOCKING=1
+# glibc's heap-corruption messages go to /dev/tty unless told otherwise: the round-2 logs show a bare SIGABRT, which is what a
+# corrupted host heap looks like then (the reply sorts were not NaN-safe at the time; they are now)
+run heapcheck LIBC_FATAL_STDERR_=1 MALLOC_CHECK_=3
 tail -c 20000 gpurun_out/ovl_diag_logged.txt > gpurun_out/ovl_diag_logged_tail.txt; rm -f gpurun_out/ovl_diag_logged.txt
 # and with the knob off on the same build: the patched library must behave like the shipped one
 RSGPU_TUNING=qs_ovl=0 timeout 150 python -m pytest -p tuning_plugin "$CASE" -x -q -p no:cacheprovider > gpurun_out/ovl_diag_knob_off.txt 2>&1; echo "knob off: rc=$?"
