@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HARNESS = os.path.join(_HERE, "_build", "libext_harness.so")
-PLUGIN = os.path.join(_ROOT, "redisearch_amd", "lib", "librsgpu_scorers.so")
+PLUGIN = os.environ.get("RSGPU_SCORERS_LIB") or os.path.join(_ROOT, "redisearch_amd", "lib", "librsgpu_scorers.so")  # (env: a sanitized build)
 REF = os.path.join(_HERE, "_ref", "libref_default_ext.so")
 
 R_UNION, R_INTERSECTION, R_TERM, R_VIRTUAL, R_NUMERIC, R_METRIC, R_HYBRID = 1, 2, 4, 8, 16, 32, 64
