@@ -257,8 +257,9 @@ int sharded_add(RSGPU_ShardedIndex *si, const void *blob, size_t label) {
   Shard *target = nullptr;
   for (auto &s : si->shards)
     if (s->flat->contains(label)) { target = s.get(); break; }
-  if (!target) {
-    size_t best = SIZE_MAX;
+  if (!target) {  // (a handle always has at least one shard)
+    target = si->shards[0].get();
+    size_t best = target->flat->size();
     for (auto &s : si->shards) {
       const size_t n = s->flat->size();
       if (n < best) { best = n; target = s.get(); }
