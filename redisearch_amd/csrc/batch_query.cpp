@@ -337,7 +337,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         // the device hands back the exact top-k SET (selected by (key, row)); reply order: (score, label) ascending
         res.resize(got);
         for (uint32_t j = 0; j < got; j++)
-          res[j] = VecSimQueryResult{(size_t)row_label_[h_rows[(size_t)i * kk + j]], score_of(h_keys[(size_t)i * kk + j])};
+          res[j] = VecSimQueryResult{(size_t)label_at(h_rows[(size_t)i * kk + j]), score_of(h_keys[(size_t)i * kk + j])};
         std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
           return score_id_before(a.score, a.id, b.score, b.id);
         });

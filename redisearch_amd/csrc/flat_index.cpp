@@ -1033,7 +1033,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     if (!two_stage) select(c.c, n, kk, Bound(), hits, nullptr);
     if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
     res.reserve(hits.size());
-    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)row_label_[h.row], score_of(h.key)});
+    for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)label_at(h.row), score_of(h.key)});
   } else {
     // multi-value: walk batches in ascending composite order, first occurrence of a label is its best
     std::unordered_map<uint64_t, char> seen;
@@ -1047,7 +1047,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
       if (hits.empty()) break;
       consumed += (uint32_t)hits.size();
       for (const Hit &h : hits) {
-        uint64_t lab = row_label_[h.row];
+        uint64_t lab = label_at(h.row);
         if (res.size() < want && seen.emplace(lab, 1).second)
           res.push_back(VecSimQueryResult{(size_t)lab, score_of(h.key)});
       }
@@ -1103,11 +1103,11 @@ VecSimQueryReply *FlatIndex::range(const void *query, double radius, VecSimQuery
   auto range_score = [&](uint32_t i) { return key_bytes == 8 ? key_to_dist64(rk64[i]) : (double)key_to_dist(rk32[i]); };
   if (!multi) {
     for (uint32_t i = 0; i < cnt; i++)
-      res.push_back(VecSimQueryResult{(size_t)row_label_[c->h_out_rows[i]], range_score(i)});
+      res.push_back(VecSimQueryResult{(size_t)label_at(c->h_out_rows[i]), range_score(i)});
   } else {
     std::unordered_map<uint64_t, size_t> best;
     for (uint32_t i = 0; i < cnt; i++) {
-      uint64_t lab = row_label_[c->h_out_rows[i]];
+      uint64_t lab = label_at(c->h_out_rows[i]);
       double d = range_score(i);
       auto it = best.find(lab);
       if (it == best.end()) {

@@ -161,7 +161,14 @@ class FlatIndex {
   // exact selection of the k smallest (key,row) composites of the scan's keys above `lower`
   void select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, std::vector<Hit> &out, Bound *upper);
   void gather(QueryCtx *c, const size_t *labels, size_t m, double *out);
-  size_t label_of_row(uint32_t row) const { return row_label_[row]; }
+  // label of a row the DEVICE named (a selected / filtered row index read back from a kernel): a row outside the index
+  // would be a kernel bug -- reported, never read past the table
+  uint64_t label_at(uint32_t row) const {
+    if (row >= row_label_.size())
+      throw std::runtime_error("the device returned row " + std::to_string(row) + " of an index of " + std::to_string(row_label_.size()));
+    return row_label_[row];
+  }
+  size_t label_of_row(uint32_t row) const { return (size_t)label_at(row); }
   // labels are identity_base + row for every row (no hash map needed, device can translate)
   bool identity_labels(uint64_t *base) const {
     if (base) *base = identity_base_;
