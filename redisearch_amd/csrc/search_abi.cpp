@@ -535,6 +535,18 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
   S_TRY
   CodecDesc cd = codec_desc(codec);
   if (cd.kind < 0) throw std::runtime_error("unknown posting codec");
+  // the arguments describe memory this function reads: refuse what cannot be a block list before touching it
+  if (n_blocks > 0xFFFFFFFEull) throw std::runtime_error("more than 2^32 - 2 blocks");
+  if (n_blocks && (!first_doc_id || !last_doc_id || !num_entries || !byte_offset)) throw std::runtime_error("a block array is NULL");
+  {
+    uint64_t total = 0;
+    for (size_t b = 0; b < n_blocks; b++) {
+      if (byte_offset[b] > byte_offset[b + 1]) throw std::runtime_error("byte_offset is not ascending");
+      total += num_entries[b];
+    }
+    if (total > 0xFFFFFFFEull) throw std::runtime_error("a posting list of 2^32 entries or more is not supported on the device path");
+    if (n_blocks && byte_offset[n_blocks] && !bytes) throw std::runtime_error("the encoded bytes are NULL");
+  }
   std::string why;
   if (!device_available(&why)) throw std::runtime_error(why);
   auto *p = new RSGPU_Postings();

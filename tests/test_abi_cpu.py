@@ -194,3 +194,27 @@ def test_search_seam_argument_errors_are_loud_and_exception_free(lib):
     sl.RSGPU_Postings_Free(None)
     sl.RSGPU_DocTable_Free(None)
     assert lib.RSGPU_SetTuning(b"no_such_knob", 1) == -1 and lib.RSGPU_SetTuning(None, 1) == -1
+
+
+def test_posting_upload_refuses_what_cannot_be_a_block_list(lib):
+    """RSGPU_Postings_Upload reads the arrays it is given: NULL arrays, a descending byte_offset and a list of 2^32 entries
+    are refused with a message before anything is read or any device is touched (so this runs without a GPU)."""
+    from redisearch_amd import search as S
+    import oracle as O
+    sl = S.load()
+    up = lambda codec, n, first, last, nent, off, data: sl.RSGPU_Postings_Upload(codec, n, first, last, nent, off, data)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    first, last = np.array([1, 50], np.uint64), np.array([40, 90], np.uint64)
+    nent, off, data = np.array([3, 2], np.uint32), np.array([0, 9, 15], np.uint64), np.zeros(15, np.uint8)
+    assert not up(99, 2, p(first), p(last), p(nent), p(off), p(data)) and "codec" in V.last_error()
+    assert not up(O.C_FREQS_ONLY, 2, None, p(last), p(nent), p(off), p(data)) and "NULL" in V.last_error()
+    assert not up(O.C_FREQS_ONLY, 2, p(first), p(last), p(nent), p(off), None) and "bytes are NULL" in V.last_error()
+    bad = np.array([0, 9, 5], np.uint64)
+    assert not up(O.C_FREQS_ONLY, 2, p(first), p(last), p(nent), p(bad), p(data)) and "ascending" in V.last_error()
+    huge = np.array([0xFFFFFFF0, 0x20], np.uint32)
+    assert not up(O.C_FREQS_ONLY, 2, p(first), p(last), p(huge), p(off), p(data)) and "2^32 entries" in V.last_error()
+    h = up(O.C_FREQS_ONLY, 2, p(first), p(last), p(nent), p(off), p(data))     # well-formed: only the device can be missing
+    if h:
+        sl.RSGPU_Postings_Free(h)
+    else:
+        assert "device" in V.last_error().lower() or "hip" in V.last_error().lower()
