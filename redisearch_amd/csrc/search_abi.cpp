@@ -1001,6 +1001,7 @@ void RSGPU_DocTable_Free(RSGPU_DocTable *t) { delete t; }
 int RSGPU_Hits_Score(RSGPU_Hits *h, const RSGPU_DocTable *t, const RSGPU_ScoreArgs *a, double *scores_out) {
   if (!h || !t || !a) return -1;
   S_TRY
+  if (t->device != h->device) throw std::runtime_error("RSGPU_Hits_Score: hits and document table live on different devices");
   HIP_CHECK(hipSetDevice(h->device));
   CtxLease c(h->device);
   ScoreParams P;
