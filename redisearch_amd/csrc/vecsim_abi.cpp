@@ -6,6 +6,7 @@
 // an error code plus a message through the installed log callback (SURVEY.md 8b "Errors").
 #include <algorithm>
 #include <cmath>
+#include <memory>
 #include <strings.h>
 
 #include "flat_index.hpp"
@@ -286,8 +287,10 @@ double VecSimIndex_GetDistanceFrom_Unsafe(VecSimIndex *index, size_t label, cons
 
 bool VecSimIndex_PreferAdHocSearch(VecSimIndex *index, size_t subsetSize, size_t k, bool initialCheck) {
   if (!index) return true;
+  ABI_TRY
   if (index->sharded) return sharded_prefer_adhoc(index->sharded, subsetSize, k, initialCheck);
   return index->flat->prefer_adhoc(subsetSize, k, initialCheck);
+  ABI_CATCH(log_ctx_of(index), "VecSimIndex_PreferAdHocSearch", true)
 }
 
 // ---- batch iterator ------------------------------------------------------------------------------
@@ -295,11 +298,11 @@ VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *que
   if (!index || !queryBlob) return nullptr;
   if (index->sharded) {
     try {
-      auto *b = new VecSimBatchIterator();
+      std::unique_ptr<VecSimBatchIterator> b(new VecSimBatchIterator());
       b->it.index = nullptr;
       b->it.ctx = nullptr;
       b->sh = sharded_batch_new(index->sharded, queryBlob, queryParams);
-      return b;
+      return b.release();
     } catch (const std::exception &e) {
       set_error(log_ctx_of(index), "VecSimBatchIterator_New", e.what());
       return nullptr;
@@ -309,14 +312,14 @@ VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *que
   ABI_TRY
   f->flush_if_needed();
   HIP_CHECK(hipSetDevice(f->device));
-  auto *b = new VecSimBatchIterator();
+  std::unique_ptr<VecSimBatchIterator> b(new VecSimBatchIterator());
   b->it.index = f;
-  b->it.ctx = CtxPool::get().acquire(f->device);
-  b->it.timeout_ctx = queryParams ? queryParams->timeoutCtx : nullptr;
   size_t bytes = f->dim * type_size(f->type);
   b->it.query.assign((const uint8_t *)queryBlob, (const uint8_t *)queryBlob + bytes);
+  b->it.timeout_ctx = queryParams ? queryParams->timeoutCtx : nullptr;
   b->it.n = f->committed_rows();
-  return b;
+  b->it.ctx = CtxPool::get().acquire(f->device);  // (last: nothing after it can throw and strand the leased context)
+  return b.release();
   ABI_CATCH(f->log_ctx, "VecSimBatchIterator_New", nullptr)
 }
 
