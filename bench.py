@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--cpu-baseline-mode", choices=["auto", "full", "sample"], default="auto")
     ap.add_argument("--no-extras", action="store_true", help="skip the N=1 sub-records (two-stage, batched MFMA, hybrid)")
     ap.add_argument("--no-two-stage-extra", action="store_true")
+    ap.add_argument("--no-callers-extra", action="store_true")
     ap.add_argument("--no-batched-extra", action="store_true")
     ap.add_argument("--no-hybrid-extra", action="store_true")
     ap.add_argument("--replicas", action="store_true", help="N>1, single process: N full replicas instead of N shards "
@@ -307,11 +308,20 @@ def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
     return worst, got
 
 
+def _lat_summary(lat_s):
+    lat = np.asarray(lat_s, np.float64) * 1e3
+    return {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "max_ms": float(lat.max())}
+
+
 def extra_two_stage(lib, V, index, queries, k, steps, warmup):
+    """The opt-in two-stage exact scan on the headline index (int8 shadow).  Every query that leaves the two-stage path
+    runs the plain fp32 scan (exact, four times the bytes): the library counts each way out (RSGPU_GetTwoStageStats) and
+    the record carries the counters next to per-query latencies -- a silent fallback shows up as `fallbacks` > 0 and as a
+    p95 near the fp32 scan's latency."""
     import torch
     lib.RSGPU_SetTuning(b"two_stage", 1)
     try:
-        for i in range(5):
+        for i in range(8):      # warm-up: workspaces at their final size, clocks up
             index.topk_query(queries[i], k)
         ids2, sc2 = index.topk_query(queries[7], k).results()
         lib.RSGPU_SetTuning(b"two_stage", 0)
@@ -319,19 +329,102 @@ def extra_two_stage(lib, V, index, queries, k, steps, warmup):
         lib.RSGPU_SetTuning(b"two_stage", 1)
         same = ids1.tolist() == ids2.tolist() and sc1.tolist() == sc2.tolist()
         torch.cuda.synchronize()
-        n2 = min(steps, 200)
+        n2 = max(min(steps, 1000), 200)   # (never fewer than 200 queries: 0.3 s)
+        lat = np.zeros(n2)
+        V.two_stage_stats(reset=True)
         t2 = time.perf_counter()
         for i in range(n2):
             q = queries[(warmup + i) % len(queries)]
+            s = time.perf_counter()
             rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
             lib.VecSimQueryReply_Free(rep)
+            lat[i] = time.perf_counter() - s
         torch.cuda.synchronize()
         el2 = time.perf_counter() - t2
-        return {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
-                "what": "opt-in: scan of an int8 shadow with per-row scales (7.72 GB) + error-bounded filter + fp32 "
-                        "re-scoring of the survivors; NOT the headline value"}
+        st = V.two_stage_stats()
+        out = {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
+               "fallbacks": st["fallbacks"], "two_stage_stats": st,
+               "what": "opt-in: scan of an int8 shadow with per-row scales (7.72 GB) + error-bounded filter + fp32 "
+                       "re-scoring of the survivors; NOT the headline value"}
+        out.update(_lat_summary(lat))
+        return out
     finally:
         lib.RSGPU_SetTuning(b"two_stage", 0)
+
+
+def _callers_lib(V):
+    """examples/concurrent_callers.c (pthread callers through the plain C ABI) as a ctypes library, built on the spot."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "redisearch_amd", "lib")
+    out = os.path.join(tempfile.mkdtemp(prefix="rs_callers_"), "libconcurrent_callers.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "concurrent_callers.c"), "-L" + libdir, "-lVectorSimilarity",
+                           "-Wl,-rpath," + libdir, "-lpthread", "-o", out])
+    cl = C.CDLL(out)
+    cl.rs_callers_run.restype = C.c_long
+    cl.rs_callers_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    return cl
+
+
+def run_callers(cl, index, queries, k, threads, seconds, keep_answers=False):
+    nq, cap = len(queries), 20000
+    lat = np.zeros((threads, cap), np.uint64)
+    counts = np.zeros(threads, np.uint64)
+    ids = np.zeros((nq, k), np.uint64) if keep_answers else None
+    sc = np.zeros((nq, k), np.float64) if keep_answers else None
+    el = C.c_double(0)
+    q = np.ascontiguousarray(queries)
+    total = cl.rs_callers_run(index.ptr, q.ctypes.data_as(C.c_void_p), q.strides[0], nq, k, threads, seconds,
+                              lat.ctypes.data_as(C.c_void_p), cap, counts.ctypes.data_as(C.c_void_p),
+                              ids.ctypes.data_as(C.c_void_p) if keep_answers else None,
+                              sc.ctypes.data_as(C.c_void_p) if keep_answers else None, C.byref(el))
+    assert total > 0, "a caller thread failed"
+    lats = np.concatenate([lat[t, :int(counts[t])] for t in range(threads)]).astype(np.float64) / 1e9
+    return total, el.value, lats, ids, sc
+
+
+def extra_concurrent_callers(lib, V, index, queries, k, rows, dim, single_qps):
+    """WORKERS-n deployments (reference src/util/workers.c:58,104): n threads, each issuing VecSimIndex_TopKQuery calls
+    back to back on the SAME plain fp32 index (no shadow in use).  The library's coalescer lets calls that arrive while
+    a corpus pass is in flight share the next pass (scan_mq_kernels.hip); the replies must be bit-identical to serial
+    ones -- checked here on every query of the run."""
+    cl = _callers_lib(V)
+    nq = 64
+    qs = queries[:nq]
+    lib.RSGPU_SetTuning(b"coalesce", 0)
+    serial = [index.topk_query(q, k).results() for q in qs]
+    total0, el0, lat0, _, _ = run_callers(cl, index, qs, k, 8, 1.5)
+    lib.RSGPU_SetTuning(b"coalesce", 1)
+    out = {"workload": "%dx%d fp32 plain index (no shadow), n caller threads through VecSimIndex_TopKQuery "
+                       "(examples/concurrent_callers.c, pthreads)" % (rows, dim),
+           "single_stream_qps": single_qps,
+           "eight_threads_without_coalescer": dict(qps=total0 / el0, **_lat_summary(lat0))}
+    for threads in (1, 2, 4, 8, 16):
+        V.coalesce_stats(reset=True)
+        lib.RSGPU_ResetProfile()
+        lib.RSGPU_SetProfiling(1)
+        total, el, lat, ids, sc = run_callers(cl, index, qs, k, threads, 2.0, keep_answers=True)
+        lib.RSGPU_SetProfiling(0)
+        st = V.coalesce_stats()
+        same = all(ids[i].tolist() == serial[i][0].tolist() and sc[i].tolist() == serial[i][1].tolist() for i in range(nq))
+        rec = dict(qps=total / el, x_single_stream=total / el / single_qps, queries=int(total),
+                   queries_per_pass=st["queries"] / max(st["passes"], 1), passes=st["passes"],
+                   multi_query_passes=st["mq_passes"], bit_identical_to_serial=bool(same), **_lat_summary(lat))
+        if st["mq_passes"]:
+            ms = st["mq_device_ns"] / st["mq_passes"] / 1e6
+            rec["multi_query_scan_ms"] = ms
+            rec["multi_query_scan_hbm_gbs"] = rows * dim * 4 / ms / 1e6
+            rec["multi_query_scan_hbm_frac"] = rows * dim * 4 / ms / 1e6 / HBM_PEAK_GBS
+            rec["linger_us_per_pass"] = st["linger_ns"] / 1e3 / max(st["passes"], 1)
+        out["%d_threads" % threads] = rec
+    out["kernel"] = V.last_mq_scan_kernel()
+    out["qps"] = out["8_threads"]["qps"]
+    out["x_single_stream"] = out["8_threads"]["x_single_stream"]
+    out["p50_ms"] = out["8_threads"]["p50_ms"]
+    out["bit_identical_to_serial"] = all(out["%d_threads" % t]["bit_identical_to_serial"] for t in (1, 2, 4, 8, 16))
+    return out
 
 
 def extra_batched(lib, V, rows, dim):
@@ -637,6 +730,11 @@ def main():
                 extras["two_stage_exact_scan_extra"] = extra_two_stage(lib, V, index, queries, k, a.steps, a.warmup)
             except Exception as e:  # an extra must never cost the headline line
                 extras["two_stage_exact_scan_extra"] = {"error": repr(e)}
+        if not a.no_callers_extra:
+            try:
+                extras["concurrent_callers"] = extra_concurrent_callers(lib, V, index, queries, k, rows, dim, a.steps / elapsed)
+            except Exception as e:
+                extras["concurrent_callers"] = {"error": repr(e)}
     cpu = None
     if single and rank == 0 and not a.no_cpu_baseline:
         try:

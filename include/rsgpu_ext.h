@@ -104,6 +104,22 @@ void RSGPU_SetProfiling(int on);
 void RSGPU_ResetProfile(void);
 /* launches, summed kernel milliseconds, algorithmic bytes (rows*dim*sizeof(type)) */
 void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes);
+/* The query coalescer behind VecSimIndex_TopKQuery (DESIGN.md "coalescer"): calls that arrive while a pass over the corpus
+ * is in flight join the next pass, which scores every row against all of them at once (scan_mq_kernels.hip, up to 8
+ * queries per pass); replies are bit-identical to uncoalesced ones.  out[0] passes, [1] queries served, [2] passes that
+ * ran the multi-query scan, [3] queries those served, [4] times a new leader waited for the previous pass's callers,
+ * [5] nanoseconds spent so, [6] device nanoseconds of the multi-query scans (HIP events), [7] queries of a multi-query
+ * pass whose batched selection overflowed and was redone through the radix levels. */
+void RSGPU_GetCoalesceStats(uint64_t out[8]);
+void RSGPU_ResetCoalesceStats(void);
+/* like RSGPU_GetLastScanKernel, for the multi-query scan */
+const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap);
+/* Two-stage (shadow) scans of this process since the last reset: out[0] attempts, [1] answered by the two-stage path,
+ * then the ways out to the plain fp32 scan (exact, but 4x the bytes): [2] unsupported shape, [3] query / error band not
+ * finite (zero query, non-finite row), [4] the first (sampled-bound) pass overflowed the candidate buffer, [5] the rows
+ * inside the error band overflowed it, [6] fewer than k rows inside the band, [7] the final select overflowed. */
+void RSGPU_GetTwoStageStats(uint64_t out[8]);
+void RSGPU_ResetTwoStageStats(void);
 /* The kernel instantiation the last full FLAT scan of this process launched, e.g.
  * "scan_kernel<f32,IP,G=64,ITERS=3,U=8,EXACT=1,NT=1> grid=4096x256" (bench.py's roofline.kernel). Returns buf. */
 const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
@@ -120,6 +136,9 @@ const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
  *   "shards"         0 (default); N > 1: VecSimIndex_New builds ONE index over N device shards (shard i on device
  *                    i mod the visible devices) behind the ordinary handle -- see RSGPU_ShardedIndex_FromHandle
  *   "shard_replicas" with "shards": every shard holds the whole corpus, queries go to one of them round-robin
+ *   "coalesce"       1 (default): concurrent VecSimIndex_TopKQuery calls on one index share corpus passes (see
+ *                    RSGPU_GetCoalesceStats); 0: every call scans on its own stream
+ *   "coalesce_linger_us"  -1 (default: 5 % of a pass, 20..300 us); "coalesce_min_mib" 64: smaller corpora never coalesce
  *   "vmm"            1 (default): row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual
  *                    range (no copy, no transient 2x HBM); 0: hipMalloc + full copy on every growth */
 int RSGPU_SetTuning(const char *key, int value);

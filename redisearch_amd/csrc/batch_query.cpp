@@ -100,8 +100,45 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     host_free(r->results);
     host_free(r);
   };
+  // No MFMA form for this index (L2, FLOAT32 without an int8 shadow, ...): the exact multi-query scan, eight queries per
+  // corpus pass (scan_mq_kernels.hip; bit-identical to single queries) -- or, failing that, one query at a time.
+  auto all_single = [&]() {
+    if (!mq_capable(k)) {
+      for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+      return;
+    }
+    for (size_t q0 = 0; q0 < n_queries; q0 += kMqMaxQueries) {
+      const size_t cnt = std::min<size_t>(kMqMaxQueries, n_queries - q0);
+      TopkJob jobs[kMqMaxQueries];
+      TopkJob *ptr[kMqMaxQueries];
+      for (size_t i = 0; i < cnt; i++) {
+        jobs[i] = TopkJob{(const uint8_t *)queries + (q0 + i) * elem_bytes_, k, nullptr, BY_SCORE};
+        ptr[i] = &jobs[i];
+      }
+      struct Cleanup {  // (a throwing pass may leave some replies behind)
+        TopkJob *j;
+        size_t n;
+        ~Cleanup() {
+          for (size_t i = 0; i < n; i++)
+            if (j[i].reply) {
+              host_free(j[i].reply->results);
+              host_free(j[i].reply);
+            }
+        }
+      } cleanup{jobs, cnt};
+      topk_pass(ptr, cnt);
+      for (size_t i = 0; i < cnt; i++) {
+        const VecSimQueryReply *r = jobs[i].reply;
+        counts_out[q0 + i] = r ? r->len : 0;
+        for (size_t j = 0; r && j < r->len; j++) {
+          ids_out[(q0 + i) * k + j] = r->results[j].id;
+          scores_out[(q0 + i) * k + j] = r->results[j].score;
+        }
+      }
+    }
+  };
   if (!gemm_ok) {
-    for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+    all_single();
     return;
   }
   flush_if_needed();
@@ -113,7 +150,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
     if (f32_needs_s8g && !via_shadow8) {
       g.unlock();
-      for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+      all_single();
       return;
     }
     // the corpus the MFMA passes read
@@ -151,7 +188,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
     if ((via_shadow || via_shadow8) && !use_qs) {  // small corpora: the single-query path is already cheap
       g.unlock();
-      for (size_t qi = 0; qi < n_queries; qi++) single(qi);
+      all_single();
       return;
     }
     // FLOAT32 rows have no tiled GEMM for the sample bound: the first int8 phase runs over n0 rows with tau = +inf -- every
@@ -295,8 +332,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                       c->stream, slack, slack_q);
-          launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                               sc.tau.p, c->stream, via_shadow8 ? ktype : KT_F32);
+          if (!launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
+                                    sc.tau.p, c->stream, via_shadow8 ? ktype : KT_F32))
+            throw std::runtime_error("batched shadow pass: the re-scoring kernel refused a row shape the route was gated on");
         }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);

@@ -54,6 +54,15 @@ ScanProfile &scan_profile() {
   return p;
 }
 
+CoalesceStats &coalesce_stats() {
+  static CoalesceStats t;
+  return t;
+}
+TwoStageStats &two_stage_stats() {
+  static TwoStageStats t;
+  return t;
+}
+
 VecSimQueryReply *new_reply(size_t len, VecSimQueryReply_Code code) {
   VecSimQueryReply *r = host_alloc<VecSimQueryReply>(1);
   r->results = len ? host_alloc<VecSimQueryResult>(len) : nullptr;
@@ -187,14 +196,19 @@ QueryCtx::QueryCtx(int dev) : device(dev) {
   dev_realloc(d_fcnt, 0, 4);
   pin_realloc(h_fcnt, 4);
   pin_realloc(h_counters, 16);
+  dev_realloc(d_mq_tau, 0, kMqMaxQueries);
+  dev_realloc(d_mq_cnt, 0, kMqMaxQueries);
+  pin_realloc(h_mq_n, 2 * kMqMaxQueries);
+  h_mq_over = h_mq_n + kMqMaxQueries;
 }
 #define HIP_IGNORE(x) (void)(x)
 QueryCtx::~QueryCtx() {
   HIP_IGNORE(hipSetDevice(device));
   HIP_IGNORE(hipStreamSynchronize(stream));
-  void *dev[] = {d_query, d_keys, d_hist, d_counters, d_bound, d_out_rows, d_out_keys, d_ids, d_dists, d_tau, d_cand, d_fcnt};
+  void *dev[] = {d_query, d_keys, d_hist, d_counters, d_bound, d_out_rows, d_out_keys, d_ids, d_dists, d_tau, d_cand, d_fcnt,
+                 d_mq_queries, d_mq_tau, d_mq_cnt, d_mq_cand};
   if (h_fcnt) HIP_IGNORE(hipHostFree(h_fcnt));
-  void *pin[] = {h_query, h_out_rows, h_out_keys, h_counters, h_ids, h_dists};
+  void *pin[] = {h_query, h_out_rows, h_out_keys, h_counters, h_ids, h_dists, h_mq_queries, h_mq_n};
   for (void *p : dev) if (p) HIP_IGNORE(hipFree(p));
   for (void *p : pin) if (p) HIP_IGNORE(hipHostFree(p));
   HIP_IGNORE(hipEventDestroy(ev0));
@@ -208,6 +222,14 @@ void QueryCtx::ensure_query(size_t bytes) {
   pin_realloc(h_query, cap);
   query_cap = cap;
   cached_query_owner = 0;
+}
+void QueryCtx::ensure_mq(size_t query_bytes) {
+  if (!d_mq_cand) dev_realloc(d_mq_cand, 0, (size_t)kMqMaxQueries * kCandCap);
+  if (query_bytes <= mq_query_cap) return;
+  const size_t cap = round_up(query_bytes, 4096);
+  dev_realloc(d_mq_queries, mq_query_cap, cap);
+  pin_realloc(h_mq_queries, cap);
+  mq_query_cap = cap;
 }
 void QueryCtx::ensure_keys(size_t rows) {
   if (rows <= keys_cap) return;
@@ -326,21 +348,28 @@ size_t FlatIndex::memory() const {
 void FlatIndex::grow(size_t min_rows) {
   // 32 rows of slack behind the rows: the batched filter pass reads its ragged last tile whole
   const size_t need_row_bytes = (min_rows + 32) * stride_;
-  if (min_rows <= cap_rows_ && need_row_bytes <= rows_buf_.capacity()) return;
+  // (the shadow is its own buffer with its own rounding: a mapped row matrix rounds up to a 256 MiB / 1 GiB chunk and
+  // covers far more rows than a 2-4x smaller shadow that is still a plain allocation of exactly what was asked for)
+  const bool shadow_fits = !shadow_ || (min_rows + 32) * sstride_ <= shadow_buf_.capacity();
+  if (min_rows <= cap_rows_ && need_row_bytes <= rows_buf_.capacity() && shadow_fits) return;
   if (min_rows > 0xFFFFFFF0ull) throw std::runtime_error("FLAT index is limited to 2^32 rows per device");
   const int mode = scan_tuning().vmm;
   // Row matrix (+ shadow): no copy once mapped (grow_buffer.hpp), so it grows by what is needed (rounded to a
   // physical chunk by the buffer); while it is a plain allocation it doubles like the label array below.
   size_t next = cap_rows_ < (1u << 22) ? cap_rows_ * 2 : cap_rows_ + cap_rows_ / 2;
   size_t new_cap = round_up(std::max(min_rows, next), 64);
-  const bool rows_mapped = rows_buf_.mapped() || (mode == 1 && need_row_bytes >= GrowBuffer::kVmmThreshold && vmm_supported(device));
-  const size_t row_target = rows_mapped ? min_rows : new_cap;
+  // a buffer that is (or is about to be) mapped grows by what is needed; a plain allocation -- small buffers, VMM switched
+  // off, or a mapping the driver refused (GrowBuffer::vmm_broken) -- is copied on every growth and therefore doubles
+  auto target_rows = [&](const GrowBuffer &b, size_t row_bytes) {
+    const bool will_map = mode == 1 && !b.vmm_broken && (b.mapped() || ((min_rows + 32) * row_bytes >= GrowBuffer::kVmmThreshold && vmm_supported(device)));
+    return will_map ? min_rows : new_cap;
+  };
   rows_buf_.reserve_factor = shadow_buf_.reserve_factor = scan_tuning().vmm_reserve_factor;
   rows_buf_.chunk_override = shadow_buf_.chunk_override = (size_t)scan_tuning().vmm_chunk_mib << 20;
-  rows_buf_.ensure(device, (row_target + 32) * stride_, (size_t)n_rows_ * stride_, wstream_, mode);
+  rows_buf_.ensure(device, (target_rows(rows_buf_, stride_) + 32) * stride_, (size_t)n_rows_ * stride_, wstream_, mode);
   d_rows_ = rows_buf_.ptr();
   if (shadow_) {
-    shadow_buf_.ensure(device, (row_target + 32) * sstride_, (size_t)n_rows_ * sstride_, wstream_, mode);
+    shadow_buf_.ensure(device, (target_rows(shadow_buf_, sstride_) + 32) * sstride_, (size_t)n_rows_ * sstride_, wstream_, mode);
     d_shadow_ = shadow_buf_.ptr();
   }
   if (min_rows <= cap_rows_) return;
@@ -901,7 +930,13 @@ void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, 
 //      select the K best (distance, row): ids and distances are bit-identical to the one-stage path.
 // Returns false (caller runs the full fp32 scan) when the survivors do not fit the candidate buffer.
 bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
-  if (dim > 1024) return false;
+  TwoStageStats &st = two_stage_stats();
+  st.v[TwoStageStats::ATTEMPTS]++;
+  auto leave = [&st](int why) {
+    st.v[why]++;
+    return false;
+  };
+  if (dim > 1024) return leave(TwoStageStats::FB_SHAPE);
   float kSlack = 2.0f * 4e-3f;
   // shadow-typed copy of the normalised query behind the fp32 one
   const size_t q16_off = round_up(stride_ + 16, 16);  // upload_query sized the buffers for it
@@ -909,6 +944,10 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
   const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
   c->ensure_keys(n);
   c->ensure_out(k);
+  // the survivors' gather buffers at their largest right away: sized per query they were re-allocated (a device free, a
+  // device allocation and two pinned-host allocations, tens of milliseconds) whenever a query kept more rows than any
+  // query before it on this workspace
+  c->ensure_gather(QueryCtx::kCandCap);
   if (shadow_ == 1) {
     uint16_t *q16 = reinterpret_cast<uint16_t *>(c->h_query + q16_off);
     memset(q16, 0, sstride_);
@@ -928,7 +967,8 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
       qmax = std::max(qmax, std::fabs(qf[i]));
       qn2 += (double)qf[i] * (double)qf[i];
     }
-    if (!(qmax > 0.0f) || !(s_max_ > 0.0f) || s_bad_ || !std::isfinite(qn2) || !std::isfinite(n2_max_)) return false;
+    if (!(qmax > 0.0f) || !(s_max_ > 0.0f) || s_bad_ || !std::isfinite(qn2) || !std::isfinite(n2_max_))
+      return leave(TwoStageStats::FB_QUERY_OR_BAND);
     const float sq = qmax / 127.0f;
     const float qn = (float)std::sqrt(qn2) * 1.000001f, xn = std::sqrt(n2_max_) * 1.0001f, qn2f = (float)qn2;
     int8_t *q8 = reinterpret_cast<int8_t *>(c->h_query + q16_off);
@@ -943,7 +983,7 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
     // fp32 rounding on both sides (d-term accumulations, |x|^2 of the row, the final sums): d 2^-23 of the largest magnitude
     const float mag = l2 ? (qn + xn) * (qn + xn) : 1.0f + qn * xn;
     const float eps = (l2 ? 2.0f * eps_dot : eps_dot) + (float)dim * 1.2e-7f * mag + 1e-6f;
-    if (!std::isfinite(eps)) return false;
+    if (!std::isfinite(eps)) return leave(TwoStageStats::FB_QUERY_OR_BAND);
     kSlack = 2.0f * eps;
     if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_I8, l2 ? KM_L2S : KM_IPS, 0, n, c->d_query + q16_off, c->d_keys, c->stream,
@@ -985,8 +1025,9 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
   HIP_CHECK(hipStreamSynchronize(c->stream));
   collect_profile(c);
   const uint32_t m = c->h_fcnt[3];
-  if (m > QueryCtx::kCandCap || m < k || c->h_fcnt[1]) return false;  // ([1]: the first int8 pass overflowed)
-  c->ensure_gather(m);
+  if (c->h_fcnt[1]) return leave(TwoStageStats::FB_FIRST_PASS_OVERFLOW);  // the first int8 pass overflowed
+  if (m > QueryCtx::kCandCap) return leave(TwoStageStats::FB_BAND_OVERFLOW);
+  if (m < k) return leave(TwoStageStats::FB_TOO_FEW);
   launch_cand_rows(c->d_cand, c->d_fcnt, QueryCtx::kCandCap, c->d_ids, c->stream);
   launch_gather(d_rows_, stride_, (uint32_t)dim, ktype, kmetric, c->d_ids, m, c->d_query, c->d_dists, c->stream);
   launch_cand_set_keys(c->d_cand, c->d_dists, m, c->stream);
@@ -994,7 +1035,8 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
                            c->h_fcnt + 2, k, c->h_fcnt + 1, c->stream);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(c->stream));
-  if (c->h_fcnt[1] || c->h_fcnt[2] < k) return false;
+  if (c->h_fcnt[1] || c->h_fcnt[2] < k) return leave(TwoStageStats::FB_SELECT);
+  st.v[TwoStageStats::OK]++;
   const uint32_t *k32 = reinterpret_cast<const uint32_t *>(c->h_out_keys);
   out.resize(k);
   for (uint32_t i = 0; i < k; i++) out[i] = Hit{c->h_out_rows[i], (uint64_t)k32[i]};
@@ -1011,11 +1053,206 @@ static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
     });
 }
 
+// ---- the coalescer (flat_index.hpp) --------------------------------------------------------------------------------
+// Which calls go through it: corpora whose scan is HBM-bound (below ~64 MiB a query is a handful of launch latencies and
+// concurrent streams serve concurrent callers better), row shapes the multi-query kernel has, single-value indexes with
+// 32-bit keys, and no two-stage shadow in use (that path has its own, four times cheaper, scan).
+bool FlatIndex::mq_capable(size_t k) const {
+  if (multi || key_bytes != 4 || !k || k > 1024) return false;
+  if ((shadow_ == 1 || shadow_ == 2) && scan_tuning().two_stage) return false;
+  return scan_mq_supported(ktype, kmetric, (uint32_t)(stride_ / 16));
+}
+bool FlatIndex::coalescible(size_t k) const {
+  const ScanTuning &t = scan_tuning();
+  if (!t.coalesce || !mq_capable(k)) return false;
+  const uint32_t n = __atomic_load_n(&n_rows_, __ATOMIC_RELAXED);
+  return (size_t)n * stride_ >= ((size_t)(t.coalesce_min_mib > 0 ? t.coalesce_min_mib : 0) << 20);
+}
+
 VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
   void *tctx = qp ? qp->timeoutCtx : nullptr;
   last_mode = STANDARD_KNN;
+  if (!coalescible(k)) {
+    flush_if_needed();
+    std::shared_lock<std::shared_mutex> g(mu);
+    return topk_locked(query, k, tctx, order);
+  }
+  TopkJob job{query, k, tctx, order};
+  std::vector<TopkJob *> batch;
+  {
+    std::unique_lock<std::mutex> lk(co_.mu);
+    co_.waiting.push_back(&job);
+    if (co_.lingering) co_.cv_leader.notify_one();
+    // sleep until a leader has answered this query, or it is this caller's turn to lead
+    co_.cv.wait(lk, [&] { return job.done || (!co_.busy && co_.waiting.front() == &job); });
+    if (job.done) {
+      lk.unlock();
+      if (job.err) std::rethrow_exception(job.err);
+      return job.reply;
+    }
+    co_.busy = true;
+    // the callers of the previous pass are on their way back with their next query: give them a moment, so that the
+    // passes stay full instead of alternating between one early bird and everybody else
+    const uint32_t expect = std::min<uint32_t>(co_.last_b, kMqMaxQueries);
+    if (co_.waiting.size() < expect) {
+      int us = scan_tuning().coalesce_linger_us;
+      if (us < 0) {  // 5 % of a pass at ~6 TB/s
+        const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)stride_ / 6.0e6;
+        us = (int)std::min(300.0, std::max(20.0, 0.05 * pass_us));
+      }
+      if (us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        co_.lingering = true;
+        co_.cv_leader.wait_for(lk, std::chrono::microseconds(us), [&] { return co_.waiting.size() >= expect; });
+        co_.lingering = false;
+        coalesce_stats().lingers++;
+        coalesce_stats().linger_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      }
+    }
+    const size_t take = std::min<size_t>(co_.waiting.size(), kMqMaxQueries);
+    batch.assign(co_.waiting.begin(), co_.waiting.begin() + (long)take);
+    co_.waiting.erase(co_.waiting.begin(), co_.waiting.begin() + (long)take);
+  }
+  std::exception_ptr err;
+  try {
+    topk_pass(batch.data(), batch.size());
+  } catch (...) {
+    err = std::current_exception();
+  }
+  {
+    std::lock_guard<std::mutex> lk(co_.mu);
+    for (TopkJob *j : batch) {
+      if (err && !j->reply) j->err = err;
+      j->done = true;
+    }
+    co_.last_b = (uint32_t)batch.size();
+    co_.busy = false;
+  }
+  co_.cv.notify_all();
+  if (job.err) std::rethrow_exception(job.err);
+  return job.reply;
+}
+
+void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
+  if (!n_jobs) return;
+  if (n_jobs > kMqMaxQueries) throw std::runtime_error("topk_pass: more jobs than the multi-query scan has slots");
+  coalesce_stats().passes++;
+  coalesce_stats().queries += n_jobs;
   flush_if_needed();
   std::shared_lock<std::shared_mutex> g(mu);
+  if (n_jobs == 1) {  // nobody to share the pass with: the single-query path, as if there were no coalescer
+    jobs[0]->reply = topk_locked(jobs[0]->query, jobs[0]->k, jobs[0]->tctx, jobs[0]->order);
+    return;
+  }
+  const uint32_t n = n_rows_;
+  // jobs the multi-query pass can serve together; everything else (timed out, nothing to return) is answered right here
+  TopkJob *live[kMqMaxQueries];
+  size_t n_live = 0;
+  for (size_t i = 0; i < n_jobs; i++) {
+    TopkJob *j = jobs[i];
+    if (timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+    else if (!n || !j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
+    else live[n_live++] = j;
+  }
+  bool mq = n_live >= 2;
+  for (size_t i = 0; i < n_live; i++) mq = mq && mq_capable(live[i]->k);
+  if (mq) {
+    topk_pass_mq(live, n_live, n);
+    return;
+  }
+  for (size_t i = 0; i < n_live; i++) live[i]->reply = topk_locked(live[i]->query, live[i]->k, live[i]->tctx, live[i]->order);
+}
+
+// >= 2 queries, one pass: the multi-query scan writes one key array per query (bit for bit the single-query scan's), then
+// the same selection as a single query's -- for every query at once where the path has a batched form (small K: sampled
+// bound, one filter pass, one select workgroup per query; short arrays: one select workgroup per query), query by query
+// through the radix levels otherwise.  K differs per caller: the selection runs with the largest, every caller gets the
+// leading K of its sorted winners (the composite (key, row) order makes the top-K a prefix of the top-K').
+void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  c->ensure_mq(nj * stride_);
+  memset(c->h_mq_queries, 0, nj * stride_);
+  uint32_t kmax = 0;
+  for (size_t b = 0; b < nj; b++) {
+    uint8_t *dst = c->h_mq_queries + b * stride_;
+    memcpy(dst, jobs[b]->query, elem_bytes_);
+    if (metric == VecSimMetric_Cosine) normalize_host(dst);
+    kmax = std::max<uint32_t>(kmax, (uint32_t)std::min<size_t>(jobs[b]->k, n));
+  }
+  HIP_CHECK(hipMemcpyAsync(c->d_mq_queries, c->h_mq_queries, nj * stride_, hipMemcpyHostToDevice, c->stream));
+  const uint32_t ld = (uint32_t)round_up(n, 1024);
+  c->ensure_keys(nj * (size_t)ld);
+  c->ensure_out(nj * (size_t)kmax);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  if (!launch_scan_mq(d_rows_, stride_, ktype, kmetric, 0, n, c->d_mq_queries, stride_, (uint32_t)nj, c->d_keys, ld, c->stream))
+    throw std::runtime_error("multi-query scan refused a row shape the coalescer was gated on");
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+  // ---- selection
+  std::vector<Hit> hits[kMqMaxQueries];
+  bool have[kMqMaxQueries] = {false};
+  int mode = 0;
+  uint32_t *out_keys32 = reinterpret_cast<uint32_t *>(c->h_out_keys);
+  if (scan_tuning().filter_select && kmax <= 1024 && n <= (1u << 15)) {
+    mode = 1;
+    for (size_t b = 0; b < nj; b++) c->h_mq_n[b] = 0;
+    launch_batch_select_keys(c->d_keys, ld, n, kmax, (uint32_t)nj, c->h_out_rows, out_keys32, c->h_mq_n, kmax, c->stream);
+  } else if (scan_tuning().filter_select && kmax <= 32 && n >= (1u << 16)) {
+    mode = 2;
+    for (size_t b = 0; b < nj; b++) c->h_mq_n[b] = c->h_mq_over[b] = 0;
+    launch_sample_threshold_batch(c->d_keys, ld, n, 64, kmax, (uint32_t)nj, c->d_mq_tau, c->d_mq_cnt, c->stream);
+    launch_filter_keys_batch(c->d_keys, ld, n, (uint32_t)nj, c->d_mq_tau, c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, c->stream);
+    launch_batch_select_cand(c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, kmax, (uint32_t)nj, c->h_out_rows, out_keys32,
+                             c->h_mq_n, kmax, c->h_mq_over, c->stream);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+      coalesce_stats().mq_device_ns += (uint64_t)((double)ms * 1e6);
+      if (prof) {  // one pass over the corpus, whatever the number of queries it served
+        ScanProfile &pf = scan_profile();
+        pf.launches++;
+        pf.bytes += (uint64_t)n * elem_bytes_;
+        pf.nanos += (uint64_t)((double)ms * 1e6);
+      }
+    }
+  }
+  coalesce_stats().mq_passes++;
+  coalesce_stats().mq_queries += nj;
+  if (mode) {
+    for (size_t b = 0; b < nj; b++) {
+      const uint32_t got = std::min<uint32_t>(c->h_mq_n[b], kmax);
+      if ((mode == 2 && c->h_mq_over[b]) || got < std::min<uint32_t>(kmax, n)) continue;  // redone below
+      hits[b].resize(got);
+      for (uint32_t i = 0; i < got; i++) hits[b][i] = Hit{c->h_out_rows[b * kmax + i], (uint64_t)out_keys32[b * kmax + i]};
+      std::sort(hits[b].begin(), hits[b].end(), [](const Hit &x, const Hit &y) { return x.key != y.key ? x.key < y.key : x.row < y.row; });
+      have[b] = true;
+    }
+  }
+  for (size_t b = 0; b < nj; b++) {
+    if (have[b]) continue;
+    if (mode) coalesce_stats().mq_redo++;
+    radix_select(c.c, c->d_keys + b * (size_t)ld, 4, n, (uint32_t)std::min<size_t>(jobs[b]->k, n), Bound(), hits[b], nullptr);
+  }
+  for (size_t b = 0; b < nj; b++) {
+    TopkJob *j = jobs[b];
+    if (timed_out(j->tctx)) {
+      j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+      continue;
+    }
+    const size_t take = std::min<size_t>(hits[b].size(), j->k);
+    VecSimQueryReply *r = new_reply(take, VecSim_QueryReply_OK);
+    for (size_t i = 0; i < take; i++) r->results[i] = VecSimQueryResult{(size_t)label_at(hits[b][i].row), score_of(hits[b][i].key)};
+    sort_reply(r, j->order);
+    j->reply = r;
+  }
+}
+
+VecSimQueryReply *FlatIndex::topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order) {
   // the callback is polled at least once, even for an index smaller than one block (App. B-7)
   if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
   const uint32_t n = n_rows_;

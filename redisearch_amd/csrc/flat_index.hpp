@@ -11,6 +11,8 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <deque>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
@@ -67,6 +69,15 @@ struct QueryCtx {
   uint64_t *d_cand = nullptr;
   uint32_t *d_fcnt = nullptr;  // [0] cand_count [1] overflow [2] out_n
   uint32_t *h_fcnt = nullptr;
+  // coalesced pass (several queries per scan, scan_mq_kernels.hip): the queries [B][stride], per-query threshold /
+  // candidate list / counter, and the pinned per-query winner count + overflow flag
+  uint8_t *d_mq_queries = nullptr, *h_mq_queries = nullptr;
+  size_t mq_query_cap = 0;
+  float *d_mq_tau = nullptr;      // [kMqMaxQueries]
+  uint32_t *d_mq_cnt = nullptr;   // [kMqMaxQueries]
+  uint64_t *d_mq_cand = nullptr;  // [kMqMaxQueries][kCandCap]
+  uint32_t *h_mq_n = nullptr, *h_mq_over = nullptr;  // [kMqMaxQueries] each (one pinned block)
+  void ensure_mq(size_t query_bytes);
   // scan profiling (events read back after the query's own sync)
   bool prof_pending = false;
   uint32_t prof_rows = 0;
@@ -119,6 +130,35 @@ struct ScanProfile {
 };
 ScanProfile &scan_profile();
 
+// What became of the two-stage (shadow) scans of this process: a query that leaves the two-stage path runs the plain
+// fp32 scan -- exact, but four times the bytes -- so every way out is counted (RSGPU_GetTwoStageStats; bench.py puts the
+// counters into its two_stage sub-record).
+struct TwoStageStats {
+  enum { ATTEMPTS, OK, FB_SHAPE, FB_QUERY_OR_BAND, FB_FIRST_PASS_OVERFLOW, FB_BAND_OVERFLOW, FB_TOO_FEW, FB_SELECT, N };
+  std::atomic<uint64_t> v[N];
+  TwoStageStats() { for (auto &x : v) x = 0; }
+};
+TwoStageStats &two_stage_stats();
+
+// One VecSimIndex_TopKQuery call on its way through the coalescer (FlatIndex::topk): the caller's arguments, and what the
+// pass that served it left behind.
+struct TopkJob {
+  const void *query;
+  size_t k;
+  void *tctx;
+  VecSimQueryReply_Order order;
+  VecSimQueryReply *reply = nullptr;
+  std::exception_ptr err;
+  bool done = false;
+};
+
+// What the coalescer did (RSGPU_GetCoalesceStats; bench.py's concurrent_callers sub-record).
+struct CoalesceStats {
+  std::atomic<uint64_t> passes{0}, queries{0}, mq_passes{0}, mq_queries{0}, lingers{0}, linger_ns{0}, mq_device_ns{0},
+      mq_redo{0};
+};
+CoalesceStats &coalesce_stats();
+
 class FlatIndex {
  public:
   explicit FlatIndex(const BFParams &p, void *log_ctx);
@@ -149,6 +189,10 @@ class FlatIndex {
   // over topk().
   void topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
                   size_t *counts_out);
+  // up to kMqMaxQueries queries in ONE pass over the corpus (the coalescer's pass; also what topk_batch uses for indexes
+  // without an MFMA form): fills job->reply (or job->err) of every job.  Replies are bit-identical to topk()'s.
+  void topk_pass(TopkJob *const *jobs, size_t n_jobs);
+  bool mq_capable(size_t k) const;   // the multi-query scan can serve a top-k query of this index
   bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
   // the decision itself: N vectors under `labels` labels, `subset` of them pass the filter
   static bool prefer_adhoc_rule(size_t N, size_t labels, size_t dim, size_t subset);
@@ -239,6 +283,21 @@ class FlatIndex {
   uint32_t s8g_built_ = 0, s8g_seen_ = 0;  // rows [0, built) are quantised; rows [0, seen) went into max |x_i|
   bool ensure_shadow8g();            // true: d_shadow_ covers every row and bounds them
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
+  // the single-query path; the caller holds the shared lock and has flushed
+  VecSimQueryReply *topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order);
+  void topk_pass_mq(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // >= 2 jobs, shared lock held
+  bool coalescible(size_t k) const;  // the multi-query scan applies and concurrent calls are worth coalescing (knob, corpus size)
+  // ---- the coalescer: queries that arrive while a pass is in flight join the next pass -----------------------------
+  // Leader / follower: the caller at the head of the queue runs the pass for everybody queued behind it (at most
+  // kMqMaxQueries), on its own thread; the others sleep until their reply is there or it is their turn to lead.  A new
+  // leader waits a moment (linger) for the callers of the previous pass to come back with their next query.
+  struct Coalescer {
+    std::mutex mu;
+    std::condition_variable cv, cv_leader;
+    bool busy = false, lingering = false;
+    std::deque<TopkJob *> waiting;
+    uint32_t last_b = 1;  // jobs in the previous pass
+  } co_;
   // rows (and their shadow) grow without copies once they are large: virtual range + mapped chunks (grow_buffer.hpp);
   // d_rows_ / d_shadow_ cache the buffers' current base addresses
   GrowBuffer rows_buf_, shadow_buf_;

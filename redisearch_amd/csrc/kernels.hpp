@@ -67,6 +67,12 @@ struct ScanTuning {
                            // (no copy, no transient 2x HBM); 0 = hipMalloc + copy on every growth
   int vmm_chunk_mib = 0;        // 0 = automatic (256 MiB, or 1 GiB for corpora reserved large); A/B knob
   int vmm_reserve_factor = 64;  // virtual range of a mapped row matrix = factor x its size at mapping time (>= 64 GiB)
+  int coalesce = 1;        // VecSimIndex_TopKQuery calls that arrive while a pass is in flight join the next pass (one
+                           // multi-query scan, scan_mq_kernels.hip); replies are bit-identical to uncoalesced ones
+  int coalesce_linger_us = -1;  // -1: automatic (5 % of the estimated pass, 20..300 us); how long a new leader waits for the
+                                // callers of the previous pass to come back
+  int coalesce_min_mib = 64;    // corpora below this many MiB are latency-bound: concurrent single-query streams win
+  int mq_blocks_per_cu = 0;     // 0 = default (8): grid cap of the multi-query scan
   int shards = 0;          // > 1: VecSimIndex_New builds one index over this many device shards (sharded_index.hpp)
   int shard_replicas = 0;  // with shards: every shard holds the whole corpus, queries go round-robin
   int num_cus = 256;
@@ -80,6 +86,15 @@ ScanTuning &scan_tuning();
 // {0, query_scale, |q|^2, 0} as f32 bits.
 void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int metric, uint32_t row_begin,
                  uint32_t row_end, const void *query, void *keys, hipStream_t s, const float *row_meta = nullptr);
+
+// Several queries per corpus pass (scan_mq_kernels.hip): keys[b * keys_ld + row] = the key launch_scan would write for
+// queries + b * qstride, bit for bit, b < nq <= kMqMaxQueries.  fp32 / fp16 / bf16 rows, IP or L2, rows of 512 B .. 4 KiB
+// in the single-query scan's 32- / 64-lane shapes; false (nothing launched) for anything else.
+constexpr uint32_t kMqMaxQueries = 8;
+bool scan_mq_supported(int type, int metric, uint32_t stride16);
+bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
+                    const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s);
+const char *last_scan_mq_kernel_name(char *buf, size_t cap);
 
 // name of the kernel instantiation the last full scan of this process launched (template arguments + grid)
 const char *last_scan_kernel_name(char *buf, size_t cap);
@@ -178,6 +193,12 @@ void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint3
 // of 1024 groups of `per` sampled keys (per % 4 == 0, n >= 1024*per); also zeroes zero4[0..3] if given
 void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uint32_t k, float *tau_out,
                              uint32_t *zero4, hipStream_t s);
+// the two kernels above for n_queries key arrays at once (keys + b * keys_ld -> tau[b], cand + b * cap, cand_count[b];
+// the threshold kernel zeroes cand_count[b])
+void launch_sample_threshold_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t per, uint32_t k,
+                                   uint32_t n_queries, float *tau_out, uint32_t *cand_count, hipStream_t s);
+void launch_filter_keys_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t n_queries, const float *tau,
+                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s);
 // candidates of a single key array: append (row,key) of every key <= orderable(*tau) to cand[0..cap),
 // counting in cand_count[0]
 // (slack is added to *tau first: the two-stage scan's error bound)

@@ -1,0 +1,317 @@
+// scan_mq_kernels.hip -- the FLAT distance scan for SEVERAL queries per corpus pass (gfx950, hand-written HIP).
+//
+// Why it exists.  VecSim's C ABI answers one query per call (reference src/iterators/hybrid_reader.c:374) and RediSearch
+// issues those calls from N worker threads (src/util/workers.c:58,104).  N concurrent single-query scans are N
+// independent passes over the same 30 GB sharing one HBM: the aggregate stays at one pass per ~4.8 ms however many
+// callers there are.  The coalescer in flat_index.cpp lets queries that arrive while a pass is in flight join the next
+// pass; this kernel is that pass: every row is read ONCE and scored against up to 8 queries held in registers.
+//
+// Bit-identity with scan_kernel is by construction, not by tolerance (scan_ops.hpp):
+//   * same chunk-to-lane map (lane l of a G-lane group owns chunks l, l+G, ...), same per-lane operation order
+//     (chunk by chunk, element by element, one fused multiply-add per element);
+//   * same reduction tree: scan_kernel folds a group with v += shfl_xor(v, m) for m = G/2 ... 1.  Here a lane holds
+//     V = U*B partial sums (U rows x B queries); at mask m a lane pairs value i with value i + V/2, KEEPS the one its
+//     own bit of m selects and hands the other to its partner, so the number of live values halves per step while every
+//     surviving value is still "own partial + partner's partial" for exactly the lane pairs of the butterfly above --
+//     fp32 addition is commutative, so the bits are the butterfly's.  V/2 + V/4 + ... ~ V exchanges for V sums instead
+//     of 6 V; masks 32 and 16 are one v_permlane32_swap / v_permlane16_swap (gfx950) per PAIR of values.
+//   * FLOAT32: two queries share one v_pk_fma_f32 (the row element broadcast through op_sel, the two queries' elements
+//     in a register pair) -- each query's accumulator still sees its products in the single-query order.
+// HBM-bound like the single-query scan: B = 8 costs ~70 VALU instructions per row and wavefront, ~1.2 ms of a 4.7 ms
+// pass at 10 M x 768.  Keys go to keys[b * keys_ld + row], one array per query, and feed the same selection kernels.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+
+#include "kernels.hpp"
+#include "scan_ops.hpp"
+
+namespace rsgpu {
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+
+constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// ---- the halving butterfly over a group of G lanes: M = current mask, CUR = live values per lane ----------------------
+template <int M, int CUR>
+struct MqRed {
+  static __device__ __forceinline__ void run(float *v, uint32_t gl) {
+    if constexpr (CUR >= 2) {
+      constexpr int H = CUR / 2;
+#pragma unroll
+      for (int i = 0; i < H; i++) {
+        const float a = v[i], b = v[i + H];
+        if constexpr (M == 32) {
+          // a' = {a.lo32, b.lo32}, b' = {a.hi32, b.hi32}: lanes < 32 get a[l] + a[l+32], lanes >= 32 b[l-32] + b[l]
+          const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+          v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        } else if constexpr (M == 16) {
+          // odd 16-lane rows of a <-> even rows of b: even rows get a[l] + a[l+16], odd rows b[l-16] + b[l]
+          const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+          v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+        } else {
+          const bool hi = (gl & (uint32_t)M) != 0;
+          const float keep = hi ? b : a, send = hi ? a : b;
+          v[i] = keep + __shfl_xor(send, M, 64);
+        }
+      }
+      if constexpr (M > 1) MqRed<M / 2, H>::run(v, gl);
+    } else {
+      v[0] += __shfl_xor(v[0], M, 64);
+      if constexpr (M > 1) MqRed<M / 2, 1>::run(v, gl);
+    }
+  }
+};
+
+// ---- B queries in registers + the per-lane partial sums of U rows against them -----------------------------------------
+// generic: one Op<TYPE, METRIC>::add per (row, query, chunk) -- fp16 / bf16
+template <int TYPE, int METRIC, int ITERS, int B>
+struct MqQ {
+  u4 q[B][ITERS];
+  __device__ __forceinline__ void load(const u4 *__restrict__ queries, uint32_t qstride16, uint32_t lane, uint32_t G,
+                                       uint32_t chunks, uint32_t nq) {
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint32_t bb = (uint32_t)b < nq ? (uint32_t)b : nq - 1;  // unused slots repeat the last query, never stored
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) {
+        const uint32_t c = lane + i * G;
+        q[b][i] = c < chunks ? queries[(size_t)bb * qstride16 + c] : zero4();
+      }
+    }
+  }
+  template <int U>
+  __device__ __forceinline__ void partial(const u4 (&x)[U][ITERS], float *v) const {
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ITERS; i++) acc = Op<TYPE, METRIC>::add(acc, x[u][i], q[b][i]);
+        v[b * U + u] = acc;
+      }
+  }
+};
+// FLOAT32: query pairs in register pairs, one packed FMA per element and pair
+template <int METRIC, int ITERS, int B>
+struct MqQ<KT_F32, METRIC, ITERS, B> {
+  f2 qp[ITERS][B / 2][4];
+  __device__ __forceinline__ void load(const u4 *__restrict__ queries, uint32_t qstride16, uint32_t lane, uint32_t G,
+                                       uint32_t chunks, uint32_t nq) {
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint32_t bb = (uint32_t)b < nq ? (uint32_t)b : nq - 1;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) {
+        const uint32_t c = lane + i * G;
+        const u4 t = c < chunks ? queries[(size_t)bb * qstride16 + c] : zero4();
+        const float e[4] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (b & 1) qp[i][b / 2][j].y = e[j];
+          else qp[i][b / 2][j].x = e[j];
+        }
+      }
+    }
+  }
+  template <int U>
+  __device__ __forceinline__ void partial(const u4 (&x)[U][ITERS], float *v) const {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      f2 acc[B / 2];
+#pragma unroll
+      for (int p = 0; p < B / 2; p++) acc[p] = (f2){0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) {
+        const float e[4] = {__uint_as_float(x[u][i].x), __uint_as_float(x[u][i].y), __uint_as_float(x[u][i].z),
+                            __uint_as_float(x[u][i].w)};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const f2 xs = (f2){e[j], e[j]};
+#pragma unroll
+          for (int p = 0; p < B / 2; p++) {
+            if (METRIC == KM_L2) {
+              const f2 d = xs - qp[i][p][j];
+              acc[p] = __builtin_elementwise_fma(d, d, acc[p]);
+            } else {
+              acc[p] = __builtin_elementwise_fma(xs, qp[i][p][j], acc[p]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < B / 2; p++) {
+        v[(2 * p) * U + u] = acc[p].x;
+        v[(2 * p + 1) * U + u] = acc[p].y;
+      }
+    }
+  }
+};
+
+// TYPE / METRIC / G / ITERS as in scan_kernel (scan_ops.hpp pick_shape); U rows per group and step; B query slots.
+// Chunks are always masked (c < chunks): a compare per load next to a 1 KiB request.
+template <int TYPE, int METRIC, int G, int ITERS, int U, int B>
+__global__ __launch_bounds__(256, 2) void scan_mq_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t chunks,
+                                                         uint32_t row_begin, uint32_t row_end,
+                                                         const u4 *__restrict__ queries, uint32_t qstride16, uint32_t nq,
+                                                         uint32_t *__restrict__ keys, uint32_t keys_ld) {
+  constexpr int GPB = 256 / G;
+  constexpr int V = U * B, LG = ilog2(G), LV = ilog2(V);
+  constexpr int H = LV < LG ? LV : LG;   // halving steps
+  constexpr int CNT = V >> H;            // finished sums per lane
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t grp = threadIdx.x / G;
+
+  MqQ<TYPE, METRIC, ITERS, B> q;
+  q.load(queries, qstride16, lane, G, chunks, nq);
+
+  constexpr bool INTERLEAVE = G < 64;  // (row <-> group mapping of scan_kernel)
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  const uint32_t tile0 = INTERLEAVE ? blockIdx.x : blockIdx.x * GPB + grp;
+  const uint32_t tile_step = INTERLEAVE ? gridDim.x : gridDim.x * GPB;
+  const uint32_t u_stride = INTERLEAVE ? GPB : 1;
+  // which finished sums this lane ends up with: the top H bits of its group lane are the top H bits of j = b * U + u
+  const uint32_t jtop = lane >> (LG - H);
+  const bool writer = (lane & ((1u << (LG - H)) - 1u)) == 0;
+
+  for (uint32_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + (INTERLEAVE ? grp : 0);
+    u4 x[U][ITERS];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * u_stride;
+      if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) {
+        const uint32_t c = lane + i * G;
+        x[u][i] = c < chunks ? load16<true>(p + c) : zero4();
+      }
+    }
+    float v[V];
+    q.template partial<U>(x, v);
+    if constexpr (G > 1) MqRed<G / 2, V>::run(v, lane);
+#pragma unroll
+    for (int p = 0; p < CNT; p++) {
+      const uint32_t j = jtop * CNT + p, b = j / U, u = j % U;
+      const uint32_t r = r0 + u * u_stride;
+      if (writer && b < nq && r < row_end) keys[(size_t)b * keys_ld + r] = to_key(finish<TYPE, METRIC>(v[p], zero4()));
+    }
+  }
+}
+
+std::atomic<uint64_t> g_last_mq{0};
+
+struct MqCtx {
+  const u4 *rows;
+  uint32_t stride16, chunks, row_begin, row_end;
+  const u4 *queries;
+  uint32_t qstride16, nq;
+  uint32_t *keys;
+  uint32_t keys_ld;
+  hipStream_t s;
+};
+
+template <int TYPE, int METRIC, int G, int ITERS, int U, int B>
+void mq_launch_one(const MqCtx &c) {
+  const ScanTuning &t = scan_tuning();
+  constexpr int GPB = 256 / G;
+  const uint32_t n = c.row_end - c.row_begin;
+  const uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : 8));
+  const uint32_t grid = need < cap ? need : cap;
+  if (!grid) return;
+  g_last_mq = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
+              ((uint64_t)B << 21) | ((uint64_t)grid << 41);
+  hipLaunchKernelGGL((scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
+                     c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+}
+
+template <int TYPE, int METRIC, int G, int ITERS, int U>
+void mq_launch_b(const MqCtx &c) {
+  // fp16 / bf16 with eight queries: the widening temporaries of three or four chunks do not fit 256 registers next to
+  // U rows in flight -- fewer rows per step (register budgets: scripts/kernel_resources.py, tests/test_kernel_resources_cpu.py)
+  constexpr int U8 = (TYPE != KT_F32 && ITERS >= 3) ? 2 : U;
+  if (c.nq <= 4) {
+    mq_launch_one<TYPE, METRIC, G, ITERS, U, 4>(c);
+  } else if constexpr (TYPE != KT_F32 && ITERS >= 4) {  // 4 KiB fp16 / bf16 rows: eight queries spill -- two passes of four
+    MqCtx lo = c, hi = c;
+    lo.nq = 4;
+    hi.nq = c.nq - 4;
+    hi.queries = c.queries + 4 * (size_t)c.qstride16;
+    hi.keys = c.keys + 4 * (size_t)c.keys_ld;
+    mq_launch_one<TYPE, METRIC, G, ITERS, U, 4>(lo);
+    mq_launch_one<TYPE, METRIC, G, ITERS, U, 4>(hi);
+  } else {
+    mq_launch_one<TYPE, METRIC, G, ITERS, U8, 8>(c);
+  }
+}
+
+template <int TYPE, int METRIC>
+bool mq_launch_shape(const MqCtx &c) {
+  const Shape sh = pick_shape(c.chunks);
+  if (sh.G == 64) {
+    switch (sh.ITERS) {
+      case 1: mq_launch_b<TYPE, METRIC, 64, 1, 4>(c); return true;
+      case 2: mq_launch_b<TYPE, METRIC, 64, 2, 4>(c); return true;
+      case 3: mq_launch_b<TYPE, METRIC, 64, 3, 4>(c); return true;
+      case 4: mq_launch_b<TYPE, METRIC, 64, 4, 2>(c); return true;
+      default: return false;
+    }
+  }
+  if (sh.G == 32) {
+    switch (sh.ITERS) {
+      case 1: mq_launch_b<TYPE, METRIC, 32, 1, 4>(c); return true;
+      case 3: mq_launch_b<TYPE, METRIC, 32, 3, 4>(c); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+bool scan_mq_supported(int type, int metric, uint32_t stride16) {
+  if (type != KT_F32 && type != KT_F16 && type != KT_BF16) return false;
+  if (metric != KM_IP && metric != KM_L2) return false;
+  const Shape sh = pick_shape(stride16);
+  return (sh.G == 64 && sh.ITERS >= 1 && sh.ITERS <= 4) || (sh.G == 32 && (sh.ITERS == 1 || sh.ITERS == 3));
+}
+
+bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
+                    const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s) {
+  if (row_end <= row_begin || !nq || nq > kMqMaxQueries || !scan_mq_supported(type, metric, (uint32_t)(stride / 16))) return false;
+  const MqCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
+                (const u4 *)queries, (uint32_t)(qstride / 16), nq, keys, keys_ld, s};
+#define RSGPU_MQ_CASE(T)                                                \
+  case T:                                                               \
+    return metric == KM_L2 ? mq_launch_shape<T, KM_L2>(c) : mq_launch_shape<T, KM_IP>(c);
+  switch (type) {
+    RSGPU_MQ_CASE(KT_F32)
+    RSGPU_MQ_CASE(KT_F16)
+    RSGPU_MQ_CASE(KT_BF16)
+    default: return false;
+  }
+#undef RSGPU_MQ_CASE
+}
+
+const char *last_scan_mq_kernel_name(char *buf, size_t cap) {
+  static const char *tn[] = {"f32", "f64", "bf16", "f16", "i8", "u8"}, *mn[] = {"L2", "IP", "COS", "IPS", "L2S", "?", "?", "?"};
+  const uint64_t v = g_last_mq.load();
+  if (!v) {
+    snprintf(buf, cap, "none");
+    return buf;
+  }
+  snprintf(buf, cap, "scan_mq_kernel<%s,%s,G=%u,ITERS=%u,U=%u,B=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7],
+           (unsigned)((v >> 6) & 127), (unsigned)((v >> 13) & 15), (unsigned)((v >> 17) & 15), (unsigned)((v >> 21) & 31),
+           (unsigned)(v >> 41));
+  return buf;
+}
+
+}  // namespace rsgpu

@@ -299,12 +299,18 @@ __device__ __forceinline__ uint32_t f2key_dev(float f) {
 // the t-th 16-byte chunk of every slab, so each load instruction is a fully coalesced 16 KiB sweep and all
 // of a thread's loads are independent.  K distinct keys are <= tau, so tau bounds the K-th smallest key of
 // the whole array.  One workgroup.
+// Several queries at once (a coalesced pass, scan_mq_kernels.hip): grid (1, B), query b reads keys + b * keys_ld, writes
+// tau_out[b] and zeroes zero_q[b] (its candidate counter).
 __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                                 uint32_t slab_stride, uint32_t slabs, uint32_t k,
                                                                 float *__restrict__ tau_out,
-                                                                uint32_t *__restrict__ zero4) {
+                                                                uint32_t *__restrict__ zero4, uint32_t keys_ld,
+                                                                uint32_t *__restrict__ zero_q) {
   const uint32_t t = threadIdx.x;
+  keys += (size_t)blockIdx.y * keys_ld;
+  tau_out += blockIdx.y;
   if (zero4 && t < 4) zero4[t] = 0;  // the filter pass's counters: saves a memset on the query's critical path
+  if (zero_q && t == 0) zero_q[blockIdx.y] = 0;
   uint32_t m = 0xFFFFFFFFu;
   for (uint32_t c0 = 0; c0 < slabs; c0 += 16) {
     u4 v[16];
@@ -363,10 +369,15 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
 
 // One streaming pass: (row, key) of every key <= orderable(*tau).  Four independent 16-byte loads per
 // thread and step, ONE ballot per step on the minimum of the 16 keys (hits are rare), then the appends.
+// (grid.y > 1: query b = blockIdx.y reads keys + b * keys_ld and tau[b], appends to cand + b * cap counting in cand_count[b])
 __global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                           const float *__restrict__ tau, uint2 *__restrict__ cand,
-                                                          uint32_t *__restrict__ cand_count, uint32_t cap, float slack) {
-  const uint32_t max_key = f2key_dev(tau[0] + slack);
+                                                          uint32_t *__restrict__ cand_count, uint32_t cap, float slack,
+                                                          uint32_t keys_ld) {
+  keys += (size_t)blockIdx.y * keys_ld;
+  cand += (size_t)blockIdx.y * cap;
+  cand_count += blockIdx.y;
+  const uint32_t max_key = f2key_dev(tau[blockIdx.y] + slack);
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t n4 = n / 4;  // whole 16-byte chunks; the 0..3 keys behind them are handled at the end
   const u4 *k4 = (const u4 *)keys;
@@ -475,7 +486,22 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
   const uint32_t slabs = per / 4;  // caller guarantees n >= 1024 * per (>= 4096 * slabs)
   const uint32_t slab_stride = slabs > 1 ? ((n - 4096) / (slabs - 1)) & ~3u : 0;
   hipLaunchKernelGGL(sample_threshold_kernel, dim3(1), dim3(1024), 0, s, keys, n, slab_stride, slabs, k, tau_out,
-                     zero4);
+                     zero4, 0u, (uint32_t *)nullptr);
+}
+
+void launch_sample_threshold_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t per, uint32_t k,
+                                   uint32_t n_queries, float *tau_out, uint32_t *cand_count, hipStream_t s) {
+  const uint32_t slabs = per / 4;
+  const uint32_t slab_stride = slabs > 1 ? ((n - 4096) / (slabs - 1)) & ~3u : 0;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3(1, n_queries), dim3(1024), 0, s, keys, n, slab_stride, slabs, k, tau_out,
+                     (uint32_t *)nullptr, keys_ld, cand_count);
+}
+
+void launch_filter_keys_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t n_queries, const float *tau,
+                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s) {
+  uint32_t need = (n / 4 + 1023) / 1024;
+  hipLaunchKernelGGL(filter_keys_kernel, dim3(need ? need : 1, n_queries), dim3(256), 0, s, keys, n, tau, (uint2 *)cand,
+                     cand_count, cap, 0.0f, keys_ld);
 }
 
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
@@ -483,7 +509,7 @@ void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void
   // one step per workgroup (a capped grid left ~20 % of the workgroups a second step: 21 us instead of ~12)
   uint32_t need = (n / 4 + 1023) / 1024;
   hipLaunchKernelGGL(filter_keys_kernel, dim3(need ? need : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap,
-                     slack);
+                     slack, 0u);
 }
 
 namespace {

@@ -644,6 +644,28 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
   if (total_ms) *total_ms = (double)scan_profile().nanos.load() / 1e6;
   if (bytes) *bytes = scan_profile().bytes.load();
 }
+void RSGPU_GetCoalesceStats(uint64_t out[8]) {
+  if (!out) return;
+  CoalesceStats &c = coalesce_stats();
+  const uint64_t v[8] = {c.passes.load(), c.queries.load(), c.mq_passes.load(), c.mq_queries.load(),
+                         c.lingers.load(), c.linger_ns.load(), c.mq_device_ns.load(), c.mq_redo.load()};
+  memcpy(out, v, sizeof v);
+}
+void RSGPU_ResetCoalesceStats(void) {
+  CoalesceStats &c = coalesce_stats();
+  c.passes = c.queries = c.mq_passes = c.mq_queries = c.lingers = c.linger_ns = c.mq_device_ns = c.mq_redo = 0;
+}
+const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap) {
+  if (!buf || !cap) return "";
+  return last_scan_mq_kernel_name(buf, cap);
+}
+void RSGPU_GetTwoStageStats(uint64_t out[8]) {
+  if (!out) return;
+  for (int i = 0; i < 8; i++) out[i] = i < TwoStageStats::N ? two_stage_stats().v[i].load() : 0;
+}
+void RSGPU_ResetTwoStageStats(void) {
+  for (auto &x : two_stage_stats().v) x = 0;
+}
 const char *RSGPU_GetLastScanKernel(char *buf, size_t cap) {
   if (!buf || !cap) return "";
   return last_scan_kernel_name(buf, cap);
@@ -664,6 +686,10 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
   else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;
   else if (!strcmp(key, "shadow8")) scan_tuning().shadow8 = value;
+  else if (!strcmp(key, "coalesce")) scan_tuning().coalesce = value;
+  else if (!strcmp(key, "coalesce_linger_us")) scan_tuning().coalesce_linger_us = value;
+  else if (!strcmp(key, "coalesce_min_mib")) scan_tuning().coalesce_min_mib = value;
+  else if (!strcmp(key, "mq_blocks_per_cu")) scan_tuning().mq_blocks_per_cu = value;
   else if (!strcmp(key, "vmm")) scan_tuning().vmm = value;
   else if (!strcmp(key, "vmm_chunk_mib")) scan_tuning().vmm_chunk_mib = value;
   else if (!strcmp(key, "vmm_reserve_factor")) scan_tuning().vmm_reserve_factor = value > 0 ? value : 64;

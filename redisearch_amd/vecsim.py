@@ -192,6 +192,11 @@ ABI = {
     "RSGPU_ResetProfile": (None, []),
     "RSGPU_GetScanProfile": (None, [C.POINTER(C.c_uint64), C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
     "RSGPU_GetLastScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
+    "RSGPU_GetTwoStageStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_ResetCoalesceStats": (None, []),
+    "RSGPU_GetLastMqScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
+    "RSGPU_ResetTwoStageStats": (None, []),
     "RSGPU_SetTuning": (_i, [C.c_char_p, _i]),
     "RSGPU_ReleaseWorkspaces": (None, []),
 }
@@ -557,6 +562,37 @@ def set_log_callback(fn):
 def last_scan_kernel():
     buf = C.create_string_buffer(256)
     return load().RSGPU_GetLastScanKernel(buf, 256).decode()
+
+
+def coalesce_stats(reset=False):
+    """RSGPU_GetCoalesceStats as a dict."""
+    a = (C.c_uint64 * 8)()
+    load().RSGPU_GetCoalesceStats(a)
+    if reset:
+        load().RSGPU_ResetCoalesceStats()
+    names = ("passes", "queries", "mq_passes", "mq_queries", "lingers", "linger_ns", "mq_device_ns", "mq_redo")
+    return {n: int(a[i]) for i, n in enumerate(names)}
+
+
+def last_mq_scan_kernel():
+    buf = C.create_string_buffer(256)
+    return load().RSGPU_GetLastMqScanKernel(buf, 256).decode()
+
+
+TWO_STAGE_STAT_NAMES = ("attempts", "two_stage", "fallback_shape", "fallback_query_or_band_not_finite",
+                        "fallback_first_pass_overflow", "fallback_band_overflow", "fallback_fewer_than_k_in_band",
+                        "fallback_final_select")
+
+
+def two_stage_stats(reset=False):
+    """RSGPU_GetTwoStageStats as a dict (+ "fallbacks" = every way out to the plain fp32 scan)."""
+    a = (C.c_uint64 * 8)()
+    load().RSGPU_GetTwoStageStats(a)
+    if reset:
+        load().RSGPU_ResetTwoStageStats()
+    d = {n: int(a[i]) for i, n in enumerate(TWO_STAGE_STAT_NAMES)}
+    d["fallbacks"] = d["attempts"] - d["two_stage"]
+    return d
 
 
 def scan_profile():
