@@ -137,7 +137,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
     }
   };
-  if (!gemm_ok) {
+  if (!gemm_ok || !scan_tuning().batch_mfma) {
     all_single();
     return;
   }

@@ -72,7 +72,9 @@ struct ScanTuning {
   int coalesce_linger_us = -1;  // -1: automatic (5 % of the estimated pass, 20..300 us); how long a new leader waits for the
                                 // callers of the previous pass to come back
   int coalesce_min_mib = 64;    // corpora below this many MiB are latency-bound: concurrent single-query streams win
-  int mq_blocks_per_cu = 0;     // 0 = default (8): grid cap of the multi-query scan
+  int mq_blocks_per_cu = 0;     // 0 = default: grid cap of the multi-query scan (4 per CU up to four queries, 8 beyond)
+  int batch_mfma = 1;           // RSGPU_FlatIndex_TopKBatch: 0 = never the matrix-core passes (every batch through the exact
+                                // multi-query scan -- bit-identical to single queries; tests and A/B)
   int shards = 0;          // > 1: VecSimIndex_New builds one index over this many device shards (sharded_index.hpp)
   int shard_replicas = 0;  // with shards: every shard holds the whole corpus, queries go round-robin
   int num_cus = 256;

@@ -17,8 +17,13 @@
 //     of 6 V; masks 32 and 16 are one v_permlane32_swap / v_permlane16_swap (gfx950) per PAIR of values.
 //   * FLOAT32: two queries share one v_pk_fma_f32 (the row element broadcast through op_sel, the two queries' elements
 //     in a register pair) -- each query's accumulator still sees its products in the single-query order.
-// HBM-bound like the single-query scan: B = 8 costs ~70 VALU instructions per row and wavefront, ~1.2 ms of a 4.7 ms
-// pass at 10 M x 768.  Keys go to keys[b * keys_ld + row], one array per query, and feed the same selection kernels.
+// HBM-bound like the single-query scan: B = 8 costs ~70 VALU instructions per row and wavefront next to 3 KiB of loads.
+// Measured at 10 M x 768 fp32 (profiles/r03_mq_scan_ab.txt): 4.68-4.79 ms per pass with 2-4 queries, 5.07 ms with 8
+// (6.06 TB/s = 76 % of the HBM peak) against 4.71-4.78 ms for the single-query scan.  Loads must stay UNCONDITIONAL (see
+// load_chunk): the first version predicated them and hipcc serialised every one behind its own s_waitcnt vmcnt(0) --
+// 8.7 ms.  A variant that streamed the rows through per-wave LDS rings by DMA (global_load_lds, no destination registers,
+// five slots in flight per wave) was built, was bit-identical, and lost: 5.26-5.38 ms with 8 queries, 4.80-5.00 with 4 --
+// removed.  Keys go to keys[b * keys_ld + row], one array per query, and feed the same selection kernels.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -34,6 +39,16 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+
+// chunk c of a row / query.  EXACT: every lane's chunks exist (chunks == G * ITERS).  Otherwise the load is still
+// UNCONDITIONAL -- from the last chunk -- and the value is dropped afterwards: a predicated load becomes a branch with
+// its own s_waitcnt vmcnt(0), i.e. one load in flight at a time.
+template <bool EXACT, bool NT>
+__device__ __forceinline__ u4 load_chunk(const u4 *__restrict__ p, uint32_t c, uint32_t chunks) {
+  if (EXACT) return load16<NT>(p + c);
+  const u4 t = load16<NT>(p + (c < chunks ? c : chunks - 1));
+  return c < chunks ? t : zero4();
+}
 
 // ---- the halving butterfly over a group of G lanes: M = current mask, CUR = live values per lane ----------------------
 template <int M, int CUR>
@@ -71,6 +86,7 @@ struct MqRed {
 template <int TYPE, int METRIC, int ITERS, int B>
 struct MqQ {
   u4 q[B][ITERS];
+  template <bool EXACT>
   __device__ __forceinline__ void load(const u4 *__restrict__ queries, uint32_t qstride16, uint32_t lane, uint32_t G,
                                        uint32_t chunks, uint32_t nq) {
 #pragma unroll
@@ -79,27 +95,31 @@ struct MqQ {
 #pragma unroll
       for (int i = 0; i < ITERS; i++) {
         const uint32_t c = lane + i * G;
-        q[b][i] = c < chunks ? queries[(size_t)bb * qstride16 + c] : zero4();
+        q[b][i] = load_chunk<EXACT, false>(queries + (size_t)bb * qstride16, c, chunks);
       }
     }
   }
-  template <int U>
-  __device__ __forceinline__ void partial(const u4 (&x)[U][ITERS], float *v) const {
+  // the B per-lane partial sums of one row
+  __device__ __forceinline__ void partial_row(const u4 (&x)[ITERS], float (&out)[B]) {
 #pragma unroll
-    for (int u = 0; u < U; u++)
+    for (int b = 0; b < B; b++) {
+      float acc = 0.0f;
 #pragma unroll
-      for (int b = 0; b < B; b++) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < ITERS; i++) acc = Op<TYPE, METRIC>::add(acc, x[u][i], q[b][i]);
-        v[b * U + u] = acc;
+      for (int i = 0; i < ITERS; i++) {
+        // (opaque: otherwise the widening of the query's halves -- loop invariant -- is hoisted out of the row loop and
+        // the queries take twice the registers, as floats)
+        asm("" : "+v"(q[b][i]));
+        acc = Op<TYPE, METRIC>::add(acc, x[i], q[b][i]);
       }
+      out[b] = acc;
+    }
   }
 };
 // FLOAT32: query pairs in register pairs, one packed FMA per element and pair
 template <int METRIC, int ITERS, int B>
 struct MqQ<KT_F32, METRIC, ITERS, B> {
   f2 qp[ITERS][B / 2][4];
+  template <bool EXACT>
   __device__ __forceinline__ void load(const u4 *__restrict__ queries, uint32_t qstride16, uint32_t lane, uint32_t G,
                                        uint32_t chunks, uint32_t nq) {
 #pragma unroll
@@ -108,7 +128,7 @@ struct MqQ<KT_F32, METRIC, ITERS, B> {
 #pragma unroll
       for (int i = 0; i < ITERS; i++) {
         const uint32_t c = lane + i * G;
-        const u4 t = c < chunks ? queries[(size_t)bb * qstride16 + c] : zero4();
+        const u4 t = load_chunk<EXACT, false>(queries + (size_t)bb * qstride16, c, chunks);
         const float e[4] = {__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -118,43 +138,37 @@ struct MqQ<KT_F32, METRIC, ITERS, B> {
       }
     }
   }
-  template <int U>
-  __device__ __forceinline__ void partial(const u4 (&x)[U][ITERS], float *v) const {
+  __device__ __forceinline__ void partial_row(const u4 (&x)[ITERS], float (&out)[B]) {
+    f2 acc[B / 2];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      f2 acc[B / 2];
+    for (int p = 0; p < B / 2; p++) acc[p] = (f2){0.0f, 0.0f};
 #pragma unroll
-      for (int p = 0; p < B / 2; p++) acc[p] = (f2){0.0f, 0.0f};
+    for (int i = 0; i < ITERS; i++) {
+      const float e[4] = {__uint_as_float(x[i].x), __uint_as_float(x[i].y), __uint_as_float(x[i].z), __uint_as_float(x[i].w)};
 #pragma unroll
-      for (int i = 0; i < ITERS; i++) {
-        const float e[4] = {__uint_as_float(x[u][i].x), __uint_as_float(x[u][i].y), __uint_as_float(x[u][i].z),
-                            __uint_as_float(x[u][i].w)};
+      for (int j = 0; j < 4; j++) {
+        const f2 xs = (f2){e[j], e[j]};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const f2 xs = (f2){e[j], e[j]};
-#pragma unroll
-          for (int p = 0; p < B / 2; p++) {
-            if (METRIC == KM_L2) {
-              const f2 d = xs - qp[i][p][j];
-              acc[p] = __builtin_elementwise_fma(d, d, acc[p]);
-            } else {
-              acc[p] = __builtin_elementwise_fma(xs, qp[i][p][j], acc[p]);
-            }
+        for (int p = 0; p < B / 2; p++) {
+          if (METRIC == KM_L2) {
+            const f2 d = xs - qp[i][p][j];
+            acc[p] = __builtin_elementwise_fma(d, d, acc[p]);
+          } else {
+            acc[p] = __builtin_elementwise_fma(xs, qp[i][p][j], acc[p]);
           }
         }
       }
+    }
 #pragma unroll
-      for (int p = 0; p < B / 2; p++) {
-        v[(2 * p) * U + u] = acc[p].x;
-        v[(2 * p + 1) * U + u] = acc[p].y;
-      }
+    for (int p = 0; p < B / 2; p++) {
+      out[2 * p] = acc[p].x;
+      out[2 * p + 1] = acc[p].y;
     }
   }
 };
 
 // TYPE / METRIC / G / ITERS as in scan_kernel (scan_ops.hpp pick_shape); U rows per group and step; B query slots.
-// Chunks are always masked (c < chunks): a compare per load next to a 1 KiB request.
-template <int TYPE, int METRIC, int G, int ITERS, int U, int B>
+template <int TYPE, int METRIC, int G, int ITERS, int U, int B, bool EXACT>
 __global__ __launch_bounds__(256, 2) void scan_mq_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t chunks,
                                                          uint32_t row_begin, uint32_t row_end,
                                                          const u4 *__restrict__ queries, uint32_t qstride16, uint32_t nq,
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void scan_mq_kernel(const u4 *__restrict__ 
   const uint32_t grp = threadIdx.x / G;
 
   MqQ<TYPE, METRIC, ITERS, B> q;
-  q.load(queries, qstride16, lane, G, chunks, nq);
+  q.template load<EXACT>(queries, qstride16, lane, G, chunks, nq);
 
   constexpr bool INTERLEAVE = G < 64;  // (row <-> group mapping of scan_kernel)
   const uint32_t n = row_end - row_begin;
@@ -191,11 +205,17 @@ __global__ __launch_bounds__(256, 2) void scan_mq_kernel(const u4 *__restrict__ 
 #pragma unroll
       for (int i = 0; i < ITERS; i++) {
         const uint32_t c = lane + i * G;
-        x[u][i] = c < chunks ? load16<true>(p + c) : zero4();
+        x[u][i] = load_chunk<EXACT, true>(p, c, chunks);
       }
     }
     float v[V];
-    q.template partial<U>(x, v);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float pr[B];
+      q.partial_row(x[u], pr);
+#pragma unroll
+      for (int b = 0; b < B; b++) v[b * U + u] = pr[b];
+    }
     if constexpr (G > 1) MqRed<G / 2, V>::run(v, lane);
 #pragma unroll
     for (int p = 0; p < CNT; p++) {
@@ -223,14 +243,21 @@ void mq_launch_one(const MqCtx &c) {
   const ScanTuning &t = scan_tuning();
   constexpr int GPB = 256 / G;
   const uint32_t n = c.row_end - c.row_begin;
+  const bool exact = c.chunks == (uint32_t)(G * ITERS);
   const uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
-  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : 8));
+  // grid cap per CU, measured at 10 M x 768 fp32 (profiles/r03_mq_scan_ab.txt): four-query kernel 4 (4.68 ms; 2: 5.7-6.1,
+  // 8: 4.74, 16: 4.95), eight-query kernel 8 (5.07 ms; 2: 5.14, 4: 5.31, 16: 5.09)
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : (B <= 4 ? 4 : 8)));
   const uint32_t grid = need < cap ? need : cap;
   if (!grid) return;
   g_last_mq = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
-              ((uint64_t)B << 21) | ((uint64_t)grid << 41);
-  hipLaunchKernelGGL((scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
-                     c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+              ((uint64_t)B << 21) | ((uint64_t)exact << 26) | ((uint64_t)grid << 41);
+  if (exact)
+    hipLaunchKernelGGL((scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B, true>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
+                       c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+  else
+    hipLaunchKernelGGL((scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B, false>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
+                       c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
 }
 
 template <int TYPE, int METRIC, int G, int ITERS, int U>
@@ -240,7 +267,7 @@ void mq_launch_b(const MqCtx &c) {
   constexpr int U8 = (TYPE != KT_F32 && ITERS >= 3) ? 2 : U;
   if (c.nq <= 4) {
     mq_launch_one<TYPE, METRIC, G, ITERS, U, 4>(c);
-  } else if constexpr (TYPE != KT_F32 && ITERS >= 4) {  // 4 KiB fp16 / bf16 rows: eight queries spill -- two passes of four
+  } else if (TYPE != KT_F32 && ITERS >= 4) {  // 4 KiB fp16 / bf16 rows: eight queries spill -- two passes of four
     MqCtx lo = c, hi = c;
     lo.nq = 4;
     hi.nq = c.nq - 4;
@@ -308,9 +335,9 @@ const char *last_scan_mq_kernel_name(char *buf, size_t cap) {
     snprintf(buf, cap, "none");
     return buf;
   }
-  snprintf(buf, cap, "scan_mq_kernel<%s,%s,G=%u,ITERS=%u,U=%u,B=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7],
+  snprintf(buf, cap, "scan_mq_kernel<%s,%s,G=%u,ITERS=%u,U=%u,B=%u,EXACT=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7],
            (unsigned)((v >> 6) & 127), (unsigned)((v >> 13) & 15), (unsigned)((v >> 17) & 15), (unsigned)((v >> 21) & 31),
-           (unsigned)(v >> 41));
+           (unsigned)((v >> 26) & 1), (unsigned)(v >> 41));
   return buf;
 }
 

@@ -690,6 +690,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "coalesce_linger_us")) scan_tuning().coalesce_linger_us = value;
   else if (!strcmp(key, "coalesce_min_mib")) scan_tuning().coalesce_min_mib = value;
   else if (!strcmp(key, "mq_blocks_per_cu")) scan_tuning().mq_blocks_per_cu = value;
+  else if (!strcmp(key, "batch_mfma")) scan_tuning().batch_mfma = value;
   else if (!strcmp(key, "vmm")) scan_tuning().vmm = value;
   else if (!strcmp(key, "vmm_chunk_mib")) scan_tuning().vmm_chunk_mib = value;
   else if (!strcmp(key, "vmm_reserve_factor")) scan_tuning().vmm_reserve_factor = value > 0 ? value : 64;

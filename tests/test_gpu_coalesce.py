@@ -27,7 +27,7 @@ def knobs():
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0
         set_.append(key)
     yield setk
-    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1}
+    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1, "batch_mfma": 1}
     for key in set_:
         lib.RSGPU_SetTuning(key.encode(), defaults[key])
 
@@ -57,9 +57,10 @@ SHAPES = [  # (type, dim): every (G, ITERS) shape of the multi-query kernel, exa
 
 @pytest.mark.parametrize("vtype,dim", SHAPES)
 @pytest.mark.parametrize("metric", [V.VecSimMetric_L2, V.VecSimMetric_IP, V.VecSimMetric_Cosine])
-def test_multi_query_pass_is_bit_identical_to_single_queries(vtype, dim, metric):
-    """RSGPU_FlatIndex_TopKBatch on an index without an MFMA form runs the multi-query scan, eight queries per pass: 19
+def test_multi_query_pass_is_bit_identical_to_single_queries(vtype, dim, metric, knobs):
+    """RSGPU_FlatIndex_TopKBatch without the matrix-core passes runs the multi-query scan, eight queries per pass: 19
     queries = passes of 8, 8 and 3 (the B = 8 and B = 4 kernels)."""
+    knobs("batch_mfma", 0)   # (fp16 / bf16 IP batches would take the MFMA passes: equal only up to the summation order)
     n = 70_000   # >= 2^16: the batched threshold-filter selection at K <= 32
     idx = _index(vtype, dim, metric, n)
     try:
@@ -73,9 +74,7 @@ def test_multi_query_pass_is_bit_identical_to_single_queries(vtype, dim, metric)
                 assert ids[i][:k].tolist() == si.tolist(), (i, k)
                 assert sc[i][:k].tolist() == ss.tolist(), (i, k)
         after = V.coalesce_stats()
-        fp16_mfma = vtype != V.VecSimType_FLOAT32 and metric != V.VecSimMetric_L2   # those batches take the matrix cores
-        if not fp16_mfma:
-            assert after["mq_passes"] - before["mq_passes"] == 9 and after["mq_queries"] - before["mq_queries"] == 57
+        assert after["mq_passes"] - before["mq_passes"] == 9 and after["mq_queries"] - before["mq_queries"] == 57
     finally:
         idx.free()
 
