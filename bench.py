@@ -33,6 +33,7 @@ and, at N=1, sub-records measured after the headline loop: `config.two_stage_exa
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -308,6 +309,26 @@ def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
     return worst, got
 
 
+class no_gc:
+    """Timed regions run with Python's cyclic collector off (and a collection right before): with torch and numpy loaded a
+    generation-2 pass takes tens of milliseconds, and one landing inside a 1.4 ms query shows up as a 30-100 ms `max_ms`
+    that has nothing to do with the library (the lump the round-2 driver run caught in the two-stage extra; none in 11 024
+    queries of scripts/diag/two_stage_lumps.py, a process without torch).  .collections = passes that ran regardless."""
+    def __enter__(self):
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        self._before = sum(g["collections"] for g in gc.get_stats())
+        self.collections = 0
+        return self
+
+    def __exit__(self, *exc):
+        self.collections = sum(g["collections"] for g in gc.get_stats()) - self._before
+        if self._was:
+            gc.enable()
+        return False
+
+
 def _lat_summary(lat_s):
     lat = np.asarray(lat_s, np.float64) * 1e3
     return {"p50_ms": float(np.percentile(lat, 50)), "p95_ms": float(np.percentile(lat, 95)), "max_ms": float(lat.max())}
@@ -332,18 +353,19 @@ def extra_two_stage(lib, V, index, queries, k, steps, warmup):
         n2 = max(min(steps, 1000), 200)   # (never fewer than 200 queries: 0.3 s)
         lat = np.zeros(n2)
         V.two_stage_stats(reset=True)
-        t2 = time.perf_counter()
-        for i in range(n2):
-            q = queries[(warmup + i) % len(queries)]
-            s = time.perf_counter()
-            rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
-            lib.VecSimQueryReply_Free(rep)
-            lat[i] = time.perf_counter() - s
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - t2
+        with no_gc() as g:
+            t2 = time.perf_counter()
+            for i in range(n2):
+                q = queries[(warmup + i) % len(queries)]
+                s = time.perf_counter()
+                rep = lib.VecSimIndex_TopKQuery(index.ptr, q.ctypes.data_as(C.c_void_p), k, None, V.BY_SCORE)
+                lib.VecSimQueryReply_Free(rep)
+                lat[i] = time.perf_counter() - s
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t2
         st = V.two_stage_stats()
         out = {"qps": n2 / el2, "ms_per_query": el2 / n2 * 1e3, "queries": n2, "bit_identical_to_fp32_scan": bool(same),
-               "fallbacks": st["fallbacks"], "two_stage_stats": st,
+               "fallbacks": st["fallbacks"], "two_stage_stats": st, "python_gc_passes_inside_the_timed_loop": g.collections,
                "what": "opt-in: scan of an int8 shadow with per-row scales (7.72 GB) + error-bounded filter + fp32 "
                        "re-scoring of the survivors; NOT the headline value"}
         out.update(_lat_summary(lat))
@@ -690,20 +712,39 @@ def main():
 
     for i in range(a.warmup):
         assert one_query(i) == k
+    if inproc:
+        ex = (C.c_uint64 * 2)()
+        lib.RSGPU_ShardedIndex_GetExchangeStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), ex, 1)
+    if ranks_mode:
+        sharded.exchanges = sharded.exchange_ns = 0
     lib.RSGPU_ResetProfile()
     lib.RSGPU_SetProfiling(1)
     lat = np.zeros(a.steps)
     barrier()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        s = time.perf_counter()
-        one_query(a.warmup + i)
-        lat[i] = time.perf_counter() - s
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with no_gc():
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            s = time.perf_counter()
+            one_query(a.warmup + i)
+            lat[i] = time.perf_counter() - s
+        barrier()
+        elapsed = time.perf_counter() - t0
     lib.RSGPU_SetProfiling(0)
     launches, kern_ms, kern_bytes = V.scan_profile()
     kernel_name = V.last_scan_kernel()
+    # the exchange step of the timed queries (N > 1): what it is, how many parties, what it cost per query
+    collective = None
+    if inproc and not a.replicas:
+        lib.RSGPU_ShardedIndex_GetExchangeStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), ex, 0)
+        collective = {"kind": "in-process: every shard's last kernel writes its top-k into pinned host memory; K-way host merge "
+                              "by (score, label) (sharded_index.cpp merge_replies) -- no device collective inside one process",
+                      "ranks": n_shards, "us_per_query": ex[1] / max(ex[0], 1) / 1e3, "queries": int(ex[0]),
+                      "payload_bytes_per_rank": k * 16}
+    elif ranks_mode:
+        collective = {"kind": "RCCL all-gather (torch.distributed nccl backend) of k*(8+8) B per rank over xGMI + D2H + merge in C "
+                              "(RSGPU_MergeTopKHost)", "ranks": world,
+                      "us_per_query": sharded.exchange_ns / max(sharded.exchanges, 1) / 1e3, "queries": int(sharded.exchanges),
+                      "payload_bytes_per_rank": k * 16}
 
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -724,6 +765,21 @@ def main():
                           "ok": bool(worst <= 1e-4), "kth_beats_regenerated_probe_rows": 3 * 2048}
         except Exception as e:
             verify = {"ok": False, "error": repr(e)}
+    if inproc and not a.replicas and not a.no_extras and not a.no_callers_extra:
+        # concurrent callers on the sharded handle: every shard's worker answers up to eight callers per pass over its rows
+        try:
+            cl = _callers_lib(V)
+            rec = {}
+            for threads in (1, 8):
+                V.coalesce_stats(reset=True)
+                total, el, lat, _, _ = run_callers(cl, index, queries[:64], k, threads, 2.0)
+                st = V.coalesce_stats()
+                rec["%d_threads" % threads] = dict(qps=total / el, queries_per_shard_pass=st["queries"] / max(st["passes"], 1),
+                                                   **_lat_summary(lat))
+            rec["x_one_caller"] = rec["8_threads"]["qps"] / rec["1_threads"]["qps"]
+            extras["concurrent_callers"] = rec
+        except Exception as e:
+            extras["concurrent_callers"] = {"error": repr(e)}
     if single and rank == 0 and not a.no_extras:
         if want_two_stage_extra:
             try:
@@ -814,6 +870,10 @@ def main():
             },
         }
         out["config"].update(extras)
+        if collective is not None:
+            out["collective"] = collective
+            out["config"]["multi_gpu_note"] = ("no 2/4/8-GPU hardware curve has been measured by the builder (1-GPU boxes only): "
+                                               "the multi-shard path is exercised with several shards on one device")
         # HBM traffic of the scan kernel: a committed rocprofv3 --pmc pass of this same command (bench.py cannot read
         # PMCs itself); used only when it was taken for the same shape AND the same kernel instantiation
         for name in ("r02_scan_pmc_hbm_traffic.json", "r01_scan_pmc_hbm_traffic.json"):

@@ -88,6 +88,11 @@ VecSimIndex *RSGPU_ShardedIndex_Shard(RSGPU_ShardedIndex *index, int shard);
  * handle owns them. */
 RSGPU_ShardedIndex *RSGPU_ShardedIndex_FromHandle(VecSimIndex *index);
 size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *index);
+/* The exchange step of the fan-out top-k queries since the last reset: out[0] queries merged, out[1] nanoseconds between
+ * "the last shard's winners are in (pinned) host memory" and "the merged reply exists" -- every shard's last kernel writes
+ * its K winners straight into host memory, so the exchange is a K-way host merge of N * K pairs (no collective inside one
+ * process; between processes the same lists travel by one RCCL all-gather, redisearch_amd/sharded.py). */
+void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *index, uint64_t out[2], int reset);
 /* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
  * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */
 int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *index, const void *blob, size_t label);

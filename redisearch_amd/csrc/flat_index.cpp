@@ -1069,6 +1069,13 @@ bool FlatIndex::coalescible(size_t k) const {
   return (size_t)n * stride_ >= ((size_t)(t.coalesce_min_mib > 0 ? t.coalesce_min_mib : 0) << 20);
 }
 
+int FlatIndex::coalesce_linger_us() const {
+  const int us = scan_tuning().coalesce_linger_us;
+  if (us >= 0) return us;
+  const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)stride_ / 6.0e6;  // ~6 TB/s
+  return (int)std::min(300.0, std::max(20.0, 0.05 * pass_us));
+}
+
 VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
   void *tctx = qp ? qp->timeoutCtx : nullptr;
   last_mode = STANDARD_KNN;
@@ -1095,11 +1102,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     // passes stay full instead of alternating between one early bird and everybody else
     const uint32_t expect = std::min<uint32_t>(co_.last_b, kMqMaxQueries);
     if (co_.waiting.size() < expect) {
-      int us = scan_tuning().coalesce_linger_us;
-      if (us < 0) {  // 5 % of a pass at ~6 TB/s
-        const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)stride_ / 6.0e6;
-        us = (int)std::min(300.0, std::max(20.0, 0.05 * pass_us));
-      }
+      const int us = coalesce_linger_us();
       if (us > 0) {
         const auto t0 = std::chrono::steady_clock::now();
         co_.lingering = true;

@@ -193,6 +193,8 @@ class FlatIndex {
   // without an MFMA form): fills job->reply (or job->err) of every job.  Replies are bit-identical to topk()'s.
   void topk_pass(TopkJob *const *jobs, size_t n_jobs);
   bool mq_capable(size_t k) const;   // the multi-query scan can serve a top-k query of this index
+  // how long a pass may wait for the callers of the previous pass to come back (knob, or 5 % of a pass: 20..300 us)
+  int coalesce_linger_us() const;
   bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
   // the decision itself: N vectors under `labels` labels, `subset` of them pass the filter
   static bool prefer_adhoc_rule(size_t N, size_t labels, size_t dim, size_t subset);

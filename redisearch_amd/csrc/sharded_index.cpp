@@ -27,16 +27,30 @@ using namespace rsgpu;
 
 namespace {
 
+// what a caller waits on: the tasks it posted (one per shard, at most), counted down by the workers
+struct Completion {
+  std::mutex mu;
+  std::condition_variable cv;
+  int remaining = 0;
+  std::string error;  // first error of a closure task
+};
+// one unit of work for a shard's worker: a closure, or a top-k query (kept apart so that the worker can put the queries
+// of several concurrent callers into ONE pass over its rows, FlatIndex::topk_pass)
+struct Task {
+  std::function<void()> fn;
+  TopkJob *topk = nullptr;
+  Completion *done = nullptr;
+};
+
 struct Shard {
   FlatIndex *flat = nullptr;
   int device = 0;
   std::thread worker;
   std::mutex mu;
   std::condition_variable cv;
-  std::function<void()> job;  // empty + stop: leave
+  std::deque<Task> q;  // FIFO; any number of callers post concurrently
   bool stop = false;
-  uint64_t posted = 0, done = 0;  // generation counters
-  std::string error;
+  uint32_t last_b = 1;  // queries in the worker's previous pass (how many to wait a moment for, as in FlatIndex::topk)
 };
 
 }  // namespace
@@ -46,71 +60,104 @@ struct RSGPU_ShardedIndex {
   bool replicas = false;
   bool multi = false;
   void *log_ctx = nullptr;
-  std::mutex done_mu;
-  std::condition_variable done_cv;
-  std::mutex query_mu;  // one fan-out at a time (the workers hold one job slot each)
   std::atomic<uint64_t> rr{0};
   std::atomic<int> last_mode{EMPTY_MODE};
   std::vector<VecSimIndex> handles;  // per-shard ABI handles (RSGPU_ShardedIndex_Shard; per-shard iterators / contexts)
+  // exchange statistics of the fan-out queries (bench.py's `collective` record): nanoseconds between the moment the last
+  // shard's winners are in host memory and the merged reply
+  std::atomic<uint64_t> merges{0}, merge_ns{0};
   size_t n() const { return shards.size(); }
   Shard *pick() { return shards[rr++ % shards.size()].get(); }  // replica mode: round-robin
 };
 
-static void worker_main(RSGPU_ShardedIndex *si, Shard *s) {
+static void task_done(Completion *c, const std::string &err) {
+  std::lock_guard<std::mutex> g(c->mu);  // (notify under the lock: the waiter owns the object and may destroy it next)
+  if (!err.empty() && c->error.empty()) c->error = err;
+  if (--c->remaining == 0) c->cv.notify_all();
+}
+
+// A shard's worker: its device is current here for good.  Top-k queries at the head of the queue -- the fan-outs of
+// concurrent callers -- are answered together, up to kMqMaxQueries per pass over the shard's rows (the coalescer of
+// FlatIndex::topk, moved to where the queries of a sharded handle meet); everything else runs task by task.
+static void worker_main(Shard *s) {
   (void)hipSetDevice(s->device);
-  uint64_t seen = 0;
   for (;;) {
-    std::function<void()> job;
+    std::vector<Task> batch;
     {
       std::unique_lock<std::mutex> g(s->mu);
-      s->cv.wait(g, [&] { return s->posted != seen; });
-      seen = s->posted;
-      if (s->stop) return;
-      job = s->job;
+      s->cv.wait(g, [&] { return s->stop || !s->q.empty(); });
+      if (s->q.empty()) return;  // (stop: the queue is drained first)
+      auto leading = [&] {
+        size_t c = 0;
+        while (c < s->q.size() && s->q[c].topk) c++;
+        return c;
+      };
+      if (s->q.front().topk) {
+        const size_t expect = std::min<uint32_t>(s->last_b, kMqMaxQueries);
+        if (leading() < expect && !s->stop) {
+          const int us = s->flat->coalesce_linger_us();
+          if (us > 0) s->cv.wait_for(g, std::chrono::microseconds(us), [&] { return s->stop || leading() >= expect; });
+        }
+        const size_t take = std::min<size_t>(leading(), kMqMaxQueries);
+        for (size_t i = 0; i < take; i++) {
+          batch.push_back(std::move(s->q.front()));
+          s->q.pop_front();
+        }
+      } else {
+        batch.push_back(std::move(s->q.front()));
+        s->q.pop_front();
+      }
     }
-    std::string err;
-    try {
-      if (job) job();
-    } catch (const std::exception &e) {
-      err = e.what();
-    } catch (...) {
-      err = "unknown error";
+    if (batch[0].topk) {
+      TopkJob *jobs[kMqMaxQueries];
+      for (size_t i = 0; i < batch.size(); i++) jobs[i] = batch[i].topk;
+      std::exception_ptr err;
+      try {
+        s->flat->topk_pass(jobs, batch.size());
+      } catch (...) {
+        err = std::current_exception();
+      }
+      s->last_b = (uint32_t)batch.size();
+      for (Task &t : batch) {
+        if (err && !t.topk->reply) t.topk->err = err;
+        task_done(t.done, std::string());
+      }
+    } else {
+      std::string err;
+      try {
+        if (batch[0].fn) batch[0].fn();
+      } catch (const std::exception &e) {
+        err = e.what();
+      } catch (...) {
+        err = "unknown error";
+      }
+      task_done(batch[0].done, err);
     }
-    {
-      std::lock_guard<std::mutex> g(si->done_mu);
-      s->error = err;
-      s->done = seen;
-    }
-    si->done_cv.notify_all();
   }
 }
 
-// Runs jobs[i] on shard i's worker (its device is current there), all at once; returns when every one has finished.
-// Throws the first error.  The caller holds query_mu.
-static void run_on_shards(RSGPU_ShardedIndex *si, const std::vector<std::function<void()>> &jobs) {
-  for (size_t i = 0; i < si->n(); i++) {
-    Shard *s = si->shards[i].get();
-    {
-      std::lock_guard<std::mutex> g(s->mu);
-      s->job = jobs[i];
-      s->posted++;
-    }
-    s->cv.notify_one();
-  }
-  std::string err;
+static void post(Shard *s, Task &&t) {
   {
-    std::unique_lock<std::mutex> g(si->done_mu);
-    si->done_cv.wait(g, [&] {
-      for (auto &s : si->shards)
-        if (s->done != s->posted) return false;
-      return true;
-    });
-    for (auto &s : si->shards) {
-      if (!s->error.empty() && err.empty()) err = s->error;
-      s->error.clear();
-    }
+    std::lock_guard<std::mutex> g(s->mu);
+    s->q.push_back(std::move(t));
   }
-  if (!err.empty()) throw std::runtime_error(err);
+  s->cv.notify_one();
+}
+static void wait_for(Completion &c) {
+  std::unique_lock<std::mutex> g(c.mu);
+  c.cv.wait(g, [&] { return c.remaining == 0; });
+}
+
+// Runs jobs[i] on shard i's worker (its device is current there), all at once; returns when every one has finished.
+// Throws the first error.  Any number of callers may be in here at the same time: the workers queue.
+static void run_on_shards(RSGPU_ShardedIndex *si, const std::vector<std::function<void()>> &jobs) {
+  Completion c;
+  for (size_t i = 0; i < si->n(); i++) c.remaining += jobs[i] ? 1 : 0;
+  if (!c.remaining) return;
+  for (size_t i = 0; i < si->n(); i++)
+    if (jobs[i]) post(si->shards[i].get(), Task{jobs[i], nullptr, &c});
+  wait_for(c);
+  if (!c.error.empty()) throw std::runtime_error(c.error);
 }
 
 // shard code that runs on the CALLER's thread selects the shard's device there: put the caller's device back afterwards
@@ -167,6 +214,8 @@ static VecSimQueryReply *merge_replies(std::vector<VecSimQueryReply *> &replies,
 
 namespace rsgpu {
 
+void sharded_free(RSGPU_ShardedIndex *si);
+
 RSGPU_ShardedIndex *sharded_new(const BFParams &p, void *log_ctx, int n_shards, const int *devices, bool replicas) {
   if (n_shards < 1 || n_shards > 64) throw std::runtime_error("1..64 shards");
   std::string why;
@@ -195,10 +244,15 @@ RSGPU_ShardedIndex *sharded_new(const BFParams &p, void *log_ctx, int n_shards, 
     throw;
   }
   HIP_CHECK(hipSetDevice(prev));
-  si->handles.resize(si->n());
-  for (size_t i = 0; i < si->n(); i++) {
-    si->handles[i].flat = si->shards[i]->flat;
-    if (!si->replicas && si->n() > 1) si->shards[i]->worker = std::thread(worker_main, si.get(), si->shards[i].get());
+  try {
+    si->handles.resize(si->n());
+    for (size_t i = 0; i < si->n(); i++) {
+      si->handles[i].flat = si->shards[i]->flat;
+      if (!si->replicas && si->n() > 1) si->shards[i]->worker = std::thread(worker_main, si->shards[i].get());
+    }
+  } catch (...) {  // (a later std::thread failed to start: the started ones are joinable and own nothing yet)
+    sharded_free(si.release());
+    throw;
   }
   return si.release();
 }
@@ -210,9 +264,8 @@ void sharded_free(RSGPU_ShardedIndex *si) {
       {
         std::lock_guard<std::mutex> g(s->mu);
         s->stop = true;
-        s->posted++;
       }
-      s->cv.notify_one();
+      s->cv.notify_all();
       s->worker.join();
     }
     try {
@@ -294,21 +347,30 @@ VecSimQueryReply *sharded_topk(RSGPU_ShardedIndex *si, const void *query, size_t
   si->last_mode = STANDARD_KNN;
   if (si->replicas) return si->pick()->flat->topk(query, k, qp, order);
   if (si->n() == 1) return si->shards[0]->flat->topk(query, k, qp, order);
-  std::lock_guard<std::mutex> q(si->query_mu);
-  std::vector<VecSimQueryReply *> replies(si->n(), nullptr);
-  std::vector<std::function<void()>> jobs;
+  // fan out: one top-k task per shard; the shard workers batch the tasks of concurrent callers into shared passes
+  std::vector<TopkJob> jobs(si->n(), TopkJob{query, k, qp ? qp->timeoutCtx : nullptr, BY_SCORE});
+  Completion c;
+  c.remaining = (int)si->n();
   for (size_t i = 0; i < si->n(); i++) {
-    FlatIndex *f = si->shards[i]->flat;
-    VecSimQueryReply **slot = &replies[i];
-    jobs.push_back([=] { *slot = f->topk(query, k, qp, BY_SCORE); });
+    si->shards[i]->flat->last_mode = STANDARD_KNN;
+    post(si->shards[i].get(), Task{nullptr, &jobs[i], &c});
   }
-  try {
-    run_on_shards(si, jobs);
-  } catch (...) {
+  wait_for(c);
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<VecSimQueryReply *> replies(si->n(), nullptr);
+  std::exception_ptr err;
+  for (size_t i = 0; i < si->n(); i++) {
+    replies[i] = jobs[i].reply;
+    if (jobs[i].err && !err) err = jobs[i].err;
+  }
+  if (err) {
     for (VecSimQueryReply *r : replies) VecSimQueryReply_Free(r);
-    throw;
+    std::rethrow_exception(err);
   }
-  return merge_replies(replies, k, true, order);
+  VecSimQueryReply *out = merge_replies(replies, k, true, order);
+  si->merges++;
+  si->merge_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return out;
 }
 
 VecSimQueryReply *sharded_range(RSGPU_ShardedIndex *si, const void *query, double radius, VecSimQueryParams *qp,
@@ -317,7 +379,6 @@ VecSimQueryReply *sharded_range(RSGPU_ShardedIndex *si, const void *query, doubl
   si->last_mode = RANGE_QUERY;
   if (si->replicas) return si->pick()->flat->range(query, radius, qp, order);
   if (si->n() == 1) return si->shards[0]->flat->range(query, radius, qp, order);
-  std::lock_guard<std::mutex> q(si->query_mu);
   std::vector<VecSimQueryReply *> replies(si->n(), nullptr);
   std::vector<std::function<void()>> jobs;
   for (size_t i = 0; i < si->n(); i++) {
@@ -405,7 +466,6 @@ VecSimQueryReply *sharded_batch_next(ShardedBatchIterator *it, size_t n, VecSimQ
   if (it->its.size() == 1) return VecSimBatchIterator_Next(it->its[0], n, order);
   std::vector<VecSimQueryReply *> replies(it->its.size(), nullptr);
   {
-    std::lock_guard<std::mutex> q(si->query_mu);
     std::vector<std::function<void()>> jobs;
     for (size_t i = 0; i < it->its.size(); i++) {
       const size_t have = it->buf[i].size();
@@ -512,7 +572,6 @@ void sharded_adhoc_distances(ShardedAdhoc *a, const size_t *labels, double *out,
       }
   }
   std::vector<std::vector<double>> d(m);
-  std::lock_guard<std::mutex> q(si->query_mu);
   std::vector<std::function<void()>> jobs;
   for (size_t s = 0; s < m; s++) {
     if (lab[s].empty()) {
@@ -580,6 +639,13 @@ VecSimIndex *RSGPU_ShardedIndex_Shard(RSGPU_ShardedIndex *si, int shard) {
 RSGPU_ShardedIndex *RSGPU_ShardedIndex_FromHandle(VecSimIndex *index) { return index ? index->sharded : nullptr; }
 
 size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *si) { return si ? sharded_size(si) : 0; }
+
+void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *si, uint64_t out[2], int reset) {
+  if (!si || !out) return;
+  out[0] = si->merges.load();
+  out[1] = si->merge_ns.load();
+  if (reset) si->merges = si->merge_ns = 0;
+}
 
 int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *si, const void *blob, size_t label) {
   if (!si || !blob) return 0;

@@ -306,6 +306,9 @@ VecSimBatchIterator *VecSimBatchIterator_New(VecSimIndex *index, const void *que
     } catch (const std::exception &e) {
       set_error(log_ctx_of(index), "VecSimBatchIterator_New", e.what());
       return nullptr;
+    } catch (...) {  // nothing may cross the C ABI
+      set_error(log_ctx_of(index), "VecSimBatchIterator_New", "unknown error");
+      return nullptr;
     }
   }
   FlatIndex *f = index->flat;
@@ -336,6 +339,9 @@ VecSimQueryReply *VecSimBatchIterator_Next(VecSimBatchIterator *iterator, size_t
       return sharded_batch_next(iterator->sh, n_results, order);
     } catch (const std::exception &e) {
       set_error(nullptr, "VecSimBatchIterator_Next", e.what());
+      return nullptr;
+    } catch (...) {
+      set_error(nullptr, "VecSimBatchIterator_Next", "unknown error");
       return nullptr;
     }
   }
@@ -427,6 +433,9 @@ VecSimAdhocBfCtx *VecSimIndex_AdhocBfCtx_New(VecSimIndex *index, const void *que
     } catch (const std::exception &e) {
       set_error(log_ctx_of(index), "VecSimIndex_AdhocBfCtx_New", e.what());
       return nullptr;
+    } catch (...) {
+      set_error(log_ctx_of(index), "VecSimIndex_AdhocBfCtx_New", "unknown error");
+      return nullptr;
     }
   }
   FlatIndex *f = index->flat;
@@ -448,6 +457,9 @@ void VecSimIndex_AdhocBfCtx_GetExactDistances(VecSimAdhocBfCtx *ctx, const size_
     } catch (const std::exception &e) {
       set_error(nullptr, "VecSimIndex_AdhocBfCtx_GetExactDistances", e.what());
       for (size_t i = 0; i < count; i++) out[i] = NAN;
+    } catch (...) {
+      set_error(nullptr, "VecSimIndex_AdhocBfCtx_GetExactDistances", "unknown error");
+      for (size_t i = 0; i < count; i++) out[i] = NAN;
     }
     return;
   }
@@ -458,6 +470,9 @@ void VecSimIndex_AdhocBfCtx_GetExactDistances(VecSimAdhocBfCtx *ctx, const size_
     f->gather(ctx->a.ctx, labels, count, out);
   } catch (const std::exception &e) {
     set_error(f->log_ctx, "VecSimIndex_AdhocBfCtx_GetExactDistances", e.what());
+    for (size_t i = 0; i < count; i++) out[i] = NAN;
+  } catch (...) {
+    set_error(f->log_ctx, "VecSimIndex_AdhocBfCtx_GetExactDistances", "unknown error");
     for (size_t i = 0; i < count; i++) out[i] = NAN;
   }
 }

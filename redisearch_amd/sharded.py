@@ -52,6 +52,7 @@ class ShardedTopK:
         self.torch, self.dist = torch, dist
         self.k, self.group = k, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchanges, self.exchange_ns = 0, 0   # the collective + D2H + merge of every query (bench.py's `collective`)
         # one collective per query: labels and the fp32 score bits travel in the same int64 buffer
         self.pack = torch.empty(2 * k, dtype=torch.int64, device=device)
         self.all_p = torch.empty(2 * k * self.world, dtype=torch.int64, device=device)
@@ -67,7 +68,9 @@ class ShardedTopK:
             self.local_topk = local_topk
 
     def query(self, q):
-        s, l = self.local_topk(q, self.k)
+        import time
+        s, l = self.local_topk(q, self.k)   # (returns when this shard's top-k is complete in device memory)
+        t0 = time.perf_counter_ns()
         k = self.k
         self.pack[:k] = l
         self.pack[k:] = s.view(self.torch.int32)
@@ -78,4 +81,7 @@ class ShardedTopK:
         ap = self.all_p.cpu().numpy().reshape(self.world, 2, k)
         labels = np.ascontiguousarray(ap[:, 0, :]).ravel().view(np.uint64)
         scores = np.ascontiguousarray(ap[:, 1, :]).astype(np.int32).ravel().view(np.float32)
-        return merge_topk(scores, labels, k)
+        out = merge_topk(scores, labels, k)
+        self.exchanges += 1
+        self.exchange_ns += time.perf_counter_ns() - t0
+        return out

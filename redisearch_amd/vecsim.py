@@ -193,6 +193,7 @@ ABI = {
     "RSGPU_GetScanProfile": (None, [C.POINTER(C.c_uint64), C.POINTER(_dbl), C.POINTER(C.c_uint64)]),
     "RSGPU_GetLastScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
     "RSGPU_GetTwoStageStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_ShardedIndex_GetExchangeStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_ResetCoalesceStats": (None, []),
     "RSGPU_GetLastMqScanKernel": (C.c_char_p, [C.c_char_p, _sz]),

@@ -4,6 +4,8 @@ one an 8-GPU node runs; with more devices visible the shards spread over them). 
 and to the oracle over the same vectors."""
 import math
 
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -142,6 +144,49 @@ def test_concurrent_callers_on_a_sharded_index():
     [t.start() for t in th]
     [t.join() for t in th]
     assert not bad
+
+
+def test_eight_shards_eight_callers_share_shard_passes():
+    """8 shards (oversubscribed on the visible devices), 8 caller threads mixing top-k, range and batch-iterator calls:
+    no caller serialises another (the shard workers queue), the workers answer several callers' top-k in one pass over
+    their rows, and every reply equals the unsharded index's -- scores included."""
+    import threading
+    n, dim, seed, shards = 160_000, 128, 17, 8
+    s = V.ShardedIndex(F32, dim, V.VecSimMetric_L2, shards, devices=_devices(shards))
+    per = n // shards
+    for i in range(shards):
+        s.shard(i).add_philox_rows(seed, i * per, per, 1 + i * per)
+    one = V.VecSimIndex(F32, dim, V.VecSimMetric_L2)
+    one.add_philox_rows(seed, 0, n, 1)
+    qs = O.philox_rows(seed, n, 32, dim)
+    exp = [one.topk_query(q, 10).results() for q in qs]
+    exp_r = [one.range_query(q, float(exp[i][1][3]), order=V.BY_ID).results() for i, q in enumerate(qs)]
+    bad, bar = [], threading.Barrier(8)
+    V.coalesce_stats(reset=True)
+
+    def run(t):
+        try:
+            bar.wait()
+            for it in range(24):
+                j = (t * 5 + it) % 32
+                ids, sc = s.topk_query(qs[j], 10).results()
+                if ids.tolist() != exp[j][0].tolist() or sc.tolist() != exp[j][1].tolist():
+                    bad.append(("topk", t, it))
+                if it % 6 == t % 6:
+                    rid, rs = s.range_query(qs[j], float(exp[j][1][3]), order=V.BY_ID).results()
+                    if rid.tolist() != exp_r[j][0].tolist():
+                        bad.append(("range", t, it))
+        except Exception as e:  # noqa: BLE001
+            bad.append(repr(e))
+    th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not bad, bad[:3]
+    st = V.coalesce_stats()
+    assert st["mq_passes"] > 0 and st["mq_queries"] > st["mq_passes"], st
+    ex = (C.c_uint64 * 2)()
+    V.load().RSGPU_ShardedIndex_GetExchangeStats(s.ptr, ex, 0)
+    assert ex[0] == 8 * 24
 
 
 # ---- the VecSim ABI handle itself over several shards ("shards" knob): multi-GPU behind the reference's unchanged seam ----
