@@ -302,7 +302,9 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     else if (scan_tuning().shadow16 && metric == VecSimMetric_Cosine) shadow_ = 1;
   }
   // FLOAT16 IP / cosine: an int8 shadow with one index-wide scale for the batched MFMA pass (batch_query.cpp)
-  if (type == VecSimType_FLOAT16 && !multi && metric != VecSimMetric_L2 && scan_tuning().shadow8) shadow_ = 3;
+  // (BFLOAT16 the same way since round 3: tests/test_gpu_batch_i8_shadow.py)
+  if ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && !multi && metric != VecSimMetric_L2 && scan_tuning().shadow8)
+    shadow_ = 3;
   sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ >= 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));

@@ -447,9 +447,18 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float *__restri
 // with the ACTUAL error norms: |eq|, |q8| are the query's own, |x8|, |ex| are bounded by their maxima over the index
 // (stats[1], stats[2], atomicMax while the rows are quantised).  One scale for every row keeps the filter an integer
 // compare per query.  stats: [0] max |x_i| (f32 bits), [1] max |x8|^2 (u32), [2] max |ex|^2 (f32 bits), [3] non-finite flag.
+// bf16 row element (no native type needed: the upper half of an fp32)
+struct Bf16 {
+  uint16_t bits;
+  __device__ __forceinline__ explicit operator float() const { return __uint_as_float((uint32_t)bits << 16); }
+};
 template <typename T>
 struct FiniteMax {  // the largest finite value of the row element type
   static constexpr float v = 65504.0f;
+};
+template <>
+struct FiniteMax<Bf16> {
+  static constexpr float v = 3.3895314e38f;  // 0x7F7F
 };
 template <>
 struct FiniteMax<float> {
@@ -483,6 +492,15 @@ __device__ __forceinline__ void load8(const _Float16 *row, uint32_t c, uint32_t 
   for (int j = 0; j < 8; j++) {
     const half2_t h = as_h2(w[j >> 1]);
     out[j] = (float)((j & 1) ? h.y : h.x);
+  }
+}
+__device__ __forceinline__ void load8(const Bf16 *row, uint32_t c, uint32_t stride_e, float out[8]) {
+  const u4 x = 8 * c < stride_e ? reinterpret_cast<const u4 *>(row)[c] : zero4();
+  const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    out[2 * j] = __uint_as_float(w[j] << 16);
+    out[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
   }
 }
 __device__ __forceinline__ void load8(const float *row, uint32_t c, uint32_t stride_e, float out[8]) {
@@ -655,7 +673,7 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
                           int type) {
   const uint32_t s16 = (uint32_t)(stride / 16);
-  if (!batch_rescore_supported(s16) || !n_queries || (type != KT_F32 && type != KT_F16)) return false;
+  if (!batch_rescore_supported(s16) || !n_queries || (type != KT_F32 && type != KT_F16 && type != KT_BF16)) return false;
   const Shape sh = pick_shape(s16);
   if ((uint32_t)(sh.G * sh.ITERS) != s16) return false;  // exact shapes only (no chunk masking here)
   // (64 slices per query: a slice walks its share of the list with one dependent load per candidate, most of which it
@@ -665,6 +683,9 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
   do {                                                                                                                     \
     if (type == KT_F16)                                                                                                    \
       hipLaunchKernelGGL((batch_rescore_kernel<KT_F16, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
+                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
+    else if (type == KT_BF16)                                                                                              \
+      hipLaunchKernelGGL((batch_rescore_kernel<KT_BF16, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,        \
                          (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
     else                                                                                                                   \
       hipLaunchKernelGGL((batch_rescore_kernel<KT_F32, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
@@ -693,6 +714,9 @@ void launch_absmax_rows(int type, const void *rows, size_t stride, uint32_t dim,
   if (type == KT_F32)
     hipLaunchKernelGGL(absmax_rows_kernel<float>, grid, block, 0, s, (const float *)rows, (uint32_t)(stride / 4), dim, row_begin,
                        row_end, stats);
+  else if (type == KT_BF16)
+    hipLaunchKernelGGL(absmax_rows_kernel<Bf16>, grid, block, 0, s, (const Bf16 *)rows, (uint32_t)(stride / 2), dim, row_begin,
+                       row_end, stats);
   else
     hipLaunchKernelGGL(absmax_rows_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)rows, (uint32_t)(stride / 2), dim,
                        row_begin, row_end, stats);
@@ -705,6 +729,9 @@ void launch_shadow8g_rows(int type, const void *rows, size_t stride, uint32_t di
   if (type == KT_F32)
     hipLaunchKernelGGL(shadow8g_rows_kernel<float>, grid, block, 0, s, (const float *)rows, (uint32_t)(stride / 4), dim, row_begin,
                        row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
+  else if (type == KT_BF16)
+    hipLaunchKernelGGL(shadow8g_rows_kernel<Bf16>, grid, block, 0, s, (const Bf16 *)rows, (uint32_t)(stride / 2), dim, row_begin,
+                       row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
   else
     hipLaunchKernelGGL(shadow8g_rows_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)rows, (uint32_t)(stride / 2), dim,
                        row_begin, row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
@@ -715,6 +742,9 @@ void launch_quantize_queries(int type, const void *queries, size_t qstride, uint
   if (type == KT_F32)
     hipLaunchKernelGGL(quantize_queries_kernel<float>, dim3(n_queries), dim3(64), 0, s, (const float *)queries,
                        (uint32_t)(qstride / 4), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
+  else if (type == KT_BF16)
+    hipLaunchKernelGGL(quantize_queries_kernel<Bf16>, dim3(n_queries), dim3(64), 0, s, (const Bf16 *)queries,
+                       (uint32_t)(qstride / 2), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);
   else
     hipLaunchKernelGGL(quantize_queries_kernel<_Float16>, dim3(n_queries), dim3(64), 0, s, (const _Float16 *)queries,
                        (uint32_t)(qstride / 2), dim, scale, stats, (int8_t *)q8, (uint32_t)sstride, qscale, slack);

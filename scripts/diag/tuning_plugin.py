@@ -8,6 +8,8 @@ def pytest_configure(config):
     spec = os.environ.get("RSGPU_TUNING", "")
     if not spec:
         return
+    import torch  # noqa: F401  (first, as in the test modules: torch's own HIP runtime must be the one in the process)
+    torch.cuda.is_available()
     from redisearch_amd import vecsim as V
     lib = V.load()
     for item in spec.split(","):

@@ -214,3 +214,42 @@ def test_f32_index_appends_deletes_and_growth(shadow8):
     shadow8.RSGPU_SetTuning(b"two_stage", 1)
     assert want[1][0][0] == n + 6 and want[2][0][0] == 8_000_000
     check(shadow8, g, queries, k, want, expect_launches=1)
+
+
+# ---- BFLOAT16 indexes (round 3): the same int8 passes, survivors re-scored with the bf16 scan's own arithmetic ----------
+@pytest.mark.parametrize("metric", [IP, COS])
+@pytest.mark.parametrize("dim,n", [(768, 530_001), (256, 700_000)])
+@pytest.mark.parametrize("k", [10, 100])
+def test_bfloat16_index_through_the_int8_passes(shadow8, metric, dim, n, k):
+    BF16 = V.VecSimType_BFLOAT16
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(dim * 7 + k)
+    x = (torch.rand((n, dim), device=dev, generator=gen) * 2 - 1).to(torch.bfloat16)
+    queries = np.random.default_rng(dim + k).uniform(-1, 1, (300, dim)).astype(np.float32)
+
+    def build_bf(rows):
+        g = V.VecSimIndex(BF16, dim, metric)
+        torch.cuda.synchronize()
+        g.add_device_rows(rows.data_ptr(), rows.shape[0], 1)
+        return g
+    shadow8.RSGPU_SetTuning(b"shadow8", 0)
+    p = build_bf(x.clone())
+    want = [p.topk_query(q, k).results() for q in queries]
+    p.free()
+    shadow8.RSGPU_SetTuning(b"shadow8", 1)
+    g = build_bf(x)
+    try:
+        launches, by = check(shadow8, g, queries, k, want, expect_launches=2)
+        assert by == 2 * n * dim                     # one byte per element: the int8 rows were what the passes read
+        # appends (one aligned with query 0) and deletes, then again
+        extra = np.random.default_rng(3).uniform(-1, 1, (20, dim)).astype(np.float32)
+        extra[4] = queries[0]
+        for i in range(20):
+            g.add_vector(extra[i], n + 1 + i)
+        for lbl in (7, n + 3, 1234):
+            g.delete_vector(lbl)
+        single = [g.topk_query(q, k).results() for q in queries[:12]]
+        check(shadow8, g, queries[:12], k, single)
+    finally:
+        g.free()

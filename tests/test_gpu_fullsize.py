@@ -120,6 +120,16 @@ def test_two_stage_int8_shadow_at_the_baseline_size(big, big_oracle):
             si, ss = sh.topk_query(qq, k).results()
             assert si.tolist() == pi.tolist() and ss.tolist() == ps.tolist()
     assert_topk_parity(sh, big_oracle, qs[1], 100)
+    # bench.py's 1 000 timed queries: NONE may leave the two-stage path (a fallback is exact but scans four times the
+    # bytes -- RSGPU_GetTwoStageStats counts every way out), and the replies are the plain index's, bit for bit
+    bench_qs = O.philox_rows(SEED, QUERY_BASE, 1000, DIM)
+    V.two_stage_stats(reset=True)
+    replies = [sh.topk_query(qq, K).results() for qq in bench_qs]
+    st = V.two_stage_stats()
+    assert st["attempts"] == 1000 and st["two_stage"] == 1000 and st["fallbacks"] == 0, st
+    for i in range(0, 1000, 25):
+        pi, ps = idx.topk_query(bench_qs[i], K).results()
+        assert replies[i][0].tolist() == pi.tolist() and replies[i][1].tolist() == ps.tolist(), i
     del sh
     plain = V.VecSimIndex(V.VecSimType_FLOAT32, DIM, V.VecSimMetric_L2)
     plain.reserve(ROWS + 64)
