@@ -221,6 +221,28 @@ typedef struct {
 } RSGPU_TreeQuery;
 RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q);
 
+/* Query trees of ANY depth: `nodes` in POST-ORDER -- a term names its list; an aggregate (RSGPU_OP_UNION /
+ * RSGPU_OP_INTERSECT) takes the n_children complete subtrees immediately before it; the last node is the root (its weight
+ * is RSGPU_ScoreArgs.root_weight).  Every intersection node may carry its own max_slop (< 0: none) / in_order, as every
+ * NewIntersectionIterator does (reference headers/iterators_ffi.h:309).  Each list appears at most once; at most 32
+ * terms, 64 nodes, 16 levels.  The hit list carries every term's frequency and the whole result tree:
+ * RSGPU_Hits_Score evaluates it as the reference's recursions do (src/ext/default.c:68-106,164-209,253-302,378-455 --
+ * an aggregate sums its children in the result's child order and multiplies by its weight, DISMAX takes a union's
+ * maximum), for any nesting.  RSGPU_ScoreArgs.idf / bm25_idf / weight are per LIST, in the order of `lists`. */
+typedef struct {
+  int op;             /* RSGPU_OP_TERM / _UNION / _INTERSECT */
+  size_t list;        /* term: index into `lists` */
+  size_t n_children;  /* aggregate */
+  double weight;      /* aggregate: the node's weight (a term's stays in RSGPU_ScoreArgs.weight) */
+  long max_slop;      /* intersection: < 0 none */
+  int in_order;       /* intersection */
+} RSGPU_TreeNode;
+RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *const *lists, size_t n_lists);
+/* The result tree behind a hit list, post-order (after the intersections sorted their children by size): per node the
+ * operator, the leaf column of a term (-1 for aggregates; leaves are the child slots of RSGPU_Hits_LeafOrder), the number
+ * of children and the weight.  Arrays of 64 entries suffice; any may be NULL.  Returns the number of nodes or -1. */
+int RSGPU_Hits_TreeNodes(const RSGPU_Hits *h, int *op, int *leaf, int *n_children, double *weight);
+
 /* NOT: doc ids 1..max_doc_id the child does not hold (rqe_iterators/src/not.rs:171-209), or -- with a
  * `universe` list of existing documents -- the universe's entries <= max_doc_id the child does not hold
  * (not_optimized.rs).  The hits are virtual results: one child with freq 1; score them with idf = 1

@@ -859,6 +859,26 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   // its weight; DISMAX takes the maximum over a UNION's children instead.  A leaf that did not match this document
   // (union children) carries frequency 0 and contributes exactly 0.
   auto fold = [&](auto leaf, bool dismax) {
+    if (P.n_nodes > 0) {
+      // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
+      // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the
+      // reference's recursions add them in -- and its own value, weight * that, goes to its parent's accumulator.
+      double acc[kMaxTreeDepth + 1];
+#pragma unroll
+      for (int d = 0; d <= kMaxTreeDepth; d++) acc[d] = 0.0;
+      for (int i = 0; i < P.n_nodes - 1; i++) {
+        const int d = P.node_depth[i];
+        double v;
+        if (P.node_op[i] == 0) {
+          v = leaf((int)P.node_leaf[i]);
+        } else {
+          v = P.node_weight[i] * acc[d];
+          acc[d] = 0.0;
+        }
+        acc[d - 1] = (dismax && P.node_in_union[i]) ? (v > acc[d - 1] ? v : acc[d - 1]) : acc[d - 1] + v;
+      }
+      return acc[0];
+    }
     double ret = 0.0;
     for (int g = 0; g < P.n_groups; g++) {
       const int a = P.group_first[g], b = P.group_first[g + 1];

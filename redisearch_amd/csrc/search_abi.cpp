@@ -194,6 +194,14 @@ struct RSGPU_Postings {
   std::atomic<bool> decoded{false};
 };
 
+// one node of a hit list's result tree, post-order over its leaf columns (a term: op 0, `leaf`; an aggregate: op 1 union /
+// 2 intersection over the n_children complete subtrees right before it)
+struct TNode {
+  uint8_t op = 0, leaf = 0;
+  uint16_t n_children = 0;
+  double weight = 1.0;
+};
+
 struct RSGPU_Hits {
   int device = 0, n_lists = 0;
   uint32_t len = 0, cap = 0;
@@ -218,6 +226,7 @@ struct RSGPU_Hits {
   uint8_t group_op[kMaxLists] = {};  // 0 term, 1 union, 2 intersection
   double group_weight[kMaxLists] = {};
   std::vector<std::unique_ptr<RSGPU_Hits>> nested;  // the groups' own hit lists (their columns are borrowed)
+  std::vector<TNode> tree;  // the whole result tree (any depth), post-order, root last; the groups above = the root's children
   std::vector<uint32_t> h_ids;  // lazily mirrored
   const std::vector<uint32_t> &host_ids() {
     if (h_ids.size() != len) {
@@ -290,6 +299,7 @@ struct Source {
   int op = 0;                // 0 term, 1 union, 2 intersection
   double weight = 1.0;
   uint64_t base = 0, first = 0, last = 0;  // ids[] are relative to base; first / last bound the doc ids from below / above
+  std::vector<TNode> tree;   // the source's own result tree over its leaves (post-order, its root last)
 };
 static Source term_source(RSGPU_Postings *p, int orig) {
   Source s;
@@ -303,6 +313,7 @@ static Source term_source(RSGPU_Postings *p, int orig) {
   s.epos[0] = nullptr;  // the position IS the entry index
   s.src[0] = p;
   s.orig[0] = orig;
+  s.tree.push_back(TNode{0, 0, 0, 1.0});
   return s;
 }
 static Source hits_source(const RSGPU_Hits *g, int op, double weight) {
@@ -321,6 +332,11 @@ static Source hits_source(const RSGPU_Hits *g, int op, double weight) {
   }
   s.op = op;
   s.weight = weight;
+  s.tree = g->tree;
+  if (!s.tree.empty()) {  // the nested list's root becomes this child: its operator and weight come from the query node
+    s.tree.back().op = (uint8_t)op;
+    s.tree.back().weight = weight;
+  }
   return s;
 }
 
@@ -351,8 +367,21 @@ static ProxParams tree_prox(const RSGPU_Hits *h, long max_slop, int in_order) {
 
 // Lays the sources out as the aggregate's children (ListView slot = group, leaves flattened in order) and records the
 // tree shape in the hit list.  Returns the leaf map for the write / proximity kernels.
-static LeafMap adopt_sources(RSGPU_Hits *h, const std::vector<Source> &srcs, ListView &v) {
+static LeafMap adopt_sources(RSGPU_Hits *h, const std::vector<Source> &srcs, ListView &v, int root_op) {
   memset(&v, 0, sizeof v);
+  h->tree.clear();
+  {
+    int leaf0 = 0;
+    for (const Source &s : srcs) {
+      for (TNode t : s.tree) {
+        if (t.op == 0) t.leaf = (uint8_t)(t.leaf + leaf0);
+        h->tree.push_back(t);
+      }
+      leaf0 += s.n_leaves;
+    }
+    h->tree.push_back(TNode{(uint8_t)root_op, 0, (uint16_t)srcs.size(), 1.0});
+    if (h->tree.size() > (size_t)kMaxNodes) throw std::runtime_error("query tree: more than 64 nodes");
+  }
   LeafMap m;
   memset(&m, 0, sizeof m);
   v.n = (int)srcs.size();
@@ -400,7 +429,7 @@ constexpr uint32_t kCountPending = 0xFFFFFFFFu;  // (a hit count cannot reach it
 static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx *c, Scratch &sc, uint32_t *total_out,
                         long max_slop, int in_order) {
   ListView v;
-  const LeafMap m = adopt_sources(h, srcs, v);
+  const LeafMap m = adopt_sources(h, srcs, v, 2);
   h->is_union = false;
   const uint32_t n0 = v.len[0];
   h->cap = std::max<uint32_t>(n0, 1);
@@ -429,7 +458,7 @@ static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx
 // OR of the sources (union_flat.rs:223-257,297-320); synchronises the stream (the total comes from per-source counts)
 static void combine_or(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx *c, Scratch &sc) {
   ListView v;
-  const LeafMap m = adopt_sources(h, srcs, v);
+  const LeafMap m = adopt_sources(h, srcs, v, 1);
   h->is_union = true;
   const size_t n = srcs.size();
   size_t sum = 0, max_len = 0;
@@ -525,6 +554,39 @@ static void tree_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_D
   // src/index_result/index_result.c:102), 1 for a single child
   P.slop = h->n_groups > 1 ? h->n_groups - 1 : 1;
   P.is_union = h->is_union ? 1 : 0;
+  // deeper than root -> groups -> leaves: the generic post-order evaluation
+  P.n_nodes = 0;
+  const int n = (int)h->tree.size();
+  if (n >= 2 && n <= kMaxNodes) {
+    struct Frame {
+      int remaining, depth, op;
+    };
+    std::vector<Frame> st;
+    std::vector<int> depth(n, 0), in_union(n, 0);
+    st.push_back(Frame{(int)h->tree[n - 1].n_children, 0, (int)h->tree[n - 1].op});
+    int max_depth = 0;
+    for (int i = n - 2; i >= 0; i--) {
+      while (!st.empty() && st.back().remaining == 0) st.pop_back();
+      if (st.empty()) throw std::runtime_error("query tree: malformed node array");
+      Frame &par = st.back();
+      depth[i] = par.depth + 1;
+      in_union[i] = par.op == 1;
+      par.remaining--;
+      max_depth = std::max(max_depth, depth[i]);
+      if (h->tree[i].op != 0) st.push_back(Frame{(int)h->tree[i].n_children, depth[i], (int)h->tree[i].op});
+    }
+    if (max_depth > kMaxTreeDepth) throw std::runtime_error("query tree: nested deeper than 16 levels");
+    if (max_depth > 2) {
+      P.n_nodes = n;
+      for (int i = 0; i < n; i++) {
+        P.node_op[i] = h->tree[i].op;
+        P.node_depth[i] = (uint8_t)depth[i];
+        P.node_leaf[i] = h->tree[i].leaf;
+        P.node_in_union[i] = (uint8_t)in_union[i];
+        P.node_weight[i] = h->tree[i].weight;
+      }
+    }
+  }
 }
 
 extern "C" {
@@ -780,6 +842,108 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
   }
   return guard.release();
   S_CATCH(nullptr)
+}
+
+/* Query trees of any depth (include/rsgpu_search.h RSGPU_EvalTreeNodes): the node array is walked once, bottom-up; every
+ * aggregate becomes a hit list of its own (kept alive inside the result) whose term columns and result tree travel up
+ * with it, exactly as the reference nests iterators (each Intersection / Union iterator owns its children and yields an
+ * aggregate result holding theirs: rqe_iterators/src/intersection.rs:313-339, union_flat.rs:297-320). */
+RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *const *lists, size_t n_lists) {
+  if (!nodes || !n_nodes || !lists || !n_lists) {
+    last_error() = "RSGPU_EvalTreeNodes: empty tree";
+    return nullptr;
+  }
+  S_TRY
+  if (n_nodes > (size_t)kMaxNodes || n_lists > (size_t)kMaxLists) throw std::runtime_error("RSGPU_EvalTreeNodes: at most 64 nodes over 32 terms");
+  check_lists("RSGPU_EvalTreeNodes", lists, n_lists);
+  const int device = lists[0]->device;
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  Scratch &sc = scratch(device);
+  struct Sub {
+    Source s;
+    size_t estimate = 0;
+    std::unique_ptr<RSGPU_Hits> own;  // an aggregate's own hit list (NULL for a term)
+  };
+  std::vector<Sub> st;
+  std::vector<char> used(n_lists, 0);
+  size_t leaves = 0;
+  for (size_t i = 0; i < n_nodes; i++) {
+    const RSGPU_TreeNode &nd = nodes[i];
+    const bool root = i + 1 == n_nodes;
+    if (nd.op == RSGPU_OP_TERM) {
+      if (nd.list >= n_lists) throw std::runtime_error("RSGPU_EvalTreeNodes: term node names a list that is not there");
+      if (used[nd.list]) throw std::runtime_error("RSGPU_EvalTreeNodes: a list may appear once in the tree");
+      used[nd.list] = 1;
+      if (++leaves > (size_t)kMaxLists) throw std::runtime_error("RSGPU_EvalTreeNodes: more than 32 terms");
+      decode_on(lists[nd.list], c.c);
+      Sub t;
+      t.s = term_source(lists[nd.list], (int)nd.list);
+      t.estimate = lists[nd.list]->n_entries;
+      if (!root) {
+        st.push_back(std::move(t));
+        continue;
+      }
+      // a bare term as the whole query: the intersection of one list
+      std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
+      h->device = device;
+      combine_and(h.get(), {t.s}, c.c, sc, c->h_counters, -1, 0);
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      h->len = c->h_counters[0];
+      return h.release();
+    }
+    if (nd.op != RSGPU_OP_UNION && nd.op != RSGPU_OP_INTERSECT) throw std::runtime_error("RSGPU_EvalTreeNodes: bad op");
+    if (!nd.n_children || nd.n_children > st.size() || nd.n_children > (size_t)kMaxLists)
+      throw std::runtime_error("RSGPU_EvalTreeNodes: an aggregate needs 1..32 complete subtrees before it (post-order)");
+    std::vector<Sub> kids;
+    for (size_t k = st.size() - nd.n_children; k < st.size(); k++) kids.push_back(std::move(st[k]));
+    st.resize(st.size() - nd.n_children);
+    // an intersection iterates its children by ascending estimate, stable, unless in_order pins the query's order
+    // (intersection.rs:94-119); a union keeps the query's order
+    if (nd.op == RSGPU_OP_INTERSECT && !nd.in_order)
+      std::stable_sort(kids.begin(), kids.end(), [](const Sub &x, const Sub &y) { return x.estimate < y.estimate; });
+    std::vector<Source> srcs;
+    for (Sub &k : kids) srcs.push_back(k.s);
+    std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
+    h->device = device;
+    size_t est = 0;
+    if (nd.op == RSGPU_OP_INTERSECT) {
+      combine_and(h.get(), srcs, c.c, sc, c->h_counters, nd.max_slop, nd.in_order);
+      HIP_CHECK(hipStreamSynchronize(c->stream));
+      h->len = c->h_counters[0];
+      est = kids[0].estimate;
+      for (const Sub &k : kids) est = std::min(est, k.estimate);
+    } else {
+      combine_or(h.get(), srcs, c.c, sc);
+      for (const Sub &k : kids) est += k.estimate;
+    }
+    for (Sub &k : kids)
+      if (k.own) h->nested.push_back(std::move(k.own));
+    if (root) {
+      if (!st.empty()) throw std::runtime_error("RSGPU_EvalTreeNodes: subtrees left over (the last node must be the root)");
+      return h.release();
+    }
+    Sub up;
+    up.s = hits_source(h.get(), nd.op == RSGPU_OP_UNION ? 1 : 2, nd.weight);
+    up.estimate = est;
+    up.own = std::move(h);
+    st.push_back(std::move(up));
+  }
+  throw std::runtime_error("RSGPU_EvalTreeNodes: the node array does not end in a root");
+  S_CATCH(nullptr)
+}
+
+/* the result tree of a hit list, post-order (RSGPU_EvalTreeNodes' own order after the intersections sorted their children):
+ * op / leaf column / children / weight per node; any output may be NULL.  Returns the number of nodes or -1. */
+int RSGPU_Hits_TreeNodes(const RSGPU_Hits *h, int *op, int *leaf, int *n_children, double *weight) {
+  if (!h) return -1;
+  for (size_t i = 0; i < h->tree.size(); i++) {
+    if (op) op[i] = h->tree[i].op;
+    if (leaf) leaf[i] = h->tree[i].op == 0 ? h->tree[i].leaf : -1;
+    if (n_children) n_children[i] = h->tree[i].n_children;
+    if (weight) weight[i] = h->tree[i].weight;
+  }
+  return (int)h->tree.size();
 }
 
 // reference src/redisearch_rs/rqe_iterators/src/not.rs:171-209 (1..=max_doc_id) and not_optimized.rs (universe)

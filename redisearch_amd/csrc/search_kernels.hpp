@@ -27,6 +27,8 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr);
 
 constexpr int kMaxLists = 32;  // children of one intersection / union (the reference's own tests go to 25)
+constexpr int kMaxNodes = 64;      // nodes of one query tree (terms + aggregates; <= kMaxLists terms)
+constexpr int kMaxTreeDepth = 16;  // nesting levels below the root
 struct ListView {
   const uint32_t *ids[kMaxLists];
   const uint32_t *freqs[kMaxLists];
@@ -116,6 +118,14 @@ struct ScoreParams {
   uint8_t group_first[kMaxLists + 1];
   uint8_t group_op[kMaxLists];
   double group_weight[kMaxLists];
+  // Deeper trees (RSGPU_EvalTreeNodes): the whole result tree in POST-ORDER over the leaf columns, n_nodes > 0.  Node i is
+  // a term (op 0: leaf column node_leaf[i]) or an aggregate (1 union / 2 intersection) whose children are the complete
+  // subtrees right before it; node_depth[i] = distance from the root (the root, last, has depth 0 and its weight is
+  // root_weight); node_in_union[i] != 0: the node's PARENT is a union (DISMAX takes the maximum there).  The groups above
+  // still describe the root's children (slop, proximity).  Depth <= kMaxTreeDepth.
+  int n_nodes;
+  uint8_t node_op[kMaxNodes], node_depth[kMaxNodes], node_leaf[kMaxNodes], node_in_union[kMaxNodes];
+  double node_weight[kMaxNodes];
   int slop;  // IndexResult_MinOffsetDelta of offset-less children: max(n_groups-1, 1)
   const int32_t *slops;  // per-hit slop computed from the term offsets (launch_prox_slop); NULL: the constant above
   int is_union;  // hits come from RSGPU_Union: per-hit slop from the matched children, DISMAX takes the maximum

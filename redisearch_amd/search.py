@@ -32,10 +32,17 @@ class TreeQuery(C.Structure):
                 ("lists", _vp), ("max_slop", C.c_long), ("in_order", _i)]
 
 
+class TreeNode(C.Structure):
+    _fields_ = [("op", _i), ("list", _sz), ("n_children", _sz), ("weight", C.c_double), ("max_slop", C.c_long),
+                ("in_order", _i)]
+
+
 OP_TERM, OP_UNION, OP_INTERSECT = 0, 1, 2
 
 ABI = {
     "RSGPU_EvalTree": (_vp, [C.POINTER(TreeQuery)]),
+    "RSGPU_EvalTreeNodes": (_vp, [C.POINTER(TreeNode), _sz, _vp, _sz]),
+    "RSGPU_Hits_TreeNodes": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
@@ -324,6 +331,39 @@ class TreeHits(Hits):
         q = TreeQuery(root_op, len(groups), _p(gf).value, _p(go).value, _p(gw).value, C.cast(arr, _vp).value,
                       -1 if max_slop is None else int(max_slop), int(in_order))
         self.ptr = _check(self.lib.RSGPU_EvalTree(C.byref(q)), "RSGPU_EvalTree")
+
+
+class NodeHits(Hits):
+    """RSGPU_EvalTreeNodes: a query tree of any depth.  `tree` is nested tuples: ("t", list_index) for a term,
+    ("and" | "or", weight, [children...]) or ("and", weight, [children...], max_slop, in_order) for an aggregate.
+    Scoring arrays (idf, bm25_idf, weight) are per list, in the order of `lists`."""
+
+    def __init__(self, tree, lists):
+        self.lib = load()
+        self._lists = list(lists)
+        self.n_lists = len(lists)
+        nodes = []
+
+        def walk(t):
+            if t[0] == "t":
+                nodes.append(TreeNode(OP_TERM, int(t[1]), 0, 1.0, -1, 0))
+                return
+            for ch in t[2]:
+                walk(ch)
+            ms = t[3] if len(t) > 3 and t[3] is not None else -1
+            io = int(bool(t[4])) if len(t) > 4 else 0
+            nodes.append(TreeNode(OP_INTERSECT if t[0] == "and" else OP_UNION, 0, len(t[2]), float(t[1]), int(ms), io))
+        walk(tree)
+        arr = (TreeNode * len(nodes))(*nodes)
+        lp = (_vp * len(lists))(*[l.ptr for l in lists])
+        self.ptr = _check(self.lib.RSGPU_EvalTreeNodes(arr, len(nodes), C.cast(lp, _vp), len(lists)), "RSGPU_EvalTreeNodes")
+
+    def tree_nodes(self):
+        """[(op, leaf, n_children, weight)] post-order, as the hit list holds it"""
+        op, leaf, nch = (np.zeros(64, np.int32) for _ in range(3))
+        w = np.zeros(64, np.float64)
+        n = self.lib.RSGPU_Hits_TreeNodes(self.ptr, _p(op), _p(leaf), _p(nch), _p(w))
+        return [(int(op[i]), int(leaf[i]), int(nch[i]), float(w[i])) for i in range(n)]
 
 
 def intersect(lists, max_slop=None, in_order=False):
