@@ -129,7 +129,7 @@ QueryIterator *RSGPU_NewUnionIterator(const RSGPU_TermArg *terms, size_t num, do
  * (the existing-documents list) only those the universe holds; `current` is a Virtual result with
  * RS_FIELDMASK_ALL. */
 QueryIterator *RSGPU_NewNotIterator(RSGPU_Postings *child, RSGPU_Postings *universe, t_docId max_doc_id, double weight);
-/* Any hit list (RSGPU_Intersect / _IntersectEx / _Union of TERM lists) behind the vtable; `terms[i]` belongs to list i
+/* Any hit list (RSGPU_Intersect / _IntersectEx / _Union / _EvalTree / _EvalTreeNodes) behind the vtable; `terms[i]` belongs to list i
  * of the call that built the hits.  With own_hits the iterator frees the hit list. */
 QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_TermArg *terms, size_t num, double weight,
                                      bool own_hits);
@@ -139,6 +139,9 @@ QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_TermArg *term
  * reference's nested iterators build: Intersection{Union{Term..}, Term, ..} with the groups in iteration order and, under
  * a union, only the children that matched the document. */
 QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const RSGPU_TermArg *terms, double weight);
+/* The same for a query tree of ANY depth (RSGPU_EvalTreeNodes): `nodes` in post-order, `terms[i]` belongs to list i. */
+QueryIterator *RSGPU_NewTreeNodesIterator(const RSGPU_TreeNode *nodes, size_t n_nodes, const RSGPU_TermArg *terms, size_t num,
+                                          double weight);
 /* The hit list behind an iterator made here (score it in one batch with RSGPU_Hits_Score, re-rank with
  * RSGPU_Hits_KnnRerank, ...); NULL for foreign iterators. */
 RSGPU_Hits *RSGPU_Iterator_Hits(QueryIterator *it);

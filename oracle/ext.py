@@ -193,6 +193,18 @@ def iter_drain(it, cap, max_children):
                 c_hash=ch[:, :m], c_same_doc=same[:, :m])
 
 
+def iter_drain_lean(it):
+    """Read() to EOF touching every record once -> (hits, checksum)"""
+    import ctypes as C
+    L = lib()
+    L.xh_iter_drain_lean.restype, L.xh_iter_drain_lean.argtypes = C.c_long, [C.c_void_p, C.POINTER(C.c_uint64)]
+    cs = C.c_uint64(0)
+    n = L.xh_iter_drain_lean(it, C.byref(cs))
+    if n < 0:
+        raise RuntimeError("iterator protocol violation while draining")
+    return n, cs.value
+
+
 def positions_hash(positions):
     h = 1469598103934665603
     for p in positions:

@@ -517,6 +517,26 @@ XH_API long xh_iter_drain(QueryIterator *it, size_t cap, size_t max_children, ui
   if (!it->atEOF || it->current) return -1; /* iterator_api.h:96-99 */
   return (long)n;
 }
+/* Read to EOF the way a lean consumer does (rpscoreNext with a trivial scorer): per hit, touch the aggregate and every
+ * child record once.  Returns the number of hits, -1 on a protocol violation; *checksum folds doc ids and frequencies. */
+XH_API long xh_iter_drain_lean(QueryIterator *it, uint64_t *checksum) {
+  size_t n = 0;
+  uint64_t acc = 0;
+  for (;;) {
+    const IteratorStatus st = it->Read(it);
+    if (st == ITERATOR_EOF) break;
+    if (st != ITERATOR_OK) return -1;
+    const RSIndexResult *r = it->current;
+    acc += r->docId + r->freq;
+    if (IndexResult_AggregateRef(r)) {
+      const XVec *v = (const XVec *)r->data.agg.records;
+      for (size_t c = 0; c < v->len; c++) acc += v->items[c]->freq + (uint64_t)v->items[c]->fieldMask;
+    }
+    n++;
+  }
+  if (checksum) *checksum = acc;
+  return (long)n;
+}
 /* ops: 0 Read, 1 SkipTo(arg), 2 Rewind, 3 NumEstimated (status_out receives the estimate).  After every op: the
  * status, lastDocId, atEOF and the doc id of `current` (0 when NULL). */
 XH_API void xh_iter_script(QueryIterator *it, size_t n_ops, const int *ops, const uint64_t *args, long *status_out,

@@ -28,6 +28,7 @@
 
 #define RSGPU_API __attribute__((visibility("default")))
 #define MAX_CHILDREN 32
+#define MAX_NODES 64
 
 static __thread char g_err[256];
 RSGPU_API const char *RSGPU_Iterators_LastError(void) { return g_err; }
@@ -90,6 +91,7 @@ typedef struct {
   RSGPU_Postings *postings;
   RSIndexResult *rec;      /* Term record (NewTokenRecord) */
   int has_freq, has_mask;
+  int offsets_set;         /* the record's offsets slice currently points into a block buffer */
   /* the current block's records */
   uint32_t *entry, *freq, *olen;
   uint64_t *mlo, *mhi, *opos;
@@ -110,11 +112,18 @@ typedef struct {
   Child child[MAX_CHILDREN];
   size_t block, blk_first, blk_count;  /* records of hits [blk_first, blk_first + blk_count) are loaded */
   RSIndexResult *result;   /* the aggregate / virtual result `current` points at */
-  /* two-level trees (RSGPU_NewTreeIterator): the root's children are groups of consecutive child slots; a group that is
-   * a union / intersection has its own aggregate between the root and its term records */
-  int n_groups;            /* 0: flat (every child hangs off the root) */
-  int group_first[MAX_CHILDREN + 1], group_op[MAX_CHILDREN];
-  RSIndexResult *group_rec[MAX_CHILDREN];
+  /* the result tree, post-order over the child slots (RSGPU_Hits_TreeNodes): node i is a term (child slot node_leaf[i]) or
+   * an aggregate with its own record and the indices of its children; the root is the last node and owns `result` */
+  int n_nodes;
+  uint8_t node_op[MAX_NODES], node_leaf[MAX_NODES];
+  uint8_t node_nkids[MAX_NODES];
+  uint8_t node_kid[MAX_NODES][MAX_CHILDREN];
+  RSIndexResult *node_rec[MAX_NODES]; /* aggregates: their record (the root's is `result`); terms: the child's record */
+  uint8_t node_present[MAX_NODES];
+  /* in-place rebuild: while the set of children present in a document equals the previous document's, every aggregate
+   * already holds the right child pointers -- only the per-document fields are patched */
+  bool wired;
+  uint32_t last_pattern;
 } GpuIt;
 
 static size_t it_num_estimated(const QueryIterator *self) { return ((const GpuIt *)self)->est; }
@@ -192,45 +201,83 @@ static int land(GpuIt *it, size_t i) {
   return load_block(it, i);
 }
 
+/* Term record of a child slot for the hit at block position j (RawTermResultBuilder::new: frequency 1 unless the codec
+ * decodes one; term.rs:95: every field unless it stores a mask).  The offsets go through the module's
+ * RSOffsetVector_SetData (types_ffi.h:444; borrowed bytes of the block buffer) -- the slice's representation is the
+ * module's business -- except that an empty slice is not set again over an empty slice (codecs without offsets). */
+static inline void patch_term(Child *ch, size_t j, t_docId id) {
+  RSIndexResult *t = ch->rec;
+  t->docId = id;
+  t->freq = ch->has_freq ? ch->freq[j] : 1;
+  t->fieldMask = ch->has_mask ? ((t_fieldMask)ch->mhi[j] << 64) | (t_fieldMask)ch->mlo[j] : RS_FIELDMASK_ALL;
+  const uint32_t ol = ch->olen[j];
+  if (ol || ch->offsets_set) {
+    g_api.RSOffsetVector_SetData(&t->data.term.offsets, ol ? (const char *)ch->obytes + (ch->opos[j] - ch->obase) : NULL, ol);
+    ch->offsets_set = ol != 0;
+  }
+}
+
 static void build_current(GpuIt *it, size_t i) {
   RSIndexResult *r = it->result;
   const t_docId id = it->ids[i];
   if (it->kind == K_NOT) {
     r->docId = id;
-  } else {
-    /* Intersection::build_aggregate_result (intersection.rs:313-341): per-document fields reset, then every child
-     * pushed as a borrowed reference -- AddChild takes the child's doc id, adds its frequency, ORs its field mask */
-    r->freq = 0;
-    r->fieldMask = 0;
-    g_api.IndexResult_AggregateReset(r);
-    const size_t j = i - it->blk_first;
-    const int ng = it->n_groups ? it->n_groups : (int)it->n_children;
-    for (int g = 0; g < ng; g++) {
-      const size_t c0 = it->n_groups ? (size_t)it->group_first[g] : (size_t)g;
-      const size_t c1 = it->n_groups ? (size_t)it->group_first[g + 1] : (size_t)g + 1;
-      RSIndexResult *parent = r;
-      if (it->n_groups && it->group_op[g] != G_TERM) { /* a nested Union / Intersection: rebuilt like the root */
-        parent = it->group_rec[g];
-        parent->freq = 0;
-        parent->fieldMask = 0;
-        g_api.IndexResult_AggregateReset(parent);
+    it->base.lastDocId = id;
+    it->base.current = r;
+    return;
+  }
+  const size_t j = i - it->blk_first;
+  /* which children hold this document (a union child -- or a whole nested aggregate -- may not) */
+  uint32_t pattern = 0;
+  for (size_t c = 0; c < it->n_children; c++) pattern |= (uint32_t)(it->child[c].entry[j] != 0xFFFFFFFFu) << c;
+  if (it->wired && pattern == it->last_pattern) {
+    /* same shape as the previous document: the aggregates keep their child pointers; what AggregateResult_AddChild
+     * derives per child -- the doc id, the frequency sum, the field-mask union (intersection.rs:313-341) -- is recomputed */
+    for (int n = 0; n < it->n_nodes; n++) {
+      if (!it->node_present[n]) continue;
+      if (it->node_op[n] == 0) {
+        patch_term(&it->child[it->node_leaf[n]], j, id);
+        continue;
       }
-      size_t added = 0;
-      for (size_t c = c0; c < c1; c++) {
-        Child *ch = &it->child[c];
-        if (ch->entry[j] == 0xFFFFFFFFu) continue; /* a union child (or a whole group) that does not hold the document */
-        RSIndexResult *t = ch->rec;
-        t->docId = id;
-        t->freq = ch->has_freq ? ch->freq[j] : 1; /* RawTermResultBuilder::new: frequency 1 unless the codec decodes one */
-        t->fieldMask = ch->has_mask ? ((t_fieldMask)ch->mhi[j] << 64) | (t_fieldMask)ch->mlo[j] : RS_FIELDMASK_ALL; /* term.rs:95 */
-        const char *ob = ch->olen[j] ? (const char *)ch->obytes + (ch->opos[j] - ch->obase) : NULL;
-        g_api.RSOffsetVector_SetData(&t->data.term.offsets, ob, ch->olen[j]);
-        g_api.AggregateResult_AddChild(parent, t);
+      RSIndexResult *a = it->node_rec[n];
+      uint32_t f = 0;
+      t_fieldMask m = 0;
+      for (int k = 0; k < it->node_nkids[n]; k++) {
+        const int kid = it->node_kid[n][k];
+        if (!it->node_present[kid]) continue;
+        f += it->node_rec[kid]->freq;
+        m |= it->node_rec[kid]->fieldMask;
+      }
+      a->freq = f;
+      a->fieldMask = m;
+      a->docId = id;
+    }
+  } else {
+    /* Intersection::build_aggregate_result (intersection.rs:313-341) / the union's (union_flat.rs:297-320), bottom-up:
+     * per-document fields reset, then every child that holds the document pushed as a borrowed reference */
+    for (int n = 0; n < it->n_nodes; n++) {
+      if (it->node_op[n] == 0) {
+        Child *ch = &it->child[it->node_leaf[n]];
+        it->node_present[n] = ch->entry[j] != 0xFFFFFFFFu;
+        if (it->node_present[n]) patch_term(ch, j, id);
+        continue;
+      }
+      RSIndexResult *a = it->node_rec[n];
+      a->freq = 0;
+      a->fieldMask = 0;
+      g_api.IndexResult_AggregateReset(a);
+      int added = 0;
+      for (int k = 0; k < it->node_nkids[n]; k++) {
+        const int kid = it->node_kid[n][k];
+        if (!it->node_present[kid]) continue;
+        g_api.AggregateResult_AddChild(a, it->node_rec[kid]); /* takes the child's doc id, adds its frequency, ORs its mask */
         added++;
       }
-      if (parent != r && added) g_api.AggregateResult_AddChild(r, parent); /* takes the group's doc id, frequency, mask */
+      it->node_present[n] = added > 0;
     }
     r->docId = id;
+    it->wired = true;
+    it->last_pattern = pattern;
   }
   it->base.lastDocId = id;
   it->base.current = r;
@@ -297,15 +344,17 @@ static void it_free(QueryIterator *self) {
       g_api.IndexResult_Free(it->child[c].rec);
     }
   }
+  /* aggregates: the children were borrowed (the root's record is `result`, the last node) */
+  for (int n = 0; n < it->n_nodes; n++)
+    if (it->node_op[n] != 0 && it->node_rec[n]) {
+      g_api.IndexResult_AggregateReset(it->node_rec[n]);
+      g_api.IndexResult_Free(it->node_rec[n]);
+      if (it->node_rec[n] == it->result) it->result = NULL;
+    }
   if (it->result) {
-    if (it->kind != K_NOT) g_api.IndexResult_AggregateReset(it->result); /* the children were borrowed */
+    if (it->kind != K_NOT) g_api.IndexResult_AggregateReset(it->result);
     g_api.IndexResult_Free(it->result);
   }
-  for (int g = 0; g < it->n_groups; g++)
-    if (it->group_rec[g]) {
-      g_api.IndexResult_AggregateReset(it->group_rec[g]);
-      g_api.IndexResult_Free(it->group_rec[g]);
-    }
   if (it->own_hits && it->hits) RSGPU_Hits_Free(it->hits);
   free(it->ids);
   free(it);
@@ -358,7 +407,36 @@ static GpuIt *make(int kind, RSGPU_Hits *hits, bool own, const RSGPU_TermArg *te
     return it;
   }
   it->n_children = num;
-  it->result = kind == K_AND ? g_api.NewIntersectResult(num, weight) : g_api.NewUnionResult(num, weight);
+  /* the result tree the device evaluated (any depth): terms = child slots, aggregates get records of their own; the root's
+   * weight is this iterator's */
+  int t_op[MAX_NODES], t_leaf[MAX_NODES], t_nch[MAX_NODES];
+  double t_w[MAX_NODES];
+  const int nn = RSGPU_Hits_TreeNodes(hits, t_op, t_leaf, t_nch, t_w);
+  if (nn < 2 || nn > MAX_NODES || t_op[nn - 1] == 0) {
+    set_err("the hit list carries no result tree", NULL);
+    it->own_hits = false;
+    it_free(&it->base);
+    return NULL;
+  }
+  it->n_nodes = nn;
+  {
+    int size[MAX_NODES]; /* nodes in the subtree ending at i */
+    for (int n = 0; n < nn; n++) {
+      it->node_op[n] = (uint8_t)t_op[n];
+      it->node_leaf[n] = (uint8_t)(t_op[n] == 0 ? t_leaf[n] : 0);
+      it->node_nkids[n] = 0;
+      size[n] = 1;
+      if (t_op[n] == 0) continue;
+      int at = n - 1, kids[MAX_CHILDREN], nk = 0;
+      for (int k = 0; k < t_nch[n] && at >= 0 && nk < MAX_CHILDREN; k++) { /* the children, last first */
+        kids[nk++] = at;
+        size[n] += size[at];
+        at -= size[at];
+      }
+      it->node_nkids[n] = (uint8_t)nk;
+      for (int k = 0; k < nk; k++) it->node_kid[n][k] = (uint8_t)kids[nk - 1 - k];
+    }
+  }
   for (size_t c = 0; c < num; c++) { /* children in the order the device iterated them */
     Child *ch = &it->child[c];
     const RSGPU_TermArg *t = &terms[order[c]];
@@ -371,8 +449,18 @@ static GpuIt *make(int kind, RSGPU_Hits *hits, bool own, const RSGPU_TermArg *te
   }
   /* the module's allocator failing is the one thing that can go wrong after the terms have been handed over: the records
    * made so far (and their terms) are released with the iterator */
-  bool ok = it->result != NULL;
+  bool ok = true;
   for (size_t c = 0; c < num; c++) ok = ok && it->child[c].rec != NULL;
+  for (int n = 0; n < nn; n++) {
+    if (it->node_op[n] == 0) {
+      it->node_rec[n] = it->child[it->node_leaf[n]].rec;
+      continue;
+    }
+    const double w = n == nn - 1 ? weight : t_w[n];
+    it->node_rec[n] = it->node_op[n] == G_UNION ? g_api.NewUnionResult(it->node_nkids[n], w) : g_api.NewIntersectResult(it->node_nkids[n], w);
+    ok = ok && it->node_rec[n] != NULL;
+  }
+  it->result = it->node_rec[nn - 1];
   if (!ok) {
     set_err("the module could not allocate a result", NULL);
     it->own_hits = false; /* the caller frees the hit list on a NULL return */
@@ -466,13 +554,6 @@ RSGPU_API QueryIterator *RSGPU_NewHitsIterator(RSGPU_Hits *hits, const RSGPU_Ter
     if (n < mn) mn = n;
     sum += n;
   }
-  int gop[MAX_CHILDREN];
-  const int ng = RSGPU_Hits_Tree(hits, NULL, NULL, gop, NULL);
-  for (int g = 0; g < ng; g++)
-    if (gop[g] != G_TERM) { /* nested groups need the tree's shape and weights: RSGPU_NewTreeIterator builds those */
-      set_err("the hit list comes from a two-level tree", "use RSGPU_NewTreeIterator");
-      return NULL;
-    }
   const int is_union = RSGPU_Hits_IsUnion(hits);
   GpuIt *it = make(is_union ? K_OR : K_AND, hits, own_hits, terms, num, weight, is_union ? sum : mn);
   return it ? &it->base : NULL;
@@ -508,30 +589,60 @@ RSGPU_API QueryIterator *RSGPU_NewTreeIterator(const RSGPU_TreeQuery *q, const R
     set_err("RSGPU_EvalTree", RSGPU_LastError());
     return NULL;
   }
-  int is_union = 0, gf[MAX_CHILDREN + 1], gop[MAX_CHILDREN];
-  double gw[MAX_CHILDREN];
-  const int ng = RSGPU_Hits_Tree(h, &is_union, gf, gop, gw);
-  GpuIt *it = ng > 0 ? make(is_union ? K_OR : K_AND, h, true, terms, num, weight, est) : NULL;
+  GpuIt *it = make(RSGPU_Hits_IsUnion(h) ? K_OR : K_AND, h, true, terms, num, weight, est);
   if (!it) {
     RSGPU_Hits_Free(h);
     return NULL;
   }
-  /* make() hung every term off the root; re-root: the root holds one child per group */
-  g_api.IndexResult_AggregateReset(it->result);
-  g_api.IndexResult_Free(it->result);
-  it->result = is_union ? g_api.NewUnionResult((size_t)ng, weight) : g_api.NewIntersectResult((size_t)ng, weight);
-  it->n_groups = ng;
-  for (int g = 0; g <= ng; g++) it->group_first[g] = gf[g];
-  for (int g = 0; g < ng; g++) {
-    it->group_op[g] = gop[g];
-    const size_t n = (size_t)(gf[g + 1] - gf[g]);
-    it->group_rec[g] = gop[g] == G_UNION ? g_api.NewUnionResult(n, gw[g]) : gop[g] == G_INTERSECT ? g_api.NewIntersectResult(n, gw[g]) : NULL;
+  return &it->base;
+}
+
+/* A query tree of any depth behind one iterator (RSGPU_EvalTreeNodes): `current` nests aggregates exactly as the
+ * reference's nested iterators do. */
+RSGPU_API QueryIterator *RSGPU_NewTreeNodesIterator(const RSGPU_TreeNode *nodes, size_t n_nodes, const RSGPU_TermArg *terms,
+                                                    size_t num, double weight) {
+  if (!nodes || !n_nodes || n_nodes > MAX_NODES || check_terms(terms, num)) {
+    if (!nodes || !n_nodes || n_nodes > MAX_NODES) set_err("1..64 tree nodes", NULL);
+    return NULL;
   }
-  bool ok = it->result != NULL;
-  for (int g = 0; g < ng; g++) ok = ok && (gop[g] == G_TERM || it->group_rec[g] != NULL);
-  if (!ok) { /* the module's allocator failed (see make()): everything made so far goes with the iterator */
-    set_err("the module could not allocate a result", NULL);
-    it_free(&it->base); /* (owns the hit list) */
+  RSGPU_Postings *lists[MAX_CHILDREN];
+  for (size_t i = 0; i < num; i++) lists[i] = terms[i].postings;
+  /* estimates as the reference's constructors compute them, bottom-up: a term its unique docs, a union the sum, an
+   * intersection the smallest child (union_flat.rs:102, intersection.rs:144-146) */
+  size_t stack[MAX_NODES], sp = 0;
+  for (size_t i = 0; i < n_nodes; i++) {
+    if (nodes[i].op == RSGPU_OP_TERM) {
+      if (nodes[i].list >= num) {
+        set_err("a term node names a list that is not there", NULL);
+        return NULL;
+      }
+      stack[sp++] = RSGPU_Postings_NumEntries(lists[nodes[i].list]);
+      continue;
+    }
+    if (!nodes[i].n_children || nodes[i].n_children > sp) {
+      set_err("the node array is not a post-order tree", NULL);
+      return NULL;
+    }
+    size_t e = nodes[i].op == RSGPU_OP_INTERSECT ? (size_t)-1 : 0;
+    for (size_t k = 0; k < nodes[i].n_children; k++) {
+      const size_t c = stack[--sp];
+      if (nodes[i].op == RSGPU_OP_INTERSECT) e = c < e ? c : e;
+      else e += c;
+    }
+    stack[sp++] = e;
+  }
+  if (sp != 1) {
+    set_err("the node array is not a post-order tree", NULL);
+    return NULL;
+  }
+  RSGPU_Hits *h = RSGPU_EvalTreeNodes(nodes, n_nodes, lists, num);
+  if (!h) {
+    set_err("RSGPU_EvalTreeNodes", RSGPU_LastError());
+    return NULL;
+  }
+  GpuIt *it = make(RSGPU_Hits_IsUnion(h) ? K_OR : K_AND, h, true, terms, num, weight, stack[0]);
+  if (!it) {
+    RSGPU_Hits_Free(h);
     return NULL;
   }
   return &it->base;

@@ -445,6 +445,8 @@ def load_iterators(result_api_handle=None):
         L.RSGPU_NewHitsIterator.restype, L.RSGPU_NewHitsIterator.argtypes = _vp, [_vp, _vp, _sz, _dbl, C.c_bool]
         L.RSGPU_Iterator_Hits.restype, L.RSGPU_Iterator_Hits.argtypes = _vp, [_vp]
         L.RSGPU_NewTreeIterator.restype, L.RSGPU_NewTreeIterator.argtypes = _vp, [C.POINTER(TreeQuery), _vp, _dbl]
+        L.RSGPU_NewTreeNodesIterator.restype = _vp
+        L.RSGPU_NewTreeNodesIterator.argtypes = [C.POINTER(TreeNode), _sz, _vp, _sz, _dbl]
         _itlib = L
     if result_api_handle is not None:
         if _itlib.RSGPU_Iterators_SetResultAPI(None, _vp(result_api_handle)) != 0:
@@ -494,6 +496,34 @@ def new_tree_iterator(root_op, groups, terms=None, weights=None, weight=1.0, max
                   -1 if max_slop is None else int(max_slop), int(in_order))
     arr = term_args(flat, terms, weights)
     it = L.RSGPU_NewTreeIterator(C.byref(q), C.cast(arr, _vp), weight)
+    if not it:
+        raise RuntimeError("tree iterator: " + L.RSGPU_Iterators_LastError().decode())
+    return it
+
+
+def tree_node_array(tree):
+    """nested tuples (see NodeHits) -> ctypes array of RSGPU_TreeNode in post-order"""
+    nodes = []
+
+    def walk(t):
+        if t[0] == "t":
+            nodes.append(TreeNode(OP_TERM, int(t[1]), 0, 1.0, -1, 0))
+            return
+        for ch in t[2]:
+            walk(ch)
+        ms = t[3] if len(t) > 3 and t[3] is not None else -1
+        io = int(bool(t[4])) if len(t) > 4 else 0
+        nodes.append(TreeNode(OP_INTERSECT if t[0] == "and" else OP_UNION, 0, len(t[2]), float(t[1]), int(ms), io))
+    walk(tree)
+    return (TreeNode * len(nodes))(*nodes), len(nodes)
+
+
+def new_tree_nodes_iterator(tree, lists, terms=None, weights=None, weight=1.0):
+    """-> QueryIterator* over a query tree of any depth (nested tuples as for NodeHits); terms / weights per list."""
+    L = load_iterators()
+    arr, n = tree_node_array(tree)
+    ta = term_args(lists, terms, weights)
+    it = L.RSGPU_NewTreeNodesIterator(arr, n, C.cast(ta, _vp), len(lists), weight)
     if not it:
         raise RuntimeError("tree iterator: " + L.RSGPU_Iterators_LastError().decode())
     return it

@@ -66,6 +66,38 @@ API int RSGPU_Hits_Tree(const RSGPU_Hits *h, int *root_is_union, int *gf, int *g
   if (gf) gf[h->n_groups] = h->group_first[h->n_groups];
   return h->n_groups;
 }
+/* the same shape as a post-order node array (what query_iterators.c builds `current` from): every group's leaves, the
+ * group's aggregate when it is one, the root last */
+API int RSGPU_Hits_TreeNodes(const RSGPU_Hits *h, int *op, int *leaf, int *n_children, double *weight) {
+  int n = 0;
+  const int ng = h->n_groups ? h->n_groups : h->n_leaves;
+  for (int g = 0; g < ng; g++) {
+    const int a = h->n_groups ? h->group_first[g] : g, b = h->n_groups ? h->group_first[g + 1] : g + 1;
+    const int gop = h->n_groups ? h->group_op[g] : 0;
+    for (int l = a; l < b; l++, n++) {
+      if (op) op[n] = 0;
+      if (leaf) leaf[n] = l;
+      if (n_children) n_children[n] = 0;
+      if (weight) weight[n] = 1.0;
+    }
+    if (gop != 0) {
+      if (op) op[n] = gop;
+      if (leaf) leaf[n] = -1;
+      if (n_children) n_children[n] = b - a;
+      if (weight) weight[n] = h->group_weight[g];
+      n++;
+    }
+  }
+  if (op) op[n] = h->is_union ? 1 : 2;
+  if (leaf) leaf[n] = -1;
+  if (n_children) n_children[n] = ng;
+  if (weight) weight[n] = 1.0;
+  return n + 1;
+}
+API RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n, RSGPU_Postings *const *l, size_t nl) {
+  (void)nodes, (void)n, (void)l, (void)nl;
+  return take();
+}
 API long RSGPU_Hits_ReadRange(const RSGPU_Hits *h, size_t first, size_t count, uint64_t *ids) {
   g_reads++;
   if (first >= h->len) return 0;

@@ -11,6 +11,8 @@ scores the results with a scorer extension) and held to
   * the reference's compiled scorers (oracle/_ref/libref_default_ext.so, src/ext/default.c) applied to the iterator's
     results one by one == RSGPU_Hits_Score over the same hit list in one batch.
 """
+import zlib
+
 import numpy as np
 import pytest
 
@@ -331,7 +333,7 @@ def test_tree_iterator_results_score_like_the_batched_tree_scorer(name, root, sh
     """The iterator's `current` for a two-level tree, scored one by one by the reference's compiled scorers (which walk
     the nested aggregates and ask IndexResult_MinOffsetDelta for the slop) == RSGPU_Hits_Score over the tree's hit list;
     doc ids, the number of root children per document and the aggregate frequency follow the oracle's set algebra."""
-    rng = np.random.default_rng(abs(hash(name)) % 1000 + 17)
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 17)
     n_lists = sum(len(g[2]) for g in shape)
     built = [tree_rand_list(rng, O.C_FULL, int(rng.integers(300, 1500)), 2500, True) for _ in range(n_lists)]
     lists, recs = [b[0] for b in built], [b[1] for b in built]
@@ -379,3 +381,58 @@ def test_tree_iterator_results_score_like_the_batched_tree_scorer(name, root, sh
                 X.iter_free(it)
     finally:
         S.load_iterators().RSGPU_Iterators_SetBlock(65536)
+
+
+# ---- query trees of any depth behind the vtable (RSGPU_NewTreeNodesIterator) --------------------------------------------
+@pytest.mark.parametrize("name,tree,n_lists", [
+    ("and_or_and", ("and", 1.0, [("or", 0.5, [("and", 2.0, [("t", 0), ("t", 1)]), ("t", 2)]), ("t", 3)]), 4),
+    ("or_and_or_and", ("or", 1.0, [("t", 0), ("and", 0.7, [("t", 1), ("or", 1.0, [("t", 2), ("and", 3.0, [("t", 3), ("t", 4)])])])]), 5),
+    ("phrase_inside", ("and", 1.0, [("or", 1.0, [("and", 1.5, [("t", 0), ("t", 1)], 4, True), ("t", 2)]), ("t", 3)]), 4),
+])
+def test_deep_tree_iterator_results_score_like_the_batched_scorer(name, tree, n_lists):
+    """`current` of a depth-3 / depth-4 tree -- nested aggregates rebuilt per document, matched children only under a
+    union -- scored one by one by the reference's COMPILED scorers (src/ext/default.c walking the nested aggregates,
+    IndexResult_MinOffsetDelta for the slop) == RSGPU_Hits_Score's post-order evaluation over the same hit list, bit for
+    bit; with the in-place rebuild forced through small record blocks."""
+    if not X.have_ref():
+        pytest.skip("needs oracle/_ref/libref_default_ext.so (the reference's scorers and IndexResult_MinOffsetDelta)")
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + 3)
+    built = [tree_rand_list(rng, O.C_FULL, int(rng.integers(900, 1900)), 2500, True) for _ in range(n_lists)]
+    lists = [b[0] for b in built]
+    sizes = [l.unique_docs for l in lists]
+    g = [gpu(l) for l in lists]
+    n_docs = 2500
+    doc_len = rng.integers(5, 200, n_docs + 1).astype(np.uint32)
+    doc_score = rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32)
+    max_freq = rng.integers(1, 40, n_docs + 1).astype(np.uint32)
+    idf = [S.calculate_idf(n_docs, s) for s in sizes]
+    bidf = [S.calculate_idf_bm25(n_docs, s) for s in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    avg = float(doc_len[1:].mean())
+    host = X.Host()
+    host.load_ref()
+    S.load_iterators().RSGPU_Iterators_SetBlock(41)
+    h = S.NodeHits(tree, g)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    want_ids = h.read()[0].tolist()
+    assert len(want_ids) > 5
+    try:
+        for scorer in ("BM25STD", "TFIDF", "BM25", "DISMAX", "TFIDF.DOCNORM"):
+            terms = [X.new_term(idf[i], bidf[i], "t%d" % i) for i in range(n_lists)]
+            it = S.new_tree_nodes_iterator(tree, g, terms=terms, weights=w, weight=1.5)
+            try:
+                ids, sc = X.iter_score_all(it, scorer, doc_len, doc_score, max_freq, len(want_ids) + 8, num_docs=n_docs,
+                                           avg_doc_len=avg, slop=0)
+                assert ids.tolist() == want_ids
+                gs = h.score(table, scorer, idf, bidf, w, n_docs, avg, root_weight=1.5)
+                assert np.array_equal(sc, gs), (scorer, np.max(np.abs(sc - gs)))
+                # rewind + skip around: the same documents again, whatever the wiring left behind
+                X.iter_script(it, [(X.OP_REWIND, 0)])
+                some = want_ids[:: max(len(want_ids) // 7, 1)]
+                res = X.iter_script(it, [(X.OP_SKIP, d) for d in some])
+                assert [r[3] for r in res] == some
+            finally:
+                X.iter_free(it)
+    finally:
+        S.load_iterators().RSGPU_Iterators_SetBlock(0)
+        h.free()

@@ -2,6 +2,8 @@
 CPU oracle: doc ids and per-term frequencies from set algebra over the oracle's decoded lists, scores from the oracle's
 result-tree scorers (O.Node) built per document in the aggregate's child order, slop and max_slop / in_order from the
 oracle's proximity restatement with merged union positions."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -141,7 +143,7 @@ T, U, I = S.OP_TERM, S.OP_UNION, S.OP_INTERSECT
     ("single_union_group", I, [(U, 1.0, [0, 1])]),
 ])
 def test_tree_matches_oracle(name, root, shape, with_offsets):
-    rng = np.random.default_rng(abs(hash(name)) % 10000 + int(with_offsets))
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + int(with_offsets))
     assert run_case(rng, root, shape, with_offsets) > 0 or name == "and_of_ands"
 
 
