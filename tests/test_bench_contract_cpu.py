@@ -89,7 +89,7 @@ def test_bench_imports_the_oracle_only_in_its_cpu_leg():
     import ast
     src = open(os.path.join(ROOT, "bench.py")).read()
     tree = ast.parse(src)
-    allowed = {"_oracle_lib", "verify_answers", "check_hybrid_with_oracle"}
+    allowed = {"_oracle_lib", "verify_answers", "check_hybrid_with_oracle", "check_batched_with_oracle"}
     users = set()
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         for node in ast.walk(fn):
