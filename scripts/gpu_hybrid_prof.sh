@@ -19,7 +19,7 @@ t0 = int(seg[0]["Start_Timestamp"])
 with open("gpurun_out/hybrid_timeline.txt", "w") as out:
     for r in seg:
         s, e = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
-        line = "%8.1f us  +%6.1f us  q%s  %s" % (s / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), r["Kernel_Name"].split("(")[0][-70:])
+        line = "%8.1f us  +%6.1f us  q%s  %s" % (s / 1e3, (e - s) / 1e3, r.get("Queue_Id", "?"), __import__("re").sub(r"\(anonymous namespace\)::|rsgpu::|void ", "", r["Kernel_Name"]).split("(")[0][:60])
         print(line); out.write(line + "\n")
     line = "span of one query on the device: %.1f us (next query's first kernel starts at %.1f us)" % ((max(int(r["End_Timestamp"]) for r in seg) - t0) / 1e3, (int(rows[last]["Start_Timestamp"]) - t0) / 1e3)
     print(line); out.write(line + "\n")

@@ -12,6 +12,10 @@ import oracle as O  # noqa: E402
 from redisearch_amd import search as S  # noqa: E402
 from redisearch_amd import vecsim as V  # noqa: E402
 
+for kv in os.environ.get("RSGPU_TUNING", "").split(","):   # e.g. RSGPU_TUNING=hybrid_one_pass=0
+    if kv:
+        key, val = kv.split("=")
+        assert V.load().RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
 n_docs, n_vec, dim = int(os.environ.get("N_DOCS", 50_000_000)), int(os.environ.get("N_VEC", 5_000_000)), 768
 reps = int(os.environ.get("REPS", 200))
 rng = np.random.default_rng(49)
