@@ -838,6 +838,9 @@ __device__ __forceinline__ uint64_t d2key(double d) {
   return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
 }
 
+// DEEP: the tree is deeper than root -> groups -> leaves (P.n_nodes > 0).  A kernel of its own because its per-level
+// accumulators are indexed dynamically and live in scratch memory: the flat / two-level kernel must not pay for them.
+template <bool DEEP>
 __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_t *__restrict__ ids,
                                                     const uint32_t *__restrict__ freqs, uint32_t len, uint32_t cap,
                                                     const uint32_t *__restrict__ doc_len,
@@ -859,7 +862,7 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreParams P, const uint32_
   // its weight; DISMAX takes the maximum over a UNION's children instead.  A leaf that did not match this document
   // (union children) carries frequency 0 and contributes exactly 0.
   auto fold = [&](auto leaf, bool dismax) {
-    if (P.n_nodes > 0) {
+    if constexpr (DEEP) {
       // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
       // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the
       // reference's recursions add them in -- and its own value, weight * that, goes to its parent's accumulator.
@@ -1304,8 +1307,12 @@ void launch_score(const ScoreParams &p, const uint32_t *ids, const uint32_t *fre
                   const uint32_t *doc_len, const float *doc_score, const uint32_t *max_freq, uint32_t table_n,
                   double *scores, uint64_t *keys, hipStream_t s, uint32_t *keys32) {
   if (!len) return;
-  hipLaunchKernelGGL(score_kernel, dim3(blocks_for(len)), dim3(256), 0, s, p, ids, freqs, len, cap, doc_len,
-                     doc_score, max_freq, table_n, scores, keys, keys32);
+  if (p.n_nodes > 0)
+    hipLaunchKernelGGL(score_kernel<true>, dim3(blocks_for(len)), dim3(256), 0, s, p, ids, freqs, len, cap, doc_len,
+                       doc_score, max_freq, table_n, scores, keys, keys32);
+  else
+    hipLaunchKernelGGL(score_kernel<false>, dim3(blocks_for(len)), dim3(256), 0, s, p, ids, freqs, len, cap, doc_len,
+                       doc_score, max_freq, table_n, scores, keys, keys32);
 }
 void launch_fetch_cand64(const void *cand, const uint32_t *count, uint32_t cap, const uint64_t *keys64,
                          const uint32_t *ids, uint32_t *out_rows, uint64_t *out_keys, uint32_t *out_ids, uint32_t *out_n,

@@ -38,8 +38,11 @@ def test_no_spills_on_any_default_path(kernels):
 
 
 def test_scratch_only_for_the_proximity_cursors(kernels):
-    scratch = {re.sub(r"<.*", "", k["name"]) for k in kernels if k["scratch"] and not k["vgpr_spill"]}
-    assert scratch <= {"prox_filter_kernel", "prox_slop_kernel"}, scratch
+    # (and the deep-tree scorer: one accumulator per nesting level, indexed dynamically -- score_kernel<true> only, the
+    # flat / two-level scorer score_kernel<false> must stay scratch-free)
+    scratch = {re.sub(r"<.*", "", k["name"]) if not k["name"].startswith("score_kernel") else k["name"]
+               for k in kernels if k["scratch"] and not k["vgpr_spill"]}
+    assert scratch <= {"prox_filter_kernel", "prox_slop_kernel", "score_kernel<true>"}, scratch
 
 
 def test_lds_fits_the_cu(kernels):
@@ -72,3 +75,15 @@ def test_single_query_scan_budget(kernels):
     for k in scan:
         u = int(re.match(r"scan_kernel<\d+, \d+, \d+, \d+, (\d+)", k["name"]).group(1))
         assert k["vgpr"] <= (512 if u >= 8 else 256), (k["name"], k["vgpr"])
+
+
+def test_multi_query_scan_budget(kernels):
+    """scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B, EXACT>: eight queries' chunks live in registers (96 of them at 768
+    fp32); the kernel must keep two wavefronts per SIMD (<= 256 registers) without spilling -- a spill here costs bandwidth,
+    not parity, so only this test would notice."""
+    mq = [k for k in kernels if k["name"].startswith("scan_mq_kernel<")]
+    assert len(mq) >= 100
+    for k in mq:
+        assert k["vgpr"] <= 256 and not k["vgpr_spill"] and not k["scratch"], (k["name"], k["vgpr"], k["vgpr_spill"])
+    head = [k for k in mq if k["name"].startswith("scan_mq_kernel<0, 1, 64, 3, 4, 8, true")]
+    assert len(head) == 1 and head[0]["vgpr"] <= 224, head     # the 10 M x 768 fp32 cosine pass
