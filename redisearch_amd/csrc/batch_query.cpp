@@ -56,10 +56,11 @@ struct BatchScratch {
   int device = -1;
   Dev<uint8_t> queries, queries16;  // (queries16: fp16 copy for the pass over an fp16 shadow; int8 copy for an int8 shadow)
   Dev<float> tau, qscale, slack_q;  // (qscale / slack_q: int8 shadow -- per-query scale product and error band)
+  Dev<float> hqn;                   // (L2 pass: [2][256] |q|^2 / 2 per query, shrunk; the queries' share of the error band)
   Dev<uint32_t> cand_count, overflow, keys, out_rows, out_keys, out_n;
   Dev<uint64_t> cand, sub_cand;
   Dev<uint32_t> sub_count;
-  Pinned hq, h_rows, h_keys, h_n, h_over, h_tau;
+  Pinned hq, h_rows, h_keys, h_n, h_over, h_tau, h_l2;
 };
 // two slots: the host builds the replies of batch b while the device works on batch b+1
 thread_local BatchScratch tls_batch[2];
@@ -80,7 +81,16 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                          scan_tuning().gemm_qs && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) &&
                          s8g_stride() / 16 <= 64 &&  // (int8 rows up to 1024 bytes)
                          batch_rescore_supported((uint32_t)(stride_ / 16));
-  const bool gemm_ok = via_shadow || (s8g_shape && type == VecSimType_FLOAT32) ||
+  // FLOAT16 / BFLOAT16 L2 indexes (round 3): the passes compute x.q on the matrix cores and fold the rows' half norms in
+  // (2 (|q|^2/2 + |x|^2/2 - x.q), gemm_qs_kernels.hip "L2"); every bound is widened by the summation-order band and the
+  // survivors are re-scored with the single-query L2 scan's arithmetic -> bit-identical to single queries
+  const bool l2_shape = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric == VecSimMetric_L2 && !multi &&
+                        k > 0 && k <= 1024 && scan_tuning().gemm_qs && scan_tuning().batch_mfma &&
+                        gemm_qs_supported((uint32_t)(stride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
+  // (an unlocked look at the size: at worst a small index computes norms it does not use, or a large one answers this batch
+  // eight queries per pass -- the decision proper is taken under the lock below)
+  bool via_l2 = l2_shape && (size_t)n_rows_ + stage_n_ > (1u << 19) && ensure_half_norms();
+  const bool gemm_ok = via_shadow || via_l2 || (s8g_shape && type == VecSimType_FLOAT32) ||
                        ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi &&
                         k > 0 && k <= 4096);
   // FLOAT16 IP / cosine indexes that carry the int8 shadow (shadow_ == 3): the filter passes run on the int8 matrix
@@ -148,7 +158,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     const uint32_t n = n_rows_;
     // (rows added since ensure_shadow8g, or a corpus the single-query path serves anyway: the plain fp16 passes)
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
-    if (f32_needs_s8g && !via_shadow8) {
+    if (via_l2 && (hn_built_ < n || hn_bad_ || n <= (1u << 19))) via_l2 = false;
+    if ((f32_needs_s8g && !via_shadow8) || (l2_shape && !via_l2)) {
       g.unlock();
       all_single();
       return;
@@ -186,14 +197,15 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
     const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
-    if ((via_shadow || via_shadow8) && !use_qs) {  // small corpora: the single-query path is already cheap
+    if ((via_shadow || via_shadow8 || via_l2) && !use_qs) {  // small corpora: the single-query path is already cheap
       g.unlock();
       all_single();
       return;
     }
     // FLOAT32 rows have no tiled GEMM for the sample bound: the first int8 phase runs over n0 rows with tau = +inf -- every
     // (row, query) pair becomes a candidate -- and the first bound is the K-th shadow distance among them + the band
-    const bool phase0 = via_shadow8 && type == VecSimType_FLOAT32;
+    // (L2 passes the same way: the tiled GEMM computes 1 - x.q only)
+    const bool phase0 = (via_shadow8 && type == VecSimType_FLOAT32) || via_l2;
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
@@ -226,6 +238,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       if (via_shadow8) {
         sc.qscale.ensure(kBatch);
         sc.slack_q.ensure(kBatch);
+      }
+      if (via_l2) {
+        sc.hqn.ensure(2 * kBatch);  // (|q|^2 / 2 shrunk, then the queries' share of the band)
+        sc.h_l2.ensure<float>(2 * kBatch);
       }
       sc.cand_count.ensure(kBatch);
       sc.overflow.ensure(kBatch);
@@ -260,6 +276,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       }
     }
     const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+    std::vector<uint8_t> l2_redo[2];  // per slot: queries of the batch the L2 pass leaves to the exact scan
 
     // everything of batch q0.. onto the slot's stream, nothing waited for
     auto enqueue = [&](int sl, size_t q0) {
@@ -287,6 +304,33 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         slack_q = sc.slack_q.p;
         qscale = sc.qscale.p;
       }
+      const float *l2_hn = nullptr, *l2_hq = nullptr;
+      RowBand rb;
+      if (via_l2) {
+        // |d~ - d| <= rel (hn[row] + hq): the MFMA's summation order against the scan's, both within dim roundings of |x||q|
+        // <= hn + hq, the rows' norms within dim roundings of hn (DESIGN.md section 3 "L2 on the matrix cores").  The pass
+        // works with norms and hq shrunk by (1 - rel/2): what it emits is the lower bound d~ - band(row, q); the candidate
+        // lists carry the upper bound lb + 2 band(row, q), the thresholds are selected from those without further slack.
+        float *hl = static_cast<float *>(sc.h_l2.p);
+        const float rel = hn_rel(), shrink = 1.0f - 0.5f * rel;
+        l2_redo[sl].assign(kBatch, 0);
+        for (uint32_t i = 0; i < kBatch; i++) {
+          float h = i < nb ? half_sq_norm_host((const uint8_t *)queries + (q0 + i) * elem_bytes_) : 0.0f;
+          if (!(h <= 3.0e38f)) {  // a query with an inf / NaN element: answered by the exact scan (finalize)
+            l2_redo[sl][i] = 1;
+            h = 0.0f;
+          }
+          hl[i] = h * shrink;
+          hl[kBatch + i] = 2.0f * rel * h;
+        }
+        HIP_CHECK(hipMemcpyAsync(sc.hqn.p, hl, 2 * kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        l2_hn = d_hnorm_;
+        l2_hq = sc.hqn.p;
+        rb.hnorm = d_hnorm_;
+        rb.hq2 = sc.hqn.p + kBatch;
+        rb.c1 = 2.0f * rel / shrink;
+        rb.inv2rel = 0.5f / rel;
+      }
       if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
       if (small) {
         launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
@@ -298,7 +342,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         // an exact bound widened by the band is as good as a shadow bound widened by it)
         if (phase0) {  // tau = +inf for the queries of the batch, -inf for the padding
           float *ht = sc.h_tau.ensure<float>(kBatch);  // (pinned, one per slot: free again once the slot's batch is finalized)
-          for (uint32_t i = 0; i < kBatch; i++) ht[i] = i < nb ? __builtin_inff() : -__builtin_inff();
+          for (uint32_t i = 0; i < kBatch; i++)
+            ht[i] = i < nb && !(via_l2 && l2_redo[sl][i]) ? __builtin_inff() : -__builtin_inff();
           HIP_CHECK(hipMemcpyAsync(sc.tau.p, ht, kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
         } else {
           if (via_shadow8)
@@ -314,10 +359,11 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           uint32_t from = 0;
           for (size_t ph = 0; ph < phase_end.size(); ph++) {
             const uint32_t e = phase_end[ph];
-            launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p,
-                           sub_cap, c->stream, qscale);
+            if (!launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
+                                c->stream, qscale, l2_hn, l2_hq))
+              throw std::runtime_error("batched pass: the matrix-core kernel refused a row shape the route was gated on");
             launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
-                                sc.cand.p, cand_cap, ph > 0, c->stream);
+                                sc.cand.p, cand_cap, ph > 0, c->stream, via_l2 ? &rb : nullptr);
             if (ph + 1 < phase_end.size())
               launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                           c->stream, slack, slack_q);
@@ -327,13 +373,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);
         }
-        if (via_shadow || via_shadow8) {
+        if (via_shadow || via_shadow8 || via_l2) {
           // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
           // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                       c->stream, slack, slack_q);
           if (!launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                                    sc.tau.p, c->stream, via_shadow8 ? ktype : KT_F32))
+                                    sc.tau.p, c->stream, via_shadow8 || via_l2 ? ktype : KT_F32, via_l2 ? KM_L2 : KM_IP,
+                                    via_l2 ? &rb : nullptr))
             throw std::runtime_error("batched shadow pass: the re-scoring kernel refused a row shape the route was gated on");
         }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
@@ -367,7 +414,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       std::vector<VecSimQueryResult> res;
       for (uint32_t i = 0; i < nb; i++) {
         const size_t qi = q0 + i;
-        if (h_over[i]) {  // candidate list overflowed: redo this query on the single-query path
+        if (h_over[i] || (via_l2 && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
           redo.push_back(qi);
           continue;
         }

@@ -338,12 +338,15 @@ FlatIndex::~FlatIndex() {
   if (d_smax_) HIP_IGNORE(hipFree(d_smax_));
   if (d_s8g_stats_) HIP_IGNORE(hipFree(d_s8g_stats_));
   if (d_s8g_f32_) HIP_IGNORE(hipFree(d_s8g_f32_));
+  if (d_hnorm_) HIP_IGNORE(hipFree(d_hnorm_));
+  if (d_hn_bad_) HIP_IGNORE(hipFree(d_hn_bad_));
   if (h_stage_) HIP_IGNORE(hipHostFree(h_stage_));
   HIP_IGNORE(hipStreamDestroy(wstream_));
 }
 
 size_t FlatIndex::memory() const {
-  return rows_buf_.physical() + shadow_buf_.physical() + s8g_f32_cap_rows_ * round_up(dim, 16) + cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
+  return rows_buf_.physical() + shadow_buf_.physical() + s8g_f32_cap_rows_ * round_up(dim, 16) + hnorm_cap_rows_ * sizeof(float) +
+         cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
          host_bytes_ + stage_cap_ * stride_;
 }
 
@@ -526,6 +529,71 @@ bool FlatIndex::ensure_shadow8g() {
   return true;
 }
 
+// |x|^2 / 2 per row for the L2 form of the batched matrix-core pass: see flat_index.hpp.
+bool FlatIndex::ensure_half_norms() {
+  flush_if_needed();
+  {
+    std::shared_lock<std::shared_mutex> g(mu);
+    if (hn_bad_) return false;
+    if (d_hnorm_ && hn_built_ >= n_rows_ && n_rows_) return true;
+  }
+  std::unique_lock<std::shared_mutex> g(mu);
+  HIP_CHECK(hipSetDevice(device));
+  const uint32_t n = n_rows_;
+  if (!n || hn_bad_) return false;
+  hn_built_ = std::min(hn_built_, n);
+  if (!d_hn_bad_) {
+    HIP_CHECK(hipMalloc((void **)&d_hn_bad_, sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d_hn_bad_, 0, sizeof(uint32_t)));
+  }
+  if ((size_t)n + 96 > hnorm_cap_rows_) {  // (the pass reads 64 norms from the first row of its last tile on)
+    if (d_hnorm_) HIP_IGNORE(hipFree(d_hnorm_));
+    d_hnorm_ = nullptr;
+    hnorm_cap_rows_ = 0;
+    const size_t cap = (size_t)n + n / 8 + 128;
+    HIP_CHECK(hipMalloc((void **)&d_hnorm_, cap * sizeof(float)));
+    HIP_CHECK(hipMemsetAsync(d_hnorm_, 0, cap * sizeof(float), wstream_));
+    hnorm_cap_rows_ = cap;
+    hn_built_ = 0;
+  }
+  if (hn_built_ < n) {
+    launch_half_norm_rows(ktype, d_rows_, stride_, hn_built_, n, 1.0f - 0.5f * hn_rel(), d_hnorm_, d_hn_bad_, wstream_);
+    HIP_CHECK(hipGetLastError());
+    uint32_t bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_hn_bad_, sizeof bad, hipMemcpyDeviceToHost, wstream_));
+    HIP_CHECK(hipStreamSynchronize(wstream_));
+    if (bad) {  // a row with an inf / NaN norm: no band bounds such an index
+      hn_bad_ = true;
+      return false;
+    }
+    hn_built_ = n;
+  }
+  return true;
+}
+
+float FlatIndex::half_sq_norm_host(const void *blob) const {
+  float s = 0.0f;
+  switch (type) {
+    case VecSimType_FLOAT32:
+      for (size_t i = 0; i < dim; i++) s += ((const float *)blob)[i] * ((const float *)blob)[i];
+      break;
+    case VecSimType_FLOAT16:
+      for (size_t i = 0; i < dim; i++) {
+        const float a = h2f(((const uint16_t *)blob)[i]);
+        s += a * a;
+      }
+      break;
+    case VecSimType_BFLOAT16:
+      for (size_t i = 0; i < dim; i++) {
+        const float a = bf2f(((const uint16_t *)blob)[i]);
+        s += a * a;
+      }
+      break;
+    default: return __builtin_nanf("");
+  }
+  return 0.5f * s;
+}
+
 void FlatIndex::flush_if_needed() {
   {
     std::shared_lock<std::shared_mutex> g(mu);
@@ -591,6 +659,7 @@ int FlatIndex::remove(size_t label) {
                                hipMemcpyDeviceToDevice, wstream_));
       HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
       if (s8g_enabled()) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
+      hn_built_ = std::min(hn_built_, r);                        // ... and their half norms recomputed
       if (shadow_ && shadow_ != 3)
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,
                                  hipMemcpyDeviceToDevice, wstream_));
@@ -607,6 +676,10 @@ int FlatIndex::remove(size_t label) {
     }
     row_label_.pop_back();
     n_rows_--;
+    // (the row that is appended next takes slot n_rows_: nothing derived from the old occupant may count as built)
+    s8g_built_ = std::min(s8g_built_, n_rows_);
+    s8g_seen_ = std::min(s8g_seen_, n_rows_);
+    hn_built_ = std::min(hn_built_, n_rows_);
   }
   HIP_CHECK(hipStreamSynchronize(wstream_));
   if (multi) multi_map_.erase(label);

@@ -284,6 +284,19 @@ class FlatIndex {
   float s8g_scale_ = 0.0f;           // the scale the built rows were quantised with (0: nothing built)
   uint32_t s8g_built_ = 0, s8g_seen_ = 0;  // rows [0, built) are quantised; rows [0, seen) went into max |x_i|
   bool ensure_shadow8g();            // true: d_shadow_ covers every row and bounds them
+  // L2 indexes of FLOAT16 / BFLOAT16 rows: |x|^2 / 2 per row (fp32) for the batched matrix-core pass (batch_query.cpp,
+  // gemm_qs_kernels.hip "L2").  Built lazily and incrementally by the first batched query that finds rows it does not
+  // cover; a delete below the built prefix recomputes from there.  4 bytes per row.
+  float *d_hnorm_ = nullptr;
+  size_t hnorm_cap_rows_ = 0;
+  uint32_t hn_built_ = 0;
+  uint32_t *d_hn_bad_ = nullptr;  // set by the kernel if a row's norm is not finite
+  bool hn_bad_ = false;
+  // relative error band of the pass against the exact scan, per unit of |x|^2/2 + |q|^2/2 (DESIGN.md section 3 "L2 on the
+  // matrix cores"): the stored norms are shrunk by (1 - rel/2)
+  float hn_rel() const { return (float)dim * 9.5367431640625e-07f + 1.9073486328125e-06f; }  // dim 2^-20 + 2^-19
+  bool ensure_half_norms();                          // true: d_hnorm_ covers every row, all finite
+  float half_sq_norm_host(const void *blob) const;   // |q|^2 / 2 of a query blob of the index's type (fp32)
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
   // the single-query path; the caller holds the shared lock and has flushed
   VecSimQueryReply *topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order);

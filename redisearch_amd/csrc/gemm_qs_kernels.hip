@@ -24,6 +24,14 @@
 // LDS layout of a tile: row-major, the 16-byte chunk index XOR-ed with (row & 15) so that the fragment
 // read (32 rows, same chunk) is bank-conflict free (SQ_LDS_BANK_CONFLICT = 0); the same XOR picks the
 // SOURCE chunk of each DMA lane (the DMA destination is lane-linear).
+// L2 indexes (template L2, round 3): |x - q|^2 = 2 (|q|^2/2 + |x|^2/2 - x.q).  The rows' half norms hn[row] (fp32, an
+// array next to the corpus) ride along with the tiles: wave 0 issues one more DMA piece per tile -- 64 floats, the first 32
+// are the tile's -- into a side ring behind the corpus ring; after the MFMA stream a lane reads the norms of its 16 rows with
+// four ds_read_b128 (issued right behind the last MFMA: their latency overlaps the matrix pipe's drain),
+// subtracts them from its accumulators and runs the same max3 filter against hq[q] - tau[q]/2.  Emitted: 2 (hq - (s - hn)).
+// The host hands in norms and hq SHRUNK by half the relative error band, which makes the emitted value a lower bound of the
+// exact distance and the test a test of that lower bound; compact_cand_kernel turns it into the upper bound the thresholds
+// are selected from (a per-row band: one huge row does not widen anybody else's), survivors are re-scored exactly.
 // Measured on 10M x 768 fp16, batch 256 (profiles/r01_batch_qs.txt): 4.0 ms per pass vs 6.9 ms for the tiled
 // kernel; the matrix pipe is busy 62 % of the cycles but the chip clocks down to ~1.4 GHz under the combined
 // MFMA + LDS + 3.6 TB/s HBM load (power), which is what now bounds it.
@@ -86,6 +94,8 @@ struct QsArgs {
   uint2 *sub_cand;      // [gridDim.x][256][2][sub_cap] (row, distance bits): one list per (workgroup, query, lane half)
   uint32_t sub_cap;
   const float *qscale;  // KT_I8: [256] distance = 1 - qscale[q] * (integer dot); row scale x query scale
+  const float *hnorm;   // L2: |x|^2 / 2 per corpus row (readable up to row_end + 95), else unused
+  const float *hq;      // L2: [256] |q|^2 / 2
 };
 
 // same for a wave-uniform value: pinned to an SGPR (otherwise kernel arguments and gridDim are re-loaded with
@@ -146,21 +156,27 @@ __device__ __forceinline__ void wait_lgkm(int n) {
     case 4: asm volatile("s_waitcnt lgkmcnt(4)"); break;
     case 5: asm volatile("s_waitcnt lgkmcnt(5)"); break;
     case 6: asm volatile("s_waitcnt lgkmcnt(6)"); break;
-    default: asm volatile("s_waitcnt lgkmcnt(7)"); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)"); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)"); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(11)"); break;
   }
 }
 
 // QB = 32-query blocks per wave: 2 -> 4 waves (one per SIMD, 512 registers), 1 -> 8 waves (two per SIMD, 256
 // registers each: while one wave pays the ~100-200 cycles an LDS-DMA piece costs at issue, or runs its filter
 // epilogue, its partner keeps the SIMD's matrix pipe busy -- MI355X_MICROARCH.md "Two waves per SIMD")
-template <int DT, int KS, int NS, int QB>
+template <int DT, int KS, int NS, int QB, bool L2>
 __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
+  static_assert(!L2 || DT != KT_I8, "the int8 pass has no L2 epilogue");
   constexpr int NW = 8 / QB;        // waves per workgroup
   constexpr int ROWC = 2 * KS;     // 16-byte chunks per row
   constexpr int TILE = 32 * ROWC;  // chunks per tile of 32 corpus rows
   constexpr int PPW = KS / NW;     // 1 KiB DMA pieces per wave per tile (a tile is KS pieces)
   constexpr int NA = QB == 2 ? 64 : 32;      // query fragments pinned to the accumulation registers (half the register file)
-  __shared__ u4 smem[NS * TILE];   // the ring, nothing else: one object (see gemm_kernels.hip)
+  constexpr int NORMC = L2 ? 16 : 0;  // L2: 64 half norms (16 chunks) per ring slot behind the corpus ring
+  __shared__ u4 smem[NS * TILE + NS * NORMC];  // the ring(s), nothing else: one object (see gemm_kernels.hip)
   const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const uint32_t r = lane & 31, h = lane >> 5;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
@@ -189,9 +205,15 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
   for (int nb = 0; nb < QB; nb++) {
     cur[nb] = 0;
     tau[nb] = g.tau[32 * QB * w + 32 * nb + r];
-    const float u = 1.0f - tau[nb];
-    thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : u - (fabsf(tau[nb]) + fabsf(u)) * 2.4e-7f;
-    qsc[nb] = 1.0f;
+    float u = 1.0f - tau[nb];
+    float mag = fabsf(tau[nb]) + fabsf(u);
+    if constexpr (L2) {  // 2 (hq - v) <= tau  <=>  v >= hq - tau / 2, v = s - hn
+      qsc[nb] = g.hq[32 * QB * w + 32 * nb + r];
+      u = qsc[nb] - 0.5f * tau[nb];
+      mag = fabsf(qsc[nb]) + fabsf(0.5f * tau[nb]) + fabsf(u);
+    }
+    thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : (tau[nb] == __builtin_inff() ? -__builtin_inff() : u - mag * 2.4e-7f);
+    if constexpr (!L2) qsc[nb] = 1.0f;
     ithr[nb] = 0x7fffffff;
     if constexpr (DT == KT_I8) {
       qsc[nb] = g.qscale[32 * QB * w + 32 * nb + r];
@@ -232,7 +254,19 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tile + opaque(poff[p])), lp, 16, 0,
                                      2);  // nt: corpus lines are used once
   };
+  // L2: the tile's half norms, one 256-byte piece (64 floats from the tile's first row on; the tile owns the first 32)
+  // into the side ring.  Wave 0 only: its vmcnt ladder below counts PPW + 1 loads per tile.
+  auto issue_norms = [&](uint32_t i, uint32_t stage) {
+    if constexpr (L2) {
+      if (wu == 0) {
+        const uint32_t row0 = row_first + i * row_step;
+        __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)(smem + NS * TILE + stage * NORMC);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g.hnorm + row0 + opaque(lane)), lp, 4, 0, 0);
+      }
+    }
+  };
   auto issue = [&](uint32_t i, uint32_t stage) {
+    issue_norms(i, stage);
 #pragma unroll
     for (int p = 0; p < PPW; p++) issue_piece(i, stage, p);
   };
@@ -249,14 +283,26 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     // tile i has landed once only this wave's DMAs of the younger tiles are outstanding (loads return
     // in order; candidate stores in the queue can only make the wait conservative) ...
     const uint32_t younger = mine - 1 - i < (uint32_t)(NS - 2) ? mine - 1 - i : (uint32_t)(NS - 2);
-    switch (younger) {
-      case 0: wait_vm<0>(); break;
-      case 1: wait_vm<PPW>(); break;
-      case 2: wait_vm<2 * PPW>(); break;
-      case 3: wait_vm<3 * PPW>(); break;
-      case 4: wait_vm<4 * PPW>(); break;
-      case 5: wait_vm<5 * PPW>(); break;
-      default: wait_vm<6 * PPW>(); break;
+    if (L2 && wu == 0) {  // (wave 0 of an L2 pass also has the tiles' norm pieces in its queue)
+      switch (younger) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<PPW + 1>(); break;
+        case 2: wait_vm<2 * (PPW + 1)>(); break;
+        case 3: wait_vm<3 * (PPW + 1)>(); break;
+        case 4: wait_vm<4 * (PPW + 1)>(); break;
+        case 5: wait_vm<5 * (PPW + 1)>(); break;
+        default: wait_vm<6 * (PPW + 1)>(); break;
+      }
+    } else {
+      switch (younger) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<PPW>(); break;
+        case 2: wait_vm<2 * PPW>(); break;
+        case 3: wait_vm<3 * PPW>(); break;
+        case 4: wait_vm<4 * PPW>(); break;
+        case 5: wait_vm<5 * PPW>(); break;
+        default: wait_vm<6 * PPW>(); break;
+      }
     }
     // ... for every wave; the barrier also says tile i-1 has been consumed by all, freeing its slot
     __builtin_amdgcn_s_barrier();
@@ -268,6 +314,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     // eight lane addresses (ks & 7) plus an immediate 256-byte step per eight k-steps cover the whole row
     const uint32_t lr = opaque(lane);
     const uint32_t tbase = lds_base + 16u * (stage * TILE + (lr & 31u) * ROWC);
+    const uint32_t nstage = opaque_s(stage);
     stage = stage + 1 == NS ? 0 : stage + 1;
     // chunk (2ks+h)^x = 16(ks>>3) + (2(ks&7) ^ (h^x)): one v_xad_u32 per read, nothing held in registers
     const uint32_t t16 = 16u * ((lr >> 5) ^ (lr & 15u));
@@ -284,18 +331,39 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     u4 xb[PF];
 #pragma unroll
     for (int ks = 0; ks < PF; ks++) xb[ks] = lds_read16(frag_addr(ks), ks >> 3);
+    u4 hnv[L2 ? 4 : 1];  // L2: half norms of the lane's 16 rows
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      wait_lgkm(KS - 1 - ks < PF - 1 ? KS - 1 - ks : PF - 1);  // fragment ks has arrived
+      // fragment ks has arrived
+      wait_lgkm(KS - 1 - ks < PF - 1 ? KS - 1 - ks : PF - 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<DT>(xb[ks % PF], Q[nb][ks], acc[nb]);
       __builtin_amdgcn_sched_barrier(0);
       if (ks + PF < KS) xb[ks % PF] = lds_read16(frag_addr(ks + PF), (ks + PF) >> 3);
-      if (ks % (KS / PPW) == 1 && refill) issue_piece(i + NS - 1, fill, ks / (KS / PPW));
+      if constexpr (L2) {  // behind the last MFMA: the fragment registers are free, the reads overlap the pipe's drain
+        if (ks == KS - 1) {
+          // the norms of this lane's rows 8 eg + 4 h .. + 3 are chunk 2 eg + h of the slot's norm piece
+          const uint32_t nbase = lds_base + 16u * (NS * TILE + nstage * NORMC + (opaque(lane) >> 5));
+#pragma unroll
+          for (int eg = 0; eg < 4; eg++) hnv[eg] = lds_read16(nbase + 32u * eg, 0);
+        }
+      }
+      if (ks % (KS / PPW) == 1 && refill) {
+        if (ks / (KS / PPW) == 0) issue_norms(i + NS - 1, fill);
+        issue_piece(i + NS - 1, fill, ks / (KS / PPW));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (refill) fill = fill + 1 == NS ? 0 : fill + 1;
+    if constexpr (L2) {  // v = s - hn: the filter below then runs on v against hq - tau / 2
+      wait_lgkm(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[nb][e] -= __uint_as_float(hnv[e >> 2][e & 3]);
+    }
     // C row = corpus row (e&3)+8*(e>>2)+4h of the tile, C col = query r of the nb block
     const uint32_t xr0 = row_first + i * row_step + 4 * (lr >> 5);
 #pragma unroll
@@ -336,9 +404,11 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
             if (gm >= thr[nb]) {
 #pragma unroll
               for (int el = 0; el < 4; el++) {
-                const float d = 1.0f - acc[nb][4 * eg + el];
+                const float d = L2 ? 2.0f * (qsc[nb] - acc[nb][4 * eg + el]) : 1.0f - acc[nb][4 * eg + el];
                 const uint32_t xr = xr0 + 8 * eg + el;
-                if (d <= tau[nb] && xr < row_end) {
+                // (L2: the test on v IS the filter -- a superset of d <= tau by the margin in thr, which is all a filter
+                // pass owes; tau itself is not kept in a register)
+                if ((L2 ? acc[nb][4 * eg + el] >= thr[nb] : d <= tau[nb]) && xr < row_end) {
                   if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
                   cur[nb]++;
                 }
@@ -360,7 +430,8 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
 __global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__restrict__ sub_count,
                                                            const uint2 *__restrict__ sub_cand, uint32_t sub_cap,
                                                            uint32_t n_wg, uint32_t *__restrict__ cand_count,
-                                                           uint2 *__restrict__ cand, uint32_t cand_cap, int append) {
+                                                           uint2 *__restrict__ cand, uint32_t cand_cap, int append,
+                                                           RowBand band) {
   __shared__ uint32_t offs[513];
   __shared__ uint32_t over;
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
@@ -392,7 +463,9 @@ __global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__re
     const uint2 *src = sub_cand + (((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap;
     for (uint32_t i = lane; i < cnt; i += 64) {
       const uint2 e = src[i];
-      cand[(size_t)q * cand_cap + base + beg + i] = make_uint2(e.x, f2key(__uint_as_float(e.y)));
+      float d = __uint_as_float(e.y);
+      if (band.hnorm) d += band.c1 * band.hnorm[e.x] + band.hq2[q];  // lower bound -> upper bound (L2 passes)
+      cand[(size_t)q * cand_cap + base + beg + i] = make_uint2(e.x, f2key(d));
     }
   }
   if (tid == 0) cand_count[q] = over ? cand_cap + 1 : base + total;
@@ -400,10 +473,16 @@ __global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__re
 
 template <int DT, int KS, int NS>
 void launch_qs_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
+  if constexpr (DT != KT_I8) {
+    if (g.hnorm) {  // L2 (eight waves x 32 queries only)
+      hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 1, true>), dim3(grid), dim3(512), 0, s, g);
+      return;
+    }
+  }
   switch (scan_tuning().gemm_qs) {  // 1: eight waves x 32 queries (default); 2: four waves x 64 queries
-    case 2: hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 2>), dim3(grid), dim3(256), 0, s, g); break;
+    case 2: hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 2, false>), dim3(grid), dim3(256), 0, s, g); break;
     default:
-      hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 1>), dim3(grid), dim3(512), 0, s, g);
+      hipLaunchKernelGGL((gemm_qs_kernel<DT, KS, NS, 1, false>), dim3(grid), dim3(512), 0, s, g);
       break;
   }
 }
@@ -440,11 +519,12 @@ uint32_t gemm_qs_grid(uint32_t n_rows) {
 
 bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                     uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
-                    hipStream_t s, const float *qscale) {
+                    hipStream_t s, const float *qscale, const float *hnorm, const float *hq) {
   if (row_end <= row_begin || !gemm_qs_supported(stride16)) return false;
-  QsArgs g{(const u4 *)rows, (const u4 *)queries, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, qscale};
+  if ((hnorm != nullptr) != (hq != nullptr) || (hnorm && dtype == KT_I8)) return false;
+  QsArgs g{(const u4 *)rows, (const u4 *)queries, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, qscale, hnorm, hq};
   const uint32_t grid = gemm_qs_grid(row_end - row_begin);
-  if (dtype == KT_I8 || scan_tuning().qs_force_i8) {  // (qs_force_i8: timing experiment over bytes that are not int8 data)
+  if (dtype == KT_I8 || (scan_tuning().qs_force_i8 && !hnorm)) {  // (qs_force_i8: timing experiment over bytes that are not int8 data)
     if (!g.qscale) g.qscale = tau;
     return launch_qs_dt<KT_I8>(g, stride16, grid, s);
   }
@@ -452,9 +532,9 @@ bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t s
 }
 
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
-                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s) {
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s, const RowBand *band) {
   hipLaunchKernelGGL(compact_cand_kernel, dim3(256), dim3(1024), 0, s, sub_count, (const uint2 *)sub_cand, sub_cap, n_wg,
-                     cand_count, (uint2 *)cand, cand_cap, append);
+                     cand_count, (uint2 *)cand, cand_cap, append, band ? *band : RowBand{});
 }
 
 }  // namespace rsgpu

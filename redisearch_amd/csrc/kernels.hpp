@@ -18,6 +18,7 @@ enum : int { KT_F32 = 0, KT_F64 = 1, KT_BF16 = 2, KT_F16 = 3, KT_I8 = 4, KT_U8 =
 // KM_L2S (KT_I8 scan only): |q|^2 + |x|^2[row] - 2 * dot * row_scale[row] * query_scale, the same for L2 indexes
 enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2, KM_IPS = 3, KM_L2S = 4 };
 // distances (and keys) of FLOAT64 indexes are 8 bytes wide, everything else computes fp32 distances
+struct RowBand;
 inline int key_bytes_of(int type) { return type == KT_F64 ? 8 : 4; }
 
 // Orderable key of an fp32 distance: ascending key <=> ascending distance, NaN last.
@@ -60,6 +61,7 @@ struct ScanTuning {
   int shadow8 = 0;         // same with an int8 shadow (+ per-row scale): a quarter of the bytes, wider error band
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
+  int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
@@ -130,7 +132,21 @@ void launch_shadow8_rows(const void *rows, size_t stride, uint32_t dim, uint32_t
 bool batch_rescore_supported(uint32_t stride16);
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
-                          int type = KT_F32);  // KT_F16: fp16 rows / queries, the fp16 scan's arithmetic
+                          int type = KT_F32, int metric = KM_IP,   // KT_F16: fp16 rows / queries, the fp16 scan's arithmetic;
+                          const struct RowBand *band = nullptr);   // KM_L2: the L2 scan's; band: the keys are upper bounds
+// hn[row] = shrink * |x|^2 / 2 (fp32) of rows [row_begin, row_end) of KT_F16 / KT_BF16 / KT_F32 rows; *bad is set if one is
+// not finite
+void launch_half_norm_rows(int type, const void *rows, size_t stride, uint32_t row_begin, uint32_t row_end, float shrink,
+                           float *hn, uint32_t *bad, hipStream_t s);
+// The L2 form of the batched matrix-core pass carries a PER-ROW error band (DESIGN.md section 3 "L2 on the matrix cores"):
+// the pass emits lower bounds lb of the distances, the candidate lists hold upper bounds ub = lb + band(row, q), the
+// re-scoring kernel derives lb back.  band(row, q) = c1 * hnorm[row] + hq2[q]; hnorm == nullptr: no band (IP passes).
+struct RowBand {
+  const float *hnorm = nullptr;  // the array the pass subtracts (shrunk half norms)
+  const float *hq2 = nullptr;    // [256]
+  float c1 = 0.0f;
+  float inv2rel = 0.0f;          // hq2[q] * inv2rel = |q|^2 / 2 (the re-scoring kernel's read-free pre-test)
+};
 // int8 shadow of FLOAT16 / FLOAT32 rows with ONE index-wide scale (the batched int8 MFMA pass, scan_kernels.hip "int8 shadow with
 // ONE index-wide scale"): stats = {max |x_i| (f32 bits), max |x8|^2 (u32), max |ex|^2 (f32 bits), non-finite flag}
 void launch_absmax_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,
@@ -181,10 +197,13 @@ bool gemm_qs_supported(uint32_t stride16);
 uint32_t gemm_qs_grid(uint32_t n_rows);
 bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t stride16, uint32_t row_begin,
                     uint32_t row_end, const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap,
-                    hipStream_t s, const float *qscale = nullptr);
+                    hipStream_t s, const float *qscale = nullptr, const float *hnorm = nullptr, const float *hq = nullptr);
+// (hnorm + hq: an L2 pass over KT_F16 / KT_BF16 rows -- hnorm[row] = |x|^2 / 2 (fp32, readable up to row_end + 95), hq[q] =
+// |q|^2 / 2; the candidates carry 2 (hq + hnorm - x.q) and tau bounds that)
 // append != 0: the sub-lists are appended behind the cand_count[q] candidates already there
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
-                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s);
+                         uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s,
+                         const struct RowBand *band = nullptr);  // band: key = sub-list distance + band(row, q)
 // per query (one workgroup each): tau_out[q] = k-th smallest distance among keys[q*ld .. +n)
 // (stride > 1: element i is keys[q*ld + i*stride], a strided sample of a longer key array)
 // (slack is added to every finite bound written: the two-stage scan's error band)

@@ -17,6 +17,7 @@
 // file is compiled with -ffp-contract=off so that no multiply-add is fused behind the C source's back.
 #include <hip/hip_runtime.h>
 
+#include "kernels.hpp"
 #include "search_kernels.hpp"
 
 namespace rsgpu {
@@ -44,6 +45,7 @@ namespace {
 // One kernel per record kind (0 qint, 1 varint delta, 2 raw u32 delta): keeping the three decoders in
 // one body made hipcc (ROCm 7.2) drop the cursor advance of the raw path.
 constexpr uint32_t kDecodeLds = 30 * 1024;  // bytes of encoded input staged per wavefront (5 wavefronts per CU)
+constexpr uint32_t kSyncSeg = 16, kSyncPts = 7;  // sync points: before records 16, 32, .. 112 of a block (kSyncPts + 1 = 8 lanes)
 
 // 7-bit groups, most significant first, +1 per continuation (reference varint/src/lib.rs); 128-bit accumulator
 template <typename Bytes>
@@ -179,6 +181,118 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
   }
 }
 
+// The qint codecs without a wide mask, parsed out of LDS with the record layout a compile-time constant (NF fields; FR / MK /
+// OS = which of fields 1..3 is the frequency / field mask / offsets length, -1 none): ONE LDS round trip per record -- the
+// NF + 2 aligned words that hold it whatever its length -- and straight-line field extraction.  The generic loop above
+// branches on the codec description per field and waits for up to three dependent LDS reads per record; a lane's 100
+// records are a serial chain, the lists of a query leave most SIMDs with a single wavefront, so the kernel's time IS that
+// chain: 52-83 us for a 2.5 M / 5 M-entry list with the generic loop, 20-26 us with this one (profiles/r03_decode.txt; a
+// register-FIFO variant that keeps the LDS reads out of the chain altogether was tried and was slower: 64-bit funnel
+// shifts cost more issue slots than the round trips they save).  Same bytes in, same arrays out
+// (reference qint/src/lib.rs:139-214; inverted_index/src/codec/{freqs_only,freqs_fields,full,...}.rs).
+template <int NF, int FR, int MK, int OS>
+__device__ __forceinline__ void decode_qint_block_lds(const uint8_t *stage, uint32_t pos, uint32_t fin, uint32_t n,
+                                                      uint32_t f0, uint32_t out, uint32_t *__restrict__ ids,
+                                                      uint32_t *__restrict__ freqs, uint32_t *__restrict__ masks,
+                                                      uint32_t *__restrict__ off_pos, uint32_t *__restrict__ off_len,
+                                                      uint32_t abs_base, uint32_t *__restrict__ sync_w, uint32_t pos0) {
+  typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+  uint32_t base = f0, e = 0;
+  while (e < n && pos < fin) {
+    if (sync_w && e && (e & (kSyncSeg - 1)) == 0 && e / kSyncSeg <= kSyncPts) {  // record e starts here, after doc id `base`
+      sync_w[2 * (e / kSyncSeg - 1)] = pos - pos0;
+      sync_w[2 * (e / kSyncSeg - 1) + 1] = base;
+    }
+    uint32_t b_id[4], b_fr[4], b_mk[4], b_op[4], b_ol[4];
+    uint32_t got = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (e < n && pos < fin) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (pos >> 2);
+        uint32_t r[NF + 2];
+#pragma unroll
+        for (int i = 0; i < NF + 2; i++) r[i] = w[i];
+        const uint32_t sh = pos & 3u;
+        uint32_t a[NF + 1];  // the record from its control byte on
+#pragma unroll
+        for (int i = 0; i < NF + 1; i++) a[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sh);
+        const uint32_t hdr = a[0];
+        uint32_t v[NF], o = 1;
+#pragma unroll
+        for (int i = 0; i < NF; i++) {
+          const uint32_t len = ((hdr >> (2 * i)) & 3u) + 1u;
+          // four bytes from byte o of the record: o <= 1 + 4 i, so they start in word 0 .. i
+          uint32_t raw = __builtin_amdgcn_alignbyte(a[1], a[0], o);
+#pragma unroll
+          for (int d = 1; d <= i; d++) raw = (o >> 2) == (uint32_t)d ? __builtin_amdgcn_alignbyte(a[d + 1], a[d], o) : raw;
+          const uint32_t drop = 32u - 8u * len;  // keep the low `len` bytes (a shift by 0 when len == 4)
+          v[i] = (raw << drop) >> drop;
+          o += len;
+        }
+        pos += o;
+        base += v[0];
+        b_id[j] = base;
+        b_fr[j] = FR >= 0 ? v[FR >= 0 ? FR : 0] : 0u;
+        b_mk[j] = MK >= 0 ? v[MK >= 0 ? MK : 0] : 0u;
+        b_op[j] = abs_base + pos;
+        b_ol[j] = OS >= 0 ? v[OS >= 0 ? OS : 0] : 0u;
+        if (OS >= 0) pos += b_ol[j];  // offsets bytes are not parsed here: the proximity kernels read them in place
+        e++;
+        got = j + 1;
+      }
+    }
+    if (got == 4) {
+      *reinterpret_cast<u4u *>(ids + out) = (u4u){b_id[0], b_id[1], b_id[2], b_id[3]};
+      if (freqs) *reinterpret_cast<u4u *>(freqs + out) = (u4u){b_fr[0], b_fr[1], b_fr[2], b_fr[3]};
+      if (masks) *reinterpret_cast<u4u *>(masks + out) = (u4u){b_mk[0], b_mk[1], b_mk[2], b_mk[3]};
+      if (off_pos) {
+        *reinterpret_cast<u4u *>(off_pos + out) = (u4u){b_op[0], b_op[1], b_op[2], b_op[3]};
+        *reinterpret_cast<u4u *>(off_len + out) = (u4u){b_ol[0], b_ol[1], b_ol[2], b_ol[3]};
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < 3; j++)
+        if (j < got) {
+          ids[out + j] = b_id[j];
+          if (freqs) freqs[out + j] = b_fr[j];
+          if (masks) masks[out + j] = b_mk[j];
+          if (off_pos) {
+            off_pos[out + j] = b_op[j];
+            off_len[out + j] = b_ol[j];
+          }
+        }
+    }
+    out += got;
+  }
+}
+
+// cd -> the instantiation above (false: not one of the reference's qint layouts, the generic loop takes it)
+__device__ __forceinline__ bool decode_qint_fast(const CodecDesc &cd, const uint8_t *stage, uint32_t pos, uint32_t fin, uint32_t n,
+                                                 uint32_t f0, uint32_t out, uint32_t *ids, uint32_t *freqs, uint32_t *masks,
+                                                 uint32_t *off_pos, uint32_t *off_len, uint32_t abs_base, uint32_t *sync_w,
+                                                 uint32_t pos0) {
+#define RSGPU_QINT(NF, FR, MK, OS)                                                                                         \
+  if (cd.n == NF && cd.freq == FR && cd.mask == MK && cd.osz == OS) {                                                      \
+    decode_qint_block_lds<NF, FR, MK, OS>(stage, pos, fin, n, f0, out, ids, freqs, masks, off_pos, off_len, abs_base,      \
+                                          sync_w, pos0);                                                                   \
+    return true;                                                                                                           \
+  }
+  RSGPU_QINT(2, 1, -1, -1)  // FreqsOnly
+  RSGPU_QINT(2, -1, 1, -1)  // FieldsOnly
+  RSGPU_QINT(2, -1, -1, 1)  // OffsetsOnly
+  RSGPU_QINT(3, 1, 2, -1)   // FreqsFields
+  RSGPU_QINT(3, 1, -1, 2)   // FreqsOffsets
+  RSGPU_QINT(3, -1, 1, 2)   // FieldsOffsets
+  RSGPU_QINT(4, 1, 2, 3)    // Full
+#undef RSGPU_QINT
+  return false;
+}
+
+// sync (qint layouts without a wide mask): [n_blocks][kSyncPts][2] = {byte offset from the block's first byte, doc id before
+// it} of records 16, 32, ... of every block.  sync_mode 1: the lane that parses a block writes them as it passes; sync_mode
+// 2: they are there, and a block is parsed by EIGHT lanes, 16 records each -- a lane's 100 records were the one serial chain
+// this kernel's time consists of (parse ~18 us of 25, whatever the list length: profiles/r03_decode.txt), a list is immutable
+// after upload, so the first decode of a list leaves the sync points behind for all later ones (8 bytes per 16 postings).
 template <int KIND>
 __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const uint8_t *__restrict__ bytes,
                                                            const uint64_t *__restrict__ byte_off,
@@ -188,28 +302,64 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
                                                            uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
                                                            uint32_t *__restrict__ masks, uint32_t *__restrict__ wmasks,
                                                            uint32_t *__restrict__ off_pos,
-                                                           uint32_t *__restrict__ off_len) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[kDecodeLds + 16];  // (+ slack: peek32 reads up to 8 bytes ahead)
-  const uint32_t b0 = blockIdx.x * 64, lane = threadIdx.x;
-  const uint32_t nb = n_blocks - b0 < 64 ? n_blocks - b0 : 64;
-  const uint64_t w_beg = byte_off[b0] & ~15ull, w_end = byte_off[b0 + nb];  // 16-byte aligned start
-  const bool staged = w_end - w_beg <= kDecodeLds;                           // wave-uniform
+                                                           uint32_t *__restrict__ off_len,
+                                                           uint32_t *__restrict__ sync, int sync_mode, uint32_t lds_cap) {
+  // lds_cap bytes of staging + 64 of slack (the parsers fetch whole words ahead); dynamic: with eight lanes per block a
+  // wavefront stages a few KiB, and 30 KiB each would leave five wavefronts per CU
+  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t lpb = sync_mode == 2 ? kSyncPts + 1 : 1, bpw = 64 / lpb;  // lanes per block, blocks per wavefront
+  const uint32_t b0 = blockIdx.x * bpw;
+  const uint32_t nb = n_blocks - b0 < bpw ? n_blocks - b0 : bpw;
+  // every lane's block description in ONE memory round trip, before anything depends on it (the wavefront's byte range
+  // is the first lane's start .. the last lane's end: no separate loads for it)
+  const uint32_t part = sync_mode == 2 ? lane & kSyncPts : 0, lb = sync_mode == 2 ? lane / (kSyncPts + 1) : lane;
+  const uint32_t b = b0 + (lb < nb ? lb : nb - 1);
+  const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
+  uint32_t my_n = nent[b], my_first = first[b], my_out = entry_off[b], my_skip = 0;
+  if (part) {
+    my_skip = sync[((size_t)b * kSyncPts + part - 1) * 2];
+    my_first = sync[((size_t)b * kSyncPts + part - 1) * 2 + 1];
+  }
+  if (sync_mode == 2) {  // records [16 part, 16 part + 16) of the block; the last lane takes whatever is left
+    const uint32_t done = part * kSyncSeg;
+    my_out += done;
+    my_n = my_n > done ? (my_n - done < kSyncSeg || part == kSyncPts ? my_n - done : kSyncSeg) : 0;
+  }
+  const uint64_t w_beg = __shfl(beg, 0) & ~15ull, w_end = __shfl(fin, (int)(nb * lpb) - 1);  // 16-byte aligned start
+  const bool staged = w_end - w_beg <= lds_cap;                                               // wave-uniform
   if (staged) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    // global -> LDS by DMA, 1 KiB per instruction, every piece in flight before the one wait: a load / ds_write loop is
+    // serialised by hipcc (each store waits for its load), which made ~20 dependent HBM round trips the longest thing
+    // this kernel did.  (The byte buffer carries 16 bytes of slack; lanes past the span stay off.)
     const uint32_t span = (uint32_t)(w_end - w_beg);
-    for (uint32_t o = lane * 16; o < span; o += 64 * 16)  // (the byte buffer carries 16 bytes of slack)
-      *reinterpret_cast<u4 *>(stage + o) = *reinterpret_cast<const u4 *>(bytes + w_beg + o);
+    const uint8_t *src = bytes + w_beg + lane * 16;
+    for (uint32_t o = 0; o < span; o += 64 * 16) {
+      if (o + lane * 16 < span)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                         (__attribute__((address_space(3))) void *)(stage + o), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const uint32_t b = b0 + lane;
-  if (lane >= nb) return;
-  const uint64_t beg = byte_off[b], fin = byte_off[b + 1];
-  if (staged)
-    decode_one_block<KIND>(cd, LdsBytes{stage}, (uint32_t)(beg - w_beg), (uint32_t)(fin - w_beg), nent[b],
-                           first[b], entry_off[b], ids, freqs, masks, wmasks, off_pos, off_len, (uint32_t)w_beg);
+  if (sync_mode == 2 && !staged) {  // (blocks too large to stage: whole blocks through the generic loop, one lane each)
+    if (part) return;
+    my_n = nent[b];
+  }
+  if (lb >= nb || !my_n) return;
+  uint32_t *sync_w = sync_mode == 1 ? sync + (size_t)b * kSyncPts * 2 : nullptr;
+  if (staged) {
+    const uint32_t pos0 = (uint32_t)(beg - w_beg);
+    if (KIND == 0 && !cd.wide && !wmasks &&
+        decode_qint_fast(cd, stage, pos0 + my_skip, (uint32_t)(fin - w_beg), my_n, my_first, my_out, ids, freqs, masks, off_pos,
+                         off_len, (uint32_t)w_beg, sync_w, pos0))
+      return;
+    decode_one_block<KIND>(cd, LdsBytes{stage}, pos0, (uint32_t)(fin - w_beg), my_n, my_first, my_out, ids, freqs, masks, wmasks,
+                           off_pos, off_len, (uint32_t)w_beg);
+  }
   else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
-    decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), nent[b], first[b], entry_off[b], ids, freqs,
-                           masks, wmasks, off_pos, off_len, (uint32_t)beg);
+    decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), my_n, my_first, my_out, ids, freqs, masks, wmasks, off_pos,
+                           off_len, (uint32_t)beg);
 }
 
 // One WAVEFRONT per block for the two record kinds whose boundaries need no parse from the block start: a varint delta
@@ -1222,14 +1372,27 @@ inline uint32_t blocks_for(uint32_t n) { return n ? (n + 255) / 256 : 1; }
 
 }  // namespace
 
+bool decode_sync_supported(const CodecDesc &cd) { return cd.kind == 0 && !cd.wide; }
+size_t decode_sync_words(uint32_t n_blocks) { return (size_t)n_blocks * kSyncPts * 2; }
+uint32_t decode_sync_blocks_per_wave() { return 64 / (kSyncPts + 1); }
+
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
-                          uint32_t *off_len) {
+                          uint32_t *off_len, uint32_t *sync, int sync_mode, uint32_t sync_span) {
   if (!n_blocks) return;
-#define RSGPU_DECODE(K)                                                                                         \
-  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + 63) / 64), dim3(64), 0, s, cd, bytes, byte_off, first, \
-                     nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len)
+  if (!sync || !decode_sync_supported(cd) || wmasks) sync_mode = 0;
+  // sync_mode 2: eight lanes per block.  Only layouts the staged fast parsers take may use it: a block whose wavefront
+  // does not fit the staging buffer falls to the generic loop, which parses whole blocks -- 8 blocks of <= 100 records
+  // of <= 17 bytes + offsets always fit unless the offsets are huge, and then every lane would redo the block: keep to
+  // one lane per block for lists with inline offsets.
+  if (sync_mode == 2 && cd.osz >= 0) sync_mode = 0;
+  const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : 64;
+  // staging bytes: everything a wavefront of sync_mode 2 can need (the caller knows the widest 8-block span), else 30 KiB
+  const uint32_t lds_cap = sync_mode == 2 && sync_span && sync_span < kDecodeLds ? ((sync_span + 255u) & ~255u) : kDecodeLds;
+#define RSGPU_DECODE(K)                                                                                            \
+  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + bpw - 1) / bpw), dim3(64), lds_cap + 64, s, cd, bytes, byte_off, \
+                     first, nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len, sync, sync_mode, lds_cap)
   // varint / raw deltas without a wide mask: one wavefront per block (decode_blocks_wave_kernel)
   const bool wave = (cd.kind == 1 || cd.kind == 2) && !cd.wide && !wmasks && !off_pos;
   if (wave && cd.kind == 1)

@@ -606,11 +606,11 @@ __global__ __launch_bounds__(64) void quantize_queries_kernel(const T *__restric
 // reduction), so the keys written here are bit-identical to the ones the single-query scan computes for these rows.
 // grid = (slices, queries); a group of G lanes per candidate.  Lists that overflowed (count > cap) are skipped: the
 // select flags them and the host redoes the query on the single-query path.
-template <int TYPE, int G, int ITERS>
+template <int TYPE, int METRIC, int G, int ITERS>
 __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t n_rows,
                                                             const u4 *__restrict__ queries, uint32_t qstride16,
                                                             uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
-                                                            uint32_t cand_cap, const float *__restrict__ tau) {
+                                                            uint32_t cand_cap, const float *__restrict__ tau, RowBand band) {
   constexpr int GPB = 256 / G;
   const uint32_t q = blockIdx.y, lane = threadIdx.x % G, grp = threadIdx.x / G;
   const uint32_t cnt = cand_count[q];
@@ -618,26 +618,79 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict
   // candidates collected under the looser bounds of the earlier passes: only those inside the FINAL band
   // (shadow distance <= tau[q]) can be in the answer; the others get the last key and are never re-read
   const uint32_t thr = tau ? f2key(tau[q]) : 0xFFFFFFFFu;
+  const float tauf = tau ? tau[q] : __builtin_inff();
+  const float hq2 = band.hnorm ? band.hq2[q] : 0.0f;
   u4 qv[ITERS];
 #pragma unroll
   for (int i = 0; i < ITERS; i++) qv[i] = queries[(size_t)q * qstride16 + lane + i * G];
   uint2 *list = cand + (size_t)q * cand_cap;
-  for (uint32_t j = blockIdx.x * GPB + grp; j < cnt; j += gridDim.x * GPB) {
-    const uint2 e = list[j];
-    const uint32_t row = e.x;
-    if (e.y > thr || row >= n_rows) {  // (row >= n_rows cannot happen; never read outside the corpus)
-      if (lane == 0) list[j].y = 0xFFFFFFFFu;
-      continue;
+  // A group looks at G candidates at a time, one per lane (a coalesced read); the few inside the band are then re-scored one
+  // after the other by the whole group.  (The lists are long and mostly outside: the int8 band leaves ~10 k collected
+  // candidates per query, the first phase of an L2 pass 16 k, of which a few hundred are inside the final band -- walking
+  // them one dependent load at a time cost 0.24 ms per batch.)
+  for (uint32_t j0 = (blockIdx.x * GPB + grp) * G; j0 < cnt; j0 += gridDim.x * GPB * G) {
+    const uint32_t j = j0 + lane;
+    uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    bool inside = false;
+    if (j < cnt) {
+      e = list[j];
+      if (e.x < n_rows) {  // (row >= n_rows cannot happen; never read outside the corpus)
+        if (band.hnorm) {  // the key is an upper bound: the test is on the lower bound it was made from
+          // First without the row's norm: |x| <= sqrt(d) + |q| bounds it from the key alone (d <= ub), and most of the
+          // list -- collected under the first phases' loose bounds -- is far enough outside to fail even so.
+          const float ub = key2f(e.y), hq = hq2 * band.inv2rel;
+          const float sx = sqrtf(fmaxf(ub, 0.0f)) + sqrtf(2.0f * hq);
+          const float worst = 1.0002f * (band.c1 * (0.5f * sx * sx) + hq2);
+          if (!(ub - worst > tauf)) {
+            const float lb = ub - 1.0001f * (band.c1 * band.hnorm[e.x] + hq2);
+            inside = lb <= tauf || !(lb == lb);
+          }
+        } else {
+          inside = e.y <= thr;
+        }
+      }
+      if (!inside) list[j].y = 0xFFFFFFFFu;
     }
+    uint64_t m = __ballot(inside);
+    if (G == 32) m = (m >> (32 * (grp & 1))) & 0xFFFFFFFFull;
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t row = __shfl(e.x, src, G);
+      const u4 *p = rows + (size_t)row * stride16;
+      u4 x[ITERS];
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[i] = load16<false>(p + lane + i * G);
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) acc = Op<TYPE, METRIC>::add(acc, x[i], qv[i]);
+      const float d = finish<TYPE, METRIC>(group_reduce<G>(acc), zero4());
+      if (lane == 0) list[j0 + src].y = to_key(d);
+    }
+  }
+}
+
+// hn[row] = shrink * |x|^2 / 2 of rows [row_begin, row_end) (fp32; the L2 form of the batched matrix-core pass,
+// gemm_qs_kernels.hip); *bad is set if a row's norm is not finite.  One wavefront per row.
+template <int TYPE>
+__global__ __launch_bounds__(256) void half_norm_rows_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t row_begin,
+                                                             uint32_t row_end, float shrink, float *__restrict__ hn,
+                                                             uint32_t *__restrict__ bad) {
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t row = row_begin + blockIdx.x * 4 + wv; row < row_end; row += gridDim.x * 4) {
     const u4 *p = rows + (size_t)row * stride16;
-    u4 x[ITERS];
-#pragma unroll
-    for (int i = 0; i < ITERS; i++) x[i] = load16<false>(p + lane + i * G);
     float acc = 0.0f;
+    for (uint32_t c = lane; c < stride16; c += 64) {
+      const u4 x = load16<true>(p + c);
+      acc = Op<TYPE, KM_IP>::add(acc, x, x);
+    }
 #pragma unroll
-    for (int i = 0; i < ITERS; i++) acc = Op<TYPE, KM_IP>::add(acc, x[i], qv[i]);
-    const float d = finish<TYPE, KM_IP>(group_reduce<G>(acc), zero4());
-    if (lane == 0) list[j].y = to_key(d);
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if (lane == 0) {
+      const float h = 0.5f * acc;
+      hn[row] = h * shrink;
+      if (!(h <= 3.0e38f)) *bad = 1;  // inf or NaN (plain store: same-address atomics would serialise the kernel)
+    }
   }
 }
 
@@ -671,25 +724,29 @@ bool batch_rescore_supported(uint32_t stride16) {
 
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
-                          int type) {
+                          int type, int metric, const RowBand *band) {
   const uint32_t s16 = (uint32_t)(stride / 16);
   if (!batch_rescore_supported(s16) || !n_queries || (type != KT_F32 && type != KT_F16 && type != KT_BF16)) return false;
+  if (metric != KM_IP && metric != KM_L2) return false;
+  const RowBand rb = band ? *band : RowBand{};
   const Shape sh = pick_shape(s16);
   if ((uint32_t)(sh.G * sh.ITERS) != s16) return false;  // exact shapes only (no chunk masking here)
   // (64 slices per query: a slice walks its share of the list with one dependent load per candidate, most of which it
   // skips -- the int8 band leaves ~10 k collected candidates per query of which a few hundred are inside the final band)
   const dim3 grid(64, n_queries), block(256);
+#define RSGPU_RESCORE_M(TT, MM, GG, II)                                                                                    \
+  hipLaunchKernelGGL((batch_rescore_kernel<TT, MM, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,             \
+                     (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau, rb)
+#define RSGPU_RESCORE_T(TT, GG, II)                                                                                        \
+  do {                                                                                                                     \
+    if (metric == KM_L2) RSGPU_RESCORE_M(TT, KM_L2, GG, II);                                                               \
+    else RSGPU_RESCORE_M(TT, KM_IP, GG, II);                                                                               \
+  } while (0)
 #define RSGPU_RESCORE(GG, II)                                                                                              \
   do {                                                                                                                     \
-    if (type == KT_F16)                                                                                                    \
-      hipLaunchKernelGGL((batch_rescore_kernel<KT_F16, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
-                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
-    else if (type == KT_BF16)                                                                                              \
-      hipLaunchKernelGGL((batch_rescore_kernel<KT_BF16, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,        \
-                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((batch_rescore_kernel<KT_F32, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,         \
-                         (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau);         \
+    if (type == KT_F16) RSGPU_RESCORE_T(KT_F16, GG, II);                                                                   \
+    else if (type == KT_BF16) RSGPU_RESCORE_T(KT_BF16, GG, II);                                                            \
+    else RSGPU_RESCORE_T(KT_F32, GG, II);                                                                                  \
   } while (0)
   if (sh.G == 32) {
     if (sh.ITERS == 1) RSGPU_RESCORE(32, 1);
@@ -703,7 +760,20 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
     }
   }
 #undef RSGPU_RESCORE
+#undef RSGPU_RESCORE_T
+#undef RSGPU_RESCORE_M
   return true;
+}
+
+void launch_half_norm_rows(int type, const void *rows, size_t stride, uint32_t row_begin, uint32_t row_end, float shrink,
+                           float *hn, uint32_t *bad, hipStream_t s) {
+  if (row_end <= row_begin) return;
+  const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 16);
+  const dim3 grid(need < cap ? need : cap), block(256);
+  const uint32_t s16 = (uint32_t)(stride / 16);
+  if (type == KT_F32) hipLaunchKernelGGL(half_norm_rows_kernel<KT_F32>, grid, block, 0, s, (const u4 *)rows, s16, row_begin, row_end, shrink, hn, bad);
+  else if (type == KT_BF16) hipLaunchKernelGGL(half_norm_rows_kernel<KT_BF16>, grid, block, 0, s, (const u4 *)rows, s16, row_begin, row_end, shrink, hn, bad);
+  else hipLaunchKernelGGL(half_norm_rows_kernel<KT_F16>, grid, block, 0, s, (const u4 *)rows, s16, row_begin, row_end, shrink, hn, bad);
 }
 
 void launch_absmax_rows(int type, const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end,

@@ -21,6 +21,9 @@ __device__ __forceinline__ uint32_t f2key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// ... and back (0xFFFFFFFF, the key of every NaN, comes back as a NaN)
+__device__ __forceinline__ float key2f(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
 template <bool NT>
 __device__ __forceinline__ u4 load16(const u4 *p) {
   if (NT) return __builtin_nontemporal_load(p);

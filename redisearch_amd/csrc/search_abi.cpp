@@ -192,6 +192,10 @@ struct RSGPU_Postings {
   // (8-12 B per posting decoded next to ~3 B encoded).
   std::mutex decode_mu;
   std::atomic<bool> decoded{false};
+  // qint layouts: sub-block sync points, left behind by the first decode for all later ones (search_kernels.hpp)
+  DevBuf<uint32_t> sync;
+  std::atomic<bool> sync_ready{false};
+  uint32_t sync_span = 0;  // widest byte range of decode_sync_blocks_per_wave() consecutive blocks
 };
 
 // one node of a hit list's result tree, post-order over its leaf columns (a term: op 0, `leaf`; an aggregate: op 1 union /
@@ -254,25 +258,33 @@ struct RSGPU_DocTable {
     return failval;                              \
   }
 
-static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
-  if (scan_tuning().cache_decoded && !force) {
-    if (p->decoded.load(std::memory_order_acquire)) return;
-    std::lock_guard<std::mutex> g(p->decode_mu);
-    if (p->decoded.load(std::memory_order_relaxed)) return;
-    launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
-                         p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
-                         c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
-                         p->has_offsets() ? p->off_len.p : nullptr);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(c->stream));  // other queries read the arrays from their own streams
-    p->decoded.store(true, std::memory_order_release);
-    return;
-  }
+static void launch_decode(RSGPU_Postings *p, QueryCtx *c, int sync_mode) {
   launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
                        p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
                        c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
-                       p->has_offsets() ? p->off_len.p : nullptr);
+                       p->has_offsets() ? p->off_len.p : nullptr, p->sync.p, sync_mode, p->sync_span);
   HIP_CHECK(hipGetLastError());
+}
+
+static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
+  const bool cached = scan_tuning().cache_decoded && !force;
+  if (cached && p->decoded.load(std::memory_order_acquire)) return;
+  const bool has_sync = p->sync.p != nullptr && scan_tuning().decode_sync;
+  if (has_sync && p->sync_ready.load(std::memory_order_acquire) && !cached) {  // eight lanes per block
+    launch_decode(p, c, 2);
+    return;
+  }
+  if (!cached && !has_sync) {  // nothing to publish: no wait
+    launch_decode(p, c, 0);
+    return;
+  }
+  // the decode that publishes something other streams will read -- the decoded arrays (cache) or the sync points
+  std::lock_guard<std::mutex> g(p->decode_mu);
+  if (cached && p->decoded.load(std::memory_order_relaxed)) return;
+  launch_decode(p, c, has_sync && !p->sync_ready.load(std::memory_order_relaxed) ? 1 : (has_sync ? 2 : 0));
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (has_sync) p->sync_ready.store(true, std::memory_order_release);
+  if (cached) p->decoded.store(true, std::memory_order_release);
 }
 
 namespace rsgpu {
@@ -645,6 +657,16 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
   p->freqs.alloc(p->n_entries);
   p->masks.alloc((cd.mask >= 0 || cd.wide) ? p->n_entries : 1);
   if (cd.wide) p->wmasks.alloc((size_t)p->n_entries * 4);
+  // sub-block sync points of the qint layouts without inline offsets (8 bytes per 16 postings; written by the first decode)
+  // -- for lists uploaded in decode-per-query mode: with the decoded arrays cached a list is decoded once
+  if (decode_sync_supported(cd) && cd.osz < 0 && n_blocks && !scan_tuning().cache_decoded && scan_tuning().decode_sync) {
+    p->sync.alloc(decode_sync_words((uint32_t)n_blocks));
+    const size_t bpw = decode_sync_blocks_per_wave();
+    uint64_t widest = 0;
+    for (size_t b = 0; b < n_blocks; b += bpw)
+      widest = std::max<uint64_t>(widest, byte_offset[std::min(b + bpw, n_blocks)] - (byte_offset[b] & ~15ull));
+    p->sync_span = (uint32_t)std::min<uint64_t>(widest, 0xFFFFFFFFull);
+  }
   if (cd.osz >= 0) {
     // the decoded offsets index addresses the byte buffer with 32 bits
     if (p->n_bytes >= 0xFFFFFFF0ull) throw std::runtime_error("posting lists with offsets are limited to 4 GiB of encoded bytes");
@@ -664,12 +686,10 @@ long RSGPU_Postings_Decode(RSGPU_Postings *p, uint64_t *doc_ids_out, uint32_t *f
   HIP_CHECK(hipSetDevice(p->device));
   CtxLease c(p->device);
   StageTimer t(c.c, 0);
-  {  // an explicit decode request always runs the kernel (it is how the decode stage is measured)
-    std::lock_guard<std::mutex> g(p->decode_mu);
-    decode_on(p, c.c, true);
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    p->decoded.store(true, std::memory_order_release);
-  }
+  // an explicit decode request always runs the kernel (it is how the decode stage is measured)
+  decode_on(p, c.c, true);
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  p->decoded.store(true, std::memory_order_release);
   t.stop();
   const uint32_t n = p->n_entries;
   if (doc_ids_out && n) {

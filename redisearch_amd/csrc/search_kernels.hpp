@@ -24,7 +24,14 @@ CodecDesc codec_desc(int codec);
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks = nullptr,
-                          uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr);
+                          uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr, uint32_t *sync = nullptr, int sync_mode = 0,
+                          uint32_t sync_span = 0);  // sync_span: the widest byte range (16-byte aligned start) of
+                                                    // decode_sync_blocks_per_wave() consecutive blocks, 0 = unknown
+// Sub-block sync points of the qint layouts (decode_sync_words(n_blocks) u32 per list): sync_mode 1 = this decode writes
+// them, 2 = they are valid and eight lanes share a block.  See postings_kernels.hip "sync".
+bool decode_sync_supported(const CodecDesc &cd);
+size_t decode_sync_words(uint32_t n_blocks);
+uint32_t decode_sync_blocks_per_wave();
 
 constexpr int kMaxLists = 32;  // children of one intersection / union (the reference's own tests go to 25)
 constexpr int kMaxNodes = 64;      // nodes of one query tree (terms + aggregates; <= kMaxLists terms)

@@ -11,20 +11,25 @@ from redisearch_amd import search as S  # noqa: E402
 from redisearch_amd import vecsim as V  # noqa: E402
 
 fl = np.load(sys.argv[1], allow_pickle=True)
+V.load().RSGPU_SetTuning(b"cache_decoded", int(os.environ.get("CACHE_DECODED", "0")))   # decode-per-query mode
+if os.environ.get("DECODE_SYNC"):
+    V.load().RSGPU_SetTuning(b"decode_sync", int(os.environ["DECODE_SYNC"]))
 out = []
 for key in fl.files:
     d = fl[key].item()
     p = S.Postings.from_flat(d)
     lib = S.load()
     best = None
+    first = None
     for _ in range(5):
         lib.RSGPU_SetProfiling(1)
         p.decode()
         prof = S.profile()
         lib.RSGPU_SetProfiling(0)
         ms = prof.get("decode_ms")
+        first = ms if first is None else first
         best = ms if best is None else min(best, ms)
-    r = {"list": key, "entries": int(p.num_entries), "bytes": int(p.num_bytes), "decode_ms": best,
+    r = {"list": key, "entries": int(p.num_entries), "bytes": int(p.num_bytes), "decode_ms": best, "first_decode_ms": first,
          "entries_per_s": p.num_entries / best * 1e3, "encoded_gbs": p.num_bytes / best / 1e6}
     out.append(r)
     print(json.dumps(r), flush=True)
