@@ -624,7 +624,7 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
                "wall_ms_p95": float(np.percentile(walls, 95)), "wall_ms_min": min(walls), "queries_timed": len(walls),
                "figure": "p50 of %d back-to-back queries, decode-cache warm (posting lists decoded once, kept in HBM)" % len(walls),
                "cold": {"wall_ms_per_query": float(np.percentile(cold, 50)), "wall_ms_p95": float(np.percentile(cold, 95)),
-                        "what": "cache_decoded = 0: every query decodes both lists from their encoded bytes (%d B) first" % enc_bytes,
+                        "what": "cache_decoded = 0: every query decodes both lists from their encoded bytes (%d B) first (eight lanes per block, from the sync points the lists' first decode left behind)" % enc_bytes,
                         "decode_plus_intersect_device_ms": prof_cold.get("intersect_ms"),
                         "decode_device_ms": max((prof_cold.get("intersect_ms") or 0) - (prof.get("intersect_ms") or 0), 0.0),
                         "decode_gbs_of_encoded_bytes": enc_bytes / max((prof_cold.get("intersect_ms") or 0) - (prof.get("intersect_ms") or 0), 1e-6) / 1e6,
