@@ -61,6 +61,8 @@ struct ScanTuning {
   int shadow8 = 0;         // same with an int8 shadow (+ per-row scale): a quarter of the bytes, wider error band
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
+  int mq16 = 1;            // multi-query scan: nine to sixteen FLOAT32 queries in ONE pass, queries in LDS (0 = two passes of up to
+                           // eight, 2 = one pass with the queries in registers; A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
@@ -94,7 +96,7 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 // Several queries per corpus pass (scan_mq_kernels.hip): keys[b * keys_ld + row] = the key launch_scan would write for
 // queries + b * qstride, bit for bit, b < nq <= kMqMaxQueries.  fp32 / fp16 / bf16 rows, IP or L2, rows of 512 B .. 4 KiB
 // in the single-query scan's 32- / 64-lane shapes; false (nothing launched) for anything else.
-constexpr uint32_t kMqMaxQueries = 8;
+constexpr uint32_t kMqMaxQueries = 16;
 bool scan_mq_supported(int type, int metric, uint32_t stride16);
 bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
                     const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s);

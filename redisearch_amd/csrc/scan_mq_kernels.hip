@@ -4,7 +4,8 @@
 // issues those calls from N worker threads (src/util/workers.c:58,104).  N concurrent single-query scans are N
 // independent passes over the same 30 GB sharing one HBM: the aggregate stays at one pass per ~4.8 ms however many
 // callers there are.  The coalescer in flat_index.cpp lets queries that arrive while a pass is in flight join the next
-// pass; this kernel is that pass: every row is read ONCE and scored against up to 8 queries held in registers.
+// pass; this kernel is that pass: every row is read ONCE and scored against up to 8 queries held in registers (up to 16
+// FLOAT32 queries held in LDS: scan_mq16_kernel).
 //
 // Bit-identity with scan_kernel is by construction, not by tolerance (scan_ops.hpp):
 //   * same chunk-to-lane map (lane l of a G-lane group owns chunks l, l+G, ...), same per-lane operation order
@@ -24,6 +25,9 @@
 // 8.7 ms.  A variant that streamed the rows through per-wave LDS rings by DMA (global_load_lds, no destination registers,
 // five slots in flight per wave) was built, was bit-identical, and lost: 5.26-5.38 ms with 8 queries, 4.80-5.00 with 4 --
 // removed.  Keys go to keys[b * keys_ld + row], one array per query, and feed the same selection kernels.
+// Nine to sixteen FLOAT32 queries: scan_mq16_kernel below (queries in LDS): 5.85-5.94 ms per sixteen-query pass against
+// 6.48-6.53 with the queries in registers (scan_mq_kernel<..., U = 2, B = 16>, kept as knob mq16 = 2) and 10.4 for two
+// passes of eight; fp16 / bf16: two launches of up to eight.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -39,6 +43,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x / 2); }
+constexpr int kMq16U3 = 2;  // rows per step of the sixteen-query kernel at three chunks per lane (dim 768 fp32)
 
 // chunk c of a row / query.  EXACT: every lane's chunks exist (chunks == G * ITERS).  Otherwise the load is still
 // UNCONDITIONAL -- from the last chunk -- and the value is dropped afterwards: a predicated load becomes a branch with
@@ -226,6 +231,107 @@ __global__ __launch_bounds__(256, 2) void scan_mq_kernel(const u4 *__restrict__ 
   }
 }
 
+// SIXTEEN FLOAT32 queries per pass: 192 query registers per lane at dim 768 leave room for two rows in flight per wave,
+// and a pass became latency-bound (6.5 ms, 4.7 TB/s).  Here the queries live in LDS, once per workgroup (every G-lane
+// group needs the same chunks), in the register-pair layout of the packed FMA -- 48 KiB at dim 768 -- and a lane fetches
+// a pair's chunk with two ds_read_b128 right where it is multiplied, for all U rows of the step at once: the registers
+// hold rows and sums only.  Per (row, query) the products still arrive chunk by chunk, element by element, and the
+// reduction is the same halving butterfly: bit for bit scan_kernel's keys.
+template <int METRIC, int G, int ITERS, int U, bool EXACT>
+__global__ __launch_bounds__(256, 2) void scan_mq16_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t chunks,
+                                                           uint32_t row_begin, uint32_t row_end,
+                                                           const u4 *__restrict__ queries, uint32_t qstride16, uint32_t nq,
+                                                           uint32_t *__restrict__ keys, uint32_t keys_ld) {
+  constexpr int B = 16, P = B / 2, GPB = 256 / G;
+  constexpr int V = U * B, LG = ilog2(G), LV = ilog2(V);
+  constexpr int H = LV < LG ? LV : LG;
+  constexpr int CNT = V >> H;
+  __shared__ u4 qs[ITERS * P * 2 * G];  // [(i * P + p) * 2 + h][lane] = {q2p[4i'+2h], q2p+1[..], q2p[4i'+2h+1], q2p+1[..]}
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t grp = threadIdx.x / G;
+  for (uint32_t idx = threadIdx.x; idx < (uint32_t)(ITERS * P * G); idx += 256) {
+    const uint32_t l = idx % G, ip = idx / G, i = ip / P, p = ip % P;
+    const uint32_t b0 = 2 * p < nq ? 2 * p : nq - 1, b1 = 2 * p + 1 < nq ? 2 * p + 1 : nq - 1;  // unused slots repeat the last query
+    const uint32_t c = l + i * G;
+    const u4 t0 = load_chunk<EXACT, false>(queries + (size_t)b0 * qstride16, c, chunks);
+    const u4 t1 = load_chunk<EXACT, false>(queries + (size_t)b1 * qstride16, c, chunks);
+    qs[(ip * 2 + 0) * G + l] = (u4){t0.x, t1.x, t0.y, t1.y};
+    qs[(ip * 2 + 1) * G + l] = (u4){t0.z, t1.z, t0.w, t1.w};
+  }
+  __syncthreads();
+
+  constexpr bool INTERLEAVE = G < 64;  // (row <-> group mapping of scan_kernel)
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  const uint32_t tile0 = INTERLEAVE ? blockIdx.x : blockIdx.x * GPB + grp;
+  const uint32_t tile_step = INTERLEAVE ? gridDim.x : gridDim.x * GPB;
+  const uint32_t u_stride = INTERLEAVE ? GPB : 1;
+  const uint32_t jtop = lane >> (LG - H);
+  const bool writer = (lane & ((1u << (LG - H)) - 1u)) == 0;
+
+  for (uint32_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + (INTERLEAVE ? grp : 0);
+    u4 x[U][ITERS];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * u_stride;
+      if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[u][i] = load_chunk<EXACT, true>(p, lane + i * G, chunks);
+    }
+    f2 acc[U][P];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int p = 0; p < P; p++) acc[u][p] = (f2){0.0f, 0.0f};
+    // (opaque per tile: the query reads do not depend on the tile, and hipcc would hoist all of them out of the row loop --
+    // 192 registers, the thing this kernel exists to avoid)
+    uint32_t ql = lane;
+    asm volatile("" : "+v"(ql));
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+#pragma unroll
+      for (int p = 0; p < P; p++) {
+        const u4 qa = qs[((i * P + p) * 2 + 0) * G + ql], qb = qs[((i * P + p) * 2 + 1) * G + ql];
+        const f2 qj[4] = {(f2){__uint_as_float(qa.x), __uint_as_float(qa.y)}, (f2){__uint_as_float(qa.z), __uint_as_float(qa.w)},
+                          (f2){__uint_as_float(qb.x), __uint_as_float(qb.y)}, (f2){__uint_as_float(qb.z), __uint_as_float(qb.w)}};
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const float e[4] = {__uint_as_float(x[u][i].x), __uint_as_float(x[u][i].y), __uint_as_float(x[u][i].z),
+                              __uint_as_float(x[u][i].w)};
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const f2 xs = (f2){e[j], e[j]};
+            if (METRIC == KM_L2) {
+              const f2 d = xs - qj[j];
+              acc[u][p] = __builtin_elementwise_fma(d, d, acc[u][p]);
+            } else {
+              acc[u][p] = __builtin_elementwise_fma(xs, qj[j], acc[u][p]);
+            }
+          }
+        }
+      }
+    }
+    float v[V];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int p = 0; p < P; p++) {
+        v[(2 * p) * U + u] = acc[u][p].x;
+        v[(2 * p + 1) * U + u] = acc[u][p].y;
+      }
+    if constexpr (G > 1) MqRed<G / 2, V>::run(v, lane);
+#pragma unroll
+    for (int p = 0; p < CNT; p++) {
+      const uint32_t j = jtop * CNT + p, b = j / U, u = j % U;
+      const uint32_t r = r0 + u * u_stride;
+      if (writer && b < nq && r < row_end) keys[(size_t)b * keys_ld + r] = to_key(finish<KT_F32, METRIC>(v[p], zero4()));
+    }
+  }
+}
+
 std::atomic<uint64_t> g_last_mq{0};
 
 struct MqCtx {
@@ -247,7 +353,7 @@ void mq_launch_one(const MqCtx &c) {
   const uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
   // grid cap per CU, measured at 10 M x 768 fp32 (profiles/r03_mq_scan_ab.txt): four-query kernel 4 (4.68 ms; 2: 5.7-6.1,
   // 8: 4.74, 16: 4.95), eight-query kernel 8 (5.07 ms; 2: 5.14, 4: 5.31, 16: 5.09)
-  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : (B <= 4 ? 4 : 8)));
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : (B <= 4 ? 4 : 8)));  // (B = 16: 8, two resident)
   const uint32_t grid = need < cap ? need : cap;
   if (!grid) return;
   g_last_mq = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
@@ -260,11 +366,55 @@ void mq_launch_one(const MqCtx &c) {
                        c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
 }
 
+template <int METRIC, int G, int ITERS, int U>
+void mq_launch_16(const MqCtx &c) {
+  const ScanTuning &t = scan_tuning();
+  constexpr int GPB = 256 / G;
+  const uint32_t n = c.row_end - c.row_begin;
+  const bool exact = c.chunks == (uint32_t)(G * ITERS);
+  const uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : 8));
+  const uint32_t grid = need < cap ? need : cap;
+  if (!grid) return;
+  g_last_mq = (uint64_t)KT_F32 | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
+              ((uint64_t)16 << 21) | ((uint64_t)exact << 26) | ((uint64_t)1 << 27) | ((uint64_t)grid << 41);
+  if (exact)
+    hipLaunchKernelGGL((scan_mq16_kernel<METRIC, G, ITERS, U, true>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16, c.chunks,
+                       c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+  else
+    hipLaunchKernelGGL((scan_mq16_kernel<METRIC, G, ITERS, U, false>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16, c.chunks,
+                       c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+}
+
 template <int TYPE, int METRIC, int G, int ITERS, int U>
 void mq_launch_b(const MqCtx &c) {
   // fp16 / bf16 with eight queries: the widening temporaries of three or four chunks do not fit 256 registers next to
   // U rows in flight -- fewer rows per step (register budgets: scripts/kernel_resources.py, tests/test_kernel_resources_cpu.py)
   constexpr int U8 = (TYPE != KT_F32 && ITERS >= 3) ? 2 : U;
+  if (c.nq > 8) {
+    // nine to sixteen queries.  FLOAT32 rows of up to 3 KiB: ONE pass, sixteen queries in registers (192 of them at dim 768;
+    // fewer rows in flight per step).  Everything else: two passes of up to eight.
+    if constexpr (TYPE == KT_F32) {
+      if (scan_tuning().mq16 == 1) {  // queries in LDS (every FLOAT32 shape: 16 KiB per chunk per lane of query data)
+        mq_launch_16<METRIC, G, ITERS, 4>(c);  // (U = 8 spills at three and four chunks per lane)
+        return;
+      }
+      if constexpr (ITERS <= 3) {
+        if (scan_tuning().mq16 == 2) {  // queries in registers (A/B: the first form of the sixteen-query pass)
+          mq_launch_one<TYPE, METRIC, G, ITERS, (ITERS == 1 ? 4 : (ITERS == 2 ? 2 : kMq16U3)), 16>(c);
+          return;
+        }
+      }
+    }
+    MqCtx lo = c, hi = c;
+    lo.nq = 8;
+    hi.nq = c.nq - 8;
+    hi.queries = c.queries + 8 * (size_t)c.qstride16;
+    hi.keys = c.keys + 8 * (size_t)c.keys_ld;
+    mq_launch_b<TYPE, METRIC, G, ITERS, U>(lo);
+    mq_launch_b<TYPE, METRIC, G, ITERS, U>(hi);
+    return;
+  }
   if (c.nq <= 4) {
     mq_launch_one<TYPE, METRIC, G, ITERS, U, 4>(c);
   } else if (TYPE != KT_F32 && ITERS >= 4) {  // 4 KiB fp16 / bf16 rows: eight queries spill -- two passes of four
@@ -335,7 +485,7 @@ const char *last_scan_mq_kernel_name(char *buf, size_t cap) {
     snprintf(buf, cap, "none");
     return buf;
   }
-  snprintf(buf, cap, "scan_mq_kernel<%s,%s,G=%u,ITERS=%u,U=%u,B=%u,EXACT=%u> grid=%ux256", tn[v & 7], mn[(v >> 3) & 7],
+  snprintf(buf, cap, "%s<%s,%s,G=%u,ITERS=%u,U=%u,B=%u,EXACT=%u> grid=%ux256", ((v >> 27) & 1) ? "scan_mq16_kernel" : "scan_mq_kernel", tn[v & 7], mn[(v >> 3) & 7],
            (unsigned)((v >> 6) & 127), (unsigned)((v >> 13) & 15), (unsigned)((v >> 17) & 15), (unsigned)((v >> 21) & 31),
            (unsigned)((v >> 26) & 1), (unsigned)(v >> 41));
   return buf;

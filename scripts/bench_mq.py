@@ -61,7 +61,7 @@ def main():
         for name, key, val in variants:
             if key:
                 assert lib.RSGPU_SetTuning(key.encode(), val) == 0
-            for nq in (2, 3, 4, 5, 8):
+            for nq in (4, 8, 12, 16):
                 idx.topk_batch(qs[:nq], a.k)
                 V.coalesce_stats(reset=True)
                 t0 = time.perf_counter()

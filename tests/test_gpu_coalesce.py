@@ -27,7 +27,7 @@ def knobs():
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0
         set_.append(key)
     yield setk
-    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1, "batch_mfma": 1}
+    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1, "batch_mfma": 1, "mq16": 1}
     for key in set_:
         lib.RSGPU_SetTuning(key.encode(), defaults[key])
 
@@ -58,13 +58,14 @@ SHAPES = [  # (type, dim): every (G, ITERS) shape of the multi-query kernel, exa
 @pytest.mark.parametrize("vtype,dim", SHAPES)
 @pytest.mark.parametrize("metric", [V.VecSimMetric_L2, V.VecSimMetric_IP, V.VecSimMetric_Cosine])
 def test_multi_query_pass_is_bit_identical_to_single_queries(vtype, dim, metric, knobs):
-    """RSGPU_FlatIndex_TopKBatch without the matrix-core passes runs the multi-query scan, eight queries per pass: 19
-    queries = passes of 8, 8 and 3 (the B = 8 and B = 4 kernels)."""
+    """RSGPU_FlatIndex_TopKBatch without the matrix-core passes runs the multi-query scan, sixteen queries per pass: 38
+    queries = passes of 16, 16 and 6 -- the sixteen-query kernel (FLOAT32 rows up to 3 KiB; two launches of eight
+    otherwise) and the eight-query one -- then 3 queries through the four-query kernel."""
     knobs("batch_mfma", 0)   # (fp16 / bf16 IP batches would take the MFMA passes: equal only up to the summation order)
     n = 70_000   # >= 2^16: the batched threshold-filter selection at K <= 32
     idx = _index(vtype, dim, metric, n)
     try:
-        qs = _queries(vtype, dim, 19)
+        qs = _queries(vtype, dim, 38)
         before = V.coalesce_stats()
         for k in (1, 10, 100):
             ids, sc, cnt = idx.topk_batch(qs, k)
@@ -74,7 +75,17 @@ def test_multi_query_pass_is_bit_identical_to_single_queries(vtype, dim, metric,
                 assert ids[i][:k].tolist() == si.tolist(), (i, k)
                 assert sc[i][:k].tolist() == ss.tolist(), (i, k)
         after = V.coalesce_stats()
-        assert after["mq_passes"] - before["mq_passes"] == 9 and after["mq_queries"] - before["mq_queries"] == 57
+        assert after["mq_passes"] - before["mq_passes"] == 9 and after["mq_queries"] - before["mq_queries"] == 114
+        ids, sc, cnt = idx.topk_batch(qs[:3], 10)
+        for i in range(3):
+            si, ss = idx.topk_query(qs[i], 10).results()
+            assert ids[i].tolist() == si.tolist() and sc[i].tolist() == ss.tolist()
+        if vtype == V.VecSimType_FLOAT32 and dim <= 768:      # ... and the same passes as two launches of eight
+            knobs("mq16", 0)
+            ids, sc, cnt = idx.topk_batch(qs[:16], 10)
+            for i in range(16):
+                si, ss = idx.topk_query(qs[i], 10).results()
+                assert ids[i].tolist() == si.tolist() and sc[i].tolist() == ss.tolist()
     finally:
         idx.free()
 

@@ -81,11 +81,12 @@ def test_single_query_scan_budget(kernels):
 
 def test_multi_query_scan_budget(kernels):
     """scan_mq_kernel<TYPE, METRIC, G, ITERS, U, B, EXACT>: eight queries' chunks live in registers (96 of them at 768
-    fp32); the kernel must keep two wavefronts per SIMD (<= 256 registers) without spilling -- a spill here costs bandwidth,
-    not parity, so only this test would notice."""
+    fp32; 192 in the sixteen-query kernel); the kernel must keep two wavefronts per SIMD (<= 256 registers) without spilling
+    -- a spill here costs bandwidth, not parity, so only this test would notice."""
     mq = [k for k in kernels if k["name"].startswith("scan_mq_kernel<")]
     assert len(mq) >= 100
     for k in mq:
         assert k["vgpr"] <= 256 and not k["vgpr_spill"] and not k["scratch"], (k["name"], k["vgpr"], k["vgpr_spill"])
     head = [k for k in mq if k["name"].startswith("scan_mq_kernel<0, 1, 64, 3, 4, 8, true")]
     assert len(head) == 1 and head[0]["vgpr"] <= 224, head     # the 10 M x 768 fp32 cosine pass
+    assert len([k for k in mq if k["name"].startswith("scan_mq_kernel<0, 1, 64, 3, 2, 16, true")]) == 1   # ... of sixteen
