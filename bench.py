@@ -451,6 +451,29 @@ def extra_concurrent_callers(lib, V, index, queries, k, rows, dim, single_qps):
             rec["linger_us_per_pass"] = st["linger_ns"] / 1e3 / max(st["passes"], 1)
         out["%d_threads" % threads] = rec
     out["kernel"] = V.last_mq_scan_kernel()
+    # the same callers with the opt-in two-stage exact scan switched on (the index carries the int8 shadow): concurrent
+    # K <= 16 calls share multi-query passes over the SHADOW (scan_mq_i8_kernel), survivors re-scored from the fp32 rows --
+    # the replies must still be the plain index's, bit for bit
+    lib.RSGPU_SetTuning(b"two_stage", 1)
+    try:
+        sh = {}
+        for threads in (1, 8, 16):
+            V.coalesce_stats(reset=True)
+            V.two_stage_stats(reset=True)
+            total, el, lat, ids, sc = run_callers(cl, index, qs, k, threads, 2.0, keep_answers=True)
+            st, ts = V.coalesce_stats(), V.two_stage_stats()
+            same = all(ids[i].tolist() == serial[i][0].tolist() and sc[i].tolist() == serial[i][1].tolist() for i in range(nq))
+            sh["%d_threads" % threads] = dict(qps=total / el, queries=int(total), queries_per_pass=st["queries"] / max(st["passes"], 1),
+                                              multi_query_passes=st["mq_passes"], redone_on_the_single_path=st["mq_redo"],
+                                              shadow_scan_ms=st["mq_device_ns"] / max(st["mq_passes"], 1) / 1e6,
+                                              two_stage_fallbacks=ts["fallbacks"], bit_identical_to_plain_serial=bool(same),
+                                              **_lat_summary(lat))
+        sh["what"] = "opt-in int8 shadow (+25 % HBM): the two-stage exact scan, coalesced; NOT the headline mode"
+        out["with_int8_shadow_two_stage"] = sh
+    except Exception as e:  # the extra must never take the record down
+        out["with_int8_shadow_two_stage"] = {"error": str(e)[:200]}
+    finally:
+        lib.RSGPU_SetTuning(b"two_stage", 0)
     out["qps"] = out["8_threads"]["qps"]
     out["x_single_stream"] = out["8_threads"]["x_single_stream"]
     out["p50_ms"] = out["8_threads"]["p50_ms"]

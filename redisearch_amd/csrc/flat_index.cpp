@@ -1004,6 +1004,30 @@ void FlatIndex::select(QueryCtx *c, uint32_t n, uint32_t k, const Bound &lower, 
 //   4. re-score the survivors from the fp32 rows with the SAME gather kernel arithmetic as the full scan and
 //      select the K best (distance, row): ids and distances are bit-identical to the one-stage path.
 // Returns false (caller runs the full fp32 scan) when the survivors do not fit the candidate buffer.
+bool FlatIndex::shadow8_query(const float *qf, int8_t *q8, float *sq_out, float *qn2_out, float *eps_out) const {
+  float qmax = 0.0f;
+  double qn2 = 0.0;
+  for (size_t i = 0; i < dim; i++) {
+    qmax = std::max(qmax, std::fabs(qf[i]));
+    qn2 += (double)qf[i] * (double)qf[i];
+  }
+  if (!(qmax > 0.0f) || !(s_max_ > 0.0f) || s_bad_ || !std::isfinite(qn2) || !std::isfinite(n2_max_)) return false;
+  const float sq = qmax / 127.0f;
+  const float qn = (float)std::sqrt(qn2) * 1.000001f, xn = std::sqrt(n2_max_) * 1.0001f;
+  for (size_t i = 0; i < dim; i++) q8[i] = (int8_t)std::min(127.0f, std::max(-127.0f, std::nearbyintf(qf[i] / sq)));
+  const float rd = std::sqrt((float)dim);
+  const float eps_dot = ((s_max_ * qn + sq * xn) * rd * 0.5f + 0.75f * s_max_ * sq * (float)dim) * 1.001f;
+  const bool l2 = kmetric == KM_L2;
+  // fp32 rounding on both sides (d-term accumulations, |x|^2 of the row, the final sums): d 2^-23 of the largest magnitude
+  const float mag = l2 ? (qn + xn) * (qn + xn) : 1.0f + qn * xn;
+  const float eps = (l2 ? 2.0f * eps_dot : eps_dot) + (float)dim * 1.2e-7f * mag + 1e-6f;
+  if (!std::isfinite(eps)) return false;
+  *sq_out = sq;
+  *qn2_out = (float)qn2;
+  *eps_out = eps;
+  return true;
+}
+
 bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out) {
   TwoStageStats &st = two_stage_stats();
   st.v[TwoStageStats::ATTEMPTS]++;
@@ -1036,29 +1060,14 @@ bool FlatIndex::two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<
     //                        = (sx |q| + sq |x|) sqrt(d)/2 + (3/4) sx sq d,   sx <= s_max, |x| <= n_max over all rows
     // (unit vectors: (sx + sq) sqrt(d)/2 + ...).  IP / cosine distance 1 - x.q: that band; L2 = |q|^2 + |x|^2 - 2 x.q:
     // twice the band, |x|^2 taken from the fp32 row at add time.
-    float qmax = 0.0f;
-    double qn2 = 0.0;
-    for (size_t i = 0; i < dim; i++) {
-      qmax = std::max(qmax, std::fabs(qf[i]));
-      qn2 += (double)qf[i] * (double)qf[i];
-    }
-    if (!(qmax > 0.0f) || !(s_max_ > 0.0f) || s_bad_ || !std::isfinite(qn2) || !std::isfinite(n2_max_))
-      return leave(TwoStageStats::FB_QUERY_OR_BAND);
-    const float sq = qmax / 127.0f;
-    const float qn = (float)std::sqrt(qn2) * 1.000001f, xn = std::sqrt(n2_max_) * 1.0001f, qn2f = (float)qn2;
+    float sq = 0.0f, qn2f = 0.0f, eps = 0.0f;
     int8_t *q8 = reinterpret_cast<int8_t *>(c->h_query + q16_off);
     memset(q8, 0, sstride_ + 16);
-    for (size_t i = 0; i < dim; i++) q8[i] = (int8_t)std::min(127.0f, std::max(-127.0f, std::nearbyintf(qf[i] / sq)));
+    if (!shadow8_query(qf, q8, &sq, &qn2f, &eps)) return leave(TwoStageStats::FB_QUERY_OR_BAND);
     memcpy(q8 + sstride_ + 4, &sq, 4);  // the extra chunk: {0, query scale, |q|^2, 0}
     memcpy(q8 + sstride_ + 8, &qn2f, 4);
     HIP_CHECK(hipMemcpyAsync(c->d_query + q16_off, q8, sstride_ + 16, hipMemcpyHostToDevice, c->stream));
-    const float rd = std::sqrt((float)dim);
-    const float eps_dot = ((s_max_ * qn + sq * xn) * rd * 0.5f + 0.75f * s_max_ * sq * (float)dim) * 1.001f;
     const bool l2 = kmetric == KM_L2;
-    // fp32 rounding on both sides (d-term accumulations, |x|^2 of the row, the final sums): d 2^-23 of the largest magnitude
-    const float mag = l2 ? (qn + xn) * (qn + xn) : 1.0f + qn * xn;
-    const float eps = (l2 ? 2.0f * eps_dot : eps_dot) + (float)dim * 1.2e-7f * mag + 1e-6f;
-    if (!std::isfinite(eps)) return leave(TwoStageStats::FB_QUERY_OR_BAND);
     kSlack = 2.0f * eps;
     if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
     launch_scan(d_shadow_, sstride_, (uint32_t)dim, KT_I8, l2 ? KM_L2S : KM_IPS, 0, n, c->d_query + q16_off, c->d_keys, c->stream,
@@ -1137,9 +1146,17 @@ bool FlatIndex::mq_capable(size_t k) const {
   if ((shadow_ == 1 || shadow_ == 2) && scan_tuning().two_stage) return false;
   return scan_mq_supported(ktype, kmetric, (uint32_t)(stride_ / 16));
 }
+// ... unless it is the int8 shadow and the caller wants few neighbours: then the two-stage scan itself has a multi-query form
+// (K <= 16: above that the single path takes the exact K-th shadow distance through radix levels, which has no batched form)
+bool FlatIndex::shadow8_mq_capable(size_t k) const {
+  if (shadow_ != 2 || !scan_tuning().two_stage || !scan_tuning().coalesce_shadow8 || multi || key_bytes != 4 || !k || k > 16) return false;
+  if (s_bad_ || sstride_ != dim || !scan_mq_i8_supported((uint32_t)(sstride_ / 16))) return false;
+  if (!batch_rescore_supported((uint32_t)(stride_ / 16))) return false;
+  return __atomic_load_n(&n_rows_, __ATOMIC_RELAXED) >= (1u << 18);
+}
 bool FlatIndex::coalescible(size_t k) const {
   const ScanTuning &t = scan_tuning();
-  if (!t.coalesce || !mq_capable(k)) return false;
+  if (!t.coalesce || (!mq_capable(k) && !shadow8_mq_capable(k))) return false;
   const uint32_t n = __atomic_load_n(&n_rows_, __ATOMIC_RELAXED);
   return (size_t)n * stride_ >= ((size_t)(t.coalesce_min_mib > 0 ? t.coalesce_min_mib : 0) << 20);
 }
@@ -1147,7 +1164,9 @@ bool FlatIndex::coalescible(size_t k) const {
 int FlatIndex::coalesce_linger_us() const {
   const int us = scan_tuning().coalesce_linger_us;
   if (us >= 0) return us;
-  const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)stride_ / 6.0e6;  // ~6 TB/s
+  // (~6 TB/s over the bytes a pass reads: the int8 shadow's when it serves the queries)
+  const size_t row_bytes = shadow_ == 2 && scan_tuning().two_stage ? sstride_ + 8 : stride_;
+  const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)row_bytes / 6.0e6;
   return (int)std::min(300.0, std::max(20.0, 0.05 * pass_us));
 }
 
@@ -1232,10 +1251,21 @@ void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
     else if (!n || !j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
     else live[n_live++] = j;
   }
-  bool mq = n_live >= 2;
-  for (size_t i = 0; i < n_live; i++) mq = mq && mq_capable(live[i]->k);
+  bool mq = n_live >= 2, mq8 = n_live >= 2;
+  for (size_t i = 0; i < n_live; i++) {
+    mq = mq && mq_capable(live[i]->k);
+    mq8 = mq8 && shadow8_mq_capable(live[i]->k);
+  }
   if (mq) {
     topk_pass_mq(live, n_live, n);
+    return;
+  }
+  if (mq8) {  // (the shadow kernel holds eight queries)
+    for (size_t at = 0; at < n_live; at += 8) {
+      const size_t cnt = std::min<size_t>(8, n_live - at);
+      if (cnt == 1) live[at]->reply = topk_locked(live[at]->query, live[at]->k, live[at]->tctx, live[at]->order);
+      else topk_pass_mq_shadow8(live + at, cnt, n);
+    }
     return;
   }
   for (size_t i = 0; i < n_live; i++) live[i]->reply = topk_locked(live[i]->query, live[i]->k, live[i]->tctx, live[i]->order);
@@ -1325,6 +1355,106 @@ void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
     const size_t take = std::min<size_t>(hits[b].size(), j->k);
     VecSimQueryReply *r = new_reply(take, VecSim_QueryReply_OK);
     for (size_t i = 0; i < take; i++) r->results[i] = VecSimQueryResult{(size_t)label_at(hits[b][i].row), score_of(hits[b][i].key)};
+    sort_reply(r, j->order);
+    j->reply = r;
+  }
+}
+
+// The two-stage exact scan (two_stage_topk, int8 shadow) for 2 .. 8 queries at once: one multi-query pass over the shadow
+// writes every query's shadow keys; per query: sampled bound -> candidates -> their exact K-th shadow distance + the query's
+// own 2 eps -> candidates inside the band -> EXACT keys from the fp32 rows (batch_rescore_kernel: the scan's arithmetic) ->
+// select.  Every step is the batched form of the single path's; a query whose lists overflow, or that cannot be quantised,
+// is answered on the single path.  K <= 16 (the selection runs with the largest K of the pass: a wider, still valid, band).
+void FlatIndex::topk_pass_mq_shadow8(TopkJob *const *jobs, size_t nj, uint32_t n) {
+  HIP_CHECK(hipSetDevice(device));
+  CtxLease c(device);
+  const size_t off_q8 = nj * stride_, off_qx = off_q8 + nj * sstride_, off_slack = off_qx + nj * 2 * sizeof(float);
+  const size_t total = round_up(off_slack + nj * sizeof(float), 16);
+  c->ensure_mq(total);
+  memset(c->h_mq_queries, 0, total);
+  bool ok[8] = {false};
+  uint32_t kmax = 0;
+  for (size_t b = 0; b < nj; b++) {
+    uint8_t *dst = c->h_mq_queries + b * stride_;
+    memcpy(dst, jobs[b]->query, elem_bytes_);
+    if (metric == VecSimMetric_Cosine) normalize_host(dst);
+    float sq = 1.0f, qn2 = 0.0f, eps = 0.0f;
+    ok[b] = shadow8_query(reinterpret_cast<const float *>(dst), reinterpret_cast<int8_t *>(c->h_mq_queries + off_q8 + b * sstride_),
+                          &sq, &qn2, &eps);
+    float *qx = reinterpret_cast<float *>(c->h_mq_queries + off_qx) + 2 * b;
+    qx[0] = sq;
+    qx[1] = qn2;
+    reinterpret_cast<float *>(c->h_mq_queries + off_slack)[b] = ok[b] ? 2.0f * eps : 0.0f;
+    kmax = std::max<uint32_t>(kmax, (uint32_t)std::min<size_t>(jobs[b]->k, n));
+  }
+  HIP_CHECK(hipMemcpyAsync(c->d_mq_queries, c->h_mq_queries, total, hipMemcpyHostToDevice, c->stream));
+  const uint32_t ld = (uint32_t)round_up(n, 1024);
+  c->ensure_keys(nj * (size_t)ld);
+  c->ensure_out(nj * (size_t)kmax);
+  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+  const float *d_slack = reinterpret_cast<const float *>(c->d_mq_queries + off_slack);
+  HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  if (!launch_scan_mq_i8(d_shadow_, sstride_, kmetric == KM_L2 ? KM_L2S : KM_IPS, 0, n, d_sscale_, c->d_mq_queries + off_q8, sstride_,
+                         reinterpret_cast<const float *>(c->d_mq_queries + off_qx), (uint32_t)nj, c->d_keys, ld, c->stream))
+    throw std::runtime_error("multi-query shadow scan refused a row shape the coalescer was gated on");
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+  uint32_t *out_keys32 = reinterpret_cast<uint32_t *>(c->h_out_keys);
+  for (size_t b = 0; b < nj; b++) c->h_mq_n[b] = c->h_mq_over[b] = 0;
+  // keys <= sampled bound -> their exact K-th + 2 eps -> keys inside the band
+  launch_sample_threshold_batch(c->d_keys, ld, n, 64, kmax, (uint32_t)nj, c->d_mq_tau, c->d_mq_cnt, c->stream);
+  launch_filter_keys_batch(c->d_keys, ld, n, (uint32_t)nj, c->d_mq_tau, c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, c->stream);
+  // (a list of exactly K candidates keeps the sampled bound, which is then the K-th distance itself: the band is added by
+  // the filter, whichever bound it gets)
+  launch_batch_threshold_cand(c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, kmax, (uint32_t)nj, (uint32_t)nj, c->d_mq_tau,
+                              c->h_mq_over, c->stream);
+  HIP_CHECK(hipMemsetAsync(c->d_mq_cnt, 0, nj * sizeof(uint32_t), c->stream));
+  launch_filter_keys_batch(c->d_keys, ld, n, (uint32_t)nj, c->d_mq_tau, c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, c->stream,
+                           d_slack);
+  // exact keys of the survivors (lists that overflowed are skipped: the select flags them)
+  if (!launch_batch_rescore(d_rows_, stride_, n, c->d_mq_queries, stride_, c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, (uint32_t)nj,
+                            nullptr, c->stream, KT_F32, kmetric == KM_L2 ? KM_L2 : KM_IP))
+    throw std::runtime_error("coalesced two-stage pass: the re-scoring kernel refused a row shape the route was gated on");
+  launch_batch_select_cand(c->d_mq_cand, c->d_mq_cnt, QueryCtx::kCandCap, kmax, (uint32_t)nj, c->h_out_rows, out_keys32, c->h_mq_n,
+                           kmax, c->h_mq_over, c->stream);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(c->stream));
+  {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
+      coalesce_stats().mq_device_ns += (uint64_t)((double)ms * 1e6);
+      if (prof) {
+        ScanProfile &pf = scan_profile();
+        pf.launches++;
+        pf.bytes += (uint64_t)n * (dim + 8);
+        pf.nanos += (uint64_t)((double)ms * 1e6);
+      }
+    }
+  }
+  coalesce_stats().mq_passes++;
+  coalesce_stats().mq_queries += nj;
+  TwoStageStats &st = two_stage_stats();
+  for (size_t b = 0; b < nj; b++) {
+    TopkJob *j = jobs[b];
+    if (timed_out(j->tctx)) {
+      j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+      continue;
+    }
+    const uint32_t got = std::min<uint32_t>(c->h_mq_n[b], kmax), want = (uint32_t)std::min<size_t>(j->k, n);
+    st.v[TwoStageStats::ATTEMPTS]++;
+    if (!ok[b] || c->h_mq_over[b] || got < std::min<uint32_t>(kmax, n)) {  // answered on the single path (which counts its own way out)
+      st.v[TwoStageStats::ATTEMPTS]--;
+      coalesce_stats().mq_redo++;
+      j->reply = topk_locked(j->query, j->k, j->tctx, j->order);
+      continue;
+    }
+    st.v[TwoStageStats::OK]++;
+    std::vector<Hit> hits(got);
+    for (uint32_t i = 0; i < got; i++) hits[i] = Hit{c->h_out_rows[b * kmax + i], (uint64_t)out_keys32[b * kmax + i]};
+    std::sort(hits.begin(), hits.end(), [](const Hit &x, const Hit &y) { return x.key != y.key ? x.key < y.key : x.row < y.row; });
+    const size_t take = std::min<size_t>(hits.size(), want);
+    VecSimQueryReply *r = new_reply(take, VecSim_QueryReply_OK);
+    for (size_t i = 0; i < take; i++) r->results[i] = VecSimQueryResult{(size_t)label_at(hits[i].row), score_of(hits[i].key)};
     sort_reply(r, j->order);
     j->reply = r;
   }

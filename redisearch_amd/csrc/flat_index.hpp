@@ -301,6 +301,13 @@ class FlatIndex {
   // the single-query path; the caller holds the shared lock and has flushed
   VecSimQueryReply *topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order);
   void topk_pass_mq(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // >= 2 jobs, shared lock held
+  // the same for indexes that carry the int8 shadow: ONE multi-query pass over the shadow (scan_mq_i8_kernel), the
+  // two-stage scan's error-banded filter for every query at once, survivors re-scored from the fp32 rows
+  void topk_pass_mq_shadow8(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // 2 .. 8 jobs, shared lock held
+  bool shadow8_mq_capable(size_t k) const;
+  // normalised fp32 query -> its int8 copy, scale, |q|^2 and the error band of the shadow distance (two_stage_topk's
+  // analysis); false: the band bounds nothing for this query (zero / non-finite query, non-finite rows)
+  bool shadow8_query(const float *qf, int8_t *q8, float *sq, float *qn2, float *eps) const;
   bool coalescible(size_t k) const;  // the multi-query scan applies and concurrent calls are worth coalescing (knob, corpus size)
   // ---- the coalescer: queries that arrive while a pass is in flight join the next pass -----------------------------
   // Leader / follower: the caller at the head of the queue runs the pass for everybody queued behind it (at most

@@ -61,6 +61,7 @@ struct ScanTuning {
   int shadow8 = 0;         // same with an int8 shadow (+ per-row scale): a quarter of the bytes, wider error band
   int two_stage = 1;       // query-time switch of the above for indexes that carry a shadow
   int cache_decoded = 1;   // posting lists: keep the decoded id/freq arrays after the first decode (0 = decode per query)
+  int coalesce_shadow8 = 1;  // coalesce concurrent K <= 16 queries on indexes that carry the int8 shadow into multi-query two-stage passes
   int mq16 = 1;            // multi-query scan: nine to sixteen FLOAT32 queries in ONE pass, queries in LDS (0 = two passes of up to
                            // eight, 2 = one pass with the queries in registers; A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
@@ -97,6 +98,13 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 // queries + b * qstride, bit for bit, b < nq <= kMqMaxQueries.  fp32 / fp16 / bf16 rows, IP or L2, rows of 512 B .. 4 KiB
 // in the single-query scan's 32- / 64-lane shapes; false (nothing launched) for anything else.
 constexpr uint32_t kMqMaxQueries = 16;
+// The same for the int8 shadow of a FLOAT32 index (rows of 256 / 512 / 768 / 1024 int8 elements, row_meta = {scale, |x|^2}
+// per row as for launch_scan's KM_IPS / KM_L2S; queries: nq int8 rows qstride bytes apart; qx[b] = {query scale, |q|^2}):
+// keys[b * keys_ld + row] = the single scan's shadow key.  nq <= 8.
+bool scan_mq_i8_supported(uint32_t stride16);
+bool launch_scan_mq_i8(const void *rows, size_t stride, int metric, uint32_t row_begin, uint32_t row_end, const float *row_meta,
+                       const void *queries, size_t qstride, const float *qx, uint32_t nq, uint32_t *keys, uint32_t keys_ld,
+                       hipStream_t s);
 bool scan_mq_supported(int type, int metric, uint32_t stride16);
 bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
                     const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s);
@@ -221,7 +229,8 @@ void launch_sample_threshold(const uint32_t *keys, uint32_t n, uint32_t per, uin
 void launch_sample_threshold_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t per, uint32_t k,
                                    uint32_t n_queries, float *tau_out, uint32_t *cand_count, hipStream_t s);
 void launch_filter_keys_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t n_queries, const float *tau,
-                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s);
+                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s,
+                              const float *slack_q = nullptr);  // slack_q[b]: added to tau[b] first (an error band per query)
 // candidates of a single key array: append (row,key) of every key <= orderable(*tau) to cand[0..cap),
 // counting in cand_count[0]
 // (slack is added to *tau first: the two-stage scan's error bound)

@@ -56,32 +56,41 @@ __device__ __forceinline__ u4 load_chunk(const u4 *__restrict__ p, uint32_t c, u
 }
 
 // ---- the halving butterfly over a group of G lanes: M = current mask, CUR = live values per lane ----------------------
-template <int M, int CUR>
+__device__ __forceinline__ uint32_t as_bits(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ uint32_t as_bits(int i) { return (uint32_t)i; }
+template <typename T>
+__device__ __forceinline__ T from_bits(uint32_t u);
+template <>
+__device__ __forceinline__ float from_bits<float>(uint32_t u) { return __uint_as_float(u); }
+template <>
+__device__ __forceinline__ int from_bits<int>(uint32_t u) { return (int)u; }
+
+template <int M, int CUR, typename T = float>
 struct MqRed {
-  static __device__ __forceinline__ void run(float *v, uint32_t gl) {
+  static __device__ __forceinline__ void run(T *v, uint32_t gl) {
     if constexpr (CUR >= 2) {
       constexpr int H = CUR / 2;
 #pragma unroll
       for (int i = 0; i < H; i++) {
-        const float a = v[i], b = v[i + H];
+        const T a = v[i], b = v[i + H];
         if constexpr (M == 32) {
           // a' = {a.lo32, b.lo32}, b' = {a.hi32, b.hi32}: lanes < 32 get a[l] + a[l+32], lanes >= 32 b[l-32] + b[l]
-          const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-          v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+          const u2v r = __builtin_amdgcn_permlane32_swap(as_bits(a), as_bits(b), false, false);
+          v[i] = from_bits<T>(r.x) + from_bits<T>(r.y);
         } else if constexpr (M == 16) {
           // odd 16-lane rows of a <-> even rows of b: even rows get a[l] + a[l+16], odd rows b[l-16] + b[l]
-          const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-          v[i] = __uint_as_float(r.x) + __uint_as_float(r.y);
+          const u2v r = __builtin_amdgcn_permlane16_swap(as_bits(a), as_bits(b), false, false);
+          v[i] = from_bits<T>(r.x) + from_bits<T>(r.y);
         } else {
           const bool hi = (gl & (uint32_t)M) != 0;
-          const float keep = hi ? b : a, send = hi ? a : b;
+          const T keep = hi ? b : a, send = hi ? a : b;
           v[i] = keep + __shfl_xor(send, M, 64);
         }
       }
-      if constexpr (M > 1) MqRed<M / 2, H>::run(v, gl);
+      if constexpr (M > 1) MqRed<M / 2, H, T>::run(v, gl);
     } else {
       v[0] += __shfl_xor(v[0], M, 64);
-      if constexpr (M > 1) MqRed<M / 2, 1>::run(v, gl);
+      if constexpr (M > 1) MqRed<M / 2, 1, T>::run(v, gl);
     }
   }
 };
@@ -332,6 +341,76 @@ __global__ __launch_bounds__(256, 2) void scan_mq16_kernel(const u4 *__restrict_
   }
 }
 
+// The int8 shadow (FLOAT32 indexes created with shadow8: int8 rows with {scale, |x|^2} per row, flat_index.hpp) scanned for
+// up to EIGHT queries per pass: the filter pass of the two-stage exact scan for coalesced callers.  Rows are dim bytes
+// (16-byte chunks, 16 lanes per row, ITERS = chunks / 16), the queries' int8 copies sit in registers, v_dot4_i32_i8 sums
+// are exact integers -- whatever the order -- and the key is the single scan's shadow8_distance of the same integer, so the
+// keys ARE scan_kernel<KT_I8, KM_IPS / KM_L2S>'s.  qx[b] = {query scale, |q|^2}.
+template <int METRIC, int ITERS, int U, int B>
+__global__ __launch_bounds__(256, 2) void scan_mq_i8_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t row_begin,
+                                                            uint32_t row_end, const float2 *__restrict__ row_meta,
+                                                            const u4 *__restrict__ queries, uint32_t qstride16,
+                                                            const float2 *__restrict__ qx, uint32_t nq,
+                                                            uint32_t *__restrict__ keys, uint32_t keys_ld) {
+  constexpr int G = 16, GPB = 256 / G;
+  constexpr int V = U * B, LG = 4, LV = ilog2(V);
+  constexpr int H = LV < LG ? LV : LG;
+  constexpr int CNT = V >> H;
+  static_assert(LV >= LG, "every lane of a group finishes at least one sum");
+  __shared__ float2 qxs[B];
+  const uint32_t lane = threadIdx.x % G, grp = threadIdx.x / G;
+  if (threadIdx.x < B) qxs[threadIdx.x] = qx[threadIdx.x < nq ? threadIdx.x : nq - 1];
+  u4 q[B][ITERS];
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    const uint32_t bb = (uint32_t)b < nq ? (uint32_t)b : nq - 1;  // unused slots repeat the last query, never stored
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) q[b][i] = queries[(size_t)bb * qstride16 + lane + i * G];
+  }
+  __syncthreads();
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = GPB * U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + grp;
+    u4 x[U][ITERS];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * GPB;
+      if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[u][i] = load16<true>(p + lane + i * G);
+    }
+    int v[V];
+#pragma unroll
+    for (int b = 0; b < B; b++)
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < ITERS; i++) {
+          acc = __builtin_amdgcn_sdot4((int)x[u][i].x, (int)q[b][i].x, acc, false);
+          acc = __builtin_amdgcn_sdot4((int)x[u][i].y, (int)q[b][i].y, acc, false);
+          acc = __builtin_amdgcn_sdot4((int)x[u][i].z, (int)q[b][i].z, acc, false);
+          acc = __builtin_amdgcn_sdot4((int)x[u][i].w, (int)q[b][i].w, acc, false);
+        }
+        v[b * U + u] = acc;
+      }
+    MqRed<G / 2, V, int>::run(v, lane);
+#pragma unroll
+    for (int p = 0; p < CNT; p++) {
+      const uint32_t j = lane * CNT + p, b = j / U, u = j % U;
+      const uint32_t r = r0 + u * GPB;
+      if (b < nq && r < row_end) {
+        const float2 qq = qxs[b];
+        const u4 qxv = (u4){0u, __float_as_uint(qq.x), __float_as_uint(qq.y), 0u};
+        keys[(size_t)b * keys_ld + r] = to_key(shadow8_distance<METRIC>((float)v[p], row_meta[r], qxv));
+      }
+    }
+  }
+}
+
 std::atomic<uint64_t> g_last_mq{0};
 
 struct MqCtx {
@@ -476,6 +555,38 @@ bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint3
     default: return false;
   }
 #undef RSGPU_MQ_CASE
+}
+
+bool scan_mq_i8_supported(uint32_t stride16) { return stride16 == 16 || stride16 == 32 || stride16 == 48 || stride16 == 64; }
+
+bool launch_scan_mq_i8(const void *rows, size_t stride, int metric, uint32_t row_begin, uint32_t row_end, const float *row_meta,
+                       const void *queries, size_t qstride, const float *qx, uint32_t nq, uint32_t *keys, uint32_t keys_ld,
+                       hipStream_t s) {
+  const uint32_t s16 = (uint32_t)(stride / 16);
+  if (row_end <= row_begin || !nq || nq > 8 || !scan_mq_i8_supported(s16) || (metric != KM_IPS && metric != KM_L2S)) return false;
+  constexpr int U = 4, B = 8;
+  const uint32_t n = row_end - row_begin, need = (n + 16 * U - 1) / (16 * U);
+  const ScanTuning &t = scan_tuning();
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : 8));
+  const dim3 grid(need < cap ? need : cap), block(256);
+#define RSGPU_MQI8(MM, II)                                                                                                 \
+  hipLaunchKernelGGL((scan_mq_i8_kernel<MM, II, U, B>), grid, block, 0, s, (const u4 *)rows, s16, row_begin, row_end,     \
+                     (const float2 *)row_meta, (const u4 *)queries, (uint32_t)(qstride / 16), (const float2 *)qx, nq, keys,  \
+                     keys_ld)
+#define RSGPU_MQI8_M(II)                       \
+  do {                                         \
+    if (metric == KM_L2S) RSGPU_MQI8(KM_L2S, II); \
+    else RSGPU_MQI8(KM_IPS, II);               \
+  } while (0)
+  switch (s16 / 16) {
+    case 1: RSGPU_MQI8_M(1); break;
+    case 2: RSGPU_MQI8_M(2); break;
+    case 3: RSGPU_MQI8_M(3); break;
+    default: RSGPU_MQI8_M(4); break;
+  }
+#undef RSGPU_MQI8_M
+#undef RSGPU_MQI8
+  return true;
 }
 
 const char *last_scan_mq_kernel_name(char *buf, size_t cap) {

@@ -373,11 +373,11 @@ __global__ __launch_bounds__(1024) void sample_threshold_kernel(const uint32_t *
 __global__ __launch_bounds__(256) void filter_keys_kernel(const uint32_t *__restrict__ keys, uint32_t n,
                                                           const float *__restrict__ tau, uint2 *__restrict__ cand,
                                                           uint32_t *__restrict__ cand_count, uint32_t cap, float slack,
-                                                          uint32_t keys_ld) {
+                                                          uint32_t keys_ld, const float *__restrict__ slack_q) {
   keys += (size_t)blockIdx.y * keys_ld;
   cand += (size_t)blockIdx.y * cap;
   cand_count += blockIdx.y;
-  const uint32_t max_key = f2key_dev(tau[blockIdx.y] + slack);
+  const uint32_t max_key = f2key_dev(tau[blockIdx.y] + (slack_q ? slack_q[blockIdx.y] : slack));
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t n4 = n / 4;  // whole 16-byte chunks; the 0..3 keys behind them are handled at the end
   const u4 *k4 = (const u4 *)keys;
@@ -498,10 +498,10 @@ void launch_sample_threshold_batch(const uint32_t *keys, uint32_t keys_ld, uint3
 }
 
 void launch_filter_keys_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n, uint32_t n_queries, const float *tau,
-                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s) {
+                              void *cand, uint32_t *cand_count, uint32_t cap, hipStream_t s, const float *slack_q) {
   uint32_t need = (n / 4 + 1023) / 1024;
   hipLaunchKernelGGL(filter_keys_kernel, dim3(need ? need : 1, n_queries), dim3(256), 0, s, keys, n, tau, (uint2 *)cand,
-                     cand_count, cap, 0.0f, keys_ld);
+                     cand_count, cap, 0.0f, keys_ld, slack_q);
 }
 
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
@@ -509,7 +509,7 @@ void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void
   // one step per workgroup (a capped grid left ~20 % of the workgroups a second step: 21 us instead of ~12)
   uint32_t need = (n / 4 + 1023) / 1024;
   hipLaunchKernelGGL(filter_keys_kernel, dim3(need ? need : 1), dim3(256), 0, s, keys, n, tau, (uint2 *)cand, cand_count, cap,
-                     slack, 0u);
+                     slack, 0u, (const float *)nullptr);
 }
 
 namespace {

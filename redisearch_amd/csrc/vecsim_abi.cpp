@@ -700,6 +700,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
   else if (!strcmp(key, "decode_sync")) scan_tuning().decode_sync = value;
   else if (!strcmp(key, "mq16")) scan_tuning().mq16 = value;
+  else if (!strcmp(key, "coalesce_shadow8")) scan_tuning().coalesce_shadow8 = value;
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;
   else if (!strcmp(key, "two_stage")) scan_tuning().two_stage = value;
   else if (!strcmp(key, "shadow8")) scan_tuning().shadow8 = value;

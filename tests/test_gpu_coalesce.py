@@ -27,7 +27,7 @@ def knobs():
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0
         set_.append(key)
     yield setk
-    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1, "batch_mfma": 1, "mq16": 1}
+    defaults = {"coalesce": 1, "coalesce_min_mib": 64, "coalesce_linger_us": -1, "filter_select": 1, "batch_mfma": 1, "mq16": 1, "coalesce_shadow8": 1}
     for key in set_:
         lib.RSGPU_SetTuning(key.encode(), defaults[key])
 
@@ -176,6 +176,52 @@ def test_concurrent_callers_share_passes_and_get_their_serial_answers(vtype, dim
         st = V.coalesce_stats()
         assert st["queries"] == 48 * 6
         assert st["mq_passes"] > 0 and st["mq_queries"] > st["mq_passes"], st
+    finally:
+        idx.free()
+
+
+@pytest.mark.parametrize("dim,metric", [(768, V.VecSimMetric_Cosine), (256, V.VecSimMetric_L2), (512, V.VecSimMetric_IP),
+                                        (1024, V.VecSimMetric_Cosine)])
+def test_concurrent_callers_on_an_int8_shadow_index_share_two_stage_passes(dim, metric, knobs):
+    """FLOAT32 index created with shadow8: concurrent K <= 16 callers share multi-query passes over the int8 shadow
+    (scan_mq_i8_kernel + the batched form of the two-stage filter + exact re-scoring); the replies equal those of a plain
+    index without a shadow, bit for bit; a K = 100 caller in the mix is answered on the single path."""
+    lib = V.load()
+    n = 300_000                                         # >= 2^18: the two-stage path's own threshold
+    qs = _queries(V.VecSimType_FLOAT32, dim, 40)
+    ks = [(10, 1, 16, 10, 5)[i % 5] for i in range(len(qs))]
+    orders = [V.BY_ID if i % 7 == 0 else V.BY_SCORE for i in range(len(qs))]
+    plain = _index(V.VecSimType_FLOAT32, dim, metric, n)
+    try:
+        knobs("coalesce", 0)
+        want = [plain.topk_query(q, k).results() for q, k in zip(qs, ks)]
+        want100 = plain.topk_query(qs[0], 100).results()
+    finally:
+        plain.free()
+    lib.RSGPU_SetTuning(b"shadow8", 1)          # (two_stage, the query-time switch, is on by default)
+    try:
+        idx = _index(V.VecSimType_FLOAT32, dim, metric, n)
+    finally:
+        lib.RSGPU_SetTuning(b"shadow8", 0)
+    try:
+        knobs("coalesce", 1)
+        knobs("coalesce_min_mib", 0)
+        V.coalesce_stats(reset=True)
+        lib.RSGPU_ResetTwoStageStats()
+        errors = _hammer(idx, qs, ks, want, 8, 5, orders)
+        assert not errors, errors[:3]
+        st, ts = V.coalesce_stats(), V.two_stage_stats()
+        assert st["queries"] == 40 * 5
+        assert st["mq_passes"] > 0 and st["mq_queries"] > st["mq_passes"], st
+        assert ts["two_stage"] >= st["mq_queries"] - st["mq_redo"] and ts["fallbacks"] == 0, (ts, st)
+        # K above the multi-query form's limit: coalesced with nobody, same answer
+        ids, sc = idx.topk_query(qs[0], 100).results()
+        assert ids.tolist() == want100[0].tolist() and sc.tolist() == want100[1].tolist()
+        # ... and with the multi-query form switched off the callers still get their answers (one two-stage scan each)
+        knobs("coalesce_shadow8", 0)
+        V.coalesce_stats(reset=True)
+        assert not _hammer(idx, qs, ks, want, 4, 1, orders)
+        assert V.coalesce_stats()["mq_passes"] == 0
     finally:
         idx.free()
 
