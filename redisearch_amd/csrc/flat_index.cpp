@@ -1142,7 +1142,7 @@ static void sort_reply(VecSimQueryReply *r, VecSimQueryReply_Order order) {
 // concurrent streams serve concurrent callers better), row shapes the multi-query kernel has, single-value indexes with
 // 32-bit keys, and no two-stage shadow in use (that path has its own, four times cheaper, scan).
 bool FlatIndex::mq_capable(size_t k) const {
-  if (multi || key_bytes != 4 || !k || k > 1024) return false;
+  if (!k || k > 1024) return false;
   if ((shadow_ == 1 || shadow_ == 2) && scan_tuning().two_stage) return false;
   return scan_mq_supported(ktype, kmetric, (uint32_t)(stride_ / 16));
 }
@@ -1279,22 +1279,37 @@ void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
 void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
   HIP_CHECK(hipSetDevice(device));
   CtxLease c(device);
-  c->ensure_mq(nj * stride_);
-  memset(c->h_mq_queries, 0, nj * stride_);
+  // INT8 / UINT8: every padded query is followed by its extra chunk {sum q^2, |q|} (as upload_query lays it out)
+  const bool int_type = type == VecSimType_INT8 || type == VecSimType_UINT8;
+  const size_t qstride = stride_ + (int_type ? 16 : 0);
+  const size_t kw = key_bytes / 4;  // u32 words per key
+  c->ensure_mq(nj * qstride);
+  memset(c->h_mq_queries, 0, nj * qstride);
   uint32_t kmax = 0;
   for (size_t b = 0; b < nj; b++) {
-    uint8_t *dst = c->h_mq_queries + b * stride_;
+    uint8_t *dst = c->h_mq_queries + b * qstride;
     memcpy(dst, jobs[b]->query, elem_bytes_);
     if (metric == VecSimMetric_Cosine) normalize_host(dst);
+    if (int_type) {
+      long long qq = 0;
+      for (size_t i = 0; i < dim; i++) {
+        const int a = type == VecSimType_INT8 ? (int)((const int8_t *)jobs[b]->query)[i] : (int)((const uint8_t *)jobs[b]->query)[i];
+        qq += (long long)a * a;
+      }
+      uint32_t extra[4] = {(uint32_t)qq, 0, 0, 0};
+      const float qn = sqrtf((float)qq);
+      memcpy(&extra[1], &qn, 4);
+      memcpy(dst + stride_, extra, 16);
+    }
     kmax = std::max<uint32_t>(kmax, (uint32_t)std::min<size_t>(jobs[b]->k, n));
   }
-  HIP_CHECK(hipMemcpyAsync(c->d_mq_queries, c->h_mq_queries, nj * stride_, hipMemcpyHostToDevice, c->stream));
+  HIP_CHECK(hipMemcpyAsync(c->d_mq_queries, c->h_mq_queries, nj * qstride, hipMemcpyHostToDevice, c->stream));
   const uint32_t ld = (uint32_t)round_up(n, 1024);
-  c->ensure_keys(nj * (size_t)ld);
+  c->ensure_keys(nj * (size_t)ld * kw);
   c->ensure_out(nj * (size_t)kmax);
   const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
   HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-  if (!launch_scan_mq(d_rows_, stride_, ktype, kmetric, 0, n, c->d_mq_queries, stride_, (uint32_t)nj, c->d_keys, ld, c->stream))
+  if (!launch_scan_mq(d_rows_, stride_, ktype, kmetric, 0, n, c->d_mq_queries, qstride, (uint32_t)nj, c->d_keys, ld, c->stream))
     throw std::runtime_error("multi-query scan refused a row shape the coalescer was gated on");
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(c->ev1, c->stream));
@@ -1303,11 +1318,12 @@ void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
   bool have[kMqMaxQueries] = {false};
   int mode = 0;
   uint32_t *out_keys32 = reinterpret_cast<uint32_t *>(c->h_out_keys);
-  if (scan_tuning().filter_select && kmax <= 1024 && n <= (1u << 15)) {
+  const bool batched_select = scan_tuning().filter_select && key_bytes == 4 && !multi;  // (the batched forms take 32-bit keys)
+  if (batched_select && kmax <= 1024 && n <= (1u << 15)) {
     mode = 1;
     for (size_t b = 0; b < nj; b++) c->h_mq_n[b] = 0;
     launch_batch_select_keys(c->d_keys, ld, n, kmax, (uint32_t)nj, c->h_out_rows, out_keys32, c->h_mq_n, kmax, c->stream);
-  } else if (scan_tuning().filter_select && kmax <= 32 && n >= (1u << 16)) {
+  } else if (batched_select && kmax <= 32 && n >= (1u << 16)) {
     mode = 2;
     for (size_t b = 0; b < nj; b++) c->h_mq_n[b] = c->h_mq_over[b] = 0;
     launch_sample_threshold_batch(c->d_keys, ld, n, 64, kmax, (uint32_t)nj, c->d_mq_tau, c->d_mq_cnt, c->stream);
@@ -1341,10 +1357,28 @@ void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
       have[b] = true;
     }
   }
+  if (multi) {
+    // multi-value: per query the walk of topk_locked over ITS key array -- batches in ascending composite order, the first
+    // occurrence of a label is its best vector
+    for (size_t b = 0; b < nj; b++) {
+      TopkJob *j = jobs[b];
+      std::vector<VecSimQueryResult> res;
+      const bool ok = multi_walk(c.c, c->d_keys + b * (size_t)ld * kw, n, j->k, j->tctx, res);
+      if (!ok) {
+        j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+        continue;
+      }
+      VecSimQueryReply *r = new_reply(res.size(), VecSim_QueryReply_OK);
+      if (!res.empty()) memcpy(r->results, res.data(), res.size() * sizeof(VecSimQueryResult));
+      sort_reply(r, j->order);
+      j->reply = r;
+    }
+    return;
+  }
   for (size_t b = 0; b < nj; b++) {
     if (have[b]) continue;
     if (mode) coalesce_stats().mq_redo++;
-    radix_select(c.c, c->d_keys + b * (size_t)ld, 4, n, (uint32_t)std::min<size_t>(jobs[b]->k, n), Bound(), hits[b], nullptr);
+    radix_select(c.c, c->d_keys + b * (size_t)ld * kw, key_bytes, n, (uint32_t)std::min<size_t>(jobs[b]->k, n), Bound(), hits[b], nullptr);
   }
   for (size_t b = 0; b < nj; b++) {
     TopkJob *j = jobs[b];
@@ -1358,6 +1392,30 @@ void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
     sort_reply(r, j->order);
     j->reply = r;
   }
+}
+
+// multi-value top-K over one key array: batches in ascending composite (key, row) order, the first occurrence of a label is
+// its best vector.  false = the caller's timeout fired.
+bool FlatIndex::multi_walk(QueryCtx *c, const uint32_t *d_keys, uint32_t n, size_t k, void *tctx, std::vector<VecSimQueryResult> &res) {
+  std::unordered_map<uint64_t, char> seen;
+  std::vector<Hit> hits;
+  Bound lower;
+  uint32_t consumed = 0;
+  const size_t want = std::min<size_t>(k, n);
+  while (res.size() < want && consumed < n) {
+    const uint32_t ask = (uint32_t)std::min<size_t>(n - consumed, std::max<size_t>((want - res.size()) * 2, 16));
+    Bound bound;
+    radix_select(c, d_keys, key_bytes, n, ask, lower, hits, &bound);
+    if (hits.empty()) break;
+    consumed += (uint32_t)hits.size();
+    for (const Hit &h : hits) {
+      const uint64_t lab = label_at(h.row);
+      if (res.size() < want && seen.emplace(lab, 1).second) res.push_back(VecSimQueryResult{(size_t)lab, score_of(h.key)});
+    }
+    lower = bound;
+    if (timed_out(tctx)) return false;
+  }
+  return true;
 }
 
 // The two-stage exact scan (two_stage_topk, int8 shadow) for 2 .. 8 queries at once: one multi-query pass over the shadow
@@ -1481,24 +1539,7 @@ VecSimQueryReply *FlatIndex::topk_locked(const void *query, size_t k, void *tctx
     for (const Hit &h : hits) res.push_back(VecSimQueryResult{(size_t)label_at(h.row), score_of(h.key)});
   } else {
     // multi-value: walk batches in ascending composite order, first occurrence of a label is its best
-    std::unordered_map<uint64_t, char> seen;
-    Bound lower;
-    uint32_t consumed = 0;
-    size_t want = std::min<size_t>(k, n);
-    while (res.size() < want && consumed < n) {
-      uint32_t ask = (uint32_t)std::min<size_t>(n - consumed, std::max<size_t>((want - res.size()) * 2, 16));
-      Bound bound;
-      select(c.c, n, ask, lower, hits, &bound);
-      if (hits.empty()) break;
-      consumed += (uint32_t)hits.size();
-      for (const Hit &h : hits) {
-        uint64_t lab = label_at(h.row);
-        if (res.size() < want && seen.emplace(lab, 1).second)
-          res.push_back(VecSimQueryResult{(size_t)lab, score_of(h.key)});
-      }
-      lower = bound;
-      if (timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);
-    }
+    if (!multi_walk(c.c, c->d_keys, n, k, tctx, res)) return new_reply(0, VecSim_QueryReply_TimedOut);
   }
   VecSimQueryReply *r = new_reply(res.size(), VecSim_QueryReply_OK);
   if (!res.empty()) memcpy(r->results, res.data(), res.size() * sizeof(VecSimQueryResult));

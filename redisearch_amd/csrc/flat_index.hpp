@@ -301,6 +301,8 @@ class FlatIndex {
   // the single-query path; the caller holds the shared lock and has flushed
   VecSimQueryReply *topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order);
   void topk_pass_mq(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // >= 2 jobs, shared lock held
+  // multi-value top-K over one key array (key_bytes wide): false = the timeout callback fired
+  bool multi_walk(QueryCtx *c, const uint32_t *d_keys, uint32_t n, size_t k, void *tctx, std::vector<VecSimQueryResult> &res);
   // the same for indexes that carry the int8 shadow: ONE multi-query pass over the shadow (scan_mq_i8_kernel), the
   // two-stage scan's error-banded filter for every query at once, survivors re-scored from the fp32 rows
   void topk_pass_mq_shadow8(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // 2 .. 8 jobs, shared lock held

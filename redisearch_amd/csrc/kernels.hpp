@@ -64,6 +64,8 @@ struct ScanTuning {
   int coalesce_shadow8 = 1;  // coalesce concurrent K <= 16 queries on indexes that carry the int8 shadow into multi-query two-stage passes
   int mq16 = 1;            // multi-query scan: nine to sixteen FLOAT32 queries in ONE pass, queries in LDS (0 = two passes of up to
                            // eight, 2 = one pass with the queries in registers; A/B knob)
+  int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
+  int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
@@ -96,7 +98,9 @@ void launch_scan(const void *rows, size_t stride, uint32_t dim, int type, int me
 
 // Several queries per corpus pass (scan_mq_kernels.hip): keys[b * keys_ld + row] = the key launch_scan would write for
 // queries + b * qstride, bit for bit, b < nq <= kMqMaxQueries.  fp32 / fp16 / bf16 rows, IP or L2, rows of 512 B .. 4 KiB
-// in the single-query scan's 32- / 64-lane shapes; false (nothing launched) for anything else.
+// in the single-query scan's 32- / 64-lane shapes; INT8 / UINT8 rows (IP, L2, KM_COS) of 128 B .. 4 KiB, every query
+// followed by its extra chunk as for launch_scan (qstride >= stride + 16); FLOAT64 rows (IP, L2) up to 6 KiB with u64 keys
+// (keys_ld counts keys).  false (nothing launched) for anything else.
 constexpr uint32_t kMqMaxQueries = 16;
 // The same for the int8 shadow of a FLOAT32 index (rows of 256 / 512 / 768 / 1024 int8 elements, row_meta = {scale, |x|^2}
 // per row as for launch_scan's KM_IPS / KM_L2S; queries: nq int8 rows qstride bytes apart; qx[b] = {query scale, |q|^2}):
@@ -107,7 +111,7 @@ bool launch_scan_mq_i8(const void *rows, size_t stride, int metric, uint32_t row
                        hipStream_t s);
 bool scan_mq_supported(int type, int metric, uint32_t stride16);
 bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
-                    const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s);
+                    const void *queries, size_t qstride, uint32_t nq, void *keys, uint32_t keys_ld, hipStream_t s);
 const char *last_scan_mq_kernel_name(char *buf, size_t cap);
 
 // name of the kernel instantiation the last full scan of this process launched (template arguments + grid)

@@ -293,23 +293,38 @@ __device__ __forceinline__ bool decode_qint_fast(const CodecDesc &cd, const uint
 // 2: they are there, and a block is parsed by EIGHT lanes, 16 records each -- a lane's 100 records were the one serial chain
 // this kernel's time consists of (parse ~18 us of 25, whatever the list length: profiles/r03_decode.txt), a list is immutable
 // after upload, so the first decode of a list leaves the sync points behind for all later ones (8 bytes per 16 postings).
+struct DecodeArgs {  // one list's decode_blocks_kernel arguments (two of them: decode_blocks_pair_kernel)
+  CodecDesc cd;
+  const uint8_t *bytes;
+  const uint64_t *byte_off;
+  const uint32_t *first, *nent, *entry_off;
+  uint32_t n_blocks;
+  uint32_t *ids, *freqs, *masks, *wmasks, *off_pos, *off_len, *sync;
+  int sync_mode;
+  uint32_t lds_cap;
+};
+
 template <int KIND>
-__global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const uint8_t *__restrict__ bytes,
-                                                           const uint64_t *__restrict__ byte_off,
-                                                           const uint32_t *__restrict__ first,
-                                                           const uint32_t *__restrict__ nent,
-                                                           const uint32_t *__restrict__ entry_off, uint32_t n_blocks,
-                                                           uint32_t *__restrict__ ids, uint32_t *__restrict__ freqs,
-                                                           uint32_t *__restrict__ masks, uint32_t *__restrict__ wmasks,
-                                                           uint32_t *__restrict__ off_pos,
-                                                           uint32_t *__restrict__ off_len,
-                                                           uint32_t *__restrict__ sync, int sync_mode, uint32_t lds_cap) {
-  // lds_cap bytes of staging + 64 of slack (the parsers fetch whole words ahead); dynamic: with eight lanes per block a
-  // wavefront stages a few KiB, and 30 KiB each would leave five wavefronts per CU
-  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+__device__ __forceinline__ void decode_blocks_body(const DecodeArgs &A, uint32_t wg, uint8_t *stage) {
+  const CodecDesc cd = A.cd;
+  const uint8_t *__restrict__ bytes = A.bytes;
+  const uint64_t *__restrict__ byte_off = A.byte_off;
+  const uint32_t *__restrict__ first = A.first;
+  const uint32_t *__restrict__ nent = A.nent;
+  const uint32_t *__restrict__ entry_off = A.entry_off;
+  const uint32_t n_blocks = A.n_blocks;
+  uint32_t *__restrict__ ids = A.ids;
+  uint32_t *__restrict__ freqs = A.freqs;
+  uint32_t *__restrict__ masks = A.masks;
+  uint32_t *__restrict__ wmasks = A.wmasks;
+  uint32_t *__restrict__ off_pos = A.off_pos;
+  uint32_t *__restrict__ off_len = A.off_len;
+  uint32_t *__restrict__ sync = A.sync;
+  const int sync_mode = A.sync_mode;
+  const uint32_t lds_cap = A.lds_cap;
   const uint32_t lane = threadIdx.x;
   const uint32_t lpb = sync_mode == 2 ? kSyncPts + 1 : 1, bpw = 64 / lpb;  // lanes per block, blocks per wavefront
-  const uint32_t b0 = blockIdx.x * bpw;
+  const uint32_t b0 = wg * bpw;
   const uint32_t nb = n_blocks - b0 < bpw ? n_blocks - b0 : bpw;
   // every lane's block description in ONE memory round trip, before anything depends on it (the wavefront's byte range
   // is the first lane's start .. the last lane's end: no separate loads for it)
@@ -360,6 +375,23 @@ __global__ __launch_bounds__(64) void decode_blocks_kernel(CodecDesc cd, const u
   else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
     decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), my_n, my_first, my_out, ids, freqs, masks, wmasks, off_pos,
                            off_len, (uint32_t)beg);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void decode_blocks_kernel(DecodeArgs a) {
+  // lds_cap bytes of staging + 64 of slack (the parsers fetch whole words ahead); dynamic: with eight lanes per block a
+  // wavefront stages a few KiB, and 30 KiB each would leave five wavefronts per CU
+  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+  decode_blocks_body<KIND>(a, blockIdx.x, stage);
+}
+
+// Two lists, one launch (the lists of a query decoded per query -- cache_decoded = 0 -- cost ~7 us of fixed time per launch
+// next to 13-20 us of work each, profiles/r03_decode.txt): workgroups [0, wgs_a) take list a, the rest list b.
+template <int KIND>
+__global__ __launch_bounds__(64) void decode_blocks_pair_kernel(DecodeArgs a, DecodeArgs b, uint32_t wgs_a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+  if (blockIdx.x < wgs_a) decode_blocks_body<KIND>(a, blockIdx.x, stage);
+  else decode_blocks_body<KIND>(b, blockIdx.x - wgs_a, stage);
 }
 
 // One WAVEFRONT per block for the two record kinds whose boundaries need no parse from the block start: a varint delta
@@ -490,22 +522,31 @@ __device__ __forceinline__ uint32_t to_list_frame(uint32_t x, long long add, boo
 // binary search confined to the window.
 constexpr uint32_t kProbeWindow = 4096;  // u32 entries of the other list staged per workgroup (16 KiB)
 
+// DPT: drivers per thread.  A workgroup's chain is four dependent global round trips (the window's ends) + the staging + an
+// LDS search, and 2.5 M drivers in tiles of 256 are 9 766 such chains in ~5 rounds over the CUs (27 us, configs[4]); tiles of
+// 1 024 (DPT = 4, window of 8 Ki entries) amortise the chain over four times the drivers.
+template <int DPT>
 __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_t *__restrict__ flags,
                                                               uint32_t *__restrict__ pos,
                                                               uint32_t *__restrict__ block_counts) {
-  __shared__ uint32_t win[kProbeWindow];
+  constexpr uint32_t TILE = 256 * DPT, WIN = kProbeWindow * (DPT > 1 ? 2 : 1);
+  __shared__ uint32_t win[WIN];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t w_lo, w_hi;
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n0 = v.len[0];
-  const uint32_t i_first = blockIdx.x * 256, i_next = i_first + 256;
-  bool hit = i < n0;
-  const uint32_t xc = hit ? shared_id(v, 0, i) : 0u;  // shared frame
+  const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  bool hit[DPT];
+  uint32_t xc[DPT];  // shared frame
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = i_first + k * 256 + threadIdx.x;
+    hit[k] = i < n0;
+    xc[k] = hit[k] ? shared_id(v, 0, i) : 0u;
+  }
   for (int l = 1; l < v.n; l++) {
     const uint32_t *__restrict__ a = v.ids[l];
     const uint32_t nl = v.len[l];
-    bool under;
-    const uint32_t x = to_list_frame(xc, v.add[l], &under);  // this list's frame
     if (wave == 0) {
       bool u0;
       const uint32_t r = wave_lower_bound(a, nl, to_list_frame(shared_id(v, 0, i_first), v.add[l], &u0), lane);
@@ -519,37 +560,52 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
     const uint32_t lo = w_lo;
     const uint32_t hi = w_hi;  // every candidate x of this workgroup has lower_bound(x) in [lo, hi]; a[hi] > x
     const uint32_t span = hi - lo;
-    uint32_t p;
-    if (span <= kProbeWindow) {
+    if (span <= WIN) {
       for (uint32_t o = threadIdx.x; o < span; o += 256) win[o] = a[lo + o];
       __syncthreads();
-      uint32_t b = 0, e = span;
-      while (b < e) {
-        const uint32_t mid = b + ((e - b) >> 1);
-        if (win[mid] < x) b = mid + 1;
-        else e = mid;
-      }
-      p = lo + b;
-      const bool m = hit && !under && b < span && win[b] == x;
-      if (hit) pos[(size_t)(l - 1) * n0 + i] = p;
-      hit = m;
-    } else {
-      uint32_t b = lo, e = hi;
-      if (hit) {
+#pragma unroll
+      for (int k = 0; k < DPT; k++) {
+        const uint32_t i = i_first + k * 256 + threadIdx.x;
+        bool under;
+        const uint32_t x = to_list_frame(xc[k], v.add[l], &under);  // this list's frame
+        uint32_t b = 0, e = span;
         while (b < e) {
           const uint32_t mid = b + ((e - b) >> 1);
-          if (a[mid] < x) b = mid + 1;
+          if (win[mid] < x) b = mid + 1;
           else e = mid;
         }
-        pos[(size_t)(l - 1) * n0 + i] = b;
-        hit = !under && b < nl && a[b] == x;
+        const bool m = hit[k] && !under && b < span && win[b] == x;
+        if (hit[k]) pos[(size_t)(l - 1) * n0 + i] = lo + b;
+        hit[k] = m;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < DPT; k++) {
+        const uint32_t i = i_first + k * 256 + threadIdx.x;
+        bool under;
+        const uint32_t x = to_list_frame(xc[k], v.add[l], &under);
+        uint32_t b = lo, e = hi;
+        if (hit[k]) {
+          while (b < e) {
+            const uint32_t mid = b + ((e - b) >> 1);
+            if (a[mid] < x) b = mid + 1;
+            else e = mid;
+          }
+          pos[(size_t)(l - 1) * n0 + i] = b;
+          hit[k] = !under && b < nl && a[b] == x;
+        }
       }
     }
     __syncthreads();  // win / w_lo / w_hi are reused by the next list
   }
-  if (i < n0) flags[i] = hit ? 1 : 0;
-  unsigned long long m = __ballot(hit);
-  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = i_first + k * 256 + threadIdx.x;
+    if (i < n0) flags[i] = hit[k] ? 1 : 0;
+    cnt += (uint32_t)__popcll(__ballot(hit[k]));
+  }
+  if (lane == 0) wave_cnt[wave] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
 }
@@ -599,31 +655,45 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(uint32_t *__restrict_
   if (threadIdx.x == 0) total_out[0] = carry;
 }
 
+template <int DPT>
 __global__ __launch_bounds__(256) void intersect_write_kernel(ListView v, LeafMap lm, const uint8_t *__restrict__ flags,
                                                               const uint32_t *__restrict__ pos,
                                                               const uint32_t *__restrict__ block_off,
                                                               uint32_t *__restrict__ out_ids,
                                                               uint32_t *__restrict__ out_freqs, uint32_t cap,
                                                               uint32_t *__restrict__ out_epos) {
-  __shared__ uint32_t wave_cnt[4];
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  constexpr uint32_t TILE = 256 * DPT;  // (the probe's tile: block_off holds one exclusive prefix per tile)
+  __shared__ uint32_t wave_cnt[DPT][4];
   const uint32_t n0 = v.len[0];
-  const bool hit = i < n0 && flags[i];
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned long long m = __ballot(hit);
-  if (lane == 0) wave_cnt[w] = (uint32_t)__popcll(m);
+  bool hit[DPT];
+  unsigned long long m[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = blockIdx.x * TILE + k * 256 + threadIdx.x;
+    hit[k] = i < n0 && flags[i];
+    m[k] = __ballot(hit[k]);
+    if (lane == 0) wave_cnt[k][w] = (uint32_t)__popcll(m[k]);
+  }
   __syncthreads();
-  if (!hit) return;
-  uint32_t off = block_off[blockIdx.x];
-  for (uint32_t j = 0; j < w; j++) off += wave_cnt[j];
-  off += (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-  out_ids[off] = shared_id(v, 0, i);
-  for (int l = 0; l < lm.n_leaves; l++) {
-    const uint32_t t = lm.leaf_list[l];
-    const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];  // the hit's position in list t
-    // (a codec that stores no frequency yields the term record's default, 1: reference index_result/src/core/mod.rs:192-197)
-    if (out_freqs) out_freqs[(size_t)l * cap + off] = lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 1u;
-    if (out_epos) out_epos[(size_t)l * cap + off] = lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
+  uint32_t run = block_off[blockIdx.x];  // hits before slice k of this tile
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    if (hit[k]) {
+      const uint32_t i = blockIdx.x * TILE + k * 256 + threadIdx.x;
+      uint32_t off = run;
+      for (uint32_t j = 0; j < w; j++) off += wave_cnt[k][j];
+      off += (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
+      out_ids[off] = shared_id(v, 0, i);
+      for (int l = 0; l < lm.n_leaves; l++) {
+        const uint32_t t = lm.leaf_list[l];
+        const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];  // the hit's position in list t
+        // (a codec that stores no frequency yields the term record's default, 1: reference index_result/src/core/mod.rs:192-197)
+        if (out_freqs) out_freqs[(size_t)l * cap + off] = lm.leaf_freq[l] ? lm.leaf_freq[l][p] : 1u;
+        if (out_epos) out_epos[(size_t)l * cap + off] = lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
+      }
+    }
+    run += wave_cnt[k][0] + wave_cnt[k][1] + wave_cnt[k][2] + wave_cnt[k][3];
   }
 }
 
@@ -1376,23 +1446,31 @@ bool decode_sync_supported(const CodecDesc &cd) { return cd.kind == 0 && !cd.wid
 size_t decode_sync_words(uint32_t n_blocks) { return (size_t)n_blocks * kSyncPts * 2; }
 uint32_t decode_sync_blocks_per_wave() { return 64 / (kSyncPts + 1); }
 
-void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
-                          const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
-                          uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
-                          uint32_t *off_len, uint32_t *sync, int sync_mode, uint32_t sync_span) {
-  if (!n_blocks) return;
+// sync_mode after the rules of the kernel + the staging size that goes with it
+static int decode_mode(const CodecDesc &cd, const uint32_t *sync, const uint32_t *wmasks, int sync_mode, uint32_t sync_span,
+                       uint32_t *lds_cap) {
   if (!sync || !decode_sync_supported(cd) || wmasks) sync_mode = 0;
   // sync_mode 2: eight lanes per block.  Only layouts the staged fast parsers take may use it: a block whose wavefront
   // does not fit the staging buffer falls to the generic loop, which parses whole blocks -- 8 blocks of <= 100 records
   // of <= 17 bytes + offsets always fit unless the offsets are huge, and then every lane would redo the block: keep to
   // one lane per block for lists with inline offsets.
   if (sync_mode == 2 && cd.osz >= 0) sync_mode = 0;
-  const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : 64;
   // staging bytes: everything a wavefront of sync_mode 2 can need (the caller knows the widest 8-block span), else 30 KiB
-  const uint32_t lds_cap = sync_mode == 2 && sync_span && sync_span < kDecodeLds ? ((sync_span + 255u) & ~255u) : kDecodeLds;
-#define RSGPU_DECODE(K)                                                                                            \
-  hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + bpw - 1) / bpw), dim3(64), lds_cap + 64, s, cd, bytes, byte_off, \
-                     first, nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len, sync, sync_mode, lds_cap)
+  *lds_cap = sync_mode == 2 && sync_span && sync_span < kDecodeLds ? ((sync_span + 255u) & ~255u) : kDecodeLds;
+  return sync_mode;
+}
+
+void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
+                          const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
+                          uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
+                          uint32_t *off_len, uint32_t *sync, int sync_mode, uint32_t sync_span) {
+  if (!n_blocks) return;
+  uint32_t lds_cap;
+  sync_mode = decode_mode(cd, sync, wmasks, sync_mode, sync_span, &lds_cap);
+  const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : 64;
+  const DecodeArgs a{cd, bytes, byte_off, first, nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len, sync,
+                     sync_mode, lds_cap};
+#define RSGPU_DECODE(K) hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + bpw - 1) / bpw), dim3(64), lds_cap + 64, s, a)
   // varint / raw deltas without a wide mask: one wavefront per block (decode_blocks_wave_kernel)
   const bool wave = (cd.kind == 1 || cd.kind == 2) && !cd.wide && !wmasks && !off_pos;
   if (wave && cd.kind == 1)
@@ -1406,17 +1484,40 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
   else RSGPU_DECODE(2);
 #undef RSGPU_DECODE
 }
-void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s) {
-  hipLaunchKernelGGL(intersect_probe_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_counts);
+
+bool launch_decode_blocks_pair(const DecodeListArgs &x, const DecodeListArgs &y, hipStream_t s) {
+  if (!x.n_blocks || !y.n_blocks || x.cd.kind != 0 || y.cd.kind != 0 || x.wmasks || y.wmasks) return false;
+  uint32_t cap_x, cap_y;
+  const int mx = decode_mode(x.cd, x.sync, x.wmasks, x.sync_mode, x.sync_span, &cap_x);
+  const int my = decode_mode(y.cd, y.sync, y.wmasks, y.sync_mode, y.sync_span, &cap_y);
+  const uint32_t bpw_x = mx == 2 ? 64 / (kSyncPts + 1) : 64, bpw_y = my == 2 ? 64 / (kSyncPts + 1) : 64;
+  const uint32_t wgs_x = (x.n_blocks + bpw_x - 1) / bpw_x, wgs_y = (y.n_blocks + bpw_y - 1) / bpw_y;
+  const DecodeArgs a{x.cd, x.bytes, x.byte_off, x.first, x.nent, x.entry_off, x.n_blocks, x.ids, x.freqs, x.masks, nullptr,
+                     x.off_pos, x.off_len, x.sync, mx, cap_x};
+  const DecodeArgs b{y.cd, y.bytes, y.byte_off, y.first, y.nent, y.entry_off, y.n_blocks, y.ids, y.freqs, y.masks, nullptr,
+                     y.off_pos, y.off_len, y.sync, my, cap_y};
+  const uint32_t lds = (cap_x > cap_y ? cap_x : cap_y) + 64;
+  hipLaunchKernelGGL(decode_blocks_pair_kernel<0>, dim3(wgs_x + wgs_y), dim3(64), lds, s, a, b, wgs_x);
+  return true;
+}
+void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s, int dpt) {
+  if (dpt == 4)
+    hipLaunchKernelGGL(intersect_probe_kernel<4>, dim3((v.len[0] + 1023) / 1024), dim3(256), 0, s, v, flags, pos, block_counts);
+  else
+    hipLaunchKernelGGL(intersect_probe_kernel<1>, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, flags, pos, block_counts);
 }
 void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s) {
   hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, s, block_counts, nb, total_out);
 }
 void launch_intersect_write(const ListView &v, const LeafMap &m, const uint8_t *flags, const uint32_t *pos,
                             const uint32_t *block_off, uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
-                            uint32_t *out_epos) {
-  hipLaunchKernelGGL(intersect_write_kernel, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, m, flags, pos, block_off,
-                     out_ids, out_freqs, cap, out_epos);
+                            uint32_t *out_epos, int dpt) {
+  if (dpt == 4)
+    hipLaunchKernelGGL(intersect_write_kernel<4>, dim3((v.len[0] + 1023) / 1024), dim3(256), 0, s, v, m, flags, pos, block_off,
+                       out_ids, out_freqs, cap, out_epos);
+  else
+    hipLaunchKernelGGL(intersect_write_kernel<1>, dim3(blocks_for(v.len[0])), dim3(256), 0, s, v, m, flags, pos, block_off,
+                       out_ids, out_freqs, cap, out_epos);
 }
 void launch_prox_filter(const ProxParams &p, const OffsetView &o, const LeafMap &m, uint32_t n0, const uint32_t *pos,
                         uint8_t *flags, uint32_t *block_counts, hipStream_t s) {

@@ -73,11 +73,11 @@ struct MqRed {
 #pragma unroll
       for (int i = 0; i < H; i++) {
         const T a = v[i], b = v[i + H];
-        if constexpr (M == 32) {
+        if constexpr (M == 32 && sizeof(T) == 4) {
           // a' = {a.lo32, b.lo32}, b' = {a.hi32, b.hi32}: lanes < 32 get a[l] + a[l+32], lanes >= 32 b[l-32] + b[l]
           const u2v r = __builtin_amdgcn_permlane32_swap(as_bits(a), as_bits(b), false, false);
           v[i] = from_bits<T>(r.x) + from_bits<T>(r.y);
-        } else if constexpr (M == 16) {
+        } else if constexpr (M == 16 && sizeof(T) == 4) {
           // odd 16-lane rows of a <-> even rows of b: even rows get a[l] + a[l+16], odd rows b[l-16] + b[l]
           const u2v r = __builtin_amdgcn_permlane16_swap(as_bits(a), as_bits(b), false, false);
           v[i] = from_bits<T>(r.x) + from_bits<T>(r.y);
@@ -411,6 +411,163 @@ __global__ __launch_bounds__(256, 2) void scan_mq_i8_kernel(const u4 *__restrict
   }
 }
 
+// ---- INT8 / UINT8 and FLOAT64 rows (round 3: the rest of the element types) --------------------------------------------
+// Integer rows: the sums of v_dot4 products are exact integers whatever the order, so the keys are scan_kernel's as soon as
+// the SAME integers go through the SAME finish<>().  A row needs sum x.q per query and -- L2, cosine -- sum x.x once; the
+// query's extra chunk {sum q^2, |q|} (FlatIndex::upload_query) sits behind every padded query and is kept in LDS.
+template <int G>
+__device__ __forceinline__ int group_reduce_i(int v) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int TYPE, int METRIC, int G, int ITERS, int U, int B, bool EXACT>
+__global__ __launch_bounds__(256, 2) void scan_mq_int_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t chunks,
+                                                             uint32_t row_begin, uint32_t row_end,
+                                                             const u4 *__restrict__ queries, uint32_t qstride16, uint32_t nq,
+                                                             uint32_t *__restrict__ keys, uint32_t keys_ld) {
+  constexpr int GPB = 256 / G;
+  constexpr int V = U * B, LG = ilog2(G), LV = ilog2(V);
+  constexpr int H = LV < LG ? LV : LG;
+  constexpr int CNT = V >> H;
+  constexpr bool NEED_XX = METRIC == KM_L2 || METRIC == KM_COS;
+  __shared__ u4 qxs[B];
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t grp = threadIdx.x / G;
+  if (threadIdx.x < B) qxs[threadIdx.x] = queries[(size_t)(threadIdx.x < nq ? threadIdx.x : nq - 1) * qstride16 + chunks];
+  u4 q[B][ITERS];
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    const uint32_t bb = (uint32_t)b < nq ? (uint32_t)b : nq - 1;  // unused slots repeat the last query, never stored
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) q[b][i] = load_chunk<EXACT, false>(queries + (size_t)bb * qstride16, lane + i * G, chunks);
+  }
+  __syncthreads();
+
+  constexpr bool INTERLEAVE = G < 64;  // (row <-> group mapping of scan_kernel)
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  const uint32_t tile0 = INTERLEAVE ? blockIdx.x : blockIdx.x * GPB + grp;
+  const uint32_t tile_step = INTERLEAVE ? gridDim.x : gridDim.x * GPB;
+  const uint32_t u_stride = INTERLEAVE ? GPB : 1;
+  const uint32_t jtop = lane >> (LG - H);
+  const bool writer = (lane & ((1u << (LG - H)) - 1u)) == 0;
+
+  for (uint32_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + (INTERLEAVE ? grp : 0);
+    u4 x[U][ITERS];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * u_stride;
+      if (r >= row_end) r = row_end - 1;  // clamp: recomputed, never stored
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[u][i] = load_chunk<EXACT, true>(p, lane + i * G, chunks);
+    }
+    int v[V], xx[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        int acc = 0;
+#pragma unroll
+        for (int i = 0; i < ITERS; i++) {
+          acc = dot4<TYPE>(x[u][i].x, q[b][i].x, acc);
+          acc = dot4<TYPE>(x[u][i].y, q[b][i].y, acc);
+          acc = dot4<TYPE>(x[u][i].z, q[b][i].z, acc);
+          acc = dot4<TYPE>(x[u][i].w, q[b][i].w, acc);
+        }
+        v[b * U + u] = acc;
+      }
+      int a = 0;
+      if constexpr (NEED_XX) {
+#pragma unroll
+        for (int i = 0; i < ITERS; i++) {
+          a = dot4<TYPE>(x[u][i].x, x[u][i].x, a);
+          a = dot4<TYPE>(x[u][i].y, x[u][i].y, a);
+          a = dot4<TYPE>(x[u][i].z, x[u][i].z, a);
+          a = dot4<TYPE>(x[u][i].w, x[u][i].w, a);
+        }
+        a = group_reduce_i<G>(a);
+      }
+      xx[u] = a;
+    }
+    if constexpr (G > 1) MqRed<G / 2, V, int>::run(v, lane);
+#pragma unroll
+    for (int p = 0; p < CNT; p++) {
+      const uint32_t j = jtop * CNT + p, b = j / U, u = j % U;
+      const uint32_t r = r0 + u * u_stride;
+      int xxu = xx[0];
+#pragma unroll
+      for (int uu = 1; uu < U; uu++) xxu = u == (uint32_t)uu ? xx[uu] : xxu;  // (no dynamic register indexing)
+      if (writer && b < nq && r < row_end) keys[(size_t)b * keys_ld + r] = to_key(finish<TYPE, METRIC>(I2{v[p], xxu}, qxs[b]));
+    }
+  }
+}
+
+// FLOAT64 rows: fp64 partial sums in scan_kernel's per-lane order, the halving butterfly on doubles (plain shuffles: the
+// 32-bit lane swaps do not apply), 64-bit keys -- one array of keys_ld u64 per query.
+template <int METRIC, int G, int ITERS, int U, int B, bool EXACT>
+__global__ __launch_bounds__(256, 2) void scan_mq_f64_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t chunks,
+                                                             uint32_t row_begin, uint32_t row_end,
+                                                             const u4 *__restrict__ queries, uint32_t qstride16, uint32_t nq,
+                                                             uint64_t *__restrict__ keys, uint32_t keys_ld) {
+  constexpr int GPB = 256 / G;
+  constexpr int V = U * B, LG = ilog2(G), LV = ilog2(V);
+  constexpr int H = LV < LG ? LV : LG;
+  constexpr int CNT = V >> H;
+  const uint32_t lane = threadIdx.x % G;
+  const uint32_t grp = threadIdx.x / G;
+  u4 q[B][ITERS];
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    const uint32_t bb = (uint32_t)b < nq ? (uint32_t)b : nq - 1;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) q[b][i] = load_chunk<EXACT, false>(queries + (size_t)bb * qstride16, lane + i * G, chunks);
+  }
+  constexpr bool INTERLEAVE = G < 64;
+  const uint32_t n = row_end - row_begin;
+  const uint32_t rows_per_step = INTERLEAVE ? GPB * U : U;
+  const uint32_t n_tiles = (n + rows_per_step - 1) / rows_per_step;
+  const uint32_t tile0 = INTERLEAVE ? blockIdx.x : blockIdx.x * GPB + grp;
+  const uint32_t tile_step = INTERLEAVE ? gridDim.x : gridDim.x * GPB;
+  const uint32_t u_stride = INTERLEAVE ? GPB : 1;
+  const uint32_t jtop = lane >> (LG - H);
+  const bool writer = (lane & ((1u << (LG - H)) - 1u)) == 0;
+
+  for (uint32_t tile = tile0; tile < n_tiles; tile += tile_step) {
+    const uint32_t r0 = row_begin + tile * rows_per_step + (INTERLEAVE ? grp : 0);
+    u4 x[U][ITERS];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      uint32_t r = r0 + u * u_stride;
+      if (r >= row_end) r = row_end - 1;
+      const u4 *p = rows + (size_t)r * stride16;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[u][i] = load_chunk<EXACT, true>(p, lane + i * G, chunks);
+    }
+    double v[V];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < ITERS; i++) acc = Op<KT_F64, METRIC>::add(acc, x[u][i], q[b][i]);
+        v[b * U + u] = acc;
+      }
+    if constexpr (G > 1) MqRed<G / 2, V, double>::run(v, lane);
+#pragma unroll
+    for (int p = 0; p < CNT; p++) {
+      const uint32_t j = jtop * CNT + p, b = j / U, u = j % U;
+      const uint32_t r = r0 + u * u_stride;
+      if (writer && b < nq && r < row_end) keys[(size_t)b * keys_ld + r] = to_key(finish<KT_F64, METRIC>(v[p], zero4()));
+    }
+  }
+}
+
 std::atomic<uint64_t> g_last_mq{0};
 
 struct MqCtx {
@@ -531,30 +688,159 @@ bool mq_launch_shape(const MqCtx &c) {
   return false;
 }
 
+// ---- launches of the integer / FLOAT64 kernels: eight (four) queries per launch, further queries in further launches ----
+template <int G, int U>
+uint32_t mq_grid(const MqCtx &c) {
+  const ScanTuning &t = scan_tuning();
+  constexpr int GPB = 256 / G;
+  const uint32_t n = c.row_end - c.row_begin;
+  const uint32_t need = G < 64 ? (n + GPB * U - 1) / (GPB * U) : ((n + U - 1) / U + GPB - 1) / GPB;
+  const uint32_t cap = (uint32_t)(t.num_cus * (t.mq_blocks_per_cu > 0 ? t.mq_blocks_per_cu : 8));
+  return need < cap ? need : cap;
+}
+
+template <int TYPE, int METRIC, int G, int ITERS, int U>
+void mq_launch_int(const MqCtx &c) {
+  constexpr int B = 8;
+  if (c.nq > (uint32_t)B) {
+    MqCtx lo = c, hi = c;
+    lo.nq = B;
+    hi.nq = c.nq - B;
+    hi.queries = c.queries + B * (size_t)c.qstride16;
+    hi.keys = c.keys + B * (size_t)c.keys_ld;
+    mq_launch_int<TYPE, METRIC, G, ITERS, U>(lo);
+    mq_launch_int<TYPE, METRIC, G, ITERS, U>(hi);
+    return;
+  }
+  const uint32_t grid = mq_grid<G, U>(c);
+  if (!grid) return;
+  const bool exact = c.chunks == (uint32_t)(G * ITERS);
+  g_last_mq = (uint64_t)TYPE | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
+              ((uint64_t)B << 21) | ((uint64_t)exact << 26) | ((uint64_t)2 << 28) | ((uint64_t)grid << 41);
+  if (exact)
+    hipLaunchKernelGGL((scan_mq_int_kernel<TYPE, METRIC, G, ITERS, U, B, true>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
+                       c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+  else
+    hipLaunchKernelGGL((scan_mq_int_kernel<TYPE, METRIC, G, ITERS, U, B, false>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16,
+                       c.chunks, c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, c.keys, c.keys_ld);
+}
+
+template <int TYPE, int METRIC>
+bool mq_launch_shape_int(const MqCtx &c) {
+  const Shape sh = pick_shape(c.chunks);
+  if (sh.ITERS == 1) {
+    switch (sh.G) {
+      case 8: mq_launch_int<TYPE, METRIC, 8, 1, 4>(c); return true;
+      case 16: mq_launch_int<TYPE, METRIC, 16, 1, 4>(c); return true;
+      case 32: mq_launch_int<TYPE, METRIC, 32, 1, 4>(c); return true;
+      case 64: mq_launch_int<TYPE, METRIC, 64, 1, 4>(c); return true;
+      default: return false;
+    }
+  }
+  if (sh.G == 16 && sh.ITERS == 3) { mq_launch_int<TYPE, METRIC, 16, 3, 4>(c); return true; }
+  if (sh.G == 32 && sh.ITERS == 3) { mq_launch_int<TYPE, METRIC, 32, 3, 4>(c); return true; }
+  if (sh.G == 64) {
+    switch (sh.ITERS) {
+      case 2: mq_launch_int<TYPE, METRIC, 64, 2, 4>(c); return true;
+      case 3: mq_launch_int<TYPE, METRIC, 64, 3, 2>(c); return true;
+      case 4: mq_launch_int<TYPE, METRIC, 64, 4, 2>(c); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+template <int METRIC, int G, int ITERS, int U>
+void mq_launch_f64(const MqCtx &c) {
+  constexpr int B = 4;
+  if (c.nq > (uint32_t)B) {
+    MqCtx lo = c, hi = c;
+    lo.nq = B;
+    hi.nq = c.nq - B;
+    hi.queries = c.queries + B * (size_t)c.qstride16;
+    hi.keys = c.keys + 2 * B * (size_t)c.keys_ld;  // (u32 words: the keys are 64 bits wide)
+    mq_launch_f64<METRIC, G, ITERS, U>(lo);
+    mq_launch_f64<METRIC, G, ITERS, U>(hi);
+    return;
+  }
+  const uint32_t grid = mq_grid<G, U>(c);
+  if (!grid) return;
+  const bool exact = c.chunks == (uint32_t)(G * ITERS);
+  g_last_mq = (uint64_t)KT_F64 | ((uint64_t)METRIC << 3) | ((uint64_t)G << 6) | ((uint64_t)ITERS << 13) | ((uint64_t)U << 17) |
+              ((uint64_t)B << 21) | ((uint64_t)exact << 26) | ((uint64_t)3 << 28) | ((uint64_t)grid << 41);
+  uint64_t *keys = reinterpret_cast<uint64_t *>(c.keys);
+  if (exact)
+    hipLaunchKernelGGL((scan_mq_f64_kernel<METRIC, G, ITERS, U, B, true>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16, c.chunks,
+                       c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, keys, c.keys_ld);
+  else
+    hipLaunchKernelGGL((scan_mq_f64_kernel<METRIC, G, ITERS, U, B, false>), dim3(grid), dim3(256), 0, c.s, c.rows, c.stride16, c.chunks,
+                       c.row_begin, c.row_end, c.queries, c.qstride16, c.nq, keys, c.keys_ld);
+}
+
+template <int METRIC>
+bool mq_launch_shape_f64(const MqCtx &c) {
+  const Shape sh = pick_shape(c.chunks);
+  if (sh.G == 32 && sh.ITERS == 1) { mq_launch_f64<METRIC, 32, 1, 4>(c); return true; }
+  if (sh.G == 32 && sh.ITERS == 3) { mq_launch_f64<METRIC, 32, 3, 4>(c); return true; }
+  if (sh.G == 64) {
+    switch (sh.ITERS) {
+      case 1: mq_launch_f64<METRIC, 64, 1, 4>(c); return true;
+      case 2: mq_launch_f64<METRIC, 64, 2, 4>(c); return true;
+      case 3: mq_launch_f64<METRIC, 64, 3, 2>(c); return true;
+      case 4: mq_launch_f64<METRIC, 64, 4, 2>(c); return true;
+      case 6: mq_launch_f64<METRIC, 64, 6, 2>(c); return true;
+      default: return false;
+    }
+  }
+  return false;
+}
+
+// which (G, ITERS) shapes the integer / FLOAT64 kernels are instantiated for (mirrors the two functions above)
+bool mq_int_shape(uint32_t stride16) {
+  const Shape sh = pick_shape(stride16);
+  if (sh.ITERS == 1) return sh.G >= 8 && sh.G <= 64;
+  return ((sh.G == 16 || sh.G == 32) && sh.ITERS == 3) || (sh.G == 64 && sh.ITERS >= 2 && sh.ITERS <= 4);
+}
+bool mq_f64_shape(uint32_t stride16) {
+  const Shape sh = pick_shape(stride16);
+  if (sh.G == 32) return sh.ITERS == 1 || sh.ITERS == 3;
+  return sh.G == 64 && (sh.ITERS == 1 || sh.ITERS == 2 || sh.ITERS == 3 || sh.ITERS == 4 || sh.ITERS == 6);
+}
+
 }  // namespace
 
 bool scan_mq_supported(int type, int metric, uint32_t stride16) {
-  if (type != KT_F32 && type != KT_F16 && type != KT_BF16) return false;
+  if (type == KT_I8 || type == KT_U8) return (metric == KM_IP || metric == KM_L2 || metric == KM_COS) && mq_int_shape(stride16);
   if (metric != KM_IP && metric != KM_L2) return false;
+  if (type == KT_F64) return mq_f64_shape(stride16);
+  if (type != KT_F32 && type != KT_F16 && type != KT_BF16) return false;
   const Shape sh = pick_shape(stride16);
   return (sh.G == 64 && sh.ITERS >= 1 && sh.ITERS <= 4) || (sh.G == 32 && (sh.ITERS == 1 || sh.ITERS == 3));
 }
 
 bool launch_scan_mq(const void *rows, size_t stride, int type, int metric, uint32_t row_begin, uint32_t row_end,
-                    const void *queries, size_t qstride, uint32_t nq, uint32_t *keys, uint32_t keys_ld, hipStream_t s) {
+                    const void *queries, size_t qstride, uint32_t nq, void *keys, uint32_t keys_ld, hipStream_t s) {
   if (row_end <= row_begin || !nq || nq > kMqMaxQueries || !scan_mq_supported(type, metric, (uint32_t)(stride / 16))) return false;
   const MqCtx c{(const u4 *)rows, (uint32_t)(stride / 16), (uint32_t)(stride / 16), row_begin, row_end,
-                (const u4 *)queries, (uint32_t)(qstride / 16), nq, keys, keys_ld, s};
+                (const u4 *)queries, (uint32_t)(qstride / 16), nq, (uint32_t *)keys, keys_ld, s};
 #define RSGPU_MQ_CASE(T)                                                \
   case T:                                                               \
     return metric == KM_L2 ? mq_launch_shape<T, KM_L2>(c) : mq_launch_shape<T, KM_IP>(c);
+#define RSGPU_MQ_CASE_INT(T)                                            \
+  case T:                                                               \
+    return metric == KM_L2 ? mq_launch_shape_int<T, KM_L2>(c)           \
+                           : (metric == KM_IP ? mq_launch_shape_int<T, KM_IP>(c) : mq_launch_shape_int<T, KM_COS>(c));
   switch (type) {
     RSGPU_MQ_CASE(KT_F32)
     RSGPU_MQ_CASE(KT_F16)
     RSGPU_MQ_CASE(KT_BF16)
+    RSGPU_MQ_CASE_INT(KT_I8)
+    RSGPU_MQ_CASE_INT(KT_U8)
+    case KT_F64: return metric == KM_L2 ? mq_launch_shape_f64<KM_L2>(c) : mq_launch_shape_f64<KM_IP>(c);
     default: return false;
   }
 #undef RSGPU_MQ_CASE
+#undef RSGPU_MQ_CASE_INT
 }
 
 bool scan_mq_i8_supported(uint32_t stride16) { return stride16 == 16 || stride16 == 32 || stride16 == 48 || stride16 == 64; }
@@ -596,7 +882,10 @@ const char *last_scan_mq_kernel_name(char *buf, size_t cap) {
     snprintf(buf, cap, "none");
     return buf;
   }
-  snprintf(buf, cap, "%s<%s,%s,G=%u,ITERS=%u,U=%u,B=%u,EXACT=%u> grid=%ux256", ((v >> 27) & 1) ? "scan_mq16_kernel" : "scan_mq_kernel", tn[v & 7], mn[(v >> 3) & 7],
+  const unsigned fam = (unsigned)((v >> 28) & 3);
+  snprintf(buf, cap, "%s<%s,%s,G=%u,ITERS=%u,U=%u,B=%u,EXACT=%u> grid=%ux256",
+           fam == 2 ? "scan_mq_int_kernel" : (fam == 3 ? "scan_mq_f64_kernel" : (((v >> 27) & 1) ? "scan_mq16_kernel" : "scan_mq_kernel")),
+           tn[v & 7], mn[(v >> 3) & 7],
            (unsigned)((v >> 6) & 127), (unsigned)((v >> 13) & 15), (unsigned)((v >> 17) & 15), (unsigned)((v >> 21) & 31),
            (unsigned)((v >> 26) & 1), (unsigned)(v >> 41));
   return buf;

@@ -287,6 +287,23 @@ static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
   if (cached) p->decoded.store(true, std::memory_order_release);
 }
 
+// Decode-per-query mode (cache_decoded = 0): two qint lists whose sync points are there go up in ONE launch (the fixed cost
+// of a launch is a third of a list's decode: profiles/r03_decode.txt).  false: not such a pair -- decode_on takes each.
+static bool decode_pair_on(RSGPU_Postings *p, RSGPU_Postings *q, QueryCtx *c) {
+  if (scan_tuning().cache_decoded || !scan_tuning().decode_sync || !scan_tuning().decode_pair || p == q) return false;
+  for (RSGPU_Postings *x : {p, q})
+    if (!x->sync.p || !x->sync_ready.load(std::memory_order_acquire) || !x->n_blocks || x->cd.kind != 0 || x->cd.wide) return false;
+  auto args = [](RSGPU_Postings *x) {
+    return DecodeListArgs{x->cd, x->bytes.p, x->byte_off.p, x->first.p, x->nent.p, x->entry_off.p, (uint32_t)x->n_blocks, x->ids.p,
+                          x->cd.freq >= 0 ? x->freqs.p : nullptr, x->cd.mask >= 0 ? x->masks.p : nullptr, nullptr,
+                          x->has_offsets() ? x->off_pos.p : nullptr, x->has_offsets() ? x->off_len.p : nullptr, x->sync.p, 2,
+                          x->sync_span};
+  };
+  const bool ok = launch_decode_blocks_pair(args(p), args(q), c->stream);
+  HIP_CHECK(hipGetLastError());
+  return ok;
+}
+
 namespace rsgpu {
 void release_search_pool() { DevPool::get().drain(); }
 }  // namespace rsgpu
@@ -451,19 +468,22 @@ static void combine_and(RSGPU_Hits *h, const std::vector<Source> &srcs, QueryCtx
   *total_out = 0;
   if (n0 == 0) return;
   *total_out = kCountPending;  // until scan_counts_kernel has written the real count (callers that poll instead of synchronising)
-  const uint32_t nb = (n0 + 255) / 256;
+  // long driving lists without a proximity filter (whose kernel re-counts per 256 drivers): tiles of 1 024 drivers
+  const bool prox = (max_slop >= 0 || in_order) && srcs.size() > 1 && h->with_offsets;
+  const int dpt = (!prox && scan_tuning().probe_dpt == 4 && n0 >= (1u << 18)) ? 4 : 1;
+  const uint32_t nb = (n0 + 256 * dpt - 1) / (256 * dpt);
   sc.flags.ensure(n0);
   sc.pos.ensure((size_t)n0 * std::max<size_t>(srcs.size() - 1, 1));
   sc.block_counts.ensure(nb);
-  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream);
-  if ((max_slop >= 0 || in_order) && srcs.size() > 1 && h->with_offsets) {
+  launch_intersect_probe(v, sc.flags.p, sc.pos.p, sc.block_counts.p, c->stream, dpt);
+  if (prox) {
     // Intersection::current_is_relevant (intersection.rs:205-215): a consensus document outside the window is dropped
     launch_prox_filter(tree_prox(h, max_slop, in_order), offset_view(h), m, n0, sc.pos.p, sc.flags.p, sc.block_counts.p,
                        c->stream);
   }
   launch_scan_counts(sc.block_counts.p, nb, total_out, c->stream);  // total_out: pinned host memory
   launch_intersect_write(v, m, sc.flags.p, sc.pos.p, sc.block_counts.p, h->ids.p, h->freqs.p, h->cap, c->stream,
-                         h->with_offsets ? h->epos.p : nullptr);
+                         h->with_offsets ? h->epos.p : nullptr, dpt);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -532,7 +552,10 @@ static void intersect_async(RSGPU_Hits *h, RSGPU_Postings *const *lists, size_t 
   // caller's order -- it is the order the terms must appear in
   if (!in_order)
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lists[a]->n_entries < lists[b]->n_entries; });
-  for (size_t l = 0; l < n_lists; l++) decode_on(lists[l], c);
+  for (size_t l = 0; l < n_lists; l++) {
+    if (l + 1 < n_lists && decode_pair_on(lists[l], lists[l + 1], c)) l++;
+    else decode_on(lists[l], c);
+  }
   std::vector<Source> srcs;
   for (size_t s = 0; s < n_lists; s++) srcs.push_back(term_source(lists[order[s]], order[s]));
   combine_and(h, srcs, c, sc, total_out, max_slop, in_order);

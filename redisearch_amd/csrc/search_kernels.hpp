@@ -27,6 +27,19 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr, uint32_t *sync = nullptr, int sync_mode = 0,
                           uint32_t sync_span = 0);  // sync_span: the widest byte range (16-byte aligned start) of
                                                     // decode_sync_blocks_per_wave() consecutive blocks, 0 = unknown
+// Two qint lists (kind 0, no wide masks) in ONE launch -- the same arguments as launch_decode_blocks, per list; false
+// (nothing launched) when a list is not of that kind or is empty.
+struct DecodeListArgs {
+  CodecDesc cd;
+  const uint8_t *bytes;
+  const uint64_t *byte_off;
+  const uint32_t *first, *nent, *entry_off;
+  uint32_t n_blocks;
+  uint32_t *ids, *freqs, *masks, *wmasks, *off_pos, *off_len, *sync;
+  int sync_mode;
+  uint32_t sync_span;
+};
+bool launch_decode_blocks_pair(const DecodeListArgs &a, const DecodeListArgs &b, hipStream_t s);
 // Sub-block sync points of the qint layouts (decode_sync_words(n_blocks) u32 per list): sync_mode 1 = this decode writes
 // them, 2 = they are valid and eight lanes share a block.  See postings_kernels.hip "sync".
 bool decode_sync_supported(const CodecDesc &cd);
@@ -58,14 +71,15 @@ struct LeafMap {
 };
 // probe: for every element of list 0, binary-search the other lists; flags[i]=1 on consensus,
 // pos[(l-1)*len0 + i] = match position in list l; block_counts[b] = hits in block b
-void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s);
+// dpt: drivers per thread -- 1 (tiles of 256 drivers, one block count each) or 4 (tiles of 1 024); probe and write must agree
+void launch_intersect_probe(const ListView &v, uint8_t *flags, uint32_t *pos, uint32_t *block_counts, hipStream_t s, int dpt = 1);
 // exclusive scan of block_counts[0..nb) in place, total -> total_out[0]
 void launch_scan_counts(uint32_t *block_counts, uint32_t nb, uint32_t *total_out, hipStream_t s);
 // ordered compaction: out_ids[h], out_freqs[leaf*cap + h]; out_epos[leaf*cap + h] (optional) = the hit's entry index in
 // the leaf's posting list
 void launch_intersect_write(const ListView &v, const LeafMap &m, const uint8_t *flags, const uint32_t *pos,
                             const uint32_t *block_off, uint32_t *out_ids, uint32_t *out_freqs, uint32_t cap, hipStream_t s,
-                            uint32_t *out_epos = nullptr);
+                            uint32_t *out_epos = nullptr, int dpt = 1);
 
 // ---- proximity over the term offsets (reference index_result/src/core/proximity.rs, index_result.c:51-103) ----------
 // Leaves are the hit list's term columns; a child of the aggregate is one leaf, or -- is_agg -- a union / intersection

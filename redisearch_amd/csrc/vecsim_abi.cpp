@@ -699,6 +699,8 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shard_replicas")) scan_tuning().shard_replicas = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
   else if (!strcmp(key, "decode_sync")) scan_tuning().decode_sync = value;
+  else if (!strcmp(key, "probe_dpt")) scan_tuning().probe_dpt = value;
+  else if (!strcmp(key, "decode_pair")) scan_tuning().decode_pair = value;
   else if (!strcmp(key, "mq16")) scan_tuning().mq16 = value;
   else if (!strcmp(key, "coalesce_shadow8")) scan_tuning().coalesce_shadow8 = value;
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;

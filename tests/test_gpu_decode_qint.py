@@ -148,3 +148,40 @@ def test_blocks_of_any_size_through_the_sync_points():
     finally:
         p.free()
         lib.RSGPU_SetTuning(b"cache_decoded", 1)
+
+
+@pytest.mark.parametrize("codecs", [(O.C_FREQS_ONLY, O.C_FREQS_ONLY), (O.C_FREQS_ONLY, O.C_FIELDS_ONLY),
+                                    (O.C_FREQS_ONLY, O.C_DOCIDS_ONLY), (O.C_FREQS_ONLY, O.C_FREQS_ONLY, O.C_FREQS_ONLY)])
+def test_the_lists_of_a_query_decoded_in_one_launch(codecs):
+    """decode-per-query mode: once their sync points are there, two qint lists of a query are decoded by ONE launch
+    (decode_blocks_pair_kernel; a third list, or a list of another record kind, keeps its own launch).  Same intersection --
+    ids and frequencies -- as the oracle's, query after query, with the pairing on and off."""
+    lib = V.load()
+    rng = np.random.default_rng(len(codecs) * 31 + sum(codecs))
+    lists = []
+    for j, codec in enumerate(codecs):
+        docs = np.unique(rng.integers(1, 300_000, 60_000 + 35_000 * j)).astype(np.uint64)
+        ii = O.InvertedIndex(codec)
+        if codec == O.C_FIELDS_ONLY:
+            for d in docs.tolist():
+                ii.add(d, 1, int(rng.integers(1, 1 << 20)))
+        else:
+            ii.add_many(docs, rng.integers(1, 70_000, docs.size).astype(np.uint32))
+        lists.append(ii)
+    oi, of, _ = O.intersect(lists)
+    try:
+        lib.RSGPU_SetTuning(b"cache_decoded", 0)
+        g = [S.Postings.from_flat(l.flatten()) for l in lists]
+        for pair in (1, 0, 1):
+            lib.RSGPU_SetTuning(b"decode_pair", pair)
+            for rep in range(3):     # (the first query of a list writes its sync points, one lane per block)
+                h = S.intersect(g)
+                gi, gf = h.read()
+                assert gi.tolist() == oi.tolist(), (pair, rep)
+                assert gf.tolist() == of.tolist(), (pair, rep)
+                h.free()
+        for p in g:
+            p.free()
+    finally:
+        lib.RSGPU_SetTuning(b"cache_decoded", 1)
+        lib.RSGPU_SetTuning(b"decode_pair", 1)

@@ -64,6 +64,41 @@ def test_windowed_intersection_probe_shapes(shape):
         assert n == 1
 
 
+@pytest.mark.parametrize("shape", ["balanced", "window_mix", "three_lists", "ragged_tail", "dense_equal"])
+@pytest.mark.parametrize("dpt", [4, 1])
+def test_wide_probe_tiles_on_long_driving_lists(shape, dpt):
+    """driving lists of >= 2^18 entries take tiles of 1 024 drivers (four per thread, a window of 8 Ki entries of the other
+    list in LDS): same hits and frequencies as the oracle and as the 256-driver tiles (knob probe_dpt = 1), on windows that
+    fit 4 Ki, fit only 8 Ki, overflow both, and on a last tile that is mostly empty"""
+    lib = V.load()
+    rng = np.random.default_rng(zlib.crc32(shape.encode()) % 1000)
+    if shape == "balanced":
+        ls = [np.unique(rng.integers(1, 6_000_000, 700_000)), np.unique(rng.integers(1, 6_000_000, 900_000))]
+    elif shape == "window_mix":      # 1 024 drivers span 40 960 entries (overflow), then 5 851 (8 Ki only), then 2 048
+        a = np.arange(1, 12_000_000, 40)
+        b = np.concatenate([np.arange(1, 3_000_000), np.arange(3_000_000, 8_000_000, 7), np.arange(8_000_000, 12_000_000, 20)])
+        ls = [a, b]
+    elif shape == "three_lists":
+        ls = [np.unique(rng.integers(1, 900_000, 450_000)), np.unique(rng.integers(1, 900_000, 500_000)),
+              np.unique(rng.integers(1, 900_000, 600_000))]
+    elif shape == "ragged_tail":     # 2^18 + 3 drivers: the last tile holds three
+        a = np.arange(10, 10 + 3 * ((1 << 18) + 3), 3)
+        b = np.unique(rng.integers(1, 800_000, 500_000))
+        ls = [a, b]
+    else:                            # the same list twice: every driver is a hit
+        a = np.unique(rng.integers(1, 2_000_000, 400_000))
+        ls = [a, a.copy()]
+    assert min(len(l) for l in ls) >= 1 << 18
+    lists_o = [postings(l, rng.integers(1, 9, len(l))) for l in ls]
+    assert lib.RSGPU_SetTuning(b"probe_dpt", dpt) == 0
+    try:
+        n = check_intersection(lists_o)
+    finally:
+        lib.RSGPU_SetTuning(b"probe_dpt", 4)
+    if shape == "dense_equal":
+        assert n == len(ls[0])
+
+
 def setup_hybrid(n_docs, n_vec, dim, seed, dfs):
     rng = np.random.default_rng(seed)
     lists_o = []
