@@ -64,7 +64,7 @@ struct ScanTuning {
   int coalesce_shadow8 = 1;  // coalesce concurrent K <= 16 queries on indexes that carry the int8 shadow into multi-query two-stage passes
   int mq16 = 1;            // multi-query scan: nine to sixteen FLOAT32 queries in ONE pass, queries in LDS (0 = two passes of up to
                            // eight, 2 = one pass with the queries in registers; A/B knob)
-  int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
+  int probe_dpt = 1;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM

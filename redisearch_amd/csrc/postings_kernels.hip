@@ -83,7 +83,8 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
                                                  uint32_t n, uint32_t f0, uint32_t out, uint32_t *__restrict__ ids,
                                                  uint32_t *__restrict__ freqs, uint32_t *__restrict__ masks,
                                                  uint32_t *__restrict__ wmasks, uint32_t *__restrict__ off_pos,
-                                                 uint32_t *__restrict__ off_len, uint32_t abs_base) {
+                                                 uint32_t *__restrict__ off_len, uint32_t abs_base,
+                                                 uint32_t *__restrict__ sync_w = nullptr, uint32_t pos0 = 0) {
   uint32_t base = f0;
   // Decoded fields are collected four records at a time and written with one 16-byte store per array: a lane's entries
   // are consecutive in the output arrays, those of its neighbours ~100 entries away, so a scalar store per record is 64
@@ -91,6 +92,12 @@ __device__ __forceinline__ void decode_one_block(const CodecDesc &cd, Bytes byte
   typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
   uint32_t b_id[4], b_fr[4], b_mk[4], b_op[4], b_ol[4];
   for (uint32_t e = 0; e < n && pos < fin; e++, out++) {
+    // (the sync points of a block this loop parses -- a wavefront whose 64 blocks did not fit the staging buffer: without
+    // them the eight lanes that share the block next time start from whatever the allocation held)
+    if (sync_w && e && (e & (kSyncSeg - 1)) == 0 && e / kSyncSeg <= kSyncPts) {
+      sync_w[2 * (e / kSyncSeg - 1)] = pos - pos0;
+      sync_w[2 * (e / kSyncSeg - 1) + 1] = base;
+    }
     uint32_t freq = 0, mask = 0, osz = 0;
     uint64_t mlo = 0, mhi = 0;
     if (KIND == 0) {
@@ -370,11 +377,11 @@ __device__ __forceinline__ void decode_blocks_body(const DecodeArgs &A, uint32_t
                          off_len, (uint32_t)w_beg, sync_w, pos0))
       return;
     decode_one_block<KIND>(cd, LdsBytes{stage}, pos0, (uint32_t)(fin - w_beg), my_n, my_first, my_out, ids, freqs, masks, wmasks,
-                           off_pos, off_len, (uint32_t)w_beg);
+                           off_pos, off_len, (uint32_t)w_beg, sync_w, pos0);
   }
   else  // positions relative to the block start stay below 2^32 (a block holds <= 1000 records)
     decode_one_block<KIND>(cd, bytes + beg, 0u, (uint32_t)(fin - beg), my_n, my_first, my_out, ids, freqs, masks, wmasks, off_pos,
-                           off_len, (uint32_t)beg);
+                           off_len, (uint32_t)beg, sync_w, 0u);
 }
 
 template <int KIND>

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--tuning", action="append", default=[])
     ap.add_argument("--ab", action="append", default=[], help="knob=v1,v2,...: repeat the measurement for each value, interleaved")
+    ap.add_argument("--variants", default="", help="k=v,k2=v2;k=v3,k2=v4: knob settings measured in turn, interleaved (several knobs per variant)")
     a = ap.parse_args()
     lib = V.load()
     for kv in a.tuning:
@@ -56,10 +57,16 @@ def main():
     for ab in a.ab:
         key, vals = ab.split("=")
         variants = [("%s=%s" % (key, v), key, int(v)) for v in vals.split(",")]
+    if a.variants:
+        variants = [(v, v, None) for v in a.variants.split(";")]
     res = {}
     for rep_outer in range(2):
         for name, key, val in variants:
-            if key:
+            if key and val is None:
+                for kv in key.split(","):
+                    k, x = kv.split("=")
+                    assert lib.RSGPU_SetTuning(k.encode(), int(x)) == 0, kv
+            elif key:
                 assert lib.RSGPU_SetTuning(key.encode(), val) == 0
             for nq in (4, 8, 12, 16):
                 idx.topk_batch(qs[:nq], a.k)

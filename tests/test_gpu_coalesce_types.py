@@ -151,7 +151,7 @@ def test_multi_value_shared_pass_against_the_oracle():
     try:
         for i in range(n):
             g.add_vector(data[i], int(labels[i]))
-            o.add_vector(data[i], int(labels[i]))
+            o.add(data[i], int(labels[i]))
         qs = rng.uniform(-1, 1, (5, dim)).astype(np.float32)
         ids, sc, cnt = g.topk_batch(qs, 25)
         for i, q in enumerate(qs):

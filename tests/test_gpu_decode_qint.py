@@ -72,6 +72,37 @@ def test_two_field_lists_decode_bit_for_bit_with_and_without_sync_points(codec, 
         lib.RSGPU_SetTuning(b"decode_sync", 1)
 
 
+@pytest.mark.parametrize("codec", [O.C_FREQS_ONLY, O.C_FIELDS_ONLY])
+def test_sync_points_of_wavefronts_that_do_not_fit_the_staging_buffer(codec):
+    """records of 6-7 bytes: 64 blocks of 100 are ~42 KiB, more than the 30 KiB a wavefront stages, so the FIRST decode of
+    the list parses every block straight from memory -- and still has to leave the sync points the later decodes (eight
+    lanes per block) start from (it did not: the lanes started from whatever the allocation held)"""
+    lib = V.load()
+    n = 20_011
+    rng = np.random.default_rng(77 + codec)
+    docs = np.cumsum(rng.integers(256, 60_000, n)).astype(np.uint64)
+    vals = rng.integers(1 << 24, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    ii = O.InvertedIndex(codec)
+    if codec == O.C_FREQS_ONLY:
+        ii.add_many(docs, vals)
+    else:
+        for d, v in zip(docs.tolist(), vals.tolist()):
+            ii.add(d, 1, v)
+    want = ii.decode_all()
+    try:
+        lib.RSGPU_SetTuning(b"cache_decoded", 0)
+        p = S.Postings.from_flat(ii.flatten())
+        try:
+            for rep in range(3):
+                ids, fr, mk = p.decode()
+                assert np.array_equal(ids, want[0]), (rep, "ids")
+                assert np.array_equal(fr if codec == O.C_FREQS_ONLY else mk, want[1 if codec == O.C_FREQS_ONLY else 2]), rep
+        finally:
+            p.free()
+    finally:
+        lib.RSGPU_SetTuning(b"cache_decoded", 1)
+
+
 def test_every_length_pair_at_every_alignment():
     """16 length pairs x 8 alignments of the record inside its 8-byte FIFO word: a list of 3-record blocks is not possible
     (blocks hold 100), so the pairs are cycled with a period coprime to 8 and the list is long enough to meet them all"""
