@@ -193,6 +193,10 @@ typedef struct {
   RSGPU_Hits **hits_out;        /* optional out: the hit list itself (caller frees); NULL = dropped */
 } RSGPU_HybridQueryArgs;
 int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
+/* how the calling thread's last RSGPU_HybridQuery ran: 0 = the staged pipeline (intersection written out, score / top-N and
+ * KNN branches on two streams), 1 = two launches (no hits_out, a flat AND of <= 4 term lists, top_n / k <= 32: one tile
+ * kernel -- probe, scores, distances, per-tile winners -- and one reduce kernel).  Same answers either way. */
+int RSGPU_HybridQueryPath(void);
 
 /* Union of 1..32 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
  * contributes freq 0 (reference rqe_iterators/src/union_flat.rs:223-257,297-320).  Scoring a union hit list

@@ -24,7 +24,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-
 
 # library name -> sources
 LIBS = {
-    "libVectorSimilarity.so": ["scan_kernels.hip", "scan_mq_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "fusion_kernels.hip", "postings_kernels.hip", "corpus_kernels.hip",
+    "libVectorSimilarity.so": ["scan_kernels.hip", "scan_mq_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "fusion_kernels.hip", "postings_kernels.hip", "hybrid_kernels.hip", "corpus_kernels.hip",
                                "flat_index.cpp", "grow_buffer.cpp", "batch_query.cpp", "sharded_index.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
 }
 
@@ -39,7 +39,7 @@ def _deps_mtime():
 
 
 # per-source extra flags: the scorers must not contract a*b+c behind the C source's back
-EXTRA = {"postings_kernels.hip": ["-ffp-contract=off"], "fusion_kernels.hip": ["-ffp-contract=off"]}
+EXTRA = {"postings_kernels.hip": ["-ffp-contract=off"], "hybrid_kernels.hip": ["-ffp-contract=off"], "fusion_kernels.hip": ["-ffp-contract=off"]}
 
 
 def _compile(src, force, hdr_m):

@@ -1,0 +1,468 @@
+// hybrid_kernels.hip -- a whole hybrid query (BASELINE configs[4]: text filter -> BM25 top-N next to an ad-hoc KNN top-k over
+// the documents the filter kept) in TWO launches (gfx950, hand-written HIP).
+//
+// The staged pipeline (postings_kernels.hip + the gather form of scan_kernel) spends a query in ten kernels of 5-27 us and the
+// launch gaps between them (profiles/r03_hybrid_one_pass.txt): probe -> scan -> ordered write -> [host reads the hit count]
+// -> score -> threshold -> filter -> fetch  ||  labels -> gather -> top-k.  None of the two answers needs the ordered hit
+// LIST -- only the caller that asked for it (hits_out) does.  Without it:
+//
+//   hybrid_tile_kernel    one workgroup per tile of 1 024 consecutive entries of the driving (shortest) list:
+//                           * the probe of intersect_probe_kernel -- the tile's window of every other list staged in LDS,
+//                             a binary search per driver -- with the match positions kept in registers;
+//                           * the score of every hit (score_one: the scorers of score_kernel, same bits) and the tile's
+//                             top-N by (descending score, ascending doc id) -- every hit counts the hits that beat it;
+//                           * the hits that have a vector, compacted in LDS, their distances -- Op<> / the reduction tree of
+//                             scan_kernel: the bits of the gather -- and the tile's top-k by (distance, doc id);
+//                           * per tile and at FIXED slots: hit count, N (score key, driver index), k (distance key, driver
+//                             index).  No atomics, no fences, no workgroup reads what another one wrote.
+//   hybrid_reduce_kernel  one workgroup of 1 024 per branch: the best entry of every thread's share of the tiles' lists, the
+//                         k-th of those as a bound, the entries at or below it ranked in LDS; the winners -- key, doc id --
+//                         and the hit count go to pinned host memory.  No tickets, no fences either.
+//
+// Exactness: the composites are total orders (the driver index is monotone in the doc id: ties break the way the staged
+// selections break them, by hit order), so "top-N of the per-tile top-Ns" IS the top-N.  Compiled with -ffp-contract=off
+// like postings_kernels.hip: a score has the bits score_kernel gives it; a distance the bits of scan_kernel<GATHER> (explicit
+// fmaf chains in scan_ops.hpp, nothing left to contract).
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "postings_ops.hpp"
+#include "search_kernels.hpp"
+
+namespace rsgpu {
+namespace {
+
+constexpr int kHybDpt = 4;                        // drivers per thread
+constexpr uint32_t kHybTile = 256 * kHybDpt;      // drivers per workgroup
+constexpr uint32_t kHybWin = 4096;                // u32 entries of another list staged per tile (16 KiB)
+constexpr uint32_t kHybMaxTiles = 16384;
+
+// (descending score, ascending driver index): key = ~d2key(score) ascending, then the index
+struct SKey {
+  uint64_t k;
+  uint32_t i;
+};
+__device__ __forceinline__ bool sk_less(const SKey &a, const SKey &b) { return a.k != b.k ? a.k < b.k : a.i < b.i; }
+__device__ __forceinline__ bool sk_same(const SKey &a, const SKey &b) { return a.k == b.k && a.i == b.i; }
+__device__ __forceinline__ SKey sk_none() { return SKey{~0ull, ~0u}; }  // (a real key is never ~0: ~d2key() of a NaN is 0)
+// (component by component: a select between two structs is a select between their ADDRESSES -- scratch memory)
+__device__ __forceinline__ SKey sk_min(const SKey &a, const SKey &b) {
+  const bool lt = sk_less(a, b);
+  return SKey{lt ? a.k : b.k, lt ? a.i : b.i};
+}
+__device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_reduce<G> with G at run time: the same tree
+  for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+template <int TYPE, int METRIC>
+__global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
+  constexpr int DPT = kHybDpt;
+  constexpr uint32_t TILE = kHybTile, WIN = kHybWin;
+  __shared__ __attribute__((aligned(16))) uint32_t win[WIN];  // probe: the window of the other list; afterwards the hits' keys | indices, then vrow | vidx | vkey
+  __shared__ u4 qs[kHybMaxChunks];   // the KNN query
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n0 = A.len[0];
+  const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  const uint32_t *__restrict__ ids0 = A.ids[0];
+
+  if (A.k)  // the query: in flight while the probe runs
+    for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
+
+  bool hit[DPT];
+  uint32_t xc[DPT];            // doc id in the frame the lists share
+  uint32_t ps[DPT][kHybMaxLists - 1];  // match position in list l
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = i_first + k * 256 + threadIdx.x;
+    hit[k] = i < n0;
+    xc[k] = hit[k] ? (uint32_t)((long long)ids0[i] + A.add[0]) : 0u;
+#pragma unroll
+    for (int l = 0; l < kHybMaxLists - 1; l++) ps[k][l] = 0;
+  }
+  const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
+  const uint32_t x_next = i_next < n0 ? (uint32_t)((long long)ids0[i_next] + A.add[0]) : 0u;
+
+  // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
+#pragma unroll
+  for (int l = 1; l < kHybMaxLists; l++) {
+    if (l < A.n) {
+      const uint32_t *__restrict__ a = A.ids[l];
+      const uint32_t nl = A.len[l];
+      const long long add = A.add[l];
+      if (wave == 0) {
+        bool u0;
+        const uint32_t r = wave_lower_bound(a, nl, to_list_frame(x_first, add, &u0), lane);
+        if (lane == 0) w_lo = r;
+      } else if (wave == 1) {
+        bool u1;
+        const uint32_t r = i_next < n0 ? wave_lower_bound(a, nl, to_list_frame(x_next, add, &u1), lane) : nl;
+        if (lane == 0) w_hi = r;
+      }
+      __syncthreads();
+      const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi]
+      const uint32_t span = hi - lo;
+      if (span <= WIN) {
+        // the window, eight loads per lane in flight at a time (a load / ds_write loop is serialised by hipcc)
+        for (uint32_t base = 0; base < span; base += 8 * 256) {
+          uint32_t t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            t[j] = a[lo + (o < span ? o : span - 1)];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            if (o < span) win[o] = t[j];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          bool under;
+          const uint32_t x = to_list_frame(xc[k], add, &under);
+          uint32_t b = 0, e = span;
+          while (b < e) {
+            const uint32_t mid = b + ((e - b) >> 1);
+            if (win[mid] < x) b = mid + 1;
+            else e = mid;
+          }
+          const bool m = hit[k] && !under && b < span && win[b] == x;
+          ps[k][l - 1] = lo + b;
+          hit[k] = m;
+        }
+      } else {  // a window that does not fit (very skewed lists): a binary search in memory, confined to the window
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          bool under;
+          const uint32_t x = to_list_frame(xc[k], add, &under);
+          uint32_t b = lo, e = hi;
+          if (hit[k]) {
+            while (b < e) {
+              const uint32_t mid = b + ((e - b) >> 1);
+              if (a[mid] < x) b = mid + 1;
+              else e = mid;
+            }
+            ps[k][l - 1] = b;
+            hit[k] = !under && b < nl && a[b] == x;
+          }
+        }
+      }
+      __syncthreads();  // win / w_lo / w_hi are reused
+    }
+  }
+  {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) cnt += (uint32_t)__popcll(__ballot(hit[k]));
+    if (lane == 0) wave_cnt[wave] = cnt;
+    if (threadIdx.x == 0) nv_sh = nh_sh = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) A.tile_hits[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+
+  // ---- branch A: score, the tile's top-N ----
+  // The hits (about a hundred of 1 024 drivers in configs[4]) are compacted first -- driver index and match positions into LDS --
+  // and scored DENSELY, one hit per lane: scoring where the hits sit (four slots per lane, a tenth of the lanes live) ran the
+  // fp64 scorer sixteen times per workgroup for the work of two wavefronts, and the kernel was bound by what it issued.
+  // Selection by RANK: every hit counts the hits that precede it in the total order, ranks below N are the list -- written
+  // straight to their slots.  (k rounds of a wave-wide arg-min per wave plus a merge were a serial chain of ~20 x 150
+  // dependent instructions.)
+  if (A.top_n) {
+    uint32_t *hidx = win;  // [TILE] driver index; then [TILE] position in list l at win + l * TILE, l = 1 .. n - 1
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      const unsigned long long m = __ballot(hit[k]);
+      if (m) {
+        uint32_t first = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == (uint32_t)leader) first = atomicAdd(&nh_sh, (uint32_t)__popcll(m));
+        first = __shfl(first, leader, 64);
+        if (hit[k]) {
+          const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          hidx[slot] = i_first + k * 256 + threadIdx.x;
+#pragma unroll
+          for (int l = 1; l < kHybMaxLists; l++)
+            if (l < A.n) win[l * TILE + slot] = ps[k][l - 1];
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nh = nh_sh;
+    uint64_t my_k[DPT];
+    uint32_t my_i[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      my_k[j] = ~0ull;
+      my_i[j] = ~0u;
+      if (e < nh) {
+        const uint32_t i = hidx[e];
+        const uint32_t x = (uint32_t)((long long)ids0[i] + A.add[0]);
+        // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
+        double fr[kHybMaxLists];
+        fr[0] = A.freq[0] ? (double)A.freq[0][i] : 1.0;
+#pragma unroll
+        for (int l = 1; l < kHybMaxLists; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[l * TILE + e]] : 1.0;
+        const long long tid = (long long)x + A.P.table_off;
+        const bool known = tid >= 0 && tid < (long long)A.table_n;
+        const uint32_t id = known ? (uint32_t)tid : 0u;
+        const float dscore = known ? A.doc_score[id] : 0.0f;
+        const uint32_t dlen = known ? A.doc_len[id] : 0u;
+        const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
+        auto F = [&](int t) { return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[3])); };
+        const double s = score_one<false>(A.P, F, dlen, dscore, mfreq, A.P.slop);
+        my_k[j] = ~d2key(s);
+        my_i[j] = i;
+      }
+    }
+    __syncthreads();  // every record has been read: keys | indices take their place
+    uint64_t *ek = reinterpret_cast<uint64_t *>(win);
+    uint32_t *ei = win + 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      if (e < nh) {
+        ek[e] = my_k[j];
+        ei[e] = my_i[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      if (e < nh) {
+        const SKey my{my_k[j], my_i[j]};
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < nh; o++) rank += sk_less(SKey{ek[o], ei[o]}, my) ? 1u : 0u;
+        if (rank < A.top_n) {
+          A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
+          A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
+        }
+      }
+    }
+    if (threadIdx.x >= nh && threadIdx.x < A.top_n) {  // fewer hits than slots
+      A.part_skey[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0ull;
+      A.part_sidx[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0u;
+    }
+    __syncthreads();  // the arrays are reused by branch B
+  }
+
+  // ---- branch B: the hits that have a vector, their distances, the tile's top-k ----
+  if (A.k) {
+    uint32_t *vrow = win, *vidx = win + TILE, *vkey = win + 2 * TILE;
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      const uint64_t id = A.ids_base + xc[k];
+      const bool has = hit[k] && id >= A.knn_base && id - A.knn_base < A.n_rows;
+      const unsigned long long m = __ballot(has);
+      if (m) {
+        uint32_t first = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == (uint32_t)leader) first = atomicAdd(&nv_sh, (uint32_t)__popcll(m));
+        first = __shfl(first, leader, 64);
+        if (has) {
+          const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          vrow[slot] = (uint32_t)(id - A.knn_base);
+          vidx[slot] = i_first + k * 256 + threadIdx.x;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nv = nv_sh;
+    const int G = A.G, ITERS = A.ITERS;
+    const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
+    const u4 *__restrict__ rows = reinterpret_cast<const u4 *>(A.rows);
+    // two rows per group and step, four chunks per row in flight: unconditional loads (from chunk 0 where the lane has none),
+    // the operations of scan_kernel in its order -- chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per
+    // chunk slot i < ITERS, then the butterfly
+    for (uint32_t j0 = grp; j0 < nv; j0 += 2 * GPB) {
+      const uint32_t j1 = j0 + GPB;
+      const bool two = j1 < nv;
+      const u4 *p0 = rows + (size_t)vrow[j0] * A.stride16, *p1 = rows + (size_t)vrow[two ? j1 : j0] * A.stride16;
+      float acc0 = 0.0f, acc1 = 0.0f;
+      for (int i0 = 0; i0 < ITERS; i0 += 4) {
+        u4 x0[4], x1[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t c = gl + (uint32_t)(i0 + u) * (uint32_t)G;
+          const bool ok = i0 + u < ITERS && c < A.chunks;
+          const uint32_t cc = ok ? c : 0u;
+          x0[u] = load16<false>(p0 + cc);
+          x1[u] = load16<false>(p1 + cc);
+          q[u] = qs[cc];
+          if (!ok) x0[u] = x1[u] = q[u] = zero4();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (i0 + u < ITERS) {
+            acc0 = Op<TYPE, METRIC>::add(acc0, x0[u], q[u]);
+            acc1 = Op<TYPE, METRIC>::add(acc1, x1[u], q[u]);
+          }
+      }
+      const float d0 = finish<TYPE, METRIC>(group_reduce_rt(acc0, G), zero4());
+      const float d1 = finish<TYPE, METRIC>(group_reduce_rt(acc1, G), zero4());
+      if (gl == 0) {
+        vkey[j0] = f2key(d0);
+        if (two) vkey[j1] = f2key(d1);
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < nv; e += 256) {
+      const uint64_t my = ((uint64_t)vkey[e] << 32) | vidx[e];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nv; j++) rank += ((((uint64_t)vkey[j] << 32) | vidx[j]) < my) ? 1u : 0u;
+      if (rank < A.k) A.part_knn[(size_t)blockIdx.x * A.k + rank] = my;
+    }
+    if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
+  }
+}
+
+// One workgroup of 1 024 per branch (block 0: the score lists and the hit count; block 1: the KNN lists), nothing shared
+// between them.  The k best of the N = tiles x k list entries, N in the tens of thousands:
+//   1. every thread keeps the best of ITS entries (entry e belongs to thread e mod 1 024): 1 024 distinct entries;
+//   2. every wavefront ranks its 64 and takes its k-th; the smallest of those 16 is the k-th of SOME k entries, so the k-th of
+//      all is not above it (ranking all 1 024 against each other -- a million comparisons on one CU -- took 50 us);
+//   3. the entries at or below that bound (a hundred or two of 24 000 in configs[4]) are collected in LDS and ranked; ranks
+//      below k are the answer.
+// More survivors than the LDS list holds (an adversarial arrangement; a wavefront with fewer than k entries of its own bounds
+// nothing): *out_n = 0xFFFFFFFF and the caller answers the query with the staged pipeline.
+constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
+template <bool SCORE>
+__device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, uint64_t *lk, uint32_t *li, uint32_t *cnt_sh) {
+  __shared__ uint64_t wtau_k[16];
+  __shared__ uint32_t wtau_i[16];
+  const uint32_t k = SCORE ? R.top_n : R.k;
+  const uint32_t n = R.n_tiles * k;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  auto entry = [&](uint32_t e) {
+    if (SCORE) return SKey{R.part_skey[e], R.part_sidx[e]};
+    const uint64_t c = R.part_knn[e];
+    return SKey{c, c == ~0ull ? ~0u : 0u};  // (the KNN composite carries its index in the low word: i is only the "none" mark)
+  };
+  // 1. the thread's best
+  SKey best = sk_none();
+  for (uint32_t e = threadIdx.x; e < n; e += 1024) best = sk_min(entry(e), best);
+  lk[threadIdx.x] = best.k;
+  li[threadIdx.x] = best.i;
+  if (threadIdx.x == 0) *cnt_sh = 0;
+  if (lane == 0) {
+    wtau_k[w] = ~0ull;
+    wtau_i[w] = ~0u;
+  }
+  __syncthreads();
+  // 2. the k-th of the wavefront's 64 (none: it holds fewer than k)
+  if (!sk_same(best, sk_none())) {
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{lk[w * 64 + j], li[w * 64 + j]}, best) ? 1u : 0u;
+    if (rank == k - 1) {
+      wtau_k[w] = best.k;
+      wtau_i[w] = best.i;
+    }
+  }
+  __syncthreads();
+  SKey tau = sk_none();
+#pragma unroll
+  for (int j = 0; j < 16; j++) tau = sk_min(SKey{wtau_k[j], wtau_i[j]}, tau);
+  __syncthreads();  // (lk / li are rewritten below)
+  // 3. survivors
+  for (uint32_t e = threadIdx.x; e < n; e += 1024) {
+    const SKey c = entry(e);
+    if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
+      const uint32_t slot = atomicAdd(cnt_sh, 1u);
+      if (slot < R.surv_cap) {
+        lk[slot] = c.k;
+        li[slot] = c.i;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t S = *cnt_sh;
+  uint32_t *out_n = SCORE ? R.out_sn : R.out_kn;
+  if (S > R.surv_cap) {
+    if (threadIdx.x == 0) *out_n = 0xFFFFFFFFu;
+    return;
+  }
+  for (uint32_t e = threadIdx.x; e < S; e += 1024) {
+    const SKey my{lk[e], li[e]};
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < S; j++) rank += sk_less(SKey{lk[j], li[j]}, my) ? 1u : 0u;
+    if (rank < k) {
+      if (SCORE) {
+        R.out_skeys[rank] = my.k;
+        R.out_sids[rank] = (uint32_t)((long long)R.ids0[my.i] + R.add0);
+      } else {
+        const uint32_t idx = (uint32_t)my.k;
+        R.out_krows[rank] = idx;
+        R.out_kkeys[rank] = (uint32_t)(my.k >> 32);
+        R.out_kids[rank] = (uint32_t)((long long)R.ids0[idx] + R.add0);
+      }
+    }
+  }
+  if (threadIdx.x == 0) *out_n = S < k ? S : k;
+}
+
+__global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R) {
+  __shared__ uint64_t lk[kHybSurvivors];
+  __shared__ uint32_t li[kHybSurvivors];
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t cnt_sh;
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (blockIdx.x == 0) {
+    uint32_t s = 0;
+    for (uint32_t t = threadIdx.x; t < R.n_tiles; t += 1024) s += R.tile_hits[t];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) wsum[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int j = 0; j < 16; j++) t += wsum[j];
+      *R.out_hits = t;
+    }
+    if (R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
+  } else if (R.k) {
+    hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+  }
+}
+
+}  // namespace
+
+uint32_t hybrid_tiles(uint32_t n0) { return (n0 + kHybTile - 1) / kHybTile; }
+bool hybrid_tile_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
+  if (top_n > (uint32_t)kHybMaxK || k > (uint32_t)kHybMaxK) return false;
+  if (n_tiles > kHybMaxTiles) return false;  // (the reduce workgroup walks tiles x k entries: 16 Ki tiles = 16 M drivers)
+  if (!k) return true;
+  if (type != KT_F32 && type != KT_F16 && type != KT_BF16) return false;
+  if (metric != KM_L2 && metric != KM_IP) return false;
+  return stride16 >= 1 && stride16 <= (uint32_t)kHybMaxChunks;
+}
+
+void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint32_t n_tiles, hipStream_t s) {
+  if (!n_tiles) return;
+  HybridTileArgs a = args;
+  if (a.k) {  // the lanes-per-row shape the scan kernels give this row length
+    const Shape sh = pick_shape(a.stride16);
+    a.G = sh.G;
+    a.ITERS = sh.ITERS;
+  } else {
+    a.G = 1;
+    a.ITERS = 0;
+  }
+#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M>), dim3(n_tiles), dim3(256), 0, s, a)
+  if (!a.k) RSGPU_HYB(KT_F32, KM_IP);  // (no KNN branch: any instantiation)
+  else if (type == KT_F32 && metric == KM_L2) RSGPU_HYB(KT_F32, KM_L2);
+  else if (type == KT_F32) RSGPU_HYB(KT_F32, KM_IP);
+  else if (type == KT_F16 && metric == KM_L2) RSGPU_HYB(KT_F16, KM_L2);
+  else if (type == KT_F16) RSGPU_HYB(KT_F16, KM_IP);
+  else if (metric == KM_L2) RSGPU_HYB(KT_BF16, KM_L2);
+  else RSGPU_HYB(KT_BF16, KM_IP);
+#undef RSGPU_HYB
+}
+void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s) {
+  hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(r.k ? 2 : 1), dim3(1024), 0, s, r);
+}
+
+}  // namespace rsgpu

@@ -1,0 +1,209 @@
+// postings_ops.hpp -- device pieces shared by postings_kernels.hip (the staged intersection / scoring / selection kernels)
+// and hybrid_kernels.hip (the same work for a whole query in two launches): the searches of the intersection probe, the
+// wave-wide top-k, and the scorers.  Both files are compiled with -ffp-contract=off and use THESE definitions, so a
+// document's score has the same bits whichever kernel computed it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scan_ops.hpp"  // f2key / d2key, the chunk operators of the KNN branch
+#include "search_kernels.hpp"
+
+namespace rsgpu {
+namespace {
+
+// ---- intersection ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound(const uint32_t *__restrict__ a, uint32_t n, uint32_t x) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (a[mid] < x) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// lower_bound by a whole wavefront: 64 evenly spaced probes per step narrow [lo, hi) 64-fold, so a 5 M-entry list
+// takes 4 dependent memory round trips instead of 23 (the probes of one step are independent loads)
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ a, uint32_t n, uint32_t x,
+                                                     uint32_t lane) {
+  uint32_t lo = 0, hi = n;  // answer in [lo, hi]
+  while (hi - lo > 64) {
+    const uint32_t step = (hi - lo + 63) / 64;                 // >= 2
+    const uint32_t p = lo + (lane + 1) * step - 1;             // last element of this lane's sub-range
+    const bool less = p < hi ? a[p] < x : false;               // sub-ranges beyond hi: "not less"
+    const unsigned long long m = __ballot(less);
+    const uint32_t c = (uint32_t)__popcll(m);                  // sub-ranges entirely below x (a is sorted: a prefix)
+    const uint32_t nlo = lo + c * step;
+    const uint32_t nhi = nlo + step - 1 < hi ? nlo + step - 1 : hi;  // a[nlo+step-1] >= x (or the range ends)
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+  }
+  const uint32_t p = lo + lane;
+  const bool less = p < hi ? a[p] < x : false;
+  return lo + (uint32_t)__popcll(__ballot(less));
+}
+
+// id i of list l in the frame the lists of a query share
+__device__ __forceinline__ uint32_t shared_id(const ListView &v, int l, uint32_t i) {
+  return (uint32_t)((long long)v.ids[l][i] + v.add[l]);
+}
+// x (shared frame) -> the frame of a list stored `add` away from it; *out: x lies outside the 32-bit range that list
+// can hold -- it cannot match, and the value returned keeps its lower bound right (0 below, the list's end above)
+__device__ __forceinline__ uint32_t to_list_frame(uint32_t x, long long add, bool *out) {
+  const long long t = (long long)x - add;
+  *out = t < 0 || t > 0xFFFFFFFFll;
+  return t < 0 ? 0u : (t > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)t);
+}
+
+// ---- wave-wide top-k ---------------------------------------------------------------------------------
+constexpr int kKnnTopkBlocks = 64, kKnnTopkPerThread = 4, kKnnTopkMaxK = 32;
+// wave-wide minimum, the same value in every lane.  Four DPP steps (xor 1, xor 2 inside a quad, half-row mirror, row
+// mirror: min is idempotent, so mirrors do as well as butterflies) leave every lane with the minimum of its row of 16;
+// four v_readlane pairs and scalar compares finish it -- ~40 instructions instead of twelve dependent ds_bpermute round
+// trips (the k rounds of wave_topk are a serial chain of these).
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_min_step(uint64_t v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  const uint32_t olo = (uint32_t)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+  const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+  const uint64_t o = ((uint64_t)ohi << 32) | olo;
+  return o < v ? o : v;
+}
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+  v = dpp_min_step<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_min_step<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_min_step<0x141>(v);  // row_half_mirror
+  v = dpp_min_step<0x140>(v);  // row_mirror
+  uint64_t m = ~0ull;
+#pragma unroll
+  for (int row = 0; row < 4; row++) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, row * 16);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), row * 16);
+    const uint64_t r = ((uint64_t)hi << 32) | lo;
+    m = r < m ? r : m;
+  }
+  return m;
+}
+// the k (<= 64) smallest of the N composites each lane holds: lane r returns the r-th smallest (~0 when there are
+// fewer).  k rounds of a wave-wide arg-min -- shuffles only, no barrier, no LDS.  Composites are unique.
+template <int N>
+__device__ __forceinline__ uint64_t wave_topk(uint64_t (&mine)[N], uint32_t k, uint32_t lane) {
+  uint64_t res = ~0ull;
+  for (uint32_t r = 0; r < k; r++) {
+    uint64_t v = mine[0];
+#pragma unroll
+    for (int j = 1; j < N; j++) v = mine[j] < v ? mine[j] : v;
+    const uint64_t m = wave_min_u64(v);
+    if (m == ~0ull) break;
+    if (lane == r) res = m;
+#pragma unroll
+    for (int j = 0; j < N; j++)
+      if (mine[j] == m) mine[j] = ~0ull;
+  }
+  return res;
+}
+
+// ---- scorers ---------------------------------------------------------------------------------------
+// One document's score.  F(t): frequency of term column t in this document (fp64); dlen / dscore / mfreq: its doc-table
+// entry (0 when the table does not hold it); slop: IndexResult_MinOffsetDelta of the result.
+// DEEP: the tree is deeper than root -> groups -> leaves (P.n_nodes > 0); its per-level accumulators are indexed
+// dynamically and live in scratch memory: the flat / two-level form must not pay for them.
+// The result tree (ScoreParams): root -> groups -> leaves.  fold(leaf) evaluates it the way the reference's recursions do
+// (src/ext/default.c:68-106,164-209,262-302,378-455): an aggregate sums its children and multiplies by its weight; DISMAX
+// takes the maximum over a UNION's children instead.  A leaf that did not match this document (union children) carries
+// frequency 0 and contributes exactly 0.
+template <bool DEEP, typename FreqFn>
+__device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint32_t dlen, float dscore, uint32_t mfreq,
+                                            int slop) {
+  double s = 0.0;
+  auto fold = [&](auto leaf, bool dismax) {
+    if constexpr (DEEP) {
+      // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
+      // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the
+      // reference's recursions add them in -- and its own value, weight * that, goes to its parent's accumulator.
+      double acc[kMaxTreeDepth + 1];
+#pragma unroll
+      for (int d = 0; d <= kMaxTreeDepth; d++) acc[d] = 0.0;
+      for (int i = 0; i < P.n_nodes - 1; i++) {
+        const int d = P.node_depth[i];
+        double v;
+        if (P.node_op[i] == 0) {
+          v = leaf((int)P.node_leaf[i]);
+        } else {
+          v = P.node_weight[i] * acc[d];
+          acc[d] = 0.0;
+        }
+        acc[d - 1] = (dismax && P.node_in_union[i]) ? (v > acc[d - 1] ? v : acc[d - 1]) : acc[d - 1] + v;
+      }
+      return acc[0];
+    }
+    double ret = 0.0;
+    for (int g = 0; g < P.n_groups; g++) {
+      const int a = P.group_first[g], b = P.group_first[g + 1];
+      double child;
+      if (P.group_op[g] == 0) {
+        child = leaf(a);
+      } else {
+        double acc = 0.0;
+        for (int t = a; t < b; t++) {
+          const double v = leaf(t);
+          acc = (dismax && P.group_op[g] == 1) ? (v > acc ? v : acc) : acc + v;
+        }
+        child = P.group_weight[g] * acc;
+      }
+      ret = (dismax && P.is_union) ? (child > ret ? child : ret) : ret + child;
+    }
+    return ret;
+  };
+  switch (P.scorer) {
+    case 0:    // BM25STD      reference src/ext/default.c:241-316
+    case 1: {  // BM25STD.TANH reference src/ext/default.c:329-359
+      const float b = 0.75f, k1 = 1.2f;
+      double ret = fold([&](int t) {
+        const double f = F(t);
+        // weight * idf * f * (k1 + 1) / (f + k1 * (1.0f - b + b * (float)doc_len/avg_doc_len))
+        const double num = P.weight[t] * P.bm25_idf[t] * f * (double)(k1 + 1);
+        const double den = f + (double)k1 * ((double)(1.0f - b) + (double)(b * (float)(int)dlen) / P.avg_doc_len);
+        return num / den;
+      }, false);
+      ret *= P.root_weight;
+      s = (double)dscore * ret;
+      if (P.scorer == 1) s = tanh(P.inv_tanh * s);
+      break;
+    }
+    case 2: {  // legacy BM25 reference src/ext/default.c:164-233
+      const float b = 0.5f, k1 = 1.2f;
+      double ret = fold([&](int t) {
+        const double f = F(t);
+        return P.weight[t] * P.idf[t] * f / (f + (double)k1 * ((double)(1.0f - b) + (double)b * P.avg_doc_len));
+      }, false);
+      ret *= P.root_weight;
+      s = (double)dscore * ret;
+      if (s < P.min_score) s = 0.0;
+      else s /= (double)slop;
+      break;
+    }
+    case 3:    // TFIDF         reference src/ext/default.c:109-145
+    case 4: {  // TFIDF.DOCNORM reference src/ext/default.c:149-153
+      const uint32_t norm = P.scorer == 3 ? mfreq : dlen;
+      if (dscore == 0.0f || norm == 0) { s = 0.0; break; }
+      double raw = fold([&](int t) { return P.weight[t] * F(t) * P.idf[t]; }, false);
+      raw *= P.root_weight;
+      s = (double)dscore * raw / (double)norm;
+      if (s < P.min_score) s = 0.0;
+      else s /= (double)slop;
+      break;
+    }
+    case 5:  // DOCSCORE reference src/ext/default.c:366-371
+      s = (double)dscore;
+      break;
+    default: {  // DISMAX reference src/ext/default.c:378-461: an intersection sums its children, a union takes their maximum
+      s = P.root_weight * fold([&](int t) { return P.weight[t] * F(t); }, true);
+      break;
+    }
+  }
+  return s;
+}
+
+}  // namespace
+}  // namespace rsgpu

@@ -123,6 +123,9 @@ struct Scratch {
   DevBuf<uint32_t> knn_cnt;
   DevBuf<uint64_t> knn_part;
   bool knn_dirty = true;  // the counters may be non-zero (first use, or a query that failed half-way)
+  // hybrid query in two launches (hybrid_kernels.hip): the tiles' lists, the reduce blocks' lists, the two tickets
+  DevBuf<uint32_t> hyb_hits, hyb_sidx;
+  DevBuf<uint64_t> hyb_skey, hyb_knn;
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -136,6 +139,8 @@ Scratch &scratch(int device) {
     s.knn_cnt.reset();
     s.knn_part.reset();
     s.knn_dirty = true;
+    s.hyb_hits.reset(); s.hyb_sidx.reset();
+    s.hyb_skey.reset(); s.hyb_knn.reset();
     s.device = device;
   }
   return s;
@@ -1405,6 +1410,145 @@ static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_D
   }
 }
 
+thread_local int tls_hybrid_path = 0;  // how the last RSGPU_HybridQuery of this thread ran: 0 staged, 1 two launches
+
+// The query in two launches (hybrid_kernels.hip): for callers that do not ask for the hit list.  The caller holds the index
+// lock and has checked the shapes (hybrid_tile_supported); ca's stream carries everything, cb lends its pinned buffers to the
+// KNN answers; the prepared query is ca->d_query.  false: the reduce kernel met more candidates at its bound than it ranks
+// (an adversarial arrangement of the tiles' lists) -- nothing was written, the staged pipeline takes the query.
+static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t knn_base, bool want_score, bool want_knn,
+                                QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev) {
+  const size_t n_lists = a->n_lists;
+  std::vector<int> order(n_lists);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a->lists[x]->n_entries < a->lists[y]->n_entries; });
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
+  for (size_t l = 0; l < n_lists; l++) {
+    if (l + 1 < n_lists && decode_pair_on(a->lists[l], a->lists[l + 1], ca)) l++;
+    else decode_on(a->lists[l], ca);
+  }
+  RSGPU_Hits h;  // the tree and the frame of the result (no arrays: nothing is written in hit order)
+  h.device = ca->device;
+  std::vector<Source> srcs;
+  for (size_t s = 0; s < n_lists; s++) srcs.push_back(term_source(a->lists[order[s]], order[s]));
+  ListView v;
+  const LeafMap m = adopt_sources(&h, srcs, v, 2);
+  h.is_union = false;
+  const uint32_t n0 = v.len[0];
+  const uint32_t top_n = want_score ? (uint32_t)a->top_n : 0u, k = want_knn ? (uint32_t)a->k : 0u;
+  const uint32_t n_tiles = hybrid_tiles(n0);
+
+  HybridTileArgs T;
+  memset(&T, 0, sizeof T);
+  T.n = v.n;
+  for (int l = 0; l < v.n; l++) {
+    T.ids[l] = v.ids[l];
+    T.freq[l] = m.leaf_freq[l];
+    T.len[l] = v.len[l];
+    T.add[l] = v.add[l];
+  }
+  T.top_n = top_n;
+  if (want_score) {
+    bool max_norm = false;
+    fill_score_params(T.P, &h, a->table, a->score, &max_norm);
+    T.doc_len = a->table->doc_len.p;
+    T.doc_score = a->table->doc_score.p;
+    T.max_freq = a->table->max_freq.p;
+    T.table_n = a->table->n;
+  }
+  T.k = k;
+  if (want_knn) {
+    T.rows = f->device_rows();
+    T.stride16 = T.chunks = (uint32_t)(f->stride() / 16);
+    T.query = ca->d_query;
+    T.ids_base = h.base;
+    T.knn_base = knn_base;
+    T.n_rows = f->committed_rows();
+  }
+  sc.hyb_hits.ensure(n_tiles);
+  if (top_n) {
+    sc.hyb_skey.ensure((size_t)n_tiles * top_n);
+    sc.hyb_sidx.ensure((size_t)n_tiles * top_n);
+  }
+  if (k) sc.hyb_knn.ensure((size_t)n_tiles * k);
+  T.tile_hits = sc.hyb_hits.p;
+  T.part_skey = sc.hyb_skey.p;
+  T.part_sidx = sc.hyb_sidx.p;
+  T.part_knn = sc.hyb_knn.p;
+
+  HybridReduceArgs R;
+  memset(&R, 0, sizeof R);
+  R.n_tiles = n_tiles;
+  R.top_n = top_n;
+  R.k = k;
+  R.surv_cap = (uint32_t)std::min(std::max(scan_tuning().hybrid_surv_cap, 1), 2048);
+  R.tile_hits = sc.hyb_hits.p;
+  R.part_skey = sc.hyb_skey.p;
+  R.part_sidx = sc.hyb_sidx.p;
+  R.part_knn = sc.hyb_knn.p;
+  R.ids0 = v.ids[0];
+  R.add0 = v.add[0];
+  ca->ensure_out(std::max<uint32_t>(top_n, 1));
+  ca->ensure_gather(std::max<uint32_t>(top_n, 1) + 1);
+  cb->ensure_out(std::max<uint32_t>(k, 1));
+  cb->ensure_gather(std::max<uint32_t>(k, 1) + 1);
+  ca->h_counters[0] = 0;
+  ca->h_fcnt[2] = 0;
+  cb->h_fcnt[2] = 0;
+  R.out_hits = ca->h_counters;
+  R.out_skeys = ca->h_out_keys;
+  R.out_sids = ca->h_ids;
+  R.out_sn = ca->h_fcnt + 2;
+  R.out_krows = cb->h_out_rows;
+  R.out_kkeys = reinterpret_cast<uint32_t *>(cb->h_out_keys);
+  R.out_kids = cb->h_ids;
+  R.out_kn = cb->h_fcnt + 2;
+
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
+  if (n_tiles) {
+    launch_hybrid_tiles(T, f ? f->ktype : 0, f ? f->kmetric : 0, n_tiles, ca->stream);
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
+    launch_hybrid_reduce(R, ca->stream);
+    HIP_CHECK(hipGetLastError());
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
+    HIP_CHECK(hipStreamSynchronize(ca->stream));
+  }
+  if (n_tiles && ((top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) || (k && cb->h_fcnt[2] == 0xFFFFFFFFu))) return false;
+
+  a->n_hits = n_tiles ? ca->h_counters[0] : 0;
+  if (top_n && n_tiles) {
+    const uint32_t n = std::min<uint32_t>(ca->h_fcnt[2], top_n);
+    for (uint32_t i = 0; i < n; i++) {
+      if (a->top_ids) a->top_ids[i] = h.base + ca->h_ids[i];
+      if (a->top_scores) a->top_scores[i] = key2score(ca->h_out_keys[i]);
+    }
+    a->n_top = n;
+  }
+  if (k && n_tiles) {
+    const uint32_t got = std::min<uint32_t>(cb->h_fcnt[2], k);
+    const uint32_t *k32 = reinterpret_cast<const uint32_t *>(cb->h_out_keys);
+    size_t out = 0;
+    for (uint32_t i = 0; i < got; i++) {  // (already in (distance, doc id) order)
+      if (k32[i] == 0xFFFFFFFFu) continue;  // NaN: a distance that is not a number ranks nowhere (hybrid_reader.c:317-320)
+      if (a->knn_ids) a->knn_ids[out] = h.base + cb->h_ids[i];
+      if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist(k32[i]);
+      out++;
+    }
+    a->n_knn = out;
+  }
+  if (prof) {
+    float ms = 0;
+    prof_ms[0] = prof_ms[2] = prof_ms[4] = 0;
+    prof_ms[1] = prof_ms[3] = 0;
+    if (n_tiles) {
+      if (hipEventElapsedTime(&ms, ev.e[0], ev.e[1]) == hipSuccess) prof_ms[0] = ms;  // decode (nothing when the lists are cached)
+      if (hipEventElapsedTime(&ms, ev.e[1], ev.e[2]) == hipSuccess) prof_ms[1] = ms;  // the tile kernel: probe + score + distances
+      if (hipEventElapsedTime(&ms, ev.e[2], ev.e[3]) == hipSuccess) prof_ms[3] = ms;  // the reduce kernel
+    }
+  }
+  return true;
+}
+
 extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   if (!a || !a->lists || !a->n_lists || a->n_lists > (size_t)kMaxLists) {
     last_error() = "RSGPU_HybridQuery: 1..32 lists";
@@ -1430,6 +1574,22 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   h->device = device;
   h->n_lists = (int)a->n_lists;
 
+  // Two launches instead of ten (hybrid_kernels.hip) when nobody asked for the hit list and the query has the plain shape:
+  // a flat AND of a few term lists, a scorer that needs neither the term offsets nor the maximum over all hits, small N / k
+  bool tiles = scan_tuning().hybrid_tiles && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && (want_score || want_knn);
+  if (tiles && want_score) {
+    bool any_offsets = false;
+    for (size_t l = 0; l < a->n_lists; l++) any_offsets |= a->lists[l]->has_offsets();
+    tiles = a->score->scorer != RSGPU_SCORER_BM25STD_NORM && !(slop_dependent(a->score->scorer) && any_offsets);
+  }
+  uint32_t n0_min = 0xFFFFFFFFu;
+  for (size_t l = 0; l < a->n_lists; l++) n0_min = std::min<uint32_t>(n0_min, a->lists[l]->n_entries);
+  if (tiles)
+    tiles = n0_min > 0 && hybrid_tile_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u,
+                                                hybrid_tiles(n0_min), want_score ? (uint32_t)a->top_n : 0u,
+                                                want_knn ? (uint32_t)a->k : 0u);
+  tls_hybrid_path = 0;
+
   // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
   uint64_t knn_base = 0;
   bool knn_identity = false;
@@ -1437,7 +1597,16 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   if (f) {
     index_lock = std::shared_lock<std::shared_mutex>(f->mu);
     knn_identity = f->identity_labels(&knn_base);
-    if (knn_identity) f->upload_query(cb.c, a->query, true);
+    if (!knn_identity) tiles = false;  // a general label map lives on the host
+    if (knn_identity) f->upload_query(tiles ? ca.c : cb.c, a->query, true);
+  }
+  if (tiles) {
+    if (hybrid_two_launches(a, f, knn_base, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
+      tls_hybrid_path = 1;
+      return 0;
+    }
+    a->n_hits = a->n_top = a->n_knn = 0;
+    if (f) f->upload_query(cb.c, a->query, true);  // (the KNN branch of the staged pipeline reads it on its own stream)
   }
 
   // ---- intersect (stream A) ----
@@ -1707,6 +1876,8 @@ double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs) {
   double total = (double)total_docs, term = (double)term_docs;
   return std::log(1.0 + (total - term + 0.5) / (term + 0.5));
 }
+
+int RSGPU_HybridQueryPath(void) { return tls_hybrid_path; }
 
 void RSGPU_SearchProfile(double *decode_ms, double *intersect_ms, double *score_ms, double *topn_ms, double *knn_ms) {
   if (decode_ms) *decode_ms = prof_ms[0];

@@ -197,6 +197,59 @@ void launch_knn_topk(const float *dists, const void *cand, uint32_t *count, uint
 // keys[i] = orderable(dists[i]) (NaN last)
 void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStream_t s);
 
+// ---- a whole hybrid query in two launches (hybrid_kernels.hip) ---------------------------------------------------
+// flat AND of up to kHybMaxLists term lists (list 0 drives) -> top_n by score next to the k nearest among the hits that have a
+// vector (identity-labelled FLAT index: row = doc id - knn_base).  Either branch may be off (top_n == 0 / k == 0).
+constexpr int kHybMaxLists = 4, kHybMaxK = 32, kHybMaxChunks = 512;
+struct HybridTileArgs {
+  int n;                               // lists
+  const uint32_t *ids[kHybMaxLists];   // decoded doc ids (relative to the list's base)
+  const uint32_t *freq[kHybMaxLists];  // decoded frequencies (NULL: the codec stores none -- 1)
+  uint32_t len[kHybMaxLists];
+  long long add[kHybMaxLists];         // ListView::add
+  // scoring: the flat result tree of the lists in this order; P.slops must be NULL
+  uint32_t top_n;
+  ScoreParams P;
+  const uint32_t *doc_len;
+  const float *doc_score;
+  const uint32_t *max_freq;
+  uint32_t table_n;
+  // KNN
+  uint32_t k;
+  const void *rows;                    // the index's row matrix
+  uint32_t stride16, chunks;           // 16-byte chunks per row (stride) / used (the same for padded rows)
+  int G, ITERS;                        // pick_shape(stride16): the lanes-per-row shape of scan_kernel
+  const void *query;                   // [chunks] 16-byte chunks, prepared as for the scan
+  uint64_t ids_base;                   // doc id = ids_base + (ids[0][i] + add[0])
+  uint64_t knn_base;
+  uint32_t n_rows;
+  // per tile, fixed slots
+  uint32_t *tile_hits;                 // [n_tiles]
+  uint64_t *part_skey;                 // [n_tiles][top_n]  ~d2key(score), ~0 = none
+  uint32_t *part_sidx;                 // [n_tiles][top_n]  driver index
+  uint64_t *part_knn;                  // [n_tiles][k]      (distance key << 32) | driver index, ~0 = none
+};
+struct HybridReduceArgs {
+  uint32_t n_tiles, top_n, k;
+  uint32_t surv_cap;                   // survivors the reduce workgroup ranks in LDS (<= 2048); more: *out_n = 0xFFFFFFFF
+  const uint32_t *tile_hits;
+  const uint64_t *part_skey;
+  const uint32_t *part_sidx;
+  const uint64_t *part_knn;
+  const uint32_t *ids0;                // the driving list: doc id of a winner = ids0[index] + add0 (shared frame)
+  long long add0;
+  // pinned host memory
+  uint32_t *out_hits;
+  uint64_t *out_skeys;                 // [top_n]
+  uint32_t *out_sids, *out_sn;
+  uint32_t *out_krows, *out_kkeys, *out_kids, *out_kn;  // [k]
+};
+uint32_t hybrid_tiles(uint32_t n0);
+// type / metric: the index's kernel type and metric (kernels.hpp KT_* / KM_*); false: the staged pipeline takes the query
+bool hybrid_tile_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k);
+void launch_hybrid_tiles(const HybridTileArgs &a, int type, int metric, uint32_t n_tiles, hipStream_t s);
+void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s);
+
 // ---- FT.HYBRID fusion (fusion_kernels.hip) -------------------------------------------------------------
 constexpr uint32_t kFuseMaxWindow = 4096;  // per upstream: (2 * 4096) * 17 bytes of LDS
 struct FuseParams {

@@ -44,6 +44,7 @@ ABI = {
     "RSGPU_EvalTreeNodes": (_vp, [C.POINTER(TreeNode), _sz, _vp, _sz]),
     "RSGPU_Hits_TreeNodes": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
+    "RSGPU_HybridQueryPath": (_i, []),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
     "RSGPU_Postings_NumEntries": (_sz, [_vp]),
@@ -299,6 +300,11 @@ class HybridQuery:
         a = self.args
         return dict(n_hits=a.n_hits, top=(self.ti[:a.n_top].copy(), self.ts[:a.n_top].copy()),
                     knn=(self.ki[:a.n_knn].copy(), self.kd[:a.n_knn].copy()))
+
+
+def hybrid_path():
+    """how this thread's last RSGPU_HybridQuery ran: 0 staged pipeline, 1 two launches (hybrid_kernels.hip)"""
+    return load().RSGPU_HybridQueryPath()
 
 
 def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,

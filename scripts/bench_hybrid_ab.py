@@ -77,7 +77,7 @@ def main():
                 lib.RSGPU_SetProfiling(0)
                 rec[name] = {"p50_ms": float(np.percentile(walls, 50)), "p95_ms": float(np.percentile(walls, 95)), "min_ms": min(walls),
                              "same_answers": bool(same),
-                             "stage_device_ms": {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")}}
+                             "stage_device_ms": {k_: prof.get(k_) for k_ in ("decode_ms", "intersect_ms", "score_ms", "topn_ms", "knn_ms")}}
             lib.RSGPU_SetTuning(b"cache_decoded", 1)
             out.append(rec)
             print(json.dumps(rec), flush=True)

@@ -94,7 +94,7 @@ def test_wide_probe_tiles_on_long_driving_lists(shape, dpt):
     try:
         n = check_intersection(lists_o)
     finally:
-        lib.RSGPU_SetTuning(b"probe_dpt", 4)
+        lib.RSGPU_SetTuning(b"probe_dpt", 1)
     if shape == "dense_equal":
         assert n == len(ls[0])
 
@@ -121,7 +121,18 @@ def setup_hybrid(n_docs, n_vec, dim, seed, dfs):
                                               (4_000_000, 600_000, (0.3, 0.2)),       # 240 k hits: prefilter path
                                               (300_000, 300_000, (0.5, 0.4, 0.3))])   # three lists, every doc has a vector
 @pytest.mark.parametrize("scorer", ["BM25STD", "TFIDF", "BM25STD.NORM"])
-def test_fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer):
+@pytest.mark.parametrize("tiles", [1, 0])
+def test_fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles):
+    """tiles = 1: the query in two launches (hybrid_kernels.hip) where its shape allows (not BM25STD.NORM: the maximum over
+    all hits); tiles = 0: the staged pipeline behind the same entry point"""
+    V.load().RSGPU_SetTuning(b"hybrid_tiles", tiles)
+    try:
+        _fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles)
+    finally:
+        V.load().RSGPU_SetTuning(b"hybrid_tiles", 1)
+
+
+def _fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles):
     lists_o, g, table, idx, idf, bidf, avg, q = setup_hybrid(n_docs, n_vec, 64, 5, dfs)
     w = [1.0] * len(g)
     # stage by stage
@@ -131,6 +142,7 @@ def test_fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer):
     ki, kd = h.knn_rerank(idx, q, 10)
     # fused
     r = S.hybrid_query(g, table, scorer, idf, bidf, w, n_docs, avg, top_n=10, index=idx, q=q, k=10)
+    assert S.hybrid_path() == (1 if tiles and scorer != "BM25STD.NORM" else 0)
     assert r["n_hits"] == len(h)
     assert r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
     assert r["knn"][0].tolist() == ki.tolist() and r["knn"][1].tolist() == kd.tolist()

@@ -1,0 +1,242 @@
+"""GPU: RSGPU_HybridQuery in two launches (hybrid_kernels.hip: one tile kernel -- probe, scores, distances, per-tile winners --
+and one reduce kernel) against the staged pipeline behind the same entry point (knob hybrid_tiles = 0) and, through it, the
+stage-by-stage entry points the oracle tests pin: hit count, top-N ids and scores, KNN ids and distances, BIT FOR BIT -- on every
+scorer, element type, metric, row shape (lanes per row / chunks per lane of the scan kernels), list count, codec without
+frequencies, 64-bit doc ids, skewed lists whose windows overflow LDS, mass ties (decided by doc id) and N / k from 1 to 32."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle as O
+from redisearch_amd import search as S
+from redisearch_amd import vecsim as V
+
+pytestmark = pytest.mark.gpu
+
+
+def postings(docs, freqs=None, codec=O.C_FREQS_ONLY):
+    docs = np.asarray(docs, np.uint64)
+    ii = O.InvertedIndex(codec)
+    if codec == O.C_FREQS_ONLY:
+        ii.add_many(docs, np.asarray(freqs if freqs is not None else np.ones(docs.size), np.uint32))
+    else:
+        for d in docs.tolist():
+            ii.add(d, 1, 1 + (d % 7))
+    return ii
+
+
+def both_paths(make):
+    """make() -> HybridQuery; returns (two-launch results, staged results) of the same argument block"""
+    lib = V.load()
+    hq = make()
+    try:
+        lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
+        hq.run()
+        path = S.hybrid_path()
+        a = hq.results()
+        hq.run()                      # (again: the tickets were put back)
+        a2 = hq.results()
+        lib.RSGPU_SetTuning(b"hybrid_tiles", 0)
+        hq.run()
+        assert S.hybrid_path() == 0
+        b = hq.results()
+    finally:
+        lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
+    for x in (a, a2):
+        assert x["n_hits"] == b["n_hits"]
+        assert x["top"][0].tolist() == b["top"][0].tolist(), "top-N ids"
+        assert x["top"][1].tolist() == b["top"][1].tolist(), "top-N scores"
+        assert x["knn"][0].tolist() == b["knn"][0].tolist(), "KNN ids"
+        assert x["knn"][1].tolist() == b["knn"][1].tolist(), "KNN distances"
+    return a, b, path
+
+
+def corpus(n_docs, dfs, seed, codec=O.C_FREQS_ONLY, first=1):
+    rng = np.random.default_rng(seed)
+    lists_o = []
+    for df in dfs:
+        docs = np.flatnonzero(rng.random(n_docs) < df).astype(np.uint64) + first
+        lists_o.append(postings(docs, np.minimum(1 + rng.geometric(0.5, docs.size), 255), codec))
+    return lists_o, rng
+
+
+SCORERS = ["BM25STD", "BM25STD.TANH", "BM25", "TFIDF", "TFIDF.DOCNORM", "DOCSCORE", "DISMAX"]
+
+
+@pytest.mark.parametrize("scorer", SCORERS)
+@pytest.mark.parametrize("n_lists", [1, 2, 3, 4])
+def test_every_scorer_and_list_count(scorer, n_lists):
+    n_docs = 700_000
+    lists_o, rng = corpus(n_docs, (0.5, 0.45, 0.6, 0.4)[:n_lists], 100 + n_lists)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), rng.choice([1.0, 0.5, 0.25], n_docs + 1).astype(np.float32),
+                       rng.integers(1, 50, n_docs + 1).astype(np.uint32))
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 48, V.VecSimMetric_L2)
+    idx.add_philox_rows(7, 0, 200_000, 1)
+    q = O.philox_rows(7, 1 << 40, 1, 48)[0]
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists_o]
+    bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists_o]
+    w = [1.0, 0.5, 2.0, 1.5][:n_lists]
+    a, b, path = both_paths(lambda: S.HybridQuery(g, table, scorer, idf, bidf, w, n_docs, 200.0, top_n=10, index=idx, q=q, k=10,
+                                                  root_weight=1.25, min_score=0.0))
+    assert path == 1
+    assert a["n_hits"] == len(O.intersect(lists_o)[0])
+    assert len(a["top"][0]) == 10 and len(a["knn"][0]) == 10
+
+
+@pytest.mark.parametrize("vtype,metric", [(V.VecSimType_FLOAT32, V.VecSimMetric_L2), (V.VecSimType_FLOAT32, V.VecSimMetric_IP),
+                                          (V.VecSimType_FLOAT32, V.VecSimMetric_Cosine), (V.VecSimType_FLOAT16, V.VecSimMetric_L2),
+                                          (V.VecSimType_FLOAT16, V.VecSimMetric_Cosine), (V.VecSimType_BFLOAT16, V.VecSimMetric_L2),
+                                          (V.VecSimType_BFLOAT16, V.VecSimMetric_IP)])
+@pytest.mark.parametrize("dim", [4, 24, 100, 384, 768, 1000, 1536])
+def test_every_element_type_metric_and_row_shape(vtype, metric, dim):
+    """dims chosen for the shapes of pick_shape: one chunk per lane with 1 .. 64 lanes, 16 / 32 lanes with three chunks, 64 lanes
+    with 2 .. 6 chunks, rows whose last chunks are padding"""
+    n_docs = 400_000
+    lists_o, rng = corpus(n_docs, (0.4, 0.3), zlib.crc32(b"%d %d %d" % (vtype, metric, dim)) % 10_000)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    idx = V.VecSimIndex(vtype, dim, metric)
+    idx.add_philox_rows(13, 0, 150_000, 100_001)     # the index covers a window of the doc ids
+    t = {V.VecSimType_FLOAT32: O.F32, V.VecSimType_FLOAT16: O.F16, V.VecSimType_BFLOAT16: O.BF16}[vtype]
+    q = O.philox_rows(13, 1 << 40, 1, dim, t)[0]
+    a, b, path = both_paths(lambda: S.HybridQuery(g, index=idx, q=q, k=10))
+    assert path == 1
+    assert len(a["knn"][0]) == 10 and 100_001 <= a["knn"][0].min() and a["knn"][0].max() <= 250_000
+    # the per-label ad-hoc seam (VecSimIndex_GetDistanceFrom_Unsafe) gives the same distances
+    assert np.array_equal(idx.adhoc_ctx(q).get_exact_distances(a["knn"][0]), a["knn"][1])
+    idx.free()
+
+
+@pytest.mark.parametrize("top_n,k", [(1, 1), (3, 32), (32, 5), (32, 32)])
+def test_list_lengths_from_one_to_thirty_two_and_fewer_hits_than_asked_for(top_n, k):
+    n_docs = 500_000
+    lists_o, rng = corpus(n_docs, (0.3, 0.2), 31)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), np.ones(n_docs + 1, np.float32))
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 32, V.VecSimMetric_L2)
+    idx.add_philox_rows(3, 0, 100_000, 1)
+    q = O.philox_rows(3, 1 << 40, 1, 32)[0]
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists_o]
+    a, b, path = both_paths(lambda: S.HybridQuery(g, table, "BM25STD", idf, idf, [1, 1], n_docs, 200.0, top_n=top_n, index=idx, q=q, k=k))
+    assert path == 1 and len(a["top"][0]) == top_n and len(a["knn"][0]) == k
+    # a handful of hits, fewer than asked for: three common documents, two of them with a vector
+    sa, sb = postings([5, 77, 90_000, 400_000, 499_999]), postings([4, 77, 90_000, 300_000, 499_999])
+    g2 = [S.Postings.from_flat(sa.flatten()), S.Postings.from_flat(sb.flatten())]
+    a, b, path = both_paths(lambda: S.HybridQuery(g2, table, "BM25STD", [1, 1], [1, 1], [1, 1], n_docs, 200.0, top_n=top_n, index=idx, q=q, k=k))
+    assert path == 1 and a["n_hits"] == 3
+    assert len(a["top"][0]) == min(top_n, 3) and set(a["top"][0].tolist()) <= {77, 90_000, 499_999}
+    assert len(a["knn"][0]) == min(k, 2) and set(a["knn"][0].tolist()) <= {77, 90_000}
+
+
+def test_mass_ties_are_decided_by_doc_id():
+    """DOCSCORE with one document score: every hit ties; the winners are the smallest doc ids, in order -- across tiles and
+    reduce blocks.  Identical vectors: every distance ties as well."""
+    n_docs = 1_200_000
+    lists_o, rng = corpus(n_docs, (0.6, 0.5), 77)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable(np.full(n_docs + 1, 100, np.uint32), np.ones(n_docs + 1, np.float32))
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 8, V.VecSimMetric_L2)
+    idx.add_bulk(np.tile(np.arange(8, dtype=np.float32), (300_000, 1)), 200_001)
+    a, b, path = both_paths(lambda: S.HybridQuery(g, table, "DOCSCORE", [1, 1], [1, 1], [1, 1], n_docs, 100.0, top_n=20, index=idx,
+                                                  q=np.zeros(8, np.float32), k=20))
+    assert path == 1
+    hits = O.intersect(lists_o)[0]
+    assert a["top"][0].tolist() == hits[:20].tolist() and set(a["top"][1].tolist()) == {1.0}
+    with_vec = hits[(hits >= 200_001) & (hits <= 500_000)]
+    assert a["knn"][0].tolist() == with_vec[:20].tolist() and len(set(a["knn"][1].tolist())) == 1
+
+
+@pytest.mark.parametrize("shape", ["skewed", "window_overflow", "clustered", "dense_equal", "ragged_tail", "disjoint"])
+def test_windows_of_every_kind(shape):
+    """the other list's window of a tile of 1 024 drivers: inside 4 Ki entries, beyond them (a search in memory), empty"""
+    rng = np.random.default_rng(zlib.crc32(shape.encode()) % 1000)
+    U = 3_000_000
+    if shape == "skewed":
+        ls = [np.unique(rng.integers(1, U, 3_000)), np.unique(rng.integers(1, U, 1_500_000))]
+    elif shape == "window_overflow":
+        ls = [np.arange(1, 900_000, 40), np.arange(1, 900_000)]
+    elif shape == "clustered":
+        ls = [np.concatenate([np.arange(1, 50_000), np.arange(2_000_000, 2_060_000, 3)]),
+              np.concatenate([np.arange(40_000, 1_000_000), np.arange(2_000_000, 2_050_000, 2)])]
+    elif shape == "dense_equal":
+        a = np.unique(rng.integers(1, 2_000_000, 400_000))
+        ls = [a, a.copy()]
+    elif shape == "ragged_tail":
+        ls = [np.arange(10, 10 + 3 * (2048 + 3), 3), np.unique(rng.integers(1, 800_000, 500_000))]
+    else:
+        ls = [np.arange(1, 100_000), np.arange(200_000, 300_000)]
+    lists_o = [postings(l, rng.integers(1, 9, len(l))) for l in ls]
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, U + 1)).astype(np.uint32), rng.choice([1.0, 0.5], U + 1).astype(np.float32))
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 16, V.VecSimMetric_L2)
+    idx.add_philox_rows(5, 0, 1_000_000, 1)
+    q = O.philox_rows(5, 1 << 40, 1, 16)[0]
+    a, b, path = both_paths(lambda: S.HybridQuery(g, table, "BM25STD", [1.5, 0.5], [1.2, 0.7], [1, 1], U, 200.0, top_n=10, index=idx, q=q, k=10))
+    assert path == 1
+    assert a["n_hits"] == len(O.intersect(lists_o)[0])
+    if shape == "disjoint":
+        assert a["n_hits"] == 0 and len(a["top"][0]) == 0 and len(a["knn"][0]) == 0
+
+
+def test_lists_without_frequencies_and_sixty_four_bit_doc_ids():
+    """FieldsOnly lists store no frequency (the term record's default, 1); doc ids beyond 2^32 (the lists keep 32-bit offsets from
+    their own bases, the doc table and the index cover windows that start up there)"""
+    first = (1 << 33) + 12_345
+    n_docs = 300_000
+    lists_o, rng = corpus(n_docs, (0.5, 0.4), 19, first=first)
+    lists_o[1] = postings(np.flatnonzero(rng.random(n_docs) < 0.4).astype(np.uint64) + first, codec=O.C_FIELDS_ONLY)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, n_docs)).astype(np.uint32), np.ones(n_docs, np.float32), first_doc_id=first)
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 20, V.VecSimMetric_L2)
+    idx.add_philox_rows(9, 0, 100_000, first + 50_000)
+    q = O.philox_rows(9, 1 << 40, 1, 20)[0]
+    a, b, path = both_paths(lambda: S.HybridQuery(g, table, "TFIDF.DOCNORM", [1.5, 0.5], [1.2, 0.7], [1, 1], n_docs, 200.0, top_n=10,
+                                                  index=idx, q=q, k=10))
+    assert path == 1 and a["n_hits"] == len(O.intersect(lists_o)[0])
+    assert a["top"][0].min() >= first and a["knn"][0].min() >= first + 50_000
+
+
+def test_shapes_the_two_launches_leave_to_the_staged_pipeline():
+    """BM25STD.NORM (the maximum over ALL hits), five lists, N > 32: the staged pipeline answers (and the same entry point
+    with hits_out set does -- search.py never sets it)"""
+    n_docs = 200_000
+    lists_o, rng = corpus(n_docs, (0.6, 0.5, 0.6, 0.5, 0.6), 23)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), np.ones(n_docs + 1, np.float32))
+    ones = [1.0] * 5
+    for args in (dict(lists=g[:2], scorer="BM25STD.NORM", top_n=10), dict(lists=g, scorer="BM25STD", top_n=10),
+                 dict(lists=g[:2], scorer="BM25STD", top_n=40)):
+        n = len(args["lists"])
+        r = S.hybrid_query(args["lists"], table, args["scorer"], ones[:n], ones[:n], ones[:n], n_docs, 200.0, top_n=args["top_n"])
+        assert S.hybrid_path() == 0 and len(r["top"][0]) == args["top_n"]
+
+
+def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():
+    """the way out of the reduce kernel (an adversarial arrangement of the tiles' lists leaves more than 2 048 entries at its
+    bound; forced here with a cap of 4): the same call answers through the staged pipeline -- same answers, path 0"""
+    lib = V.load()
+    n_docs = 300_000
+    lists_o, rng = corpus(n_docs, (0.5, 0.4), 41)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), np.ones(n_docs + 1, np.float32))
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 16, V.VecSimMetric_L2)
+    idx.add_philox_rows(3, 0, 100_000, 1)
+    q = O.philox_rows(3, 1 << 40, 1, 16)[0]
+    hq = S.HybridQuery(g, table, "BM25STD", [1.5, 0.5], [1.2, 0.7], [1, 1], n_docs, 200.0, top_n=10, index=idx, q=q, k=10)
+    hq.run()
+    assert S.hybrid_path() == 1
+    want = hq.results()
+    try:
+        lib.RSGPU_SetTuning(b"hybrid_surv_cap", 4)
+        for rep in range(2):
+            hq.run()
+            assert S.hybrid_path() == 0
+            got = hq.results()
+            assert got["n_hits"] == want["n_hits"]
+            for key in ("top", "knn"):
+                assert got[key][0].tolist() == want[key][0].tolist() and got[key][1].tolist() == want[key][1].tolist()
+    finally:
+        lib.RSGPU_SetTuning(b"hybrid_surv_cap", 2048)
+    hq.run()
+    assert S.hybrid_path() == 1
