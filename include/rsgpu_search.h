@@ -197,6 +197,9 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * KNN branches on two streams), 1 = two launches (no hits_out, a flat AND of <= 4 term lists, top_n / k <= 32: one tile
  * kernel -- probe, scores, distances, per-tile winners -- and one reduce kernel).  Same answers either way. */
 int RSGPU_HybridQueryPath(void);
+/* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
+ * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
+long RSGPU_HybridTrace(uint64_t *out, size_t cap_tiles);
 
 /* Union of 1..32 lists: documents present in ANY list, ascending doc id; a list that does not hold the document
  * contributes freq 0 (reference rqe_iterators/src/union_flat.rs:223-257,297-320).  Scoring a union hit list

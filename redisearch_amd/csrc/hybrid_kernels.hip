@@ -25,6 +25,8 @@
 // fmaf chains in scan_ops.hpp, nothing left to contract).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels.hpp"
 #include "postings_ops.hpp"
 #include "search_kernels.hpp"
@@ -34,7 +36,6 @@ namespace {
 
 constexpr int kHybDpt = 4;                        // drivers per thread
 constexpr uint32_t kHybTile = 256 * kHybDpt;      // drivers per workgroup
-constexpr uint32_t kHybWin = 4096;                // u32 entries of another list staged per tile (16 KiB)
 constexpr uint32_t kHybMaxTiles = 16384;
 
 // (descending score, ascending driver index): key = ~d2key(score) ascending, then the index
@@ -55,35 +56,50 @@ __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_red
   return v;
 }
 
+// phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
+#define RSGPU_HYB_MARK(p)                                                                                   \
+  do {                                                                                                      \
+    if (A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
+// Dynamic LDS: pool_words u32 (the probe's window of another list; then the hits' records -- doc id | frequency in list 0 |
+// position in list l -- then their keys | doc ids; then the vector rows | doc ids | distance keys of branch B), then the KNN
+// query (chunks x 16 bytes).
 template <int TYPE, int METRIC>
-__global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
   constexpr int DPT = kHybDpt;
-  constexpr uint32_t TILE = kHybTile, WIN = kHybWin;
-  __shared__ __attribute__((aligned(16))) uint32_t win[WIN];  // probe: the window of the other list; afterwards the hits' keys | indices, then vrow | vidx | vkey
-  __shared__ u4 qs[kHybMaxChunks];   // the KNN query
+  constexpr uint32_t TILE = kHybTile;
+  extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh;
+  const uint32_t WIN = A.pool_words;
+  u4 *qs = reinterpret_cast<u4 *>(win + WIN);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n0 = A.len[0];
   const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
   const uint32_t *__restrict__ ids0 = A.ids[0];
 
+  RSGPU_HYB_MARK(0);
   if (A.k)  // the query: in flight while the probe runs
     for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
 
   bool hit[DPT];
   uint32_t xc[DPT];            // doc id in the frame the lists share
+  uint32_t f0[DPT];            // its frequency in the driving list
   uint32_t ps[DPT][kHybMaxLists - 1];  // match position in list l
 #pragma unroll
   for (int k = 0; k < DPT; k++) {
     const uint32_t i = i_first + k * 256 + threadIdx.x;
     hit[k] = i < n0;
-    xc[k] = hit[k] ? (uint32_t)((long long)ids0[i] + A.add[0]) : 0u;
+    const uint32_t ic = hit[k] ? i : n0 - 1;  // (unconditional loads)
+    xc[k] = (uint32_t)((long long)ids0[ic] + A.add[0]);
+    // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
+    f0[k] = (A.top_n && A.freq[0]) ? A.freq[0][ic] : 1u;
 #pragma unroll
     for (int l = 0; l < kHybMaxLists - 1; l++) ps[k][l] = 0;
   }
   const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
-  const uint32_t x_next = i_next < n0 ? (uint32_t)((long long)ids0[i_next] + A.add[0]) : 0u;
+  const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
 
   // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
 #pragma unroll
@@ -102,6 +118,7 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
         if (lane == 0) w_hi = r;
       }
       __syncthreads();
+      if (l == 1) RSGPU_HYB_MARK(1);
       const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi]
       const uint32_t span = hi - lo;
       if (span <= WIN) {
@@ -120,18 +137,29 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
           }
         }
         __syncthreads();
+        if (l == 1) RSGPU_HYB_MARK(2);
+        // lower bounds of the lane's four drivers in step: a fixed-length search (the halving sequence depends on the span
+        // alone), one LDS read per driver and step, the four reads of a step independent of each other -- four data-dependent
+        // loops one after the other were 48 dependent LDS round trips
+        uint32_t xl[DPT], b[DPT];
+        bool under[DPT];
 #pragma unroll
         for (int k = 0; k < DPT; k++) {
-          bool under;
-          const uint32_t x = to_list_frame(xc[k], add, &under);
-          uint32_t b = 0, e = span;
-          while (b < e) {
-            const uint32_t mid = b + ((e - b) >> 1);
-            if (win[mid] < x) b = mid + 1;
-            else e = mid;
-          }
-          const bool m = hit[k] && !under && b < span && win[b] == x;
-          ps[k][l - 1] = lo + b;
+          xl[k] = to_list_frame(xc[k], add, &under[k]);
+          b[k] = 0;
+        }
+        uint32_t rem = span;
+        while (rem > 1) {
+          const uint32_t half = rem >> 1;
+#pragma unroll
+          for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
+          rem -= half;
+        }
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          if (span && win[b[k]] < xl[k]) b[k]++;
+          const bool m = hit[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
+          ps[k][l - 1] = lo + b[k];
           hit[k] = m;
         }
       } else {  // a window that does not fit (very skewed lists): a binary search in memory, confined to the window
@@ -163,16 +191,17 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
   }
   __syncthreads();
   if (threadIdx.x == 0) A.tile_hits[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  RSGPU_HYB_MARK(3);
 
   // ---- branch A: score, the tile's top-N ----
-  // The hits (about a hundred of 1 024 drivers in configs[4]) are compacted first -- driver index and match positions into LDS --
-  // and scored DENSELY, one hit per lane: scoring where the hits sit (four slots per lane, a tenth of the lanes live) ran the
-  // fp64 scorer sixteen times per workgroup for the work of two wavefronts, and the kernel was bound by what it issued.
-  // Selection by RANK: every hit counts the hits that precede it in the total order, ranks below N are the list -- written
-  // straight to their slots.  (k rounds of a wave-wide arg-min per wave plus a merge were a serial chain of ~20 x 150
-  // dependent instructions.)
+  // The hits (about a hundred of 1 024 drivers in configs[4]) are compacted first -- doc id, frequency in the driving list and
+  // match positions into LDS -- and scored DENSELY, one hit per lane: scoring where the hits sit (four slots per lane, a tenth
+  // of the lanes live) ran the fp64 scorer sixteen times per workgroup for the work of two wavefronts.
+  // Selection by RANK: every hit counts the hits that precede it in the total order (descending score, ascending doc id),
+  // ranks below N are the list -- written straight to their slots.  (k rounds of a wave-wide arg-min per wave plus a merge
+  // were a serial chain of ~20 x 150 dependent instructions.)
   if (A.top_n) {
-    uint32_t *hidx = win;  // [TILE] driver index; then [TILE] position in list l at win + l * TILE, l = 1 .. n - 1
+    uint32_t *rx = win, *rf0 = win + TILE;  // then the position in list l at win + (l + 1) * TILE
 #pragma unroll
     for (int k = 0; k < DPT; k++) {
       const unsigned long long m = __ballot(hit[k]);
@@ -183,30 +212,30 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
         first = __shfl(first, leader, 64);
         if (hit[k]) {
           const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          hidx[slot] = i_first + k * 256 + threadIdx.x;
+          rx[slot] = xc[k];
+          rf0[slot] = f0[k];
 #pragma unroll
           for (int l = 1; l < kHybMaxLists; l++)
-            if (l < A.n) win[l * TILE + slot] = ps[k][l - 1];
+            if (l < A.n) win[(l + 1) * TILE + slot] = ps[k][l - 1];
         }
       }
     }
     __syncthreads();
+    RSGPU_HYB_MARK(4);
     const uint32_t nh = nh_sh;
     uint64_t my_k[DPT];
-    uint32_t my_i[DPT];
+    uint32_t my_x[DPT];
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
       const uint32_t e = j * 256 + threadIdx.x;
       my_k[j] = ~0ull;
-      my_i[j] = ~0u;
+      my_x[j] = ~0u;
       if (e < nh) {
-        const uint32_t i = hidx[e];
-        const uint32_t x = (uint32_t)((long long)ids0[i] + A.add[0]);
-        // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
+        const uint32_t x = rx[e];
         double fr[kHybMaxLists];
-        fr[0] = A.freq[0] ? (double)A.freq[0][i] : 1.0;
+        fr[0] = (double)rf0[e];
 #pragma unroll
-        for (int l = 1; l < kHybMaxLists; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[l * TILE + e]] : 1.0;
+        for (int l = 1; l < kHybMaxLists; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
         const long long tid = (long long)x + A.P.table_off;
         const bool known = tid >= 0 && tid < (long long)A.table_n;
         const uint32_t id = known ? (uint32_t)tid : 0u;
@@ -216,18 +245,19 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
         auto F = [&](int t) { return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[3])); };
         const double s = score_one<false>(A.P, F, dlen, dscore, mfreq, A.P.slop);
         my_k[j] = ~d2key(s);
-        my_i[j] = i;
+        my_x[j] = x;
       }
     }
-    __syncthreads();  // every record has been read: keys | indices take their place
+    __syncthreads();  // every record has been read: keys | doc ids take their place
+    RSGPU_HYB_MARK(5);
     uint64_t *ek = reinterpret_cast<uint64_t *>(win);
-    uint32_t *ei = win + 2 * TILE;
+    uint32_t *ex = win + 2 * TILE;
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
       const uint32_t e = j * 256 + threadIdx.x;
       if (e < nh) {
         ek[e] = my_k[j];
-        ei[e] = my_i[j];
+        ex[e] = my_x[j];
       }
     }
     __syncthreads();
@@ -235,9 +265,9 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
     for (int j = 0; j < DPT; j++) {
       const uint32_t e = j * 256 + threadIdx.x;
       if (e < nh) {
-        const SKey my{my_k[j], my_i[j]};
+        const SKey my{my_k[j], my_x[j]};
         uint32_t rank = 0;
-        for (uint32_t o = 0; o < nh; o++) rank += sk_less(SKey{ek[o], ei[o]}, my) ? 1u : 0u;
+        for (uint32_t o = 0; o < nh; o++) rank += sk_less(SKey{ek[o], ex[o]}, my) ? 1u : 0u;
         if (rank < A.top_n) {
           A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
           A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
@@ -250,10 +280,11 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
     }
     __syncthreads();  // the arrays are reused by branch B
   }
+  RSGPU_HYB_MARK(6);
 
   // ---- branch B: the hits that have a vector, their distances, the tile's top-k ----
   if (A.k) {
-    uint32_t *vrow = win, *vidx = win + TILE, *vkey = win + 2 * TILE;
+    uint32_t *vrow = win, *vx = win + TILE, *vkey = win + 2 * TILE;
 #pragma unroll
     for (int k = 0; k < DPT; k++) {
       const uint64_t id = A.ids_base + xc[k];
@@ -267,7 +298,7 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
         if (has) {
           const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
           vrow[slot] = (uint32_t)(id - A.knn_base);
-          vidx[slot] = i_first + k * 256 + threadIdx.x;
+          vx[slot] = xc[k];
         }
       }
     }
@@ -276,50 +307,60 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
     const int G = A.G, ITERS = A.ITERS;
     const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
     const u4 *__restrict__ rows = reinterpret_cast<const u4 *>(A.rows);
-    // two rows per group and step, four chunks per row in flight: unconditional loads (from chunk 0 where the lane has none),
-    // the operations of scan_kernel in its order -- chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per
-    // chunk slot i < ITERS, then the butterfly
-    for (uint32_t j0 = grp; j0 < nv; j0 += 2 * GPB) {
-      const uint32_t j1 = j0 + GPB;
-      const bool two = j1 < nv;
-      const u4 *p0 = rows + (size_t)vrow[j0] * A.stride16, *p1 = rows + (size_t)vrow[two ? j1 : j0] * A.stride16;
-      float acc0 = 0.0f, acc1 = 0.0f;
-      for (int i0 = 0; i0 < ITERS; i0 += 4) {
-        u4 x0[4], x1[4], q[4];
+    // three rows per group and step, three chunks per row in flight (nine 16-byte loads per lane; four rows spill at six waves per SIMD): unconditional loads (from
+    // chunk 0 where the lane has none, from the step's first row past the end), the operations of scan_kernel in its order --
+    // chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly
+    constexpr int RU = 3, CU = 3;
+    for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
+      const u4 *p[RU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t c = gl + (uint32_t)(i0 + u) * (uint32_t)G;
-          const bool ok = i0 + u < ITERS && c < A.chunks;
-          const uint32_t cc = ok ? c : 0u;
-          x0[u] = load16<false>(p0 + cc);
-          x1[u] = load16<false>(p1 + cc);
-          q[u] = qs[cc];
-          if (!ok) x0[u] = x1[u] = q[u] = zero4();
+      for (int u = 0; u < RU; u++) {
+        const uint32_t ju = j0 + u * GPB;
+        p[u] = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
+      }
+      float acc[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) acc[u] = 0.0f;
+      for (int i0 = 0; i0 < ITERS; i0 += CU) {
+        u4 x[RU][CU];
+        uint32_t cc[CU];
+        bool ok[CU];
+#pragma unroll
+        for (int c = 0; c < CU; c++) {
+          const uint32_t ch = gl + (uint32_t)(i0 + c) * (uint32_t)G;
+          ok[c] = i0 + c < ITERS && ch < A.chunks;
+          cc[c] = ok[c] ? ch : 0u;
+#pragma unroll
+          for (int u = 0; u < RU; u++) x[u][c] = load16<false>(p[u] + cc[c]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-          if (i0 + u < ITERS) {
-            acc0 = Op<TYPE, METRIC>::add(acc0, x0[u], q[u]);
-            acc1 = Op<TYPE, METRIC>::add(acc1, x1[u], q[u]);
+        for (int c = 0; c < CU; c++)
+          if (i0 + c < ITERS) {
+            const u4 q = ok[c] ? qs[cc[c]] : zero4();
+#pragma unroll
+            for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
           }
       }
-      const float d0 = finish<TYPE, METRIC>(group_reduce_rt(acc0, G), zero4());
-      const float d1 = finish<TYPE, METRIC>(group_reduce_rt(acc1, G), zero4());
-      if (gl == 0) {
-        vkey[j0] = f2key(d0);
-        if (two) vkey[j1] = f2key(d1);
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const uint32_t ju = j0 + u * GPB;
+        const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
+        if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
       }
     }
     __syncthreads();
+    RSGPU_HYB_MARK(7);
     for (uint32_t e = threadIdx.x; e < nv; e += 256) {
-      const uint64_t my = ((uint64_t)vkey[e] << 32) | vidx[e];
+      const uint64_t my = ((uint64_t)vkey[e] << 32) | vx[e];
       uint32_t rank = 0;
-      for (uint32_t j = 0; j < nv; j++) rank += ((((uint64_t)vkey[j] << 32) | vidx[j]) < my) ? 1u : 0u;
+      for (uint32_t j = 0; j < nv; j++) rank += ((((uint64_t)vkey[j] << 32) | vx[j]) < my) ? 1u : 0u;
       if (rank < A.k) A.part_knn[(size_t)blockIdx.x * A.k + rank] = my;
     }
     if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
   }
+  RSGPU_HYB_MARK(8);
 }
+#undef RSGPU_HYB_MARK
 
 // One workgroup of 1 024 per branch (block 0: the score lists and the hit count; block 1: the KNN lists), nothing shared
 // between them.  The k best of the N = tiles x k list entries, N in the tens of thousands:
@@ -328,6 +369,7 @@ __global__ __launch_bounds__(256) void hybrid_tile_kernel(HybridTileArgs A) {
 //      all is not above it (ranking all 1 024 against each other -- a million comparisons on one CU -- took 50 us);
 //   3. the entries at or below that bound (a hundred or two of 24 000 in configs[4]) are collected in LDS and ranked; ranks
 //      below k are the answer.
+// Both passes over the entries keep eight loads per lane in flight (a loop of single loads is one L2 round trip per entry).
 // More survivors than the LDS list holds (an adversarial arrangement; a wavefront with fewer than k entries of its own bounds
 // nothing): *out_n = 0xFFFFFFFF and the caller answers the query with the staged pipeline.
 constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
@@ -336,16 +378,32 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   __shared__ uint64_t wtau_k[16];
   __shared__ uint32_t wtau_i[16];
   const uint32_t k = SCORE ? R.top_n : R.k;
-  const uint32_t n = R.n_tiles * k;
+  const uint32_t n = R.n_tiles * k;  // >= 1
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  auto entry = [&](uint32_t e) {
-    if (SCORE) return SKey{R.part_skey[e], R.part_sidx[e]};
-    const uint64_t c = R.part_knn[e];
-    return SKey{c, c == ~0ull ? ~0u : 0u};  // (the KNN composite carries its index in the low word: i is only the "none" mark)
+  // eight entries e0 + j * 1024 (past the end: none) -- the KNN composite carries its doc id in the low word, i is only the
+  // "none" mark there
+  auto load8 = [&](uint32_t e0, uint64_t (&ck)[8], uint32_t (&ci)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t e = e0 + j * 1024, ee = e < n ? e : n - 1;
+      ck[j] = SCORE ? R.part_skey[ee] : R.part_knn[ee];
+      ci[j] = SCORE ? R.part_sidx[ee] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (e0 + j * 1024 >= n) ck[j] = ~0ull;
+      if (ck[j] == ~0ull) ci[j] = ~0u;
+    }
   };
   // 1. the thread's best
   SKey best = sk_none();
-  for (uint32_t e = threadIdx.x; e < n; e += 1024) best = sk_min(entry(e), best);
+  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += 8 * 1024) {
+    uint64_t ck[8];
+    uint32_t ci[8];
+    load8(e0, ck, ci);
+#pragma unroll
+    for (int j = 0; j < 8; j++) best = sk_min(SKey{ck[j], ci[j]}, best);
+  }
   lk[threadIdx.x] = best.k;
   li[threadIdx.x] = best.i;
   if (threadIdx.x == 0) *cnt_sh = 0;
@@ -369,13 +427,19 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   for (int j = 0; j < 16; j++) tau = sk_min(SKey{wtau_k[j], wtau_i[j]}, tau);
   __syncthreads();  // (lk / li are rewritten below)
   // 3. survivors
-  for (uint32_t e = threadIdx.x; e < n; e += 1024) {
-    const SKey c = entry(e);
-    if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
-      const uint32_t slot = atomicAdd(cnt_sh, 1u);
-      if (slot < R.surv_cap) {
-        lk[slot] = c.k;
-        li[slot] = c.i;
+  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += 8 * 1024) {
+    uint64_t ck[8];
+    uint32_t ci[8];
+    load8(e0, ck, ci);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const SKey c{ck[j], ci[j]};
+      if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
+        const uint32_t slot = atomicAdd(cnt_sh, 1u);
+        if (slot < R.surv_cap) {
+          lk[slot] = c.k;
+          li[slot] = c.i;
+        }
       }
     }
   }
@@ -393,12 +457,11 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
     if (rank < k) {
       if (SCORE) {
         R.out_skeys[rank] = my.k;
-        R.out_sids[rank] = (uint32_t)((long long)R.ids0[my.i] + R.add0);
+        R.out_sids[rank] = my.i;
       } else {
-        const uint32_t idx = (uint32_t)my.k;
-        R.out_krows[rank] = idx;
+        R.out_krows[rank] = (uint32_t)my.k;
         R.out_kkeys[rank] = (uint32_t)(my.k >> 32);
-        R.out_kids[rank] = (uint32_t)((long long)R.ids0[idx] + R.add0);
+        R.out_kids[rank] = (uint32_t)my.k;
       }
     }
   }
@@ -451,7 +514,10 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
     a.G = 1;
     a.ITERS = 0;
   }
-#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M>), dim3(n_tiles), dim3(256), 0, s, a)
+  // LDS: the pool -- a window of 4 Ki entries; (lists + 1) record arrays of a tile's hits -- and the KNN query
+  a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
+  const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
+#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M>), dim3(n_tiles), dim3(256), lds, s, a)
   if (!a.k) RSGPU_HYB(KT_F32, KM_IP);  // (no KNN branch: any instantiation)
   else if (type == KT_F32 && metric == KM_L2) RSGPU_HYB(KT_F32, KM_L2);
   else if (type == KT_F32) RSGPU_HYB(KT_F32, KM_IP);

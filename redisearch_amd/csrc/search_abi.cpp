@@ -125,7 +125,8 @@ struct Scratch {
   bool knn_dirty = true;  // the counters may be non-zero (first use, or a query that failed half-way)
   // hybrid query in two launches (hybrid_kernels.hip): the tiles' lists, the reduce blocks' lists, the two tickets
   DevBuf<uint32_t> hyb_hits, hyb_sidx;
-  DevBuf<uint64_t> hyb_skey, hyb_knn;
+  DevBuf<uint64_t> hyb_skey, hyb_knn, hyb_trace;
+  uint32_t hyb_trace_tiles = 0;
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -140,7 +141,8 @@ Scratch &scratch(int device) {
     s.knn_part.reset();
     s.knn_dirty = true;
     s.hyb_hits.reset(); s.hyb_sidx.reset();
-    s.hyb_skey.reset(); s.hyb_knn.reset();
+    s.hyb_skey.reset(); s.hyb_knn.reset(); s.hyb_trace.reset();
+    s.hyb_trace_tiles = 0;
     s.device = device;
   }
   return s;
@@ -1471,6 +1473,12 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     sc.hyb_sidx.ensure((size_t)n_tiles * top_n);
   }
   if (k) sc.hyb_knn.ensure((size_t)n_tiles * k);
+  sc.hyb_trace_tiles = 0;
+  if (scan_tuning().hybrid_trace) {
+    sc.hyb_trace.ensure((size_t)n_tiles * kHybTracePhases);
+    T.trace = sc.hyb_trace.p;
+    sc.hyb_trace_tiles = n_tiles;
+  }
   T.tile_hits = sc.hyb_hits.p;
   T.part_skey = sc.hyb_skey.p;
   T.part_sidx = sc.hyb_sidx.p;
@@ -1486,8 +1494,6 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
   R.part_skey = sc.hyb_skey.p;
   R.part_sidx = sc.hyb_sidx.p;
   R.part_knn = sc.hyb_knn.p;
-  R.ids0 = v.ids[0];
-  R.add0 = v.add[0];
   ca->ensure_out(std::max<uint32_t>(top_n, 1));
   ca->ensure_gather(std::max<uint32_t>(top_n, 1) + 1);
   cb->ensure_out(std::max<uint32_t>(k, 1));
@@ -1878,6 +1884,17 @@ double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs) {
 }
 
 int RSGPU_HybridQueryPath(void) { return tls_hybrid_path; }
+
+// diagnostics (knob hybrid_trace): the phase clock of every tile of the calling thread's last two-launch query, [tiles][9]
+// readings of the 100 MHz device clock; returns the number of tiles (0: no trace)
+long RSGPU_HybridTrace(uint64_t *out, size_t cap_tiles) {
+  S_TRY
+  Scratch &sc = tls_scratch;
+  const size_t n = std::min<size_t>(sc.hyb_trace_tiles, cap_tiles);
+  if (n && out) HIP_CHECK(hipMemcpy(out, sc.hyb_trace.p, n * kHybTracePhases * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return (long)n;
+  S_CATCH(-1)
+}
 
 void RSGPU_SearchProfile(double *decode_ms, double *intersect_ms, double *score_ms, double *topn_ms, double *knn_ms) {
   if (decode_ms) *decode_ms = prof_ms[0];

@@ -201,6 +201,7 @@ void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStre
 // flat AND of up to kHybMaxLists term lists (list 0 drives) -> top_n by score next to the k nearest among the hits that have a
 // vector (identity-labelled FLAT index: row = doc id - knn_base).  Either branch may be off (top_n == 0 / k == 0).
 constexpr int kHybMaxLists = 4, kHybMaxK = 32, kHybMaxChunks = 512;
+constexpr int kHybTracePhases = 9;  // start | window ends | window staged | probe done | hits compacted | scored | ranked | distances | end
 struct HybridTileArgs {
   int n;                               // lists
   const uint32_t *ids[kHybMaxLists];   // decoded doc ids (relative to the list's base)
@@ -226,8 +227,10 @@ struct HybridTileArgs {
   // per tile, fixed slots
   uint32_t *tile_hits;                 // [n_tiles]
   uint64_t *part_skey;                 // [n_tiles][top_n]  ~d2key(score), ~0 = none
-  uint32_t *part_sidx;                 // [n_tiles][top_n]  driver index
-  uint64_t *part_knn;                  // [n_tiles][k]      (distance key << 32) | driver index, ~0 = none
+  uint32_t *part_sidx;                 // [n_tiles][top_n]  doc id in the shared frame (ids[0][i] + add[0])
+  uint64_t *part_knn;                  // [n_tiles][k]      (distance key << 32) | doc id in the shared frame, ~0 = none
+  uint32_t pool_words;                 // set by the launcher: u32 words of LDS before the query
+  uint64_t *trace;                     // NULL, or [n_tiles][kHybTracePhases] clock readings (diagnostics)
 };
 struct HybridReduceArgs {
   uint32_t n_tiles, top_n, k;
@@ -236,8 +239,6 @@ struct HybridReduceArgs {
   const uint64_t *part_skey;
   const uint32_t *part_sidx;
   const uint64_t *part_knn;
-  const uint32_t *ids0;                // the driving list: doc id of a winner = ids0[index] + add0 (shared frame)
-  long long add0;
   // pinned host memory
   uint32_t *out_hits;
   uint64_t *out_skeys;                 // [top_n]

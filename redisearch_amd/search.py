@@ -45,6 +45,7 @@ ABI = {
     "RSGPU_Hits_TreeNodes": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridQueryPath": (_i, []),
+    "RSGPU_HybridTrace": (C.c_long, [_vp, _sz]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
     "RSGPU_Postings_NumEntries": (_sz, [_vp]),
@@ -305,6 +306,15 @@ class HybridQuery:
 def hybrid_path():
     """how this thread's last RSGPU_HybridQuery ran: 0 staged pipeline, 1 two launches (hybrid_kernels.hip)"""
     return load().RSGPU_HybridQueryPath()
+
+
+def hybrid_trace(max_tiles=1 << 15):
+    """[tiles, 9] phase clock (100 MHz ticks) of the last two-launch query of this thread (knob hybrid_trace = 1)"""
+    out = np.zeros((max_tiles, 9), np.uint64)
+    n = load().RSGPU_HybridTrace(_p(out), max_tiles)
+    if n < 0:
+        raise RuntimeError(V.last_error())
+    return out[:n]
 
 
 def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,
