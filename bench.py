@@ -604,11 +604,29 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
             hq.run()
             return hq.results()
         r = fused()
+        path = S.hybrid_path()        # 1: two launches (hybrid_kernels.hip), 0: the staged pipeline
         walls = []
         for _ in range(40):           # the bare C call (argument block prepared once, as a C caller's is)
             t0 = time.perf_counter()
             hq.run()
             walls.append((time.perf_counter() - t0) * 1e3)
+        # the same call through the staged pipeline (ten kernels on two streams), same process: the A/B of the two-launch form
+        lib.RSGPU_SetTuning(b"hybrid_tiles", 0)
+        try:
+            hq.run()
+            r_staged = hq.results()
+            walls_staged = []
+            for _ in range(40):
+                t0 = time.perf_counter()
+                hq.run()
+                walls_staged.append((time.perf_counter() - t0) * 1e3)
+            lib.RSGPU_SetProfiling(1)
+            hq.run()
+            prof_staged = S.profile()
+            lib.RSGPU_SetProfiling(0)
+        finally:
+            lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
+        staged_same = all(r[k_][j].tolist() == r_staged[k_][j].tolist() for k_ in ("top", "knn") for j in (0, 1)) and r["n_hits"] == r_staged["n_hits"]
         fused_ok = (r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
                     and r["knn"][0].tolist() == ki.tolist() and r["knn"][1].tolist() == kd.tolist())
         # COLD: the lists' decoded arrays are not kept (cache_decoded = 0): every query decodes both posting lists from
@@ -641,6 +659,9 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
         adhoc = idx.adhoc_ctx(q)
         seam_ok = bool(np.array_equal(adhoc.get_exact_distances(ki), kd))   # the per-label ad-hoc seam gives the same distances
         n_cand = int(np.searchsorted(gi, n_vec, side="right"))
+        # decode of both lists per query: its own stage in the two-launch form (events around the decode launches), the
+        # difference of the intersect stages in the staged one
+        dec_ms = (prof_cold.get("decode_ms") or 0.0) if path == 1 else max((prof_cold.get("intersect_ms") or 0) - (prof.get("intersect_ms") or 0), 0.0)
         n_ent = [x.num_entries for x in g]
         rec = {"workload": "2-term intersect (Zipf df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD top-10" % (n_docs, n_vec, dim),
                "wall_ms_per_query": float(np.percentile(walls, 50)), "qps": 1e3 / float(np.percentile(walls, 50)),
@@ -648,21 +669,33 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
                "figure": "p50 of %d back-to-back queries, decode-cache warm (posting lists decoded once, kept in HBM)" % len(walls),
                "cold": {"wall_ms_per_query": float(np.percentile(cold, 50)), "wall_ms_p95": float(np.percentile(cold, 95)),
                         "what": "cache_decoded = 0: every query decodes both lists from their encoded bytes (%d B) first (eight lanes per block, from the sync points the lists' first decode left behind)" % enc_bytes,
-                        "decode_plus_intersect_device_ms": prof_cold.get("intersect_ms"),
-                        "decode_device_ms": max((prof_cold.get("intersect_ms") or 0) - (prof.get("intersect_ms") or 0), 0.0),
-                        "decode_gbs_of_encoded_bytes": enc_bytes / max((prof_cold.get("intersect_ms") or 0) - (prof.get("intersect_ms") or 0), 1e-6) / 1e6,
-                        "decode_plus_intersect_gbs_of_encoded_bytes": enc_bytes / max(prof_cold.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                        "decode_plus_intersect_device_ms": dec_ms + (prof_cold.get("intersect_ms") or 0) if path == 1 else prof_cold.get("intersect_ms"),
+                        "decode_device_ms": dec_ms,
+                        "decode_gbs_of_encoded_bytes": enc_bytes / max(dec_ms, 1e-6) / 1e6,
+                        "decode_plus_intersect_gbs_of_encoded_bytes": enc_bytes / max((dec_ms + (prof_cold.get("intersect_ms") or 0)) if path == 1 else (prof_cold.get("intersect_ms") or 1e-9), 1e-9) / 1e6,
                         "same_answers": bool(cold_ok)},
                "encoded_posting_bytes": enc_bytes,
                "postings": n_ent, "hits": len(gi),
-               "entry_point": "RSGPU_HybridQuery (one call, two stream syncs; score/top-N and KNN branches on two streams)",
+               "entry_point": ("RSGPU_HybridQuery, two launches: hybrid_tile_kernel (probe + scores + KNN distances + per-tile winners) and "
+                               "hybrid_reduce_kernel, one stream sync" if path == 1 else
+                               "RSGPU_HybridQuery (one call, two stream syncs; score/top-N and KNN branches on two streams)"),
+               "path": "two_launches" if path == 1 else "staged",
+               "staged_pipeline_same_process": {"wall_ms_per_query": float(np.percentile(walls_staged, 50)), "wall_ms_p95": float(np.percentile(walls_staged, 95)),
+                                                "stage_device_ms": {k_: prof_staged.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
+                                                "bit_identical_to_the_two_launch_answers": bool(staged_same),
+                                                "what": "the same call with hybrid_tiles = 0: intersection written out, score / top-N and KNN branches on two streams (ten kernels)"},
                "wall_ms_stage_by_stage_entry_points": min(staged[1:]),
                "candidates_with_vector": n_cand,
-               "stage_device_ms": {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
-               "stage_gbs": {"intersect, warm (4 B per DECODED posting of both lists)": sum(n_ent) * 4 / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
-                             "intersect, warm, in encoded bytes of both lists (SURVEY 8d's unit)": enc_bytes / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
-                             "score (20 B read + 20 B written per hit)": len(gi) * 40 / max(prof.get("score_ms") or 1e-9, 1e-9) / 1e6,
-                             "knn gather (dim*4 B per candidate with a vector)": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6},
+               "stage_device_ms": ({"tile_kernel_ms": prof.get("intersect_ms"), "reduce_kernel_ms": prof.get("topn_ms")} if path == 1 else
+                                   {k_: prof.get(k_) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")}),
+               "stage_gbs": ({"tile kernel: 4 B per DECODED posting of both lists + 12 B per hit (frequency, doc table) + dim*4 B per candidate with a vector":
+                              (sum(n_ent) * 4 + len(gi) * 12 + n_cand * dim * 4) / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                              "tile kernel, in encoded bytes of both lists (SURVEY 8d's unit)": enc_bytes / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6}
+                             if path == 1 else
+                             {"intersect, warm (4 B per DECODED posting of both lists)": sum(n_ent) * 4 / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                              "intersect, warm, in encoded bytes of both lists (SURVEY 8d's unit)": enc_bytes / max(prof.get("intersect_ms") or 1e-9, 1e-9) / 1e6,
+                              "score (20 B read + 20 B written per hit)": len(gi) * 40 / max(prof.get("score_ms") or 1e-9, 1e-9) / 1e6,
+                              "knn gather (dim*4 B per candidate with a vector)": n_cand * dim * 4 / max(prof.get("knn_ms") or 1e-9, 1e-9) / 1e6}),
                "parity": {"ok": bool(fused_ok and seam_ok), "vs": "fused == stage-by-stage entry points; KNN distances equal the per-label ad-hoc "
                                                                  "seam's (the CPU-oracle check runs in the cpu_baseline leg)"}}
         payload = dict(raw=raw, doc_len=doc_len, doc_score=doc_score, idf=idf, bidf=bidf, n_docs=n_docs, avg=avg,

@@ -51,6 +51,30 @@ __device__ __forceinline__ SKey sk_min(const SKey &a, const SKey &b) {
   const bool lt = sk_less(a, b);
   return SKey{lt ? a.k : b.k, lt ? a.i : b.i};
 }
+// wave_lower_bound with the first level's probes -- 64 positions that depend on the list's length alone -- REQUESTED before the
+// value searched for is known: `first` = a[(lane + 1) * ceil(n / 64) - 1] (anything past the end).  One dependent memory round
+// trip less per window end (the tile's first doc id and the probes travel together).  n > 64.
+__device__ __forceinline__ uint32_t wave_lower_bound_from(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
+                                                          uint32_t first) {
+  uint32_t lo = 0, hi = n;
+  bool level1 = true;
+  while (hi - lo > 64) {
+    const uint32_t step = (hi - lo + 63) / 64;
+    const uint32_t p = lo + (lane + 1) * step - 1;
+    const uint32_t v = level1 ? first : (p < hi ? a[p] : 0u);
+    level1 = false;
+    const bool less = p < hi ? v < x : false;
+    const uint32_t c = (uint32_t)__popcll(__ballot(less));
+    const uint32_t nlo = lo + c * step;
+    const uint32_t nhi = nlo + step - 1 < hi ? nlo + step - 1 : hi;
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+  }
+  const uint32_t p = lo + lane;
+  const bool less = p < hi ? a[p] < x : false;
+  return lo + (uint32_t)__popcll(__ballot(less));
+}
+
 __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_reduce<G> with G at run time: the same tree
   for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
@@ -80,6 +104,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   const uint32_t *__restrict__ ids0 = A.ids[0];
 
   RSGPU_HYB_MARK(0);
+  // the first level of the window-end searches in list 1 (64 fixed positions), requested together with the tile's doc ids
+  uint32_t lvl1 = 0;
+  const bool pre1 = A.n > 1 && A.len[1] > 64;
+  if (pre1) {
+    const uint32_t step = (A.len[1] + 63) / 64, p = (lane + 1) * step - 1;
+    lvl1 = A.ids[1][p < A.len[1] ? p : A.len[1] - 1];
+  }
   if (A.k)  // the query: in flight while the probe runs
     for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
 
@@ -110,11 +141,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const long long add = A.add[l];
       if (wave == 0) {
         bool u0;
-        const uint32_t r = wave_lower_bound(a, nl, to_list_frame(x_first, add, &u0), lane);
+        const uint32_t xf = to_list_frame(x_first, add, &u0);
+        const uint32_t r = (l == 1 && pre1) ? wave_lower_bound_from(a, nl, xf, lane, lvl1) : wave_lower_bound(a, nl, xf, lane);
         if (lane == 0) w_lo = r;
       } else if (wave == 1) {
         bool u1;
-        const uint32_t r = i_next < n0 ? wave_lower_bound(a, nl, to_list_frame(x_next, add, &u1), lane) : nl;
+        const uint32_t xn = to_list_frame(x_next, add, &u1);
+        const uint32_t r = i_next < n0 ? ((l == 1 && pre1) ? wave_lower_bound_from(a, nl, xn, lane, lvl1) : wave_lower_bound(a, nl, xn, lane)) : nl;
         if (lane == 0) w_hi = r;
       }
       __syncthreads();
@@ -243,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const uint32_t dlen = known ? A.doc_len[id] : 0u;
         const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
         auto F = [&](int t) { return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[3])); };
-        const double s = score_one<false>(A.P, F, dlen, dscore, mfreq, A.P.slop);
+        const double s = score_one<false, kHybMaxLists>(A.P, F, dlen, dscore, mfreq, A.P.slop);
         my_k[j] = ~d2key(s);
         my_x[j] = x;
       }
@@ -369,7 +402,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 //      all is not above it (ranking all 1 024 against each other -- a million comparisons on one CU -- took 50 us);
 //   3. the entries at or below that bound (a hundred or two of 24 000 in configs[4]) are collected in LDS and ranked; ranks
 //      below k are the answer.
-// Both passes over the entries keep eight loads per lane in flight (a loop of single loads is one L2 round trip per entry).
+// Both passes over the entries keep twelve loads per lane in flight (a loop of single loads is one L2 round trip per entry).
 // More survivors than the LDS list holds (an adversarial arrangement; a wavefront with fewer than k entries of its own bounds
 // nothing): *out_n = 0xFFFFFFFF and the caller answers the query with the staged pipeline.
 constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
@@ -380,29 +413,30 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   const uint32_t k = SCORE ? R.top_n : R.k;
   const uint32_t n = R.n_tiles * k;  // >= 1
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // eight entries e0 + j * 1024 (past the end: none) -- the KNN composite carries its doc id in the low word, i is only the
+  // kB entries e0 + j * 1024 (past the end: none) -- the KNN composite carries its doc id in the low word, i is only the
   // "none" mark there
-  auto load8 = [&](uint32_t e0, uint64_t (&ck)[8], uint32_t (&ci)[8]) {
+  constexpr int kB = 12;
+  auto load_batch = [&](uint32_t e0, uint64_t (&ck)[kB], uint32_t (&ci)[kB]) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < kB; j++) {
       const uint32_t e = e0 + j * 1024, ee = e < n ? e : n - 1;
       ck[j] = SCORE ? R.part_skey[ee] : R.part_knn[ee];
       ci[j] = SCORE ? R.part_sidx[ee] : 0u;
     }
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < kB; j++) {
       if (e0 + j * 1024 >= n) ck[j] = ~0ull;
       if (ck[j] == ~0ull) ci[j] = ~0u;
     }
   };
   // 1. the thread's best
   SKey best = sk_none();
-  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += 8 * 1024) {
-    uint64_t ck[8];
-    uint32_t ci[8];
-    load8(e0, ck, ci);
+  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += kB * 1024) {
+    uint64_t ck[kB];
+    uint32_t ci[kB];
+    load_batch(e0, ck, ci);
 #pragma unroll
-    for (int j = 0; j < 8; j++) best = sk_min(SKey{ck[j], ci[j]}, best);
+    for (int j = 0; j < kB; j++) best = sk_min(SKey{ck[j], ci[j]}, best);
   }
   lk[threadIdx.x] = best.k;
   li[threadIdx.x] = best.i;
@@ -427,12 +461,12 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   for (int j = 0; j < 16; j++) tau = sk_min(SKey{wtau_k[j], wtau_i[j]}, tau);
   __syncthreads();  // (lk / li are rewritten below)
   // 3. survivors
-  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += 8 * 1024) {
-    uint64_t ck[8];
-    uint32_t ci[8];
-    load8(e0, ck, ci);
+  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += kB * 1024) {
+    uint64_t ck[kB];
+    uint32_t ci[kB];
+    load_batch(e0, ck, ci);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < kB; j++) {
       const SKey c{ck[j], ci[j]};
       if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
         const uint32_t slot = atomicAdd(cnt_sh, 1u);
@@ -474,7 +508,7 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t cnt_sh;
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == gridDim.x - 1) {  // the hit count: with the KNN lists (8-byte entries: the lighter workgroup) when there are two
     uint32_t s = 0;
     for (uint32_t t = threadIdx.x; t < R.n_tiles; t += 1024) s += R.tile_hits[t];
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -485,10 +519,10 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
       for (int j = 0; j < 16; j++) t += wsum[j];
       *R.out_hits = t;
     }
-    if (R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
-  } else if (R.k) {
-    hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+    __syncthreads();
   }
+  if (blockIdx.x == 0 && R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
+  else if (R.k && (blockIdx.x == 1 || !R.top_n)) hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
 }
 
 }  // namespace
@@ -528,7 +562,7 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
 #undef RSGPU_HYB
 }
 void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s) {
-  hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(r.k ? 2 : 1), dim3(1024), 0, s, r);
+  hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(r.k && r.top_n ? 2 : 1), dim3(1024), 0, s, r);
 }
 
 }  // namespace rsgpu

@@ -112,11 +112,22 @@ __device__ __forceinline__ uint64_t wave_topk(uint64_t (&mine)[N], uint32_t k, u
 // (src/ext/default.c:68-106,164-209,262-302,378-455): an aggregate sums its children and multiplies by its weight; DISMAX
 // takes the maximum over a UNION's children instead.  A leaf that did not match this document (union children) carries
 // frequency 0 and contributes exactly 0.
-template <bool DEEP, typename FreqFn>
+// FLAT (> 0): the caller knows the tree is an intersection of FLAT-or-fewer TERMS (every group is one leaf, no union
+// anywhere): the same sum in the same order -- 0.0 + leaf(0) + leaf(1) ... -- with the leaf numbers compile-time constants,
+// so the weights / idfs come out of the argument block with constant offsets, all at once, instead of one dependent scalar
+// load after the other.
+template <bool DEEP, int FLAT = 0, typename FreqFn>
 __device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint32_t dlen, float dscore, uint32_t mfreq,
                                             int slop) {
   double s = 0.0;
   auto fold = [&](auto leaf, bool dismax) {
+    if constexpr (FLAT > 0) {
+      double ret = 0.0;
+#pragma unroll
+      for (int g = 0; g < FLAT; g++)
+        if (g < P.n_groups) ret = ret + leaf(g);
+      return ret;
+    }
     if constexpr (DEEP) {
       // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
       // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the

@@ -23,7 +23,8 @@ b = c.get("batched_mfma", {})
 print("batched", {k: b.get(k) for k in ("device_ms_per_pass", "qps_device", "hbm_frac", "mfma_frac", "parity", "error")})
 print("  i8", {k: (b.get("int8_shadow_extra") or {}).get(k) for k in ("device_ms_per_pass", "qps_device", "bit_identical_to_single_queries", "error")})
 h = c.get("hybrid", {})
-print("hybrid", {k: h.get(k) for k in ("wall_ms_per_query", "wall_ms_p95", "wall_ms_min", "stage_device_ms", "parity", "error")})
+print("hybrid", {k: h.get(k) for k in ("path", "wall_ms_per_query", "wall_ms_p95", "wall_ms_min", "stage_device_ms", "parity", "error")})
+print("  staged", h.get("staged_pipeline_same_process"))
 print("  cold", h.get("cold"))
 print("cpu", {k: d.get("cpu_baseline", {}).get(k) for k in ("value", "cores", "p50_ms", "eight_threads", "gpu_answers_checked_against_oracle_on_full_corpus")})
 PY
