@@ -80,6 +80,82 @@ __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_red
   return v;
 }
 
+// The k smallest of a tile's n entries (n <= TILE; entry e = j * 256 + thread sits in mk[j] / mx[j], "none" past n; get(e)
+// reads it back from LDS), each handed to put(rank, entry).  Called by the whole workgroup.
+//   n <= 192: every entry counts the entries that precede it (n LDS reads each).
+//   more (dense tiles -- a one-term filter, lists that are nearly equal): counting all against all is n^2 / 256 reads per lane
+//   (0.5 ms per query with every driver a hit).  Instead: the best entry of every lane, the k-th of each wavefront's 64 bests --
+//   the smallest of the four bounds the k-th of all from above -- and only the entries at or below it (a few dozen) are
+//   ranked.  More of those than the scratch list holds: all against all after all.
+constexpr uint32_t kHybDirect = 192, kHybScratch = 256;
+template <int DPT, typename Get, typename Put>
+__device__ __forceinline__ void tile_select(const uint64_t (&mk)[DPT], const uint32_t (&mx)[DPT], uint32_t n, uint32_t k, Get get,
+                                            uint64_t *sk, uint32_t *sx, uint32_t *cnt, uint64_t *wtk, uint32_t *wtx, Put put) {
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  bool direct = n <= kHybDirect;
+  if (!direct) {
+    SKey best = sk_none();
+#pragma unroll
+    for (int j = 0; j < DPT; j++) best = sk_min(SKey{mk[j], mx[j]}, best);
+    sk[threadIdx.x] = best.k;
+    sx[threadIdx.x] = best.i;
+    if (threadIdx.x == 0) *cnt = 0;
+    if (lane == 0) {
+      wtk[w] = ~0ull;
+      wtx[w] = ~0u;
+    }
+    __syncthreads();
+    if (!sk_same(best, sk_none())) {
+      uint32_t rank = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{sk[w * 64 + j], sx[w * 64 + j]}, best) ? 1u : 0u;
+      if (rank == k - 1) {
+        wtk[w] = best.k;
+        wtx[w] = best.i;
+      }
+    }
+    __syncthreads();
+    SKey tau = sk_none();
+#pragma unroll
+    for (int j = 0; j < 4; j++) tau = sk_min(SKey{wtk[j], wtx[j]}, tau);
+    __syncthreads();  // (sk / sx are rewritten)
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const SKey c{mk[j], mx[j]};
+      if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
+        const uint32_t slot = atomicAdd(cnt, 1u);
+        if (slot < kHybScratch) {
+          sk[slot] = c.k;
+          sx[slot] = c.i;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t S = *cnt;
+    if (S <= kHybScratch) {
+      if (threadIdx.x < S) {
+        const SKey my{sk[threadIdx.x], sx[threadIdx.x]};
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < S; o++) rank += sk_less(SKey{sk[o], sx[o]}, my) ? 1u : 0u;
+        if (rank < k) put(rank, my);
+      }
+    } else {
+      direct = true;
+    }
+  }
+  if (direct) {
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const SKey my{mk[j], mx[j]};
+      if (!sk_same(my, sk_none())) {
+        uint32_t rank = 0;
+        for (uint32_t o = 0; o < n; o++) rank += sk_less(get(o), my) ? 1u : 0u;
+        if (rank < k) put(rank, my);
+      }
+    }
+  }
+}
+
 // phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
 #define RSGPU_HYB_MARK(p)                                                                                   \
   do {                                                                                                      \
@@ -95,7 +171,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   constexpr uint32_t TILE = kHybTile;
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t wave_cnt[4];
-  __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh;
+  __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh, sel_cnt;
+  __shared__ uint64_t sel_k[kHybScratch], sel_wtk[4];
+  __shared__ uint32_t sel_x[kHybScratch], sel_wtx[4];
   const uint32_t WIN = A.pool_words;
   u4 *qs = reinterpret_cast<u4 *>(win + WIN);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -294,19 +372,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DPT; j++) {
-      const uint32_t e = j * 256 + threadIdx.x;
-      if (e < nh) {
-        const SKey my{my_k[j], my_x[j]};
-        uint32_t rank = 0;
-        for (uint32_t o = 0; o < nh; o++) rank += sk_less(SKey{ek[o], ex[o]}, my) ? 1u : 0u;
-        if (rank < A.top_n) {
-          A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
-          A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
-        }
-      }
-    }
+    tile_select<DPT>(my_k, my_x, nh, A.top_n, [&](uint32_t o) { return SKey{ek[o], ex[o]}; }, sel_k, sel_x, &sel_cnt, sel_wtk, sel_wtx,
+                     [&](uint32_t rank, const SKey &my) {
+                       A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
+                       A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
+                     });
     if (threadIdx.x >= nh && threadIdx.x < A.top_n) {  // fewer hits than slots
       A.part_skey[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0ull;
       A.part_sidx[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0u;
@@ -383,12 +453,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     __syncthreads();
     RSGPU_HYB_MARK(7);
-    for (uint32_t e = threadIdx.x; e < nv; e += 256) {
-      const uint64_t my = ((uint64_t)vkey[e] << 32) | vx[e];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < nv; j++) rank += ((((uint64_t)vkey[j] << 32) | vx[j]) < my) ? 1u : 0u;
-      if (rank < A.k) A.part_knn[(size_t)blockIdx.x * A.k + rank] = my;
+    uint64_t vk_mine[DPT];
+    uint32_t vx_mine[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      vk_mine[j] = e < nv ? (uint64_t)vkey[e] : ~0ull;
+      vx_mine[j] = e < nv ? vx[e] : ~0u;
     }
+    tile_select<DPT>(vk_mine, vx_mine, nv, A.k, [&](uint32_t o) { return SKey{(uint64_t)vkey[o], vx[o]}; }, sel_k, sel_x, &sel_cnt,
+                     sel_wtk, sel_wtx, [&](uint32_t rank, const SKey &my) {
+                       A.part_knn[(size_t)blockIdx.x * A.k + rank] = (my.k << 32) | my.i;
+                     });
     if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
   }
   RSGPU_HYB_MARK(8);
@@ -449,6 +525,7 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   // 2. the k-th of the wavefront's 64 (none: it holds fewer than k)
   if (!sk_same(best, sk_none())) {
     uint32_t rank = 0;
+#pragma unroll 8
     for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{lk[w * 64 + j], li[w * 64 + j]}, best) ? 1u : 0u;
     if (rank == k - 1) {
       wtau_k[w] = best.k;
