@@ -3,7 +3,7 @@
 mkdir -p gpurun_out
 (hostname; rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique') > gpurun_out/r03_box_id.txt 2>&1
 T0=$(date +%s)
-timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=8 > gpurun_out/r03_full_tests.txt 2>&1
+timeout 2400 python -m pytest tests/ -x -q -m gpu --durations=8 -p no:cacheprovider > gpurun_out/r03_full_tests.txt 2>&1
 echo "tests rc=$? t=$(( $(date +%s) - T0 ))s" >> gpurun_out/r03_full_tests.txt
 tail -22 gpurun_out/r03_full_tests.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
