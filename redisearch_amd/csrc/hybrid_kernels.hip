@@ -136,6 +136,8 @@ __device__ __forceinline__ void tile_select(const uint64_t (&mk)[DPT], const uin
       if (threadIdx.x < S) {
         const SKey my{sk[threadIdx.x], sx[threadIdx.x]};
         uint32_t rank = 0;
+        // (unrolled: eight LDS reads in flight -- one read per iteration is one LDS round trip per iteration)
+#pragma unroll 8
         for (uint32_t o = 0; o < S; o++) rank += sk_less(SKey{sk[o], sx[o]}, my) ? 1u : 0u;
         if (rank < k) put(rank, my);
       }
@@ -149,6 +151,7 @@ __device__ __forceinline__ void tile_select(const uint64_t (&mk)[DPT], const uin
       const SKey my{mk[j], mx[j]};
       if (!sk_same(my, sk_none())) {
         uint32_t rank = 0;
+#pragma unroll 8
         for (uint32_t o = 0; o < n; o++) rank += sk_less(get(o), my) ? 1u : 0u;
         if (rank < k) put(rank, my);
       }
@@ -564,6 +567,7 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   for (uint32_t e = threadIdx.x; e < S; e += 1024) {
     const SKey my{lk[e], li[e]};
     uint32_t rank = 0;
+#pragma unroll 8
     for (uint32_t j = 0; j < S; j++) rank += sk_less(SKey{lk[j], li[j]}, my) ? 1u : 0u;
     if (rank < k) {
       if (SCORE) {
