@@ -474,46 +474,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 }
 #undef RSGPU_HYB_MARK
 
-// One workgroup of 1 024 per branch (block 0: the score lists and the hit count; block 1: the KNN lists), nothing shared
-// between them.  The k best of the N = tiles x k list entries, N in the tens of thousands:
-//   1. every thread keeps the best of ITS entries (entry e belongs to thread e mod 1 024): 1 024 distinct entries;
+// One workgroup of 1 024 per branch (block 0: the score lists; the last block: the hit count and the KNN lists), nothing shared
+// between them.  The k best of the tiles' lists (a list is sorted: its first entry is the tile's best):
+//   1. every thread keeps the best of ITS tiles' first entries (tile t belongs to thread t mod 1 024): 1 024 distinct entries;
 //   2. every wavefront ranks its 64 and takes its k-th; the smallest of those 16 is the k-th of SOME k entries, so the k-th of
-//      all is not above it (ranking all 1 024 against each other -- a million comparisons on one CU -- took 50 us);
-//   3. the entries at or below that bound (a hundred or two of 24 000 in configs[4]) are collected in LDS and ranked; ranks
-//      below k are the answer.
-// Both passes over the entries keep twelve loads per lane in flight (a loop of single loads is one L2 round trip per entry).
-// More survivors than the LDS list holds (an adversarial arrangement; a wavefront with fewer than k entries of its own bounds
-// nothing): *out_n = 0xFFFFFFFF and the caller answers the query with the staged pipeline.
+//      all is not above it; for k <= 16 the wavefronts' k best (16 k entries) are ranked against each other as well, which
+//      gives the k-th of all 1 024 -- a bound that only about k tiles' firsts pass;
+//   3. a winner's tile has its first entry at or below the bound: only THOSE tiles' lists are read (the first version walked
+//      all tiles x k entries twice -- 600 KB through one CU), their entries at or below the bound are collected in LDS and
+//      ranked; ranks below k are the answer.
+// More survivors than the LDS list holds (an adversarial arrangement): *out_n = 0xFFFFFFFF and the caller answers the query
+// with the staged pipeline.
 constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
 template <bool SCORE>
 __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, uint64_t *lk, uint32_t *li, uint32_t *cnt_sh) {
   __shared__ uint64_t wtau_k[16];
   __shared__ uint32_t wtau_i[16];
   const uint32_t k = SCORE ? R.top_n : R.k;
-  const uint32_t n = R.n_tiles * k;  // >= 1
+  const uint32_t n_tiles = R.n_tiles;  // >= 1
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // kB entries e0 + j * 1024 (past the end: none) -- the KNN composite carries its doc id in the low word, i is only the
-  // "none" mark there
-  constexpr int kB = 12;
-  auto load_batch = [&](uint32_t e0, uint64_t (&ck)[kB], uint32_t (&ci)[kB]) {
+  // entry e -- the KNN composite carries its doc id in the low word, i is only the "none" mark there
+  auto entry = [&](uint32_t e) {
+    const uint64_t ck = SCORE ? R.part_skey[e] : R.part_knn[e];
+    const uint32_t ci = ck == ~0ull ? ~0u : (SCORE ? R.part_sidx[e] : 0u);
+    return SKey{ck, ci};
+  };
+  // the first entries of the thread's tiles t0 + j * 1024 (none past the end), kB loads in flight
+  constexpr int kB = 8;
+  auto load_firsts = [&](uint32_t t0, uint64_t (&ck)[kB], uint32_t (&ci)[kB]) {
 #pragma unroll
     for (int j = 0; j < kB; j++) {
-      const uint32_t e = e0 + j * 1024, ee = e < n ? e : n - 1;
-      ck[j] = SCORE ? R.part_skey[ee] : R.part_knn[ee];
-      ci[j] = SCORE ? R.part_sidx[ee] : 0u;
+      const uint32_t t = t0 + j * 1024, tt = t < n_tiles ? t : n_tiles - 1;
+      ck[j] = SCORE ? R.part_skey[(size_t)tt * k] : R.part_knn[(size_t)tt * k];
+      ci[j] = SCORE ? R.part_sidx[(size_t)tt * k] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < kB; j++) {
-      if (e0 + j * 1024 >= n) ck[j] = ~0ull;
+      if (t0 + j * 1024 >= n_tiles) ck[j] = ~0ull;
       if (ck[j] == ~0ull) ci[j] = ~0u;
     }
   };
   // 1. the thread's best
   SKey best = sk_none();
-  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += kB * 1024) {
+  for (uint32_t t0 = threadIdx.x; t0 < n_tiles; t0 += kB * 1024) {
     uint64_t ck[kB];
     uint32_t ci[kB];
-    load_batch(e0, ck, ci);
+    load_firsts(t0, ck, ci);
 #pragma unroll
     for (int j = 0; j < kB; j++) best = sk_min(SKey{ck[j], ci[j]}, best);
   }
@@ -524,8 +530,15 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
     wtau_k[w] = ~0ull;
     wtau_i[w] = ~0u;
   }
+  const bool refine = k <= 16;
+  uint64_t *tk = lk + 1024;  // [16][k]
+  uint32_t *ti = li + 1024;
+  if (refine && threadIdx.x < 16 * k) {
+    tk[threadIdx.x] = ~0ull;
+    ti[threadIdx.x] = ~0u;
+  }
   __syncthreads();
-  // 2. the k-th of the wavefront's 64 (none: it holds fewer than k)
+  // 2. the bound
   if (!sk_same(best, sk_none())) {
     uint32_t rank = 0;
 #pragma unroll 8
@@ -534,25 +547,47 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
       wtau_k[w] = best.k;
       wtau_i[w] = best.i;
     }
+    if (refine && rank < k) {
+      tk[w * k + rank] = best.k;
+      ti[w * k + rank] = best.i;
+    }
+  }
+  __syncthreads();
+  if (refine && threadIdx.x < 16 * k) {
+    const SKey my{tk[threadIdx.x], ti[threadIdx.x]};
+    if (!sk_same(my, sk_none())) {
+      uint32_t rank = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < 16 * k; j++) rank += sk_less(SKey{tk[j], ti[j]}, my) ? 1u : 0u;
+      if (rank == k - 1) {  // (at or below every wavefront's own k-th)
+        wtau_k[0] = my.k;
+        wtau_i[0] = my.i;
+      }
+    }
   }
   __syncthreads();
   SKey tau = sk_none();
 #pragma unroll
   for (int j = 0; j < 16; j++) tau = sk_min(SKey{wtau_k[j], wtau_i[j]}, tau);
   __syncthreads();  // (lk / li are rewritten below)
-  // 3. survivors
-  for (uint32_t e0 = threadIdx.x; e0 < n; e0 += kB * 1024) {
+  // 3. the lists of the tiles whose first entry passes; survivors
+  for (uint32_t t0 = threadIdx.x; t0 < n_tiles; t0 += kB * 1024) {
     uint64_t ck[kB];
     uint32_t ci[kB];
-    load_batch(e0, ck, ci);
+    load_firsts(t0, ck, ci);
 #pragma unroll
     for (int j = 0; j < kB; j++) {
-      const SKey c{ck[j], ci[j]};
-      if (!sk_same(c, sk_none()) && !sk_less(tau, c)) {
-        const uint32_t slot = atomicAdd(cnt_sh, 1u);
-        if (slot < R.surv_cap) {
-          lk[slot] = c.k;
-          li[slot] = c.i;
+      const SKey first{ck[j], ci[j]};
+      if (!sk_same(first, sk_none()) && !sk_less(tau, first)) {
+        const size_t base = (size_t)(t0 + j * 1024) * k;
+        for (uint32_t i = 0; i < k; i++) {
+          const SKey c = i ? entry((uint32_t)(base + i)) : first;
+          if (sk_same(c, sk_none()) || sk_less(tau, c)) break;  // (sorted: nothing further down passes)
+          const uint32_t slot = atomicAdd(cnt_sh, 1u);
+          if (slot < R.surv_cap) {
+            lk[slot] = c.k;
+            li[slot] = c.i;
+          }
         }
       }
     }
@@ -591,7 +626,16 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == gridDim.x - 1) {  // the hit count: with the KNN lists (8-byte entries: the lighter workgroup) when there are two
     uint32_t s = 0;
-    for (uint32_t t = threadIdx.x; t < R.n_tiles; t += 1024) s += R.tile_hits[t];
+    for (uint32_t t0 = threadIdx.x; t0 < R.n_tiles; t0 += 4 * 1024) {  // (four loads in flight)
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t t = t0 + j * 1024;
+        v[j] = R.tile_hits[t < R.n_tiles ? t : R.n_tiles - 1];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) s += t0 + j * 1024 < R.n_tiles ? v[j] : 0u;
+    }
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) wsum[w] = s;
     __syncthreads();
