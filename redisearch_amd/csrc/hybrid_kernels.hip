@@ -51,17 +51,20 @@ __device__ __forceinline__ SKey sk_min(const SKey &a, const SKey &b) {
   const bool lt = sk_less(a, b);
   return SKey{lt ? a.k : b.k, lt ? a.i : b.i};
 }
-// wave_lower_bound with the first level's probes -- 64 positions that depend on the list's length alone -- REQUESTED before the
-// value searched for is known: `first` = a[(lane + 1) * ceil(n / 64) - 1] (anything past the end).  One dependent memory round
-// trip less per window end (the tile's first doc id and the probes travel together).  n > 64.
-__device__ __forceinline__ uint32_t wave_lower_bound_from(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
-                                                          uint32_t first) {
-  uint32_t lo = 0, hi = n;
-  bool level1 = true;
+// wave_lower_bound (postings_ops.hpp) cut short and started early: the 64-ary narrowing WITHOUT its last probe -- *lo_out <=
+// lower_bound(x) <= *hi_out, at most 64 apart -- because the caller stages a window anyway and a window up to 64 entries wider
+// at either end costs nothing, while the last probe is one more dependent memory round trip; and with the first level's
+// probes -- 64 positions that depend on the list's length alone -- REQUESTED before the value searched for is known
+// (use_first: `first` = a[(lane + 1) * ceil(n / 64) - 1], anything past the end), so that the tile's first doc id and the
+// probes travel together.
+__device__ __forceinline__ void wave_lower_bound_range(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
+                                                       uint32_t first, bool use_first, uint32_t *lo_out, uint32_t *hi_out) {
+  uint32_t lo = 0, hi = n;  // answer in [lo, hi]
+  bool level1 = use_first;
   while (hi - lo > 64) {
     const uint32_t step = (hi - lo + 63) / 64;
     const uint32_t p = lo + (lane + 1) * step - 1;
-    const uint32_t v = level1 ? first : (p < hi ? a[p] : 0u);
+    const uint32_t v = level1 ? first : a[p < hi ? p : hi - 1];
     level1 = false;
     const bool less = p < hi ? v < x : false;
     const uint32_t c = (uint32_t)__popcll(__ballot(less));
@@ -70,9 +73,8 @@ __device__ __forceinline__ uint32_t wave_lower_bound_from(const uint32_t *__rest
     lo = nlo < hi ? nlo : hi;
     hi = nhi;
   }
-  const uint32_t p = lo + lane;
-  const bool less = p < hi ? a[p] < x : false;
-  return lo + (uint32_t)__popcll(__ballot(less));
+  *lo_out = lo;
+  *hi_out = hi;
 }
 
 __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_reduce<G> with G at run time: the same tree
@@ -220,20 +222,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const uint32_t *__restrict__ a = A.ids[l];
       const uint32_t nl = A.len[l];
       const long long add = A.add[l];
-      if (wave == 0) {
+      if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
         bool u0;
-        const uint32_t xf = to_list_frame(x_first, add, &u0);
-        const uint32_t r = (l == 1 && pre1) ? wave_lower_bound_from(a, nl, xf, lane, lvl1) : wave_lower_bound(a, nl, xf, lane);
-        if (lane == 0) w_lo = r;
-      } else if (wave == 1) {
+        uint32_t rlo, rhi;
+        wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+        if (lane == 0) w_lo = rlo;
+      } else if (wave == 1) {  // its end: at or above lower_bound(first driver of the next tile)
         bool u1;
-        const uint32_t xn = to_list_frame(x_next, add, &u1);
-        const uint32_t r = i_next < n0 ? ((l == 1 && pre1) ? wave_lower_bound_from(a, nl, xn, lane, lvl1) : wave_lower_bound(a, nl, xn, lane)) : nl;
-        if (lane == 0) w_hi = r;
+        uint32_t rlo, rhi = nl;
+        if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, add, &u1), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+        if (lane == 0) w_hi = rhi;
       }
       __syncthreads();
       if (l == 1) RSGPU_HYB_MARK(1);
-      const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi]
+      const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi] (up to 64 entries of slack at either end)
       const uint32_t span = hi - lo;
       if (span <= WIN) {
         // the window, eight loads per lane in flight at a time (a load / ds_write loop is serialised by hipcc)
