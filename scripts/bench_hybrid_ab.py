@@ -24,7 +24,7 @@ def main():
         k, vs = a.split("=")
         knobs.append((k, [int(x) for x in vs.split(",")]))
     lib = V.load()
-    n_docs, n_vec, dim = 50_000_000, 5_000_000, 768
+    n_docs, n_vec, dim = 50_000_000, int(os.environ.get("N_VEC", 5_000_000)), 768   # N_VEC=50000000: every document has a vector
     rng = np.random.default_rng(49)
     raw = []
     for r in (2, 4):
