@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           ok[c] = i0 + c < ITERS && ch < A.chunks;
           cc[c] = ok[c] ? ch : 0u;
 #pragma unroll
-          for (int u = 0; u < RU; u++) x[u][c] = load16<false>(p[u] + cc[c]);
+          for (int u = 0; u < RU; u++) x[u][c] = load16<true>(p[u] + cc[c]);  // (rows are read once: streamed past the caches)
         }
 #pragma unroll
         for (int c = 0; c < CU; c++)
