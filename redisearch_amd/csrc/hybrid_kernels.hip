@@ -51,32 +51,6 @@ __device__ __forceinline__ SKey sk_min(const SKey &a, const SKey &b) {
   const bool lt = sk_less(a, b);
   return SKey{lt ? a.k : b.k, lt ? a.i : b.i};
 }
-// wave_lower_bound (postings_ops.hpp) cut short and started early: the 64-ary narrowing WITHOUT its last probe -- *lo_out <=
-// lower_bound(x) <= *hi_out, at most 64 apart -- because the caller stages a window anyway and a window up to 64 entries wider
-// at either end costs nothing, while the last probe is one more dependent memory round trip; and with the first level's
-// probes -- 64 positions that depend on the list's length alone -- REQUESTED before the value searched for is known
-// (use_first: `first` = a[(lane + 1) * ceil(n / 64) - 1], anything past the end), so that the tile's first doc id and the
-// probes travel together.
-__device__ __forceinline__ void wave_lower_bound_range(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
-                                                       uint32_t first, bool use_first, uint32_t *lo_out, uint32_t *hi_out) {
-  uint32_t lo = 0, hi = n;  // answer in [lo, hi]
-  bool level1 = use_first;
-  while (hi - lo > 64) {
-    const uint32_t step = (hi - lo + 63) / 64;
-    const uint32_t p = lo + (lane + 1) * step - 1;
-    const uint32_t v = level1 ? first : a[p < hi ? p : hi - 1];
-    level1 = false;
-    const bool less = p < hi ? v < x : false;
-    const uint32_t c = (uint32_t)__popcll(__ballot(less));
-    const uint32_t nlo = lo + c * step;
-    const uint32_t nhi = nlo + step - 1 < hi ? nlo + step - 1 : hi;
-    lo = nlo < hi ? nlo : hi;
-    hi = nhi;
-  }
-  *lo_out = lo;
-  *hi_out = hi;
-}
-
 __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_reduce<G> with G at run time: the same tree
   for (int m = G >> 1; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;

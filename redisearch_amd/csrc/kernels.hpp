@@ -67,7 +67,7 @@ struct ScanTuning {
   int hybrid_tiles = 1;    // RSGPU_HybridQuery without hits_out: the query in two launches (hybrid_kernels.hip); 0 = the staged pipeline
   int hybrid_trace = 0;    // diagnostics: the tile kernel records a phase clock per tile (RSGPU_HybridTrace)
   int hybrid_surv_cap = 2048;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)
-  int probe_dpt = 1;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
+  int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM

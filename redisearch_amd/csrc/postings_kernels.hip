@@ -503,46 +503,78 @@ __global__ __launch_bounds__(256) void intersect_probe_kernel(ListView v, uint8_
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n0 = v.len[0];
   const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  // (end of round 3, from hybrid_tile_kernel: the first level of the window-end searches in list 1 -- 64 positions that depend on
+  // the list's length alone -- is requested together with the tile's doc ids; the searches stop one level early (a window up
+  // to 64 entries wider at either end instead of one more dependent round trip); the window is staged with up to eight loads
+  // per lane in flight; a lane's searches in LDS are fixed-length and advance in step)
+  uint32_t lvl1 = 0;
+  const bool pre1 = v.n > 1 && v.len[1] > 64;
+  if (pre1) {
+    const uint32_t step = (v.len[1] + 63) / 64, p = (lane + 1) * step - 1;
+    lvl1 = v.ids[1][p < v.len[1] ? p : v.len[1] - 1];
+  }
   bool hit[DPT];
   uint32_t xc[DPT];  // shared frame
 #pragma unroll
   for (int k = 0; k < DPT; k++) {
     const uint32_t i = i_first + k * 256 + threadIdx.x;
     hit[k] = i < n0;
-    xc[k] = hit[k] ? shared_id(v, 0, i) : 0u;
+    xc[k] = shared_id(v, 0, hit[k] ? i : n0 - 1);
   }
+  const uint32_t x_first = shared_id(v, 0, i_first), x_next = shared_id(v, 0, i_next < n0 ? i_next : n0 - 1);
   for (int l = 1; l < v.n; l++) {
     const uint32_t *__restrict__ a = v.ids[l];
     const uint32_t nl = v.len[l];
-    if (wave == 0) {
+    if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
       bool u0;
-      const uint32_t r = wave_lower_bound(a, nl, to_list_frame(shared_id(v, 0, i_first), v.add[l], &u0), lane);
-      if (lane == 0) w_lo = r;
-    } else if (wave == 1) {
+      uint32_t rlo, rhi;
+      wave_lower_bound_range(a, nl, to_list_frame(x_first, v.add[l], &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+      if (lane == 0) w_lo = rlo;
+    } else if (wave == 1) {  // its end: at or above lower_bound(first driver of the next tile)
       bool u1;
-      const uint32_t r = i_next < n0 ? wave_lower_bound(a, nl, to_list_frame(shared_id(v, 0, i_next), v.add[l], &u1), lane) : nl;
-      if (lane == 0) w_hi = r;
+      uint32_t rlo, rhi = nl;
+      if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, v.add[l], &u1), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+      if (lane == 0) w_hi = rhi;
     }
     __syncthreads();
     const uint32_t lo = w_lo;
-    const uint32_t hi = w_hi;  // every candidate x of this workgroup has lower_bound(x) in [lo, hi]; a[hi] > x
+    const uint32_t hi = w_hi;  // every candidate x of this workgroup has lower_bound(x) in [lo, hi]
     const uint32_t span = hi - lo;
     if (span <= WIN) {
-      for (uint32_t o = threadIdx.x; o < span; o += 256) win[o] = a[lo + o];
+      for (uint32_t base = 0; base < span; base += 8 * 256) {
+        uint32_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t o = base + j * 256 + threadIdx.x;
+          t[j] = a[lo + (o < span ? o : span - 1)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t o = base + j * 256 + threadIdx.x;
+          if (o < span) win[o] = t[j];
+        }
+      }
       __syncthreads();
+      uint32_t xl[DPT], b[DPT];
+      bool under[DPT];
+#pragma unroll
+      for (int k = 0; k < DPT; k++) {
+        xl[k] = to_list_frame(xc[k], v.add[l], &under[k]);  // this list's frame
+        b[k] = 0;
+      }
+      uint32_t rem = span;
+      while (rem > 1) {
+        const uint32_t half = rem >> 1;
+#pragma unroll
+        for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
+        rem -= half;
+      }
 #pragma unroll
       for (int k = 0; k < DPT; k++) {
         const uint32_t i = i_first + k * 256 + threadIdx.x;
-        bool under;
-        const uint32_t x = to_list_frame(xc[k], v.add[l], &under);  // this list's frame
-        uint32_t b = 0, e = span;
-        while (b < e) {
-          const uint32_t mid = b + ((e - b) >> 1);
-          if (win[mid] < x) b = mid + 1;
-          else e = mid;
-        }
-        const bool m = hit[k] && !under && b < span && win[b] == x;
-        if (hit[k]) pos[(size_t)(l - 1) * n0 + i] = lo + b;
+        if (span && win[b[k]] < xl[k]) b[k]++;
+        const bool m = hit[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
+        if (hit[k]) pos[(size_t)(l - 1) * n0 + i] = lo + b[k];
         hit[k] = m;
       }
     } else {

@@ -43,6 +43,32 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
   return lo + (uint32_t)__popcll(__ballot(less));
 }
 
+// wave_lower_bound cut short and started early: the 64-ary narrowing WITHOUT its last probe -- *lo_out <=
+// lower_bound(x) <= *hi_out, at most 64 apart -- because the caller stages a window anyway and a window up to 64 entries wider
+// at either end costs nothing, while the last probe is one more dependent memory round trip; and with the first level's
+// probes -- 64 positions that depend on the list's length alone -- REQUESTED before the value searched for is known
+// (use_first: `first` = a[(lane + 1) * ceil(n / 64) - 1], anything past the end), so that the tile's first doc id and the
+// probes travel together.
+__device__ __forceinline__ void wave_lower_bound_range(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
+                                                       uint32_t first, bool use_first, uint32_t *lo_out, uint32_t *hi_out) {
+  uint32_t lo = 0, hi = n;  // answer in [lo, hi]
+  bool level1 = use_first;
+  while (hi - lo > 64) {
+    const uint32_t step = (hi - lo + 63) / 64;
+    const uint32_t p = lo + (lane + 1) * step - 1;
+    const uint32_t v = level1 ? first : a[p < hi ? p : hi - 1];
+    level1 = false;
+    const bool less = p < hi ? v < x : false;
+    const uint32_t c = (uint32_t)__popcll(__ballot(less));
+    const uint32_t nlo = lo + c * step;
+    const uint32_t nhi = nlo + step - 1 < hi ? nlo + step - 1 : hi;
+    lo = nlo < hi ? nlo : hi;
+    hi = nhi;
+  }
+  *lo_out = lo;
+  *hi_out = hi;
+}
+
 // id i of list l in the frame the lists of a query share
 __device__ __forceinline__ uint32_t shared_id(const ListView &v, int l, uint32_t i) {
   return (uint32_t)((long long)v.ids[l][i] + v.add[l]);

@@ -94,7 +94,7 @@ def test_wide_probe_tiles_on_long_driving_lists(shape, dpt):
     try:
         n = check_intersection(lists_o)
     finally:
-        lib.RSGPU_SetTuning(b"probe_dpt", 1)
+        lib.RSGPU_SetTuning(b"probe_dpt", 4)
     if shape == "dense_equal":
         assert n == len(ls[0])
 
