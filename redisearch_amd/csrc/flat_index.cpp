@@ -1167,7 +1167,10 @@ int FlatIndex::coalesce_linger_us() const {
   // (~6 TB/s over the bytes a pass reads: the int8 shadow's when it serves the queries)
   const size_t row_bytes = shadow_ == 2 && scan_tuning().two_stage ? sstride_ + 8 : stride_;
   const double pass_us = (double)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * (double)row_bytes / 6.0e6;
-  return (int)std::min(300.0, std::max(20.0, 0.05 * pass_us));
+  // (the wait ends as soon as the expected callers are back; the bound only matters when they are not: 8 % of a pass, at least
+  // the ~50 us a caller needs to wake up, merge and fan out again -- 5 % / 20 us left two-shard handles alternating between a
+  // group of five and a group of three)
+  return (int)std::min(400.0, std::max(50.0, 0.08 * pass_us));
 }
 
 VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams *qp, VecSimQueryReply_Order order) {
@@ -1222,7 +1225,10 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
       if (err && !j->reply) j->err = err;
       j->done = true;
     }
-    co_.last_b = (uint32_t)batch.size();
+    // how many callers there are: the ones this pass answered -- on their way back with their next query -- AND the ones
+    // that arrived while it ran.  With the pass's own size alone two half-size groups can alternate for ever (each group's
+    // leader sees its "expected" number right away and never waits for the other group to come back): half the throughput.
+    co_.last_b = (uint32_t)std::min<size_t>(batch.size() + co_.waiting.size(), kMqMaxQueries);
     co_.busy = false;
   }
   co_.cv.notify_all();

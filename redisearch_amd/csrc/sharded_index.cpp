@@ -117,7 +117,12 @@ static void worker_main(Shard *s) {
       } catch (...) {
         err = std::current_exception();
       }
-      s->last_b = (uint32_t)batch.size();
+      {  // the callers there are = the ones answered just now + the ones queued meanwhile (see FlatIndex::topk)
+        std::lock_guard<std::mutex> g(s->mu);
+        size_t queued = 0;
+        while (queued < s->q.size() && s->q[queued].topk) queued++;
+        s->last_b = (uint32_t)std::min<size_t>(batch.size() + queued, kMqMaxQueries);
+      }
       for (Task &t : batch) {
         if (err && !t.topk->reply) t.topk->err = err;
         task_done(t.done, std::string());

@@ -1,15 +1,27 @@
 #!/bin/bash
-# round 3, call q: coalesced two-stage passes over the int8 shadow -- parity, then the callers bench with the shadow leg
+# round 3, call q: the coalescers' expectation = callers answered + callers queued meanwhile (two half-size groups alternated on
+# the sharded handle): tests, the two-shard bench, the single-index bench with its concurrent-callers extra
 R="$GRAFT_REPO_ROOT"; cd "$R" && mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_coalesce.py tests/test_gpu_two_stage.py tests/test_gpu_fullsize.py -x -q -p no:cacheprovider -k "not oracle_full" > gpurun_out/r03q_tests.txt 2>&1; echo "tests rc=$?"
-tail -8 gpurun_out/r03q_tests.txt
-timeout 900 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batched-extra --no-hybrid-extra > gpurun_out/r03q_callers.json 2> gpurun_out/r03q_callers.err; echo "bench rc=$?"
-python - <<'PY'
+rocm-smi --showuniqueid 2>/dev/null | grep -i unique | head -2
+timeout 900 python -m pytest tests/test_gpu_coalesce.py tests/test_gpu_coalesce_types.py tests/test_gpu_sharded.py tests/test_gpu_concurrency.py -q -p no:cacheprovider --maxfail=10 > gpurun_out/r03q_tests.txt 2>&1; echo "tests rc=$?"
+tail -4 gpurun_out/r03q_tests.txt
+for rep in 1 2; do
+RSGPU_BENCH_OVERSUBSCRIBE=1 timeout 600 python3 bench.py --gpus 2 --steps 20 --warmup 5 --rows 2000000 > gpurun_out/r03q_bench_g2_$rep.json 2> gpurun_out/r03q_bench_g2.err
+python3 - <<PY
 import json
-d = json.loads(open("gpurun_out/r03q_callers.json").read().strip().splitlines()[-1])
-c = d["config"]["concurrent_callers"]
-for k in ("8_threads", "16_threads"):
-    r = c[k]; print(k, {x: (round(r[x], 3) if isinstance(r[x], float) else r[x]) for x in r if x in ("qps", "x_single_stream", "queries_per_pass", "p50_ms", "multi_query_scan_ms", "bit_identical_to_serial")})
-print(json.dumps(c.get("with_int8_shadow_two_stage"), indent=0)[:2500])
-print(json.dumps(d["config"].get("two_stage_exact_scan_extra"))[:600])
+d = json.load(open("gpurun_out/r03q_bench_g2_$rep.json"))
+print("g2", d["value"], json.dumps(d["config"].get("concurrent_callers"))[:500])
+PY
+done
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r03q_bench.json 2> gpurun_out/r03q_bench.err; echo "bench rc=$?"
+python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r03q_bench.json"))
+cc = d["config"]["concurrent_callers"]
+print("value", d["value"])
+for t in (1, 2, 4, 8, 16):
+    r = cc["%d_threads" % t]
+    print(t, "qps %.0f x %.2f per pass %.2f p50 %.2f same %s" % (r["qps"], r["x_single_stream"], r["queries_per_pass"], r["p50_ms"], r["bit_identical_to_serial"]))
+sh = cc.get("with_int8_shadow_two_stage", {})
+print({k: (v.get("qps"), v.get("queries_per_pass")) for k, v in sh.items() if isinstance(v, dict)})
 PY
