@@ -1567,6 +1567,8 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   const int device = a->lists[0]->device;
   FlatIndex *f = want_knn ? a->index->flat : nullptr;
   if (f && f->device != device) throw std::runtime_error("RSGPU_HybridQuery: postings and index live on different devices");
+  if (want_score && a->table->device != device)
+    throw std::runtime_error("RSGPU_HybridQuery: postings and document table live on different devices");
   if (f && f->key_bytes != 4) throw std::runtime_error("RSGPU_HybridQuery: FLOAT64 indexes are not served by the fused path");
   a->n_hits = a->n_top = a->n_knn = 0;
   HIP_CHECK(hipSetDevice(device));
