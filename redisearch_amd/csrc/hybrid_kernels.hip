@@ -9,18 +9,19 @@
 //   hybrid_tile_kernel    one workgroup per tile of 1 024 consecutive entries of the driving (shortest) list:
 //                           * the probe of intersect_probe_kernel -- the tile's window of every other list staged in LDS,
 //                             a binary search per driver -- with the match positions kept in registers;
-//                           * the score of every hit (score_one: the scorers of score_kernel, same bits) and the tile's
-//                             top-N by (descending score, ascending doc id) -- every hit counts the hits that beat it;
+//                           * the hits compacted into LDS and scored one per lane (score_one: the scorers of score_kernel,
+//                             same bits); the tile's top-N by (descending score, ascending doc id) -- every hit counts the
+//                             hits that beat it and writes itself to the slot of its rank;
 //                           * the hits that have a vector, compacted in LDS, their distances -- Op<> / the reduction tree of
 //                             scan_kernel: the bits of the gather -- and the tile's top-k by (distance, doc id);
-//                           * per tile and at FIXED slots: hit count, N (score key, driver index), k (distance key, driver
-//                             index).  No atomics, no fences, no workgroup reads what another one wrote.
-//   hybrid_reduce_kernel  one workgroup of 1 024 per branch: the best entry of every thread's share of the tiles' lists, the
-//                         k-th of those as a bound, the entries at or below it ranked in LDS; the winners -- key, doc id --
-//                         and the hit count go to pinned host memory.  No tickets, no fences either.
+//                           * per tile and at FIXED slots: hit count, N (score key, doc id), k (distance key, doc id), each
+//                             list sorted.  No atomics, no fences, no workgroup reads what another one wrote.
+//   hybrid_reduce_kernel  one workgroup of 1 024 per branch: the best of every thread's tiles' FIRST entries, a bound from
+//                         their k-th, the lists of the few tiles whose first entry passes it ranked in LDS; the winners --
+//                         key, doc id -- and the hit count go to pinned host memory.  No tickets, no fences either.
 //
-// Exactness: the composites are total orders (the driver index is monotone in the doc id: ties break the way the staged
-// selections break them, by hit order), so "top-N of the per-tile top-Ns" IS the top-N.  Compiled with -ffp-contract=off
+// Exactness: the composites are total orders (ties break the way the staged selections break them: by hit order, which is
+// doc-id order), so "top-N of the per-tile top-Ns" IS the top-N.  Compiled with -ffp-contract=off
 // like postings_kernels.hip: a score has the bits score_kernel gives it; a distance the bits of scan_kernel<GATHER> (explicit
 // fmaf chains in scan_ops.hpp, nothing left to contract).
 #include <hip/hip_runtime.h>
@@ -38,7 +39,7 @@ constexpr int kHybDpt = 4;                        // drivers per thread
 constexpr uint32_t kHybTile = 256 * kHybDpt;      // drivers per workgroup
 constexpr uint32_t kHybMaxTiles = 16384;
 
-// (descending score, ascending driver index): key = ~d2key(score) ascending, then the index
+// (descending score, ascending doc id): key = ~d2key(score) ascending, then the doc id in the frame the lists share
 struct SKey {
   uint64_t k;
   uint32_t i;
