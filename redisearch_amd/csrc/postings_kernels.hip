@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void decode_blocks_wave_kernel(const uint8_t *
 }
 
 // ---- intersection ----------------------------------------------------------------------------------
-// (lower_bound, wave_lower_bound, shared_id, to_list_frame: postings_ops.hpp)
+// (lower_bound, wave_lower_bound_range, shared_id, to_list_frame: postings_ops.hpp)
 
 // Intersection probe.  The 256 candidates of a workgroup are consecutive in the (sorted) driving list, so their
 // matches in another list lie in ONE window [lower_bound(first), lower_bound(first of the next workgroup)): the

@@ -22,33 +22,13 @@ __device__ __forceinline__ uint32_t lower_bound(const uint32_t *__restrict__ a, 
   return lo;
 }
 
-// lower_bound by a whole wavefront: 64 evenly spaced probes per step narrow [lo, hi) 64-fold, so a 5 M-entry list
-// takes 4 dependent memory round trips instead of 23 (the probes of one step are independent loads)
-__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ a, uint32_t n, uint32_t x,
-                                                     uint32_t lane) {
-  uint32_t lo = 0, hi = n;  // answer in [lo, hi]
-  while (hi - lo > 64) {
-    const uint32_t step = (hi - lo + 63) / 64;                 // >= 2
-    const uint32_t p = lo + (lane + 1) * step - 1;             // last element of this lane's sub-range
-    const bool less = p < hi ? a[p] < x : false;               // sub-ranges beyond hi: "not less"
-    const unsigned long long m = __ballot(less);
-    const uint32_t c = (uint32_t)__popcll(m);                  // sub-ranges entirely below x (a is sorted: a prefix)
-    const uint32_t nlo = lo + c * step;
-    const uint32_t nhi = nlo + step - 1 < hi ? nlo + step - 1 : hi;  // a[nlo+step-1] >= x (or the range ends)
-    lo = nlo < hi ? nlo : hi;
-    hi = nhi;
-  }
-  const uint32_t p = lo + lane;
-  const bool less = p < hi ? a[p] < x : false;
-  return lo + (uint32_t)__popcll(__ballot(less));
-}
-
-// wave_lower_bound cut short and started early: the 64-ary narrowing WITHOUT its last probe -- *lo_out <=
-// lower_bound(x) <= *hi_out, at most 64 apart -- because the caller stages a window anyway and a window up to 64 entries wider
-// at either end costs nothing, while the last probe is one more dependent memory round trip; and with the first level's
-// probes -- 64 positions that depend on the list's length alone -- REQUESTED before the value searched for is known
-// (use_first: `first` = a[(lane + 1) * ceil(n / 64) - 1], anything past the end), so that the tile's first doc id and the
-// probes travel together.
+// lower_bound by a whole wavefront: 64 evenly spaced probes per step narrow [lo, hi) 64-fold, so a 5 M-entry list takes 3 dependent
+// memory round trips instead of 23 (the probes of one step are independent loads) -- WITHOUT a last probe that would pin the
+// position down: *lo_out <= lower_bound(x) <= *hi_out, at most 64 apart, because the callers stage a window anyway and a window
+// up to 64 entries wider at either end costs nothing, while the last probe is one more dependent round trip; and with the first
+// level's probes -- 64 positions that depend on the list's length alone -- REQUESTED before the value searched for is known
+// (use_first: `first` = a[(lane + 1) * ceil(n / 64) - 1], anything past the end), so that a tile's first doc id and the probes
+// travel together.
 __device__ __forceinline__ void wave_lower_bound_range(const uint32_t *__restrict__ a, uint32_t n, uint32_t x, uint32_t lane,
                                                        uint32_t first, bool use_first, uint32_t *lo_out, uint32_t *hi_out) {
   uint32_t lo = 0, hi = n;  // answer in [lo, hi]
