@@ -240,3 +240,37 @@ def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():
         lib.RSGPU_SetTuning(b"hybrid_surv_cap", 2048)
     hq.run()
     assert S.hybrid_path() == 1
+
+
+@pytest.mark.parametrize("scorer", SCORERS)
+def test_top_n_against_the_cpu_oracle_directly(scorer):
+    """not through the staged pipeline: the oracle's intersection (find_consensus restated), its scoring loop (default.c restated,
+    oracle_score_flat) and the reference's order (score descending, equal scores by doc id: result_processor.c:849) against the
+    two-launch answer -- ids exact, scores bit-exact (BM25STD.TANH: 1e-12, the libm tanh)"""
+    n_docs = 400_000
+    lists_o, rng = corpus(n_docs, (0.35, 0.5, 0.45), 7)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
+    doc_score = rng.uniform(0.2, 1.0, n_docs + 1).astype(np.float32)
+    max_freq = np.maximum(doc_len // 7, 1).astype(np.uint32)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists_o]
+    bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists_o]
+    w = [1.0, 0.5, 2.0]
+    avg = float(doc_len[1:].mean())
+    r = S.hybrid_query(g, table, scorer, idf, bidf, w, n_docs, avg, top_n=25, root_weight=0.7)
+    assert S.hybrid_path() == 1
+    oi, of, _ = O.intersect(lists_o)
+    sel = oi.astype(np.int64)
+    # the intersection's children -- and so the terms of the scorers' sums -- come in the iterator's order: by estimated size,
+    # ascending and stable (intersection.rs:94-119); fp64 addition is not associative, (a + c) + b is not (a + b) + c
+    it = np.argsort([l.unique_docs for l in lists_o], kind="stable")
+    os_ = O.score_flat(scorer, of[it], doc_len[sel], max_freq[sel], doc_score[sel], [idf[i] for i in it], [bidf[i] for i in it],
+                       [w[i] for i in it], 0.7, n_docs, avg)
+    order = np.lexsort((oi, -os_))[:25]
+    assert r["n_hits"] == len(oi)
+    assert r["top"][0].tolist() == oi[order].tolist()
+    if scorer == "BM25STD.TANH":
+        assert np.allclose(r["top"][1], os_[order], rtol=1e-12, atol=0)
+    else:
+        assert np.array_equal(r["top"][1], os_[order])
