@@ -87,10 +87,22 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   const bool l2_shape = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric == VecSimMetric_L2 && !multi &&
                         k > 0 && k <= 1024 && scan_tuning().gemm_qs && scan_tuning().batch_mfma &&
                         gemm_qs_supported((uint32_t)(stride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
+  // FLOAT32 indexes WITHOUT a shadow (round 4): the matrix-core passes read the fp32 rows themselves and round them to bf16 on
+  // their way from LDS to the matrix pipe (gemm_qs_f32_kernel) -- HBM traffic is what the exact scan reads anyway, nothing is
+  // stored next to the index.  Every bound is widened by the rounding band (gemm_qs_f32_rel: 2u + u^2 of |x||q| + the two
+  // summation orders; cosine: |x| = |q| = 1; L2: per row through the half norms, as the 16-bit L2 passes), the survivors are
+  // re-scored from the same fp32 rows with the single-query scan's arithmetic -> bit-identical to single queries
+  const bool f32_shape = type == VecSimType_FLOAT32 && !via_shadow && !(s8g_shape && scan_tuning().two_stage) && !multi && k > 0 &&
+                         k <= 1024 && (metric == VecSimMetric_Cosine || metric == VecSimMetric_L2) && scan_tuning().gemm_qs &&
+                         scan_tuning().gemm_qs_f32 && scan_tuning().batch_mfma && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) &&
+                         batch_rescore_supported((uint32_t)(stride_ / 16));
+  bool via_f32 = f32_shape && (size_t)n_rows_ + stage_n_ > (1u << 19);
+  const bool l2_any = l2_shape || (f32_shape && metric == VecSimMetric_L2);
   // (an unlocked look at the size: at worst a small index computes norms it does not use, or a large one answers this batch
   // eight queries per pass -- the decision proper is taken under the lock below)
-  bool via_l2 = l2_shape && (size_t)n_rows_ + stage_n_ > (1u << 19) && ensure_half_norms();
-  const bool gemm_ok = via_shadow || via_l2 || (s8g_shape && type == VecSimType_FLOAT32) ||
+  bool via_l2 = l2_any && (size_t)n_rows_ + stage_n_ > (1u << 19) && ensure_half_norms();
+  if (f32_shape && metric == VecSimMetric_L2) via_f32 = via_f32 && via_l2;
+  const bool gemm_ok = via_shadow || via_l2 || via_f32 || (s8g_shape && type == VecSimType_FLOAT32) ||
                        ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi &&
                         k > 0 && k <= 4096);
   // FLOAT16 IP / cosine indexes that carry the int8 shadow (shadow_ == 3): the filter passes run on the int8 matrix
@@ -98,8 +110,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // from the fp16 rows with the single-query scan's arithmetic -> ids and distances bit-identical to single queries
   bool via_shadow8 = !via_shadow && s8g_shape && ensure_shadow8g();
   // a FLOAT32 index has no MFMA form of its own: without the int8 rows (too small, a non-finite row, ...) -> single queries
-  const bool f32_needs_s8g = type == VecSimType_FLOAT32 && !via_shadow;
-  const float slack = via_shadow ? 2.0f * 4e-3f : 0.0f;  // eps: FlatIndex::two_stage_topk
+  const bool f32_needs_s8g = type == VecSimType_FLOAT32 && !via_shadow && !f32_shape;
+  // eps of the fp16 shadow: FlatIndex::two_stage_topk; of the bf16 pass over normalised fp32 rows: |x|, |q| <= 1 + 1e-3
+  const float slack = via_shadow ? 2.0f * 4e-3f : (via_f32 && metric == VecSimMetric_Cosine ? 2.0f * 1.002f * gemm_qs_f32_rel(dim) : 0.0f);
   auto single = [&](size_t qi) {
     VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
     counts_out[qi] = r->len;
@@ -159,13 +172,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // (rows added since ensure_shadow8g, or a corpus the single-query path serves anyway: the plain fp16 passes)
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
     if (via_l2 && (hn_built_ < n || hn_bad_ || n <= (1u << 19))) via_l2 = false;
-    if ((f32_needs_s8g && !via_shadow8) || (l2_shape && !via_l2)) {
+    if (via_f32 && (n <= (1u << 19) || (metric == VecSimMetric_L2 && !via_l2))) via_f32 = false;
+    if ((f32_needs_s8g && !via_shadow8) || (l2_any && !via_l2) || (f32_shape && !via_f32)) {
       g.unlock();
       all_single();
       return;
     }
     // the corpus the MFMA passes read
-    const int g_type = via_shadow ? KT_F16 : (via_shadow8 ? KT_I8 : ktype);
+    const int g_type = via_shadow ? KT_F16 : (via_shadow8 ? KT_I8 : ktype);  // (via_f32: KT_F32 rows, launch_gemm_qs_f32)
     const size_t g_stride = via_shadow ? sstride_ : (via_shadow8 ? s8g_stride() : stride_);
     if (!n) {
       for (size_t qi = 0; qi < n_queries; qi++) counts_out[qi] = 0;
@@ -196,8 +210,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // (the exact k-th distance of those rows), the pass over the next 3/16 does it again, and the last
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
-    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && gemm_qs_supported(stride16);
-    if ((via_shadow || via_shadow8 || via_l2) && !use_qs) {  // small corpora: the single-query path is already cheap
+    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && (via_f32 ? gemm_qs_f32_supported(stride16) : gemm_qs_supported(stride16));
+    if ((via_shadow || via_shadow8 || via_l2 || via_f32) && !use_qs) {  // small corpora: the single-query path is already cheap
       g.unlock();
       all_single();
       return;
@@ -205,7 +219,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // FLOAT32 rows have no tiled GEMM for the sample bound: the first int8 phase runs over n0 rows with tau = +inf -- every
     // (row, query) pair becomes a candidate -- and the first bound is the K-th shadow distance among them + the band
     // (L2 passes the same way: the tiled GEMM computes 1 - x.q only)
-    const bool phase0 = (via_shadow8 && type == VecSimType_FLOAT32) || via_l2;
+    const bool phase0 = (via_shadow8 && type == VecSimType_FLOAT32) || via_l2 || via_f32;
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
@@ -226,7 +240,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         seen = std::max(seen, e);
         from = e;
       }
-      expect_total *= via_shadow ? 18 : (via_shadow8 ? 48 : 6);  // (a shadow's error band multiplies the survivors)
+      expect_total *= via_shadow || via_f32 ? 18 : (via_shadow8 ? 48 : 6);  // (a shadow's error band multiplies the survivors)
       if (phase0) expect_total += n0;
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
@@ -234,6 +248,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       BatchScratch &sc = tls_batch[sl];
       sc.queries.ensure((size_t)kBatch * stride_);
       if (via_shadow || via_shadow8) sc.queries16.ensure((size_t)kBatch * (via_shadow ? sstride_ : s8g_stride()));
+      if (via_f32) sc.queries16.ensure((size_t)kBatch * (stride_ / 2));
       sc.tau.ensure(kBatch);
       if (via_shadow8) {
         sc.qscale.ensure(kBatch);
@@ -264,7 +279,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         const uint32_t grid = gemm_qs_grid(e - from);
         qs_grid_max = std::max(qs_grid_max, grid);
         const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
-        while (sub_cap < (via_shadow ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
+        while (sub_cap < (via_shadow || via_f32 ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
         if (phase0 && from == 0)  // every row of the first phase lands in a sub-list: 16 per lane and tile
           while (sub_cap < 16u * (((e + 31) / 32 + grid - 1) / grid)) sub_cap *= 2;
         seen = std::max(seen, e);
@@ -294,6 +309,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       const uint8_t *g_queries = sc.queries.p;
       if (via_shadow) {  // fp16 (RNE) copy of the normalised queries, made by the kernel that makes the shadow rows
         launch_shadow_rows(sc.queries.p, stride_, (uint32_t)dim, 0, kBatch, sc.queries16.p, sstride_, c->stream);
+        g_queries = sc.queries16.p;
+      }
+      if (via_f32) {  // bf16 copies of the (normalised) queries, rounded as the pass rounds the rows
+        launch_convert_queries_bf16(sc.queries.p, stride_, (uint32_t)dim, kBatch, sc.queries16.p, stride_ / 2, c->stream);
         g_queries = sc.queries16.p;
       }
       const float *slack_q = nullptr, *qscale = nullptr;
@@ -359,8 +378,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           uint32_t from = 0;
           for (size_t ph = 0; ph < phase_end.size(); ph++) {
             const uint32_t e = phase_end[ph];
-            if (!launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
-                                c->stream, qscale, l2_hn, l2_hq))
+            if (!(via_f32 ? launch_gemm_qs_f32(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
+                                               c->stream, l2_hn, l2_hq)
+                          : launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
+                                           c->stream, qscale, l2_hn, l2_hq)))
               throw std::runtime_error("batched pass: the matrix-core kernel refused a row shape the route was gated on");
             launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
                                 sc.cand.p, cand_cap, ph > 0, c->stream, via_l2 ? &rb : nullptr);
@@ -373,7 +394,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
                            sc.cand.p, cand_cap, c->stream);
         }
-        if (via_shadow || via_shadow8 || via_l2) {
+        if (via_shadow || via_shadow8 || via_l2 || via_f32) {
           // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
           // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
@@ -419,6 +440,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           continue;
         }
         const uint32_t got = std::min(h_n[i], kk);
+        if (got < kk) {  // fewer winners than rows asked for: NaN distances the filter passes drop -- the exact scan ranks them last
+          redo.push_back(qi);
+          continue;
+        }
         // the device hands back the exact top-k SET (selected by (key, row)); reply order: (score, label) ascending
         res.resize(got);
         for (uint32_t j = 0; j < got; j++)

@@ -193,6 +193,7 @@ class FlatIndex {
   // without an MFMA form): fills job->reply (or job->err) of every job.  Replies are bit-identical to topk()'s.
   void topk_pass(TopkJob *const *jobs, size_t n_jobs);
   bool mq_capable(size_t k) const;   // the multi-query scan can serve a top-k query of this index
+  bool coalescible(size_t k) const;  // ... and concurrent calls are worth coalescing (knobs "coalesce" / "coalesce_min_mib", corpus size)
   // how long a pass may wait for the callers of the previous pass to come back (knob, or 5 % of a pass: 20..300 us)
   int coalesce_linger_us() const;
   bool prefer_adhoc(size_t subset, size_t k, bool initial_check);
@@ -294,7 +295,11 @@ class FlatIndex {
   bool hn_bad_ = false;
   // relative error band of the pass against the exact scan, per unit of |x|^2/2 + |q|^2/2 (DESIGN.md section 3 "L2 on the
   // matrix cores"): the stored norms are shrunk by (1 - rel/2)
-  float hn_rel() const { return (float)dim * 9.5367431640625e-07f + 1.9073486328125e-06f; }  // dim 2^-20 + 2^-19
+  // (FLOAT32 rows go through the matrix cores as bf16: twice gemm_qs_f32_rel of |x||q| <= hn + hq on top, kernels.hpp)
+  float hn_rel() const {
+    return (float)dim * 9.5367431640625e-07f + 1.9073486328125e-06f  // dim 2^-20 + 2^-19
+           + (type == VecSimType_FLOAT32 ? 2.0f * gemm_qs_f32_rel(dim) : 0.0f);
+  }
   bool ensure_half_norms();                          // true: d_hnorm_ covers every row, all finite
   float half_sq_norm_host(const void *blob) const;   // |q|^2 / 2 of a query blob of the index's type (fp32)
   bool two_stage_topk(QueryCtx *c, uint32_t n, uint32_t k, std::vector<Hit> &out);
@@ -310,7 +315,6 @@ class FlatIndex {
   // normalised fp32 query -> its int8 copy, scale, |q|^2 and the error band of the shadow distance (two_stage_topk's
   // analysis); false: the band bounds nothing for this query (zero / non-finite query, non-finite rows)
   bool shadow8_query(const float *qf, int8_t *q8, float *sq, float *qn2, float *eps) const;
-  bool coalescible(size_t k) const;  // the multi-query scan applies and concurrent calls are worth coalescing (knob, corpus size)
   // ---- the coalescer: queries that arrive while a pass is in flight join the next pass -----------------------------
   // Leader / follower: the caller at the head of the queue runs the pass for everybody queued behind it (at most
   // kMqMaxQueries), on its own thread; the others sleep until their reply is there or it is their turn to lead.  A new

@@ -424,6 +424,264 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_kernel(QsArgs g) {
     g.sub_count[((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + r) * 2 + h] = cur[nb];
 }
 
+// ---- FLOAT32 rows on the matrix cores, no stored shadow (round 4) --------------------------------------------------------
+// The same query-stationary pass over the fp32 corpus itself: the tiles go global -> LDS by DMA as they are (fp32), and a
+// wave turns the 32 bytes of a fragment (8 fp32 of one row) into the 16 bytes the MFMA wants with four v_cvt_pk_bf16_f32 on
+// its way from LDS to the matrix pipe -- bf16 keeps fp32's exponent range, so no row can overflow or flush, whatever the
+// metric.  HBM traffic is the 4 bytes per element the exact scan reads anyway; nothing is stored next to the index.  The
+// pass is a FILTER: |x~.q~ - x.q| <= (2u + u^2) |x||q| with u = 2^-9 (both operands rounded to nearest) plus the two fp32
+// summation orders; the host widens every threshold by that band and the survivors are re-scored from the same fp32 rows with
+// the single-query scan's arithmetic (batch_rescore_kernel) -> ids and distances bit-identical to VecSimIndex_TopKQuery.
+// A 32-row tile of fp32 rows is 96 KiB at dim 768, so the ring's slots hold a K-PART of a tile: 32 rows x KH k-steps (16
+// elements each) = 2 KiB x KH (48 KiB at KH = 24); the accumulators live across the NPART = KS / KH parts of a tile and the
+// filter epilogue runs behind the last one.  Fragment (ksl, lane): row r = lane & 31, chunks 4 ksl + 2 h + {0, 1} of the
+// slot row, XOR-ed with (r & 15) as in the 16-bit kernel: a b128 read's sixteen-lane groups hold sixteen different r & 15,
+// hence sixteen different chunks of one 256-byte bank line -- conflict free.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (one v_cvt_pk_bf16_f32, round to nearest even; left to the compiler so that it sees the instruction next to the MFMAs)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(uint32_t a, uint32_t b) {
+  const f32x2 f = {__uint_as_float(a), __uint_as_float(b)};
+  const bf16x2 v = __builtin_convertvector(f, bf16x2);
+  uint32_t r;
+  __builtin_memcpy(&r, &v, 4);
+  return r;
+}
+
+template <int KS, int KH, int NS, int QB, bool L2>
+__global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
+  static_assert(KS % KH == 0, "a tile is a whole number of K parts");
+  constexpr int NW = 8 / QB;          // waves per workgroup
+  constexpr int NPART = KS / KH;      // ring slots per 32-row tile
+  constexpr int RC = 4 * KH;          // 16-byte chunks per slot row (fp32: four per k-step)
+  constexpr int SROW = 4 * KS;        // ... per corpus row
+  constexpr int SLOT = 32 * RC;       // chunks per slot
+  constexpr int PPW = 2 * KH / NW;    // 1 KiB DMA pieces per wave per slot (a slot is 2 KH pieces)
+  constexpr int STEP = KH / PPW;      // a piece is issued every STEP k-steps
+  static_assert(PPW * NW == 2 * KH && STEP * PPW == KH && RC % 16 == 0, "shape");
+  constexpr int NA = QB == 2 ? 64 : 32;
+  constexpr int NORMC = L2 ? 16 : 0;
+  __shared__ u4 smem[NS * SLOT + NS * NORMC];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t r = lane & 31, h = lane >> 5;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+
+  // the wave's queries (bf16, made by convert_queries_bf16_kernel) as B fragments for the whole K, as in gemm_qs_kernel
+  u4 Q[QB][KS];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) Q[nb][ks] = g.queries[(size_t)(32 * QB * w + 32 * nb + r) * (2 * KS) + 2 * ks + h];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      if (nb * KS + ks < NA) asm volatile("" : "+a"(Q[nb][ks]));
+    }
+  float tau[QB], thr[QB], qsc[QB];
+  uint32_t cur[QB];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++) {
+    cur[nb] = 0;
+    tau[nb] = g.tau[32 * QB * w + 32 * nb + r];
+    float u = 1.0f - tau[nb];
+    float mag = fabsf(tau[nb]) + fabsf(u);
+    qsc[nb] = 1.0f;
+    if constexpr (L2) {
+      qsc[nb] = g.hq[32 * QB * w + 32 * nb + r];
+      u = qsc[nb] - 0.5f * tau[nb];
+      mag = fabsf(qsc[nb]) + fabsf(0.5f * tau[nb]) + fabsf(u);
+    }
+    thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : (tau[nb] == __builtin_inff() ? -__builtin_inff() : u - mag * 2.4e-7f);
+  }
+
+  const uint32_t n = g.row_end - g.row_begin;
+  const uint32_t n_tiles = (n + 31) / 32;
+  const uint32_t mine = n_tiles > blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t n_slots = mine * NPART;
+  const uint32_t row_first = opaque_s(g.row_begin + blockIdx.x * 32);
+  const uint32_t row_step = opaque_s(gridDim.x * 32);
+  const uint32_t row_end = opaque_s(g.row_end);
+
+  const uint32_t wu = __builtin_amdgcn_readfirstlane(w);
+  uint32_t poff[PPW];  // the lane's source offset inside a (tile, part): bytes from the part's first byte of the tile's first row
+#pragma unroll
+  for (int p = 0; p < PPW; p++) {
+    const uint32_t s = 64 * (PPW * w + p) + lane;
+    const uint32_t rr = s / RC, cc = s - rr * RC;
+    poff[p] = 16u * (rr * SROW + (cc ^ (rr & 15u)));
+  }
+  // slot j = (tile j / NPART, part j % NPART) of this workgroup
+  auto issue_piece = [&](uint32_t j, uint32_t stage, int p) {
+    const uint32_t i = NPART == 1 ? j : j / NPART, part = NPART == 1 ? 0 : j - i * NPART;
+    const uint32_t row0 = row_first + i * row_step;
+    __attribute__((address_space(3))) void *lp =
+        (__attribute__((address_space(3))) void *)(smem + stage * SLOT + 64 * (PPW * wu + p));
+    const char *src = reinterpret_cast<const char *>(g.rows) + (size_t)row0 * (SROW * 16) + part * (RC * 16);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + opaque(poff[p])), lp, 16, 0, 2);
+  };
+  // L2: the tile's half norms ride with EVERY slot of the tile (256 bytes next to 2 KiB x KH: the ladder below stays one
+  // count per slot); the epilogue reads them from the last part's stage
+  auto issue_norms = [&](uint32_t j, uint32_t stage) {
+    if constexpr (L2) {
+      if (wu == 0) {
+        const uint32_t i = NPART == 1 ? j : j / NPART;
+        const uint32_t row0 = row_first + i * row_step;
+        __attribute__((address_space(3))) void *lp = (__attribute__((address_space(3))) void *)(smem + NS * SLOT + stage * NORMC);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g.hnorm + row0 + opaque(lane)), lp, 4, 0, 0);
+      }
+    }
+  };
+  auto issue = [&](uint32_t j, uint32_t stage) {
+    issue_norms(j, stage);
+#pragma unroll
+    for (int p = 0; p < PPW; p++) issue_piece(j, stage, p);
+  };
+
+  uint32_t fill = 0;
+#pragma unroll
+  for (int p = 0; p < NS - 1; p++)
+    if ((uint32_t)p < n_slots) {
+      issue(p, fill);
+      fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+  uint32_t stage = 0;
+  for (uint32_t i = 0; i < mine; i++) {
+    typename AccT<KT_BF16>::t acc[QB];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++) acc[nb][e] = 0;
+    u4 hnv[L2 ? 4 : 1];
+#pragma unroll
+    for (int part = 0; part < NPART; part++) {
+      const uint32_t j = i * NPART + part;
+      const uint32_t younger = n_slots - 1 - j < (uint32_t)(NS - 2) ? n_slots - 1 - j : (uint32_t)(NS - 2);
+      if (L2 && wu == 0) {
+        switch (younger) {
+          case 0: wait_vm<0>(); break;
+          case 1: wait_vm<PPW + 1>(); break;
+          case 2: wait_vm<2 * (PPW + 1)>(); break;
+          case 3: wait_vm<3 * (PPW + 1)>(); break;
+          case 4: wait_vm<4 * (PPW + 1)>(); break;
+          case 5: wait_vm<5 * (PPW + 1)>(); break;
+          default: wait_vm<6 * (PPW + 1)>(); break;
+        }
+      } else {
+        switch (younger) {
+          case 0: wait_vm<0>(); break;
+          case 1: wait_vm<PPW>(); break;
+          case 2: wait_vm<2 * PPW>(); break;
+          case 3: wait_vm<3 * PPW>(); break;
+          case 4: wait_vm<4 * PPW>(); break;
+          case 5: wait_vm<5 * PPW>(); break;
+          default: wait_vm<6 * PPW>(); break;
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      const bool refill = j + NS - 1 < n_slots;
+      // (opaque: the eight fragment addresses of a slot are one v_xad_u32 each, not eight registers held across the loop)
+      const uint32_t lr = opaque(lane);
+      // chunk (4 ksl + 2 h + e) ^ (r & 15) = 16 (ksl >> 2) + ((4 (ksl & 3) + e) ^ (2 h ^ (r & 15)))
+      const uint32_t t16 = 16u * ((2u * (lr >> 5)) ^ (lr & 15u));
+      const uint32_t tbase = lds_base + 16u * (stage * SLOT + (lr & 31u) * RC);
+      const uint32_t nstage = opaque_s(stage);
+      stage = stage + 1 == NS ? 0 : stage + 1;
+      auto frag_addr = [&](int ksl, int e) { return tbase + ((64u * (uint32_t)(ksl & 3) + 16u * (uint32_t)e) ^ t16); };
+      constexpr int PF = QB == 1 ? 2 : 3;  // fragments (two reads each) ahead
+      u4 xa[PF], xb[PF];
+#pragma unroll
+      for (int ksl = 0; ksl < PF && ksl < KH; ksl++) {
+        xa[ksl] = lds_read16(frag_addr(ksl, 0), ksl >> 2);
+        xb[ksl] = lds_read16(frag_addr(ksl, 1), ksl >> 2);
+      }
+#pragma unroll
+      for (int ksl = 0; ksl < KH; ksl++) {
+        const int ahead = KH - 1 - ksl < PF - 1 ? KH - 1 - ksl : PF - 1;
+        wait_lgkm(2 * ahead);
+        __builtin_amdgcn_sched_barrier(0);
+        u4 f;
+        f[0] = cvt_pk_bf16(xa[ksl % PF][0], xa[ksl % PF][1]);
+        f[1] = cvt_pk_bf16(xa[ksl % PF][2], xa[ksl % PF][3]);
+        f[2] = cvt_pk_bf16(xb[ksl % PF][0], xb[ksl % PF][1]);
+        f[3] = cvt_pk_bf16(xb[ksl % PF][2], xb[ksl % PF][3]);
+#pragma unroll
+        for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<KT_BF16>(f, Q[nb][part * KH + ksl], acc[nb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ksl + PF < KH) {
+          xa[ksl % PF] = lds_read16(frag_addr(ksl + PF, 0), (ksl + PF) >> 2);
+          xb[ksl % PF] = lds_read16(frag_addr(ksl + PF, 1), (ksl + PF) >> 2);
+        }
+        if constexpr (L2) {
+          if (part == NPART - 1 && ksl == KH - 1) {
+            const uint32_t nbase = lds_base + 16u * (NS * SLOT + nstage * NORMC + (opaque(lane) >> 5));
+#pragma unroll
+            for (int eg = 0; eg < 4; eg++) hnv[eg] = lds_read16(nbase + 32u * eg, 0);
+          }
+        }
+        if (ksl % STEP == (STEP > 1 ? 1 : 0) && refill) {
+          if (ksl / STEP == 0) issue_norms(j + NS - 1, fill);
+          issue_piece(j + NS - 1, fill, ksl / STEP);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (refill) fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    if constexpr (L2) {
+      wait_lgkm(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[nb][e] -= __uint_as_float(hnv[e >> 2][e & 3]);
+    }
+    const uint32_t lr = opaque(lane);
+    const uint32_t xr0 = row_first + i * row_step + 4 * (lr >> 5);
+#pragma unroll
+    for (int nb = 0; nb < QB; nb++) {
+      float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
+      m = max3(m, acc[nb][15], acc[nb][15]);
+      if (m >= thr[nb]) {
+        uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+#pragma unroll
+        for (int eg = 0; eg < 4; eg++) {
+          const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+          if (gm >= thr[nb]) {
+#pragma unroll
+            for (int el = 0; el < 4; el++) {
+              const float d = L2 ? 2.0f * (qsc[nb] - acc[nb][4 * eg + el]) : 1.0f - acc[nb][4 * eg + el];
+              const uint32_t xr = xr0 + 8 * eg + el;
+              // (the test on the accumulator IS the filter -- a superset of d <= tau by the margin in thr, which is all a
+              // filter pass owes: the survivors are re-scored; tau itself is not kept in a register)
+              if (acc[nb][4 * eg + el] >= thr[nb] && xr < row_end) {
+                if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                cur[nb]++;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+    g.sub_count[((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + r) * 2 + h] = cur[nb];
+}
+
+// queries (fp32 rows, qstride bytes apart) -> bf16 rows of 2 * dim bytes padded to 16 (round to nearest even, the
+// conversion the pass applies to the corpus): one wavefront per query
+__global__ __launch_bounds__(256) void convert_queries_bf16_kernel(const float *__restrict__ q, uint32_t qstride4, uint32_t dim,
+                                                                   uint32_t n_queries, uint32_t *__restrict__ out, uint32_t ostride4) {
+  const uint32_t lane = threadIdx.x & 63, qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qi >= n_queries) return;
+  for (uint32_t c = lane; c < ostride4; c += 64) {
+    const float a = 2 * c < dim ? q[(size_t)qi * qstride4 + 2 * c] : 0.0f, b = 2 * c + 1 < dim ? q[(size_t)qi * qstride4 + 2 * c + 1] : 0.0f;
+    out[(size_t)qi * ostride4 + c] = cvt_pk_bf16(__float_as_uint(a), __float_as_uint(b));
+  }
+}
+
 // One workgroup per query: concatenate its 2 * n_wg sub-lists (row, distance bits) into
 // cand[q*cand_cap ..] as (row, orderable key) and set cand_count[q] (cand_cap+1 when a sub-list or the
 // list itself overflowed -> the select flags the query and the host redoes it).
@@ -529,6 +787,48 @@ bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t s
     return launch_qs_dt<KT_I8>(g, stride16, grid, s);
   }
   return dtype == KT_F16 ? launch_qs_dt<KT_F16>(g, stride16, grid, s) : launch_qs_dt<KT_BF16>(g, stride16, grid, s);
+}
+
+// ---- FLOAT32 rows (gemm_qs_f32_kernel): stride16 = fp32 chunks per row -----------------------------------------------------
+bool gemm_qs_f32_supported(uint32_t stride16) {
+  return stride16 == 192 || stride16 == 128 || stride16 == 96 || stride16 == 64 || stride16 == 32;
+}
+
+namespace {
+template <int KS, int KH, int NS>
+void launch_qs_f32_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
+  const bool wide = scan_tuning().gemm_qs_f32 == 2;  // 2: four waves x 64 queries (one 512-register wave per SIMD; A/B knob)
+  if (g.hnorm) {
+    if (wide) hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 2, true>), dim3(grid), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 1, true>), dim3(grid), dim3(512), 0, s, g);
+  } else {
+    if (wide) hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 2, false>), dim3(grid), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 1, false>), dim3(grid), dim3(512), 0, s, g);
+  }
+}
+}  // namespace
+
+bool launch_gemm_qs_f32(const void *rows, const void *queries_bf16, uint32_t stride16, uint32_t row_begin, uint32_t row_end,
+                        const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *hnorm,
+                        const float *hq) {
+  if (row_end <= row_begin || !gemm_qs_f32_supported(stride16) || (hnorm != nullptr) != (hq != nullptr)) return false;
+  QsArgs g{(const u4 *)rows, (const u4 *)queries_bf16, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, nullptr, hnorm, hq};
+  const uint32_t grid = gemm_qs_grid(row_end - row_begin);
+  switch (stride16) {  // KS = dim / 16 k-steps; slots of 2 KiB x KH, the ring as deep as ~144 KiB of LDS allows
+    case 192: launch_qs_f32_shape<48, 24, 3>(g, grid, s); return true;
+    case 128: launch_qs_f32_shape<32, 16, 4>(g, grid, s); return true;
+    case 96: launch_qs_f32_shape<24, 24, 3>(g, grid, s); return true;
+    case 64: launch_qs_f32_shape<16, 16, 4>(g, grid, s); return true;
+    case 32: launch_qs_f32_shape<8, 8, 8>(g, grid, s); return true;
+    default: return false;
+  }
+}
+
+void launch_convert_queries_bf16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, void *out, size_t ostride,
+                                 hipStream_t s) {
+  if (!n_queries) return;
+  hipLaunchKernelGGL(convert_queries_bf16_kernel, dim3((n_queries + 3) / 4), dim3(256), 0, s, (const float *)queries,
+                     (uint32_t)(qstride / 4), dim, n_queries, (uint32_t *)out, (uint32_t)(ostride / 4));
 }
 
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,

@@ -71,6 +71,8 @@ struct ScanTuning {
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
+  int gemm_qs_f32 = 1;     // FLOAT32 indexes: batched / coalesced queries through the matrix cores, rows converted to bf16 in flight
+                           // (gemm_qs_f32_kernel; 0 = off: the exact multi-query scan; 2 = four waves x 64 queries, A/B knob)
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
@@ -217,6 +219,19 @@ bool launch_gemm_qs(int dtype, const void *rows, const void *queries, uint32_t s
                     hipStream_t s, const float *qscale = nullptr, const float *hnorm = nullptr, const float *hq = nullptr);
 // (hnorm + hq: an L2 pass over KT_F16 / KT_BF16 rows -- hnorm[row] = |x|^2 / 2 (fp32, readable up to row_end + 95), hq[q] =
 // |q|^2 / 2; the candidates carry 2 (hq + hnorm - x.q) and tau bounds that)
+// The same pass over FLOAT32 rows, converted to bf16 on their way from LDS to the matrix pipe (gemm_qs_f32_kernel): no
+// stored shadow, HBM traffic = the fp32 rows.  stride16 = fp32 chunks per row in {32, 64, 96, 128, 192} (dim 128 .. 768);
+// queries_bf16: [256] bf16 rows of 2 * dim bytes (launch_convert_queries_bf16).  A filter: |emitted - exact| <=
+// gemm_qs_f32_rel(dim) * |x||q| for IP / cosine distances, twice that for L2 (hnorm / hq as for launch_gemm_qs).
+bool gemm_qs_f32_supported(uint32_t stride16);
+bool launch_gemm_qs_f32(const void *rows, const void *queries_bf16, uint32_t stride16, uint32_t row_begin, uint32_t row_end,
+                        const float *tau, uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s,
+                        const float *hnorm = nullptr, const float *hq = nullptr);
+void launch_convert_queries_bf16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, void *out, size_t ostride,
+                                 hipStream_t s);
+// |x~.q~ - x.q| / (|x||q|) of that pass against the exact scan: both operands rounded to bf16 (u = 2^-9, to nearest:
+// 2u + u^2), the MFMA's and the scan's fp32 summation orders (dim 2^-24 each, of sum |x_i q_i| (1 + u)^2), 2 % to spare
+inline float gemm_qs_f32_rel(size_t dim) { return (0.00390625f + 3.9e-6f + (float)dim * 1.2e-7f * 1.004f) * 1.02f; }
 // append != 0: the sub-lists are appended behind the cand_count[q] candidates already there
 void launch_compact_cand(const uint32_t *sub_count, const void *sub_cand, uint32_t sub_cap, uint32_t n_wg,
                          uint32_t *cand_count, void *cand, uint32_t cand_cap, int append, hipStream_t s,

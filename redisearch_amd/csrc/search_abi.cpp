@@ -935,6 +935,7 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
         continue;
       }
       // a bare term as the whole query: the intersection of one list
+      if (!st.empty()) throw std::runtime_error("RSGPU_EvalTreeNodes: subtrees left over (the last node must be the root)");
       std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
       h->device = device;
       combine_and(h.get(), {t.s}, c.c, sc, c->h_counters, -1, 0);

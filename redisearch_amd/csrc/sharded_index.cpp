@@ -92,7 +92,12 @@ static void worker_main(Shard *s) {
         while (c < s->q.size() && s->q[c].topk) c++;
         return c;
       };
-      if (s->q.front().topk) {
+      // (the "coalesce" / "coalesce_min_mib" knobs and the multi-query scan's shapes gate the batching here as they do in
+      // FlatIndex::topk: a shard they rule out answers one task at a time, without the wait)
+      if (s->q.front().topk && !s->flat->coalescible(s->q.front().topk->k)) {
+        batch.push_back(std::move(s->q.front()));
+        s->q.pop_front();
+      } else if (s->q.front().topk) {
         const size_t expect = std::min<uint32_t>(s->last_b, kMqMaxQueries);
         if (leading() < expect && !s->stop) {
           const int us = s->flat->coalesce_linger_us();

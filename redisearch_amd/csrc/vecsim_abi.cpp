@@ -693,6 +693,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_dma")) scan_tuning().gemm_dma = value;
   else if (!strcmp(key, "filter_select")) scan_tuning().filter_select = value;
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
+  else if (!strcmp(key, "gemm_qs_f32")) scan_tuning().gemm_qs_f32 = value;
   else if (!strcmp(key, "qs_phases")) scan_tuning().qs_phases = value;
   else if (!strcmp(key, "qs_force_i8")) scan_tuning().qs_force_i8 = value;
   else if (!strcmp(key, "shards")) scan_tuning().shards = value;

@@ -76,7 +76,7 @@ def lint(path):
     out, cur, buf = {}, None, []
     with open(path) as f:
         for ln, raw in enumerate(f, 1):
-            m = re.match(r"^(_ZN5rsgpu\S*gemm_qs_kernel\S*):", raw)
+            m = re.match(r"^(_ZN5rsgpu\S*gemm_qs_(?:f32_)?kernel\S*):", raw)
             if m:
                 cur, buf = m.group(1), []
                 continue
