@@ -432,7 +432,7 @@ def extra_concurrent_callers(lib, V, index, queries, k, rows, dim, single_qps):
                        "(examples/concurrent_callers.c, pthreads)" % (rows, dim),
            "single_stream_qps": single_qps,
            "eight_threads_without_coalescer": dict(qps=total0 / el0, **_lat_summary(lat0))}
-    for threads in (1, 2, 4, 8, 16):
+    for threads in (1, 2, 4, 8, 16, 32, 64):
         V.coalesce_stats(reset=True)
         lib.RSGPU_ResetProfile()
         lib.RSGPU_SetProfiling(1)
@@ -443,6 +443,12 @@ def extra_concurrent_callers(lib, V, index, queries, k, rows, dim, single_qps):
         rec = dict(qps=total / el, x_single_stream=total / el / single_qps, queries=int(total),
                    queries_per_pass=st["queries"] / max(st["passes"], 1), passes=st["passes"],
                    multi_query_passes=st["mq_passes"], bit_identical_to_serial=bool(same), **_lat_summary(lat))
+        if st["wide_passes"]:   # more than sixteen callers: one matrix-core filter pass + exact re-scoring for all of them
+            launches_w, ms_w, _ = V.scan_profile()
+            rec["wide_passes"] = st["wide_passes"]
+            rec["queries_per_wide_pass"] = st["wide_queries"] / st["wide_passes"]
+            rec["wide_pass_device_ms"] = ms_w / max(launches_w, 1)
+            rec["wide_pass_hbm_frac"] = rows * dim * 4 / max(ms_w / max(launches_w, 1), 1e-9) / 1e6 / HBM_PEAK_GBS
         if st["mq_passes"]:
             ms = st["mq_device_ns"] / st["mq_passes"] / 1e6
             rec["multi_query_scan_ms"] = ms
@@ -477,8 +483,46 @@ def extra_concurrent_callers(lib, V, index, queries, k, rows, dim, single_qps):
     out["qps"] = out["8_threads"]["qps"]
     out["x_single_stream"] = out["8_threads"]["x_single_stream"]
     out["p50_ms"] = out["8_threads"]["p50_ms"]
-    out["bit_identical_to_serial"] = all(out["%d_threads" % t]["bit_identical_to_serial"] for t in (1, 2, 4, 8, 16))
+    out["bit_identical_to_serial"] = all(out["%d_threads" % t]["bit_identical_to_serial"] for t in (1, 2, 4, 8, 16, 32, 64))
+    out["wide_pass_kernel"] = ("more than 16 queued callers: gemm_qs_f32_kernel (fp32 tiles by DMA, rounded to bf16 on the way to the "
+                               "matrix cores, 256 queries stationary) + exact re-scoring from the fp32 rows; no stored shadow")
     return out
+
+
+def extra_batched_f32(lib, V, index, rows, dim):
+    """The rest of K5: 256 queries per corpus pass on the PLAIN fp32 headline index (RediSearch's default type) through
+    RSGPU_FlatIndex_TopKBatch -- the matrix-core filter pass reads the fp32 rows themselves (no shadow; gemm_qs_f32_kernel),
+    survivors are re-scored exactly.  Replies must be bit-identical to VecSimIndex_TopKQuery."""
+    k, batch, reps = 100, 256, 8
+    qs = philox_host_rows(V, QUERY_BASE + 5000, batch * 4, dim).reshape(4, batch, dim)
+    index.topk_batch(qs[0], k)  # allocations
+    V.coalesce_stats(reset=True)
+    lib.RSGPU_ResetProfile()
+    lib.RSGPU_SetProfiling(1)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        ids, sc, cnt = index.topk_batch(qs[(i + 1) % 4], k)
+    el = time.perf_counter() - t0
+    lib.RSGPU_SetProfiling(0)
+    launches, ms, _ = V.scan_profile()
+    mq = V.coalesce_stats()["mq_passes"]
+    dev_ms = ms / max(launches, 1)
+    same = True
+    for i in (0, 85, 170, 255):
+        si, ss = index.topk_query(qs[reps % 4][i], k).results()
+        same &= si.tolist() == ids[i].tolist() and ss.tolist() == sc[i].tolist()
+    flops = 2.0 * batch * dim * rows
+    return {"workload": "%dx%d fp32 FLAT COSINE top-%d on the plain index (no shadow), batch=%d queries per corpus pass "
+                        "(RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
+            "device_ms_per_pass": dev_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": reps * batch / el,
+            "matrix_core_passes": int(launches), "exact_multi_query_scan_passes_instead": int(mq),
+            "hbm_gbs": rows * dim * 4 / dev_ms / 1e6, "hbm_frac": rows * dim * 4 / dev_ms / 1e6 / HBM_PEAK_GBS,
+            "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
+            "kernel": "gemm_qs_f32_kernel (fp32 tiles global->LDS by DMA in K-part ring slots, v_cvt_pk_bf16_f32 on the way to "
+                      "v_mfma_f32_32x32x16_bf16, 256 queries register-stationary) + progressive thresholds + batch_rescore_kernel "
+                      "(the single-query scan's arithmetic) + per-query select; HIP events around the whole device pipeline of a pass",
+            "bit_identical_to_single_queries": bool(same),
+            "algorithmic_bytes_per_pass": rows * dim * 4}
 
 
 def extra_batched(lib, V, rows, dim):
@@ -921,6 +965,11 @@ def main():
                 extras["concurrent_callers"] = extra_concurrent_callers(lib, V, index, queries, k, rows, dim, a.steps / elapsed)
             except Exception as e:
                 extras["concurrent_callers"] = {"error": repr(e)}
+        if not a.no_batched_extra and a.metric == "cosine":
+            try:
+                extras["batched_mfma_f32"] = extra_batched_f32(lib, V, index, rows, dim)
+            except Exception as e:
+                extras["batched_mfma_f32"] = {"error": repr(e)}
     cpu = None
     if single and rank == 0 and not a.no_cpu_baseline:
         try:

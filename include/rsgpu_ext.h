@@ -117,6 +117,11 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
  * pass whose batched selection overflowed and was redone through the radix levels. */
 void RSGPU_GetCoalesceStats(uint64_t out[8]);
 void RSGPU_ResetCoalesceStats(void);
+/* ... of those passes, the WIDE ones (round 4): more than sixteen calls queued on an index whose batched queries are exact
+ * (FLOAT32 cosine / L2 with or without a shadow, FLOAT16 / BFLOAT16 L2) share ONE matrix-core filter pass + exact
+ * re-scoring, up to 256 per pass, replies bit-identical to serial ones.  out[0] wide passes, [1] queries they served.
+ * Knob "coalesce_wide" (default 1).  Reset by RSGPU_ResetCoalesceStats. */
+void RSGPU_GetWidePassStats(uint64_t out[2]);
 /* like RSGPU_GetLastScanKernel, for the multi-query scan */
 const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap);
 /* Two-stage (shadow) scans of this process since the last reset: out[0] attempts, [1] answered by the two-stage path,
@@ -143,6 +148,9 @@ const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
  *   "shard_replicas" with "shards": every shard holds the whole corpus, queries go to one of them round-robin
  *   "coalesce"       1 (default): concurrent VecSimIndex_TopKQuery calls on one index share corpus passes (see
  *                    RSGPU_GetCoalesceStats); 0: every call scans on its own stream
+ *   "coalesce_wide"  1 (default): more than sixteen queued calls share one matrix-core pass (RSGPU_GetWidePassStats)
+ *   "gemm_qs_f32"    1 (default): FLOAT32 indexes answer batches / wide passes on the matrix cores, rows rounded to bf16 in
+ *                    flight + exact re-scoring (no stored shadow); 0: the exact multi-query scan, sixteen per pass
  *   "coalesce_linger_us"  -1 (default: 5 % of a pass, 20..300 us); "coalesce_min_mib" 64: smaller corpora never coalesce
  *   "vmm"            1 (default): row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual
  *                    range (no copy, no transient 2x HBM); 0: hipMalloc + full copy on every growth */

@@ -6,7 +6,10 @@
 // the fp32 summation order (MFMA k-order vs the scan's lane order), i.e. inside the parity tolerance.
 #include <algorithm>
 #include <cmath>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <vector>
 
 #include "flat_index.hpp"
 
@@ -62,13 +65,80 @@ struct BatchScratch {
   Dev<uint32_t> sub_count;
   Pinned hq, h_rows, h_keys, h_n, h_over, h_tau, h_l2;
 };
-// two slots: the host builds the replies of batch b while the device works on batch b+1
-thread_local BatchScratch tls_batch[2];
+// two slots: the host builds the replies of batch b while the device works on batch b+1.  Pooled, not per thread: the
+// coalescer's wide passes (FlatIndex::topk_pass_wide) run on whichever caller leads, and every thread that ever led would
+// otherwise keep ~150 MB of device scratch of its own.
+struct BatchScratchPair {
+  BatchScratch s[2];
+};
+std::mutex g_batch_pool_mu;
+std::vector<std::unique_ptr<BatchScratchPair>> g_batch_pool;
+
+struct BatchLease {
+  std::unique_ptr<BatchScratchPair> p;
+  explicit BatchLease(int device) {
+    {
+      std::lock_guard<std::mutex> g(g_batch_pool_mu);
+      for (size_t i = 0; i < g_batch_pool.size(); i++)
+        if (g_batch_pool[i]->s[0].device == device) {
+          p = std::move(g_batch_pool[i]);
+          g_batch_pool.erase(g_batch_pool.begin() + (long)i);
+          break;
+        }
+    }
+    if (!p) {
+      p.reset(new BatchScratchPair());
+      p->s[0].device = p->s[1].device = device;
+    }
+  }
+  ~BatchLease() {
+    std::lock_guard<std::mutex> g(g_batch_pool_mu);
+    if (g_batch_pool.size() < 4) g_batch_pool.push_back(std::move(p));  // (more concurrent batches than that free theirs)
+  }
+  BatchScratch &operator[](int sl) { return p->s[sl]; }
+};
 
 }  // namespace
 
+void release_batch_pool() {
+  std::vector<std::unique_ptr<BatchScratchPair>> drop;
+  {
+    std::lock_guard<std::mutex> g(g_batch_pool_mu);
+    drop.swap(g_batch_pool);
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  for (auto &p : drop) {
+    (void)hipSetDevice(p->s[0].device);
+    p.reset();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+// The routes of topk_batch whose replies are bit-identical to single queries (exact re-scoring behind the matrix-core
+// filter): what the coalescer may put concurrent VecSimIndex_TopKQuery calls through.  Mirrors the gating below.
+bool FlatIndex::wide_pass_capable(size_t k) const {
+  const ScanTuning &t = scan_tuning();
+  if (!t.coalesce_wide || !t.batch_mfma || !t.gemm_qs || multi || !k || k > 1024 || key_bytes != 4) return false;
+  if (__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) <= (1u << 19)) return false;
+  if (!batch_rescore_supported((uint32_t)(stride_ / 16))) return false;
+  if (type == VecSimType_FLOAT32) {
+    if (shadow_ == 1 && metric == VecSimMetric_Cosine && t.two_stage && dim <= 1024 && dim % 8 == 0 && gemm_qs_supported((uint32_t)(sstride_ / 16)))
+      return true;  // fp16 shadow
+    if (s8g_enabled() && metric != VecSimMetric_L2 && t.two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) && s8g_stride() / 16 <= 64 && !s_bad_)
+      return true;  // int8 rows with one scale
+    return t.gemm_qs_f32 && (metric == VecSimMetric_Cosine || metric == VecSimMetric_L2) && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) &&
+           !(metric == VecSimMetric_L2 && hn_bad_);
+  }
+  return (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric == VecSimMetric_L2 && !hn_bad_ &&
+         gemm_qs_supported((uint32_t)(stride_ / 16));
+}
+
 void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
-                           size_t *counts_out) {
+                           size_t *counts_out, const size_t *k_each) {
+  // k_each (the coalescer's wide pass): query qi wants its k_each[qi] <= k best; the passes select with k, every query takes
+  // the leading k_each[qi] of its winners in (key, row) order -- the composite order makes a top-K a prefix of a top-K'
+  auto k_of = [&](size_t qi) { return k_each ? std::min(k_each[qi], k) : k; };
   // FLOAT32 cosine indexes that carry an fp16 shadow (two-stage exact scan, flat_index.cpp): the MFMA filter pass
   // runs over the shadow with a 2*eps wider threshold, the survivors are re-scored from the fp32 rows with the
   // single-query scan's arithmetic -> ids and distances bit-identical to 256 single queries
@@ -114,7 +184,12 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // eps of the fp16 shadow: FlatIndex::two_stage_topk; of the bf16 pass over normalised fp32 rows: |x|, |q| <= 1 + 1e-3
   const float slack = via_shadow ? 2.0f * 4e-3f : (via_f32 && metric == VecSimMetric_Cosine ? 2.0f * 1.002f * gemm_qs_f32_rel(dim) : 0.0f);
   auto single = [&](size_t qi) {
-    VecSimQueryReply *r = topk((const uint8_t *)queries + qi * elem_bytes_, k, nullptr, BY_SCORE);
+    VecSimQueryReply *r;
+    {  // (not through the coalescer: this may BE the coalescer's leader)
+      flush_if_needed();
+      std::shared_lock<std::shared_mutex> g(mu);
+      r = topk_locked((const uint8_t *)queries + qi * elem_bytes_, k_of(qi), nullptr, BY_SCORE);
+    }
     counts_out[qi] = r->len;
     for (size_t j = 0; j < r->len; j++) {
       ids_out[qi * k + j] = r->results[j].id;
@@ -135,7 +210,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       TopkJob jobs[kMqMaxQueries];
       TopkJob *ptr[kMqMaxQueries];
       for (size_t i = 0; i < cnt; i++) {
-        jobs[i] = TopkJob{(const uint8_t *)queries + (q0 + i) * elem_bytes_, k, nullptr, BY_SCORE};
+        jobs[i] = TopkJob{(const uint8_t *)queries + (q0 + i) * elem_bytes_, k_of(q0 + i), nullptr, BY_SCORE};
         ptr[i] = &jobs[i];
       }
       struct Cleanup {  // (a throwing pass may leave some replies behind)
@@ -190,14 +265,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     const int n_slots = n_batches > 1 ? 2 : 1;
     CtxLease lease0(device), lease1(device);
     QueryCtx *ctxs[2] = {lease0.c, lease1.c};
-    for (int sl = 0; sl < n_slots; sl++) {
-      BatchScratch &sc = tls_batch[sl];
-      if (sc.device != device) {
-        sc.~BatchScratch();
-        new (&sc) BatchScratch();
-        sc.device = device;
-      }
-    }
+    BatchLease tls_batch(device);
     const uint32_t kk = (uint32_t)std::min<size_t>(k, n);
     const uint8_t *g_rows = via_shadow ? d_shadow_ : (via_shadow8 ? s8g_rows() : d_rows_);
     const uint32_t stride16 = (uint32_t)(g_stride / 16);
@@ -445,14 +513,24 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           continue;
         }
         // the device hands back the exact top-k SET (selected by (key, row)); reply order: (score, label) ascending
-        res.resize(got);
-        for (uint32_t j = 0; j < got; j++)
-          res[j] = VecSimQueryResult{(size_t)label_at(h_rows[(size_t)i * kk + j]), score_of(h_keys[(size_t)i * kk + j])};
+        uint32_t take = got;
+        if (k_each && k_of(qi) < got) {  // the leading k_each of the winners in the selection's own order
+          take = (uint32_t)k_of(qi);
+          std::vector<std::pair<uint32_t, uint32_t>> kr(got);
+          for (uint32_t j = 0; j < got; j++) kr[j] = {h_keys[(size_t)i * kk + j], h_rows[(size_t)i * kk + j]};
+          std::sort(kr.begin(), kr.end());
+          res.resize(take);
+          for (uint32_t j = 0; j < take; j++) res[j] = VecSimQueryResult{(size_t)label_at(kr[j].second), score_of(kr[j].first)};
+        } else {
+          res.resize(got);
+          for (uint32_t j = 0; j < got; j++)
+            res[j] = VecSimQueryResult{(size_t)label_at(h_rows[(size_t)i * kk + j]), score_of(h_keys[(size_t)i * kk + j])};
+        }
         std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
           return score_id_before(a.score, a.id, b.score, b.id);
         });
-        counts_out[qi] = got;
-        for (uint32_t j = 0; j < got; j++) {
+        counts_out[qi] = take;
+        for (uint32_t j = 0; j < take; j++) {
           ids_out[qi * k + j] = res[j].id;
           scores_out[qi * k + j] = res[j].score;
         }

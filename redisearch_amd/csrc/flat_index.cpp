@@ -1183,6 +1183,9 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   }
   TopkJob job{query, k, tctx, order};
   std::vector<TopkJob *> batch;
+  // how many calls a pass may hold: sixteen through the exact multi-query scan; kWidePass where the index's batches go
+  // through a matrix-core filter pass + exact re-scoring (same bits, one corpus pass for all of them)
+  const uint32_t cap = wide_pass_capable(k) ? kWidePass : kMqMaxQueries;
   {
     std::unique_lock<std::mutex> lk(co_.mu);
     co_.waiting.push_back(&job);
@@ -1197,7 +1200,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     co_.busy = true;
     // the callers of the previous pass are on their way back with their next query: give them a moment, so that the
     // passes stay full instead of alternating between one early bird and everybody else
-    const uint32_t expect = std::min<uint32_t>(co_.last_b, kMqMaxQueries);
+    const uint32_t expect = std::min<uint32_t>(co_.last_b, cap);
     if (co_.waiting.size() < expect) {
       const int us = coalesce_linger_us();
       if (us > 0) {
@@ -1209,7 +1212,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
         coalesce_stats().linger_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       }
     }
-    const size_t take = std::min<size_t>(co_.waiting.size(), kMqMaxQueries);
+    const size_t take = std::min<size_t>(co_.waiting.size(), cap);
     batch.assign(co_.waiting.begin(), co_.waiting.begin() + (long)take);
     co_.waiting.erase(co_.waiting.begin(), co_.waiting.begin() + (long)take);
   }
@@ -1228,7 +1231,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     // how many callers there are: the ones this pass answered -- on their way back with their next query -- AND the ones
     // that arrived while it ran.  With the pass's own size alone two half-size groups can alternate for ever (each group's
     // leader sees its "expected" number right away and never waits for the other group to come back): half the throughput.
-    co_.last_b = (uint32_t)std::min<size_t>(batch.size() + co_.waiting.size(), kMqMaxQueries);
+    co_.last_b = (uint32_t)std::min<size_t>(batch.size() + co_.waiting.size(), kWidePass);
     co_.busy = false;
   }
   co_.cv.notify_all();
@@ -1236,9 +1239,56 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   return job.reply;
 }
 
+// More than sixteen calls in one pass: their queries side by side through topk_batch -- a matrix-core filter pass over the
+// corpus for all of them, exact re-scoring, the usual exact selection; every caller takes the leading K of its winners.
+// Jobs the batch cannot hold (K beyond its limit) and whatever it declines are answered sixteen per exact pass.
+void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
+  std::vector<TopkJob *> wide, rest;
+  for (size_t i = 0; i < n_jobs; i++) {
+    TopkJob *j = jobs[i];
+    if (timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+    else if (!j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
+    else (wide_pass_capable(j->k) ? wide : rest).push_back(j);
+  }
+  if (wide.size() <= kMqMaxQueries) {
+    rest.insert(rest.end(), wide.begin(), wide.end());
+    wide.clear();
+  }
+  for (size_t at = 0; at < rest.size(); at += kMqMaxQueries) topk_pass(rest.data() + at, std::min<size_t>(kMqMaxQueries, rest.size() - at));
+  if (wide.empty()) return;
+  coalesce_stats().passes++;
+  coalesce_stats().queries += wide.size();
+  coalesce_stats().wide_passes++;
+  coalesce_stats().wide_queries += wide.size();
+  size_t kmax = 0;
+  for (TopkJob *j : wide) kmax = std::max(kmax, j->k);
+  std::vector<uint8_t> qbuf(wide.size() * elem_bytes_);
+  std::vector<size_t> k_each(wide.size()), ids(wide.size() * kmax), cnt(wide.size());
+  std::vector<double> sc(wide.size() * kmax);
+  for (size_t i = 0; i < wide.size(); i++) {
+    memcpy(qbuf.data() + i * elem_bytes_, wide[i]->query, elem_bytes_);
+    k_each[i] = wide[i]->k;
+  }
+  topk_batch(qbuf.data(), wide.size(), kmax, ids.data(), sc.data(), cnt.data(), k_each.data());
+  for (size_t i = 0; i < wide.size(); i++) {
+    TopkJob *j = wide[i];
+    if (timed_out(j->tctx)) {
+      j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+      continue;
+    }
+    VecSimQueryReply *r = new_reply(cnt[i], VecSim_QueryReply_OK);
+    for (size_t t = 0; t < cnt[i]; t++) r->results[t] = VecSimQueryResult{ids[i * kmax + t], sc[i * kmax + t]};
+    sort_reply(r, j->order);
+    j->reply = r;
+  }
+}
+
 void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
   if (!n_jobs) return;
-  if (n_jobs > kMqMaxQueries) throw std::runtime_error("topk_pass: more jobs than the multi-query scan has slots");
+  if (n_jobs > kMqMaxQueries) {
+    topk_pass_wide(jobs, n_jobs);
+    return;
+  }
   coalesce_stats().passes++;
   coalesce_stats().queries += n_jobs;
   flush_if_needed();

@@ -155,7 +155,7 @@ struct TopkJob {
 // What the coalescer did (RSGPU_GetCoalesceStats; bench.py's concurrent_callers sub-record).
 struct CoalesceStats {
   std::atomic<uint64_t> passes{0}, queries{0}, mq_passes{0}, mq_queries{0}, lingers{0}, linger_ns{0}, mq_device_ns{0},
-      mq_redo{0};
+      mq_redo{0}, wide_passes{0}, wide_queries{0};
 };
 CoalesceStats &coalesce_stats();
 
@@ -188,7 +188,11 @@ class FlatIndex {
   // fp16/bf16 IP/cosine run as a GEMM on the matrix cores (batch_query.cpp); everything else loops
   // over topk().
   void topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
-                  size_t *counts_out);
+                  size_t *counts_out, const size_t *k_each = nullptr);  // k_each[qi] <= k: per-query K (the coalescer's wide pass)
+  // topk_batch would answer a K = k query of this index through a matrix-core filter pass + exact re-scoring (replies
+  // bit-identical to single queries): the coalescer may then put up to kWidePass concurrent calls into one pass
+  bool wide_pass_capable(size_t k) const;
+  static constexpr uint32_t kWidePass = 256;
   // up to kMqMaxQueries queries in ONE pass over the corpus (the coalescer's pass; also what topk_batch uses for indexes
   // without an MFMA form): fills job->reply (or job->err) of every job.  Replies are bit-identical to topk()'s.
   void topk_pass(TopkJob *const *jobs, size_t n_jobs);
@@ -306,6 +310,7 @@ class FlatIndex {
   // the single-query path; the caller holds the shared lock and has flushed
   VecSimQueryReply *topk_locked(const void *query, size_t k, void *tctx, VecSimQueryReply_Order order);
   void topk_pass_mq(TopkJob *const *jobs, size_t n_jobs, uint32_t n);  // >= 2 jobs, shared lock held
+  void topk_pass_wide(TopkJob *const *jobs, size_t n_jobs);            // 17 .. kWidePass jobs through topk_batch (no lock held)
   // multi-value top-K over one key array (key_bytes wide): false = the timeout callback fired
   bool multi_walk(QueryCtx *c, const uint32_t *d_keys, uint32_t n, size_t k, void *tctx, std::vector<VecSimQueryResult> &res);
   // the same for indexes that carry the int8 shadow: ONE multi-query pass over the shadow (scan_mq_i8_kernel), the
@@ -390,6 +395,8 @@ void radix_select(QueryCtx *c, const void *d_keys, int key_bytes, uint32_t n, ui
                   std::vector<Hit> &out, Bound *upper);
 // frees the device buffers parked by the search seam's pool (search_abi.cpp)
 void release_search_pool();
+// ... and the batched path's pooled scratch (batch_query.cpp)
+void release_batch_pool();
 // k smallest (key,index) of a u32 key array: one-workgroup select for short arrays, radix levels otherwise
 void select_keys32(QueryCtx *c, const uint32_t *d_keys, uint32_t n, uint32_t k, std::vector<Hit> &out);
 // asynchronous halves of its one-sync paths (flat_index.cpp): enqueue -> [caller synchronises c->stream] -> collect

@@ -669,6 +669,12 @@ void RSGPU_GetCoalesceStats(uint64_t out[8]) {
 void RSGPU_ResetCoalesceStats(void) {
   CoalesceStats &c = coalesce_stats();
   c.passes = c.queries = c.mq_passes = c.mq_queries = c.lingers = c.linger_ns = c.mq_device_ns = c.mq_redo = 0;
+  c.wide_passes = c.wide_queries = 0;
+}
+void RSGPU_GetWidePassStats(uint64_t out[2]) {
+  if (!out) return;
+  out[0] = coalesce_stats().wide_passes.load();
+  out[1] = coalesce_stats().wide_queries.load();
 }
 const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap) {
   if (!buf || !cap) return "";
@@ -712,6 +718,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shadow8")) scan_tuning().shadow8 = value;
   else if (!strcmp(key, "coalesce")) scan_tuning().coalesce = value;
   else if (!strcmp(key, "coalesce_linger_us")) scan_tuning().coalesce_linger_us = value;
+  else if (!strcmp(key, "coalesce_wide")) scan_tuning().coalesce_wide = value;
   else if (!strcmp(key, "coalesce_min_mib")) scan_tuning().coalesce_min_mib = value;
   else if (!strcmp(key, "mq_blocks_per_cu")) scan_tuning().mq_blocks_per_cu = value;
   else if (!strcmp(key, "batch_mfma")) scan_tuning().batch_mfma = value;
@@ -724,6 +731,7 @@ int RSGPU_SetTuning(const char *key, int value) {
 void RSGPU_ReleaseWorkspaces(void) {
   CtxPool::get().drain();
   rsgpu::release_search_pool();  // parked hit-list buffers of the search seam
+  rsgpu::release_batch_pool();   // the batched path's scratch
 }
 
 }  // extern "C"

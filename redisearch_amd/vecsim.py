@@ -195,6 +195,7 @@ ABI = {
     "RSGPU_GetTwoStageStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_ShardedIndex_GetExchangeStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_GetWidePassStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_ResetCoalesceStats": (None, []),
     "RSGPU_GetLastMqScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
     "RSGPU_ResetTwoStageStats": (None, []),
@@ -569,10 +570,14 @@ def coalesce_stats(reset=False):
     """RSGPU_GetCoalesceStats as a dict."""
     a = (C.c_uint64 * 8)()
     load().RSGPU_GetCoalesceStats(a)
+    w = (C.c_uint64 * 2)()
+    load().RSGPU_GetWidePassStats(w)
     if reset:
         load().RSGPU_ResetCoalesceStats()
     names = ("passes", "queries", "mq_passes", "mq_queries", "lingers", "linger_ns", "mq_device_ns", "mq_redo")
-    return {n: int(a[i]) for i, n in enumerate(names)}
+    out = {n: int(a[i]) for i, n in enumerate(names)}
+    out["wide_passes"], out["wide_queries"] = int(w[0]), int(w[1])
+    return out
 
 
 def last_mq_scan_kernel():
