@@ -287,6 +287,52 @@ def encode_freqs_only(docs, freqs, block_entries=100):
                 offset=byte_off, bytes=out[:total], codec=2)   # RSGPU_CODEC_FREQS_ONLY
 
 
+def encode_full(docs, freqs, masks, off_bytes, block_entries=100):
+    """The same list in the reference's Full format (inverted_index/src/codec/full.rs:117-190: qint4 [delta, freq, field
+    mask, offsets length] followed by the record's offsets bytes -- the term positions as varint deltas), the default of
+    FT.CREATE without NOOFFSETS / NOFIELDS.  off_bytes: the concatenated offsets bytes of all records, record r owning
+    freqs[r] of them (every position delta here is below 128: one varint byte each).  Pure numpy, byte-identical to the
+    oracle's block writer (tests/test_bench_contract_cpu.py)."""
+    docs = np.ascontiguousarray(docs, np.uint64)
+    n = docs.size
+    idx = np.arange(n)
+    delta = np.zeros(n, np.uint64)
+    delta[1:] = docs[1:] - docs[:-1]
+    delta[idx % block_entries == 0] = 0
+    assert n == 0 or int(delta.max()) <= 0xFFFFFFFF
+    osz = np.ascontiguousarray(freqs, np.uint64)          # one offsets byte per occurrence
+    fields = [delta, np.ascontiguousarray(freqs, np.uint64), np.ascontiguousarray(masks, np.uint64), osz]
+    assert int(osz.sum()) == len(off_bytes)
+
+    def nbytes(v):
+        return (1 + (v > 0xFF) + (v > 0xFFFF) + (v > 0xFFFFFF)).astype(np.int64)
+    lens = [nbytes(f) for f in fields]
+    head = 1 + lens[0] + lens[1] + lens[2] + lens[3]
+    rec = head + osz.astype(np.int64)
+    off = np.cumsum(rec) - rec
+    total = int(off[-1] + rec[-1]) if n else 0
+    out = np.zeros(max(total, 1), np.uint8)
+    ctrl = np.zeros(n, np.int64)
+    for i in range(4):
+        ctrl |= (lens[i] - 1) << (2 * i)
+    out[off] = ctrl.astype(np.uint8)
+    at = off + 1
+    for i in range(4):
+        for b in range(4):
+            m = lens[i] > b
+            out[at[m] + b] = ((fields[i][m] >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+        at = at + lens[i]
+    if len(off_bytes):
+        first_tail = np.cumsum(osz.astype(np.int64)) - osz.astype(np.int64)
+        pos = np.repeat(at - first_tail, osz.astype(np.int64)) + np.arange(len(off_bytes))
+        out[pos] = off_bytes
+    starts = np.arange(0, n, block_entries)
+    ends = np.minimum(starts + block_entries, n)
+    byte_off = np.concatenate([off[starts], [total]]).astype(np.uint64) if n else np.zeros(1, np.uint64)
+    return dict(first=docs[starts], last=docs[ends - 1] if n else docs[:0], num_entries=(ends - starts).astype(np.uint32),
+                offset=byte_off, bytes=out[:total], codec=0)   # RSGPU_CODEC_FULL
+
+
 def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
     """Independent check of timed answers without the oracle's corpus: the rows a query returned are REGENERATED on the
     host from (seed, label) and re-scored in fp64; the K-th distance must also beat 2048 other regenerated rows."""
@@ -603,18 +649,117 @@ def extra_batched(lib, V, rows, dim):
         idx.free()
 
 
-def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
+def _term_list(rng, n_docs, df):
+    """A term's postings: membership as an independent Bernoulli(df / n_docs) draw per document -- sampled through its gaps
+    (geometric), which is the same process as hashing every (term, doc) pair at a hundredth of the draws --
+    frequency 1 + Geometric(0.5) capped at 255, one field-mask byte and one position delta (< 128) per occurrence."""
+    gaps = rng.geometric(df / n_docs, int(df * 1.02) + 4096)
+    docs = np.cumsum(gaps, dtype=np.uint64)
+    docs = docs[docs <= n_docs]
+    freqs = np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32)
+    masks = (1 << rng.integers(0, 8, docs.size)).astype(np.uint32)
+    offs = rng.integers(1, 128, int(freqs.sum())).astype(np.uint8)
+    return docs, freqs, masks, offs
+
+
+def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3):
+    """A STREAM of distinct queries: n_a x n_b term pairs over independent lists and a query vector of its
+    own per query, issued round-robin so that consecutive queries share neither a list nor candidate rows.  One cycle touches
+    every list's decoded arrays (240 MB at 4 + 4 lists) and 16 x 77 MB of rows -- several times the 256 MiB Infinity Cache --
+    so every query reads its postings, doc-table lines and rows from HBM.  enc: the uploaded-format dicts of the lists (the
+    first n_a are the rank-2 terms).  Returns (record, per-pair results)."""
+    n_b = len(enc) - n_a
+    pairs = [(i % n_a, n_a + (i + i // n_a) % n_b) for i in range(n_a * n_b)]
+    enc_bytes = [len(e["bytes"]) for e in enc]
+    out, answers = {}, None
+    for mode in ("warm", "cold"):
+        lib.RSGPU_SetTuning(b"cache_decoded", 1 if mode == "warm" else 0)
+        lists = [S.Postings.from_flat(e) for e in enc]
+        try:
+            hqs = []
+            for qi, (i, j) in enumerate(pairs):
+                dfs = [raws[i][0].size, raws[j][0].size]
+                hqs.append(S.HybridQuery([lists[i], lists[j]], table, "BM25STD", [S.calculate_idf(n_docs, d) for d in dfs],
+                                         [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10, index=idx,
+                                         q=qvecs[qi], k=10))
+            res = []
+            for hq in hqs:   # untimed first cycle: allocations, and (warm) every list's one decode
+                hq.run()
+                res.append(hq.results())
+            path = S.hybrid_path()
+            walls = []
+            with no_gc():
+                for _ in range(cycles):
+                    for hq in hqs:
+                        t0 = time.perf_counter()
+                        hq.run()
+                        walls.append((time.perf_counter() - t0) * 1e3)
+            lib.RSGPU_SetProfiling(1)   # per-stage device times (HIP events; a sync per stage: not the wall figure)
+            prof = []
+            for hq in hqs:
+                hq.run()
+                prof.append(S.profile())
+            lib.RSGPU_SetProfiling(0)
+            same = all(hq.results()["top"][0].tolist() == r["top"][0].tolist() and hq.results()["knn"][0].tolist() == r["knn"][0].tolist()
+                       for hq, r in zip(hqs, res))
+            tile = float(np.mean([x.get("intersect_ms") or 0.0 for x in prof]))
+            red = float(np.mean([x.get("topn_ms") or 0.0 for x in prof]))
+            dec = float(np.mean([x.get("decode_ms") or 0.0 for x in prof]))
+            rec = {"wall_ms_p50": float(np.percentile(walls, 50)), "wall_ms_p95": float(np.percentile(walls, 95)), "wall_ms_min": min(walls),
+                   "queries_timed": len(walls), "qps": 1e3 / float(np.percentile(walls, 50)),
+                   "path": "two_launches" if path == 1 else "staged",
+                   "device_ms": {"tile_kernel": tile, "reduce_kernel": red, "decode": dec} if path == 1 else
+                                {k_: float(np.mean([x.get(k_) or 0.0 for x in prof])) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
+                   "same_answers_every_cycle": bool(same)}
+            if mode == "warm":
+                answers = res
+                # algorithmic bytes of the tile kernel, per query: 4 B per decoded posting of both lists + 12 B per hit
+                # (frequency in the second list, doc length, doc score) + a row per hit that has a vector
+                hits = np.array([r["n_hits"] for r in res], np.float64)
+                n_cand = []
+                for (i, j) in pairs[:4]:   # exact candidate counts of four pairs (the staged intersection, read back)
+                    h = S.intersect([lists[i], lists[j]])
+                    gi, _ = h.read()
+                    n_cand.append(int(np.searchsorted(gi, n_vec, side="right")))
+                    h.free()
+                cand = float(np.mean(n_cand))
+                postings = float(np.mean([raws[i][0].size + raws[j][0].size for i, j in pairs]))
+                alg = postings * 4 + float(hits.mean()) * 12 + cand * dim * 4
+                rec.update({"hits_mean": float(hits.mean()), "candidates_with_vector_mean_of_4_pairs": cand,
+                            "tile_kernel_algorithmic_bytes": alg})
+                if path == 1 and tile > 0:
+                    rec["tile_kernel_gbs"] = alg / tile / 1e6
+                    rec["tile_kernel_hbm_frac"] = alg / tile / 1e6 / HBM_PEAK_GBS
+                    rec["tile_plus_reduce_hbm_frac"] = alg / (tile + red) / 1e6 / HBM_PEAK_GBS
+            else:
+                eb = float(np.mean([enc_bytes[i] + enc_bytes[j] for i, j in pairs]))
+                rec["encoded_bytes_per_query"] = eb
+                if dec > 0:
+                    rec["decode_gbs_of_encoded_bytes"] = eb / dec / 1e6
+                    rec["decode_hbm_frac_of_encoded_bytes"] = eb / dec / 1e6 / HBM_PEAK_GBS
+                if path == 1 and dec + tile > 0:
+                    rec["decode_plus_intersect_gbs_of_encoded_bytes"] = eb / (dec + tile) / 1e6
+                rec["same_answers_as_warm"] = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["knn"][0].tolist() == b_["knn"][0].tolist()
+                                                  and a["n_hits"] == b_["n_hits"] for a, b_ in zip(res, answers))
+            out[mode] = rec
+        finally:
+            lib.RSGPU_SetTuning(b"cache_decoded", 1)
+            for x in lists:
+                x.free()
+    out["pairs"] = len(pairs)
+    out["lists"] = {"rank_2_terms": n_a, "rank_4_terms": n_b, "postings": [int(r[0].size) for r in raws], "encoded_bytes": enc_bytes}
+    return out, answers, pairs
+
+
+def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b=4):
     """BASELINE configs[4]: 2-term intersection over Zipf postings (50M docs) -> FLAT 5M x 768 ad-hoc KNN top-10 + BM25STD.
+    The headline figure is a STREAM of distinct queries (16 term pairs over 4 + 4 independent lists, a query vector each) --
+    FreqsOnly postings and, as SURVEY 8(d)'s second variant, the same lists in the Full codec (FT.CREATE's default) -- warm
+    and cold; the earlier same-query-repeated figure is kept as `repeat_same_query`.
     Returns (record, payload): the payload holds what the cpu-baseline leg needs to hold the answers to the CPU oracle
     (check_hybrid_with_oracle); nothing here touches oracle/."""
     from redisearch_amd import search as S
-    rng = np.random.default_rng(49)
-    raw = []
-    for r in (2, 4):
-        docs = np.flatnonzero(rng.random(n_docs + 1) < 0.2 / r).astype(np.uint64)
-        docs = docs[docs > 0]
-        freqs = np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32)
-        raw.append((docs, freqs))
+    rng = np.random.default_rng(149)
     doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
     doc_score = np.ones(n_docs + 1, np.float32)
     avg = float(doc_len[1:].mean())
@@ -623,6 +768,54 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
     try:
         idx.reserve(n_vec)
         idx.add_philox_rows(SEED, 0, n_vec, 1)
+        t0 = time.perf_counter()
+        raws = [_term_list(rng, n_docs, n_docs * 0.2 / r) for r in [2] * n_a + [4] * n_b]
+        enc_fo = [encode_freqs_only(d, f) for d, f, _, _ in raws]
+        enc_full = [encode_full(d, f, m, o) for d, f, m, o in raws]
+        gen_s = time.perf_counter() - t0
+        qvecs = philox_host_rows(V, QUERY_BASE + 100, n_a * n_b, dim)
+        fo, ans_fo, pairs = _hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a)
+        full, ans_full, _ = _hybrid_stream(lib, S, enc_full, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a)
+        codec_same = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["top"][1].tolist() == b_["top"][1].tolist()
+                         and a["knn"][0].tolist() == b_["knn"][0].tolist() and a["n_hits"] == b_["n_hits"] for a, b_ in zip(ans_fo, ans_full))
+        rep, payload = _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_docs, n_vec, dim)
+        w = fo["warm"]
+        rec = {"workload": "2-term intersect (Zipf ranks 2 and 4: df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD "
+                           "top-10; a round-robin STREAM over %d distinct term pairs (%d + %d independent lists), a query vector per query"
+                           % (n_docs, n_vec, dim, len(pairs), n_a, n_b),
+               "wall_ms_per_query": w["wall_ms_p50"], "wall_ms_p95": w["wall_ms_p95"], "qps": w["qps"], "queries_timed": w["queries_timed"],
+               "figure": "p50 of %d queries of the distinct-query stream, FreqsOnly postings, decode-cache warm (every list decoded "
+                         "once, kept in HBM); consecutive queries share no list and no candidate row -- the cycle's working set is "
+                         "several times the Infinity Cache" % w["queries_timed"],
+               "path": w["path"],
+               "stream_freqs_only": fo, "stream_full_codec": full,
+               "full_codec_answers_equal_freqs_only": bool(codec_same),
+               "input_generation_s": gen_s,
+               "repeat_same_query": rep,
+               "parity": rep.get("parity")}
+        # the cpu leg holds two queries of the stream (one per codec) to the CPU oracle, KNN included
+        payload["stream"] = [dict(codec=c, raw=[raws[i], raws[j]], q=qvecs[qi], n_vec=n_vec, dim=dim, ans=ans[qi],
+                                  idf=[S.calculate_idf(n_docs, raws[t][0].size) for t in (i, j)],
+                                  bidf=[S.calculate_idf_bm25(n_docs, raws[t][0].size) for t in (i, j)])
+                             for c, ans, qi in (("freqs_only", ans_fo, 0), ("full", ans_full, 5)) for (i, j) in [pairs[qi]]]
+        return rec, payload
+    finally:
+        idx.free()
+
+
+def _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_docs, n_vec, dim):
+    """The round-1..3 figure of configs[4], kept for continuity: ONE term pair (ranks 2 and 4, membership by an independent
+    hash, seed 49) and ONE query vector, the same query 40 times back to back -- its whole working set (30 MB of decoded
+    postings, 77 MB of rows, the gather lines) stays in the 256 MiB Infinity Cache, so this is a cache-resident figure, not
+    an HBM one.  Also: the staged pipeline behind the same call (A/B), the cold form, the parity payload."""
+    rng = np.random.default_rng(49)
+    raw = []
+    for r in (2, 4):
+        docs = np.flatnonzero(rng.random(n_docs + 1) < 0.2 / r).astype(np.uint64)
+        docs = docs[docs > 0]
+        freqs = np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32)
+        raw.append((docs, freqs))
+    if True:
         q = philox_host_rows(V, QUERY_BASE, 1, dim)[0]
         g = [S.Postings.from_flat(encode_freqs_only(d, f)) for d, f in raw]
         idf = [S.calculate_idf(n_docs, d.size) for d, _ in raw]
@@ -744,9 +937,9 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768):
                                                                  "seam's (the CPU-oracle check runs in the cpu_baseline leg)"}}
         payload = dict(raw=raw, doc_len=doc_len, doc_score=doc_score, idf=idf, bidf=bidf, n_docs=n_docs, avg=avg,
                        gi=gi, gf=gf, ti=ti, ts=ts, ok=bool(fused_ok and seam_ok))
+        for x in g + g_cold:
+            x.free()
         return rec, payload
-    finally:
-        idx.free()
 
 
 def check_batched_with_oracle(p):
@@ -796,9 +989,38 @@ def check_hybrid_with_oracle(p):
     order = np.lexsort((oi, -os_))[:10]
     ok = (p["gi"].tolist() == oi.tolist() and p["gf"].tolist() == of.tolist() and p["ti"].tolist() == oi[order].tolist()
           and bool(np.allclose(p["ts"], os_[order], rtol=1e-12, atol=0)))
-    return {"ok": bool(ok and p["ok"]), "cpu_oracle_intersect_ms": t_int,
+    # two queries of the distinct-query stream (one per codec) against the oracle DIRECTLY, the two-launch KNN answer included:
+    # oracle intersection -> BM25STD top-10 in the reference's order; candidates with a vector -> their rows regenerated on the
+    # host -> the oracle's FLAT L2 top-10 over exactly those rows
+    stream = []
+    for sp in p.get("stream", []):
+        ls = []
+        for docs, freqs, _, _ in sp["raw"]:
+            ii = O.InvertedIndex(O.C_FREQS_ONLY)
+            ii.add_many(docs, freqs)
+            ls.append(ii)
+        si, sf, _ = O.intersect(ls)
+        sel2 = si.astype(np.int64)
+        idf, bidf = sp["idf"], sp["bidf"]
+        ss = O.score_flat("BM25STD", sf, p["doc_len"][sel2], np.ones(len(sel2)), p["doc_score"][sel2], idf, bidf, [1.0, 1.0], 1.0,
+                          p["n_docs"], p["avg"])
+        o10 = np.lexsort((si, -ss))[:10]
+        a = sp["ans"]
+        top_ok = a["n_hits"] == len(si) and a["top"][0].tolist() == si[o10].tolist() and bool(np.allclose(a["top"][1], ss[o10], rtol=1e-12, atol=0))
+        cand = si[si <= sp["n_vec"]]
+        rows = np.concatenate([O.philox_rows(SEED, int(l) - 1, 1, sp["dim"]) for l in cand]) if len(cand) else np.zeros((0, sp["dim"]), np.float32)
+        fo = O.FlatIndex(O.F32, sp["dim"], O.L2)
+        fo.add_bulk(rows, 1)
+        ki, kd = fo.topk(sp["q"], 10)
+        knn_ids = cand[ki.astype(np.int64) - 1]
+        knn_ok = a["knn"][0].tolist() == knn_ids.tolist() and bool(np.all(np.abs(a["knn"][1] - kd) <= 1e-4 + 1e-5 * np.abs(kd)))
+        stream.append({"codec": sp["codec"], "top_n_ok": bool(top_ok), "knn_ok": bool(knn_ok), "hits": int(len(si)), "candidates": int(len(cand)),
+                       "knn_max_abs_diff": float(np.max(np.abs(a["knn"][1] - kd))) if len(kd) == len(a["knn"][1]) else None})
+        ok = ok and top_ok and knn_ok
+    return {"ok": bool(ok and p["ok"]), "cpu_oracle_intersect_ms": t_int, "stream_queries_vs_oracle": stream,
             "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), KNN distances equal "
-                  "the per-label ad-hoc seam's; fused == stage-by-stage"}
+                  "the per-label ad-hoc seam's; fused == stage-by-stage; two queries of the stream (FreqsOnly, Full): hit count, "
+                  "BM25STD top-10 and the KNN top-10 (ids identical, distances within 1e-4 + 1e-5 |d|) against the oracle directly"}
 
 
 # ---- main ------------------------------------------------------------------------------------------------------------------

@@ -83,6 +83,31 @@ def test_bench_posting_encoder_matches_the_oracle_block_writer():
         assert bytes(mine["bytes"]) == bytes(ref["bytes"]), n
 
 
+def test_bench_full_codec_encoder_matches_the_oracle_block_writer():
+    """... and its Full-codec lists (configs[4]'s second variant): qint4 [delta, freq, mask, offsets length] +
+    the offsets bytes, record by record what the oracle's writer produces."""
+    import numpy as np
+    import oracle as O
+    b = load_bench([])
+    rng = np.random.default_rng(6)
+    for n, max_gap, max_freq in ((1, 5, 5), (99, 3, 9), (100, 70000, 3), (101, 300, 2), (731, 20_000_000, 40)):
+        docs = np.cumsum(rng.integers(1, max_gap + 1, n)).astype(np.uint64)
+        freqs = rng.integers(1, max_freq + 1, n).astype(np.uint32)
+        masks = rng.integers(1, 1 << int(rng.integers(1, 31)), n).astype(np.uint32)
+        offs = rng.integers(1, 128, int(freqs.sum())).astype(np.uint8)
+        mine = b.encode_full(docs, freqs, masks, offs)
+        ii = O.InvertedIndex(O.C_FULL)
+        at = 0
+        for d, f, m in zip(docs.tolist(), freqs.tolist(), masks.tolist()):
+            ii.add(d, f, m, offs[at:at + f].tobytes())
+            at += f
+        ref = ii.flatten()
+        assert mine["codec"] == ref["codec"] == O.C_FULL
+        for key in ("first", "last", "num_entries", "offset"):
+            assert np.array_equal(np.asarray(mine[key], np.uint64), np.asarray(ref[key], np.uint64)), (n, key)
+        assert bytes(mine["bytes"]) == bytes(ref["bytes"]), n
+
+
 def test_bench_imports_the_oracle_only_in_its_cpu_leg():
     """bench.py may use oracle/ only as the checker / CPU baseline: every import of it sits inside cpu_baseline's helpers,
     the host-side verification and the extras' oracle check, all of which run only when the cpu_baseline leg runs."""
