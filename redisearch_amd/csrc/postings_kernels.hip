@@ -310,6 +310,8 @@ struct DecodeArgs {  // one list's decode_blocks_kernel arguments (two of them: 
   uint32_t *ids, *freqs, *masks, *wmasks, *off_pos, *off_len, *sync;
   int sync_mode;
   uint32_t lds_cap;
+  uint32_t bpw1;  // blocks per wavefront when a lane parses a whole block (sync_mode 0 / 1): 64, or fewer for lists whose blocks
+                  // are long (inline offsets) so that a wavefront's byte range still fits the staging buffer
 };
 
 template <int KIND>
@@ -331,7 +333,7 @@ __device__ __forceinline__ void decode_blocks_body(const DecodeArgs &A, uint32_t
   const int sync_mode = A.sync_mode;
   const uint32_t lds_cap = A.lds_cap;
   const uint32_t lane = threadIdx.x;
-  const uint32_t lpb = sync_mode == 2 ? kSyncPts + 1 : 1, bpw = 64 / lpb;  // lanes per block, blocks per wavefront
+  const uint32_t lpb = sync_mode == 2 ? kSyncPts + 1 : 1, bpw = sync_mode == 2 ? 64 / lpb : A.bpw1;  // lanes per block, blocks per wavefront
   const uint32_t b0 = wg * bpw;
   const uint32_t nb = n_blocks - b0 < bpw ? n_blocks - b0 : bpw;
   // every lane's block description in ONE memory round trip, before anything depends on it (the wavefront's byte range
@@ -1298,31 +1300,39 @@ inline uint32_t blocks_for(uint32_t n) { return n ? (n + 255) / 256 : 1; }
 bool decode_sync_supported(const CodecDesc &cd) { return cd.kind == 0 && !cd.wide; }
 size_t decode_sync_words(uint32_t n_blocks) { return (size_t)n_blocks * kSyncPts * 2; }
 uint32_t decode_sync_blocks_per_wave() { return 64 / (kSyncPts + 1); }
+uint32_t decode_stage_bytes() { return kDecodeLds; }
 
 // sync_mode after the rules of the kernel + the staging size that goes with it
 static int decode_mode(const CodecDesc &cd, const uint32_t *sync, const uint32_t *wmasks, int sync_mode, uint32_t sync_span,
                        uint32_t *lds_cap) {
   if (!sync || !decode_sync_supported(cd) || wmasks) sync_mode = 0;
-  // sync_mode 2: eight lanes per block.  Only layouts the staged fast parsers take may use it: a block whose wavefront
-  // does not fit the staging buffer falls to the generic loop, which parses whole blocks -- 8 blocks of <= 100 records
-  // of <= 17 bytes + offsets always fit unless the offsets are huge, and then every lane would redo the block: keep to
-  // one lane per block for lists with inline offsets.
-  if (sync_mode == 2 && cd.osz >= 0) sync_mode = 0;
+  // sync_mode 2: eight lanes per block.  Only layouts the staged fast parsers take may use it.  Lists with inline offsets
+  // (Full, *Offsets: round 4) too -- their sync points are only allocated when every 8-block span fits the staging buffer
+  // (RSGPU_Postings_Upload); a wavefront that does not fit parses whole blocks, one lane each (decode_blocks_body).
   // staging bytes: everything a wavefront of sync_mode 2 can need (the caller knows the widest 8-block span), else 30 KiB
   *lds_cap = sync_mode == 2 && sync_span && sync_span < kDecodeLds ? ((sync_span + 255u) & ~255u) : kDecodeLds;
   return sync_mode;
 }
 
+// blocks per wavefront of the lane-per-block modes: as many (a power of two, <= 64) as keep the wavefront's byte range inside
+// the staging buffer for blocks of the list's average length + 30 % (FreqsOnly: ~300 B -> 64; Full: ~800 B -> 16 or 32)
+static uint32_t decode_bpw1(uint32_t avg_block_bytes) {
+  uint32_t bpw = 64;
+  while (bpw > 4 && (uint64_t)bpw * avg_block_bytes * 13 / 10 + 64 > kDecodeLds) bpw >>= 1;
+  return bpw;
+}
+
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
-                          uint32_t *off_len, uint32_t *sync, int sync_mode, uint32_t sync_span) {
+                          uint32_t *off_len, uint32_t *sync, int sync_mode, uint32_t sync_span, uint32_t avg_block_bytes) {
   if (!n_blocks) return;
   uint32_t lds_cap;
   sync_mode = decode_mode(cd, sync, wmasks, sync_mode, sync_span, &lds_cap);
-  const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : 64;
+  const uint32_t bpw1 = decode_bpw1(avg_block_bytes);
+  const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : bpw1;
   const DecodeArgs a{cd, bytes, byte_off, first, nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len, sync,
-                     sync_mode, lds_cap};
+                     sync_mode, lds_cap, bpw1};
 #define RSGPU_DECODE(K) hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + bpw - 1) / bpw), dim3(64), lds_cap + 64, s, a)
   // varint / raw deltas without a wide mask: one wavefront per block (decode_blocks_wave_kernel)
   const bool wave = (cd.kind == 1 || cd.kind == 2) && !cd.wide && !wmasks && !off_pos;
@@ -1346,9 +1356,10 @@ bool launch_decode_blocks_pair(const DecodeListArgs &x, const DecodeListArgs &y,
   const uint32_t bpw_x = mx == 2 ? 64 / (kSyncPts + 1) : 64, bpw_y = my == 2 ? 64 / (kSyncPts + 1) : 64;
   const uint32_t wgs_x = (x.n_blocks + bpw_x - 1) / bpw_x, wgs_y = (y.n_blocks + bpw_y - 1) / bpw_y;
   const DecodeArgs a{x.cd, x.bytes, x.byte_off, x.first, x.nent, x.entry_off, x.n_blocks, x.ids, x.freqs, x.masks, nullptr,
-                     x.off_pos, x.off_len, x.sync, mx, cap_x};
+                     x.off_pos, x.off_len, x.sync, mx, cap_x, 64};
   const DecodeArgs b{y.cd, y.bytes, y.byte_off, y.first, y.nent, y.entry_off, y.n_blocks, y.ids, y.freqs, y.masks, nullptr,
-                     y.off_pos, y.off_len, y.sync, my, cap_y};
+                     y.off_pos, y.off_len, y.sync, my, cap_y, 64};
+  if (mx != 2 || my != 2) return false;  // (the pair launch is for lists whose sync points are there)
   const uint32_t lds = (cap_x > cap_y ? cap_x : cap_y) + 64;
   hipLaunchKernelGGL(decode_blocks_pair_kernel<0>, dim3(wgs_x + wgs_y), dim3(64), lds, s, a, b, wgs_x);
   return true;

@@ -269,7 +269,8 @@ static void launch_decode(RSGPU_Postings *p, QueryCtx *c, int sync_mode) {
   launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
                        p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
                        c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
-                       p->has_offsets() ? p->off_len.p : nullptr, p->sync.p, sync_mode, p->sync_span);
+                       p->has_offsets() ? p->off_len.p : nullptr, p->sync.p, sync_mode, p->sync_span,
+                       (uint32_t)std::min<uint64_t>(p->n_blocks ? p->n_bytes / p->n_blocks : 0, 0xFFFFFFFFull));
   HIP_CHECK(hipGetLastError());
 }
 
@@ -689,13 +690,17 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
   if (cd.wide) p->wmasks.alloc((size_t)p->n_entries * 4);
   // sub-block sync points of the qint layouts without inline offsets (8 bytes per 16 postings; written by the first decode)
   // -- for lists uploaded in decode-per-query mode: with the decoded arrays cached a list is decoded once
-  if (decode_sync_supported(cd) && cd.osz < 0 && n_blocks && !scan_tuning().cache_decoded && scan_tuning().decode_sync) {
-    p->sync.alloc(decode_sync_words((uint32_t)n_blocks));
+  // (round 4: lists with inline offsets -- Full, the *Offsets codecs -- too, as long as every 8-block span fits the decode
+  // kernel's staging buffer: their blocks are 2-3 x as long, a lane per block was 0.1 TB/s of encoded bytes)
+  if (decode_sync_supported(cd) && n_blocks && !scan_tuning().cache_decoded && scan_tuning().decode_sync) {
     const size_t bpw = decode_sync_blocks_per_wave();
     uint64_t widest = 0;
     for (size_t b = 0; b < n_blocks; b += bpw)
       widest = std::max<uint64_t>(widest, byte_offset[std::min(b + bpw, n_blocks)] - (byte_offset[b] & ~15ull));
-    p->sync_span = (uint32_t)std::min<uint64_t>(widest, 0xFFFFFFFFull);
+    if (cd.osz < 0 || widest + 256 < decode_stage_bytes()) {
+      p->sync.alloc(decode_sync_words((uint32_t)n_blocks));
+      p->sync_span = (uint32_t)std::min<uint64_t>(widest, 0xFFFFFFFFull);
+    }
   }
   if (cd.osz >= 0) {
     // the decoded offsets index addresses the byte buffer with 32 bits

@@ -25,8 +25,9 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks = nullptr,
                           uint32_t *off_pos = nullptr, uint32_t *off_len = nullptr, uint32_t *sync = nullptr, int sync_mode = 0,
-                          uint32_t sync_span = 0);  // sync_span: the widest byte range (16-byte aligned start) of
+                          uint32_t sync_span = 0,   // sync_span: the widest byte range (16-byte aligned start) of
                                                     // decode_sync_blocks_per_wave() consecutive blocks, 0 = unknown
+                          uint32_t avg_block_bytes = 0);  // encoded bytes / blocks: sizes the lane-per-block modes' wavefronts
 // Two qint lists (kind 0, no wide masks) in ONE launch -- the same arguments as launch_decode_blocks, per list; false
 // (nothing launched) when a list is not of that kind or is empty.
 struct DecodeListArgs {
@@ -45,6 +46,7 @@ bool launch_decode_blocks_pair(const DecodeListArgs &a, const DecodeListArgs &b,
 bool decode_sync_supported(const CodecDesc &cd);
 size_t decode_sync_words(uint32_t n_blocks);
 uint32_t decode_sync_blocks_per_wave();
+uint32_t decode_stage_bytes();  // bytes of encoded input a decode wavefront can stage in LDS
 
 constexpr int kMaxLists = 32;  // children of one intersection / union (the reference's own tests go to 25)
 constexpr int kMaxNodes = 64;      // nodes of one query tree (terms + aggregates; <= kMaxLists terms)

@@ -216,3 +216,50 @@ def test_the_lists_of_a_query_decoded_in_one_launch(codecs):
     finally:
         lib.RSGPU_SetTuning(b"cache_decoded", 1)
         lib.RSGPU_SetTuning(b"decode_pair", 1)
+
+
+@pytest.mark.parametrize("codec", [O.C_FULL, O.C_FREQS_OFFSETS, O.C_FIELDS_OFFSETS, O.C_OFFSETS_ONLY])
+@pytest.mark.parametrize("n,max_off", [(3, 4), (101, 4), (6_401, 6), (20_011, 3), (5_000, 120)])
+def test_lists_with_inline_offsets_through_the_sync_points(codec, n, max_off):
+    """Round 4: the qint layouts WITH inline offsets (Full is FT.CREATE's default) take the sync points too -- first decode a
+    block per lane (32 or 16 blocks per wavefront, so that the longer blocks still fit the staging buffer), later decodes
+    eight lanes per block.  ids / freqs / masks equal the oracle's reader decode after decode; the offsets index the decode
+    leaves behind (where every record's position list lies) is checked through what reads it: slop / in-order intersections
+    against the oracle.  max_off 120: blocks of ~12 KiB -- eight of them do not fit, such a list gets no sync points."""
+    lib = V.load()
+    rng = np.random.default_rng(31 * codec + n)
+
+    def make(seed_shift):
+        docs = np.unique(rng.integers(1, 4 * n + 10, n))
+        ii = O.InvertedIndex(codec)
+        for d in docs.tolist():
+            pos = sorted(set(int(x) for x in rng.integers(1, 40 * max_off, int(rng.integers(0, max_off)))))
+            offs, last = b"", 0
+            for p in pos:
+                offs += O.varint_encode(p - last)
+                last = p
+            ii.add(d, int(rng.integers(1, 300)), int(rng.integers(1, 2 ** 31)), offs)
+        return ii
+    a, b = make(0), make(1)
+    want = a.decode_all()
+    try:
+        lib.RSGPU_SetTuning(b"cache_decoded", 0)
+        ga, gb = S.Postings.from_flat(a.flatten()), S.Postings.from_flat(b.flatten())
+        try:
+            for rep in range(3):
+                ids, fr, mk = ga.decode()
+                assert np.array_equal(ids, want[0]), (rep, "ids")
+                if codec in (O.C_FULL, O.C_FREQS_OFFSETS):
+                    assert np.array_equal(fr, want[1]), (rep, "freqs")
+                if codec in (O.C_FULL, O.C_FIELDS_OFFSETS):
+                    assert np.array_equal(mk, want[2]), (rep, "masks")
+            for max_slop, in_order in ((None, False), (0, False), (3, False), (None, True), (5, True)):
+                for rep in range(2):
+                    gi, gf = S.intersect([ga, gb], max_slop=max_slop, in_order=in_order).read()
+                    oi, of, _ = O.intersect_ex([a, b], max_slop, in_order)
+                    assert gi.tolist() == oi.tolist() and gf.tolist() == of.tolist(), (max_slop, in_order, rep)
+        finally:
+            ga.free()
+            gb.free()
+    finally:
+        lib.RSGPU_SetTuning(b"cache_decoded", 1)
