@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   RSGPU_HYB_MARK(0);
   // the first level of the window-end searches in list 1 (64 fixed positions), requested together with the tile's doc ids
   uint32_t lvl1 = 0;
-  const bool pre1 = A.n > 1 && A.len[1] > 64;
+  const bool pre1 = A.n > 1 && A.len[1] > 64 && !A.dir[1];
   if (pre1) {
     const uint32_t step = (A.len[1] + 63) / 64, p = (lane + 1) * step - 1;
     lvl1 = A.ids[1][p < A.len[1] ? p : A.len[1] - 1];
@@ -197,7 +197,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       const uint32_t *__restrict__ a = A.ids[l];
       const uint32_t nl = A.len[l];
       const long long add = A.add[l];
-      if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
+      if (A.dir[l]) {  // bucket directory: both ends in one round trip
+        if (threadIdx.x == 0) {
+          bool u0, u1;
+          const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
+          const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
+          const uint32_t bf = xf >> sh, bn = (xn >> sh) + 1;
+          const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
+          w_lo = dlo;
+          w_hi = i_next < n0 ? dhi : nl;
+        }
+      } else if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
         bool u0;
         uint32_t rlo, rhi;
         wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
@@ -330,8 +340,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const long long tid = (long long)x + A.P.table_off;
         const bool known = tid >= 0 && tid < (long long)A.table_n;
         const uint32_t id = known ? (uint32_t)tid : 0u;
-        const float dscore = known ? A.doc_score[id] : 0.0f;
-        const uint32_t dlen = known ? A.doc_len[id] : 0u;
+        float dscore;
+        uint32_t dlen;
+        if (A.len_score) {  // (one 8-byte gather: a 64-byte line per hit instead of two)
+          const uint2 ls = A.len_score[id];
+          dlen = known ? ls.x : 0u;
+          dscore = known ? __uint_as_float(ls.y) : 0.0f;
+        } else {
+          dscore = known ? A.doc_score[id] : 0.0f;
+          dlen = known ? A.doc_len[id] : 0u;
+        }
         const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
         auto F = [&](int t) { return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[3])); };
         const double s = score_one<false, kHybMaxLists>(A.P, F, dlen, dscore, mfreq, A.P.slop);
@@ -463,6 +481,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 // More survivors than the LDS list holds (an adversarial arrangement): *out_n = 0xFFFFFFFF and the caller answers the query
 // with the staged pipeline.
 constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
+#define RSGPU_RED_MARK(p)                                                                                              \
+  do {                                                                                                                 \
+    if (R.trace && threadIdx.x == 0) R.trace[(SCORE ? 0 : kHybTracePhases) + (p)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 template <bool SCORE>
 __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, uint64_t *lk, uint32_t *li, uint32_t *cnt_sh) {
   __shared__ uint64_t wtau_k[16];
@@ -491,9 +513,15 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
       if (ck[j] == ~0ull) ci[j] = ~0u;
     }
   };
-  // 1. the thread's best
+  RSGPU_RED_MARK(0);
+  // 1. the thread's best (the first kB of its tiles stay in registers for step 3)
   SKey best = sk_none();
-  for (uint32_t t0 = threadIdx.x; t0 < n_tiles; t0 += kB * 1024) {
+  uint64_t ck0[kB];
+  uint32_t ci0[kB];
+  load_firsts(threadIdx.x, ck0, ci0);
+#pragma unroll
+  for (int j = 0; j < kB; j++) best = sk_min(SKey{ck0[j], ci0[j]}, best);
+  for (uint32_t t0 = threadIdx.x + kB * 1024; t0 < n_tiles; t0 += kB * 1024) {
     uint64_t ck[kB];
     uint32_t ci[kB];
     load_firsts(t0, ck, ci);
@@ -502,78 +530,107 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   }
   lk[threadIdx.x] = best.k;
   li[threadIdx.x] = best.i;
-  if (threadIdx.x == 0) *cnt_sh = 0;
-  if (lane == 0) {
-    wtau_k[w] = ~0ull;
-    wtau_i[w] = ~0u;
+  if (threadIdx.x == 0) {
+    *cnt_sh = 0;
+    wtau_k[0] = ~0ull;
+    wtau_i[0] = ~0u;
   }
-  const bool refine = k <= 16;
-  uint64_t *tk = lk + 1024;  // [16][k]
-  uint32_t *ti = li + 1024;
-  if (refine && threadIdx.x < 16 * k) {
-    tk[threadIdx.x] = ~0ull;
-    ti[threadIdx.x] = ~0u;
-  }
+  RSGPU_RED_MARK(1);  // firsts loaded
   __syncthreads();
-  // 2. the bound
-  if (!sk_same(best, sk_none())) {
-    uint32_t rank = 0;
-#pragma unroll 8
-    for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{lk[w * 64 + j], li[w * 64 + j]}, best) ? 1u : 0u;
-    if (rank == k - 1) {
-      wtau_k[w] = best.k;
-      wtau_i[w] = best.i;
-    }
-    if (refine && rank < k) {
-      tk[w * k + rank] = best.k;
-      ti[w * k + rank] = best.i;
-    }
-  }
-  __syncthreads();
-  if (refine && threadIdx.x < 16 * k) {
-    const SKey my{tk[threadIdx.x], ti[threadIdx.x]};
-    if (!sk_same(my, sk_none())) {
+  // 2. the bound: the k-th smallest of 64 GROUP minima (group g = the threads g, g + 64, ...: sixteen threads' bests, i.e. the
+  // best first entry of a 64th of the tiles).  k groups have their minimum at or below it, so the k-th entry of all is not
+  // above it; a tile that is not its group's best passes it with probability ~k / tiles, so about k tiles pass.  One
+  // wavefront ranks 64 values -- the first version ranked the 1 024 thread bests inside every wavefront and 16 k of them
+  // against each other: 9 of the kernel's 17 us on one CU (profiles/r04_hybrid_trace.txt).
+  if (threadIdx.x < 64) {
+    SKey g = sk_none();
+#pragma unroll
+    for (int j = 0; j < 16; j++) g = sk_min(SKey{lk[threadIdx.x + 64 * j], li[threadIdx.x + 64 * j]}, g);
+    lk[1024 + threadIdx.x] = g.k;
+    li[1024 + threadIdx.x] = g.i;
+    // (one wavefront: its own LDS writes are visible to it after the wait the compiler inserts; no barrier needed)
+    __builtin_amdgcn_wave_barrier();
+    if (!sk_same(g, sk_none())) {
       uint32_t rank = 0;
 #pragma unroll 8
-      for (uint32_t j = 0; j < 16 * k; j++) rank += sk_less(SKey{tk[j], ti[j]}, my) ? 1u : 0u;
-      if (rank == k - 1) {  // (at or below every wavefront's own k-th)
-        wtau_k[0] = my.k;
-        wtau_i[0] = my.i;
+      for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{lk[1024 + j], li[1024 + j]}, g) ? 1u : 0u;
+      if (rank == k - 1) {
+        wtau_k[0] = g.k;
+        wtau_i[0] = g.i;
       }
     }
   }
   __syncthreads();
-  SKey tau = sk_none();
-#pragma unroll
-  for (int j = 0; j < 16; j++) tau = sk_min(SKey{wtau_k[j], wtau_i[j]}, tau);
+  const SKey tau{wtau_k[0], wtau_i[0]};  // (none: fewer than k groups hold anything -- everything passes)
   __syncthreads();  // (lk / li are rewritten below)
-  // 3. the lists of the tiles whose first entry passes; survivors
+  RSGPU_RED_MARK(2);  // bound
+  // 3. the lists of the tiles whose first entry passes; survivors.  The passing tiles (about k of them) are listed first, then
+  // ALL their entries are requested at once, one (tile, entry) pair per thread: walking a list entry by entry until one
+  // fails the bound was up to k dependent memory round trips on the one workgroup the whole query waits for
+  __shared__ uint32_t pass_t[1024];
+  __shared__ uint32_t pass_n;
+  if (threadIdx.x == 0) pass_n = 0;
+  __syncthreads();
   for (uint32_t t0 = threadIdx.x; t0 < n_tiles; t0 += kB * 1024) {
     uint64_t ck[kB];
     uint32_t ci[kB];
-    load_firsts(t0, ck, ci);
+    if (t0 == threadIdx.x) {
+#pragma unroll
+      for (int j = 0; j < kB; j++) {
+        ck[j] = ck0[j];
+        ci[j] = ci0[j];
+      }
+    } else {
+      load_firsts(t0, ck, ci);
+    }
 #pragma unroll
     for (int j = 0; j < kB; j++) {
       const SKey first{ck[j], ci[j]};
       if (!sk_same(first, sk_none()) && !sk_less(tau, first)) {
-        const size_t base = (size_t)(t0 + j * 1024) * k;
-        for (uint32_t i = 0; i < k; i++) {
-          const SKey c = i ? entry((uint32_t)(base + i)) : first;
-          if (sk_same(c, sk_none()) || sk_less(tau, c)) break;  // (sorted: nothing further down passes)
-          const uint32_t slot = atomicAdd(cnt_sh, 1u);
-          if (slot < R.surv_cap) {
-            lk[slot] = c.k;
-            li[slot] = c.i;
-          }
-        }
+        const uint32_t slot = atomicAdd(&pass_n, 1u);
+        if (slot < 1024) pass_t[slot] = t0 + j * 1024;
       }
     }
   }
   __syncthreads();
+  const uint32_t P = pass_n;
+  RSGPU_RED_MARK(3);  // passing tiles listed
+  if (P > 1024) {  // (more tiles at the bound than the list holds: the staged pipeline answers)
+    if (threadIdx.x == 0) {
+      *(SCORE ? R.out_sn : R.out_kn) = 0xFFFFFFFFu;
+      __hip_atomic_store(R.done + (SCORE ? 0 : 1), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  for (uint32_t e0 = 0; e0 < P * k; e0 += 4 * 1024) {  // four loads in flight per thread
+    SKey c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t e = e0 + j * 1024 + threadIdx.x;
+      const uint32_t ec = e < P * k ? e : 0;
+      c[j] = entry((uint32_t)((size_t)pass_t[ec / k] * k + ec % k));
+      if (e >= P * k) c[j] = sk_none();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (!sk_same(c[j], sk_none()) && !sk_less(tau, c[j])) {
+        const uint32_t slot = atomicAdd(cnt_sh, 1u);
+        if (slot < R.surv_cap) {
+          lk[slot] = c[j].k;
+          li[slot] = c[j].i;
+        }
+      }
+  }
+  __syncthreads();
+  RSGPU_RED_MARK(4);  // their entries collected
   const uint32_t S = *cnt_sh;
   uint32_t *out_n = SCORE ? R.out_sn : R.out_kn;
+  uint32_t *done = R.done + (SCORE ? 0 : 1);
   if (S > R.surv_cap) {
-    if (threadIdx.x == 0) *out_n = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) {
+      *out_n = 0xFFFFFFFFu;
+      __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   for (uint32_t e = threadIdx.x; e < S; e += 1024) {
@@ -590,10 +647,17 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
         R.out_kkeys[rank] = (uint32_t)(my.k >> 32);
         R.out_kids[rank] = (uint32_t)my.k;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (the few threads that wrote an answer: it is in host memory before the flag)
     }
   }
-  if (threadIdx.x == 0) *out_n = S < k ? S : k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *out_n = S < k ? S : k;
+    __hip_atomic_store(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  RSGPU_RED_MARK(5);  // ranked, written
 }
+#undef RSGPU_RED_MARK
 
 __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R) {
   __shared__ uint64_t lk[kHybSurvivors];
@@ -601,7 +665,7 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t cnt_sh;
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (blockIdx.x == gridDim.x - 1) {  // the hit count: with the KNN lists (8-byte entries: the lighter workgroup) when there are two
+  if (blockIdx.x == gridDim.x - 1) {  // the hit count: a workgroup of its own (it was two memory round trips in front of the KNN branch)
     uint32_t s = 0;
     for (uint32_t t0 = threadIdx.x; t0 < R.n_tiles; t0 += 4 * 1024) {  // (four loads in flight)
       uint32_t v[4];
@@ -620,14 +684,45 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
       uint32_t t = 0;
       for (int j = 0; j < 16; j++) t += wsum[j];
       *R.out_hits = t;
+      __hip_atomic_store(R.done + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __syncthreads();
+    return;
   }
   if (blockIdx.x == 0 && R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
-  else if (R.k && (blockIdx.x == 1 || !R.top_n)) hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+  else if (R.k) hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+}
+
+
+
+// dir[b] = lower_bound(ids, b << shift): entry i owns the buckets behind its predecessor's up to its own (the first entry
+// the buckets from 0, the last one also those behind its own up to dir_n - 1, which hold n)
+__global__ __launch_bounds__(256) void build_bucket_dir_kernel(const uint32_t *__restrict__ ids, uint32_t n, uint32_t shift,
+                                                               uint32_t *__restrict__ dir, uint32_t dir_n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t b = ids[i] >> shift;
+    uint32_t from = i ? (ids[i - 1] >> shift) + 1 : 0;
+    for (; from <= b && from < dir_n; from++) dir[from] = i;
+    if (i + 1 == n)
+      for (uint32_t t = b + 1; t < dir_n; t++) dir[t] = n;
+  }
+}
+__global__ __launch_bounds__(256) void pack_len_score_kernel(const uint32_t *__restrict__ doc_len, const float *__restrict__ doc_score,
+                                                             uint32_t n, uint2 *__restrict__ ls) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) ls[i] = make_uint2(doc_len[i], __float_as_uint(doc_score[i]));
 }
 
 }  // namespace
+
+void launch_build_bucket_dir(const uint32_t *ids, uint32_t n, uint32_t shift, uint32_t *dir, uint32_t dir_n, hipStream_t s) {
+  if (!n || !dir_n) return;
+  const uint32_t need = (n + 255) / 256;
+  hipLaunchKernelGGL(build_bucket_dir_kernel, dim3(need < 4096 ? need : 4096), dim3(256), 0, s, ids, n, shift, dir, dir_n);
+}
+void launch_pack_len_score(const uint32_t *doc_len, const float *doc_score, uint32_t n, void *ls, hipStream_t s) {
+  if (!n) return;
+  const uint32_t need = (n + 255) / 256;
+  hipLaunchKernelGGL(pack_len_score_kernel, dim3(need < 8192 ? need : 8192), dim3(256), 0, s, doc_len, doc_score, n, (uint2 *)ls);
+}
 
 uint32_t hybrid_tiles(uint32_t n0) { return (n0 + kHybTile - 1) / kHybTile; }
 bool hybrid_tile_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
@@ -664,7 +759,7 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
 #undef RSGPU_HYB
 }
 void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s) {
-  hipLaunchKernelGGL(hybrid_reduce_kernel, dim3(r.k && r.top_n ? 2 : 1), dim3(1024), 0, s, r);
+  hipLaunchKernelGGL(hybrid_reduce_kernel, dim3((r.k ? 1 : 0) + (r.top_n ? 1 : 0) + 1), dim3(1024), 0, s, r);
 }
 
 }  // namespace rsgpu

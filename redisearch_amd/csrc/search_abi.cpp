@@ -203,6 +203,12 @@ struct RSGPU_Postings {
   DevBuf<uint32_t> sync;
   std::atomic<bool> sync_ready{false};
   uint32_t sync_span = 0;  // widest byte range of decode_sync_blocks_per_wave() consecutive blocks
+  // bucket directory over the decoded doc ids (round 4; hybrid_kernels.hip): dir[b] = lower_bound(ids, b << dir_shift) --
+  // built once by the first two-launch hybrid query that probes this list (a list is immutable: every later decode
+  // reproduces the same ids), ~4 bytes per 32 postings
+  DevBuf<uint32_t> dir;
+  uint32_t dir_shift = 0, dir_n = 0;
+  std::atomic<bool> dir_ready{false};
 };
 
 // one node of a hit list's result tree, post-order over its leaf columns (a term: op 0, `leaf`; an aggregate: op 1 union /
@@ -254,6 +260,7 @@ struct RSGPU_DocTable {
   uint64_t first = 0;  // doc id of entry 0
   DevBuf<uint32_t> doc_len, max_freq;
   DevBuf<float> doc_score;
+  DevBuf<uint64_t> len_score;  // {doc_len, bits of doc_score} per document: the two-launch hybrid query's one gather per hit
 };
 
 #define S_TRY try {
@@ -1213,6 +1220,12 @@ RSGPU_DocTable *RSGPU_DocTable_UploadWindow(uint64_t first_doc_id, size_t n, con
   t->doc_len.upload(doc_len, n);
   t->doc_score.upload(doc_score, n);
   if (max_term_freq) t->max_freq.upload(max_term_freq, n);
+  if (n && scan_tuning().hybrid_packed_docs) {
+    t->len_score.alloc(n);
+    launch_pack_len_score(t->doc_len.p, t->doc_score.p, (uint32_t)n, t->len_score.p, nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+  }
   return guard.release();
   S_CATCH(nullptr)
 }
@@ -1420,6 +1433,26 @@ static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_D
 
 thread_local int tls_hybrid_path = 0;  // how the last RSGPU_HybridQuery of this thread ran: 0 staged, 1 two launches
 
+// The bucket directory of a probed list (see RSGPU_Postings::dir): built on the query's stream right behind the decode, once.
+// Buckets of ~32 postings on average: shift = log2 of (doc-id range / (entries / 32)).
+static void ensure_bucket_dir(RSGPU_Postings *p, QueryCtx *c) {
+  if (p->dir_ready.load(std::memory_order_acquire) || !p->n_entries) return;
+  std::lock_guard<std::mutex> g(p->decode_mu);
+  if (p->dir_ready.load(std::memory_order_relaxed)) return;
+  const uint64_t range = p->last - p->base + 1;  // ids[] hold doc id - base
+  uint32_t shift = 0;
+  while (shift < 31 && (range >> shift) > (uint64_t)p->n_entries / 32 + 1) shift++;
+  const uint64_t dn = ((p->last - p->base) >> shift) + 2;
+  if (dn > (1ull << 28)) return;  // (cannot happen with the shift above; the wave-wide searches take such a list)
+  p->dir.alloc((size_t)dn);
+  p->dir_shift = shift;
+  p->dir_n = (uint32_t)dn;
+  launch_build_bucket_dir(p->ids.p, p->n_entries, shift, p->dir.p, p->dir_n, c->stream);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(c->stream));  // (once per list: other streams read it from now on)
+  p->dir_ready.store(true, std::memory_order_release);
+}
+
 // The query in two launches (hybrid_kernels.hip): for callers that do not ask for the hit list.  The caller holds the index
 // lock and has checked the shapes (hybrid_tile_supported); ca's stream carries everything, cb lends its pinned buffers to the
 // KNN answers; the prepared query is ca->d_query.  false: the reduce kernel met more candidates at its bound than it ranks
@@ -1455,6 +1488,16 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     T.len[l] = v.len[l];
     T.add[l] = v.add[l];
   }
+  if (scan_tuning().hybrid_dir)
+    for (int l = 1; l < v.n; l++) {
+      RSGPU_Postings *pl = a->lists[order[l]];
+      ensure_bucket_dir(pl, ca);
+      if (pl->dir_ready.load(std::memory_order_acquire) && v.ids[l] == pl->ids.p) {
+        T.dir[l] = pl->dir.p;
+        T.dir_shift[l] = pl->dir_shift;
+        T.dir_n[l] = pl->dir_n;
+      }
+    }
   T.top_n = top_n;
   if (want_score) {
     bool max_norm = false;
@@ -1463,6 +1506,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     T.doc_score = a->table->doc_score.p;
     T.max_freq = a->table->max_freq.p;
     T.table_n = a->table->n;
+    T.len_score = scan_tuning().hybrid_packed_docs ? reinterpret_cast<const uint2 *>(a->table->len_score.p) : nullptr;
   }
   T.k = k;
   if (want_knn) {
@@ -1481,9 +1525,10 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
   if (k) sc.hyb_knn.ensure((size_t)n_tiles * k);
   sc.hyb_trace_tiles = 0;
   if (scan_tuning().hybrid_trace) {
-    sc.hyb_trace.ensure((size_t)n_tiles * kHybTracePhases);
+    sc.hyb_trace.ensure((size_t)(n_tiles + 2) * kHybTracePhases);  // (+ the two branches of the reduce kernel)
+    HIP_CHECK(hipMemsetAsync(sc.hyb_trace.p + (size_t)n_tiles * kHybTracePhases, 0, 2 * kHybTracePhases * sizeof(uint64_t), ca->stream));
     T.trace = sc.hyb_trace.p;
-    sc.hyb_trace_tiles = n_tiles;
+    sc.hyb_trace_tiles = n_tiles + 2;
   }
   T.tile_hits = sc.hyb_hits.p;
   T.part_skey = sc.hyb_skey.p;
@@ -1515,6 +1560,14 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
   R.out_kkeys = reinterpret_cast<uint32_t *>(cb->h_out_keys);
   R.out_kids = cb->h_ids;
   R.out_kn = cb->h_fcnt + 2;
+  R.trace = T.trace ? T.trace + (size_t)n_tiles * kHybTracePhases : nullptr;
+  // completion flags the host polls (h_counters[1..3]: pinned, device-visible): hipStreamSynchronize costs several
+  // microseconds of a 60 us query once the device is done
+  volatile uint32_t *done = ca->h_counters + 1;
+  done[0] = top_n ? 0u : 1u;
+  done[1] = k ? 0u : 1u;
+  done[2] = 0u;
+  R.done = ca->h_counters + 1;
 
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
   if (n_tiles) {
@@ -1523,7 +1576,18 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     launch_hybrid_reduce(R, ca->stream);
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
-    HIP_CHECK(hipStreamSynchronize(ca->stream));
+    bool finished = false;
+    if (!prof && !T.trace && scan_tuning().hybrid_poll) {
+      for (int spin = 0; spin < 400000; spin++) {
+        if (done[0] && done[1] && done[2]) {
+          finished = true;
+          break;
+        }
+        __builtin_ia32_pause();
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!finished) HIP_CHECK(hipStreamSynchronize(ca->stream));
   }
   if (n_tiles && ((top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) || (k && cb->h_fcnt[2] == 0xFFFFFFFFu))) return false;
 

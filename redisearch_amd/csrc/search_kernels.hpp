@@ -233,7 +233,18 @@ struct HybridTileArgs {
   uint64_t *part_knn;                  // [n_tiles][k]      (distance key << 32) | doc id in the shared frame, ~0 = none
   uint32_t pool_words;                 // set by the launcher: u32 words of LDS before the query
   uint64_t *trace;                     // NULL, or [n_tiles][kHybTracePhases] clock readings (diagnostics)
+  // round 4 ---------------------------------------------------------------------------------------------------------
+  // bucket directory of list l >= 1 (NULL: the wave-wide searches): dir[l][b] = lower_bound(ids[l], b << dir_shift[l]) for
+  // b < dir_n[l], dir[l][dir_n[l] - 1] = len[l] -- a tile's window ends are two independent loads, one round trip, where
+  // the 64-ary searches were three to four dependent ones
+  const uint32_t *dir[kHybMaxLists];
+  uint32_t dir_shift[kHybMaxLists], dir_n[kHybMaxLists];
+  const uint2 *len_score;              // NULL, or {doc length, doc score bits} per document: one 8-byte gather per hit for two
 };
+// dir[b] = lower_bound(ids, b << shift), b < dir_n (ids ascending, n > 0; dir_n >= (ids[n - 1] >> shift) + 2)
+void launch_build_bucket_dir(const uint32_t *ids, uint32_t n, uint32_t shift, uint32_t *dir, uint32_t dir_n, hipStream_t s);
+// ls[i] = {doc_len[i], bits of doc_score[i]}
+void launch_pack_len_score(const uint32_t *doc_len, const float *doc_score, uint32_t n, void *ls, hipStream_t s);
 struct HybridReduceArgs {
   uint32_t n_tiles, top_n, k;
   uint32_t surv_cap;                   // survivors the reduce workgroup ranks in LDS (<= 2048); more: *out_n = 0xFFFFFFFF
@@ -246,6 +257,9 @@ struct HybridReduceArgs {
   uint64_t *out_skeys;                 // [top_n]
   uint32_t *out_sids, *out_sn;
   uint32_t *out_krows, *out_kkeys, *out_kids, *out_kn;  // [k]
+  uint64_t *trace;                     // NULL, or [2][kHybTracePhases] clock readings of the two branches (diagnostics)
+  uint32_t *done;                      // pinned host memory, [3] (score branch, KNN branch, hit count): set to 1 -- system-scope
+                                       // release -- once that workgroup's answers are in host memory; the host polls them
 };
 uint32_t hybrid_tiles(uint32_t n0);
 // type / metric: the index's kernel type and metric (kernels.hpp KT_* / KM_*); false: the staged pipeline takes the query
