@@ -71,6 +71,10 @@ def parse():
     ap.add_argument("--replicas", action="store_true", help="N>1, single process: N full replicas instead of N shards "
                                                             "(throughput of concurrent callers; reported separately)")
     ap.add_argument("--tuning", action="append", default=[], help="engine knob key=value (A/B experiments only)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="only the multi-GPU pre-flight: a small index sharded over EVERY visible device (hipSetDevice, VMM, pinned "
+                         "host merge, then the RCCL exchange across all of them), answers held to a one-device index; prints one "
+                         "JSON line and fails loudly with the device index")
     ap.add_argument("--cpu-config0", action="store_true",
                     help="no GPU: time BASELINE configs[0] (100k x 128 fp32 L2 top-10, single query) on the host cores with "
                          "the cpu_baseline port and print one JSON line")
@@ -1023,6 +1027,79 @@ def check_hybrid_with_oracle(p):
                   "BM25STD top-10 and the KNN top-10 (ids identical, distances within 1e-4 + 1e-5 |d|) against the oracle directly"}
 
 
+def preflight(lib, V, n_devices, rows=100_000, dim=64, k=10):
+    """Every visible device once, before anything long runs on them: a FLAT index on each device alone (allocation, the
+    Philox kernel, a scan, the select's pinned-memory write), then ONE handle sharded over all of them answering through the
+    host merge and through the RCCL exchange (ncclCommInitAll + ncclAllGather + merge kernel), all against the same
+    one-device answers.  Raises with the device index on the first failure."""
+    import torch
+    q = np.random.default_rng(1).uniform(-1, 1, (4, dim)).astype(np.float32)
+    out = {"devices": n_devices, "per_device_ok": []}
+    ref = None
+    for d in range(n_devices):
+        try:
+            torch.cuda.set_device(d)
+            idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+            assert idx.add_philox_rows(SEED, 0, rows, 1) == rows
+            ans = [idx.topk_query(x, k).results() for x in q]
+            idx.free()
+            if ref is None:
+                ref = ans
+            assert all(a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() for a, b in zip(ans, ref)), "answers differ from device 0's"
+            out["per_device_ok"].append(d)
+        except Exception as e:
+            raise RuntimeError("pre-flight failed on device %d: %r" % (d, e))
+    torch.cuda.set_device(0)
+    if n_devices > 1:
+        lib.RSGPU_SetTuning(b"shards", n_devices)
+        try:
+            sh = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+        finally:
+            lib.RSGPU_SetTuning(b"shards", 0)
+        try:
+            assert sh.add_philox_rows(SEED, 0, rows, 1) == rows
+            for name, knob in (("host_merge", 0), ("rccl_exchange", 1)):
+                lib.RSGPU_SetTuning(b"shard_exchange", knob)
+                try:
+                    ans = [sh.topk_query(x, k).results() for x in q]
+                    assert all(a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() for a, b in zip(ans, ref)), name
+                    out[name] = "ok"
+                except Exception as e:
+                    raise RuntimeError("pre-flight failed in the %d-shard %s: %r / %s" % (n_devices, name, e, V.last_error()))
+            st = (C.c_uint64 * 3)()
+            lib.RSGPU_ShardedIndex_GetRcclStats(lib.RSGPU_ShardedIndex_FromHandle(sh.ptr), st, 0)
+            out["rccl_ranks"] = int(st[2])
+        finally:
+            lib.RSGPU_SetTuning(b"shard_exchange", 0)
+            sh.free()
+    return out
+
+
+def extra_collective_rccl(lib, V, index, queries, k, dev, steps=40):
+    """The RCCL exchange of the multi-GPU path on whatever this run has -- at N = 1 a ONE-rank communicator: the local top-k
+    goes through the same C code the N-rank run executes (H2D of the winners, ncclAllGather, merge kernel, pinned-memory
+    result), so the line carries what the exchange costs next to a query and that it returns the plain answers."""
+    from redisearch_amd.sharded import ShardComm
+    sc = ShardComm(index, k, dev)
+    try:
+        same = True
+        for i in range(3):
+            labels, scores = sc.query(queries[i])
+            wi, ws = index.topk_query(queries[i], k).results()
+            same &= labels.tolist() == wi.tolist() and scores.tolist() == ws.tolist()
+        sc.stats(reset=True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            sc.query(queries[(3 + i) % len(queries)])
+        el = time.perf_counter() - t0
+        n, ns = sc.stats()
+        return {"kind": sc.kind, "ranks": sc.world, "us_per_query": ns / max(n, 1) / 1e3, "queries": int(n), "qps": steps / el,
+                "payload_bytes_per_rank": k * 16, "same_answers_as_VecSimIndex_TopKQuery": bool(same),
+                "note": "one-rank communicator on a one-GPU run: the N-rank code path with a degenerate collective"}
+    finally:
+        sc.free()
+
+
 # ---- main ------------------------------------------------------------------------------------------------------------------
 def main():
     a = parse()
@@ -1052,6 +1129,12 @@ def main():
 
     from redisearch_amd import vecsim as V
     lib = V.load()   # (oracle/ is imported by the cpu_baseline leg only: verification of the answers + the CPU timing)
+    pre = None
+    if a.preflight or inproc:   # every visible device once, before 30 GB per device go up
+        pre = preflight(lib, V, torch.cuda.device_count() if a.preflight else a.gpus)
+        if a.preflight:
+            print(json.dumps({"preflight": pre}), flush=True)
+            return
     for kv in a.tuning:
         key, val = kv.split("=")
         assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
@@ -1087,8 +1170,10 @@ def main():
     queries = philox_host_rows(V, QUERY_BASE, 1000, dim)   # the product's own generator, read back to the host
 
     if ranks_mode:
-        from redisearch_amd.sharded import ShardedTopK
-        sharded = ShardedTopK(index, k, dev)
+        # the exchange in C: ncclAllGather + merge kernel (shard_comm.cpp); torch.distributed only hands rank 0's unique id
+        # to the other ranks and provides the barriers around the timed region
+        from redisearch_amd.sharded import ShardComm
+        sharded = ShardComm(index, k, dev)
 
     def one_query(i):
         q = queries[i % len(queries)]
@@ -1112,7 +1197,7 @@ def main():
         ex = (C.c_uint64 * 2)()
         lib.RSGPU_ShardedIndex_GetExchangeStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), ex, 1)
     if ranks_mode:
-        sharded.exchanges = sharded.exchange_ns = 0
+        sharded.stats(reset=True)
     lib.RSGPU_ResetProfile()
     lib.RSGPU_SetProfiling(1)
     lat = np.zeros(a.steps)
@@ -1137,9 +1222,8 @@ def main():
                       "ranks": n_shards, "us_per_query": ex[1] / max(ex[0], 1) / 1e3, "queries": int(ex[0]),
                       "payload_bytes_per_rank": k * 16}
     elif ranks_mode:
-        collective = {"kind": "RCCL all-gather (torch.distributed nccl backend) of k*(8+8) B per rank over xGMI + D2H + merge in C "
-                              "(RSGPU_MergeTopKHost)", "ranks": world,
-                      "us_per_query": sharded.exchange_ns / max(sharded.exchanges, 1) / 1e3, "queries": int(sharded.exchanges),
+        ex_n, ex_ns = sharded.stats()
+        collective = {"kind": sharded.kind, "ranks": world, "us_per_query": ex_ns / max(ex_n, 1) / 1e3, "queries": int(ex_n),
                       "payload_bytes_per_rank": k * 16}
 
     if dist is not None:
@@ -1161,6 +1245,33 @@ def main():
                           "ok": bool(worst <= 1e-4), "kth_beats_regenerated_probe_rows": 3 * 2048}
         except Exception as e:
             verify = {"ok": False, "error": repr(e)}
+    if inproc and not a.replicas:
+        # the same queries through the RCCL exchange (knob shard_exchange = 1: ncclCommInitAll over the shard devices, one
+        # ncclAllGather + merge kernel per query) -- reported next to the host merge the timed loop used
+        try:
+            lib.RSGPU_SetTuning(b"shard_exchange", 1)
+            for i in range(3):
+                one_query(i)
+            st = (C.c_uint64 * 3)()
+            hnd = lib.RSGPU_ShardedIndex_FromHandle(index.ptr)
+            lib.RSGPU_ShardedIndex_GetRcclStats(hnd, st, 1)
+            rl = np.zeros(max(a.steps, 1))
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                s_ = time.perf_counter()
+                one_query(a.warmup + i)
+                rl[i] = time.perf_counter() - s_
+            el_r = time.perf_counter() - t0
+            lib.RSGPU_ShardedIndex_GetRcclStats(hnd, st, 0)
+            extras["collective_rccl"] = {"kind": "in-process: ncclCommInitAll over the shard devices; per query ONE ncclAllGather of k*16 B per "
+                                                 "rank + merge kernel (shard_comm.cpp), issued by the shard workers",
+                                         "ranks": int(st[2]), "queries": int(st[0]), "global_qps": a.steps / el_r,
+                                         "p50_ms": float(np.percentile(rl, 50) * 1e3), "p95_ms": float(np.percentile(rl, 95) * 1e3),
+                                         "payload_bytes_per_rank": k * 16}
+        except Exception as e:
+            extras["collective_rccl"] = {"error": repr(e), "last_error": V.last_error()}
+        finally:
+            lib.RSGPU_SetTuning(b"shard_exchange", 0)
     if inproc and not a.replicas and not a.no_extras and not a.no_callers_extra:
         # concurrent callers on the sharded handle: every shard's worker answers up to eight callers per pass over its rows
         try:
@@ -1187,6 +1298,10 @@ def main():
                 extras["concurrent_callers"] = extra_concurrent_callers(lib, V, index, queries, k, rows, dim, a.steps / elapsed)
             except Exception as e:
                 extras["concurrent_callers"] = {"error": repr(e)}
+        try:
+            extras["collective_rccl"] = extra_collective_rccl(lib, V, index, queries, k, dev)
+        except Exception as e:
+            extras["collective_rccl"] = {"error": repr(e)}
         if not a.no_batched_extra and a.metric == "cosine":
             try:
                 extras["batched_mfma_f32"] = extra_batched_f32(lib, V, index, rows, dim)
@@ -1240,7 +1355,7 @@ def main():
         par = ("single GPU" if n_gpus == 1 else
                "%d full replicas in one process behind the plain VecSim handle, one caller thread (replica mode)" % n_gpus if (inproc and a.replicas) else
                "row-sharded x%d in ONE process behind the plain VecSim handle (\"shards\" knob: worker thread per device, host K-way merge)" % n_gpus if inproc else
-               "row-sharded x%d, one rank per GPU: RCCL all-gather of per-shard top-k + merge in C" % n_gpus)
+               "row-sharded x%d, one rank per GPU: ncclAllGather of per-shard top-k issued from C + merge kernel on every rank" % n_gpus)
         out = {
             "metric": "KNN queries/sec + p50 latency, 10M×768 fp32 FLAT top-10, 1/2/4/8 GPU",  # BASELINE.json's metric
             "value": global_qps * scale,
@@ -1277,6 +1392,8 @@ def main():
             },
         }
         out["config"].update(extras)
+        if pre is not None:
+            out["config"]["preflight"] = pre
         if collective is not None:
             out["collective"] = collective
             out["config"]["multi_gpu_note"] = ("no 2/4/8-GPU hardware curve has been measured by the builder (1-GPU boxes only): "

@@ -65,6 +65,30 @@ int RSGPU_MergeTopK(int device, const float *dev_scores, const uint64_t *dev_lab
 int RSGPU_MergeTopKHost(const float *scores, const uint64_t *labels, size_t m, size_t k, double *scores_out,
                         uint64_t *labels_out);
 
+/* ---- the exchange over RCCL, in C (shard_comm.cpp; SURVEY.md 8e, BASELINE north star) -----------------------------
+ * One rank per GPU, every rank holds a row shard behind an ordinary VecSim handle.  RSGPU_ShardComm_TopK: the local shard
+ * answers through the single-query path, its k winners travel as {label, orderable distance key} entries in ONE
+ * ncclAllGather over xGMI, a merge kernel ranks the world x k candidates by (distance, label) on every rank and writes the
+ * k best into pinned host memory -- every rank returns the global answer (the collective analogue of the coordinator's
+ * per-shard top-K -> heap merge, reference src/module.c:3541-3547).  Every rank must call it with the same query and k, in
+ * the same order.  Bootstrap as with any NCCL program: rank 0 calls RSGPU_ShardComm_GetUniqueId (128 bytes), the launcher
+ * hands the id to every rank (MPI_Bcast, a torch.distributed broadcast, a file ...), every rank calls RSGPU_ShardComm_Init.
+ * RCCL is bound at first use (dlopen); without it these return an error and RSGPU_LastError says why. */
+typedef struct RSGPU_ShardComm RSGPU_ShardComm;
+int RSGPU_ShardComm_GetUniqueId(void *id128);
+RSGPU_ShardComm *RSGPU_ShardComm_Init(int rank, int world, const void *id128, int device);
+void RSGPU_ShardComm_Free(RSGPU_ShardComm *c);
+int RSGPU_ShardComm_World(const RSGPU_ShardComm *c);
+/* returns the number of results written (<= k), -1 on error */
+long RSGPU_ShardComm_TopK(RSGPU_ShardComm *c, VecSimIndex *local, const void *query, size_t k, uint64_t *labels_out,
+                          double *scores_out);
+/* out[0] exchanges, out[1] nanoseconds spent in them (H2D of the local winners + all-gather + merge kernel + sync) */
+void RSGPU_ShardComm_GetStats(RSGPU_ShardComm *c, uint64_t out[2], int reset);
+/* the merge kernel alone on n <= 8192 gathered candidates given on the host (labels[i] == UINT64_MAX: padding): the k best
+ * by (score, label) ascending, as RSGPU_MergeTopKHost orders them.  Returns the number written or -1. */
+long RSGPU_MergeTopKDevice(int device, const float *scores, const uint64_t *labels, size_t n, size_t k, double *scores_out,
+                           uint64_t *labels_out);
+
 /* ---- one index over several GPUs of one process (sharded_index.cpp) ------------------------------
  * The in-process form of the coordinator's per-shard top-K -> heap merge (reference src/module.c:3541-3547): the corpus
  * is row-partitioned over n_shards FLAT shards, shard i resident on devices[i] (NULL: i mod the visible devices;
@@ -93,6 +117,10 @@ size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *index);
  * its K winners straight into host memory, so the exchange is a K-way host merge of N * K pairs (no collective inside one
  * process; between processes the same lists travel by one RCCL all-gather, redisearch_amd/sharded.py). */
 void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *index, uint64_t out[2], int reset);
+/* ... and of the queries that took the RCCL exchange instead (RSGPU_SetTuning("shard_exchange", 1): one ncclAllGather of the
+ * per-shard top-k + a merge kernel, shard_comm.cpp; needs one device per shard): out[0] queries, out[1] nanoseconds of the
+ * whole fan-out, out[2] ranks of the communicator (0 before the first such query) */
+void RSGPU_ShardedIndex_GetRcclStats(RSGPU_ShardedIndex *si, uint64_t out[3], int reset);
 /* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
  * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */
 int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *index, const void *blob, size_t label);

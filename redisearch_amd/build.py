@@ -24,8 +24,8 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-
 
 # library name -> sources
 LIBS = {
-    "libVectorSimilarity.so": ["scan_kernels.hip", "scan_mq_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "fusion_kernels.hip", "postings_kernels.hip", "hybrid_kernels.hip", "corpus_kernels.hip",
-                               "flat_index.cpp", "grow_buffer.cpp", "batch_query.cpp", "sharded_index.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
+    "libVectorSimilarity.so": ["scan_kernels.hip", "scan_mq_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "fusion_kernels.hip", "postings_kernels.hip", "hybrid_kernels.hip", "corpus_kernels.hip", "exchange_kernels.hip",
+                               "flat_index.cpp", "grow_buffer.cpp", "batch_query.cpp", "sharded_index.cpp", "shard_comm.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
 }
 
 
@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
             objs = list(ex.map(lambda s: _compile(s, force, hdr_m), paths))
         target = os.path.join(LIBDIR, lib)
         if force or not os.path.exists(target) or any(os.path.getmtime(o) > os.path.getmtime(target) for o in objs):
-            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", target] + objs
+            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", target] + objs + ["-ldl"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -491,7 +491,7 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   __shared__ uint32_t wtau_i[16];
   const uint32_t k = SCORE ? R.top_n : R.k;
   const uint32_t n_tiles = R.n_tiles;  // >= 1
-  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  (void)0;
   // entry e -- the KNN composite carries its doc id in the low word, i is only the "none" mark there
   auto entry = [&](uint32_t e) {
     const uint64_t ck = SCORE ? R.part_skey[e] : R.part_knn[e];

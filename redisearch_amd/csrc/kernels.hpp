@@ -93,6 +93,8 @@ struct ScanTuning {
   int batch_mfma = 1;           // RSGPU_FlatIndex_TopKBatch: 0 = never the matrix-core passes (every batch through the exact
                                 // multi-query scan -- bit-identical to single queries; tests and A/B)
   int shards = 0;          // > 1: VecSimIndex_New builds one index over this many device shards (sharded_index.hpp)
+  int shard_exchange = 0;  // sharded handles: 0 = K-way merge on the host (every shard's winners are in pinned memory already), 1 = ONE
+                           // ncclAllGather of the per-shard top-k + a merge kernel (shard_comm.cpp; one device per shard)
   int shard_replicas = 0;  // with shards: every shard holds the whole corpus, queries go round-robin
   int num_cus = 256;
 };

@@ -1,0 +1,336 @@
+// shard_comm.cpp -- the exchange step of a row-sharded FLAT index over RCCL, in C (round 4).
+//
+// BASELINE's north star: "the corpus shards naturally by row across the 8 GPUs of one node with a RCCL all-gather of
+// per-shard top-K over xGMI".  One RSGPU_ShardComm per rank (= per GPU): a RCCL communicator, a stream, a k x 16-byte send
+// slot and a world x k x 16-byte receive buffer in device memory.  A query: the rank's own shard answers through the
+// ordinary single-query path (VecSimIndex_TopKQuery's code), its k winners go up as {label, orderable distance key}
+// entries, ONE ncclAllGather moves them over xGMI, merge_topk_kernel (exchange_kernels.hip) ranks the world x k
+// candidates by (distance, label) on every rank and writes the k best into pinned host memory: every rank returns the
+// global answer, as every shard of the reference's coordinator could (src/module.c:3541-3547 merges per-shard top-K
+// replies in a heap; src/shard_window_ratio.c:35-48 sizes what a shard sends).
+// Two ways in: rank per process (RSGPU_ShardComm_Init with a unique id the launcher distributes -- bench.py under
+// torch.distributed.run does it with one broadcast) and all ranks in one process (RSGPU_ShardComm_InitAll:
+// ncclCommInitAll over the devices, one communicator per device; sharded_index.cpp's "exchange" knob).
+// RCCL is bound at first use (dlopen of librccl.so.1 -- the instance PyTorch has loaded, when there is one): the library
+// itself has no link-time dependency on it and loads on machines without RCCL.
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "flat_index.hpp"
+#include "rsgpu_ext.h"
+
+namespace rsgpu {
+bool launch_merge_topk(const void *all, uint32_t n, uint32_t k, void *out_pinned, uint32_t *out_n_pinned, hipStream_t s);
+}
+using namespace rsgpu;
+
+namespace {
+
+// the few RCCL entry points the exchange needs (rccl.h: ncclResult_t is an enum, 0 = success; ncclChar = 0)
+struct Nccl {
+  typedef struct {
+    char internal[128];
+  } UniqueId;
+  int (*GetUniqueId)(UniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+  int (*CommInitAll)(void **, int, const int *) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string why;
+  bool ok = false;
+};
+
+Nccl &nccl() {
+  static Nccl n;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) {
+      n.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+      return;
+    }
+#define RSGPU_NCCL_SYM(field, sym)                                  \
+  *(void **)(&n.field) = dlsym(h, sym);                             \
+  if (!n.field) {                                                   \
+    n.why = std::string("RCCL lacks ") + sym;                       \
+    return;                                                         \
+  }
+    RSGPU_NCCL_SYM(GetUniqueId, "ncclGetUniqueId")
+    RSGPU_NCCL_SYM(CommInitRank, "ncclCommInitRank")
+    RSGPU_NCCL_SYM(CommInitAll, "ncclCommInitAll")
+    RSGPU_NCCL_SYM(AllGather, "ncclAllGather")
+    RSGPU_NCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RSGPU_NCCL_SYM(GroupStart, "ncclGroupStart")
+    RSGPU_NCCL_SYM(GroupEnd, "ncclGroupEnd")
+    RSGPU_NCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RSGPU_NCCL_SYM
+    n.ok = true;
+  });
+  return n;
+}
+
+// RCCL prints a version banner to STDOUT when a communicator is created; a host program's stdout may be a protocol
+// (bench.py's one JSON line): the banner goes to stderr instead.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+  }
+  ~StdoutToStderr() {
+    fflush(stdout);
+    if (saved >= 0) {
+      (void)dup2(saved, 1);
+      close(saved);
+    }
+  }
+};
+
+void nccl_check(int rc, const char *what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (nccl().GetErrorString ? nccl().GetErrorString(rc) : "RCCL error"));
+}
+
+struct Entry {  // one candidate on the wire
+  uint64_t label;
+  uint32_t key;  // dist_to_key(fp32 distance): ascending key <=> ascending distance, NaN last
+  uint32_t pad;
+};
+static_assert(sizeof(Entry) == 16, "wire format");
+
+}  // namespace
+
+struct RSGPU_ShardComm {
+  int rank = 0, world = 1, device = 0;
+  void *comm = nullptr;
+  hipStream_t stream = nullptr;
+  size_t k_cap = 0;
+  Entry *d_send = nullptr, *d_recv = nullptr;  // [k_cap], [world][k_cap]
+  Entry *h_send = nullptr, *h_out = nullptr;   // pinned: [k_cap] each
+  uint32_t *h_n = nullptr;                     // pinned
+  std::mutex mu;                               // one exchange at a time per communicator (collectives are ordered)
+  uint64_t exchanges = 0, exchange_ns = 0;
+
+  void ensure(size_t k) {
+    if (k <= k_cap) return;
+    release_buffers();
+    const size_t cap = std::max<size_t>(k, 16);
+    HIP_CHECK(hipMalloc((void **)&d_send, cap * sizeof(Entry)));
+    HIP_CHECK(hipMalloc((void **)&d_recv, cap * (size_t)world * sizeof(Entry)));
+    HIP_CHECK(hipHostMalloc((void **)&h_send, cap * sizeof(Entry), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_out, cap * sizeof(Entry), hipHostMallocDefault));
+    k_cap = cap;
+  }
+  void release_buffers() {
+    if (d_send) (void)hipFree(d_send);
+    if (d_recv) (void)hipFree(d_recv);
+    if (h_send) (void)hipHostFree(h_send);
+    if (h_out) (void)hipHostFree(h_out);
+    d_send = d_recv = h_send = h_out = nullptr;
+    k_cap = 0;
+  }
+  ~RSGPU_ShardComm() {
+    (void)hipSetDevice(device);
+    if (comm && nccl().ok) (void)nccl().CommDestroy(comm);
+    release_buffers();
+    if (h_n) (void)hipHostFree(h_n);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace rsgpu {
+
+// This rank's `n_local` <= k winners (label, score) -> all-gather -> merge on the device -> the global k best on this rank.
+// Every rank of the communicator must call it for the same query, in the same order.  Returns the number of results.
+size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, size_t n_local, size_t k, uint64_t *labels_out,
+                           double *scores_out) {
+  std::lock_guard<std::mutex> g(c->mu);
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_CHECK(hipSetDevice(c->device));
+  c->ensure(k);
+  for (size_t i = 0; i < k; i++) {
+    if (i < n_local) c->h_send[i] = Entry{(uint64_t)local[i].id, dist_to_key((float)local[i].score), 0};
+    else c->h_send[i] = Entry{~0ull, 0xFFFFFFFFu, 0};
+  }
+  HIP_CHECK(hipMemcpyAsync(c->d_send, c->h_send, k * sizeof(Entry), hipMemcpyHostToDevice, c->stream));
+  nccl_check(nccl().AllGather(c->d_send, c->d_recv, k * sizeof(Entry), /*ncclChar*/ 0, c->comm, c->stream), "ncclAllGather");
+  const uint32_t n = (uint32_t)(k * (size_t)c->world);
+  size_t got = 0;
+  if (launch_merge_topk(c->d_recv, n, (uint32_t)k, c->h_out, c->h_n, c->stream)) {
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    got = std::min<size_t>(*c->h_n, k);
+    for (size_t i = 0; i < got; i++) {
+      labels_out[i] = c->h_out[i].label;
+      scores_out[i] = (double)key_to_dist(c->h_out[i].key);
+    }
+  } else {  // more candidates than the merge kernel ranks in LDS (k x world > 8192): the host merge
+    std::vector<Entry> all(n);
+    HIP_CHECK(hipMemcpyAsync(all.data(), c->d_recv, (size_t)n * sizeof(Entry), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    std::vector<float> sc(n);
+    std::vector<uint64_t> lb(n);
+    for (uint32_t i = 0; i < n; i++) {
+      sc[i] = key_to_dist(all[i].key);
+      lb[i] = all[i].label;
+    }
+    const int m = RSGPU_MergeTopKHost(sc.data(), lb.data(), n, k, scores_out, labels_out);
+    if (m < 0) throw std::runtime_error("shard exchange: host merge failed");
+    got = (size_t)m;
+  }
+  c->exchanges++;
+  c->exchange_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return got;
+}
+
+static RSGPU_ShardComm *new_comm(int rank, int world, int device, void *comm) {
+  std::unique_ptr<RSGPU_ShardComm> c(new RSGPU_ShardComm());
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  c->comm = comm;
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_CHECK(hipHostMalloc((void **)&c->h_n, 64, hipHostMallocDefault));
+  return c.release();
+}
+
+// all ranks in this process: one communicator per device (devices must be distinct -- RCCL's rule)
+std::vector<RSGPU_ShardComm *> shard_comm_init_all(const std::vector<int> &devices) {
+  Nccl &n = nccl();
+  if (!n.ok) throw std::runtime_error(n.why);
+  for (size_t i = 0; i < devices.size(); i++)
+    for (size_t j = 0; j < i; j++)
+      if (devices[i] == devices[j]) throw std::runtime_error("a RCCL communicator needs one device per rank (two shards share device " + std::to_string(devices[i]) + ")");
+  std::vector<void *> comms(devices.size(), nullptr);
+  {
+    StdoutToStderr quiet;
+    nccl_check(n.CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+  }
+  std::vector<RSGPU_ShardComm *> out;
+  for (size_t i = 0; i < devices.size(); i++) out.push_back(new_comm((int)i, (int)devices.size(), devices[i], comms[i]));
+  return out;
+}
+
+}  // namespace rsgpu
+
+extern "C" {
+
+int RSGPU_ShardComm_GetUniqueId(void *id128) {
+  if (!id128) return -1;
+  try {
+    Nccl &n = nccl();
+    if (!n.ok) throw std::runtime_error(n.why);
+    Nccl::UniqueId id;
+    nccl_check(n.GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id128, &id, sizeof id);
+    return 0;
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return -1;
+  }
+}
+
+RSGPU_ShardComm *RSGPU_ShardComm_Init(int rank, int world, const void *id128, int device) {
+  try {
+    if (rank < 0 || world < 1 || rank >= world || !id128) throw std::runtime_error("RSGPU_ShardComm_Init: bad rank / world / id");
+    Nccl &n = nccl();
+    if (!n.ok) throw std::runtime_error(n.why);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+      throw std::runtime_error("RSGPU_ShardComm_Init: device " + std::to_string(device) + " of " + std::to_string(n_dev) + " visible");
+    HIP_CHECK(hipSetDevice(device));
+    Nccl::UniqueId id;
+    memcpy(&id, id128, sizeof id);
+    void *comm = nullptr;
+    {
+      StdoutToStderr quiet;
+      nccl_check(n.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+    }
+    return new_comm(rank, world, device, comm);
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    return nullptr;
+  }
+}
+
+void RSGPU_ShardComm_Free(RSGPU_ShardComm *c) { delete c; }
+
+int RSGPU_ShardComm_World(const RSGPU_ShardComm *c) { return c ? c->world : 0; }
+
+/* local: this rank's shard (an ordinary single-device VecSim handle).  Every rank calls it with the same query and k. */
+long RSGPU_ShardComm_TopK(RSGPU_ShardComm *c, VecSimIndex *local, const void *query, size_t k, uint64_t *labels_out, double *scores_out) {
+  if (!c || !local || !local->flat || !query || !k || !labels_out || !scores_out) return -1;
+  VecSimQueryReply *r = nullptr;
+  try {
+    if (local->flat->device != c->device) throw std::runtime_error("RSGPU_ShardComm_TopK: the shard lives on another device than the communicator");
+    r = local->flat->topk(query, k, nullptr, BY_SCORE);
+    const size_t got = shard_comm_exchange(c, r->results, r->len, k, labels_out, scores_out);
+    VecSimQueryReply_Free(r);
+    return (long)got;
+  } catch (const std::exception &e) {
+    if (r) VecSimQueryReply_Free(r);
+    last_error() = e.what();
+    return -1;
+  }
+}
+
+/* The merge step alone, on `device`: n gathered candidates (labels[i] == UINT64_MAX: padding) through merge_topk_kernel.
+ * What the tests hold against RSGPU_MergeTopKHost on many-rank inputs a one-GPU box cannot produce with a communicator. */
+long RSGPU_MergeTopKDevice(int device, const float *scores, const uint64_t *labels, size_t n, size_t k, double *scores_out,
+                           uint64_t *labels_out) {
+  if (!scores || !labels || !scores_out || !labels_out || !k) return -1;
+  Entry *d = nullptr, *h_out = nullptr;
+  uint32_t *h_n = nullptr;
+  long got = -1;
+  try {
+    HIP_CHECK(hipSetDevice(device));
+    std::vector<Entry> all(n);
+    for (size_t i = 0; i < n; i++) all[i] = Entry{labels[i], labels[i] == ~0ull ? 0xFFFFFFFFu : dist_to_key(scores[i]), 0};
+    HIP_CHECK(hipMalloc((void **)&d, std::max<size_t>(n, 1) * sizeof(Entry)));
+    HIP_CHECK(hipHostMalloc((void **)&h_out, k * sizeof(Entry), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h_n, 64, hipHostMallocDefault));
+    HIP_CHECK(hipMemcpy(d, all.data(), n * sizeof(Entry), hipMemcpyHostToDevice));
+    if (!launch_merge_topk(d, (uint32_t)n, (uint32_t)k, h_out, h_n, nullptr)) throw std::runtime_error("RSGPU_MergeTopKDevice: 1..8192 candidates");
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+    got = (long)std::min<size_t>(*h_n, k);
+    for (long i = 0; i < got; i++) {
+      labels_out[i] = h_out[i].label;
+      scores_out[i] = (double)key_to_dist(h_out[i].key);
+    }
+  } catch (const std::exception &e) {
+    last_error() = e.what();
+    got = -1;
+  }
+  if (d) (void)hipFree(d);
+  if (h_out) (void)hipHostFree(h_out);
+  if (h_n) (void)hipHostFree(h_n);
+  return got;
+}
+
+void RSGPU_ShardComm_GetStats(RSGPU_ShardComm *c, uint64_t out[2], int reset) {
+  if (!c) return;
+  std::lock_guard<std::mutex> g(c->mu);
+  if (out) {
+    out[0] = c->exchanges;
+    out[1] = c->exchange_ns;
+  }
+  if (reset) c->exchanges = c->exchange_ns = 0;
+}
+
+}  // extern "C"

@@ -66,6 +66,12 @@ struct RSGPU_ShardedIndex {
   // exchange statistics of the fan-out queries (bench.py's `collective` record): nanoseconds between the moment the last
   // shard's winners are in host memory and the merged reply
   std::atomic<uint64_t> merges{0}, merge_ns{0};
+  // "shard_exchange" = 1: the per-shard top-k travel through ONE ncclAllGather + a merge kernel (shard_comm.cpp) instead of
+  // the host merge -- one communicator per shard device, created by the first such query; collectives are ordered, so
+  // these queries go one at a time
+  std::mutex exchange_mu;
+  std::vector<RSGPU_ShardComm *> comms;
+  std::atomic<uint64_t> rccl_queries{0}, rccl_ns{0};
   size_t n() const { return shards.size(); }
   Shard *pick() { return shards[rr++ % shards.size()].get(); }  // replica mode: round-robin
 };
@@ -283,6 +289,7 @@ void sharded_free(RSGPU_ShardedIndex *si) {
     } catch (...) {
     }
   }
+  for (RSGPU_ShardComm *c : si->comms) RSGPU_ShardComm_Free(c);
   delete si;
 }
 
@@ -351,11 +358,62 @@ double sharded_distance_from(RSGPU_ShardedIndex *si, size_t label, const void *n
   return NAN;
 }
 
+// The exchange over RCCL (knob "shard_exchange" = 1; BASELINE north star: "RCCL all-gather of per-shard top-K over xGMI"):
+// every shard's worker answers its rows, then calls shard_comm_exchange on ITS communicator -- N threads, N ranks, one
+// ncclAllGather -- and the merge kernel leaves the global k best on every device; rank 0's copy is the reply.  A shard
+// that fails still takes part in the collective (with nothing to offer): the other ranks must not be left waiting.
+static VecSimQueryReply *sharded_topk_rccl(RSGPU_ShardedIndex *si, const void *query, size_t k, VecSimQueryParams *qp,
+                                           VecSimQueryReply_Order order) {
+  std::lock_guard<std::mutex> g(si->exchange_mu);
+  if (si->comms.empty()) {
+    std::vector<int> devs;
+    for (auto &s : si->shards) devs.push_back(s->device);
+    si->comms = shard_comm_init_all(devs);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t n = si->n();
+  std::vector<std::vector<uint64_t>> labels(n, std::vector<uint64_t>(k));
+  std::vector<std::vector<double>> scores(n, std::vector<double>(k));
+  std::vector<size_t> got(n, 0);
+  std::vector<int> codes(n, (int)VecSim_QueryReply_OK);
+  std::vector<std::function<void()>> jobs(n);
+  for (size_t i = 0; i < n; i++)
+    jobs[i] = [&, i] {
+      VecSimQueryReply *r = nullptr;
+      std::exception_ptr err;
+      try {
+        si->shards[i]->flat->last_mode = STANDARD_KNN;
+        r = si->shards[i]->flat->topk(query, k, qp, BY_SCORE);
+        codes[i] = (int)r->code;
+      } catch (...) {
+        err = std::current_exception();
+      }
+      try {
+        got[i] = shard_comm_exchange(si->comms[i], r ? r->results : nullptr, r ? r->len : 0, k, labels[i].data(), scores[i].data());
+      } catch (...) {
+        if (!err) err = std::current_exception();
+      }
+      if (r) VecSimQueryReply_Free(r);
+      if (err) std::rethrow_exception(err);
+    };
+  run_on_shards(si, jobs);
+  for (size_t i = 0; i < n; i++)
+    if (codes[i] == (int)VecSim_QueryReply_TimedOut) return new_reply(0, VecSim_QueryReply_TimedOut);
+  VecSimQueryReply *out = new_reply(got[0], VecSim_QueryReply_OK);
+  for (size_t j = 0; j < got[0]; j++) out->results[j] = VecSimQueryResult{(size_t)labels[0][j], scores[0][j]};
+  if (order == BY_ID)
+    std::sort(out->results, out->results + out->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
+  si->rccl_queries++;
+  si->rccl_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return out;
+}
+
 VecSimQueryReply *sharded_topk(RSGPU_ShardedIndex *si, const void *query, size_t k, VecSimQueryParams *qp,
                                VecSimQueryReply_Order order) {
   DeviceGuard dg;
   si->last_mode = STANDARD_KNN;
   if (si->replicas) return si->pick()->flat->topk(query, k, qp, order);
+  if (scan_tuning().shard_exchange == 1 && k) return sharded_topk_rccl(si, query, k, qp, order);
   if (si->n() == 1) return si->shards[0]->flat->topk(query, k, qp, order);
   // fan out: one top-k task per shard; the shard workers batch the tasks of concurrent callers into shared passes
   std::vector<TopkJob> jobs(si->n(), TopkJob{query, k, qp ? qp->timeoutCtx : nullptr, BY_SCORE});
@@ -655,6 +713,15 @@ void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *si, uint64_t out[2]
   out[0] = si->merges.load();
   out[1] = si->merge_ns.load();
   if (reset) si->merges = si->merge_ns = 0;
+}
+/* the same for the queries that took the RCCL exchange (knob "shard_exchange" = 1): out[0] queries, out[1] nanoseconds of
+ * the whole fan-out (shard scans + all-gather + merge kernel), out[2] ranks of the communicator (0: not created yet) */
+void RSGPU_ShardedIndex_GetRcclStats(RSGPU_ShardedIndex *si, uint64_t out[3], int reset) {
+  if (!si || !out) return;
+  out[0] = si->rccl_queries.load();
+  out[1] = si->rccl_ns.load();
+  out[2] = si->comms.size();
+  if (reset) si->rccl_queries = si->rccl_ns = 0;
 }
 
 int RSGPU_ShardedIndex_AddVector(RSGPU_ShardedIndex *si, const void *blob, size_t label) {

@@ -5,12 +5,20 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "flat_index.hpp"
 
 struct RSGPU_ShardedIndex;
+struct RSGPU_ShardComm;
 
 namespace rsgpu {
+
+// the exchange over RCCL (shard_comm.cpp): one communicator per device for ranks that live in one process, and the
+// exchange itself -- this rank's winners -> ncclAllGather -> merge kernel -> the global k best
+std::vector<RSGPU_ShardComm *> shard_comm_init_all(const std::vector<int> &devices);
+size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, size_t n_local, size_t k, uint64_t *labels_out,
+                           double *scores_out);
 
 RSGPU_ShardedIndex *sharded_new(const BFParams &p, void *log_ctx, int n_shards, const int *devices, bool replicas);
 void sharded_free(RSGPU_ShardedIndex *si);

@@ -42,8 +42,64 @@ def merge_topk_numpy(scores, labels, k):
     return labels[order], scores[order]
 
 
+class ShardComm:
+    """The exchange in C (redisearch_amd/csrc/shard_comm.cpp, include/rsgpu_ext.h RSGPU_ShardComm_*): ncclAllGather of the
+    per-shard top-k + a merge kernel, one communicator per rank.  This wrapper only bootstraps it -- rank 0's unique id
+    reaches the other ranks through ONE torch.distributed broadcast, as an MPI launcher would MPI_Bcast it -- and forwards
+    query(): no torch collective, no numpy merge on the query path."""
+
+    def __init__(self, index, k, device, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import vecsim as V
+        self.lib, self.V, self.index, self.k = V.load(), V, index, k
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        uid = (C.c_char * 128)()
+        if rank == 0 and self.lib.RSGPU_ShardComm_GetUniqueId(uid) != 0:
+            raise RuntimeError(V.last_error())
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+            dist.broadcast(t, src=0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        self.ptr = self.lib.RSGPU_ShardComm_Init(rank, self.world, uid, device.index if device.index is not None else 0)
+        if not self.ptr:
+            raise RuntimeError(V.last_error())
+        self._labels, self._scores = np.zeros(k, np.uint64), np.zeros(k, np.float64)
+        self.kind = "RCCL all-gather issued from C (ncclAllGather, shard_comm.cpp) of k*16 B per rank over xGMI + merge kernel on every rank"
+
+    def query(self, q):
+        qb = self.index._q(q)
+        n = self.lib.RSGPU_ShardComm_TopK(self.ptr, self.index.ptr, qb.ctypes.data_as(C.c_void_p), self.k,
+                                          self._labels.ctypes.data_as(C.c_void_p), self._scores.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            raise RuntimeError(self.V.last_error())
+        return self._labels[:n].copy(), self._scores[:n].copy()
+
+    def stats(self, reset=False):
+        a = (C.c_uint64 * 2)()
+        self.lib.RSGPU_ShardComm_GetStats(self.ptr, a, 1 if reset else 0)
+        return int(a[0]), int(a[1])
+
+    @property
+    def exchanges(self):
+        return self.stats()[0]
+
+    @property
+    def exchange_ns(self):
+        return self.stats()[1]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.lib.RSGPU_ShardComm_Free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
 class ShardedTopK:
-    """`local` is this rank's shard: a redisearch_amd.vecsim.VecSimIndex (GPU) or a callable
+    """The same exchange through torch.distributed (what the world-size-2 / 4 gloo tests run on CPU; on GPUs ShardComm above
+    is the product path).  `local` is this rank's shard: a redisearch_amd.vecsim.VecSimIndex (GPU) or a callable
     local_topk(q, k) -> (scores tensor[k] float32, labels tensor[k] int64) padded with +inf / -1 (CPU tests)."""
 
     def __init__(self, local, k, device, group=None):
@@ -52,6 +108,7 @@ class ShardedTopK:
         self.torch, self.dist = torch, dist
         self.k, self.group = k, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.kind = "all-gather through torch.distributed + RSGPU_MergeTopKHost"
         self.exchanges, self.exchange_ns = 0, 0   # the collective + D2H + merge of every query (bench.py's `collective`)
         # one collective per query: labels and the fp32 score bits travel in the same int64 buffer
         self.pack = torch.empty(2 * k, dtype=torch.int64, device=device)

@@ -194,8 +194,16 @@ ABI = {
     "RSGPU_GetLastScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
     "RSGPU_GetTwoStageStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_ShardedIndex_GetExchangeStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
+    "RSGPU_ShardedIndex_GetRcclStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_GetWidePassStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_ShardComm_GetUniqueId": (_i, [_vp]),
+    "RSGPU_ShardComm_Init": (_vp, [_i, _i, _vp, _i]),
+    "RSGPU_ShardComm_Free": (None, [_vp]),
+    "RSGPU_ShardComm_World": (_i, [_vp]),
+    "RSGPU_ShardComm_TopK": (C.c_long, [_vp, _vp, _vp, _sz, _vp, _vp]),
+    "RSGPU_ShardComm_GetStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
+    "RSGPU_MergeTopKDevice": (C.c_long, [_i, _vp, _vp, _sz, _sz, _vp, _vp]),
     "RSGPU_ResetCoalesceStats": (None, []),
     "RSGPU_GetLastMqScanKernel": (C.c_char_p, [C.c_char_p, _sz]),
     "RSGPU_ResetTwoStageStats": (None, []),

@@ -96,11 +96,11 @@ def test_hybrid_two_launch_kernels_budget(kernels):
     """hybrid_tile_kernel keeps seven (six for fp16 / bf16 L2) workgroups per CU -- its phases are dependent memory round trips,
     residency is what hides them: at most 80 registers (six waves per SIMD), no scratch (a select between two structs put the
     first version's keys into scratch memory), static LDS small next to the dynamic pool (16-20 KiB + the query).  The reduce
-    kernel is one workgroup of 1 024: at most 128 registers (four waves per SIMD), its survivor lists inside 32 KiB."""
+    kernel is one workgroup of 1 024: at most 128 registers (four waves per SIMD), its survivor lists + the list of passing tiles inside 40 KiB."""
     tiles = [k for k in kernels if k["name"].startswith("hybrid_tile_kernel<")]
     assert len(tiles) == 6                # FLOAT32 / FLOAT16 / BFLOAT16 x L2 / IP
     for k in tiles:
         assert k["vgpr"] <= 80 and not k["scratch"] and k["lds"] <= 4096 and k["wg"] == 256, k
     red = [k for k in kernels if k["name"].startswith("hybrid_reduce_kernel")]
     assert len(red) == 1
-    assert red[0]["vgpr"] <= 128 and not red[0]["scratch"] and red[0]["lds"] <= 32768 and red[0]["wg"] == 1024, red[0]
+    assert red[0]["vgpr"] <= 128 and not red[0]["scratch"] and red[0]["lds"] <= 40960 and red[0]["wg"] == 1024, red[0]
