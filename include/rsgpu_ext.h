@@ -150,6 +150,10 @@ void RSGPU_ResetCoalesceStats(void);
  * re-scoring, up to 256 per pass, replies bit-identical to serial ones.  out[0] wide passes, [1] queries they served.
  * Knob "coalesce_wide" (default 1).  Reset by RSGPU_ResetCoalesceStats. */
 void RSGPU_GetWidePassStats(uint64_t out[2]);
+/* calls that left the coalescer's queue because their timeout callback fired while they waited (round 4): a queued call
+ * polls ITS OWN timeoutCtx on ITS OWN thread every millisecond -- the callback never runs on another caller's thread -- and
+ * returns VecSim_QueryReply_TimedOut without waiting for the pass in flight.  Reset by RSGPU_ResetCoalesceStats. */
+uint64_t RSGPU_GetCoalesceTimeouts(void);
 /* like RSGPU_GetLastScanKernel, for the multi-query scan */
 const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap);
 /* Two-stage (shadow) scans of this process since the last reset: out[0] attempts, [1] answered by the two-stage path,

@@ -1182,7 +1182,15 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     return topk_locked(query, k, tctx, order);
   }
   TopkJob job{query, k, tctx, order};
+  job.owner_polls = true;
   std::vector<TopkJob *> batch;
+  // what the caller gets when ITS timeout fired while the call sat in the queue or in somebody's pass
+  auto finish = [&](VecSimQueryReply *r) -> VecSimQueryReply * {
+    if (!tctx || !r || r->code != VecSim_QueryReply_OK || !timed_out(tctx)) return r;
+    host_free(r->results);
+    host_free(r);
+    return new_reply(0, VecSim_QueryReply_TimedOut);
+  };
   // how many calls a pass may hold: sixteen through the exact multi-query scan; kWidePass where the index's batches go
   // through a matrix-core filter pass + exact re-scoring (same bits, one corpus pass for all of them)
   const uint32_t cap = wide_pass_capable(k) ? kWidePass : kMqMaxQueries;
@@ -1190,12 +1198,49 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     std::unique_lock<std::mutex> lk(co_.mu);
     co_.waiting.push_back(&job);
     if (co_.lingering) co_.cv_leader.notify_one();
-    // sleep until a leader has answered this query, or it is this caller's turn to lead
-    co_.cv.wait(lk, [&] { return job.done || (!co_.busy && co_.waiting.front() == &job); });
+    // sleep until a leader has answered this query, or it is this caller's turn to lead -- in slices of a millisecond when
+    // the call carries a timeout context: a call that times out while it is QUEUED (a pass it is not part of takes 5-6 ms at
+    // 10 M x 768) leaves the queue at once (reference src/util/timeout.h:70,89 polls every 100 iterations of its loops)
+    auto ready = [&] { return job.done || (!co_.busy && !co_.waiting.empty() && co_.waiting.front() == &job); };
+    if (!tctx) {
+      co_.cv.wait(lk, ready);
+    } else {
+      while (!ready()) {  // (polled when the call joins the queue, then every millisecond)
+        if (!job.taken) {   // (in a pass: its leader owns the job until the pass is done)
+          lk.unlock();
+          const bool expired = timed_out(tctx);  // (the host's callback: never under the coalescer's lock)
+          lk.lock();
+          if (expired && !job.taken && !job.done) {
+            auto it = std::find(co_.waiting.begin(), co_.waiting.end(), &job);
+            if (it != co_.waiting.end()) {
+              const bool was_front = it == co_.waiting.begin();
+              co_.waiting.erase(it);
+              coalesce_stats().left_queue++;
+              lk.unlock();
+              if (was_front) co_.cv.notify_all();  // (whoever is first now may be due to lead)
+              return new_reply(0, VecSim_QueryReply_TimedOut);
+            }
+          }
+          if (ready()) break;
+        }
+        co_.cv.wait_for(lk, std::chrono::milliseconds(1), ready);
+      }
+    }
     if (job.done) {
       lk.unlock();
       if (job.err) std::rethrow_exception(job.err);
-      return job.reply;
+      return finish(job.reply);
+    }
+    if (tctx) {  // this caller leads: its own timeout first (the passes do not poll a coalesced job's callback)
+      lk.unlock();
+      const bool expired = timed_out(tctx);
+      lk.lock();
+      if (expired) {
+        co_.waiting.erase(std::find(co_.waiting.begin(), co_.waiting.end(), &job));
+        lk.unlock();
+        co_.cv.notify_all();
+        return new_reply(0, VecSim_QueryReply_TimedOut);
+      }
     }
     co_.busy = true;
     // the callers of the previous pass are on their way back with their next query: give them a moment, so that the
@@ -1214,6 +1259,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     }
     const size_t take = std::min<size_t>(co_.waiting.size(), cap);
     batch.assign(co_.waiting.begin(), co_.waiting.begin() + (long)take);
+    for (TopkJob *j : batch) j->taken = true;
     co_.waiting.erase(co_.waiting.begin(), co_.waiting.begin() + (long)take);
   }
   std::exception_ptr err;
@@ -1236,7 +1282,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   }
   co_.cv.notify_all();
   if (job.err) std::rethrow_exception(job.err);
-  return job.reply;
+  return finish(job.reply);
 }
 
 // More than sixteen calls in one pass: their queries side by side through topk_batch -- a matrix-core filter pass over the
@@ -1246,7 +1292,7 @@ void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
   std::vector<TopkJob *> wide, rest;
   for (size_t i = 0; i < n_jobs; i++) {
     TopkJob *j = jobs[i];
-    if (timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+    if (!j->owner_polls && timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
     else if (!j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
     else (wide_pass_capable(j->k) ? wide : rest).push_back(j);
   }
@@ -1272,7 +1318,7 @@ void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
   topk_batch(qbuf.data(), wide.size(), kmax, ids.data(), sc.data(), cnt.data(), k_each.data());
   for (size_t i = 0; i < wide.size(); i++) {
     TopkJob *j = wide[i];
-    if (timed_out(j->tctx)) {
+    if (!j->owner_polls && timed_out(j->tctx)) {
       j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
       continue;
     }
@@ -1303,7 +1349,7 @@ void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
   size_t n_live = 0;
   for (size_t i = 0; i < n_jobs; i++) {
     TopkJob *j = jobs[i];
-    if (timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
+    if (!j->owner_polls && timed_out(j->tctx)) j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
     else if (!n || !j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
     else live[n_live++] = j;
   }
@@ -1438,7 +1484,7 @@ void FlatIndex::topk_pass_mq(TopkJob *const *jobs, size_t nj, uint32_t n) {
   }
   for (size_t b = 0; b < nj; b++) {
     TopkJob *j = jobs[b];
-    if (timed_out(j->tctx)) {
+    if (!j->owner_polls && timed_out(j->tctx)) {
       j->reply = new_reply(0, VecSim_QueryReply_TimedOut);
       continue;
     }

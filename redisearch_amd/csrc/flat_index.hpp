@@ -150,12 +150,17 @@ struct TopkJob {
   VecSimQueryReply *reply = nullptr;
   std::exception_ptr err;
   bool done = false;
+  // the coalescer's jobs (FlatIndex::topk): the timeout callback is the CALLER's to poll -- on its own thread, as the
+  // single-query path does (a host callback may rely on thread-local state), every millisecond while it waits in the queue --
+  // so the pass that serves the job does not poll it; `taken`: a leader has put the job into its pass (the caller can no
+  // longer leave the queue; it checks its timeout again when the pass is done)
+  bool owner_polls = false, taken = false;
 };
 
 // What the coalescer did (RSGPU_GetCoalesceStats; bench.py's concurrent_callers sub-record).
 struct CoalesceStats {
   std::atomic<uint64_t> passes{0}, queries{0}, mq_passes{0}, mq_queries{0}, lingers{0}, linger_ns{0}, mq_device_ns{0},
-      mq_redo{0}, wide_passes{0}, wide_queries{0};
+      mq_redo{0}, wide_passes{0}, wide_queries{0}, left_queue{0};
 };
 CoalesceStats &coalesce_stats();
 

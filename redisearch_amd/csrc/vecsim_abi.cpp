@@ -669,13 +669,14 @@ void RSGPU_GetCoalesceStats(uint64_t out[8]) {
 void RSGPU_ResetCoalesceStats(void) {
   CoalesceStats &c = coalesce_stats();
   c.passes = c.queries = c.mq_passes = c.mq_queries = c.lingers = c.linger_ns = c.mq_device_ns = c.mq_redo = 0;
-  c.wide_passes = c.wide_queries = 0;
+  c.wide_passes = c.wide_queries = c.left_queue = 0;
 }
 void RSGPU_GetWidePassStats(uint64_t out[2]) {
   if (!out) return;
   out[0] = coalesce_stats().wide_passes.load();
   out[1] = coalesce_stats().wide_queries.load();
 }
+uint64_t RSGPU_GetCoalesceTimeouts(void) { return coalesce_stats().left_queue.load(); }
 const char *RSGPU_GetLastMqScanKernel(char *buf, size_t cap) {
   if (!buf || !cap) return "";
   return last_scan_mq_kernel_name(buf, cap);

@@ -197,6 +197,7 @@ ABI = {
     "RSGPU_ShardedIndex_GetRcclStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_GetWidePassStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_GetCoalesceTimeouts": (C.c_uint64, []),
     "RSGPU_ShardComm_GetUniqueId": (_i, [_vp]),
     "RSGPU_ShardComm_Init": (_vp, [_i, _i, _vp, _i]),
     "RSGPU_ShardComm_Free": (None, [_vp]),
@@ -580,11 +581,13 @@ def coalesce_stats(reset=False):
     load().RSGPU_GetCoalesceStats(a)
     w = (C.c_uint64 * 2)()
     load().RSGPU_GetWidePassStats(w)
+    left = int(load().RSGPU_GetCoalesceTimeouts())
     if reset:
         load().RSGPU_ResetCoalesceStats()
     names = ("passes", "queries", "mq_passes", "mq_queries", "lingers", "linger_ns", "mq_device_ns", "mq_redo")
     out = {n: int(a[i]) for i, n in enumerate(names)}
     out["wide_passes"], out["wide_queries"] = int(w[0]), int(w[1])
+    out["left_queue_on_timeout"] = left
     return out
 
 

@@ -294,3 +294,58 @@ def test_writers_and_timeouts_next_to_coalesced_readers(knobs):
             del cb
     finally:
         idx.free()
+
+
+def test_a_timeout_that_fires_while_the_call_is_queued(knobs):
+    """Round 4: a call parked behind a pass it is not part of polls ITS OWN timeout callback on ITS OWN
+    thread and leaves the queue with VecSim_QueryReply_TimedOut -- it neither waits for that pass nor rides in the next one;
+    the callback is never invoked from another caller's thread; calls without a deadline get their serial answers."""
+    knobs("coalesce_min_mib", 0)
+    n, dim = 3_000_000, 256                       # ~0.6 ms per pass: long enough for callers to queue behind it
+    idx = _index(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2, n)
+    try:
+        qs = _queries(V.VecSimType_FLOAT32, dim, 16)
+        want = [idx.topk_query(q, 10).results() for q in qs]
+        calls = []                                 # (ctx, thread id) of every callback invocation
+        armed = threading.Event()
+
+        def on_timeout(ctx):
+            calls.append((int(ctx or 0), threading.get_ident()))
+            return 1 if ctx and armed.is_set() else 0
+        cb = V.set_timeout_callback(on_timeout)
+        try:
+            n_threads, reps = 12, 30
+            owner = {}
+            out = [[] for _ in range(n_threads)]
+            bar = threading.Barrier(n_threads)
+
+            def caller(t):
+                owner[t + 1] = threading.get_ident()
+                qp = V.VecSimQueryParams()
+                qp.timeoutCtx = t + 1 if t % 3 == 0 else None      # every third caller carries a deadline
+                bar.wait()
+                for r in range(reps):
+                    rep = idx.topk_query(qs[(t + r) % len(qs)], 10, params=qp)
+                    out[t].append((rep.code, rep.results()[0].tolist(), (t + r) % len(qs)))
+            V.coalesce_stats(reset=True)
+            armed.set()
+            th = [threading.Thread(target=caller, args=(t,)) for t in range(n_threads)]
+            [x.start() for x in th]
+            [x.join() for x in th]
+            st = V.coalesce_stats()
+            for t in range(n_threads):
+                for code, ids, qi in out[t]:
+                    if t % 3 == 0:
+                        assert code == V.VecSim_QueryReply_TimedOut and ids == []
+                    else:
+                        assert code == V.VecSim_QueryReply_OK and ids == want[qi][0].tolist()
+            # expired calls never rode in a pass; some of them were queued behind one when they gave up
+            assert st["queries"] == (n_threads - n_threads // 3) * reps, st
+            assert st["left_queue_on_timeout"] > 0, st
+            # the callback ran on the thread that owns the context, never on a leader's or a worker's
+            assert calls and all(tid == owner[ctx] for ctx, tid in calls if ctx), [c for c in calls if c[0] and c[1] != owner[c[0]]][:3]
+        finally:
+            V.set_timeout_callback(None)
+            del cb
+    finally:
+        idx.free()
