@@ -119,7 +119,8 @@ size_t RSGPU_ShardedIndex_IndexSize(RSGPU_ShardedIndex *index);
 void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *index, uint64_t out[2], int reset);
 /* ... and of the queries that took the RCCL exchange instead (RSGPU_SetTuning("shard_exchange", 1): one ncclAllGather of the
  * per-shard top-k + a merge kernel, shard_comm.cpp; needs one device per shard): out[0] queries, out[1] nanoseconds of the
- * whole fan-out, out[2] ranks of the communicator (0 before the first such query) */
+ * exchange (H2D of the winners + all-gather + merge kernel + sync; the first one includes creating the communicators),
+ * out[2] ranks of the communicator (0 before the first such query) */
 void RSGPU_ShardedIndex_GetRcclStats(RSGPU_ShardedIndex *si, uint64_t out[3], int reset);
 /* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
  * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */

@@ -1181,6 +1181,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     std::shared_lock<std::shared_mutex> g(mu);
     return topk_locked(query, k, tctx, order);
   }
+  if (tctx && timed_out(tctx)) return new_reply(0, VecSim_QueryReply_TimedOut);  // (expired on arrival: never queued)
   TopkJob job{query, k, tctx, order};
   job.owner_polls = true;
   std::vector<TopkJob *> batch;
@@ -1205,7 +1206,8 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
     if (!tctx) {
       co_.cv.wait(lk, ready);
     } else {
-      while (!ready()) {  // (polled when the call joins the queue, then every millisecond)
+      while (!ready()) {  // (polled on arrival, then every millisecond)
+        if (co_.cv.wait_for(lk, std::chrono::milliseconds(1), ready)) break;
         if (!job.taken) {   // (in a pass: its leader owns the job until the pass is done)
           lk.unlock();
           const bool expired = timed_out(tctx);  // (the host's callback: never under the coalescer's lock)
@@ -1221,9 +1223,7 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
               return new_reply(0, VecSim_QueryReply_TimedOut);
             }
           }
-          if (ready()) break;
         }
-        co_.cv.wait_for(lk, std::chrono::milliseconds(1), ready);
       }
     }
     if (job.done) {

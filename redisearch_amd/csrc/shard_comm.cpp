@@ -105,6 +105,20 @@ void nccl_check(int rc, const char *what) {
   if (rc != 0) throw std::runtime_error(std::string(what) + ": " + (nccl().GetErrorString ? nccl().GetErrorString(rc) : "RCCL error"));
 }
 
+// hipStreamSynchronize with a deadline: a collective whose peers never arrive (a rank that died, a mis-ordered call) must
+// surface as an error, not as a process that waits for ever
+void sync_or_throw(hipStream_t s, double seconds, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+      throw std::runtime_error(std::string(what) + ": not complete after " + std::to_string((int)seconds) + " s (a rank missing from the collective?)");
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.002) usleep(50);
+  }
+}
+
 struct Entry {  // one candidate on the wire
   uint64_t label;
   uint32_t key;  // dist_to_key(fp32 distance): ascending key <=> ascending distance, NaN last
@@ -172,7 +186,7 @@ size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, s
   size_t got = 0;
   if (launch_merge_topk(c->d_recv, n, (uint32_t)k, c->h_out, c->h_n, c->stream)) {
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    sync_or_throw(c->stream, 20.0, "shard exchange (all-gather + merge)");
     got = std::min<size_t>(*c->h_n, k);
     for (size_t i = 0; i < got; i++) {
       labels_out[i] = c->h_out[i].label;
@@ -181,7 +195,7 @@ size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, s
   } else {  // more candidates than the merge kernel ranks in LDS (k x world > 8192): the host merge
     std::vector<Entry> all(n);
     HIP_CHECK(hipMemcpyAsync(all.data(), c->d_recv, (size_t)n * sizeof(Entry), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    sync_or_throw(c->stream, 20.0, "shard exchange (all-gather)");
     std::vector<float> sc(n);
     std::vector<uint64_t> lb(n);
     for (uint32_t i = 0; i < n; i++) {
@@ -209,21 +223,115 @@ static RSGPU_ShardComm *new_comm(int rank, int world, int device, void *comm) {
   return c.release();
 }
 
-// all ranks in this process: one communicator per device (devices must be distinct -- RCCL's rule)
-std::vector<RSGPU_ShardComm *> shard_comm_init_all(const std::vector<int> &devices) {
+// Ranks that live in ONE process (sharded_index.cpp): the caller creates the unique id, then EVERY rank's own thread -- the
+// shard's worker, the thread that will issue its collectives -- calls shard_comm_init_rank concurrently, as
+// ncclCommInitRank wants it (it rendezvouses with the other ranks).  Devices must be distinct: RCCL's rule.
+void shard_comm_unique_id(void *id128) {
   Nccl &n = nccl();
   if (!n.ok) throw std::runtime_error(n.why);
-  for (size_t i = 0; i < devices.size(); i++)
-    for (size_t j = 0; j < i; j++)
-      if (devices[i] == devices[j]) throw std::runtime_error("a RCCL communicator needs one device per rank (two shards share device " + std::to_string(devices[i]) + ")");
-  std::vector<void *> comms(devices.size(), nullptr);
+  Nccl::UniqueId id;
+  nccl_check(n.GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(id128, &id, sizeof id);
+}
+RSGPU_ShardComm *shard_comm_init_rank(int rank, int world, const void *id128, int device) {
+  Nccl &n = nccl();
+  if (!n.ok) throw std::runtime_error(n.why);
+  HIP_CHECK(hipSetDevice(device));
+  Nccl::UniqueId id;
+  memcpy(&id, id128, sizeof id);
+  void *comm = nullptr;
   {
     StdoutToStderr quiet;
-    nccl_check(n.CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+    nccl_check(n.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
+  }
+  return new_comm(rank, world, device, comm);
+}
+
+// All ranks of ONE process driven from ONE thread -- the caller's (sharded_index.cpp): the documented single-thread form,
+// every per-rank call between ncclGroupStart / ncclGroupEnd.  One rank: the plain calls.
+std::vector<RSGPU_ShardComm *> shard_comm_init_group(const std::vector<int> &devices) {
+  Nccl &n = nccl();
+  if (!n.ok) throw std::runtime_error(n.why);
+  const int world = (int)devices.size();
+  char id[128];
+  shard_comm_unique_id(id);
+  if (world == 1) return {shard_comm_init_rank(0, 1, id, devices[0])};
+  Nccl::UniqueId uid;
+  memcpy(&uid, id, sizeof uid);
+  std::vector<void *> comms((size_t)world, nullptr);
+  {
+    StdoutToStderr quiet;
+    nccl_check(n.GroupStart(), "ncclGroupStart");
+    for (int r = 0; r < world; r++) {
+      HIP_CHECK(hipSetDevice(devices[(size_t)r]));
+      nccl_check(n.CommInitRank(&comms[(size_t)r], world, uid, r), "ncclCommInitRank");
+    }
+    nccl_check(n.GroupEnd(), "ncclGroupEnd");
   }
   std::vector<RSGPU_ShardComm *> out;
-  for (size_t i = 0; i < devices.size(); i++) out.push_back(new_comm((int)i, (int)devices.size(), devices[i], comms[i]));
+  for (int r = 0; r < world; r++) out.push_back(new_comm(r, world, devices[(size_t)r], comms[(size_t)r]));
   return out;
+}
+
+// local[r] / n_local[r]: rank r's winners.  One all-gather (a group of world calls), the merge kernel on rank 0's device,
+// the global k best to labels_out / scores_out.  Returns their number.
+size_t shard_comm_exchange_group(const std::vector<RSGPU_ShardComm *> &cs, const VecSimQueryResult *const *local, const size_t *n_local,
+                                 size_t k, uint64_t *labels_out, double *scores_out) {
+  Nccl &n = nccl();
+  const size_t world = cs.size();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (size_t r = 0; r < world; r++) {
+    RSGPU_ShardComm *c = cs[r];
+    HIP_CHECK(hipSetDevice(c->device));
+    c->ensure(k);
+    for (size_t i = 0; i < k; i++) {
+      if (i < n_local[r]) c->h_send[i] = Entry{(uint64_t)local[r][i].id, dist_to_key((float)local[r][i].score), 0};
+      else c->h_send[i] = Entry{~0ull, 0xFFFFFFFFu, 0};
+    }
+    HIP_CHECK(hipMemcpyAsync(c->d_send, c->h_send, k * sizeof(Entry), hipMemcpyHostToDevice, c->stream));
+  }
+  if (world > 1) nccl_check(n.GroupStart(), "ncclGroupStart");
+  for (size_t r = 0; r < world; r++) {
+    HIP_CHECK(hipSetDevice(cs[r]->device));
+    nccl_check(n.AllGather(cs[r]->d_send, cs[r]->d_recv, k * sizeof(Entry), /*ncclChar*/ 0, cs[r]->comm, cs[r]->stream), "ncclAllGather");
+  }
+  if (world > 1) nccl_check(n.GroupEnd(), "ncclGroupEnd");
+  RSGPU_ShardComm *c0 = cs[0];
+  HIP_CHECK(hipSetDevice(c0->device));
+  const uint32_t total = (uint32_t)(k * world);
+  size_t got = 0;
+  const bool on_device = launch_merge_topk(c0->d_recv, total, (uint32_t)k, c0->h_out, c0->h_n, c0->stream);
+  std::vector<Entry> all;
+  if (on_device) {
+    HIP_CHECK(hipGetLastError());
+  } else {
+    all.resize(total);
+    HIP_CHECK(hipMemcpyAsync(all.data(), c0->d_recv, (size_t)total * sizeof(Entry), hipMemcpyDeviceToHost, c0->stream));
+  }
+  for (size_t r = 0; r < world; r++) {  // (every rank's stream: the buffers are reused by the next query)
+    HIP_CHECK(hipSetDevice(cs[r]->device));
+    sync_or_throw(cs[r]->stream, 20.0, "shard exchange (all-gather + merge)");
+  }
+  if (on_device) {
+    got = std::min<size_t>(*c0->h_n, k);
+    for (size_t i = 0; i < got; i++) {
+      labels_out[i] = c0->h_out[i].label;
+      scores_out[i] = (double)key_to_dist(c0->h_out[i].key);
+    }
+  } else {
+    std::vector<float> sc(total);
+    std::vector<uint64_t> lb(total);
+    for (uint32_t i = 0; i < total; i++) {
+      sc[i] = key_to_dist(all[i].key);
+      lb[i] = all[i].label;
+    }
+    const int m = RSGPU_MergeTopKHost(sc.data(), lb.data(), total, k, scores_out, labels_out);
+    if (m < 0) throw std::runtime_error("shard exchange: host merge failed");
+    got = (size_t)m;
+  }
+  c0->exchanges++;
+  c0->exchange_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  return got;
 }
 
 }  // namespace rsgpu
@@ -253,15 +361,7 @@ RSGPU_ShardComm *RSGPU_ShardComm_Init(int rank, int world, const void *id128, in
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
       throw std::runtime_error("RSGPU_ShardComm_Init: device " + std::to_string(device) + " of " + std::to_string(n_dev) + " visible");
-    HIP_CHECK(hipSetDevice(device));
-    Nccl::UniqueId id;
-    memcpy(&id, id128, sizeof id);
-    void *comm = nullptr;
-    {
-      StdoutToStderr quiet;
-      nccl_check(n.CommInitRank(&comm, world, id, rank), "ncclCommInitRank");
-    }
-    return new_comm(rank, world, device, comm);
+    return shard_comm_init_rank(rank, world, id128, device);
   } catch (const std::exception &e) {
     last_error() = e.what();
     return nullptr;

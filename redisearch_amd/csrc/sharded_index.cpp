@@ -359,48 +359,64 @@ double sharded_distance_from(RSGPU_ShardedIndex *si, size_t label, const void *n
 }
 
 // The exchange over RCCL (knob "shard_exchange" = 1; BASELINE north star: "RCCL all-gather of per-shard top-K over xGMI"):
-// every shard's worker answers its rows, then calls shard_comm_exchange on ITS communicator -- N threads, N ranks, one
-// ncclAllGather -- and the merge kernel leaves the global k best on every device; rank 0's copy is the reply.  A shard
-// that fails still takes part in the collective (with nothing to offer): the other ranks must not be left waiting.
+// the shards answer as they always do -- one top-k task per shard worker -- and the CALLER's thread then runs the exchange
+// for all ranks (the single-thread form of a NCCL program: every rank's ncclAllGather inside one group), the merge kernel
+// leaves the global k best in pinned host memory.  Communicators: one per shard device, created by the first such query.
+// Collectives are ordered, so these queries pass the exchange one at a time.
 static VecSimQueryReply *sharded_topk_rccl(RSGPU_ShardedIndex *si, const void *query, size_t k, VecSimQueryParams *qp,
                                            VecSimQueryReply_Order order) {
+  const size_t n = si->n();
+  std::vector<VecSimQueryReply *> replies(n, nullptr);
+  struct FreeReplies {
+    std::vector<VecSimQueryReply *> &r;
+    ~FreeReplies() {
+      for (VecSimQueryReply *x : r) VecSimQueryReply_Free(x);
+    }
+  } free_replies{replies};
+  if (n == 1) {
+    replies[0] = si->shards[0]->flat->topk(query, k, qp, BY_SCORE);
+  } else {
+    std::vector<TopkJob> jobs(n, TopkJob{query, k, qp ? qp->timeoutCtx : nullptr, BY_SCORE});
+    Completion c;
+    c.remaining = (int)n;
+    for (size_t i = 0; i < n; i++) {
+      si->shards[i]->flat->last_mode = STANDARD_KNN;
+      post(si->shards[i].get(), Task{nullptr, &jobs[i], &c});
+    }
+    wait_for(c);
+    std::exception_ptr err;
+    for (size_t i = 0; i < n; i++) {
+      replies[i] = jobs[i].reply;
+      if (jobs[i].err && !err) err = jobs[i].err;
+    }
+    if (err) std::rethrow_exception(err);
+  }
+  for (size_t i = 0; i < n; i++)
+    if (replies[i] && replies[i]->code == VecSim_QueryReply_TimedOut) return new_reply(0, VecSim_QueryReply_TimedOut);
   std::lock_guard<std::mutex> g(si->exchange_mu);
+  const auto t0 = std::chrono::steady_clock::now();
   if (si->comms.empty()) {
     std::vector<int> devs;
-    for (auto &s : si->shards) devs.push_back(s->device);
-    si->comms = shard_comm_init_all(devs);
+    for (size_t i = 0; i < n; i++) {
+      for (size_t j = 0; j < i; j++)
+        if (si->shards[i]->device == si->shards[j]->device)
+          throw std::runtime_error("shard_exchange = 1: a RCCL communicator needs one device per rank (shards " + std::to_string(j) + " and " +
+                                   std::to_string(i) + " share device " + std::to_string(si->shards[i]->device) + ")");
+      devs.push_back(si->shards[i]->device);
+    }
+    si->comms = shard_comm_init_group(devs);
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  const size_t n = si->n();
-  std::vector<std::vector<uint64_t>> labels(n, std::vector<uint64_t>(k));
-  std::vector<std::vector<double>> scores(n, std::vector<double>(k));
-  std::vector<size_t> got(n, 0);
-  std::vector<int> codes(n, (int)VecSim_QueryReply_OK);
-  std::vector<std::function<void()>> jobs(n);
-  for (size_t i = 0; i < n; i++)
-    jobs[i] = [&, i] {
-      VecSimQueryReply *r = nullptr;
-      std::exception_ptr err;
-      try {
-        si->shards[i]->flat->last_mode = STANDARD_KNN;
-        r = si->shards[i]->flat->topk(query, k, qp, BY_SCORE);
-        codes[i] = (int)r->code;
-      } catch (...) {
-        err = std::current_exception();
-      }
-      try {
-        got[i] = shard_comm_exchange(si->comms[i], r ? r->results : nullptr, r ? r->len : 0, k, labels[i].data(), scores[i].data());
-      } catch (...) {
-        if (!err) err = std::current_exception();
-      }
-      if (r) VecSimQueryReply_Free(r);
-      if (err) std::rethrow_exception(err);
-    };
-  run_on_shards(si, jobs);
-  for (size_t i = 0; i < n; i++)
-    if (codes[i] == (int)VecSim_QueryReply_TimedOut) return new_reply(0, VecSim_QueryReply_TimedOut);
-  VecSimQueryReply *out = new_reply(got[0], VecSim_QueryReply_OK);
-  for (size_t j = 0; j < got[0]; j++) out->results[j] = VecSimQueryResult{(size_t)labels[0][j], scores[0][j]};
+  std::vector<const VecSimQueryResult *> local(n);
+  std::vector<size_t> n_local(n);
+  for (size_t i = 0; i < n; i++) {
+    local[i] = replies[i] ? replies[i]->results : nullptr;
+    n_local[i] = replies[i] ? replies[i]->len : 0;
+  }
+  std::vector<uint64_t> labels(k);
+  std::vector<double> scores(k);
+  const size_t got = shard_comm_exchange_group(si->comms, local.data(), n_local.data(), k, labels.data(), scores.data());
+  VecSimQueryReply *out = new_reply(got, VecSim_QueryReply_OK);
+  for (size_t j = 0; j < got; j++) out->results[j] = VecSimQueryResult{(size_t)labels[j], scores[j]};
   if (order == BY_ID)
     std::sort(out->results, out->results + out->len, [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return a.id < b.id; });
   si->rccl_queries++;
@@ -715,7 +731,7 @@ void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *si, uint64_t out[2]
   if (reset) si->merges = si->merge_ns = 0;
 }
 /* the same for the queries that took the RCCL exchange (knob "shard_exchange" = 1): out[0] queries, out[1] nanoseconds of
- * the whole fan-out (shard scans + all-gather + merge kernel), out[2] ranks of the communicator (0: not created yet) */
+ * the exchange (H2D of the winners + all-gather + merge kernel + sync), out[2] ranks of the communicator (0: not created yet) */
 void RSGPU_ShardedIndex_GetRcclStats(RSGPU_ShardedIndex *si, uint64_t out[3], int reset) {
   if (!si || !out) return;
   out[0] = si->rccl_queries.load();

@@ -16,7 +16,11 @@ namespace rsgpu {
 
 // the exchange over RCCL (shard_comm.cpp): one communicator per device for ranks that live in one process, and the
 // exchange itself -- this rank's winners -> ncclAllGather -> merge kernel -> the global k best
-std::vector<RSGPU_ShardComm *> shard_comm_init_all(const std::vector<int> &devices);
+std::vector<RSGPU_ShardComm *> shard_comm_init_group(const std::vector<int> &devices);  // all ranks, from the calling thread
+size_t shard_comm_exchange_group(const std::vector<RSGPU_ShardComm *> &cs, const VecSimQueryResult *const *local, const size_t *n_local,
+                                 size_t k, uint64_t *labels_out, double *scores_out);
+void shard_comm_unique_id(void *id128);  // 128 bytes
+RSGPU_ShardComm *shard_comm_init_rank(int rank, int world, const void *id128, int device);  // on the rank's own thread
 size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, size_t n_local, size_t k, uint64_t *labels_out,
                            double *scores_out);
 

@@ -298,23 +298,29 @@ def test_writers_and_timeouts_next_to_coalesced_readers(knobs):
 
 def test_a_timeout_that_fires_while_the_call_is_queued(knobs):
     """Round 4: a call parked behind a pass it is not part of polls ITS OWN timeout callback on ITS OWN
-    thread and leaves the queue with VecSim_QueryReply_TimedOut -- it neither waits for that pass nor rides in the next one;
-    the callback is never invoked from another caller's thread; calls without a deadline get their serial answers."""
+    thread -- on arrival, then every millisecond -- and leaves the queue with VecSim_QueryReply_TimedOut instead of waiting
+    for that pass and riding in the next one; the callback is never invoked from another caller's thread; calls without a
+    deadline get their serial answers.  The deadlines here expire AFTER the arrival poll: the call is in the queue (or in
+    a pass) when it finds out."""
     knobs("coalesce_min_mib", 0)
-    n, dim = 3_000_000, 256                       # ~0.6 ms per pass: long enough for callers to queue behind it
+    n, dim = 8_000_000, 256                       # ~1.5 ms per pass: queued calls get to poll while it runs
     idx = _index(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2, n)
     try:
         qs = _queries(V.VecSimType_FLOAT32, dim, 16)
         want = [idx.topk_query(q, 10).results() for q in qs]
         calls = []                                 # (ctx, thread id) of every callback invocation
-        armed = threading.Event()
+        polls = {}                                 # ctx -> invocations since the owner's current call began
 
         def on_timeout(ctx):
-            calls.append((int(ctx or 0), threading.get_ident()))
-            return 1 if ctx and armed.is_set() else 0
+            ctx = int(ctx or 0)
+            calls.append((ctx, threading.get_ident()))
+            if not ctx:
+                return 0
+            polls[ctx] = polls.get(ctx, 0) + 1
+            return 1 if polls[ctx] > 1 else 0      # fine on arrival, expired at the next look
         cb = V.set_timeout_callback(on_timeout)
         try:
-            n_threads, reps = 12, 30
+            n_threads, reps = 12, 20
             owner = {}
             out = [[] for _ in range(n_threads)]
             bar = threading.Barrier(n_threads)
@@ -325,10 +331,10 @@ def test_a_timeout_that_fires_while_the_call_is_queued(knobs):
                 qp.timeoutCtx = t + 1 if t % 3 == 0 else None      # every third caller carries a deadline
                 bar.wait()
                 for r in range(reps):
+                    polls[t + 1] = 0
                     rep = idx.topk_query(qs[(t + r) % len(qs)], 10, params=qp)
                     out[t].append((rep.code, rep.results()[0].tolist(), (t + r) % len(qs)))
             V.coalesce_stats(reset=True)
-            armed.set()
             th = [threading.Thread(target=caller, args=(t,)) for t in range(n_threads)]
             [x.start() for x in th]
             [x.join() for x in th]
@@ -339,9 +345,10 @@ def test_a_timeout_that_fires_while_the_call_is_queued(knobs):
                         assert code == V.VecSim_QueryReply_TimedOut and ids == []
                     else:
                         assert code == V.VecSim_QueryReply_OK and ids == want[qi][0].tolist()
-            # expired calls never rode in a pass; some of them were queued behind one when they gave up
-            assert st["queries"] == (n_threads - n_threads // 3) * reps, st
+            # some of the expired calls were queued behind a pass when they gave up (others found out as they were about to
+            # lead, or inside a pass that had already taken them: those still rode in it)
             assert st["left_queue_on_timeout"] > 0, st
+            assert st["queries"] >= (n_threads - n_threads // 3) * reps, st
             # the callback ran on the thread that owns the context, never on a leader's or a worker's
             assert calls and all(tid == owner[ctx] for ctx, tid in calls if ctx), [c for c in calls if c[0] and c[1] != owner[c[0]]][:3]
         finally:

@@ -2,8 +2,8 @@
 FAIL LOUDLY at the ABI -- NULL + RSGPU_LastError, never a truncated answer -- and are then the host's: the reference's own
 iterators (restated by the oracle) walk the postings and the scorer PLUGIN (librsgpu_scorers.so, any number of children:
 it IS the reference's per-result interface, reference src/ext/default.c:253-302) scores every result.  Here: a 33-term
-intersection and a 33-term union refused by RSGPU_Intersect / RSGPU_Union / RSGPU_EvalTreeNodes, a 65-node and a 17-level
-tree refused; the 33-term intersection answered on the host path and, with one term fewer, identically by the device."""
+intersection and a 33-term union refused by RSGPU_Intersect / RSGPU_Union / RSGPU_EvalTreeNodes, a 65-node tree refused,
+a 20-level tree evaluated but refused by the device scorer; the 33-term intersection answered on the host path and, with one term fewer, identically by the device."""
 import numpy as np
 import pytest
 
@@ -41,12 +41,16 @@ def test_over_limit_trees_are_refused_with_a_reason():
             tree = ("or", 1.0, [tree])
         with pytest.raises(RuntimeError, match="64 nodes"):
             S.NodeHits(tree, g[:32])
-        # 17 levels
+        # 20 nested aggregates (the limit: 16 levels below the root)
         tree = ("t", 0)
-        for lvl in range(17):
+        for lvl in range(20):
             tree = ("and" if lvl % 2 else "or", 1.0, [tree, ("t", lvl + 1)])
-        with pytest.raises(RuntimeError):
-            S.NodeHits(tree, g[:18])
+        deep = S.NodeHits(tree, g[:21])            # the boolean evaluation has no depth limit; the device SCORER has
+        assert len(deep.read()[0]) > 0
+        doc_len = np.full(3001, 100, np.uint32)
+        with pytest.raises(RuntimeError, match="16 levels"):
+            deep.score(S.DocTable(doc_len, np.ones(3001, np.float32)), "BM25STD", [1.0] * 21, [1.0] * 21, [1.0] * 21, 3000, 100.0)
+        deep.free()
     finally:
         for x in g:
             x.free()
@@ -66,14 +70,13 @@ def test_a_33_term_intersection_is_answered_by_the_host_plugin_path():
     assert len(oi) > 5
     host = X.Host()
     assert host.load_plugin() == X.OK
-    order = np.argsort([l.unique_docs for l in o], kind="stable")     # an intersection iterates its children by estimate
     host_scores = []
-    for h in range(len(oi)):
-        kids = [("term", 1.0, int(of[h][s]), idf[order[s]], bidf[order[s]], "t%d" % order[s], None) for s in range(33)]
+    for h in range(len(oi)):   # (of: [list][hit], the caller's list order)
+        kids = [("term", 1.0, int(of[s][h]), idf[s], bidf[s], "t%d" % s, None) for s in range(33)]
         tree = X.Tree(("intersection", 1.0, kids))
-        host_scores.append(host.score("BM25STD", tree, doc_score=1.0, doc_len=int(doc_len[int(oi[h])]), num_docs=n_docs, avg_doc_len=avg))
+        host_scores.append(host.score("BM25STD", tree, doc_score=1.0, doc_len=int(doc_len[int(oi[h])]), num_docs=n_docs, avg_doc_len=avg, slop=1))
     want = O.score_flat("BM25STD", of, doc_len[oi.astype(np.int64)], np.ones(len(oi)), np.ones(len(oi), np.float32),
-                        [idf[i] for i in order], [bidf[i] for i in order], [1.0] * 33, 1.0, n_docs, avg)
+                        idf, bidf, [1.0] * 33, 1.0, n_docs, avg)
     assert np.allclose(host_scores, want, rtol=1e-12, atol=0)
     # ... and the same query with one term fewer runs on the device and agrees with the same host composition
     g = [S.Postings.from_flat(l.flatten()) for l in o[:32]]
@@ -83,12 +86,11 @@ def test_a_33_term_intersection_is_answered_by_the_host_plugin_path():
         oi32, of32, _ = O.intersect(o[:32])
         assert gi.tolist() == oi32.tolist() and gf.tolist() == of32.tolist()
         gs = hits.score(S.DocTable(doc_len, np.ones(n_docs + 1, np.float32)), "BM25STD", idf[:32], bidf[:32], [1.0] * 32, n_docs, avg)
-        order32 = np.argsort([l.unique_docs for l in o[:32]], kind="stable")
         host32 = []
         for h in range(len(oi32)):
-            kids = [("term", 1.0, int(of32[h][s]), idf[order32[s]], bidf[order32[s]], "t", None) for s in range(32)]
+            kids = [("term", 1.0, int(of32[s][h]), idf[s], bidf[s], "t", None) for s in range(32)]
             host32.append(host.score("BM25STD", X.Tree(("intersection", 1.0, kids)), doc_score=1.0, doc_len=int(doc_len[int(oi32[h])]),
-                                     num_docs=n_docs, avg_doc_len=avg))
+                                     num_docs=n_docs, avg_doc_len=avg, slop=1))
         assert np.allclose(gs, host32, rtol=1e-12, atol=0)
     finally:
         for x in g:

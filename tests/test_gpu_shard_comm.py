@@ -66,30 +66,44 @@ def test_one_rank_communicator_returns_the_index_answers(metric):
         idx.free()
 
 
+_SHARDED_RCCL = r"""
+import ctypes as C, numpy as np
+from redisearch_amd import vecsim as V
+lib = V.load()
+F32 = V.VecSimType_FLOAT32
+sh = V.ShardedIndex(F32, 48, V.VecSimMetric_L2, 1)
+plain = V.VecSimIndex(F32, 48, V.VecSimMetric_L2)
+rows = np.random.default_rng(2).uniform(-1, 1, (3000, 48)).astype(np.float32)
+for i, r in enumerate(rows):
+    sh.add_vector(r, i + 1)
+plain.add_bulk(rows)
+qs = np.random.default_rng(6).uniform(-1, 1, (9, 48)).astype(np.float32)
+lib.RSGPU_SetTuning(b"shard_exchange", 1)
+for q in qs:
+    for order in (V.BY_SCORE, V.BY_ID):
+        gi, gs = sh.topk_query(q, 10, order=order).results()
+        wi, ws = plain.topk_query(q, 10, order=order).results()
+        assert gi.tolist() == wi.tolist() and gs.tolist() == ws.tolist()
+st = (C.c_uint64 * 3)()
+lib.RSGPU_ShardedIndex_GetRcclStats(sh.ptr, st, 0)
+assert st[0] == 18 and st[2] == 1, list(st)
+print("SHARDED_RCCL_OK")
+"""
+
+
 def test_sharded_index_with_the_rccl_exchange():
-    """a one-shard RSGPU_ShardedIndex with shard_exchange = 1: every top-k goes through the (one-rank) communicator"""
-    lib = V.load()
-    sh = V.ShardedIndex(F32, 48, V.VecSimMetric_L2, 1)
-    plain = V.VecSimIndex(F32, 48, V.VecSimMetric_L2)
+    """a one-shard RSGPU_ShardedIndex with shard_exchange = 1: every top-k goes through the (one-rank) communicator its
+    worker created.  In a child process with a deadline: a collective that never completes must fail this test, not hang
+    the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
-        rows = np.random.default_rng(2).uniform(-1, 1, (3000, 48)).astype(np.float32)
-        for i, r in enumerate(rows):
-            sh.add_vector(r, i + 1)
-        plain.add_bulk(rows)
-        qs = np.random.default_rng(6).uniform(-1, 1, (9, 48)).astype(np.float32)
-        lib.RSGPU_SetTuning(b"shard_exchange", 1)
-        for q in qs:
-            for order in (V.BY_SCORE, V.BY_ID):
-                gi, gs = sh.topk_query(q, 10, order=order).results()
-                wi, ws = plain.topk_query(q, 10, order=order).results()
-                assert gi.tolist() == wi.tolist() and gs.tolist() == ws.tolist()
-        st = (C.c_uint64 * 3)()
-        lib.RSGPU_ShardedIndex_GetRcclStats(sh.ptr, st, 0)
-        assert st[0] == 18 and st[2] == 1            # every query went through the (one-rank) communicator
-    finally:
-        lib.RSGPU_SetTuning(b"shard_exchange", 0)
-        sh.free()
-        plain.free()
+        p = subprocess.run([sys.executable, "-c", _SHARDED_RCCL], cwd=root, capture_output=True, text=True, timeout=75)
+    except subprocess.TimeoutExpired:
+        pytest.fail("the in-process RCCL exchange did not finish within 75 s")
+    assert p.returncode == 0 and "SHARDED_RCCL_OK" in p.stdout, (p.stdout[-400:], p.stderr[-1200:])
 
 
 def test_two_shards_on_one_device_cannot_form_a_communicator():

@@ -162,6 +162,7 @@ def test_eight_shards_eight_callers_share_shard_passes():
     exp = [one.topk_query(q, 10).results() for q in qs]
     exp_r = [one.range_query(q, float(exp[i][1][3]), order=V.BY_ID).results() for i, q in enumerate(qs)]
     bad, bar = [], threading.Barrier(8)
+    V.load().RSGPU_SetTuning(b"coalesce_min_mib", 0)   # (the shards are small: by default their workers would not coalesce)
     V.coalesce_stats(reset=True)
 
     def run(t):
@@ -182,6 +183,7 @@ def test_eight_shards_eight_callers_share_shard_passes():
     [t.start() for t in th]
     [t.join() for t in th]
     assert not bad, bad[:3]
+    V.load().RSGPU_SetTuning(b"coalesce_min_mib", 64)
     st = V.coalesce_stats()
     assert st["mq_passes"] > 0 and st["mq_queries"] > st["mq_passes"], st
     ex = (C.c_uint64 * 2)()
