@@ -127,8 +127,7 @@ bool FlatIndex::wide_pass_capable(size_t k) const {
       return true;  // fp16 shadow
     if (s8g_enabled() && metric != VecSimMetric_L2 && t.two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) && s8g_stride() / 16 <= 64 && !s_bad_)
       return true;  // int8 rows with one scale
-    return t.gemm_qs_f32 && (metric == VecSimMetric_Cosine || metric == VecSimMetric_L2) && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) &&
-           !(metric == VecSimMetric_L2 && hn_bad_);
+    return t.gemm_qs_f32 && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) && !(metric != VecSimMetric_Cosine && hn_bad_);
   }
   return (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric == VecSimMetric_L2 && !hn_bad_ &&
          gemm_qs_supported((uint32_t)(stride_ / 16));
@@ -163,7 +162,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // summation orders; cosine: |x| = |q| = 1; L2: per row through the half norms, as the 16-bit L2 passes), the survivors are
   // re-scored from the same fp32 rows with the single-query scan's arithmetic -> bit-identical to single queries
   const bool f32_shape = type == VecSimType_FLOAT32 && !via_shadow && !(s8g_shape && scan_tuning().two_stage) && !multi && k > 0 &&
-                         k <= 1024 && (metric == VecSimMetric_Cosine || metric == VecSimMetric_L2) && scan_tuning().gemm_qs &&
+                         k <= 1024 && scan_tuning().gemm_qs &&
                          scan_tuning().gemm_qs_f32 && scan_tuning().batch_mfma && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) &&
                          batch_rescore_supported((uint32_t)(stride_ / 16));
   bool via_f32 = f32_shape && (size_t)n_rows_ + stage_n_ > (1u << 19);
@@ -172,6 +171,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // eight queries per pass -- the decision proper is taken under the lock below)
   bool via_l2 = l2_any && (size_t)n_rows_ + stage_n_ > (1u << 19) && ensure_half_norms();
   if (f32_shape && metric == VecSimMetric_L2) via_f32 = via_f32 && via_l2;
+  // IP over rows that are not normalised: the band is rel |x||q| with |x| bounded by the largest row norm of the index (the
+  // half norms are computed for that bound; a per-query band 2 rel |x|max |q| widens every threshold of query q)
+  const bool f32_ip = f32_shape && metric == VecSimMetric_IP;
+  if (f32_ip) via_f32 = via_f32 && ensure_half_norms();
   const bool gemm_ok = via_shadow || via_l2 || via_f32 || (s8g_shape && type == VecSimType_FLOAT32) ||
                        ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi &&
                         k > 0 && k <= 4096);
@@ -247,7 +250,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // (rows added since ensure_shadow8g, or a corpus the single-query path serves anyway: the plain fp16 passes)
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
     if (via_l2 && (hn_built_ < n || hn_bad_ || n <= (1u << 19))) via_l2 = false;
-    if (via_f32 && (n <= (1u << 19) || (metric == VecSimMetric_L2 && !via_l2))) via_f32 = false;
+    if (via_f32 && (n <= (1u << 19) || (metric == VecSimMetric_L2 && !via_l2) || (f32_ip && (hn_built_ < n || hn_bad_)))) via_f32 = false;
     if ((f32_needs_s8g && !via_shadow8) || (l2_any && !via_l2) || (f32_shape && !via_f32)) {
       g.unlock();
       all_single();
@@ -322,6 +325,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         sc.qscale.ensure(kBatch);
         sc.slack_q.ensure(kBatch);
       }
+      if (via_f32 && f32_ip) {
+        sc.slack_q.ensure(kBatch);
+        sc.h_l2.ensure<float>(2 * kBatch);
+      }
       if (via_l2) {
         sc.hqn.ensure(2 * kBatch);  // (|q|^2 / 2 shrunk, then the queries' share of the band)
         sc.h_l2.ensure<float>(2 * kBatch);
@@ -391,6 +398,18 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         slack_q = sc.slack_q.p;
         qscale = sc.qscale.p;
       }
+      if (via_f32 && f32_ip) {  // per-query band: 2 rel |x|max |q|; a query whose norm is not finite goes to the exact scan
+        float *hl = static_cast<float *>(sc.h_l2.p);
+        const float rel = gemm_qs_f32_rel(dim) * 1.002f, xmax = sqrtf(2.0f * hn_max_) * 1.000001f;
+        l2_redo[sl].assign(kBatch, 0);
+        for (uint32_t i = 0; i < kBatch; i++) {
+          const float h = i < nb ? half_sq_norm_host((const uint8_t *)queries + (q0 + i) * elem_bytes_) : 0.0f;
+          if (!(h <= 3.0e38f)) l2_redo[sl][i] = 1;
+          hl[i] = h <= 3.0e38f ? 2.0f * rel * xmax * sqrtf(2.0f * h) * 1.000001f : 0.0f;
+        }
+        HIP_CHECK(hipMemcpyAsync(sc.slack_q.p, hl, kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        slack_q = sc.slack_q.p;
+      }
       const float *l2_hn = nullptr, *l2_hq = nullptr;
       RowBand rb;
       if (via_l2) {
@@ -430,7 +449,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         if (phase0) {  // tau = +inf for the queries of the batch, -inf for the padding
           float *ht = sc.h_tau.ensure<float>(kBatch);  // (pinned, one per slot: free again once the slot's batch is finalized)
           for (uint32_t i = 0; i < kBatch; i++)
-            ht[i] = i < nb && !(via_l2 && l2_redo[sl][i]) ? __builtin_inff() : -__builtin_inff();
+            ht[i] = i < nb && !((via_l2 || f32_ip) && l2_redo[sl][i]) ? __builtin_inff() : -__builtin_inff();
           HIP_CHECK(hipMemcpyAsync(sc.tau.p, ht, kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
         } else {
           if (via_shadow8)
@@ -503,7 +522,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       std::vector<VecSimQueryResult> res;
       for (uint32_t i = 0; i < nb; i++) {
         const size_t qi = q0 + i;
-        if (h_over[i] || (via_l2 && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
+        if (h_over[i] || ((via_l2 || (via_f32 && f32_ip)) && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
           redo.push_back(qi);
           continue;
         }

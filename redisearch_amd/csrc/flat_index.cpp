@@ -543,8 +543,8 @@ bool FlatIndex::ensure_half_norms() {
   if (!n || hn_bad_) return false;
   hn_built_ = std::min(hn_built_, n);
   if (!d_hn_bad_) {
-    HIP_CHECK(hipMalloc((void **)&d_hn_bad_, sizeof(uint32_t)));
-    HIP_CHECK(hipMemset(d_hn_bad_, 0, sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc((void **)&d_hn_bad_, 2 * sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(d_hn_bad_, 0, 2 * sizeof(uint32_t)));
   }
   if ((size_t)n + 96 > hnorm_cap_rows_) {  // (the pass reads 64 norms from the first row of its last tile on)
     if (d_hnorm_) HIP_IGNORE(hipFree(d_hnorm_));
@@ -558,14 +558,18 @@ bool FlatIndex::ensure_half_norms() {
   }
   if (hn_built_ < n) {
     launch_half_norm_rows(ktype, d_rows_, stride_, hn_built_, n, 1.0f - 0.5f * hn_rel(), d_hnorm_, d_hn_bad_, wstream_);
+    launch_max_f32_bits(d_hnorm_, hn_built_, n, d_hn_bad_ + 1, wstream_);
     HIP_CHECK(hipGetLastError());
-    uint32_t bad = 0;
-    HIP_CHECK(hipMemcpyAsync(&bad, d_hn_bad_, sizeof bad, hipMemcpyDeviceToHost, wstream_));
+    uint32_t bad[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(bad, d_hn_bad_, sizeof bad, hipMemcpyDeviceToHost, wstream_));
     HIP_CHECK(hipStreamSynchronize(wstream_));
-    if (bad) {  // a row with an inf / NaN norm: no band bounds such an index
+    if (bad[0]) {  // a row with an inf / NaN norm: no band bounds such an index
       hn_bad_ = true;
       return false;
     }
+    float stored_max;
+    memcpy(&stored_max, &bad[1], 4);
+    hn_max_ = stored_max / (1.0f - 0.5f * hn_rel()) * 1.000001f;  // (the stored norms are shrunk)
     hn_built_ = n;
   }
   return true;

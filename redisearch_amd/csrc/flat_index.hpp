@@ -300,8 +300,9 @@ class FlatIndex {
   float *d_hnorm_ = nullptr;
   size_t hnorm_cap_rows_ = 0;
   uint32_t hn_built_ = 0;
-  uint32_t *d_hn_bad_ = nullptr;  // set by the kernel if a row's norm is not finite
+  uint32_t *d_hn_bad_ = nullptr;  // [0] set by the kernel if a row's norm is not finite; [1] bits of the largest stored half norm
   bool hn_bad_ = false;
+  float hn_max_ = 0.0f;           // upper bound of |x|^2 / 2 over the rows covered (deletes do not lower it: a bound may be loose)
   // relative error band of the pass against the exact scan, per unit of |x|^2/2 + |q|^2/2 (DESIGN.md section 3 "L2 on the
   // matrix cores"): the stored norms are shrunk by (1 - rel/2)
   // (FLOAT32 rows go through the matrix cores as bf16: twice gemm_qs_f32_rel of |x||q| <= hn + hq on top, kernels.hpp)

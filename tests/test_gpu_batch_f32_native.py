@@ -2,7 +2,7 @@
 `gemm_qs_f32_kernel`, batch_query.cpp `via_f32`): the fp32 tiles go global -> LDS by DMA as they are and are rounded to bf16
 on their way to the MFMA; every bound is widened by the rounding band and the survivors are re-scored from the same fp32
 rows with the single-query scan's arithmetic.  The replies must be BIT-IDENTICAL to one VecSimIndex_TopKQuery per query
-(ids and distances) -- cosine and L2, every row width the kernel has, ragged tail tiles, rows whose norms differ by a factor
+(ids and distances) -- cosine, L2 and IP, every row width the kernel has, ragged tail tiles, rows whose norms differ by a factor
 of 16, a row with a huge norm, clustered rows that overflow the band (fallback), deletes and appends, a non-finite query and
 a non-finite row -- and wherever the route applies the passes must really have been taken (profiled batch launches, no
 multi-query scan passes).  One case is held to the CPU oracle directly, one to a torch fp32 reference of the same op."""
@@ -88,6 +88,30 @@ def test_l2_pass_is_bit_identical_to_single_queries(dim, n):
             rs, ri = torch.topk(ref, k, largest=False)
             assert np.allclose(got[1][i], rs.cpu().numpy().astype(np.float64), rtol=2e-4, atol=1e-3)   # (fp32 summation orders)
             assert len(set(got[0][i].tolist()) ^ set((ri.cpu().numpy() + 1).tolist())) <= 4
+    finally:
+        g.free()
+
+
+@pytest.mark.parametrize("dim,n", [(768, 525_001), (256, 600_000), (128, 700_003)])
+def test_ip_pass_is_bit_identical_to_single_queries(dim, n):
+    """IP over rows that are not normalised: the band comes from the largest row norm of the index (a per-query widening)"""
+    x = rows(n, dim, dim + n + 1, spread=True)
+    g = build(x, dim, IP)
+    try:
+        b, k = 300, 50
+        qt = rows(b, dim, dim + 2, spread=True)
+        queries = qt.cpu().numpy()
+        got = batched(g, queries, k, 2)
+        assert (got[2] == k).all()
+        same_as_singles(g, queries, k, got)
+        for i in (0, 299):
+            ref = 1.0 - (x @ qt[i])
+            rs, ri = torch.topk(ref, k, largest=False)
+            assert np.allclose(got[1][i], rs.cpu().numpy().astype(np.float64), rtol=2e-4, atol=2e-3)
+            assert len(set(got[0][i].tolist()) ^ set((ri.cpu().numpy() + 1).tolist())) <= 4
+        q2 = queries[:6].copy()
+        q2[2, 1] = np.inf                                   # a non-finite query: the exact scan's
+        same_as_singles(g, q2, k, g.topk_batch(q2, k))
     finally:
         g.free()
 
@@ -181,7 +205,7 @@ def test_knob_off_and_unsupported_shapes_take_the_exact_scans():
     finally:
         lib.RSGPU_SetTuning(b"gemm_qs_f32", 1)
         g.free()
-    for dim, n, metric in ((96, 600_000, COS), (128, 100_000, COS), (128, 530_000, IP)):   # no shape / below the cut-over / IP
+    for dim, n, metric in ((96, 600_000, COS), (128, 100_000, COS), (1024, 530_000, IP)):   # no shape / below the cut-over / 1024 wide
         x = rows(n, dim, dim + 1)
         g = build(x, dim, metric)
         try:
