@@ -182,7 +182,7 @@ const char *RSGPU_GetLastScanKernel(char *buf, size_t cap);
  *   "coalesce"       1 (default): concurrent VecSimIndex_TopKQuery calls on one index share corpus passes (see
  *                    RSGPU_GetCoalesceStats); 0: every call scans on its own stream
  *   "coalesce_wide"  1 (default): more than sixteen queued calls share one matrix-core pass (RSGPU_GetWidePassStats)
- *   "gemm_qs_f32"    1 (default): FLOAT32 indexes answer batches / wide passes on the matrix cores, rows rounded to bf16 in
+ *   "gemm_qs_f32"    2 (default; 1: the eight-wave shape): FLOAT32 indexes answer batches / wide passes on the matrix cores, rows rounded to bf16 in
  *                    flight + exact re-scoring (no stored shadow); 0: the exact multi-query scan, sixteen per pass
  *   "coalesce_linger_us"  -1 (default: 5 % of a pass, 20..300 us); "coalesce_min_mib" 64: smaller corpora never coalesce
  *   "vmm"            1 (default): row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual

@@ -109,4 +109,24 @@ void launch_philox_rows(void *rows, size_t stride, uint32_t dim, int type, uint6
   }
 }
 
+// *out_bits = max(*out_bits, bits of v[i]) over v[begin, end): non-negative floats order like their bits
+__global__ __launch_bounds__(256) void max_f32_bits_kernel(const float *__restrict__ v, uint32_t begin, uint32_t end, uint32_t *__restrict__ out_bits) {
+  uint32_t m = 0;
+  for (uint32_t i = begin + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
+    const uint32_t b = __float_as_uint(v[i]);
+    m = b > m && !(b & 0x80000000u) ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out_bits, m);
+}
+void launch_max_f32_bits(const float *v, uint32_t begin, uint32_t end, uint32_t *out_bits, hipStream_t s) {
+  if (end <= begin) return;
+  const uint32_t need = (end - begin + 255) / 256;
+  hipLaunchKernelGGL(max_f32_bits_kernel, dim3(need < 1024 ? need : 1024), dim3(256), 0, s, v, begin, end, out_bits);
+}
+
 }  // namespace rsgpu

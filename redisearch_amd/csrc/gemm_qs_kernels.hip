@@ -797,7 +797,7 @@ bool gemm_qs_f32_supported(uint32_t stride16) {
 namespace {
 template <int KS, int KH, int NS>
 void launch_qs_f32_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
-  const bool wide = scan_tuning().gemm_qs_f32 == 2;  // 2: four waves x 64 queries (one 512-register wave per SIMD; A/B knob)
+  const bool wide = scan_tuning().gemm_qs_f32 != 1;  // default: four waves x 64 queries (one 512-register wave per SIMD); 1: eight x 32
   if (g.hnorm) {
     if (wide) hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 2, true>), dim3(grid), dim3(256), 0, s, g);
     else hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KH, NS, 1, true>), dim3(grid), dim3(512), 0, s, g);

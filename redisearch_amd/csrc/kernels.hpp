@@ -74,8 +74,10 @@ struct ScanTuning {
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
-  int gemm_qs_f32 = 1;     // FLOAT32 indexes: batched / coalesced queries through the matrix cores, rows converted to bf16 in flight
-                           // (gemm_qs_f32_kernel; 0 = off: the exact multi-query scan; 2 = four waves x 64 queries, A/B knob)
+  int gemm_qs_f32 = 2;     // FLOAT32 indexes: batched / coalesced queries through the matrix cores, rows converted to bf16 in flight
+                           // (gemm_qs_f32_kernel; 0 = off: the exact multi-query scan; 2 = four waves x 64 queries -- every converted
+                           // fragment feeds two MFMAs, half the LDS reads: 6.20 vs 6.56 ms per pass, profiles/r04_batch_f32_shapes_ab.json
+                           // -- 1 = eight waves x 32 queries)
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range

@@ -53,7 +53,7 @@ for mname, metric in (("cosine", V.VecSimMetric_Cosine), ("l2", V.VecSimMetric_L
             "mq_scan_passes": mq, "hbm_gbs_of_fp32_rows": rows * dim * 4 / dev_ms / 1e6, "hbm_frac": rows * dim * 4 / dev_ms / 1e6 / 8000,
             "mfma_tflops": flops / dev_ms / 1e9, "first_call_s": first, "bit_identical_to_single_queries": bool(same)}
         print(mname, shape, json.dumps(out["%s_shape%d" % (mname, shape)]), flush=True)
-    lib.RSGPU_SetTuning(b"gemm_qs_f32", 1)
+    lib.RSGPU_SetTuning(b"gemm_qs_f32", 2)
     idx.free()
     lib.RSGPU_ReleaseWorkspaces()
 os.makedirs("gpurun_out", exist_ok=True)

@@ -200,10 +200,10 @@ def test_knob_off_and_unsupported_shapes_take_the_exact_scans():
         got = g.topk_batch(queries, 10)
         assert V.coalesce_stats()["mq_passes"] > before        # sixteen queries per exact pass
         same_as_singles(g, queries, 10, got)
-        lib.RSGPU_SetTuning(b"gemm_qs_f32", 2)                 # four waves x 64 queries: the A/B shape gives the same answers
+        lib.RSGPU_SetTuning(b"gemm_qs_f32", 1)                 # eight waves x 32 queries: the A/B shape gives the same answers
         same_as_singles(g, queries, 10, batched(g, queries, 10, 1))
     finally:
-        lib.RSGPU_SetTuning(b"gemm_qs_f32", 1)
+        lib.RSGPU_SetTuning(b"gemm_qs_f32", 2)
         g.free()
     for dim, n, metric in ((96, 600_000, COS), (128, 100_000, COS), (1024, 530_000, IP)):   # no shape / below the cut-over / 1024 wide
         x = rows(n, dim, dim + 1)

@@ -64,6 +64,19 @@ def test_query_stationary_pass_budget(kernels):
         assert k["lds"] <= 147456 + (ns * 256 if l2 else 0)   # the ring (~144 KiB) + the L2 form's 64 half norms per slot
 
 
+def test_fp32_source_query_stationary_pass_budget(kernels):
+    """gemm_qs_f32_kernel<KS, KH, NS, QB, L2> (round 4: fp32 tiles, bf16 in flight): no spills -- a spilled query fragment is
+    reloaded through the counted vmcnt queue of the LDS-DMA ring every tile -- two waves per SIMD in the eight-wave shape,
+    one 512-register wave in the four-wave shape, the K-part ring inside the CU's LDS."""
+    qs = [k for k in kernels if k["name"].startswith("gemm_qs_f32_kernel<")]
+    assert len(qs) == 20                  # five row widths x two shapes x {IP / cosine, L2}
+    for k in qs:
+        ks, kh, ns, qb = (int(x) for x in re.match(r"gemm_qs_f32_kernel<(\d+), (\d+), (\d+), (\d+)", k["name"]).groups())
+        assert not k["vgpr_spill"] and not k["scratch"], k["name"]
+        assert k["wg"] == 512 // qb and k["vgpr"] <= (256 if qb == 1 else 512), (k["name"], k["vgpr"])
+        assert k["lds"] <= ns * kh * 2048 + ns * 256 and k["lds"] <= LDS_PER_CU, (k["name"], k["lds"])
+
+
 def test_tiled_gemm_default_variant_budget(kernels):
     ring = [k for k in kernels if re.match(r"gemm_topk_ring_kernel<\d+, 8, 3, 2, \d>", k["name"])]
     assert len(ring) == 4                 # f16 / bf16 x all-keys / filter
