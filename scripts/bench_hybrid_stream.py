@@ -34,9 +34,13 @@ enc = [B.encode_freqs_only(d, f) for d, f, _, _ in raws] if codec == "freqs_only
 qvecs = B.philox_host_rows(V, B.QUERY_BASE + 100, n_a * n_b, dim)
 out = {}
 ref = None
-for name, knobs in (("all off", (0, 0, 0)), ("dir", (1, 0, 0)), ("dir+packed", (1, 1, 0)), ("dir+packed+poll", (1, 1, 1)),
-                    ("poll only", (0, 0, 1)), ("all on, again", (1, 1, 1))):
-    for key, val in zip((b"hybrid_dir", b"hybrid_packed_docs", b"hybrid_poll"), knobs):
+KEYS = (b"hybrid_dir", b"hybrid_packed_docs", b"hybrid_poll")
+CONFIGS = (("all off (round 3)", (0, 0, 0)), ("dir", (1, 0, 0)), ("dir+packed", (1, 1, 0)), ("dir+packed+poll", (1, 1, 1)),
+           ("poll only", (0, 0, 1)), ("all on, again", (1, 1, 1)))
+if os.environ.get("ONLY_DEFAULT") == "1":   # (PMC passes: the shipped configuration alone)
+    CONFIGS = (("all on", (1, 1, 1)),)
+for name, knobs in CONFIGS:
+    for key, val in zip(KEYS, knobs):
         lib.RSGPU_SetTuning(key, val)
     rec, ans, pairs = B._hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 4)))
     if ref is None:
