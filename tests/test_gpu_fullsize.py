@@ -145,6 +145,60 @@ def test_two_stage_int8_shadow_at_the_baseline_size(big, big_oracle):
     assert si[0] == 777_778 and ss[0] == 0.0
 
 
+def test_fp32_native_matrix_core_batch_at_the_baseline_size(big, big_oracle):
+    """Round 4 (K5): 256 queries per corpus pass on the PLAIN fp32 index of the headline configuration -- the matrix-core
+    filter reads the fp32 rows themselves (bf16 in flight), survivors are re-scored exactly.  Every one of 300 replies is
+    bit-identical to VecSimIndex_TopKQuery on the same index, the passes were really taken, and whole queries -- the planted
+    one among them -- are held to the CPU oracle on the full 10 M + 12 rows."""
+    idx, q, planted, _ = big
+    lib = V.load()
+    queries = np.concatenate([q[None, :], O.philox_rows(SEED, QUERY_BASE + 7000, 299, DIM)]).astype(np.float32)
+    for k in (10, 100):
+        before = V.coalesce_stats()["mq_passes"]
+        lib.RSGPU_ResetProfile()
+        lib.RSGPU_SetProfiling(1)
+        ids, sc, cnt = idx.topk_batch(queries, k)
+        lib.RSGPU_SetProfiling(0)
+        assert V.scan_profile()[0] == 2 and V.coalesce_stats()["mq_passes"] == before, "the matrix-core passes were not taken"
+        assert (cnt == k).all()
+        for i in range(0, 300, 7):
+            si, ss = idx.topk_query(queries[i], k).results()
+            assert ids[i].tolist() == si.tolist() and sc[i].tolist() == ss.tolist(), (k, i)
+        assert ids[0][:min(k, K + 2)].tolist() == planted[:min(k, K + 2)]
+        for i in (0, 1, 147, 294):          # (queries whose batched reply was just shown to BE the single-query reply)
+            gi, gs = assert_topk_parity(idx, big_oracle, queries[i], k)
+            assert ids[i].tolist() == gi.tolist() and sc[i].tolist() == gs.tolist()
+
+
+def test_fp32_native_l2_batch_at_the_baseline_size():
+    """... and on an L2 index of the same rows (per-row band through the half norms): bit-identical to single queries"""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 80 * 2 ** 30:
+        pytest.skip("needs an MI355X-class device")
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, DIM, V.VecSimMetric_L2)
+    try:
+        idx.reserve(ROWS)
+        assert idx.add_philox_rows(SEED, 0, ROWS, 1) == ROWS
+        queries = O.philox_rows(SEED, QUERY_BASE + 8000, 256, DIM).astype(np.float32)
+        lib = V.load()
+        lib.RSGPU_ResetProfile()
+        lib.RSGPU_SetProfiling(1)
+        ids, sc, cnt = idx.topk_batch(queries, 100)
+        lib.RSGPU_SetProfiling(0)
+        assert V.scan_profile()[0] == 1, "the matrix-core pass was not taken"
+        assert (cnt == 100).all()
+        for i in range(0, 256, 5):
+            si, ss = idx.topk_query(queries[i], 100).results()
+            assert ids[i].tolist() == si.tolist() and sc[i].tolist() == ss.tolist(), i
+        # size-independent: ascending scores, and row 12345 is its own nearest neighbour at distance 0
+        assert np.all(np.diff(sc, axis=1) >= 0)
+        own = O.philox_rows(SEED, 12344, 1, DIM).astype(np.float32)
+        oi, os_, _ = idx.topk_batch(np.repeat(own, 2, axis=0), 1)
+        assert oi[0][0] == 12345 and os_[0][0] == 0.0
+    finally:
+        idx.free()
+
+
 def test_planted_neighbours_found_in_order(big):
     idx, q, planted, _ = big
     ids, sc = idx.topk_query(q, K).results()
