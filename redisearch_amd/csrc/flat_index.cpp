@@ -1289,7 +1289,19 @@ VecSimQueryReply *FlatIndex::topk(const void *query, size_t k, VecSimQueryParams
   return finish(job.reply);
 }
 
-// More than sixteen calls in one pass: their queries side by side through topk_batch -- a matrix-core filter pass over the
+// set while a wide pass runs topk_batch on this thread: whatever that declines comes back through topk_pass in groups of
+// sixteen and must take the exact scans there, not another wide pass
+static thread_local bool tls_in_wide_pass = false;
+
+size_t FlatIndex::wide_min() const {
+  // (the early switch is for plain FLOAT32 indexes: next to a shadow the coalesced two-stage passes -- eight queries per 1.4 ms --
+  // stay ahead until more callers queue than two of them hold)
+  if (type != VecSimType_FLOAT32 || shadow_ != 0 || s8g_enabled()) return kMqMaxQueries + 1;
+  const int v = scan_tuning().coalesce_wide_min;
+  return v < 2 ? 2 : (size_t)v;
+}
+
+// More than sixteen calls in one pass (or nine and more, knob coalesce_wide_min): their queries side by side through topk_batch -- a matrix-core filter pass over the
 // corpus for all of them, exact re-scoring, the usual exact selection; every caller takes the leading K of its winners.
 // Jobs the batch cannot hold (K beyond its limit) and whatever it declines are answered sixteen per exact pass.
 void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
@@ -1300,7 +1312,7 @@ void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
     else if (!j->k) j->reply = new_reply(0, VecSim_QueryReply_OK);
     else (wide_pass_capable(j->k) ? wide : rest).push_back(j);
   }
-  if (wide.size() <= kMqMaxQueries) {
+  if (wide.size() < wide_min()) {
     rest.insert(rest.end(), wide.begin(), wide.end());
     wide.clear();
   }
@@ -1319,7 +1331,13 @@ void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
     memcpy(qbuf.data() + i * elem_bytes_, wide[i]->query, elem_bytes_);
     k_each[i] = wide[i]->k;
   }
-  topk_batch(qbuf.data(), wide.size(), kmax, ids.data(), sc.data(), cnt.data(), k_each.data());
+  {
+    struct Flag {
+      Flag() { tls_in_wide_pass = true; }
+      ~Flag() { tls_in_wide_pass = false; }
+    } in_wide;
+    topk_batch(qbuf.data(), wide.size(), kmax, ids.data(), sc.data(), cnt.data(), k_each.data());
+  }
   for (size_t i = 0; i < wide.size(); i++) {
     TopkJob *j = wide[i];
     if (!j->owner_polls && timed_out(j->tctx)) {
@@ -1335,7 +1353,14 @@ void FlatIndex::topk_pass_wide(TopkJob *const *jobs, size_t n_jobs) {
 
 void FlatIndex::topk_pass(TopkJob *const *jobs, size_t n_jobs) {
   if (!n_jobs) return;
-  if (n_jobs > kMqMaxQueries) {
+  // nine and more callers: the matrix-core pass (4.9 ms per 10 M x 768 corpus whatever the number of queries) beats the exact
+  // multi-query scan's sixteen-query form (5.8 ms, VALU-bound) -- where the index's batches are exact; see wide_min()
+  bool wide = n_jobs > kMqMaxQueries;
+  if (!wide && n_jobs >= wide_min() && !tls_in_wide_pass) {
+    wide = true;
+    for (size_t i = 0; i < n_jobs && wide; i++) wide = wide_pass_capable(jobs[i]->k);
+  }
+  if (wide) {
     topk_pass_wide(jobs, n_jobs);
     return;
   }

@@ -198,6 +198,7 @@ class FlatIndex {
   // bit-identical to single queries): the coalescer may then put up to kWidePass concurrent calls into one pass
   bool wide_pass_capable(size_t k) const;
   static constexpr uint32_t kWidePass = 256;
+  size_t wide_min() const;  // passes of at least this many capable calls take the matrix-core form (knob coalesce_wide_min)
   // up to kMqMaxQueries queries in ONE pass over the corpus (the coalescer's pass; also what topk_batch uses for indexes
   // without an MFMA form): fills job->reply (or job->err) of every job.  Replies are bit-identical to topk()'s.
   void topk_pass(TopkJob *const *jobs, size_t n_jobs);

@@ -724,6 +724,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "coalesce")) scan_tuning().coalesce = value;
   else if (!strcmp(key, "coalesce_linger_us")) scan_tuning().coalesce_linger_us = value;
   else if (!strcmp(key, "coalesce_wide")) scan_tuning().coalesce_wide = value;
+  else if (!strcmp(key, "coalesce_wide_min")) scan_tuning().coalesce_wide_min = value;
   else if (!strcmp(key, "coalesce_min_mib")) scan_tuning().coalesce_min_mib = value;
   else if (!strcmp(key, "mq_blocks_per_cu")) scan_tuning().mq_blocks_per_cu = value;
   else if (!strcmp(key, "batch_mfma")) scan_tuning().batch_mfma = value;

@@ -274,3 +274,35 @@ def test_top_n_against_the_cpu_oracle_directly(scorer):
         assert np.allclose(r["top"][1], os_[order], rtol=1e-12, atol=0)
     else:
         assert np.array_equal(r["top"][1], os_[order])
+
+
+@pytest.mark.parametrize("vtype,otype,metric,ometric,dim", [
+    (V.VecSimType_FLOAT32, O.F32, V.VecSimMetric_L2, O.L2, 768), (V.VecSimType_FLOAT32, O.F32, V.VecSimMetric_Cosine, O.COSINE, 128),
+    (V.VecSimType_FLOAT16, O.F16, V.VecSimMetric_IP, O.IP, 256)])
+def test_knn_branch_against_the_cpu_oracle_directly(vtype, otype, metric, ometric, dim):
+    """Round 4: the KNN answer of the two-launch query against the ORACLE, not against the product's other
+    paths -- the oracle's intersection gives the candidates, the documents among them that have a vector go into an oracle FLAT
+    index of their own (labels = doc ids), its top-k is the answer: ids identical, distances inside the parity tolerance."""
+    n_docs, n_vec, k = 300_000, 120_000, 10
+    lists_o, rng = corpus(n_docs, (0.3, 0.4), 11)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    gi = V.VecSimIndex(vtype, dim, metric)
+    assert gi.add_philox_rows(5, 0, n_vec, 1) == n_vec           # documents 1 .. n_vec have a vector
+    rows = O.philox_rows(5, 0, n_vec, dim, otype)                # (the generator's own rows of that type: what the device made)
+    q = O.philox_rows(5, 1 << 40, 1, dim, O.F32)[0]
+    try:
+        r = S.hybrid_query(g, index=gi, q=q, k=k)
+        assert S.hybrid_path() == 1
+        oi, _, _ = O.intersect(lists_o)
+        cand = oi[oi <= n_vec].astype(np.int64)
+        assert r["n_hits"] == len(oi) and len(cand) > 100
+        o = O.FlatIndex(otype, dim, ometric)
+        o.add_bulk(rows[cand - 1], 1)                            # oracle labels 1 .. m  <->  cand[0 .. m)
+        li, ls = o.topk(q, k)
+        want_ids = cand[li.astype(np.int64) - 1]
+        assert r["knn"][0].tolist() == want_ids.tolist()
+        assert np.all(np.abs(r["knn"][1] - ls) <= 1e-4 + 1e-5 * np.abs(ls))
+    finally:
+        gi.free()
+        for x in g:
+            x.free()
