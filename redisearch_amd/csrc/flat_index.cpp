@@ -1296,7 +1296,7 @@ static thread_local bool tls_in_wide_pass = false;
 size_t FlatIndex::wide_min() const {
   // (the early switch is for plain FLOAT32 indexes: next to a shadow the coalesced two-stage passes -- eight queries per 1.4 ms --
   // stay ahead until more callers queue than two of them hold)
-  if (type != VecSimType_FLOAT32 || shadow_ != 0 || s8g_enabled()) return kMqMaxQueries + 1;
+  if (type != VecSimType_FLOAT32 || ((shadow_ != 0 || s8g_enabled()) && scan_tuning().two_stage)) return kMqMaxQueries + 1;
   const int v = scan_tuning().coalesce_wide_min;
   return v < 2 ? 2 : (size_t)v;
 }
