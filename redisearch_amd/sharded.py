@@ -42,6 +42,22 @@ def merge_topk_numpy(scores, labels, k):
     return labels[order], scores[order]
 
 
+def broadcast_unique_id(uid, device, group=None):
+    """rank 0's 128-byte RCCL unique id to every rank of the process group (the one launcher-side step of the bootstrap;
+    an MPI program would MPI_Bcast it).  uid: bytes on rank 0, anything elsewhere.  Returns the 128 bytes on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bytes(uid)
+    if dist.get_rank(group) == 0:
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
+    else:
+        t = torch.zeros(128, dtype=torch.uint8, device=device)
+    assert t.numel() == 128
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return bytes(t.cpu().numpy().tobytes())
+
+
 class ShardComm:
     """The exchange in C (redisearch_amd/csrc/shard_comm.cpp, include/rsgpu_ext.h RSGPU_ShardComm_*): ncclAllGather of the
     per-shard top-k + a merge kernel, one communicator per rank.  This wrapper only bootstraps it -- rank 0's unique id
@@ -58,10 +74,7 @@ class ShardComm:
         uid = (C.c_char * 128)()
         if rank == 0 and self.lib.RSGPU_ShardComm_GetUniqueId(uid) != 0:
             raise RuntimeError(V.last_error())
-        if self.world > 1:
-            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
-            dist.broadcast(t, src=0, group=group)
-            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        uid = (C.c_char * 128).from_buffer_copy(broadcast_unique_id(bytes(uid), device, group))
         self.ptr = self.lib.RSGPU_ShardComm_Init(rank, self.world, uid, device.index if device.index is not None else 0)
         if not self.ptr:
             raise RuntimeError(V.last_error())

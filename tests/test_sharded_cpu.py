@@ -68,6 +68,28 @@ def test_sharded_topk_matches_single_index(tmp_path, world, rows, k):
         assert np.allclose(sc[i], s.astype(np.float32), atol=1e-6)
 
 
+def _uid_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from redisearch_amd.sharded import broadcast_unique_id
+    mine = bytes((7 * i + 3) % 256 for i in range(128)) if rank == 0 else b""
+    got = broadcast_unique_id(mine, torch.device("cpu"))
+    open(os.path.join(out_dir, "uid%d.bin" % rank), "wb").write(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_unique_id_reaches_every_rank(tmp_path, world):
+    """the one launcher-side step of the RCCL bootstrap (RSGPU_ShardComm_Init takes the id every rank must share): rank 0's
+    128 bytes arrive unchanged on every rank -- here over gloo; bench.py uses the same function over the nccl backend"""
+    mp.spawn(_uid_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = bytes((7 * i + 3) % 256 for i in range(128))
+    for r in range(world):
+        assert open(tmp_path / ("uid%d.bin" % r), "rb").read() == want
+
+
 def test_merge_topk_ties_and_padding():
     from redisearch_amd.sharded import merge_topk, merge_topk_numpy
     rng = np.random.default_rng(3)
