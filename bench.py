@@ -1027,7 +1027,7 @@ def check_hybrid_with_oracle(p):
                   "BM25STD top-10 and the KNN top-10 (ids identical, distances within 1e-4 + 1e-5 |d|) against the oracle directly"}
 
 
-def preflight(lib, V, n_devices, rows=100_000, dim=64, k=10):
+def preflight(lib, V, n_devices, rows=100_000, dim=64, k=10, n_shards=None):
     """Every visible device once, before anything long runs on them: a FLAT index on each device alone (allocation, the
     Philox kernel, a scan, the select's pinned-memory write), then ONE handle sharded over all of them answering through the
     host merge and through the RCCL exchange (ncclCommInitAll + ncclAllGather + merge kernel), all against the same
@@ -1050,22 +1050,26 @@ def preflight(lib, V, n_devices, rows=100_000, dim=64, k=10):
         except Exception as e:
             raise RuntimeError("pre-flight failed on device %d: %r" % (d, e))
     torch.cuda.set_device(0)
-    if n_devices > 1:
-        lib.RSGPU_SetTuning(b"shards", n_devices)
+    n_shards = n_devices if n_shards is None else n_shards
+    oversubscribed = n_shards > n_devices          # (RSGPU_BENCH_OVERSUBSCRIBE: several shards per device -- no communicator)
+    if n_shards > 1:
+        lib.RSGPU_SetTuning(b"shards", n_shards)
         try:
             sh = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
         finally:
             lib.RSGPU_SetTuning(b"shards", 0)
         try:
             assert sh.add_philox_rows(SEED, 0, rows, 1) == rows
-            for name, knob in (("host_merge", 0), ("rccl_exchange", 1)):
+            for name, knob in (("host_merge", 0),) + ((("rccl_exchange", 1),) if not oversubscribed else ()):
                 lib.RSGPU_SetTuning(b"shard_exchange", knob)
                 try:
                     ans = [sh.topk_query(x, k).results() for x in q]
                     assert all(a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() for a, b in zip(ans, ref)), name
                     out[name] = "ok"
                 except Exception as e:
-                    raise RuntimeError("pre-flight failed in the %d-shard %s: %r / %s" % (n_devices, name, e, V.last_error()))
+                    raise RuntimeError("pre-flight failed in the %d-shard %s: %r / %s" % (n_shards, name, e, V.last_error()))
+            if oversubscribed:
+                out["rccl_exchange"] = "skipped: %d shards on %d device(s) (RCCL wants one device per rank)" % (n_shards, n_devices)
             st = (C.c_uint64 * 3)()
             lib.RSGPU_ShardedIndex_GetRcclStats(lib.RSGPU_ShardedIndex_FromHandle(sh.ptr), st, 0)
             out["rccl_ranks"] = int(st[2])
@@ -1131,7 +1135,8 @@ def main():
     lib = V.load()   # (oracle/ is imported by the cpu_baseline leg only: verification of the answers + the CPU timing)
     pre = None
     if a.preflight or inproc:   # every visible device once, before 30 GB per device go up
-        pre = preflight(lib, V, torch.cuda.device_count() if a.preflight else a.gpus)
+        pre = preflight(lib, V, torch.cuda.device_count() if a.preflight else min(a.gpus, torch.cuda.device_count()),
+                        n_shards=None if a.preflight else a.gpus)
         if a.preflight:
             print(json.dumps({"preflight": pre}), flush=True)
             return

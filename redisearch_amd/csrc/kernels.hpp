@@ -88,8 +88,9 @@ struct ScanTuning {
                            // multi-query scan, scan_mq_kernels.hip); replies are bit-identical to uncoalesced ones
   int coalesce_wide = 1;   // more than sixteen calls queued on an index whose batches are exact (wide_pass_capable): up to 256 of
                            // them share ONE matrix-core filter pass + exact re-scoring (batch_query.cpp); 0 = sixteen per pass
-  int coalesce_wide_min = 9;  // ... and already passes of this many queued calls (the sixteen-query exact scan is VALU-bound: 5.8 ms
-                              // against 4.9 for the matrix-core pass); 17 = only what the exact scan cannot hold
+  int coalesce_wide_min = 5;  // ... and already passes of this many queued calls on plain FLOAT32 indexes (the exact multi-query scan
+                              // takes 5.1 ms with eight queries and 5.8 with sixteen -- VALU-bound -- against 4.7-4.9 ms for the
+                              // matrix-core pass whatever the number of queries); 17 = only what the exact scan cannot hold
   int coalesce_linger_us = -1;  // -1: automatic (8 % of the estimated pass, 50..400 us); how long a new leader waits for the
                                 // callers of the previous pass to come back
   int coalesce_min_mib = 64;    // corpora below this many MiB are latency-bound: concurrent single-query streams win
