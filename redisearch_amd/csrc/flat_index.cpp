@@ -1297,6 +1297,10 @@ size_t FlatIndex::wide_min() const {
   // (the early switch is for plain FLOAT32 indexes: next to a shadow the coalesced two-stage passes -- eight queries per 1.4 ms --
   // stay ahead until more callers queue than two of them hold)
   if (type != VecSimType_FLOAT32 || ((shadow_ != 0 || s8g_enabled()) && scan_tuning().two_stage)) return kMqMaxQueries + 1;
+  // (... and for LARGE ones: the matrix-core pass carries ~0.3 ms of phases, thresholds and re-scoring that a 10 M x 768 corpus
+  // amortises -- eight callers 1 655 QPS against 1 477 -- and a 2 M-row shard does not: eight such shards on one device fell
+  // from 888 to 390 QPS with the early switch, profiles/r04_bench_8shards_one_device*.json)
+  if ((uint64_t)__atomic_load_n(&n_rows_, __ATOMIC_RELAXED) * stride_ < (16ull << 30)) return kMqMaxQueries + 1;
   const int v = scan_tuning().coalesce_wide_min;
   return v < 2 ? 2 : (size_t)v;
 }
