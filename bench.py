@@ -1104,11 +1104,32 @@ def extra_collective_rccl(lib, V, index, queries, k, dev, steps=40):
         sc.free()
 
 
-# ---- main ------------------------------------------------------------------------------------------------------------------
+# stdout carries ONE JSON line and nothing else: libraries that print there (RCCL's version banner at communicator creation,
+# under torch.distributed as much as under RSGPU_ShardComm_Init) are sent to stderr for the duration of the run -- at the file
+# descriptor, where they write -- and the line itself goes out on the real stdout at the end.
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.dup2(_REAL_STDOUT, 1)
+    print(json.dumps(obj), flush=True)
+
+
 def main():
     a = parse()
+    _quiet_stdout()
     if a.cpu_config0:
-        print(json.dumps(cpu_config0()), flush=True)
+        emit(cpu_config0())
         return
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -1138,7 +1159,7 @@ def main():
         pre = preflight(lib, V, torch.cuda.device_count() if a.preflight else min(a.gpus, torch.cuda.device_count()),
                         n_shards=None if a.preflight else a.gpus)
         if a.preflight:
-            print(json.dumps({"preflight": pre}), flush=True)
+            emit({"preflight": pre})
             return
     for kv in a.tuning:
         key, val = kv.split("=")
@@ -1422,7 +1443,7 @@ def main():
             out["roofline"]["traffic_note"] = "no committed PMC pass matches this kernel's source hash: run scripts/gpu_prof_r03.sh"
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
