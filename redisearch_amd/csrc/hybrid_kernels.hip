@@ -412,6 +412,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // chunk 0 where the lane has none, from the step's first row past the end), the operations of scan_kernel in its order --
     // chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly
     constexpr int RU = 3, CU = 3;
+    if (ITERS <= CU && A.knn_pipeline) {
+      // Rows of at most CU chunks per lane (3 KiB fp32 rows at 64 lanes per row: every configs[4] row): ONE batch of loads per
+      // step, so the NEXT step's rows are requested as soon as this step's have been multiplied in -- their round trip
+      // (3.7 us under the kernel's own traffic) runs behind this step's butterfly, distance and store instead of after them.
+      // Same loads, same Op::add order, same reduction tree: the gather's bits.
+      u4 x[RU][CU];
+      uint32_t cc[CU];
+      bool ok[CU];
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        const uint32_t ch = gl + (uint32_t)c * (uint32_t)G;
+        ok[c] = c < ITERS && ch < A.chunks;
+        cc[c] = ok[c] ? ch : 0u;
+      }
+      auto request = [&](uint32_t j0) {
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+          const uint32_t ju = j0 + u * GPB;
+          const u4 *pu = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
+#pragma unroll
+          for (int c = 0; c < CU; c++) x[u][c] = load16<true>(pu + cc[c]);
+        }
+      };
+      if (grp < nv) request(grp);
+      for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
+        float acc[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) acc[u] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CU; c++)
+          if (c < ITERS) {
+            const u4 q = ok[c] ? qs[cc[c]] : zero4();
+#pragma unroll
+            for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
+          }
+        // (unconditional -- past the end the step's first row again: a branch around the loads lets the scheduler sink them
+        // to their use; the barriers pin them in front of the reduction they are meant to overlap)
+        __builtin_amdgcn_sched_barrier(0);
+        request(j0 + RU * GPB < nv ? j0 + RU * GPB : j0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+          const uint32_t ju = j0 + u * GPB;
+          const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
+          if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
     for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
       const u4 *p[RU];
 #pragma unroll

@@ -67,6 +67,7 @@ struct ScanTuning {
   int hybrid_tiles = 1;    // RSGPU_HybridQuery without hits_out: the query in two launches (hybrid_kernels.hip); 0 = the staged pipeline
   int hybrid_dir = 1;      // ... a probed list's window ends come from its bucket directory (one round trip; 0 = wave-wide searches)
   int hybrid_packed_docs = 1;  // document tables uploaded while set also keep {doc length, doc score} side by side (one gather per hit)
+  int hybrid_knn_pipeline = 1;  // ... the tile kernel requests the next step's vector rows before it reduces this step's distances
   int hybrid_poll = 1;     // ... the host polls completion flags in pinned memory instead of synchronising the stream
   int hybrid_trace = 0;    // diagnostics: the tile kernel records a phase clock per tile (RSGPU_HybridTrace)
   int hybrid_surv_cap = 2048;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)

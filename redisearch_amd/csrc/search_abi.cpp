@@ -1498,6 +1498,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
         T.dir_n[l] = pl->dir_n;
       }
     }
+  T.knn_pipeline = scan_tuning().hybrid_knn_pipeline;
   T.top_n = top_n;
   if (want_score) {
     bool max_norm = false;

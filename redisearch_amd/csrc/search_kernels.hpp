@@ -240,6 +240,7 @@ struct HybridTileArgs {
   const uint32_t *dir[kHybMaxLists];
   uint32_t dir_shift[kHybMaxLists], dir_n[kHybMaxLists];
   const uint2 *len_score;              // NULL, or {doc length, doc score bits} per document: one 8-byte gather per hit for two
+  int knn_pipeline;                    // the next step's rows are requested before this step's distances are reduced
 };
 // dir[b] = lower_bound(ids, b << shift), b < dir_n (ids ascending, n > 0; dir_n >= (ids[n - 1] >> shift) + 2)
 void launch_build_bucket_dir(const uint32_t *ids, uint32_t n, uint32_t shift, uint32_t *dir, uint32_t dir_n, hipStream_t s);

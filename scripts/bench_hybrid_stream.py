@@ -34,11 +34,11 @@ enc = [B.encode_freqs_only(d, f) for d, f, _, _ in raws] if codec == "freqs_only
 qvecs = B.philox_host_rows(V, B.QUERY_BASE + 100, n_a * n_b, dim)
 out = {}
 ref = None
-KEYS = (b"hybrid_dir", b"hybrid_packed_docs", b"hybrid_poll")
-CONFIGS = (("all off (round 3)", (0, 0, 0)), ("dir", (1, 0, 0)), ("dir+packed", (1, 1, 0)), ("dir+packed+poll", (1, 1, 1)),
-           ("poll only", (0, 0, 1)), ("all on, again", (1, 1, 1)))
+KEYS = (b"hybrid_dir", b"hybrid_packed_docs", b"hybrid_poll", b"hybrid_knn_pipeline")
+CONFIGS = (("all off (round 3)", (0, 0, 0, 0)), ("dir+packed+poll", (1, 1, 1, 0)), ("+ knn pipeline", (1, 1, 1, 1)),
+           ("dir+packed+poll, again", (1, 1, 1, 0)), ("+ knn pipeline, again", (1, 1, 1, 1)))
 if os.environ.get("ONLY_DEFAULT") == "1":   # (PMC passes: the shipped configuration alone)
-    CONFIGS = (("all on", (1, 1, 1)),)
+    CONFIGS = (("all on", (1, 1, 1, 1)),)
 for name, knobs in CONFIGS:
     for key, val in zip(KEYS, knobs):
         lib.RSGPU_SetTuning(key, val)
