@@ -755,6 +755,80 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
     return out, answers, pairs
 
 
+def _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_docs, avg, n_a, cycles=3):
+    """The query shapes round 3's two-launch form handed back to the staged pipeline, through the general tile kernel (round 4:
+    hybrid_tree_tile_kernel, RSGPU_HybridQueryPath == 2) and -- knob hybrid_tree_tiles = 0 -- staged, same process, same
+    queries: the hit list wanted (a third launch packs it), a slop-dependent scorer over Full-codec lists (per-hit
+    IndexResult_MinOffsetDelta from the term offsets), a (b|c) (a union child), a phrase window (max_slop over the offsets).
+    Eight queries per shape, round-robin over distinct lists, decode-cache warm."""
+    n_b = len(enc_fo) - n_a
+    fo = [S.Postings.from_flat(e) for e in enc_fo]
+    fu = [S.Postings.from_flat(e) for e in enc_full]
+    out = {}
+    try:
+        def sc(ix):
+            dfs = [raws[t][0].size for t in ix]
+            return dict(table=table, scorer=None, idf=[S.calculate_idf(n_docs, d) for d in dfs],
+                        bm25_idf=[S.calculate_idf_bm25(n_docs, d) for d in dfs], weight=[1.0] * len(ix), num_docs=n_docs, avg_doc_len=avg,
+                        top_n=10)
+        shapes = {}
+        pairs = [(i % n_a, n_a + (i + i // n_a) % n_b) for i in range(8)]
+        mk = []
+        for qi, (i, j) in enumerate(pairs):
+            a = sc([i, j]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridQuery([fo[i], fo[j]], index=idx, q=qvecs[qi], k=10, want_hits=True, **a))
+        shapes["hit_list_wanted_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):
+            a = sc([i, j]); a["scorer"] = "TFIDF.DOCNORM"   # (the bench table has no max-frequency column: TFIDF proper would score 0)
+            mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridQuery([fu[i], fu[j]], index=idx, q=qvecs[qi], k=10, **a))
+        shapes["tfidf_docnorm_over_full_codec_slop_from_offsets_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):
+            j2 = n_a + (j - n_a + 1) % n_b
+            a = sc([i, j, j2]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, j=j, j2=j2, qi=qi: S.HybridTreeQuery(S.OP_INTERSECT, [(S.OP_TERM, 1.0, [fo[i]]), (S.OP_UNION, 1.0, [fo[j], fo[j2]])],
+                                                                           index=idx, q=qvecs[qi], k=10, **a))
+        shapes["term_and_union_of_two_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):
+            a = sc([i, j]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridTreeQuery(S.OP_INTERSECT, [(S.OP_TERM, 1.0, [fu[i]]), (S.OP_TERM, 1.0, [fu[j]])], max_slop=30,
+                                                                     index=idx, q=qvecs[qi], k=10, **a))
+        shapes["two_terms_max_slop_30_full_codec_bm25std_knn"] = mk
+        for name, makers in shapes.items():
+            rec = {}
+            answers = {}
+            for mode, knob in (("general_kernel", 1), ("staged", 0)):
+                lib.RSGPU_SetTuning(b"hybrid_tree_tiles", knob)
+                try:
+                    hqs = [m() for m in makers]
+                    for hq in hqs:
+                        hq.run()
+                    path = S.hybrid_path()
+                    answers[mode] = [hq.results() for hq in hqs]
+                    walls = []
+                    with no_gc():
+                        for _ in range(cycles):
+                            for hq in hqs:
+                                t0 = time.perf_counter()
+                                hq.run()
+                                walls.append((time.perf_counter() - t0) * 1e3)
+                    rec[mode] = {"wall_ms_p50": float(np.percentile(walls, 50)), "wall_ms_p95": float(np.percentile(walls, 95)), "path": path,
+                                 "hits_mean": float(np.mean([r["n_hits"] for r in answers[mode]]))}
+                    del hqs
+                finally:
+                    lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
+            rec["same_answers"] = all(x["n_hits"] == y["n_hits"] and x["top"][0].tolist() == y["top"][0].tolist() and
+                                      x["top"][1].tolist() == y["top"][1].tolist() and x["knn"][0].tolist() == y["knn"][0].tolist()
+                                      for x, y in zip(answers["general_kernel"], answers["staged"]))
+            out[name] = rec
+    finally:
+        for x in fo + fu:
+            x.free()
+    return out
+
+
 def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b=4):
     """BASELINE configs[4]: 2-term intersection over Zipf postings (50M docs) -> FLAT 5M x 768 ad-hoc KNN top-10 + BM25STD.
     The headline figure is a STREAM of distinct queries (16 term pairs over 4 + 4 independent lists, a query vector each) --
@@ -783,6 +857,10 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
         codec_same = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["top"][1].tolist() == b_["top"][1].tolist()
                          and a["knn"][0].tolist() == b_["knn"][0].tolist() and a["n_hits"] == b_["n_hits"] for a, b_ in zip(ans_fo, ans_full))
         rep, payload = _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_docs, n_vec, dim)
+        try:
+            general = _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_docs, avg, n_a)
+        except Exception as e:                      # (an extra: the stream record above stands on its own)
+            general = {"error": repr(e)}
         w = fo["warm"]
         rec = {"workload": "2-term intersect (Zipf ranks 2 and 4: df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD "
                            "top-10; a round-robin STREAM over %d distinct term pairs (%d + %d independent lists), a query vector per query"
@@ -793,6 +871,7 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
                          "several times the Infinity Cache" % w["queries_timed"],
                "path": w["path"],
                "stream_freqs_only": fo, "stream_full_codec": full,
+               "general_tile_kernel_shapes": general,
                "full_codec_answers_equal_freqs_only": bool(codec_same),
                "input_generation_s": gen_s,
                "repeat_same_query": rep,

@@ -193,9 +193,13 @@ typedef struct {
   RSGPU_Hits **hits_out;        /* optional out: the hit list itself (caller frees); NULL = dropped */
 } RSGPU_HybridQueryArgs;
 int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
-/* how the calling thread's last RSGPU_HybridQuery ran: 0 = the staged pipeline (intersection written out, score / top-N and
- * KNN branches on two streams), 1 = two launches (no hits_out, a flat AND of <= 4 term lists, top_n / k <= 32: one tile
- * kernel -- probe, scores, distances, per-tile winners -- and one reduce kernel).  Same answers either way. */
+/* how the calling thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 = the staged pipeline (intersection written
+ * out, score / top-N and KNN branches on two streams; stage by stage for trees), 1 = two launches (no hits_out, a flat AND of
+ * <= 4 term lists, top_n / k <= 32, no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
+ * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
+ * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
+ * offsets; hits_out wanted: a third launch packs the list).  BM25STD.NORM, a root union, a root whose children are all unions
+ * and indexes with a general label map stay staged.  Same answers either way. */
 int RSGPU_HybridQueryPath(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
@@ -227,6 +231,12 @@ typedef struct {
   int in_order;
 } RSGPU_TreeQuery;
 RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q);
+/* RSGPU_HybridQuery over such a tree -- the filter the reference hands its hybrid iterator as `childIt`
+ * (src/iterators/hybrid_reader.c:625 NewHybridVectorIterator; intersections with max_slop / in_order:
+ * rqe_iterators/src/intersection.rs:94-119) -- in one call: args->lists / n_lists are ignored (tree->lists are the terms;
+ * RSGPU_ScoreArgs.idf / bm25_idf / weight per LIST in their order), everything else as RSGPU_HybridQuery, hits_out included.
+ * Results are those of RSGPU_EvalTree + RSGPU_Hits_Score / _TopN / _KnnRerank; RSGPU_HybridQueryPath tells how it ran. */
+int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *tree, RSGPU_HybridQueryArgs *args);
 
 /* Query trees of ANY depth: `nodes` in POST-ORDER -- a term names its list; an aggregate (RSGPU_OP_UNION /
  * RSGPU_OP_INTERSECT) takes the n_children complete subtrees immediately before it; the last node is the root (its weight

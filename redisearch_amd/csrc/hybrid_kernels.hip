@@ -136,6 +136,105 @@ __device__ __forceinline__ void tile_select(const uint64_t (&mk)[DPT], const uin
   }
 }
 
+// The distances of a tile's nv compacted vector rows (vrow[j]: row number, in LDS) against the query staged in LDS (qs), their
+// orderable keys to vkey[j].  Called by the whole workgroup of 256; Args: HybridTileArgs / HybridTreeArgs (the KNN fields).
+template <int TYPE, int METRIC, typename Args>
+__device__ __forceinline__ void hyb_knn_distances(const Args &A, const uint32_t *vrow, uint32_t *vkey, uint32_t nv, const u4 *qs) {
+  const int G = A.G, ITERS = A.ITERS;
+  const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
+  const u4 *__restrict__ rows = reinterpret_cast<const u4 *>(A.rows);
+  // three rows per group and step, three chunks per row in flight (nine 16-byte loads per lane; four rows spill at six waves per SIMD): unconditional loads (from
+  // chunk 0 where the lane has none, from the step's first row past the end), the operations of scan_kernel in its order --
+  // chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly
+  constexpr int RU = 3, CU = 3;
+  if (ITERS <= CU && A.knn_pipeline) {
+    // Rows of at most CU chunks per lane (3 KiB fp32 rows at 64 lanes per row: every configs[4] row): ONE batch of loads per
+    // step, so the NEXT step's rows are requested as soon as this step's have been multiplied in -- their round trip
+    // (3.7 us under the kernel's own traffic) runs behind this step's butterfly, distance and store instead of after them.
+    // Same loads, same Op::add order, same reduction tree: the gather's bits.
+    u4 x[RU][CU];
+    uint32_t cc[CU];
+    bool ok[CU];
+#pragma unroll
+    for (int c = 0; c < CU; c++) {
+      const uint32_t ch = gl + (uint32_t)c * (uint32_t)G;
+      ok[c] = c < ITERS && ch < A.chunks;
+      cc[c] = ok[c] ? ch : 0u;
+    }
+    auto request = [&](uint32_t j0) {
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const uint32_t ju = j0 + u * GPB;
+        const u4 *pu = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
+#pragma unroll
+        for (int c = 0; c < CU; c++) x[u][c] = load16<true>(pu + cc[c]);
+      }
+    };
+    if (grp < nv) request(grp);
+    for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
+      float acc[RU];
+#pragma unroll
+      for (int u = 0; u < RU; u++) acc[u] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < CU; c++)
+        if (c < ITERS) {
+          const u4 q = ok[c] ? qs[cc[c]] : zero4();
+#pragma unroll
+          for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
+        }
+      // (unconditional -- past the end the step's first row again: a branch around the loads lets the scheduler sink them
+      // to their use; the barriers pin them in front of the reduction they are meant to overlap)
+      __builtin_amdgcn_sched_barrier(0);
+      request(j0 + RU * GPB < nv ? j0 + RU * GPB : j0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < RU; u++) {
+        const uint32_t ju = j0 + u * GPB;
+        const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
+        if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else
+  for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
+    const u4 *p[RU];
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      const uint32_t ju = j0 + u * GPB;
+      p[u] = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
+    }
+    float acc[RU];
+#pragma unroll
+    for (int u = 0; u < RU; u++) acc[u] = 0.0f;
+    for (int i0 = 0; i0 < ITERS; i0 += CU) {
+      u4 x[RU][CU];
+      uint32_t cc[CU];
+      bool ok[CU];
+#pragma unroll
+      for (int c = 0; c < CU; c++) {
+        const uint32_t ch = gl + (uint32_t)(i0 + c) * (uint32_t)G;
+        ok[c] = i0 + c < ITERS && ch < A.chunks;
+        cc[c] = ok[c] ? ch : 0u;
+#pragma unroll
+        for (int u = 0; u < RU; u++) x[u][c] = load16<true>(p[u] + cc[c]);  // (rows are read once: streamed past the caches)
+      }
+#pragma unroll
+      for (int c = 0; c < CU; c++)
+        if (i0 + c < ITERS) {
+          const u4 q = ok[c] ? qs[cc[c]] : zero4();
+#pragma unroll
+          for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; u++) {
+      const uint32_t ju = j0 + u * GPB;
+      const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
+      if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
+    }
+  }
+}
+
 // phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
 #define RSGPU_HYB_MARK(p)                                                                                   \
   do {                                                                                                      \
@@ -405,99 +504,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     __syncthreads();
     const uint32_t nv = nv_sh;
-    const int G = A.G, ITERS = A.ITERS;
-    const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
-    const u4 *__restrict__ rows = reinterpret_cast<const u4 *>(A.rows);
-    // three rows per group and step, three chunks per row in flight (nine 16-byte loads per lane; four rows spill at six waves per SIMD): unconditional loads (from
-    // chunk 0 where the lane has none, from the step's first row past the end), the operations of scan_kernel in its order --
-    // chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly
-    constexpr int RU = 3, CU = 3;
-    if (ITERS <= CU && A.knn_pipeline) {
-      // Rows of at most CU chunks per lane (3 KiB fp32 rows at 64 lanes per row: every configs[4] row): ONE batch of loads per
-      // step, so the NEXT step's rows are requested as soon as this step's have been multiplied in -- their round trip
-      // (3.7 us under the kernel's own traffic) runs behind this step's butterfly, distance and store instead of after them.
-      // Same loads, same Op::add order, same reduction tree: the gather's bits.
-      u4 x[RU][CU];
-      uint32_t cc[CU];
-      bool ok[CU];
-#pragma unroll
-      for (int c = 0; c < CU; c++) {
-        const uint32_t ch = gl + (uint32_t)c * (uint32_t)G;
-        ok[c] = c < ITERS && ch < A.chunks;
-        cc[c] = ok[c] ? ch : 0u;
-      }
-      auto request = [&](uint32_t j0) {
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-          const uint32_t ju = j0 + u * GPB;
-          const u4 *pu = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
-#pragma unroll
-          for (int c = 0; c < CU; c++) x[u][c] = load16<true>(pu + cc[c]);
-        }
-      };
-      if (grp < nv) request(grp);
-      for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
-        float acc[RU];
-#pragma unroll
-        for (int u = 0; u < RU; u++) acc[u] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < CU; c++)
-          if (c < ITERS) {
-            const u4 q = ok[c] ? qs[cc[c]] : zero4();
-#pragma unroll
-            for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
-          }
-        // (unconditional -- past the end the step's first row again: a branch around the loads lets the scheduler sink them
-        // to their use; the barriers pin them in front of the reduction they are meant to overlap)
-        __builtin_amdgcn_sched_barrier(0);
-        request(j0 + RU * GPB < nv ? j0 + RU * GPB : j0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-          const uint32_t ju = j0 + u * GPB;
-          const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
-          if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else
-    for (uint32_t j0 = grp; j0 < nv; j0 += RU * GPB) {
-      const u4 *p[RU];
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        const uint32_t ju = j0 + u * GPB;
-        p[u] = rows + (size_t)vrow[ju < nv ? ju : j0] * A.stride16;
-      }
-      float acc[RU];
-#pragma unroll
-      for (int u = 0; u < RU; u++) acc[u] = 0.0f;
-      for (int i0 = 0; i0 < ITERS; i0 += CU) {
-        u4 x[RU][CU];
-        uint32_t cc[CU];
-        bool ok[CU];
-#pragma unroll
-        for (int c = 0; c < CU; c++) {
-          const uint32_t ch = gl + (uint32_t)(i0 + c) * (uint32_t)G;
-          ok[c] = i0 + c < ITERS && ch < A.chunks;
-          cc[c] = ok[c] ? ch : 0u;
-#pragma unroll
-          for (int u = 0; u < RU; u++) x[u][c] = load16<true>(p[u] + cc[c]);  // (rows are read once: streamed past the caches)
-        }
-#pragma unroll
-        for (int c = 0; c < CU; c++)
-          if (i0 + c < ITERS) {
-            const u4 q = ok[c] ? qs[cc[c]] : zero4();
-#pragma unroll
-            for (int u = 0; u < RU; u++) acc[u] = Op<TYPE, METRIC>::add(acc[u], ok[c] ? x[u][c] : zero4(), q);
-          }
-      }
-#pragma unroll
-      for (int u = 0; u < RU; u++) {
-        const uint32_t ju = j0 + u * GPB;
-        const float d = finish<TYPE, METRIC>(group_reduce_rt(acc[u], G), zero4());
-        if (gl == 0 && ju < nv) vkey[ju] = f2key(d);
-      }
-    }
+    hyb_knn_distances<TYPE, METRIC>(A, vrow, vkey, nv, qs);
     __syncthreads();
     RSGPU_HYB_MARK(7);
     uint64_t vk_mine[DPT];
@@ -743,6 +750,383 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
 
 
 
+// ---- the general form: a root intersection over terms / unions / intersections of terms, max_slop / in_order, per-hit slop, the
+// ordered hit list (search_kernels.hpp HybridTreeArgs) ----------------------------------------------------------------------------
+constexpr uint32_t kHybNone = 0xFFFFFFFFu;
+
+// Ordered compaction of the workgroup's flagged slots: slot (k, thread) -- k-major: the order of the drivers, and of compacted
+// entries k * 256 + thread -- gets the number of flagged slots before it; returns their total.  seg: DPT * 4 + 1 words of LDS,
+// free again once every thread has passed a later barrier.
+template <int DPT>
+__device__ __forceinline__ uint32_t ordered_slots(const bool (&flag)[DPT], uint32_t (&slot)[DPT], uint32_t *seg) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long m[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    m[k] = __ballot(flag[k]);
+    if (lane == 0) seg[k * 4 + wave] = (uint32_t)__popcll(m[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int q = 0; q < DPT * 4; q++) {
+      const uint32_t c = seg[q];
+      seg[q] = run;
+      run += c;
+    }
+    seg[DPT * 4] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < DPT; k++) slot[k] = seg[k * 4 + wave] + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull));
+  return seg[DPT * 4];
+}
+
+// Dynamic LDS as hybrid_tile_kernel: pool_words u32 -- a probed list's window; then the candidates' records: doc id |
+// entry index per LEAF ((n + 1) arrays of a tile's drivers), the frequencies in the entry indices' place once they are
+// gathered; then keys | doc ids; then branch B's rows | doc ids | keys -- and the KNN query behind it.
+template <int TYPE, int METRIC>
+__global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A) {
+  constexpr int DPT = kHybDpt, ML = kHybTreeMaxLists;
+  constexpr uint32_t TILE = kHybTile;
+  extern __shared__ __attribute__((aligned(16))) uint32_t win[];
+  __shared__ uint32_t seg[DPT * 4 + 1];
+  __shared__ uint32_t w_lo, w_hi, nv_sh, sel_cnt;
+  __shared__ uint64_t sel_k[kHybScratch], sel_wtk[4];
+  __shared__ uint32_t sel_x[kHybScratch], sel_wtx[4];
+  const uint32_t WIN = A.pool_words;
+  u4 *qs = reinterpret_cast<u4 *>(win + WIN);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n0 = A.len[0];
+  const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  const uint32_t *__restrict__ ids0 = A.ids[0];
+  if (threadIdx.x == 0) nv_sh = 0;
+  if (A.k)
+    for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
+
+  bool live[DPT];
+  uint32_t xc[DPT];           // doc id in the frame the lists share
+  uint32_t ps[DPT][ML - 1];   // match position in list l, kHybNone: list l does not hold the document
+  uint32_t mb[DPT];           // bit l: list l holds it
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = i_first + k * 256 + threadIdx.x;
+    live[k] = i < n0;
+    const uint32_t ic = live[k] ? i : n0 - 1;
+    xc[k] = (uint32_t)((long long)ids0[ic] + A.add[0]);
+    mb[k] = live[k] ? 1u : 0u;
+#pragma unroll
+    for (int l = 0; l < ML - 1; l++) ps[k][l] = kHybNone;
+  }
+  const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);
+  const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
+
+  // ---- probe: every other list through its window (hybrid_tile_kernel's, without the early exit: a union's lists are
+  // alternatives, a driver that misses one may still be a candidate) ----
+#pragma unroll
+  for (int l = 1; l < ML; l++) {
+    if (l < A.n) {
+      const uint32_t *__restrict__ a = A.ids[l];
+      const uint32_t nl = A.len[l];
+      const long long add = A.add[l];
+      if (A.dir[l]) {
+        if (threadIdx.x == 0) {
+          bool u0, u1;
+          const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
+          const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
+          const uint32_t bf = xf >> sh, bn = (xn >> sh) + 1;
+          const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
+          w_lo = dlo;
+          w_hi = i_next < n0 ? dhi : nl;
+        }
+      } else if (wave == 0) {
+        bool u0;
+        uint32_t rlo, rhi;
+        wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, 0u, false, &rlo, &rhi);
+        if (lane == 0) w_lo = rlo;
+      } else if (wave == 1) {
+        bool u1;
+        uint32_t rlo, rhi = nl;
+        if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, add, &u1), lane, 0u, false, &rlo, &rhi);
+        if (lane == 0) w_hi = rhi;
+      }
+      __syncthreads();
+      const uint32_t lo = w_lo, hi = w_hi;
+      const uint32_t span = hi - lo;
+      if (span <= WIN) {
+        for (uint32_t base = 0; base < span; base += 8 * 256) {
+          uint32_t t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            t[j] = a[lo + (o < span ? o : span - 1)];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            if (o < span) win[o] = t[j];
+          }
+        }
+        __syncthreads();
+        uint32_t xl[DPT], b[DPT];
+        bool under[DPT];
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          xl[k] = to_list_frame(xc[k], add, &under[k]);
+          b[k] = 0;
+        }
+        uint32_t rem = span;
+        while (rem > 1) {
+          const uint32_t half = rem >> 1;
+#pragma unroll
+          for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
+          rem -= half;
+        }
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          if (span && win[b[k]] < xl[k]) b[k]++;
+          const bool m = live[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
+          if (m) {
+            ps[k][l - 1] = lo + b[k];
+            mb[k] |= 1u << l;
+          }
+        }
+      } else {  // a window that does not fit: a binary search in memory, confined to the window
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          bool under;
+          const uint32_t x = to_list_frame(xc[k], add, &under);
+          uint32_t b = lo, e = hi;
+          if (live[k]) {
+            while (b < e) {
+              const uint32_t mid = b + ((e - b) >> 1);
+              if (a[mid] < x) b = mid + 1;
+              else e = mid;
+            }
+            if (!under && b < nl && a[b] == x) {
+              ps[k][l - 1] = b;
+              mb[k] |= 1u << l;
+            }
+          }
+        }
+      }
+      __syncthreads();  // win / w_lo / w_hi are reused
+    }
+  }
+
+  // ---- candidates: a list of every required set holds the document; compacted in driver order ----
+  bool hit[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; k++) {
+    bool h = live[k];
+#pragma unroll
+    for (int r = 0; r < ML; r++)
+      if (r < A.n_req) h = h && (mb[k] & A.req[r]) != 0u;
+    hit[k] = h;
+  }
+  uint32_t slot[DPT];
+  const uint32_t nc = ordered_slots<DPT>(hit, slot, seg);
+#pragma unroll
+  for (int k = 0; k < DPT; k++)
+    if (hit[k]) {
+      const uint32_t s = slot[k];
+      win[s] = xc[k];
+      win[(1u + A.leaf_of[0]) * TILE + s] = i_first + k * 256 + threadIdx.x;
+#pragma unroll
+      for (int l = 1; l < ML; l++)
+        if (l < A.n) win[(1u + A.leaf_of[l]) * TILE + s] = ps[k][l - 1];
+    }
+  __syncthreads();
+
+  // ---- max_slop / in_order (Intersection::current_is_relevant, intersection.rs:205-215): prox_filter_kernel's test, one
+  // candidate per lane where they sit compacted; the survivors close ranks, still in driver order ----
+  uint32_t nh = nc;
+  if (A.prox_filter) {
+    bool keep[DPT];
+    uint32_t ex_[DPT], ee[DPT][ML];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      keep[j] = false;
+      ex_[j] = 0;
+#pragma unroll
+      for (int t = 0; t < ML; t++) ee[j][t] = kHybNone;
+      if (e < nc) {
+        ex_[j] = win[e];
+#pragma unroll
+        for (int t = 0; t < ML; t++)
+          if (t < A.n) ee[j][t] = win[(1u + t) * TILE + e];
+        ProxCtx<ML> x;
+        prox_load<ML>(A.X, A.O, x, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
+        keep[j] = prox_within_range<ML>(A.X, x);
+      }
+    }
+    nh = ordered_slots<DPT>(keep, slot, seg);  // (its barriers: every record has been read before one is rewritten)
+#pragma unroll
+    for (int j = 0; j < DPT; j++)
+      if (keep[j]) {
+        const uint32_t s = slot[j];
+        win[s] = ex_[j];
+#pragma unroll
+        for (int t = 0; t < ML; t++)
+          if (t < A.n) win[(1u + t) * TILE + s] = ee[j][t];
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) A.tile_hits[blockIdx.x] = nh;
+
+  // ---- per hit: slop, frequencies (per leaf, 0 where a union's term is absent), the hit list's records, the score ----
+  uint64_t my_k[DPT];
+  uint32_t my_x[DPT];
+  const size_t g0 = (size_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int j = 0; j < DPT; j++) {
+    const uint32_t e = j * 256 + threadIdx.x;
+    my_k[j] = ~0ull;
+    my_x[j] = ~0u;
+    if (e < nh) {
+      const uint32_t x = win[e];
+      my_x[j] = x;
+      int slop = A.P.slop;
+      if (A.prox_slop && A.top_n) {  // IndexResult_MinOffsetDelta from the term offsets (prox_slop_kernel's)
+        ProxCtx<ML> c;
+        prox_load<ML>(A.X, A.O, c, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
+        slop = prox_min_offset_delta<ML>(A.X, c);
+      }
+#pragma unroll
+      for (int t = 0; t < ML; t++)
+        if (t < A.n) {
+          const uint32_t ep = win[(1u + t) * TILE + e];
+          const uint32_t *__restrict__ fq = A.lfreq[t];
+          // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
+          const uint32_t fv = ep == kHybNone ? 0u : (fq ? fq[ep] : 1u);
+          if (A.hit_ids) {
+            A.hit_freqs[(size_t)t * A.hit_stride + g0 + e] = fv;
+            if (A.hit_epos) A.hit_epos[(size_t)t * A.hit_stride + g0 + e] = ep;
+          }
+          win[(1u + t) * TILE + e] = fv;  // (this lane's own record: nobody else reads it)
+        }
+      if (A.hit_ids) A.hit_ids[g0 + e] = x;
+      if (A.top_n) {
+        const long long tid = (long long)x + A.P.table_off;
+        const bool known = tid >= 0 && tid < (long long)A.table_n;
+        const uint32_t id = known ? (uint32_t)tid : 0u;
+        float dscore;
+        uint32_t dlen;
+        if (A.len_score) {
+          const uint2 ls = A.len_score[id];
+          dlen = known ? ls.x : 0u;
+          dscore = known ? __uint_as_float(ls.y) : 0.0f;
+        } else {
+          dscore = known ? A.doc_score[id] : 0.0f;
+          dlen = known ? A.doc_len[id] : 0u;
+        }
+        const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
+        auto F = [&](int t) { return (double)win[(1u + (uint32_t)t) * TILE + e]; };
+        const double s = score_one<false>(A.P, F, dlen, dscore, mfreq, slop);
+        my_k[j] = ~d2key(s);
+      }
+    }
+  }
+  __syncthreads();  // every record has been read: keys | doc ids (branch A), rows | doc ids | keys (branch B) take their place
+
+  // ---- branch A: the tile's top-N ----
+  if (A.top_n) {
+    uint64_t *ek = reinterpret_cast<uint64_t *>(win);
+    uint32_t *ex = win + 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      if (e < nh) {
+        ek[e] = my_k[j];
+        ex[e] = my_x[j];
+      }
+    }
+    __syncthreads();
+    uint32_t sx_[DPT];  // (tile_select takes "none" past the end in both components)
+#pragma unroll
+    for (int j = 0; j < DPT; j++) sx_[j] = my_k[j] == ~0ull ? ~0u : my_x[j];
+    tile_select<DPT>(my_k, sx_, nh, A.top_n, [&](uint32_t o) { return SKey{ek[o], ex[o]}; }, sel_k, sel_x, &sel_cnt, sel_wtk, sel_wtx,
+                     [&](uint32_t rank, const SKey &my) {
+                       A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
+                       A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
+                     });
+    if (threadIdx.x >= nh && threadIdx.x < A.top_n) {
+      A.part_skey[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0ull;
+      A.part_sidx[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0u;
+    }
+    __syncthreads();
+  }
+
+  // ---- branch B: the hits that have a vector, their distances, the tile's top-k ----
+  if (A.k) {
+    uint32_t *vrow = win, *vx = win + TILE, *vkey = win + 2 * TILE;
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      const uint64_t id = A.ids_base + my_x[j];
+      const bool has = e < nh && id >= A.knn_base && id - A.knn_base < A.n_rows;
+      const unsigned long long m = __ballot(has);
+      if (m) {
+        uint32_t first = 0;
+        const int leader = __builtin_ctzll(m);
+        if (lane == (uint32_t)leader) first = atomicAdd(&nv_sh, (uint32_t)__popcll(m));
+        first = __shfl(first, leader, 64);
+        if (has) {
+          const uint32_t s = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          vrow[s] = (uint32_t)(id - A.knn_base);
+          vx[s] = my_x[j];
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nv = nv_sh;
+    hyb_knn_distances<TYPE, METRIC>(A, vrow, vkey, nv, qs);
+    __syncthreads();
+    uint64_t vk_mine[DPT];
+    uint32_t vx_mine[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+      const uint32_t e = j * 256 + threadIdx.x;
+      vk_mine[j] = e < nv ? (uint64_t)vkey[e] : ~0ull;
+      vx_mine[j] = e < nv ? vx[e] : ~0u;
+    }
+    tile_select<DPT>(vk_mine, vx_mine, nv, A.k, [&](uint32_t o) { return SKey{(uint64_t)vkey[o], vx[o]}; }, sel_k, sel_x, &sel_cnt,
+                     sel_wtk, sel_wtx, [&](uint32_t rank, const SKey &my) {
+                       A.part_knn[(size_t)blockIdx.x * A.k + rank] = (my.k << 32) | my.i;
+                     });
+    if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
+  }
+}
+
+// The hit list out of the tiles' fixed slots: tile t's hits go behind those of the tiles before it.  One workgroup per tile; it
+// sums the counts below its own (n_tiles <= 16 Ki words, L2-resident).  Runs BEHIND the reduce kernel: the query's answers are
+// in host memory before this kernel starts.
+__global__ __launch_bounds__(256) void hybrid_hits_pack_kernel(const uint32_t *__restrict__ tile_hits, uint32_t n_tiles, int n_leaves,
+                                                               const uint32_t *__restrict__ src_ids, const uint32_t *__restrict__ src_freqs,
+                                                               const uint32_t *__restrict__ src_epos, uint32_t src_stride,
+                                                               uint32_t *__restrict__ dst_ids, uint32_t *__restrict__ dst_freqs,
+                                                               uint32_t *__restrict__ dst_epos, uint32_t dst_cap, uint32_t *total_out) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t t = blockIdx.x;
+  uint32_t s = 0;
+  for (uint32_t u = threadIdx.x; u < t; u += 256) s += tile_hits[u];
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const uint32_t off = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const uint32_t cnt = tile_hits[t];
+  const size_t from = (size_t)t * kHybTile;
+  for (uint32_t r = threadIdx.x; r < cnt; r += 256) {
+    dst_ids[off + r] = src_ids[from + r];
+    for (int l = 0; l < n_leaves; l++) {
+      dst_freqs[(size_t)l * dst_cap + off + r] = src_freqs[(size_t)l * src_stride + from + r];
+      if (src_epos) dst_epos[(size_t)l * dst_cap + off + r] = src_epos[(size_t)l * src_stride + from + r];
+    }
+  }
+  if (t == n_tiles - 1 && threadIdx.x == 0) *total_out = off + cnt;
+}
+
 // dir[b] = lower_bound(ids, b << shift): entry i owns the buckets behind its predecessor's up to its own (the first entry
 // the buckets from 0, the last one also those behind its own up to dir_n - 1, which hold n)
 __global__ __launch_bounds__(256) void build_bucket_dir_kernel(const uint32_t *__restrict__ ids, uint32_t n, uint32_t shift,
@@ -806,6 +1190,39 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
   else if (metric == KM_L2) RSGPU_HYB(KT_BF16, KM_L2);
   else RSGPU_HYB(KT_BF16, KM_IP);
 #undef RSGPU_HYB
+}
+bool hybrid_tree_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k, int n_lists) {
+  return n_lists >= 1 && n_lists <= kHybTreeMaxLists && hybrid_tile_supported(type, metric, stride16, n_tiles, top_n, k);
+}
+void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, uint32_t n_tiles, hipStream_t s) {
+  if (!n_tiles) return;
+  HybridTreeArgs a = args;
+  if (a.k) {
+    const Shape sh = pick_shape(a.stride16);
+    a.G = sh.G;
+    a.ITERS = sh.ITERS;
+  } else {
+    a.G = 1;
+    a.ITERS = 0;
+  }
+  a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
+  const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
+#define RSGPU_HYBT(T, M) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M>), dim3(n_tiles), dim3(256), lds, s, a)
+  if (!a.k) RSGPU_HYBT(KT_F32, KM_IP);
+  else if (type == KT_F32 && metric == KM_L2) RSGPU_HYBT(KT_F32, KM_L2);
+  else if (type == KT_F32) RSGPU_HYBT(KT_F32, KM_IP);
+  else if (type == KT_F16 && metric == KM_L2) RSGPU_HYBT(KT_F16, KM_L2);
+  else if (type == KT_F16) RSGPU_HYBT(KT_F16, KM_IP);
+  else if (metric == KM_L2) RSGPU_HYBT(KT_BF16, KM_L2);
+  else RSGPU_HYBT(KT_BF16, KM_IP);
+#undef RSGPU_HYBT
+}
+void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
+                             const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,
+                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s) {
+  if (!n_tiles) return;
+  hipLaunchKernelGGL(hybrid_hits_pack_kernel, dim3(n_tiles), dim3(256), 0, s, tile_hits, n_tiles, n_leaves, src_ids, src_freqs, src_epos,
+                     src_stride, dst_ids, dst_freqs, dst_epos, dst_cap, total_out);
 }
 void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s) {
   hipLaunchKernelGGL(hybrid_reduce_kernel, dim3((r.k ? 1 : 0) + (r.top_n ? 1 : 0) + 1), dim3(1024), 0, s, r);

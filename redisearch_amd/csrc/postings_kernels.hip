@@ -837,187 +837,7 @@ __global__ __launch_bounds__(256) void not_universe_write_kernel(const uint32_t 
   }
 }
 
-// ---- proximity: max_slop / in_order and the scorers' slop, over the offset bytes in place ---------------------------------
-// Reference: index_result/src/core/proximity.rs:134-298 (within_range_in_order / _unordered, OffsetIter::Merge) and
-// src/index_result/index_result.c:51-103 (IndexResult_MinOffsetDelta).  One thread per candidate / hit; a term's
-// positions are read straight out of the list's byte buffer (varint deltas), nothing is materialised.
-constexpr uint32_t kPosEof = 0xFFFFFFFFu;
-struct TermIt {
-  const uint8_t *p;
-  uint32_t len, pos, last;
-};
-__device__ __forceinline__ uint32_t term_next(TermIt &t) {
-  if (t.pos >= t.len) return kPosEof;
-  uint32_t c = t.p[t.pos++];
-  uint32_t val = c & 0x7fu;
-  while (c & 0x80u) {
-    if (t.pos >= t.len) return kPosEof;  // truncated varint: the reference's reader errors -> EOF
-    val++;
-    c = t.p[t.pos++];
-    val = (val << 7) | (c & 0x7fu);
-  }
-  t.last += val;
-  return t.last;
-}
-
-template <int MAXL>
-struct ProxCtx {
-  TermIt leaf[MAXL];
-  uint32_t look[MAXL];
-  uint32_t present;  // bit l: leaf l matched this document (union children may be absent)
-
-  __device__ __forceinline__ bool child_present(const ProxParams &P, int c) const {
-    uint32_t m = 0;
-    for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) m |= (present >> l) & 1u;
-    return m != 0;
-  }
-
-  __device__ __forceinline__ bool merged(const ProxParams &P, int c) const {
-    return P.is_agg[c] && (P.child_first[c + 1] - P.child_first[c]) != 1;
-  }
-  // proximity.rs:72-90: a term takes part iff it has offsets, an aggregate of terms always does
-  __device__ __forceinline__ bool has(const ProxParams &P, int c) const {
-    return P.is_agg[c] ? child_present(P, c) : (P.child_first[c + 1] > P.child_first[c] && leaf[P.child_first[c]].len > 0);
-  }
-  __device__ __forceinline__ void reset(const ProxParams &P, int c) {
-    for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) {
-      leaf[l].pos = 0;
-      leaf[l].last = 0;
-    }
-    if (merged(P, c))
-      for (int l = P.child_first[c]; l < P.child_first[c + 1]; l++) look[l] = term_next(leaf[l]);
-  }
-  __device__ __forceinline__ uint32_t next(const ProxParams &P, int c) {
-    const int a = P.child_first[c], b = P.child_first[c + 1];
-    if (!merged(P, c)) return b > a ? term_next(leaf[a]) : kPosEof;
-    int best = -1;
-    uint32_t mv = kPosEof;
-    for (int l = a; l < b; l++)
-      if (look[l] != kPosEof && look[l] < mv) {
-        mv = look[l];
-        best = l;
-      }
-    if (best < 0) return kPosEof;
-    look[best] = term_next(leaf[best]);
-    return mv;
-  }
-};
-
-template <int MAXL>
-__device__ bool prox_within_range(const ProxParams &P, ProxCtx<MAXL> &x) {
-  if (P.n_children <= 1) return true;
-  int m[MAXL], n = 0;
-  for (int c = 0; c < P.n_children; c++)
-    if (x.has(P, c)) {
-      x.reset(P, c);
-      m[n++] = c;
-    }
-  if (n <= 1) return true;
-  const uint32_t max_slop = P.max_slop < 0 ? 0xFFFFFFFFu : (uint32_t)P.max_slop;
-  uint32_t positions[MAXL];
-  if (P.in_order) {
-    for (int i = 0; i < n; i++) positions[i] = 0;
-    for (;;) {
-      int span = 0;
-      bool over = false;
-      for (int i = 0; i < n; i++) {
-        uint32_t pos;
-        if (i == 0) {
-          pos = x.next(P, m[0]);
-          if (pos == kPosEof) return false;
-        } else {
-          pos = positions[i];
-        }
-        const uint32_t last_pos = i == 0 ? 0u : positions[i - 1];
-        while (pos < last_pos) {
-          pos = x.next(P, m[i]);
-          if (pos == kPosEof) return false;
-        }
-        positions[i] = pos;
-        if (i > 0) {
-          span += (int)pos - (int)last_pos - 1;
-          if (span > 0 && (uint32_t)span > max_slop) {
-            over = true;
-            break;
-          }
-        }
-      }
-      if (!over) return true;
-    }
-  }
-  for (int i = 0; i < n; i++) {
-    positions[i] = x.next(P, m[i]);
-    if (positions[i] == kPosEof) return false;
-  }
-  uint32_t max_pos = 0;
-  for (int i = 0; i < n; i++)
-    if (positions[i] >= max_pos) max_pos = positions[i];
-  for (;;) {
-    uint32_t min_pos = kPosEof;
-    int min_idx = 0;
-    for (int i = 0; i < n; i++)
-      if (positions[i] < min_pos) {
-        min_pos = positions[i];
-        min_idx = i;
-      }
-    if (min_pos != max_pos) {
-      const int span = (int)max_pos - (int)min_pos - (n - 1);
-      if (span < 0 || (uint32_t)span <= max_slop) return true;
-    }
-    const uint32_t np = x.next(P, m[min_idx]);
-    if (np == kPosEof) return false;
-    positions[min_idx] = np;
-    if (np > max_pos) max_pos = np;
-  }
-}
-
-template <int MAXL>
-__device__ int prox_min_offset_delta(const ProxParams &P, ProxCtx<MAXL> &x) {
-  const int nc = P.n_children;
-  // a union's aggregate only holds the children that matched this document (union_flat.rs:297-320)
-  int num = nc;
-  if (P.count_present) {
-    num = 0;
-    for (int c = 0; c < nc; c++) num += x.child_present(P, c) ? 1 : 0;
-  }
-  if (num <= 1) return 1;
-  int dist = 0, i = 0;
-  while (i < nc) {
-    while (i < nc && !x.has(P, i)) i++;
-    if (i == nc) break;
-    const int c1 = i++;
-    while (i < nc && !x.has(P, i)) i++;
-    if (i == nc) break;
-    const int c2 = i;  // (not consumed: it is the first of the next pair)
-    x.reset(P, c1);
-    x.reset(P, c2);
-    uint32_t p1 = x.next(P, c1), p2 = x.next(P, c2);
-    int cd = (int)(p2 > p1 ? p2 - p1 : p1 - p2);
-    while (cd > 1 && p1 != kPosEof && p2 != kPosEof) {
-      const uint32_t a = p2 > p1 ? p2 - p1 : p1 - p2;
-      if (a < (uint32_t)cd) cd = (int)a;
-      if (p2 > p1) p1 = x.next(P, c1);
-      else p2 = x.next(P, c2);
-    }
-    dist += cd * cd;
-  }
-  return dist ? (int)sqrt((double)dist) : num - 1;
-}
-
-template <int MAXL, typename EntryOf>
-__device__ __forceinline__ void prox_load(const ProxParams &P, const OffsetView &o, ProxCtx<MAXL> &x, EntryOf entry_of) {
-  x.present = 0;
-  for (int l = 0; l < P.n_leaves; l++) {
-    const uint32_t e = entry_of(l);
-    if (e != 0xFFFFFFFFu) x.present |= 1u << l;
-    const bool on = o.off_pos[l] != nullptr && e != 0xFFFFFFFFu;
-    x.leaf[l].p = on ? o.bytes[l] + o.off_pos[l][e] : nullptr;
-    x.leaf[l].len = on ? o.off_len[l][e] : 0u;
-    x.leaf[l].pos = 0;
-    x.leaf[l].last = 0;
-  }
-}
-
+// ---- proximity: the per-candidate / per-hit device functions live in postings_ops.hpp (hybrid_kernels.hip runs them too) ----
 template <int MAXL>
 __global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetView o, LeafMap lm, uint32_t n0,
                                                           const uint32_t *__restrict__ pos, uint8_t *__restrict__ flags,

@@ -127,6 +127,8 @@ struct Scratch {
   DevBuf<uint32_t> hyb_hits, hyb_sidx;
   DevBuf<uint64_t> hyb_skey, hyb_knn, hyb_trace;
   uint32_t hyb_trace_tiles = 0;
+  // ... its general form, hit list wanted: doc id | frequencies | entry indices at the tiles' fixed slots (hybrid_hits_pack)
+  DevBuf<uint32_t> hyb_hit_ids, hyb_hit_freqs, hyb_hit_epos;
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -143,6 +145,7 @@ Scratch &scratch(int device) {
     s.hyb_hits.reset(); s.hyb_sidx.reset();
     s.hyb_skey.reset(); s.hyb_knn.reset(); s.hyb_trace.reset();
     s.hyb_trace_tiles = 0;
+    s.hyb_hit_ids.reset(); s.hyb_hit_freqs.reset(); s.hyb_hit_epos.reset();
     s.device = device;
   }
   return s;
@@ -1453,6 +1456,102 @@ static void ensure_bucket_dir(RSGPU_Postings *p, QueryCtx *c) {
   p->dir_ready.store(true, std::memory_order_release);
 }
 
+// ---- shared by the two forms of the tile path (hybrid_two_launches, hybrid_general) ----
+// Scratch for the tiles' lists, the reduce kernel's arguments (answers and completion flags in pinned host memory: ca's for the
+// hit count and the scores, cb's for the KNN winners), the flags re-armed.
+static void hyb_outputs(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k, HybridReduceArgs &R) {
+  sc.hyb_hits.ensure(n_tiles);
+  if (top_n) {
+    sc.hyb_skey.ensure((size_t)n_tiles * top_n);
+    sc.hyb_sidx.ensure((size_t)n_tiles * top_n);
+  }
+  if (k) sc.hyb_knn.ensure((size_t)n_tiles * k);
+  memset(&R, 0, sizeof R);
+  R.n_tiles = n_tiles;
+  R.top_n = top_n;
+  R.k = k;
+  R.surv_cap = (uint32_t)std::min(std::max(scan_tuning().hybrid_surv_cap, 1), 2048);
+  R.tile_hits = sc.hyb_hits.p;
+  R.part_skey = sc.hyb_skey.p;
+  R.part_sidx = sc.hyb_sidx.p;
+  R.part_knn = sc.hyb_knn.p;
+  ca->ensure_out(std::max<uint32_t>(top_n, 1));
+  ca->ensure_gather(std::max<uint32_t>(top_n, 1) + 1);
+  cb->ensure_out(std::max<uint32_t>(k, 1));
+  cb->ensure_gather(std::max<uint32_t>(k, 1) + 1);
+  ca->h_counters[0] = 0;
+  ca->h_fcnt[2] = 0;
+  cb->h_fcnt[2] = 0;
+  R.out_hits = ca->h_counters;
+  R.out_skeys = ca->h_out_keys;
+  R.out_sids = ca->h_ids;
+  R.out_sn = ca->h_fcnt + 2;
+  R.out_krows = cb->h_out_rows;
+  R.out_kkeys = reinterpret_cast<uint32_t *>(cb->h_out_keys);
+  R.out_kids = cb->h_ids;
+  R.out_kn = cb->h_fcnt + 2;
+  // completion flags the host polls (h_counters[1..3]: pinned, device-visible): hipStreamSynchronize costs several
+  // microseconds of a 60 us query once the device is done
+  volatile uint32_t *done = ca->h_counters + 1;
+  done[0] = top_n ? 0u : 1u;
+  done[1] = k ? 0u : 1u;
+  done[2] = 0u;
+  R.done = ca->h_counters + 1;
+}
+// the reduce kernel's three flags (may_poll), then -- sync_after: kernels were enqueued behind the reduce kernel -- the stream
+static void hyb_wait(QueryCtx *ca, bool may_poll, bool sync_after) {
+  volatile uint32_t *done = ca->h_counters + 1;
+  bool finished = false;
+  if (may_poll && scan_tuning().hybrid_poll) {
+    for (int spin = 0; spin < 400000; spin++) {
+      if (done[0] && done[1] && done[2]) {
+        finished = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!finished || sync_after) HIP_CHECK(hipStreamSynchronize(ca->stream));
+}
+// the answers out of pinned memory; false: the reduce kernel met more candidates at its bound than it ranks
+static bool hyb_collect(RSGPU_HybridQueryArgs *a, uint64_t base, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
+  if (n_tiles && ((top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) || (k && cb->h_fcnt[2] == 0xFFFFFFFFu))) return false;
+  a->n_hits = n_tiles ? ca->h_counters[0] : 0;
+  if (top_n && n_tiles) {
+    const uint32_t n = std::min<uint32_t>(ca->h_fcnt[2], top_n);
+    for (uint32_t i = 0; i < n; i++) {
+      if (a->top_ids) a->top_ids[i] = base + ca->h_ids[i];
+      if (a->top_scores) a->top_scores[i] = key2score(ca->h_out_keys[i]);
+    }
+    a->n_top = n;
+  }
+  if (k && n_tiles) {
+    const uint32_t got = std::min<uint32_t>(cb->h_fcnt[2], k);
+    const uint32_t *k32 = reinterpret_cast<const uint32_t *>(cb->h_out_keys);
+    size_t out = 0;
+    for (uint32_t i = 0; i < got; i++) {  // (already in (distance, doc id) order)
+      if (k32[i] == 0xFFFFFFFFu) continue;  // NaN: a distance that is not a number ranks nowhere (hybrid_reader.c:317-320)
+      if (a->knn_ids) a->knn_ids[out] = base + cb->h_ids[i];
+      if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist(k32[i]);
+      out++;
+    }
+    a->n_knn = out;
+  }
+  return true;
+}
+static void hyb_profile(bool prof, FusedEvents &ev, uint32_t n_tiles) {
+  if (!prof) return;
+  float ms = 0;
+  prof_ms[0] = prof_ms[2] = prof_ms[4] = 0;
+  prof_ms[1] = prof_ms[3] = 0;
+  if (n_tiles) {
+    if (hipEventElapsedTime(&ms, ev.e[0], ev.e[1]) == hipSuccess) prof_ms[0] = ms;  // decode (nothing when the lists are cached)
+    if (hipEventElapsedTime(&ms, ev.e[1], ev.e[2]) == hipSuccess) prof_ms[1] = ms;  // the tile kernel: probe + score + distances
+    if (hipEventElapsedTime(&ms, ev.e[2], ev.e[3]) == hipSuccess) prof_ms[3] = ms;  // the reduce kernel (+ the hit list's pack)
+  }
+}
+
 // The query in two launches (hybrid_kernels.hip): for callers that do not ask for the hit list.  The caller holds the index
 // lock and has checked the shapes (hybrid_tile_supported); ca's stream carries everything, cb lends its pinned buffers to the
 // KNN answers; the prepared query is ca->d_query.  false: the reduce kernel met more candidates at its bound than it ranks
@@ -1518,12 +1617,8 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     T.knn_base = knn_base;
     T.n_rows = f->committed_rows();
   }
-  sc.hyb_hits.ensure(n_tiles);
-  if (top_n) {
-    sc.hyb_skey.ensure((size_t)n_tiles * top_n);
-    sc.hyb_sidx.ensure((size_t)n_tiles * top_n);
-  }
-  if (k) sc.hyb_knn.ensure((size_t)n_tiles * k);
+  HybridReduceArgs R;
+  hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
   sc.hyb_trace_tiles = 0;
   if (scan_tuning().hybrid_trace) {
     sc.hyb_trace.ensure((size_t)(n_tiles + 2) * kHybTracePhases);  // (+ the two branches of the reduce kernel)
@@ -1535,40 +1630,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
   T.part_skey = sc.hyb_skey.p;
   T.part_sidx = sc.hyb_sidx.p;
   T.part_knn = sc.hyb_knn.p;
-
-  HybridReduceArgs R;
-  memset(&R, 0, sizeof R);
-  R.n_tiles = n_tiles;
-  R.top_n = top_n;
-  R.k = k;
-  R.surv_cap = (uint32_t)std::min(std::max(scan_tuning().hybrid_surv_cap, 1), 2048);
-  R.tile_hits = sc.hyb_hits.p;
-  R.part_skey = sc.hyb_skey.p;
-  R.part_sidx = sc.hyb_sidx.p;
-  R.part_knn = sc.hyb_knn.p;
-  ca->ensure_out(std::max<uint32_t>(top_n, 1));
-  ca->ensure_gather(std::max<uint32_t>(top_n, 1) + 1);
-  cb->ensure_out(std::max<uint32_t>(k, 1));
-  cb->ensure_gather(std::max<uint32_t>(k, 1) + 1);
-  ca->h_counters[0] = 0;
-  ca->h_fcnt[2] = 0;
-  cb->h_fcnt[2] = 0;
-  R.out_hits = ca->h_counters;
-  R.out_skeys = ca->h_out_keys;
-  R.out_sids = ca->h_ids;
-  R.out_sn = ca->h_fcnt + 2;
-  R.out_krows = cb->h_out_rows;
-  R.out_kkeys = reinterpret_cast<uint32_t *>(cb->h_out_keys);
-  R.out_kids = cb->h_ids;
-  R.out_kn = cb->h_fcnt + 2;
   R.trace = T.trace ? T.trace + (size_t)n_tiles * kHybTracePhases : nullptr;
-  // completion flags the host polls (h_counters[1..3]: pinned, device-visible): hipStreamSynchronize costs several
-  // microseconds of a 60 us query once the device is done
-  volatile uint32_t *done = ca->h_counters + 1;
-  done[0] = top_n ? 0u : 1u;
-  done[1] = k ? 0u : 1u;
-  done[2] = 0u;
-  R.done = ca->h_counters + 1;
 
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
   if (n_tiles) {
@@ -1577,52 +1639,246 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     launch_hybrid_reduce(R, ca->stream);
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
-    bool finished = false;
-    if (!prof && !T.trace && scan_tuning().hybrid_poll) {
-      for (int spin = 0; spin < 400000; spin++) {
-        if (done[0] && done[1] && done[2]) {
-          finished = true;
-          break;
-        }
-        __builtin_ia32_pause();
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    if (!finished) HIP_CHECK(hipStreamSynchronize(ca->stream));
+    hyb_wait(ca, !prof && !T.trace, false);
   }
-  if (n_tiles && ((top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) || (k && cb->h_fcnt[2] == 0xFFFFFFFFu))) return false;
+  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k)) return false;
+  hyb_profile(prof, ev, n_tiles);
+  return true;
+}
 
-  a->n_hits = n_tiles ? ca->h_counters[0] : 0;
-  if (top_n && n_tiles) {
-    const uint32_t n = std::min<uint32_t>(ca->h_fcnt[2], top_n);
-    for (uint32_t i = 0; i < n; i++) {
-      if (a->top_ids) a->top_ids[i] = h.base + ca->h_ids[i];
-      if (a->top_scores) a->top_scores[i] = key2score(ca->h_out_keys[i]);
-    }
-    a->n_top = n;
+// ---- the general form of the tile path (hybrid_tree_tile_kernel): a root intersection over terms / unions of terms /
+// intersections of terms, max_slop / in_order, slop-dependent scorers over lists with offsets, the hit list itself ----
+// One child of the root, in the RESULT's child order (the order RSGPU_EvalTree / intersect_async give the children).
+struct HybGroup {
+  int op = 0;              // 0 term, 1 union, 2 intersection
+  double weight = 1.0;
+  std::vector<int> lists;  // the caller's list indices, in the child's own leaf order
+  size_t estimate = 0;
+};
+// a flat AND: every list a term child, ascending by size, stable (intersection.rs:94-119; intersect_async)
+static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_t n_lists) {
+  std::vector<int> order(n_lists);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lists[x]->n_entries < lists[y]->n_entries; });
+  std::vector<HybGroup> g;
+  for (int li : order) {
+    HybGroup t;
+    t.lists.push_back(li);
+    t.estimate = lists[li]->n_entries;
+    g.push_back(t);
   }
-  if (k && n_tiles) {
-    const uint32_t got = std::min<uint32_t>(cb->h_fcnt[2], k);
-    const uint32_t *k32 = reinterpret_cast<const uint32_t *>(cb->h_out_keys);
-    size_t out = 0;
-    for (uint32_t i = 0; i < got; i++) {  // (already in (distance, doc id) order)
-      if (k32[i] == 0xFFFFFFFFu) continue;  // NaN: a distance that is not a number ranks nowhere (hybrid_reader.c:317-320)
-      if (a->knn_ids) a->knn_ids[out] = h.base + cb->h_ids[i];
-      if (a->knn_dists) a->knn_dists[out] = (double)key_to_dist(k32[i]);
-      out++;
+  return g;
+}
+// a two-level tree under a root intersection: the children and their leaves in the order RSGPU_EvalTree evaluates them
+static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_lists) {
+  std::vector<HybGroup> groups;
+  for (size_t g = 0; g < q->n_groups; g++) {
+    const size_t a = q->group_first[g], b = q->group_first[g + 1];
+    if (b <= a || b > n_lists) throw std::runtime_error("RSGPU_HybridTreeQuery: bad group_first");
+    const int op = q->group_op ? q->group_op[g] : RSGPU_OP_TERM;
+    HybGroup t;
+    t.weight = q->group_weight ? q->group_weight[g] : 1.0;
+    if (op == RSGPU_OP_TERM) {
+      if (b - a != 1) throw std::runtime_error("RSGPU_HybridTreeQuery: a term group holds exactly one list");
+      t.lists.push_back((int)a);
+      t.estimate = q->lists[a]->n_entries;
+      t.weight = 1.0;  // (a term's own weight stays in RSGPU_ScoreArgs.weight)
+    } else if (op == RSGPU_OP_INTERSECT || op == RSGPU_OP_UNION) {
+      t.op = op == RSGPU_OP_UNION ? 1 : 2;
+      for (size_t l = a; l < b; l++) t.lists.push_back((int)l);
+      if (op == RSGPU_OP_INTERSECT) {
+        std::stable_sort(t.lists.begin(), t.lists.end(), [&](int x, int y) { return q->lists[x]->n_entries < q->lists[y]->n_entries; });
+        t.estimate = q->lists[t.lists[0]]->n_entries;  // num_estimated of an intersection: its smallest child
+      } else {
+        for (int li : t.lists) t.estimate += q->lists[li]->n_entries;  // ... of a union: the sum
+      }
+    } else {
+      throw std::runtime_error("RSGPU_HybridTreeQuery: bad group_op");
     }
-    a->n_knn = out;
+    groups.push_back(t);
   }
-  if (prof) {
-    float ms = 0;
-    prof_ms[0] = prof_ms[2] = prof_ms[4] = 0;
-    prof_ms[1] = prof_ms[3] = 0;
-    if (n_tiles) {
-      if (hipEventElapsedTime(&ms, ev.e[0], ev.e[1]) == hipSuccess) prof_ms[0] = ms;  // decode (nothing when the lists are cached)
-      if (hipEventElapsedTime(&ms, ev.e[1], ev.e[2]) == hipSuccess) prof_ms[1] = ms;  // the tile kernel: probe + score + distances
-      if (hipEventElapsedTime(&ms, ev.e[2], ev.e[3]) == hipSuccess) prof_ms[3] = ms;  // the reduce kernel
+  if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const HybGroup &x, const HybGroup &y) { return x.estimate < y.estimate; });
+  return groups;
+}
+// the leaf that drives the probe: the shortest list every hit must hold (a term child, a term of a child intersection);
+// -1: every child is a union -- the staged pipeline takes the query
+static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists, uint32_t *n0_out) {
+  int best = -1;
+  uint32_t n0 = 0;
+  for (const HybGroup &g : groups)
+    if (g.op != 1)
+      for (int li : g.lists)
+        if (best < 0 || lists[li]->n_entries < n0) {
+          best = li;
+          n0 = lists[li]->n_entries;
+        }
+  *n0_out = n0;
+  return best;
+}
+
+// The caller holds the index lock and has checked the shapes (hybrid_tree_supported over the driver's tiles, every list
+// non-empty, <= kHybTreeMaxLists lists, not BM25STD.NORM).  hits_out (may be NULL): receives the hit list.  false: the reduce
+// kernel met more candidates at its bound than it ranks -- nothing was handed out, the staged pipeline takes the query.
+static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *lists, const std::vector<HybGroup> &groups, long max_slop,
+                           int in_order, RSGPU_Hits **hits_out, FlatIndex *f, uint64_t knn_base, bool want_score, bool want_knn,
+                           QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev) {
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
+  for (const HybGroup &g : groups)
+    for (int li : g.lists) decode_on(lists[li], ca);
+  // the result's tree, frame and leaf columns: the children as sources (an aggregate child only lends its shape here -- its
+  // lists are probed one by one, no hit list of its own is ever built)
+  std::unique_ptr<RSGPU_Hits> hp(new RSGPU_Hits());
+  RSGPU_Hits &h = *hp;
+  h.device = ca->device;
+  std::vector<Source> srcs;
+  for (const HybGroup &g : groups) {
+    if (g.op == 0) {
+      srcs.push_back(term_source(lists[g.lists[0]], g.lists[0]));
+      continue;
+    }
+    Source s;
+    s.op = g.op;
+    s.weight = g.weight;
+    s.n_leaves = (int)g.lists.size();
+    s.len = (uint32_t)std::min<size_t>(std::max<size_t>(g.estimate, 1), 0xFFFFFFF0ull);
+    s.first = ~0ull;
+    for (size_t j = 0; j < g.lists.size(); j++) {
+      RSGPU_Postings *pl = lists[g.lists[j]];
+      s.freq[j] = pl->cd.freq >= 0 ? pl->freqs.p : nullptr;
+      s.src[j] = pl;
+      s.orig[j] = g.lists[j];
+      s.first = std::min(s.first, pl->first_id);
+      s.last = std::max(s.last, pl->last);
+      s.tree.push_back(TNode{0, (uint8_t)j, 0, 1.0});
+    }
+    s.base = s.first;  // (only v.add of the ListView uses it: not read here)
+    s.tree.push_back(TNode{(uint8_t)g.op, 0, (uint16_t)g.lists.size(), g.weight});
+    srcs.push_back(s);
+  }
+  ListView v;
+  const LeafMap m = adopt_sources(&h, srcs, v, 2);
+  h.is_union = false;
+  const int n = h.n_lists;  // leaves
+  uint32_t n0 = 0;
+  const int driver = hyb_driver(groups, lists, &n0);  // (a caller's list index)
+  const uint32_t top_n = want_score ? (uint32_t)a->top_n : 0u, k = want_knn ? (uint32_t)a->k : 0u;
+  const uint32_t n_tiles = hybrid_tiles(n0);
+
+  HybridTreeArgs T;
+  memset(&T, 0, sizeof T);
+  T.n = n;
+  // lists in probe order: the driver, then the other leaves in leaf order
+  int leaf_of_list[kHybTreeMaxLists], list_of_leaf[kHybTreeMaxLists];
+  {
+    int driver_leaf = -1;
+    for (int t = 0; t < n; t++)
+      if (driver_leaf < 0 && h.order[t] == driver) driver_leaf = t;
+    int l = 1;
+    for (int t = 0; t < n; t++) {
+      const int slot = t == driver_leaf ? 0 : l++;
+      leaf_of_list[slot] = t;
+      list_of_leaf[t] = slot;
     }
   }
+  for (int l = 0; l < n; l++) {
+    const int t = leaf_of_list[l];
+    RSGPU_Postings *pl = const_cast<RSGPU_Postings *>(h.src[t]);
+    T.ids[l] = pl->ids.p;
+    T.len[l] = pl->n_entries;
+    T.add[l] = (long long)(pl->base - h.base);  // (two's complement: negative when the list's base lies below the frame's)
+    T.leaf_of[l] = (uint8_t)t;
+    if (l && scan_tuning().hybrid_dir) {
+      ensure_bucket_dir(pl, ca);
+      if (pl->dir_ready.load(std::memory_order_acquire)) {
+        T.dir[l] = pl->dir.p;
+        T.dir_shift[l] = pl->dir_shift;
+        T.dir_n[l] = pl->dir_n;
+      }
+    }
+  }
+  for (int t = 0; t < n; t++) {
+    T.lfreq[t] = m.leaf_freq[t];
+    const RSGPU_Postings *pl = h.src[t];
+    T.O.bytes[t] = pl->bytes.p;
+    T.O.off_pos[t] = pl->has_offsets() ? pl->off_pos.p : nullptr;
+    T.O.off_len[t] = pl->has_offsets() ? pl->off_len.p : nullptr;
+  }
+  // what a hit must hold: a term; every term of a child intersection; any term of a child union
+  for (int g = 0; g < h.n_groups; g++) {
+    uint32_t any = 0;
+    for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) {
+      if (h.group_op[g] == 1) any |= 1u << list_of_leaf[t];
+      else T.req[T.n_req++] = 1u << list_of_leaf[t];
+    }
+    if (h.group_op[g] == 1) T.req[T.n_req++] = any;
+  }
+  T.X = tree_prox(&h, max_slop, in_order);
+  // (combine_and: the filter runs when a window is asked for, the root has more than one child and some list stores offsets)
+  T.prox_filter = ((max_slop >= 0 || in_order) && h.n_groups > 1 && h.with_offsets) ? 1 : 0;
+  T.knn_pipeline = scan_tuning().hybrid_knn_pipeline;
+  T.top_n = top_n;
+  if (want_score) {
+    bool max_norm = false;
+    fill_score_params(T.P, &h, a->table, a->score, &max_norm);
+    // (hit_slops: the per-hit slop exists when some list stores offsets and the root has two children or more)
+    T.prox_slop = (slop_dependent(T.P.scorer) && h.with_offsets && h.n_groups >= 2) ? 1 : 0;
+    T.doc_len = a->table->doc_len.p;
+    T.doc_score = a->table->doc_score.p;
+    T.max_freq = a->table->max_freq.p;
+    T.table_n = a->table->n;
+    T.len_score = scan_tuning().hybrid_packed_docs ? reinterpret_cast<const uint2 *>(a->table->len_score.p) : nullptr;
+  }
+  T.k = k;
+  if (want_knn) {
+    T.rows = f->device_rows();
+    T.stride16 = T.chunks = (uint32_t)(f->stride() / 16);
+    T.query = ca->d_query;
+    T.ids_base = h.base;
+    T.knn_base = knn_base;
+    T.n_rows = f->committed_rows();
+  }
+  HybridReduceArgs R;
+  hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
+  sc.hyb_trace_tiles = 0;
+  T.tile_hits = sc.hyb_hits.p;
+  T.part_skey = sc.hyb_skey.p;
+  T.part_sidx = sc.hyb_sidx.p;
+  T.part_knn = sc.hyb_knn.p;
+  const uint32_t stride = n_tiles * 1024u;
+  if (hits_out) {
+    sc.hyb_hit_ids.ensure(stride);
+    sc.hyb_hit_freqs.ensure((size_t)stride * n);
+    if (h.with_offsets) sc.hyb_hit_epos.ensure((size_t)stride * n);
+    T.hit_ids = sc.hyb_hit_ids.p;
+    T.hit_freqs = sc.hyb_hit_freqs.p;
+    T.hit_epos = h.with_offsets ? sc.hyb_hit_epos.p : nullptr;
+    T.hit_stride = stride;
+    h.cap = std::max<uint32_t>(n0, 1);
+    h.ids.alloc(h.cap);
+    h.freqs.alloc((size_t)h.cap * n);
+    if (h.with_offsets) h.epos.alloc((size_t)h.cap * n);
+  }
+  ca->h_fcnt[0] = 0;
+
+  if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
+  if (n_tiles) {
+    launch_hybrid_tree_tiles(T, f ? f->ktype : 0, f ? f->kmetric : 0, n_tiles, ca->stream);
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
+    launch_hybrid_reduce(R, ca->stream);
+    if (hits_out)
+      launch_hybrid_hits_pack(sc.hyb_hits.p, n_tiles, n, T.hit_ids, T.hit_freqs, T.hit_epos, stride, h.ids.p, h.freqs.p,
+                              h.with_offsets ? h.epos.p : nullptr, h.cap, ca->h_fcnt, ca->stream);
+    HIP_CHECK(hipGetLastError());
+    if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
+    hyb_wait(ca, !prof, hits_out != nullptr);
+  }
+  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k)) return false;
+  if (hits_out) {
+    h.len = n_tiles ? ca->h_fcnt[0] : 0;
+    if (h.len != a->n_hits) throw std::runtime_error("RSGPU_HybridQuery: the packed hit list and the hit count disagree");
+    *hits_out = hp.release();
+  }
+  hyb_profile(prof, ev, n_tiles);
   return true;
 }
 
@@ -1654,19 +1910,25 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   h->n_lists = (int)a->n_lists;
 
   // Two launches instead of ten (hybrid_kernels.hip) when nobody asked for the hit list and the query has the plain shape:
-  // a flat AND of a few term lists, a scorer that needs neither the term offsets nor the maximum over all hits, small N / k
-  bool tiles = scan_tuning().hybrid_tiles && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && (want_score || want_knn);
-  if (tiles && want_score) {
-    bool any_offsets = false;
-    for (size_t l = 0; l < a->n_lists; l++) any_offsets |= a->lists[l]->has_offsets();
-    tiles = a->score->scorer != RSGPU_SCORER_BM25STD_NORM && !(slop_dependent(a->score->scorer) && any_offsets);
-  }
+  // a flat AND of a few term lists, a scorer that needs neither the term offsets nor the maximum over all hits, small N / k.
+  // The general form of the tile kernel (round 4) takes what that leaves -- the hit list wanted (a third launch packs it),
+  // five to eight lists, scorers that divide by the slop over lists with offsets -- except BM25STD.NORM.
+  const bool tile_knob = scan_tuning().hybrid_tiles && (want_score || want_knn);
+  const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
+  bool slop_offsets = false;
+  if (want_score && slop_dependent(a->score->scorer))
+    for (size_t l = 0; l < a->n_lists; l++) slop_offsets |= a->lists[l]->has_offsets();
+  bool tiles = tile_knob && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && !norm && !slop_offsets;
+  bool general = tile_knob && !tiles && scan_tuning().hybrid_tree_tiles && a->n_lists <= (size_t)kHybTreeMaxLists && !norm;
   uint32_t n0_min = 0xFFFFFFFFu;
   for (size_t l = 0; l < a->n_lists; l++) n0_min = std::min<uint32_t>(n0_min, a->lists[l]->n_entries);
-  if (tiles)
-    tiles = n0_min > 0 && hybrid_tile_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u,
-                                                hybrid_tiles(n0_min), want_score ? (uint32_t)a->top_n : 0u,
-                                                want_knn ? (uint32_t)a->k : 0u);
+  if (tiles || general) {
+    const bool ok = n0_min > 0 && hybrid_tile_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u,
+                                                        hybrid_tiles(n0_min), want_score ? (uint32_t)a->top_n : 0u,
+                                                        want_knn ? (uint32_t)a->k : 0u);
+    tiles = tiles && ok;
+    general = general && ok;
+  }
   tls_hybrid_path = 0;
 
   // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
@@ -1676,8 +1938,8 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   if (f) {
     index_lock = std::shared_lock<std::shared_mutex>(f->mu);
     knn_identity = f->identity_labels(&knn_base);
-    if (!knn_identity) tiles = false;  // a general label map lives on the host
-    if (knn_identity) f->upload_query(tiles ? ca.c : cb.c, a->query, true);
+    if (!knn_identity) tiles = general = false;  // a general label map lives on the host
+    if (knn_identity) f->upload_query((tiles || general) ? ca.c : cb.c, a->query, true);
   }
   if (tiles) {
     if (hybrid_two_launches(a, f, knn_base, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
@@ -1686,6 +1948,15 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     }
     a->n_hits = a->n_top = a->n_knn = 0;
     if (f) f->upload_query(cb.c, a->query, true);  // (the KNN branch of the staged pipeline reads it on its own stream)
+  }
+  if (general) {
+    if (hybrid_general(a, a->lists, hyb_groups_flat(a->lists, a->n_lists), -1, 0, a->hits_out, f, knn_base, want_score, want_knn,
+                       ca.c, cb.c, sc, prof, ev)) {
+      tls_hybrid_path = 2;
+      return 0;
+    }
+    a->n_hits = a->n_top = a->n_knn = 0;
+    if (f) f->upload_query(cb.c, a->query, true);
   }
 
   // ---- intersect (stream A) ----
@@ -1893,6 +2164,84 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     if (want_knn && len && !knn_on_host_map && hipEventSynchronize(ev.e[5]) == hipSuccess &&
         hipEventElapsedTime(&ms, ev.e[4], ev.e[5]) == hipSuccess)
       prof_ms[4] = ms;
+  }
+  if (a->hits_out) *a->hits_out = h.release();
+  return 0;
+  S_CATCH(-1)
+}
+
+/* RSGPU_HybridQuery over a two-level query tree (include/rsgpu_search.h): the general tile kernel when the root is an
+ * intersection of at most eight lists with a term to drive it, else stage by stage -- RSGPU_EvalTree, then the entry points a
+ * caller would use on its hit list.  Same answers. */
+extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQueryArgs *a) {
+  if (!q || !a || !q->lists || !q->n_groups || !q->group_first) {
+    last_error() = "RSGPU_HybridTreeQuery: empty tree";
+    return -1;
+  }
+  S_TRY
+  const size_t n_lists = q->group_first[q->n_groups];
+  if (q->n_groups > (size_t)kMaxLists || n_lists > (size_t)kMaxLists || !n_lists)
+    throw std::runtime_error("RSGPU_HybridTreeQuery: at most 32 groups and 32 terms");
+  if (q->root_op != RSGPU_OP_INTERSECT && q->root_op != RSGPU_OP_UNION) throw std::runtime_error("RSGPU_HybridTreeQuery: bad root_op");
+  check_lists("RSGPU_HybridTreeQuery", q->lists, n_lists);
+  const bool want_score = a->table && a->score && a->top_n;
+  const bool want_knn = a->index && a->query && a->k;
+  const int device = q->lists[0]->device;
+  FlatIndex *f = want_knn ? a->index->flat : nullptr;
+  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridTreeQuery: postings and index live on different devices");
+  if (want_score && a->table->device != device)
+    throw std::runtime_error("RSGPU_HybridTreeQuery: postings and document table live on different devices");
+  a->n_hits = a->n_top = a->n_knn = 0;
+  if (a->hits_out) *a->hits_out = nullptr;
+  tls_hybrid_path = 0;
+  HIP_CHECK(hipSetDevice(device));
+
+  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) &&
+                 q->root_op == RSGPU_OP_INTERSECT && n_lists <= (size_t)kHybTreeMaxLists &&
+                 !(want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM) && (!want_knn || (f && f->key_bytes == 4));
+  for (size_t l = 0; l < n_lists && general; l++) general = q->lists[l]->n_entries > 0;
+  if (general) {
+    const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists);
+    uint32_t n0 = 0;
+    general = hyb_driver(groups, q->lists, &n0) >= 0 &&
+              hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, hybrid_tiles(n0),
+                                    want_score ? (uint32_t)a->top_n : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
+    if (general) {
+      if (f) f->flush_if_needed();
+      CtxLease ca(device), cb(device);
+      Scratch &sc = scratch(device);
+      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+      FusedEvents &ev = tls_events;
+      if (prof) ev.ensure(device);
+      uint64_t knn_base = 0;
+      std::shared_lock<std::shared_mutex> index_lock;
+      if (f) {
+        index_lock = std::shared_lock<std::shared_mutex>(f->mu);
+        general = f->identity_labels(&knn_base);  // (a general label map lives on the host)
+        if (general) f->upload_query(ca.c, a->query, true);
+      }
+      if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, knn_base, want_score, want_knn, ca.c,
+                                    cb.c, sc, prof, ev)) {
+        tls_hybrid_path = 2;
+        return 0;
+      }
+      a->n_hits = a->n_top = a->n_knn = 0;
+    }
+  }
+  // stage by stage (the index lock is released: the entry points below take it themselves)
+  std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
+  if (!h) return -1;
+  a->n_hits = h->len;
+  if (want_score) {
+    if (RSGPU_Hits_Score(h.get(), a->table, a->score, nullptr) != 0) return -1;
+    const long nt = RSGPU_Hits_TopN(h.get(), a->top_n, a->top_ids, a->top_scores);
+    if (nt < 0) return -1;
+    a->n_top = (size_t)nt;
+  }
+  if (want_knn) {
+    const long nk = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
+    if (nk < 0) return -1;
+    a->n_knn = (size_t)nk;
   }
   if (a->hits_out) *a->hits_out = h.release();
   return 0;

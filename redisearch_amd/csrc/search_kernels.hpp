@@ -268,6 +268,79 @@ bool hybrid_tile_supported(int type, int metric, uint32_t stride16, uint32_t n_t
 void launch_hybrid_tiles(const HybridTileArgs &a, int type, int metric, uint32_t n_tiles, hipStream_t s);
 void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s);
 
+// ---- the general form of the tile kernel (round 4, hybrid_kernels.hip: hybrid_tree_tile_kernel) ---------------------------
+// A root INTERSECTION whose children are terms, unions of terms or intersections of terms (a two-level RSGPU_TreeQuery), with
+// max_slop / in_order, per-hit slop for the scorers that divide by it, and -- when the caller wants it -- the ordered hit list
+// itself: everything RSGPU_HybridQuery's two-launch form (above) leaves to the staged pipeline except BM25STD.NORM.
+//   * up to kHybTreeMaxLists posting lists; list 0 -- a term leaf of the tree, the shortest one -- drives, every other list is
+//     probed through its window as above; a driver is a candidate when every REQUIRED set of lists (req[r]: a term, each
+//     term of a child intersection, any term of a child union) holds it;
+//   * candidates are compacted in DRIVER ORDER (= doc-id order) with their entry index in every leaf's list (0xFFFFFFFF: a
+//     union leaf that does not hold the document); max_slop / in_order filters them where they sit compacted
+//     (prox_within_range, the code of prox_filter_kernel), a second ordered compaction follows;
+//   * per hit: frequencies gathered per LEAF (0 where absent), the slop from the term offsets (prox_min_offset_delta) when
+//     the scorer wants it, the score through the two-level fold of score_one (the result's child order: ScoreParams groups);
+//   * hit list wanted: doc id | per-leaf frequency | per-leaf entry index at the tile's FIXED slots (tile * 1024 + rank),
+//     hybrid_hits_pack_kernel -- a third launch, behind the reduce kernel: the answers do not wait for it -- moves them to
+//     their place in the list (exclusive sum of the tiles' hit counts).
+constexpr int kHybTreeMaxLists = 8;
+struct HybridOffsetView {  // OffsetView over the tree's leaves
+  const uint8_t *bytes[kHybTreeMaxLists];
+  const uint32_t *off_pos[kHybTreeMaxLists];
+  const uint32_t *off_len[kHybTreeMaxLists];
+};
+struct HybridTreeArgs {
+  int n;                                       // lists = leaves of the result tree
+  const uint32_t *ids[kHybTreeMaxLists];       // by LIST (probe order: list 0 drives)
+  uint32_t len[kHybTreeMaxLists];
+  long long add[kHybTreeMaxLists];
+  const uint32_t *dir[kHybTreeMaxLists];       // bucket directories (NULL: wave-wide searches)
+  uint32_t dir_shift[kHybTreeMaxLists], dir_n[kHybTreeMaxLists];
+  uint8_t leaf_of[kHybTreeMaxLists];           // list l -> its leaf column in the result tree
+  int n_req;
+  uint32_t req[kHybTreeMaxLists];              // bit l: list l; a candidate matches a list of EVERY set
+  const uint32_t *lfreq[kHybTreeMaxLists];     // by LEAF: decoded frequencies (NULL: the codec stores none -- 1)
+  // proximity (by leaf): X.max_slop / X.in_order for the filter, the children for both
+  int prox_filter, prox_slop;
+  ProxParams X;
+  HybridOffsetView O;
+  // scoring: the two-level result tree in P (groups over the leaf columns); P.slops must be NULL
+  uint32_t top_n;
+  ScoreParams P;
+  const uint32_t *doc_len;
+  const float *doc_score;
+  const uint32_t *max_freq;
+  uint32_t table_n;
+  const uint2 *len_score;
+  // KNN (as HybridTileArgs)
+  uint32_t k;
+  const void *rows;
+  uint32_t stride16, chunks;
+  int G, ITERS;
+  const void *query;
+  uint64_t ids_base, knn_base;
+  uint32_t n_rows;
+  int knn_pipeline;
+  // per tile, fixed slots (as HybridTileArgs)
+  uint32_t *tile_hits;
+  uint64_t *part_skey;
+  uint32_t *part_sidx;
+  uint64_t *part_knn;
+  // the hit list at the tiles' fixed slots (NULL: not wanted)
+  uint32_t *hit_ids;                           // [n_tiles * 1024]
+  uint32_t *hit_freqs;                         // [n][hit_stride]
+  uint32_t *hit_epos;                          // [n][hit_stride], NULL: no list stores offsets
+  uint32_t hit_stride;
+  uint32_t pool_words;                         // set by the launcher
+};
+bool hybrid_tree_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k, int n_lists);
+void launch_hybrid_tree_tiles(const HybridTreeArgs &a, int type, int metric, uint32_t n_tiles, hipStream_t s);
+// dst[off(t) + r] = src[t * 1024 + r], r < tile_hits[t], off(t) = sum of tile_hits below t; ids, then n leaf columns of freqs
+// (src stride src_stride, dst stride dst_cap) and -- unless NULL -- of entry indices; *total_out (device or pinned) = the sum
+void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
+                             const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,
+                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s);
+
 // ---- FT.HYBRID fusion (fusion_kernels.hip) -------------------------------------------------------------
 constexpr uint32_t kFuseMaxWindow = 4096;  // per upstream: (2 * 4096) * 17 bytes of LDS
 struct FuseParams {

@@ -44,6 +44,7 @@ ABI = {
     "RSGPU_EvalTreeNodes": (_vp, [C.POINTER(TreeNode), _sz, _vp, _sz]),
     "RSGPU_Hits_TreeNodes": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
+    "RSGPU_HybridTreeQuery": (_i, [C.POINTER(TreeQuery), C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridQueryPath": (_i, []),
     "RSGPU_HybridTrace": (C.c_long, [_vp, _sz]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
@@ -270,13 +271,17 @@ class HybridQuery:
     run() is the bare C call (what a C caller pays); results() reads the outputs of the last run."""
 
     def __init__(self, lists, table=None, scorer=None, idf=None, bm25_idf=None, weight=None, num_docs=0, avg_doc_len=1.0,
-                 top_n=0, index=None, q=None, k=0, root_weight=1.0, min_score=0.0, tanh_factor=4):
+                 top_n=0, index=None, q=None, k=0, root_weight=1.0, min_score=0.0, tanh_factor=4, want_hits=False):
         self.lib = load()
         self._fn = self.lib.RSGPU_HybridQuery
         self._arr = (_vp * len(lists))(*[l.ptr for l in lists])
         a = self.args = HybridQueryArgs()
         a.lists, a.n_lists = C.cast(self._arr, _vp), len(lists)
         self._keep = [lists, table, index]
+        self._lists = list(lists)
+        self._hits_ptr = _vp() if want_hits else None
+        if want_hits:
+            a.hits_out = C.cast(C.pointer(self._hits_ptr), _vp)
         if table is not None and scorer is not None and top_n:
             idf_, bidf_, w_ = (np.ascontiguousarray(x, np.float64) for x in (idf, bm25_idf, weight))
             sa = ScoreArgs(SCORERS[scorer] if scorer in SCORERS else PIPELINE_SCORERS[scorer], num_docs, avg_doc_len, tanh_factor,
@@ -293,8 +298,14 @@ class HybridQuery:
             a.index, a.query, a.k = index.ptr, _p(qb).value, k
         self._ref = C.byref(a)
 
+    def _call(self):
+        return self._fn(self._ref)
+
     def run(self):
-        if self._fn(self._ref) != 0:
+        if self._hits_ptr is not None and self._hits_ptr.value:      # the previous run's hit list
+            self.lib.RSGPU_Hits_Free(self._hits_ptr)
+            self._hits_ptr.value = None
+        if self._call() != 0:
             raise RuntimeError(V.last_error())
 
     def results(self):
@@ -302,9 +313,23 @@ class HybridQuery:
         return dict(n_hits=a.n_hits, top=(self.ti[:a.n_top].copy(), self.ts[:a.n_top].copy()),
                     knn=(self.ki[:a.n_knn].copy(), self.kd[:a.n_knn].copy()))
 
+    def take_hits(self):
+        """the hit list of the last run (want_hits=True) as a Hits object that owns it"""
+        h = Hits.__new__(Hits)
+        h.lib, h._lists, h.n_lists = self.lib, self._lists, len(self._lists)
+        h.ptr = _check(self._hits_ptr.value, "hits_out")
+        self._hits_ptr.value = None
+        return h
+
+    def __del__(self):
+        if getattr(self, "_hits_ptr", None) is not None and self._hits_ptr.value:
+            self.lib.RSGPU_Hits_Free(self._hits_ptr)
+            self._hits_ptr.value = None
+
 
 def hybrid_path():
-    """how this thread's last RSGPU_HybridQuery ran: 0 staged pipeline, 1 two launches (hybrid_kernels.hip)"""
+    """how this thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 staged pipeline, 1 two launches, 2 the general
+    tile kernel (hybrid_kernels.hip)"""
     return load().RSGPU_HybridQueryPath()
 
 
@@ -324,6 +349,27 @@ def hybrid_query(lists, table=None, scorer=None, idf=None, bm25_idf=None, weight
                      min_score, tanh_factor)
     hq.run()
     return hq.results()
+
+
+class HybridTreeQuery(HybridQuery):
+    """RSGPU_HybridTreeQuery: HybridQuery over a two-level tree -- groups as TreeHits takes them; idf / bm25_idf / weight per
+    list in the flattened order of `groups`."""
+
+    def __init__(self, root_op, groups, max_slop=None, in_order=False, **kw):
+        flat, first, ops, ws = [], [0], [], []
+        for op, w, ls in groups:
+            flat += list(ls)
+            first.append(len(flat))
+            ops.append(op)
+            ws.append(w)
+        HybridQuery.__init__(self, flat, **kw)
+        self._gf, self._go, self._gw = np.asarray(first, np.uint64), np.asarray(ops, np.int32), np.asarray(ws, np.float64)
+        self._tq = TreeQuery(root_op, len(groups), _p(self._gf).value, _p(self._go).value, _p(self._gw).value,
+                             C.cast(self._arr, _vp).value, -1 if max_slop is None else int(max_slop), int(in_order))
+        self._tfn = self.lib.RSGPU_HybridTreeQuery
+
+    def _call(self):
+        return self._tfn(C.byref(self._tq), self._ref)
 
 
 class TreeHits(Hits):

@@ -32,7 +32,9 @@ def kernels():
 
 
 def test_no_spills_on_any_default_path(kernels):
-    spilling = [k["name"] for k in kernels if k["vgpr_spill"] or k["sgpr_spill"]]
+    # (the general hybrid tile kernel parks a dozen and a half scalars -- kernel-argument pointers of its eight lists -- in
+    # the lanes of a vector register: v_writelane / v_readlane outside its loops, no memory traffic; VECTOR spills it has none)
+    spilling = [k["name"] for k in kernels if k["vgpr_spill"] or (k["sgpr_spill"] and not k["name"].startswith("hybrid_tree_tile_kernel<"))]
     # gemm_dma = 2 (24 KiB stages, two workgroups per CU) in filter mode: an A/B knob, never the default (kernels.hpp)
     assert all(re.match(r"gemm_topk_ring_kernel<\d+, 4, 3, 4, 1>", n) for n in spilling), spilling
 
@@ -42,7 +44,8 @@ def test_scratch_only_for_the_proximity_cursors(kernels):
     # flat / two-level scorer score_kernel<false> must stay scratch-free)
     scratch = {re.sub(r"<.*", "", k["name"]) if not k["name"].startswith("score_kernel") else k["name"]
                for k in kernels if k["scratch"] and not k["vgpr_spill"]}
-    assert scratch <= {"prox_filter_kernel", "prox_slop_kernel", "score_kernel<true>"}, scratch
+    # (... and the general hybrid tile kernel, which runs the proximity functions on its compacted candidates)
+    assert scratch <= {"prox_filter_kernel", "prox_slop_kernel", "score_kernel<true>", "hybrid_tree_tile_kernel"}, scratch
 
 
 def test_lds_fits_the_cu(kernels):
@@ -117,3 +120,16 @@ def test_hybrid_two_launch_kernels_budget(kernels):
     red = [k for k in kernels if k["name"].startswith("hybrid_reduce_kernel")]
     assert len(red) == 1
     assert red[0]["vgpr"] <= 128 and not red[0]["scratch"] and red[0]["lds"] <= 40960 and red[0]["wg"] == 1024, red[0]
+
+
+def test_general_hybrid_tile_kernel_budget(kernels):
+    """hybrid_tree_tile_kernel (round 4): up to eight lists' match positions per driver live in registers through the probe --
+    at most 128 registers (four waves per SIMD; the LDS pool of (lists + 1) KiB-words bounds residency before that), scratch only
+    for the proximity cursors (ProxCtx<8>: 240 bytes per lane, touched by the lanes that hold a candidate when a window or a
+    slop-dependent scorer asks for the term offsets), no vector spills.  The pack kernel is a copy."""
+    tiles = [k for k in kernels if k["name"].startswith("hybrid_tree_tile_kernel<")]
+    assert len(tiles) == 6
+    for k in tiles:
+        assert k["vgpr"] <= 128 and not k["vgpr_spill"] and k["scratch"] <= 512 and k["lds"] <= 4096 and k["wg"] == 256, k
+    pack = [k for k in kernels if k["name"].startswith("hybrid_hits_pack_kernel")]
+    assert len(pack) == 1 and pack[0]["vgpr"] <= 32 and not pack[0]["scratch"], pack
