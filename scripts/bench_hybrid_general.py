@@ -1,0 +1,45 @@
+"""configs[4]'s setup of bench.py once, then (a) the distinct-query stream on the shipped configuration (the two-launch tile
+kernel after round 4's refactor of its KNN phase into a shared device function) and (b) the shapes the general tile kernel
+took over from the staged pipeline, general vs staged in the same process (bench.py _hybrid_general_shapes)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.argv = [sys.argv[0]]
+import bench as B  # noqa: E402
+from redisearch_amd import search as S  # noqa: E402
+from redisearch_amd import vecsim as V  # noqa: E402
+
+torch.cuda.set_device(0)
+lib = V.load()
+n_docs, n_vec, dim, n_a, n_b = 50_000_000, 5_000_000, 768, 4, 4
+rng = np.random.default_rng(149)
+doc_len = (50 + rng.poisson(150, n_docs + 1)).astype(np.uint32)
+doc_score = np.ones(n_docs + 1, np.float32)
+avg = float(doc_len[1:].mean())
+table = S.DocTable(doc_len, doc_score)
+idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_L2)
+idx.reserve(n_vec)
+idx.add_philox_rows(B.SEED, 0, n_vec, 1)
+raws = [B._term_list(rng, n_docs, n_docs * 0.2 / r) for r in [2] * n_a + [4] * n_b]
+enc_fo = [B.encode_freqs_only(d, f) for d, f, _, _ in raws]
+enc_full = [B.encode_full(d, f, m, o) for d, f, m, o in raws]
+qvecs = B.philox_host_rows(V, B.QUERY_BASE + 100, n_a * n_b, dim)
+out = {}
+if os.environ.get("SKIP_STREAM") != "1":
+    rec, ans, pairs = B._hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 3)))
+    out["stream_freqs_only"] = {"warm_p50": rec["warm"]["wall_ms_p50"], "warm_dev": rec["warm"]["device_ms"],
+                                "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"), "cold_p50": rec["cold"]["wall_ms_p50"],
+                                "cold_dev": rec["cold"]["device_ms"]}
+    print("stream", json.dumps(out["stream_freqs_only"]), flush=True)
+g = B._hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_docs, avg, n_a)
+out["general_tile_kernel_shapes"] = g
+for k, v in g.items():
+    print(k, json.dumps(v), flush=True)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/r04_hybrid_general_shapes.json", "w"), indent=1)
