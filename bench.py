@@ -711,8 +711,8 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
             dec = float(np.mean([x.get("decode_ms") or 0.0 for x in prof]))
             rec = {"wall_ms_p50": float(np.percentile(walls, 50)), "wall_ms_p95": float(np.percentile(walls, 95)), "wall_ms_min": min(walls),
                    "queries_timed": len(walls), "qps": 1e3 / float(np.percentile(walls, 50)),
-                   "path": "two_launches" if path == 1 else "staged",
-                   "device_ms": {"tile_kernel": tile, "reduce_kernel": red, "decode": dec} if path == 1 else
+                   "path": "two_launches" if path == 1 else ("general_tile_kernel" if path == 2 else "staged"),
+                   "device_ms": {"tile_kernel": tile, "reduce_kernel": red, "decode": dec} if path in (1, 2) else
                                 {k_: float(np.mean([x.get(k_) or 0.0 for x in prof])) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
                    "same_answers_every_cycle": bool(same)}
             if mode == "warm":
@@ -731,7 +731,7 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                 alg = postings * 4 + float(hits.mean()) * 12 + cand * dim * 4
                 rec.update({"hits_mean": float(hits.mean()), "candidates_with_vector_mean_of_4_pairs": cand,
                             "tile_kernel_algorithmic_bytes": alg})
-                if path == 1 and tile > 0:
+                if path in (1, 2) and tile > 0:
                     rec["tile_kernel_gbs"] = alg / tile / 1e6
                     rec["tile_kernel_hbm_frac"] = alg / tile / 1e6 / HBM_PEAK_GBS
                     rec["tile_plus_reduce_hbm_frac"] = alg / (tile + red) / 1e6 / HBM_PEAK_GBS

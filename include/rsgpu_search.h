@@ -231,6 +231,9 @@ typedef struct {
   int in_order;
 } RSGPU_TreeQuery;
 RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q);
+/* (round 4: a root intersection with an aggregate child over at most eight lists, one of them a term every hit must hold, is
+ * evaluated by the general hybrid tile kernel -- every list probed in place, no child hit list built first; the calling
+ * thread's RSGPU_HybridQueryPath reads 2 after such a call, 0 after a stage-by-stage one.  Same hit list either way.) */
 /* RSGPU_HybridQuery over such a tree -- the filter the reference hands its hybrid iterator as `childIt`
  * (src/iterators/hybrid_reader.c:625 NewHybridVectorIterator; intersections with max_slop / in_order:
  * rqe_iterators/src/intersection.rs:94-119) -- in one call: args->lists / n_lists are ignored (tree->lists are the terms;

@@ -828,6 +828,9 @@ RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists) {
   S_CATCH(nullptr)
 }
 
+// RSGPU_EvalTree through the general hybrid tile kernel (defined next to it, below): NULL = not such a tree, stage by stage
+static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists);
+
 /* Two-level query tree: root (AND / OR) over groups, each a term or an OR / AND of terms -- e.g. the stemmer's
  * (run|running|ran) (shoe|shoes), or (a b) | (c d).  Nested groups are evaluated first (their hit lists stay alive
  * inside the result), the root then combines the groups' id lists and carries every term's frequency and entry index
@@ -845,6 +848,9 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
   check_lists("RSGPU_EvalTree", q->lists, n_lists);
   const int device = q->lists[0]->device;
   HIP_CHECK(hipSetDevice(device));
+  // A root intersection with an aggregate child (a (b|c), (a b) c ...) over at most eight lists: the general hybrid tile kernel
+  // probes every list in place and writes the hit list (round 4) -- no child is materialised first.  Same hit list.
+  if (RSGPU_Hits *fast = eval_tree_tiles(q, n_lists)) return fast;
   CtxLease c(device);
   Scratch &sc = scratch(device);
   auto *h = new RSGPU_Hits();
@@ -1670,16 +1676,16 @@ static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_
   return g;
 }
 // a two-level tree under a root intersection: the children and their leaves in the order RSGPU_EvalTree evaluates them
-static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_lists) {
+static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_lists, const char *who = "RSGPU_HybridTreeQuery") {
   std::vector<HybGroup> groups;
   for (size_t g = 0; g < q->n_groups; g++) {
     const size_t a = q->group_first[g], b = q->group_first[g + 1];
-    if (b <= a || b > n_lists) throw std::runtime_error("RSGPU_HybridTreeQuery: bad group_first");
+    if (b <= a || b > n_lists) throw std::runtime_error(std::string(who) + ": bad group_first");
     const int op = q->group_op ? q->group_op[g] : RSGPU_OP_TERM;
     HybGroup t;
     t.weight = q->group_weight ? q->group_weight[g] : 1.0;
     if (op == RSGPU_OP_TERM) {
-      if (b - a != 1) throw std::runtime_error("RSGPU_HybridTreeQuery: a term group holds exactly one list");
+      if (b - a != 1) throw std::runtime_error(std::string(who) + ": a term group holds exactly one list");
       t.lists.push_back((int)a);
       t.estimate = q->lists[a]->n_entries;
       t.weight = 1.0;  // (a term's own weight stays in RSGPU_ScoreArgs.weight)
@@ -1693,7 +1699,7 @@ static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_
         for (int li : t.lists) t.estimate += q->lists[li]->n_entries;  // ... of a union: the sum
       }
     } else {
-      throw std::runtime_error("RSGPU_HybridTreeQuery: bad group_op");
+      throw std::runtime_error(std::string(who) + ": bad group_op");
     }
     groups.push_back(t);
   }
@@ -1882,6 +1888,31 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   return true;
 }
 
+static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists) {
+  tls_hybrid_path = 0;
+  if (!scan_tuning().hybrid_tiles || !scan_tuning().hybrid_tree_tiles || q->root_op != RSGPU_OP_INTERSECT ||
+      n_lists > (size_t)kHybTreeMaxLists || !q->group_op)
+    return nullptr;
+  bool aggregate = false;
+  for (size_t g = 0; g < q->n_groups; g++) aggregate |= q->group_op[g] != RSGPU_OP_TERM;
+  if (!aggregate) return nullptr;  // (a flat AND: the staged intersection is three launches as well)
+  for (size_t l = 0; l < n_lists; l++)
+    if (!q->lists[l]->n_entries) return nullptr;
+  const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists, "RSGPU_EvalTree");
+  uint32_t n0 = 0;
+  if (hyb_driver(groups, q->lists, &n0) < 0 || !hybrid_tree_supported(0, 0, 1u, hybrid_tiles(n0), 0u, 0u, (int)n_lists)) return nullptr;
+  const int device = q->lists[0]->device;
+  CtxLease ca(device), cb(device);
+  RSGPU_HybridQueryArgs none;
+  memset(&none, 0, sizeof none);
+  RSGPU_Hits *out = nullptr;
+  if (!hybrid_general(&none, q->lists, groups, q->max_slop, q->in_order, &out, nullptr, 0, false, false, ca.c, cb.c, scratch(device), false,
+                      tls_events))
+    return nullptr;
+  tls_hybrid_path = 2;
+  return out;
+}
+
 extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   if (!a || !a->lists || !a->n_lists || a->n_lists > (size_t)kMaxLists) {
     last_error() = "RSGPU_HybridQuery: 1..32 lists";
@@ -1918,7 +1949,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   bool slop_offsets = false;
   if (want_score && slop_dependent(a->score->scorer))
     for (size_t l = 0; l < a->n_lists; l++) slop_offsets |= a->lists[l]->has_offsets();
-  bool tiles = tile_knob && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && !norm && !slop_offsets;
+  bool tiles = tile_knob && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && !norm && !slop_offsets && !scan_tuning().hybrid_force_general;
   bool general = tile_knob && !tiles && scan_tuning().hybrid_tree_tiles && a->n_lists <= (size_t)kHybTreeMaxLists && !norm;
   uint32_t n0_min = 0xFFFFFFFFu;
   for (size_t l = 0; l < a->n_lists; l++) n0_min = std::min<uint32_t>(n0_min, a->lists[l]->n_entries);
@@ -2230,6 +2261,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   }
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
+  tls_hybrid_path = 0;  // (RSGPU_EvalTree may have built the list with the tile kernel; this QUERY ran stage by stage)
   if (!h) return -1;
   a->n_hits = h->len;
   if (want_score) {

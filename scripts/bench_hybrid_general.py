@@ -37,6 +37,15 @@ if os.environ.get("SKIP_STREAM") != "1":
                                 "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"), "cold_p50": rec["cold"]["wall_ms_p50"],
                                 "cold_dev": rec["cold"]["device_ms"]}
     print("stream", json.dumps(out["stream_freqs_only"]), flush=True)
+    lib.RSGPU_SetTuning(b"hybrid_force_general", 1)   # the same stream through the general kernel: what its generality costs
+    rec, ans2, _ = B._hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 3)))
+    lib.RSGPU_SetTuning(b"hybrid_force_general", 0)
+    out["stream_freqs_only_general_kernel_forced"] = {"path": rec["warm"]["path"], "warm_p50": rec["warm"]["wall_ms_p50"], "warm_dev": rec["warm"]["device_ms"],
+                                                      "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"),
+                                                      "same_answers": all(x["top"][0].tolist() == y["top"][0].tolist() and x["top"][1].tolist() == y["top"][1].tolist()
+                                                                          and x["knn"][0].tolist() == y["knn"][0].tolist() and x["n_hits"] == y["n_hits"]
+                                                                          for x, y in zip(ans, ans2))}
+    print("stream, general kernel forced", json.dumps(out["stream_freqs_only_general_kernel_forced"]), flush=True)
 g = B._hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_docs, avg, n_a)
 out["general_tile_kernel_shapes"] = g
 for k, v in g.items():

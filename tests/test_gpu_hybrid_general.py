@@ -338,3 +338,39 @@ def test_tree_query_shapes_the_general_kernel_declines():
         h.score(table, scorer, idf[:nl], bidf[:nl], w[:nl], 2500, 150.0, want_scores=False)
         ti, ts = h.topn(10)
         assert r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
+
+
+# ---- RSGPU_EvalTree through the tile kernel -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("with_offsets,max_slop,in_order", [(False, None, False), (True, None, False), (True, 3, False), (True, None, True)])
+@pytest.mark.parametrize("name,shape", SHAPES)
+def test_eval_tree_builds_the_same_hit_list_with_the_tile_kernel(name, shape, with_offsets, max_slop, in_order):
+    """RSGPU_EvalTree (and with it the iterator seam's tree iterators) over a root intersection with an aggregate child: the
+    tile kernel probes every list in place; the staged evaluation builds each child's hit list first.  Same doc ids, per-term
+    frequencies, term records, leaf order and -- scored stage by stage -- the same doubles from every scorer."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + 3 * int(with_offsets) + (max_slop or 0) + 5 * int(in_order))
+    codec = O.C_FULL if with_offsets else O.C_FREQS_ONLY
+    n_lists = sum(len(gp[2]) for gp in shape)
+    built = [rand_list(rng, codec, int(rng.integers(900, 2200)), 2500, with_offsets) for _ in range(n_lists)]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    sizes = [x[0].unique_docs for x in built]
+    groups = [(op, w, [g[i] for i in idx]) for op, w, idx in shape]
+    try:
+        knob("hybrid_tree_tiles", 1)
+        ha = S.TreeHits(I, groups, max_slop=max_slop, in_order=in_order)
+        assert S.hybrid_path() == 2
+        knob("hybrid_tree_tiles", 0)
+        hb = S.TreeHits(I, groups, max_slop=max_slop, in_order=in_order)
+        assert S.hybrid_path() == 0
+    finally:
+        knob("hybrid_tree_tiles", 1)
+    ids, _ = same_hit_lists(ha, hb, n_lists, with_records=with_offsets)
+    ot = OracleTree(I, shape, [x[1] for x in built], sizes, max_slop, in_order)
+    assert ids.tolist() == ot.docs
+    table = table_for(rng, 2500)
+    idf = [S.calculate_idf(2500, s) for s in sizes]
+    bidf = [S.calculate_idf_bm25(2500, s) for s in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    for scorer in SCORERS + ["BM25STD.NORM"]:
+        sa = ha.score(table, scorer, idf, bidf, w, 2500, 150.0, root_weight=1.5)
+        sb = hb.score(table, scorer, idf, bidf, w, 2500, 150.0, root_weight=1.5)
+        assert np.array_equal(sa, sb), scorer
