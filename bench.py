@@ -666,7 +666,7 @@ def _term_list(rng, n_docs, df):
     return docs, freqs, masks, offs
 
 
-def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3):
+def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3, decoded_bpp=8):
     """A STREAM of distinct queries: n_a x n_b term pairs over independent lists and a query vector of its
     own per query, issued round-robin so that consecutive queries share neither a list nor candidate rows.  One cycle touches
     every list's decoded arrays (240 MB at 4 + 4 lists) and 16 x 77 MB of rows -- several times the 256 MiB Infinity Cache --
@@ -741,6 +741,12 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                 if dec > 0:
                     rec["decode_gbs_of_encoded_bytes"] = eb / dec / 1e6
                     rec["decode_hbm_frac_of_encoded_bytes"] = eb / dec / 1e6 / HBM_PEAK_GBS
+                    # what the decode kernel moves: the encoded bytes read + the decoded arrays written (decoded_bpp bytes per
+                    # posting: doc id + frequency; the Full codec also mask, offsets position, offsets length)
+                    wr = float(np.mean([raws[i][0].size + raws[j][0].size for i, j in pairs])) * decoded_bpp
+                    rec["decoded_bytes_written_per_query"] = wr
+                    rec["decode_gbs_read_plus_written"] = (eb + wr) / dec / 1e6
+                    rec["decode_hbm_frac_read_plus_written"] = (eb + wr) / dec / 1e6 / HBM_PEAK_GBS
                 if path == 1 and dec + tile > 0:
                     rec["decode_plus_intersect_gbs_of_encoded_bytes"] = eb / (dec + tile) / 1e6
                 rec["same_answers_as_warm"] = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["knn"][0].tolist() == b_["knn"][0].tolist()
@@ -853,7 +859,7 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
         gen_s = time.perf_counter() - t0
         qvecs = philox_host_rows(V, QUERY_BASE + 100, n_a * n_b, dim)
         fo, ans_fo, pairs = _hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a)
-        full, ans_full, _ = _hybrid_stream(lib, S, enc_full, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a)
+        full, ans_full, _ = _hybrid_stream(lib, S, enc_full, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, decoded_bpp=20)
         codec_same = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["top"][1].tolist() == b_["top"][1].tolist()
                          and a["knn"][0].tolist() == b_["knn"][0].tolist() and a["n_hits"] == b_["n_hits"] for a, b_ in zip(ans_fo, ans_full))
         rep, payload = _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_docs, n_vec, dim)

@@ -50,5 +50,25 @@ g = B._hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, 
 out["general_tile_kernel_shapes"] = g
 for k, v in g.items():
     print(k, json.dumps(v), flush=True)
+# RSGPU_EvalTree on its own -- what creating the iterator seam's tree iterator costs: a (b|c), the hit list built by the tile kernel
+# (tile + hit count + pack) against the staged evaluation (the union's own hit list first, then the intersection)
+import time  # noqa: E402
+fo = [S.Postings.from_flat(e) for e in enc_fo[:1] + enc_fo[n_a:n_a + 2]]
+groups = [(S.OP_TERM, 1.0, [fo[0]]), (S.OP_UNION, 1.0, [fo[1], fo[2]])]
+ev = {}
+for mode, knob in (("tile_kernel", 1), ("staged", 0)):
+    lib.RSGPU_SetTuning(b"hybrid_tree_tiles", knob)
+    S.TreeHits(S.OP_INTERSECT, groups).free()
+    t = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        h = S.TreeHits(S.OP_INTERSECT, groups)
+        t.append((time.perf_counter() - t0) * 1e3)
+        n = len(h)
+        h.free()
+    ev[mode] = {"ms_p50": float(np.percentile(t, 50)), "hits": n, "path": S.hybrid_path()}
+lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
+out["eval_tree_term_and_union_of_two"] = ev
+print("eval_tree", json.dumps(ev), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/r04_hybrid_general_shapes.json", "w"), indent=1)
