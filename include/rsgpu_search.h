@@ -240,6 +240,14 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q);
  * RSGPU_ScoreArgs.idf / bm25_idf / weight per LIST in their order), everything else as RSGPU_HybridQuery, hits_out included.
  * Results are those of RSGPU_EvalTree + RSGPU_Hits_Score / _TopN / _KnnRerank; RSGPU_HybridQueryPath tells how it ran. */
 int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *tree, RSGPU_HybridQueryArgs *args);
+/* For RSGPU_HybridTreeQuery only: a child of a root INTERSECTION that EXCLUDES documents -- `a -b`, `a (b|c) -(d|e)`: the group's
+ * lists are the excluded terms (a document that any of them holds is not a hit).  The reference's Not iterator yields a VIRTUAL
+ * result of frequency 0 (rqe_iterators/src/not.rs:106-118, index_result/src/core/mod.rs:103-112): it adds nothing to any scorer's
+ * sum and has no offsets, but it IS a child of the intersection's result -- IndexResult_MinOffsetDelta counts it (the offset-less
+ * slop is children - 1).  Its lists take no idf / weight (leave their RSGPU_ScoreArgs entries 0) and are not part of a hit list:
+ * hits_out must be NULL, and the query runs on the general tile kernel or not at all (more than eight lists, no term to drive, a
+ * general label map: -1 with a message; RSGPU_EvalTree rejects the operator). */
+#define RSGPU_OP_NOT 3
 
 /* Query trees of ANY depth: `nodes` in POST-ORDER -- a term names its list; an aggregate (RSGPU_OP_UNION /
  * RSGPU_OP_INTERSECT) takes the n_children complete subtrees immediately before it; the last node is the root (its weight

@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 #pragma unroll
     for (int r = 0; r < ML; r++)
       if (r < A.n_req) h = h && (mb[k] & A.req[r]) != 0u;
-    hit[k] = h;
+    hit[k] = h && (mb[k] & A.veto) == 0u;  // (NOT children: not.rs:171-209 -- the document must be absent from every excluded list)
   }
   uint32_t slot[DPT];
   const uint32_t nc = ordered_slots<DPT>(hit, slot, seg);
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
       win[(1u + A.leaf_of[0]) * TILE + s] = i_first + k * 256 + threadIdx.x;
 #pragma unroll
       for (int l = 1; l < ML; l++)
-        if (l < A.n) win[(1u + A.leaf_of[l]) * TILE + s] = ps[k][l - 1];
+        if (l < A.n && A.leaf_of[l] != 0xFFu) win[(1u + A.leaf_of[l]) * TILE + s] = ps[k][l - 1];
     }
   __syncthreads();
 
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
         ex_[j] = win[e];
 #pragma unroll
         for (int t = 0; t < ML; t++)
-          if (t < A.n) ee[j][t] = win[(1u + t) * TILE + e];
+          if (t < A.n_leaves) ee[j][t] = win[(1u + t) * TILE + e];
         ProxCtx<ML> x;
         prox_load<ML>(A.X, A.O, x, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
         keep[j] = prox_within_range<ML>(A.X, x);
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
         win[s] = ex_[j];
 #pragma unroll
         for (int t = 0; t < ML; t++)
-          if (t < A.n) win[(1u + t) * TILE + s] = ee[j][t];
+          if (t < A.n_leaves) win[(1u + t) * TILE + s] = ee[j][t];
       }
     __syncthreads();
   }
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
       }
 #pragma unroll
       for (int t = 0; t < ML; t++)
-        if (t < A.n) {
+        if (t < A.n_leaves) {
           const uint32_t ep = win[(1u + t) * TILE + e];
           const uint32_t *__restrict__ fq = A.lfreq[t];
           // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
@@ -1205,7 +1205,7 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, 
     a.G = 1;
     a.ITERS = 0;
   }
-  a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
+  a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n_leaves + 1) * kHybTile);
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
 #define RSGPU_HYBT(T, M) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M>), dim3(n_tiles), dim3(256), lds, s, a)
   if (!a.k) RSGPU_HYBT(KT_F32, KM_IP);

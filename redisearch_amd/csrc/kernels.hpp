@@ -66,6 +66,7 @@ struct ScanTuning {
                            // eight, 2 = one pass with the queries in registers; A/B knob)
   int hybrid_tiles = 1;    // RSGPU_HybridQuery without hits_out: the query in two launches (hybrid_kernels.hip); 0 = the staged pipeline
   int hybrid_tree_tiles = 1;  // ... its general form (hybrid_tree_tile_kernel): hit list wanted, 5-8 lists, slop-dependent scorers over offsets, RSGPU_HybridTreeQuery; 0 = staged
+  int prioritize_union_children = 0;  // the module's prioritizeIntersectUnionChildren (src/config.h:451, off by default): a child union's sort key in an intersection is estimate x children
   int hybrid_force_general = 0;  // diagnostics: RSGPU_HybridQuery takes the general tile kernel even for the shapes the two-launch form serves
   int hybrid_dir = 1;      // ... a probed list's window ends come from its bucket directory (one round trip; 0 = wave-wide searches)
   int hybrid_packed_docs = 1;  // document tables uploaded while set also keep {doc length, doc score} side by side (one gather per hit)

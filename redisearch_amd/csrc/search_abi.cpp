@@ -348,6 +348,16 @@ struct Source {
   uint64_t base = 0, first = 0, last = 0;  // ids[] are relative to base; first / last bound the doc ids from below / above
   std::vector<TNode> tree;   // the source's own result tree over its leaves (post-order, its root last)
 };
+// What an intersection sorts its children by (rqe_iterators/src/intersection.rs:94-119): num_estimated x
+// intersection_sort_weight -- 1 / (number of children) for a child INTERSECTION (intersection.rs:580-582: fewer children, tighter
+// selectivity), the number of children for a child UNION when the module's prioritizeIntersectUnionChildren is set (union_flat.rs:
+// 817-823; off by default, src/config.h:451: knob prioritize_union_children), 1 for everything else.  op: 0 term, 1 union, 2 intersection.
+static double intersection_sort_key(size_t estimate, int op, size_t n_children) {
+  double w = 1.0;
+  if (op == 2) w = 1.0 / (double)std::max<size_t>(n_children, 1);
+  else if (op == 1 && scan_tuning().prioritize_union_children) w = (double)std::max<size_t>(n_children, 1);
+  return (double)estimate * w;
+}
 static Source term_source(RSGPU_Postings *p, int orig) {
   Source s;
   s.ids = p->ids.p;
@@ -861,6 +871,7 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
     Source s;
     size_t estimate;
     int index;
+    double key = 0.0;  // what the root intersection sorts by
   };
   std::vector<Grp> groups;
   for (size_t g = 0; g < q->n_groups; g++) {
@@ -871,7 +882,8 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
     if (op == RSGPU_OP_TERM || b - a == 1) {
       if (b - a != 1) throw std::runtime_error("RSGPU_EvalTree: a term group holds exactly one list");
       if (op == RSGPU_OP_TERM) {
-        groups.push_back(Grp{term_source(q->lists[a], (int)a), q->lists[a]->n_entries, (int)g});
+        groups.push_back(Grp{term_source(q->lists[a], (int)a), q->lists[a]->n_entries, (int)g,
+                             intersection_sort_key(q->lists[a]->n_entries, 0, 1)});
         continue;
       }
     }
@@ -896,13 +908,14 @@ RSGPU_Hits *RSGPU_EvalTree(const RSGPU_TreeQuery *q) {
     } else {
       throw std::runtime_error("RSGPU_EvalTree: bad group_op");
     }
-    groups.push_back(Grp{hits_source(sub.get(), op == RSGPU_OP_UNION ? 1 : 2, w), est, (int)g});
+    groups.push_back(Grp{hits_source(sub.get(), op == RSGPU_OP_UNION ? 1 : 2, w), est, (int)g,
+                         intersection_sort_key(est, op == RSGPU_OP_UNION ? 1 : 2, b - a)});
     h->nested.push_back(std::move(sub));
   }
   std::vector<Source> srcs;
   if (q->root_op == RSGPU_OP_INTERSECT) {
     // children sorted by estimate, ascending and stable, unless in_order pins the caller's order
-    if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const Grp &x, const Grp &y) { return x.estimate < y.estimate; });
+    if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const Grp &x, const Grp &y) { return x.key < y.key; });
     for (auto &g : groups) srcs.push_back(g.s);
     combine_and(h, srcs, c.c, sc, c->h_counters, q->max_slop, q->in_order);
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -934,6 +947,7 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
   struct Sub {
     Source s;
     size_t estimate = 0;
+    double key = 0.0;                 // estimate x intersection_sort_weight: what a parent intersection sorts by
     std::unique_ptr<RSGPU_Hits> own;  // an aggregate's own hit list (NULL for a term)
   };
   std::vector<Sub> st;
@@ -951,6 +965,7 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
       Sub t;
       t.s = term_source(lists[nd.list], (int)nd.list);
       t.estimate = lists[nd.list]->n_entries;
+      t.key = intersection_sort_key(t.estimate, 0, 1);
       if (!root) {
         st.push_back(std::move(t));
         continue;
@@ -973,7 +988,7 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
     // an intersection iterates its children by ascending estimate, stable, unless in_order pins the query's order
     // (intersection.rs:94-119); a union keeps the query's order
     if (nd.op == RSGPU_OP_INTERSECT && !nd.in_order)
-      std::stable_sort(kids.begin(), kids.end(), [](const Sub &x, const Sub &y) { return x.estimate < y.estimate; });
+      std::stable_sort(kids.begin(), kids.end(), [](const Sub &x, const Sub &y) { return x.key < y.key; });
     std::vector<Source> srcs;
     for (Sub &k : kids) srcs.push_back(k.s);
     std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
@@ -998,6 +1013,7 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
     Sub up;
     up.s = hits_source(h.get(), nd.op == RSGPU_OP_UNION ? 1 : 2, nd.weight);
     up.estimate = est;
+    up.key = intersection_sort_key(est, nd.op == RSGPU_OP_UNION ? 1 : 2, nd.n_children);
     up.own = std::move(h);
     st.push_back(std::move(up));
   }
@@ -1520,15 +1536,40 @@ static void hyb_wait(QueryCtx *ca, bool may_poll, bool sync_after) {
   }
   if (!finished || sync_after) HIP_CHECK(hipStreamSynchronize(ca->stream));
 }
-// the answers out of pinned memory; false: the reduce kernel met more candidates at its bound than it ranks
-static bool hyb_collect(RSGPU_HybridQueryArgs *a, uint64_t base, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
+// the answers out of pinned memory; false: the reduce kernel met more candidates at its bound than it ranks -- or, BM25STD.NORM,
+// the division made a tie across the cut (below): the staged pipeline takes the query.
+// norm (SCORER BM25STD.NORM = BM25STD, then every score divided by the largest one: RPMaxScoreNormalizer, src/result_processor.c:
+// 1770-1812): the tile kernels ranked BM25STD; the largest score over ALL hits is the first entry's, so the division happens here,
+// on the top_n - 1 entries the caller asked for (one more was launched).  x / max is monotone, so the order stands -- except where
+// two DIFFERENT scores round to the same quotient: the staged selection ranks the quotients and breaks that tie by doc id.  Inside the
+// list that is a re-sort; across the cut (entry top_n - 2 against entry top_n - 1) the list itself might differ: hand the query back.
+static bool hyb_collect(RSGPU_HybridQueryArgs *a, uint64_t base, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k,
+                        bool norm) {
   if (n_tiles && ((top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) || (k && cb->h_fcnt[2] == 0xFFFFFFFFu))) return false;
   a->n_hits = n_tiles ? ca->h_counters[0] : 0;
   if (top_n && n_tiles) {
-    const uint32_t n = std::min<uint32_t>(ca->h_fcnt[2], top_n);
+    const uint32_t got = std::min<uint32_t>(ca->h_fcnt[2], top_n);
+    const uint32_t want = norm ? top_n - 1 : top_n;
+    std::vector<double> sc(got);
+    std::vector<uint32_t> id(ca->h_ids, ca->h_ids + got), ord(got);
+    for (uint32_t i = 0; i < got; i++) sc[i] = key2score(ca->h_out_keys[i]);
+    std::iota(ord.begin(), ord.end(), 0u);
+    if (norm && got) {
+      if (std::isnan(sc[0])) return false;
+      const double mx = sc[0] > 0.0 ? sc[0] : 0.0;  // max(0, the largest score)
+      if (mx != 0.0) {
+        std::vector<double> q(got);
+        for (uint32_t i = 0; i < got; i++) q[i] = sc[i] / mx;
+        if (got > want && q[want - 1] == q[want] && sc[want - 1] != sc[want]) return false;
+        std::stable_sort(ord.begin(), ord.begin() + std::min(got, want),
+                         [&](uint32_t x, uint32_t y) { return q[x] != q[y] ? q[x] > q[y] : id[x] < id[y]; });
+        sc.swap(q);
+      }
+    }
+    const uint32_t n = std::min(got, want);
     for (uint32_t i = 0; i < n; i++) {
-      if (a->top_ids) a->top_ids[i] = base + ca->h_ids[i];
-      if (a->top_scores) a->top_scores[i] = key2score(ca->h_out_keys[i]);
+      if (a->top_ids) a->top_ids[i] = base + id[ord[i]];
+      if (a->top_scores) a->top_scores[i] = sc[ord[i]];
     }
     a->n_top = n;
   }
@@ -1581,7 +1622,8 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
   const LeafMap m = adopt_sources(&h, srcs, v, 2);
   h.is_union = false;
   const uint32_t n0 = v.len[0];
-  const uint32_t top_n = want_score ? (uint32_t)a->top_n : 0u, k = want_knn ? (uint32_t)a->k : 0u;
+  const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;  // (one entry more: hyb_collect)
+  const uint32_t top_n = want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, k = want_knn ? (uint32_t)a->k : 0u;
   const uint32_t n_tiles = hybrid_tiles(n0);
 
   HybridTileArgs T;
@@ -1647,7 +1689,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof && !T.trace, false);
   }
-  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k)) return false;
+  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
   hyb_profile(prof, ev, n_tiles);
   return true;
 }
@@ -1660,6 +1702,7 @@ struct HybGroup {
   double weight = 1.0;
   std::vector<int> lists;  // the caller's list indices, in the child's own leaf order
   size_t estimate = 0;
+  double key() const { return op == 3 ? 1.0e300 : intersection_sort_key(estimate, op, lists.size()); }  // (a Not: max_doc_id, last)
 };
 // a flat AND: every list a term child, ascending by size, stable (intersection.rs:94-119; intersect_async)
 static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_t n_lists) {
@@ -1676,7 +1719,8 @@ static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_
   return g;
 }
 // a two-level tree under a root intersection: the children and their leaves in the order RSGPU_EvalTree evaluates them
-static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_lists, const char *who = "RSGPU_HybridTreeQuery") {
+static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_lists, const char *who = "RSGPU_HybridTreeQuery",
+                                             bool allow_not = true) {
   std::vector<HybGroup> groups;
   for (size_t g = 0; g < q->n_groups; g++) {
     const size_t a = q->group_first[g], b = q->group_first[g + 1];
@@ -1698,12 +1742,16 @@ static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_
       } else {
         for (int li : t.lists) t.estimate += q->lists[li]->n_entries;  // ... of a union: the sum
       }
+    } else if (op == RSGPU_OP_NOT && allow_not && q->root_op == RSGPU_OP_INTERSECT) {
+      t.op = 3;  // excluded lists: no leaf of the result tree, a virtual child of frequency 0
+      for (size_t l = a; l < b; l++) t.lists.push_back((int)l);
+      t.estimate = ~(size_t)0;  // (a Not's estimate is max_doc_id, never below a real child's: it sorts behind them)
     } else {
       throw std::runtime_error(std::string(who) + ": bad group_op");
     }
     groups.push_back(t);
   }
-  if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const HybGroup &x, const HybGroup &y) { return x.estimate < y.estimate; });
+  if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const HybGroup &x, const HybGroup &y) { return x.key() < y.key(); });
   return groups;
 }
 // the leaf that drives the probe: the shortest list every hit must hold (a term child, a term of a child intersection);
@@ -1712,7 +1760,7 @@ static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const
   int best = -1;
   uint32_t n0 = 0;
   for (const HybGroup &g : groups)
-    if (g.op != 1)
+    if (g.op == 0 || g.op == 2)
       for (int li : g.lists)
         if (best < 0 || lists[li]->n_entries < n0) {
           best = li;
@@ -1742,6 +1790,16 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       srcs.push_back(term_source(lists[g.lists[0]], g.lists[0]));
       continue;
     }
+    if (g.op == 3) {  // a NOT child: a virtual result -- no leaves, contributes weight * 0 -- that still counts as a child
+      Source s;
+      s.op = 2;
+      s.weight = g.weight;
+      s.n_leaves = 0;
+      s.len = 0;
+      s.tree.push_back(TNode{2, 0, 0, g.weight});
+      srcs.push_back(s);
+      continue;
+    }
     Source s;
     s.op = g.op;
     s.weight = g.weight;
@@ -1767,12 +1825,20 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   const int n = h.n_lists;  // leaves
   uint32_t n0 = 0;
   const int driver = hyb_driver(groups, lists, &n0);  // (a caller's list index)
-  const uint32_t top_n = want_score ? (uint32_t)a->top_n : 0u, k = want_knn ? (uint32_t)a->k : 0u;
+  const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;  // (one entry more: hyb_collect)
+  const uint32_t top_n = want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, k = want_knn ? (uint32_t)a->k : 0u;
   const uint32_t n_tiles = hybrid_tiles(n0);
 
+  std::vector<RSGPU_Postings *> excluded;  // NOT children's lists: probed behind the leaves, no column of their own
+  for (const HybGroup &g : groups)
+    if (g.op == 3)
+      for (int li : g.lists) excluded.push_back(lists[li]);
+  if (n + (int)excluded.size() > kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight lists");
+  if (!excluded.empty() && hits_out) throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children has no hit list (hits_out must be NULL)");
   HybridTreeArgs T;
   memset(&T, 0, sizeof T);
-  T.n = n;
+  T.n = n + (int)excluded.size();
+  T.n_leaves = n;
   // lists in probe order: the driver, then the other leaves in leaf order
   int leaf_of_list[kHybTreeMaxLists], list_of_leaf[kHybTreeMaxLists];
   {
@@ -1802,6 +1868,23 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       }
     }
   }
+  for (size_t x = 0; x < excluded.size(); x++) {
+    const int l = n + (int)x;
+    RSGPU_Postings *pl = excluded[x];
+    T.ids[l] = pl->ids.p;
+    T.len[l] = pl->n_entries;
+    T.add[l] = (long long)(pl->base - h.base);
+    T.leaf_of[l] = 0xFF;
+    T.veto |= 1u << l;
+    if (scan_tuning().hybrid_dir) {
+      ensure_bucket_dir(pl, ca);
+      if (pl->dir_ready.load(std::memory_order_acquire)) {
+        T.dir[l] = pl->dir.p;
+        T.dir_shift[l] = pl->dir_shift;
+        T.dir_n[l] = pl->dir_n;
+      }
+    }
+  }
   for (int t = 0; t < n; t++) {
     T.lfreq[t] = m.leaf_freq[t];
     const RSGPU_Postings *pl = h.src[t];
@@ -1816,7 +1899,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       if (h.group_op[g] == 1) any |= 1u << list_of_leaf[t];
       else T.req[T.n_req++] = 1u << list_of_leaf[t];
     }
-    if (h.group_op[g] == 1) T.req[T.n_req++] = any;
+    if (h.group_op[g] == 1) T.req[T.n_req++] = any;  // (a NOT child's virtual group has no leaves: nothing required)
   }
   T.X = tree_prox(&h, max_slop, in_order);
   // (combine_and: the filter runs when a window is asked for, the root has more than one child and some list stores offsets)
@@ -1878,7 +1961,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
   }
-  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k)) return false;
+  if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
   if (hits_out) {
     h.len = n_tiles ? ca->h_fcnt[0] : 0;
     if (h.len != a->n_hits) throw std::runtime_error("RSGPU_HybridQuery: the packed hit list and the hit count disagree");
@@ -1898,7 +1981,7 @@ static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists) {
   if (!aggregate) return nullptr;  // (a flat AND: the staged intersection is three launches as well)
   for (size_t l = 0; l < n_lists; l++)
     if (!q->lists[l]->n_entries) return nullptr;
-  const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists, "RSGPU_EvalTree");
+  const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists, "RSGPU_EvalTree", false);
   uint32_t n0 = 0;
   if (hyb_driver(groups, q->lists, &n0) < 0 || !hybrid_tree_supported(0, 0, 1u, hybrid_tiles(n0), 0u, 0u, (int)n_lists)) return nullptr;
   const int device = q->lists[0]->device;
@@ -1943,19 +2026,20 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   // Two launches instead of ten (hybrid_kernels.hip) when nobody asked for the hit list and the query has the plain shape:
   // a flat AND of a few term lists, a scorer that needs neither the term offsets nor the maximum over all hits, small N / k.
   // The general form of the tile kernel (round 4) takes what that leaves -- the hit list wanted (a third launch packs it),
-  // five to eight lists, scorers that divide by the slop over lists with offsets -- except BM25STD.NORM.
+  // five to eight lists, scorers that divide by the slop over lists with offsets.  BM25STD.NORM: ranked as BM25STD, divided
+  // by the first entry's score on the host (hyb_collect).
   const bool tile_knob = scan_tuning().hybrid_tiles && (want_score || want_knn);
   const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
   bool slop_offsets = false;
   if (want_score && slop_dependent(a->score->scorer))
     for (size_t l = 0; l < a->n_lists; l++) slop_offsets |= a->lists[l]->has_offsets();
-  bool tiles = tile_knob && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && !norm && !slop_offsets && !scan_tuning().hybrid_force_general;
-  bool general = tile_knob && !tiles && scan_tuning().hybrid_tree_tiles && a->n_lists <= (size_t)kHybTreeMaxLists && !norm;
+  bool tiles = tile_knob && !a->hits_out && a->n_lists <= (size_t)kHybMaxLists && !slop_offsets && !scan_tuning().hybrid_force_general;
+  bool general = tile_knob && !tiles && scan_tuning().hybrid_tree_tiles && a->n_lists <= (size_t)kHybTreeMaxLists;
   uint32_t n0_min = 0xFFFFFFFFu;
   for (size_t l = 0; l < a->n_lists; l++) n0_min = std::min<uint32_t>(n0_min, a->lists[l]->n_entries);
   if (tiles || general) {
     const bool ok = n0_min > 0 && hybrid_tile_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u,
-                                                        hybrid_tiles(n0_min), want_score ? (uint32_t)a->top_n : 0u,
+                                                        hybrid_tiles(n0_min), want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u,
                                                         want_knn ? (uint32_t)a->k : 0u);
     tiles = tiles && ok;
     general = general && ok;
@@ -2228,15 +2312,15 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   HIP_CHECK(hipSetDevice(device));
 
   bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) &&
-                 q->root_op == RSGPU_OP_INTERSECT && n_lists <= (size_t)kHybTreeMaxLists &&
-                 !(want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM) && (!want_knn || (f && f->key_bytes == 4));
+                 q->root_op == RSGPU_OP_INTERSECT && n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
+  const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
   for (size_t l = 0; l < n_lists && general; l++) general = q->lists[l]->n_entries > 0;
   if (general) {
     const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists);
     uint32_t n0 = 0;
     general = hyb_driver(groups, q->lists, &n0) >= 0 &&
               hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, hybrid_tiles(n0),
-                                    want_score ? (uint32_t)a->top_n : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
+                                    want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
     if (general) {
       if (f) f->flush_if_needed();
       CtxLease ca(device), cb(device);
@@ -2259,6 +2343,12 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
       a->n_hits = a->n_top = a->n_knn = 0;
     }
   }
+  if (q->group_op)
+    for (size_t g = 0; g < q->n_groups; g++)
+      if (q->group_op[g] == RSGPU_OP_NOT)
+        throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children runs on the general tile kernel only -- a root "
+                                 "intersection of at most eight lists with a term to drive it, identity labels, no hits_out, top_n / k <= 32"
+                                 " (or its reduce kernel met a mass tie at its bound)");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
   tls_hybrid_path = 0;  // (RSGPU_EvalTree may have built the list with the tile kernel; this QUERY ran stage by stage)

@@ -290,13 +290,15 @@ struct HybridOffsetView {  // OffsetView over the tree's leaves
   const uint32_t *off_len[kHybTreeMaxLists];
 };
 struct HybridTreeArgs {
-  int n;                                       // lists = leaves of the result tree
+  int n;                                       // lists probed: the n_leaves leaves of the result tree, then the excluded (NOT) lists
+  int n_leaves;
+  uint32_t veto;                               // bit l: a document list l holds is not a hit
   const uint32_t *ids[kHybTreeMaxLists];       // by LIST (probe order: list 0 drives)
   uint32_t len[kHybTreeMaxLists];
   long long add[kHybTreeMaxLists];
   const uint32_t *dir[kHybTreeMaxLists];       // bucket directories (NULL: wave-wide searches)
   uint32_t dir_shift[kHybTreeMaxLists], dir_n[kHybTreeMaxLists];
-  uint8_t leaf_of[kHybTreeMaxLists];           // list l -> its leaf column in the result tree
+  uint8_t leaf_of[kHybTreeMaxLists];           // list l -> its leaf column in the result tree (0xFF: an excluded list, no column)
   int n_req;
   uint32_t req[kHybTreeMaxLists];              // bit l: list l; a candidate matches a list of EVERY set
   const uint32_t *lfreq[kHybTreeMaxLists];     // by LEAF: decoded frequencies (NULL: the codec stores none -- 1)

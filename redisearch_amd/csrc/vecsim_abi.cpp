@@ -717,6 +717,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "hybrid_tiles")) scan_tuning().hybrid_tiles = value;
   else if (!strcmp(key, "hybrid_tree_tiles")) scan_tuning().hybrid_tree_tiles = value;
   else if (!strcmp(key, "hybrid_force_general")) scan_tuning().hybrid_force_general = value;
+  else if (!strcmp(key, "prioritize_union_children")) scan_tuning().prioritize_union_children = value;
   else if (!strcmp(key, "hybrid_surv_cap")) scan_tuning().hybrid_surv_cap = value;
   else if (!strcmp(key, "hybrid_trace")) scan_tuning().hybrid_trace = value;
   else if (!strcmp(key, "mq16")) scan_tuning().mq16 = value;

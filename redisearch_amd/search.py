@@ -37,7 +37,7 @@ class TreeNode(C.Structure):
                 ("in_order", _i)]
 
 
-OP_TERM, OP_UNION, OP_INTERSECT = 0, 1, 2
+OP_TERM, OP_UNION, OP_INTERSECT, OP_NOT = 0, 1, 2, 3
 
 ABI = {
     "RSGPU_EvalTree": (_vp, [C.POINTER(TreeQuery)]),

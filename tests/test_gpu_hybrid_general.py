@@ -317,7 +317,8 @@ def test_tree_query_over_many_tiles():
 
 def test_tree_query_shapes_the_general_kernel_declines():
     """a root whose children are all unions has no list every hit must hold (nothing drives the probe), a root union is not an
-    intersection, BM25STD.NORM needs the maximum over all hits: staged, same entry point, same answers as stage by stage"""
+    intersection: staged, same entry point, same answers as stage by stage.  BM25STD.NORM (the maximum over all hits = the first
+    entry's score: divided on the host) takes the general kernel."""
     rng = np.random.default_rng(31)
     built = [rand_list(rng, O.C_FREQS_ONLY, int(rng.integers(900, 2000)), 2500, False) for _ in range(4)]
     g = [S.Postings.from_flat(x[0].flatten()) for x in built]
@@ -332,7 +333,7 @@ def test_tree_query_shapes_the_general_kernel_declines():
         hq = S.HybridTreeQuery(root, groups, table=table, scorer=scorer, idf=idf[:nl], bm25_idf=bidf[:nl], weight=w[:nl], num_docs=2500,
                                avg_doc_len=150.0, top_n=10)
         hq.run()
-        assert S.hybrid_path() == 0
+        assert S.hybrid_path() == (2 if scorer == "BM25STD.NORM" else 0)
         r = hq.results()
         h = S.TreeHits(root, groups)
         h.score(table, scorer, idf[:nl], bidf[:nl], w[:nl], 2500, 150.0, want_scores=False)
@@ -374,3 +375,136 @@ def test_eval_tree_builds_the_same_hit_list_with_the_tile_kernel(name, shape, wi
         sa = ha.score(table, scorer, idf, bidf, w, 2500, 150.0, root_weight=1.5)
         sb = hb.score(table, scorer, idf, bidf, w, 2500, 150.0, root_weight=1.5)
         assert np.array_equal(sa, sb), scorer
+
+
+# ---- BM25STD.NORM on the tile paths ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [None, SHAPES[0][1], SHAPES[3][1]])
+def test_bm25std_norm_is_ranked_as_bm25std_and_divided_by_the_first_score(shape):
+    """SCORER BM25STD.NORM = BM25STD, then every score over the largest one (RPMaxScoreNormalizer, result_processor.c:1770-1812):
+    the tile kernels rank BM25STD, the host divides by the first entry's score -- against the staged pipeline (score_max_kernel +
+    score_normalize_kernel over ALL hits, then the selection), bit for bit, and against BM25STD's own top list."""
+    rng = np.random.default_rng(77 if shape is None else len(shape))
+    if shape is None:
+        lists_o, rng = flat_corpus(400_000, (0.4, 0.5, 0.3), 78)
+        g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+        n_docs, sizes = 400_000, [l.unique_docs for l in lists_o]
+        make = lambda scorer, n: S.HybridQuery(g, table, scorer, idf, bidf, w, n_docs, 200.0, top_n=n, root_weight=0.7)
+        want_path = 1
+    else:
+        n_lists = sum(len(gp[2]) for gp in shape)
+        built = [rand_list(rng, O.C_FREQS_ONLY, int(rng.integers(900, 2200)), 2500, False) for _ in range(n_lists)]
+        g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+        n_docs, sizes = 2500, [x[0].unique_docs for x in built]
+        groups = [(op, wt, [g[i] for i in idx]) for op, wt, idx in shape]
+        make = lambda scorer, n: S.HybridTreeQuery(I, groups, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w, num_docs=n_docs,
+                                                   avg_doc_len=200.0, top_n=n, root_weight=0.7)
+        want_path = 2
+    table = table_for(rng, n_docs)
+    idf = [S.calculate_idf(n_docs, s_) for s_ in sizes]
+    bidf = [S.calculate_idf_bm25(n_docs, s_) for s_ in sizes]
+    w = [1.0, 0.5, 2.0, 1.5, 1.0, 0.25][:len(sizes)]
+    for n in (1, 10, 31):
+        hq = make("BM25STD.NORM", n)
+        hq.run()
+        assert S.hybrid_path() == want_path
+        a = hq.results()
+        try:
+            knob("hybrid_tiles", 0)
+            hq.run()
+            assert S.hybrid_path() == 0
+            b = hq.results()
+        finally:
+            knob("hybrid_tiles", 1)
+        assert a["n_hits"] == b["n_hits"] and a["top"][0].tolist() == b["top"][0].tolist() and a["top"][1].tolist() == b["top"][1].tolist()
+        raw = make("BM25STD", n)
+        raw.run()
+        r = raw.results()
+        assert a["top"][0].tolist() == r["top"][0].tolist() and a["top"][1].tolist() == (r["top"][1] / r["top"][1][0]).tolist()
+        assert a["top"][1][0] == 1.0
+
+
+# ---- NOT children ------------------------------------------------------------------------------------------------------------------
+NOT_SHAPES = [
+    ("a -b", [(T, 1.0, [0])], [(1.0, [1])]),
+    ("a b -c", [(T, 1.0, [0]), (T, 1.0, [1])], [(2.0, [2])]),
+    ("a (b|c) -d -e", [(T, 1.0, [0]), (U, 0.5, [1, 2])], [(1.0, [3]), (1.0, [4])]),
+    ("(a b) c -(d|e)", [(I, 3.0, [0, 1]), (T, 1.0, [2])], [(1.0, [3, 4])]),
+]
+
+
+@pytest.mark.parametrize("with_offsets,max_slop,in_order", [(False, None, False), (True, None, False), (True, 4, False), (True, None, True)])
+@pytest.mark.parametrize("name,pos,neg", NOT_SHAPES)
+def test_not_children_against_the_oracle(name, pos, neg, with_offsets, max_slop, in_order):
+    """`a -b` under a root intersection: the excluded lists veto a candidate in the tile kernel; the result is the positive
+    children's PLUS a virtual child of frequency 0 per NOT (not.rs:106-118): it adds nothing to any sum and has no offsets, but
+    IndexResult_MinOffsetDelta counts it (offset-less slop = children - 1).  No staged twin exists (RSGPU_EvalTree has no NOT
+    node): the CPU oracle directly -- set algebra, the oracle's proximity test over the positive children, its scorers over
+    Intersection{..., Virtual} in the reference's order."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + 3 * int(with_offsets) + (max_slop or 0) + 5 * int(in_order))
+    codec = O.C_FULL if with_offsets else O.C_FREQS_ONLY
+    n_lists = sum(len(gp[2]) for gp in pos) + sum(len(x[1]) for x in neg)
+    built = [rand_list(rng, codec, int(rng.integers(700, 1800)), 2500, with_offsets) for _ in range(n_lists)]
+    recs, sizes = [x[1] for x in built], [x[0].unique_docs for x in built]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    groups = [(op, wt, [g[i] for i in idx]) for op, wt, idx in pos] + [(S.OP_NOT, wt, [g[i] for i in idx]) for wt, idx in neg]
+    n_docs = 2500
+    doc_len = rng.integers(5, 200, n_docs + 1).astype(np.uint32)
+    doc_score = rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32)
+    max_freq = rng.integers(1, 40, n_docs + 1).astype(np.uint32)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    idf = [S.calculate_idf(n_docs, s_) for s_ in sizes]
+    bidf = [S.calculate_idf_bm25(n_docs, s_) for s_ in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    avg = float(doc_len[1:].mean())
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    idx.add_philox_rows(11, 0, 1200, 100)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    ot = OracleTree(I, pos, recs, sizes, max_slop, in_order)
+    gone = set().union(*[set(recs[i]) for _, ix in neg for i in ix])
+    docs = [d for d in ot.docs if d not in gone]
+    assert len(docs) < len(ot.docs) or not ot.docs
+    for scorer in SCORERS:
+        hq = S.HybridTreeQuery(I, groups, max_slop=max_slop, in_order=in_order, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
+                               num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10, root_weight=1.5)
+        hq.run()
+        assert S.hybrid_path() == 2
+        a = hq.results()
+        assert a["n_hits"] == len(docs), (scorer, a["n_hits"], len(docs))
+        scored = []
+        for d in docs:
+            kids = ot.node(d, idf, bidf, w).kids + [O.Node(O.R_VIRTUAL, wt, 0) for wt, _ in neg]
+            node = O.intersection(kids)
+            node.c.weight = 1.5
+            scored.append((O.score(scorer, node, float(doc_score[d]), int(max_freq[d]), int(doc_len[d]), n_docs, avg), d))
+        scored.sort(key=lambda t: (-t[0], t[1]))
+        assert a["top"][0].tolist() == [d for _, d in scored[:10]], (scorer, a["top"][0], scored[:10])
+        if scorer == "BM25STD.TANH":
+            assert a["top"][1] == pytest.approx([x for x, _ in scored[:10]], rel=1e-12)
+        else:
+            assert a["top"][1].tolist() == [x for x, _ in scored[:10]], scorer
+    cand = np.asarray([d for d in docs if 100 <= d < 1300], np.int64)
+    if len(cand):
+        o = O.FlatIndex(O.F32, 24, O.L2)
+        o.add_bulk(O.philox_rows(11, 0, 1200, 24)[cand - 100], 1)
+        li, ls = o.topk(q, 10)
+        assert a["knn"][0].tolist() == cand[li.astype(np.int64) - 1].tolist()
+    else:
+        assert len(a["knn"][0]) == 0
+    idx.free()
+
+
+def test_not_children_where_the_tile_kernel_cannot_run():
+    rng = np.random.default_rng(3)
+    built = [rand_list(rng, O.C_FREQS_ONLY, 800, 2500, False) for _ in range(3)]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    table = table_for(rng, 2500)
+    ones = [1.0] * 3
+    # hits_out with a NOT child, a NOT child under a root of unions only, RSGPU_EvalTree: refused with a message, not answered wrongly
+    for kw, groups in ((dict(want_hits=True), [(T, 1.0, g[:1]), (S.OP_NOT, 1.0, g[1:2])]),
+                       (dict(), [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])])):
+        hq = S.HybridTreeQuery(I, groups, table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones, num_docs=2500, avg_doc_len=150.0,
+                               top_n=10, **kw)
+        with pytest.raises(RuntimeError, match="NOT"):
+            hq.run()
+    with pytest.raises(RuntimeError):
+        S.TreeHits(I, [(T, 1.0, g[:1]), (S.OP_NOT, 1.0, g[1:2])])

@@ -123,8 +123,8 @@ def setup_hybrid(n_docs, n_vec, dim, seed, dfs):
 @pytest.mark.parametrize("scorer", ["BM25STD", "TFIDF", "BM25STD.NORM"])
 @pytest.mark.parametrize("tiles", [1, 0])
 def test_fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles):
-    """tiles = 1: the query in two launches (hybrid_kernels.hip) where its shape allows (not BM25STD.NORM: the maximum over
-    all hits); tiles = 0: the staged pipeline behind the same entry point"""
+    """tiles = 1: the query in two launches (hybrid_kernels.hip) -- BM25STD.NORM too since round 4: ranked as BM25STD, the
+    division by the largest score (the first entry's) done on the host; tiles = 0: the staged pipeline behind the same entry point"""
     V.load().RSGPU_SetTuning(b"hybrid_tiles", tiles)
     try:
         _fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles)
@@ -142,7 +142,7 @@ def _fused_query_equals_staged_pipeline(n_docs, n_vec, dfs, scorer, tiles):
     ki, kd = h.knn_rerank(idx, q, 10)
     # fused
     r = S.hybrid_query(g, table, scorer, idf, bidf, w, n_docs, avg, top_n=10, index=idx, q=q, k=10)
-    assert S.hybrid_path() == (1 if tiles and scorer != "BM25STD.NORM" else 0)
+    assert S.hybrid_path() == (1 if tiles else 0)
     assert r["n_hits"] == len(h)
     assert r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
     assert r["knn"][0].tolist() == ki.tolist() and r["knn"][1].tolist() == kd.tolist()

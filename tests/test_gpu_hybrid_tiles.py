@@ -198,27 +198,31 @@ def test_lists_without_frequencies_and_sixty_four_bit_doc_ids():
 
 
 def test_shapes_the_two_launches_leave_to_the_staged_pipeline():
-    """BM25STD.NORM (the maximum over ALL hits) and N > 32: the staged pipeline answers.  Five lists: the general tile kernel
-    since round 4 (path 2, tests/test_gpu_hybrid_general.py), the staged pipeline with its knob off."""
+    """N > 32: the staged pipeline answers.  Round 4: five lists run the general tile kernel (path 2,
+    tests/test_gpu_hybrid_general.py); BM25STD.NORM -- the maximum over ALL hits is the first entry's score -- is ranked as BM25STD
+    by the two launches and divided on the host.  Each against the staged pipeline (knob hybrid_tiles = 0), bit for bit."""
     lib = V.load()
     n_docs = 200_000
     lists_o, rng = corpus(n_docs, (0.6, 0.5, 0.6, 0.5, 0.6), 23)
     g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
-    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), np.ones(n_docs + 1, np.float32))
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32))
     ones = [1.0] * 5
-    for args, path in ((dict(lists=g[:2], scorer="BM25STD.NORM", top_n=10), 0), (dict(lists=g, scorer="BM25STD", top_n=10), 2),
+    for args, path in ((dict(lists=g[:2], scorer="BM25STD.NORM", top_n=10), 1), (dict(lists=g[:2], scorer="BM25STD.NORM", top_n=32), 0),
+                       (dict(lists=g, scorer="BM25STD", top_n=10), 2), (dict(lists=g, scorer="BM25STD.NORM", top_n=31), 2),
                        (dict(lists=g[:2], scorer="BM25STD", top_n=40), 0)):
         n = len(args["lists"])
         r = S.hybrid_query(args["lists"], table, args["scorer"], ones[:n], ones[:n], ones[:n], n_docs, 200.0, top_n=args["top_n"])
-        assert S.hybrid_path() == path and len(r["top"][0]) == args["top_n"]
-        if path == 2:
+        assert S.hybrid_path() == path and len(r["top"][0]) == args["top_n"], args
+        if path:
             try:
-                lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 0)
+                lib.RSGPU_SetTuning(b"hybrid_tiles", 0)
                 r0 = S.hybrid_query(args["lists"], table, args["scorer"], ones[:n], ones[:n], ones[:n], n_docs, 200.0, top_n=args["top_n"])
                 assert S.hybrid_path() == 0
             finally:
-                lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
+                lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
             assert r0["n_hits"] == r["n_hits"] and r0["top"][0].tolist() == r["top"][0].tolist() and r0["top"][1].tolist() == r["top"][1].tolist()
+            if args["scorer"] == "BM25STD.NORM":
+                assert r["top"][1][0] == 1.0 and np.all(r["top"][1] <= 1.0)
 
 
 def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():

@@ -48,7 +48,9 @@ class OracleTree:
                 est, docs = sizes[idx[0]], set(recs[idx[0]])
             gs.append(dict(op=op, w=w, idx=list(idx), est=est, docs=docs))
         if root_op == S.OP_INTERSECT and not in_order:
-            gs = sorted(gs, key=lambda g: g["est"])
+            # the sort key of an intersection's children: estimate x intersection_sort_weight -- 1 / children for a child
+            # intersection (intersection.rs:94-119,580-582), 1 for terms and (prioritizeIntersectUnionChildren off) unions
+            gs = sorted(gs, key=lambda g: g["est"] * (1.0 / len(g["idx"]) if g["op"] == S.OP_INTERSECT else 1.0))
         self.groups = gs
         docs = set.intersection(*[g["docs"] for g in gs]) if root_op == S.OP_INTERSECT else set.union(*[g["docs"] for g in gs])
         self.docs = sorted(docs)
@@ -158,7 +160,7 @@ def test_tree_with_slop_and_order_merges_union_positions(max_slop, in_order):
 # ---- trees of any depth (RSGPU_EvalTreeNodes) ----------------------------------------------------------------------------
 class DeepOracle:
     """Set algebra + result trees for nested tuples ("t", i) / ("and" | "or", weight, [children], max_slop, in_order): the
-    reference's iterators, restated -- an intersection iterates its children by ascending estimate (stable) unless
+    reference's iterators, restated -- an intersection iterates its children by ascending estimate x sort weight (stable) unless
     in_order (intersection.rs:94-119; estimate = the smallest child's), a union keeps the query order (estimate = the
     sum) and its result holds the matched children only (union_flat.rs:297-320)."""
 
@@ -176,7 +178,8 @@ class DeepOracle:
         max_slop = t[3] if len(t) > 3 else None
         if t[0] == "and":
             if not in_order:
-                kids = sorted(kids, key=lambda k: k["est"])
+                # estimate x intersection_sort_weight (intersection.rs:94-119): 1 / children for a child intersection
+                kids = sorted(kids, key=lambda k: k["est"] * (1.0 / len(k["kids"]) if k["op"] == "and" else 1.0))
             docs = set.intersection(*[k["docs"] for k in kids])
             if max_slop is not None or in_order:
                 docs = {d for d in docs if O.within_range([self._offsets(k, d) for k in kids], max_slop, in_order)}
