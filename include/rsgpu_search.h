@@ -195,11 +195,11 @@ typedef struct {
 int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
 /* how the calling thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 = the staged pipeline (intersection written
  * out, score / top-N and KNN branches on two streams; stage by stage for trees), 1 = two launches (no hits_out, a flat AND of
- * <= 4 term lists, top_n / k <= 32, no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
+ * <= 4 term lists, top_n / k <= 32 (31 for BM25STD.NORM), no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
  * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
  * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
- * offsets; hits_out wanted: a third launch packs the list).  BM25STD.NORM, a root union, a root whose children are all unions
- * and indexes with a general label map stay staged.  Same answers either way. */
+ * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list).  A root union, a root whose children are
+ * all unions, top_n / k > 32 and indexes with a general label map stay staged.  Same answers either way. */
 int RSGPU_HybridQueryPath(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
