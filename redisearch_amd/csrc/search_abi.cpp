@@ -1976,6 +1976,7 @@ static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists) {
   if (!scan_tuning().hybrid_tiles || !scan_tuning().hybrid_tree_tiles || q->root_op != RSGPU_OP_INTERSECT ||
       n_lists > (size_t)kHybTreeMaxLists || !q->group_op)
     return nullptr;
+  if (scan_profile().enabled.load(std::memory_order_relaxed)) return nullptr;  // (per-STAGE device times are the staged form's)
   bool aggregate = false;
   for (size_t g = 0; g < q->n_groups; g++) aggregate |= q->group_op[g] != RSGPU_OP_TERM;
   if (!aggregate) return nullptr;  // (a flat AND: the staged intersection is three launches as well)
