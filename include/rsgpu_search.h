@@ -108,6 +108,8 @@ RSGPU_Hits *RSGPU_Intersect(RSGPU_Postings *const *lists, size_t n_lists);
  * (which are then NOT re-ordered by size).  Lists whose codec stores no offsets do not take part in the check.
  * The hit list borrows the posting lists (slop-aware scoring reads their offset bytes): free the hits first. */
 RSGPU_Hits *RSGPU_IntersectEx(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order);
+/* (round 4: with a window over at most eight lists that store offsets the general hybrid tile kernel builds the list -- probe,
+ * window test and ordered write in one launch + a pack launch; RSGPU_HybridQueryPath reads 2 after such a call.  Same hit list.) */
 void RSGPU_Hits_Free(RSGPU_Hits *h);
 size_t RSGPU_Hits_Len(const RSGPU_Hits *h);
 /* doc_ids[len]; freqs[n_lists][len] in the order the lists were given. Either may be NULL. */

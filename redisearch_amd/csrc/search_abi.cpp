@@ -781,6 +781,8 @@ long RSGPU_Postings_DecodeWideMasks(RSGPU_Postings *p, uint64_t *masks_lo_out, u
   S_CATCH(-1)
 }
 
+// with a window (max_slop / in_order) through the general hybrid tile kernel (defined next to it, below): NULL = stage by stage
+static RSGPU_Hits *intersect_tiles(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order);
 RSGPU_Hits *RSGPU_IntersectEx(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order) {
   if (!lists || !n_lists || n_lists > (size_t)kMaxLists) {
     last_error() = "RSGPU_Intersect: 1..32 lists";
@@ -790,6 +792,10 @@ RSGPU_Hits *RSGPU_IntersectEx(RSGPU_Postings *const *lists, size_t n_lists, long
   check_lists("RSGPU_Intersect", lists, n_lists);
   const int device = lists[0]->device;
   HIP_CHECK(hipSetDevice(device));
+  // A phrase / proximity intersection (max_slop / in_order over lists that store offsets): the general hybrid tile kernel tests
+  // the candidates' windows where it finds them and writes the hit list (round 4) -- the staged form's prox_filter_kernel is a
+  // launch of its own over every driver, between the probe and the ordered write.  Same hit list.
+  if (RSGPU_Hits *fast = intersect_tiles(lists, n_lists, max_slop, in_order)) return fast;
   CtxLease c(device);
   auto *h = new RSGPU_Hits();
   std::unique_ptr<RSGPU_Hits> guard(h);
@@ -1705,10 +1711,11 @@ struct HybGroup {
   double key() const { return op == 3 ? 1.0e300 : intersection_sort_key(estimate, op, lists.size()); }  // (a Not: max_doc_id, last)
 };
 // a flat AND: every list a term child, ascending by size, stable (intersection.rs:94-119; intersect_async)
-static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_t n_lists) {
+static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_t n_lists, bool in_order = false) {
   std::vector<int> order(n_lists);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lists[x]->n_entries < lists[y]->n_entries; });
+  if (!in_order)  // (in_order: the caller's order is the order the terms must appear in)
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lists[x]->n_entries < lists[y]->n_entries; });
   std::vector<HybGroup> g;
   for (int li : order) {
     HybGroup t;
@@ -1992,6 +1999,30 @@ static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists) {
   RSGPU_Hits *out = nullptr;
   if (!hybrid_general(&none, q->lists, groups, q->max_slop, q->in_order, &out, nullptr, 0, false, false, ca.c, cb.c, scratch(device), false,
                       tls_events))
+    return nullptr;
+  tls_hybrid_path = 2;
+  return out;
+}
+
+static RSGPU_Hits *intersect_tiles(RSGPU_Postings *const *lists, size_t n_lists, long max_slop, int in_order) {
+  tls_hybrid_path = 0;
+  if (!(max_slop >= 0 || in_order) || n_lists < 2 || n_lists > (size_t)kHybTreeMaxLists) return nullptr;
+  if (!scan_tuning().hybrid_tiles || !scan_tuning().hybrid_tree_tiles || scan_profile().enabled.load(std::memory_order_relaxed)) return nullptr;
+  bool offsets = false;
+  uint32_t n0 = 0xFFFFFFFFu;
+  for (size_t l = 0; l < n_lists; l++) {
+    if (!lists[l]->n_entries) return nullptr;
+    offsets |= lists[l]->has_offsets();
+    n0 = std::min<uint32_t>(n0, lists[l]->n_entries);
+  }
+  if (!offsets || !hybrid_tree_supported(0, 0, 1u, hybrid_tiles(n0), 0u, 0u, (int)n_lists)) return nullptr;
+  const int device = lists[0]->device;
+  CtxLease ca(device), cb(device);
+  RSGPU_HybridQueryArgs none;
+  memset(&none, 0, sizeof none);
+  RSGPU_Hits *out = nullptr;
+  if (!hybrid_general(&none, lists, hyb_groups_flat(lists, n_lists, in_order != 0), max_slop, in_order, &out, nullptr, 0, false, false, ca.c,
+                      cb.c, scratch(device), false, tls_events))
     return nullptr;
   tls_hybrid_path = 2;
   return out;

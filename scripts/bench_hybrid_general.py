@@ -70,5 +70,23 @@ for mode, knob in (("tile_kernel", 1), ("staged", 0)):
 lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
 out["eval_tree_term_and_union_of_two"] = ev
 print("eval_tree", json.dumps(ev), flush=True)
+# RSGPU_IntersectEx with a window alone -- `"a b"` as a phrase (slop 0, in order) over two Full-codec lists: the tile kernel's hit
+# list against the staged probe -> prox_filter -> scan -> write
+fu = [S.Postings.from_flat(e) for e in (enc_full[0], enc_full[n_a])]
+ph = {}
+for mode, knob in (("tile_kernel", 1), ("staged", 0)):
+    lib.RSGPU_SetTuning(b"hybrid_tree_tiles", knob)
+    S.intersect(fu, max_slop=0, in_order=True).free()
+    t = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        h = S.intersect(fu, max_slop=0, in_order=True)
+        t.append((time.perf_counter() - t0) * 1e3)
+        n = len(h)
+        h.free()
+    ph[mode] = {"ms_p50": float(np.percentile(t, 50)), "hits": n, "path": S.hybrid_path()}
+lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
+out["phrase_intersection_two_full_codec_terms"] = ph
+print("phrase", json.dumps(ph), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/r04_hybrid_general_shapes.json", "w"), indent=1)

@@ -508,3 +508,33 @@ def test_not_children_where_the_tile_kernel_cannot_run():
             hq.run()
     with pytest.raises(RuntimeError):
         S.TreeHits(I, [(T, 1.0, g[:1]), (S.OP_NOT, 1.0, g[1:2])])
+
+
+# ---- RSGPU_IntersectEx with a window through the tile kernel ---------------------------------------------------------------------
+@pytest.mark.parametrize("n_lists", [2, 3, 5])
+@pytest.mark.parametrize("max_slop,in_order", [(0, False), (3, False), (None, True), (0, True), (12, True)])
+def test_phrase_intersection_builds_the_same_hit_list_with_the_tile_kernel(n_lists, max_slop, in_order):
+    """`"hello world"` (slop 0, in order) and looser windows over Full-codec lists: the tile kernel's list against the staged
+    probe -> prox_filter -> scan -> write, and against the oracle's intersection with the same window"""
+    rng = np.random.default_rng(1000 * n_lists + 10 * (max_slop or 0) + int(in_order))
+    built = [rand_list(rng, O.C_FULL, int(rng.integers(2500, 6000)), 8000, True) for _ in range(n_lists)]
+    lists_o = [x[0] for x in built]
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    try:
+        knob("hybrid_tree_tiles", 1)
+        ha = S.intersect(g, max_slop=max_slop, in_order=in_order)
+        assert S.hybrid_path() == 2
+        knob("hybrid_tree_tiles", 0)
+        hb = S.intersect(g, max_slop=max_slop, in_order=in_order)
+        assert S.hybrid_path() == 0
+    finally:
+        knob("hybrid_tree_tiles", 1)
+    ids, fr = same_hit_lists(ha, hb, n_lists, with_records=True)
+    oi, of, _ = O.intersect_ex(lists_o, max_slop, in_order)
+    assert ids.tolist() == oi.tolist() and np.array_equal(fr, of)
+    table = table_for(rng, 8000)
+    sizes = [l.unique_docs for l in lists_o]
+    idf = [S.calculate_idf(8000, s_) for s_ in sizes]
+    bidf = [S.calculate_idf_bm25(8000, s_) for s_ in sizes]
+    for scorer in ("TFIDF", "BM25", "BM25STD"):
+        assert np.array_equal(ha.score(table, scorer, idf, bidf, [1.0] * n_lists, 8000, 150.0), hb.score(table, scorer, idf, bidf, [1.0] * n_lists, 8000, 150.0))
