@@ -571,6 +571,27 @@ _sig("oracle_union", _sz, _vp, _sz, _sz, _vp, _vp, _vp)
 _sig("oracle_not", _sz, _vp, _vp, C.c_uint64, _sz, _vp)
 
 
+_sig("oracle_intersection_sort_key", _dbl, _sz, _i, _sz, _i)
+_sig("oracle_intersection_child_order", None, _sz, _vp, _vp, _vp, _i, _i, _vp)
+K_TERM, K_UNION, K_INTERSECTION = 0, 1, 2
+
+
+def intersection_sort_key(num_estimated, kind=K_TERM, n_children=1, prioritize_union_children=False):
+    """num_estimated x intersection_sort_weight (oracle_intersection_sort_key)"""
+    return lib.oracle_intersection_sort_key(int(num_estimated), int(kind), int(n_children), int(prioritize_union_children))
+
+
+def intersection_child_order(children, prioritize_union_children=False, in_order=False):
+    """children: [(num_estimated, kind, n_children)] in query order -> their indices in iteration (= result) order"""
+    n = len(children)
+    est = np.asarray([c[0] for c in children], np.uint64)
+    kind = np.asarray([c[1] for c in children], np.int32)
+    nch = np.asarray([c[2] for c in children], np.uint64)
+    out = np.zeros(max(n, 1), np.uint64)
+    lib.oracle_intersection_child_order(n, _p(est), _p(kind), _p(nch), int(prioritize_union_children), int(in_order), _p(out))
+    return out[:n].astype(int).tolist()
+
+
 def union_lists(lists):
     """N-way OR of InvertedIndex objects -> (ids[H], freqs[N,H], masks[N,H]); absent = 0."""
     n = len(lists)

@@ -574,3 +574,34 @@ size_t oracle_not(const OInv *child, const OInv *universe, uint64_t max_doc_id, 
   oreader_free(c);
   return hits;
 }
+
+/* The order an intersection iterates its children in -- and the order its result holds them in, which is the order the
+ * scorers add in.  Reference src/redisearch_rs/rqe_iterators/src/intersection.rs:94-119 (new_with_slop_order: a STABLE
+ * sort by num_estimated() as f64 * intersection_sort_weight(), total_cmp; in_order keeps the query's order), the weights:
+ * intersection.rs:580-582 (a child Intersection: 1 / children, at least one), union_flat.rs:817-823 / union_heap.rs:686-692 (a
+ * child Union: its children when prioritizeIntersectUnionChildren -- off by default, src/config.h:451 -- else 1),
+ * lib.rs:325-328 (everything else 1).  kind: 0 term / other, 1 union, 2 intersection. */
+double oracle_intersection_sort_key(size_t num_estimated, int kind, size_t n_children, int prioritize_union_children) {
+  double w = 1.0;
+  size_t n = n_children > 1 ? n_children : 1;
+  if (kind == 2) w = 1.0 / (double)n;
+  else if (kind == 1 && prioritize_union_children) w = (double)n;
+  return (double)num_estimated * w;
+}
+void oracle_intersection_child_order(size_t n, const size_t *num_estimated, const int *kind, const size_t *n_children,
+                                     int prioritize_union_children, int in_order, size_t *order_out) {
+  for (size_t i = 0; i < n; i++) order_out[i] = i;
+  if (in_order) return;
+  for (size_t i = 1; i < n; i++) { /* insertion sort: stable */
+    size_t c = order_out[i];
+    double kc = oracle_intersection_sort_key(num_estimated[c], kind[c], n_children[c], prioritize_union_children);
+    size_t j = i;
+    while (j > 0) {
+      size_t p = order_out[j - 1];
+      if (oracle_intersection_sort_key(num_estimated[p], kind[p], n_children[p], prioritize_union_children) <= kc) break;
+      order_out[j] = p;
+      j--;
+    }
+    order_out[j] = c;
+  }
+}
