@@ -280,3 +280,50 @@ def test_restated_oracle_equals_reference(seed):
                 assert got == pytest.approx(ref, rel=1e-15, abs=1e-300)
             else:
                 assert got == ref or (got != got and ref != ref), (sc, spec, kw, got, ref)
+
+
+# ---- what a NOT child is to the scorers (round 4: the general tile kernel's `a -b`) ---------------------------------------------
+@need_ref
+def test_a_not_child_is_a_virtual_result_of_frequency_zero_to_the_reference_scorers():
+    """`a b -c` is Intersection{a, b, Not{c}}; the Not iterator's result is VIRTUAL, frequency 0, weight = the node's
+    (rqe_iterators/src/not.rs:106-118, index_result/src/core/mod.rs:103-112).  On the REFERENCE's compiled scorers
+    (src/ext/default.c) and IndexResult_MinOffsetDelta (src/index_result/index_result.c): it adds nothing to any scorer's sum --
+    the scores of Intersection{a, b, Virtual} are those of Intersection{a, b} whenever the two have the same slop -- and it
+    counts as a child for the slop: with term offsets the pairs of children that HAVE offsets decide (same value), without
+    them the answer is children - 1 (2 instead of 1).  The restated oracle agrees; this is what `hybrid_general` builds its
+    ScoreParams / ProxParams from (an empty aggregate per NOT child)."""
+    h = X.Host()
+    assert h.load_ref() == X.OK
+    rng = np.random.default_rng(5)
+    for it in range(100):
+        with_offsets = bool(it % 2)
+        terms = []
+        for name in ("a", "b"):
+            pos = sorted(set(int(x) for x in rng.integers(1, 40, int(rng.integers(1, 4))))) if with_offsets else None
+            terms.append(("term", float(rng.choice([1.0, 0.5, 2.0])), int(rng.integers(1, 20)), float(rng.uniform(0.1, 5)),
+                          float(rng.uniform(0.1, 5)), name, pos))
+        wn = float(rng.choice([1.0, 0.3, 4.0]))
+        pos_spec = ("intersection", 1.5, terms)
+        not_spec = ("intersection", 1.5, terms + [("virtual", wn, 0)])
+        tp, tn = X.Tree(pos_spec), X.Tree(not_spec)
+        sp, sn = h.ref_slop(tp), h.ref_slop(tn)
+        if with_offsets:
+            # decided by the children that have offsets -- unless their distance is 0 (the same position in both terms):
+            # "return dist ? sqrt(dist) : num - 1" falls back to the child count there too
+            assert sn == sp or (sp, sn) == (1, 2)
+        else:
+            assert (sp, sn) == (1, 2)                         # children - 1
+        assert O.lib.oracle_slop(_to_oracle(not_spec).ptr) == sn
+        kw = dict(doc_score=float(rng.choice([1.0, 0.25])), max_freq=int(rng.choice([3, 50])), doc_len=int(rng.choice([9, 1234])),
+                  num_docs=int(rng.integers(10, 10 ** 5)), avg_doc_len=float(rng.uniform(1, 300)), tanh_factor=4)
+        for sc in ("TFIDF", "TFIDF.DOCNORM", "BM25", "BM25STD", "BM25STD.TANH", "DISMAX", "DOCSCORE"):
+            ref_n, ref_p = h.score(sc, tn, **kw), h.score(sc, tp, **kw)
+            got_n = O.score(sc, _to_oracle(not_spec), **kw)
+            if sc == "BM25STD.TANH":
+                assert got_n == pytest.approx(ref_n, rel=1e-15, abs=1e-300)
+            else:
+                assert got_n == ref_n, (sc, not_spec, got_n, ref_n)
+            if sc in ("TFIDF", "TFIDF.DOCNORM", "BM25") and sn != sp:
+                assert ref_n == ref_p * sp / sn or ref_n == pytest.approx(ref_p * sp / sn, rel=1e-15)   # the slop divides
+            else:
+                assert ref_n == ref_p, (sc, ref_n, ref_p)
