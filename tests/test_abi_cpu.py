@@ -194,6 +194,19 @@ def test_search_seam_argument_errors_are_loud_and_exception_free(lib):
     sl.RSGPU_Postings_Free(None)
     sl.RSGPU_DocTable_Free(None)
     assert lib.RSGPU_SetTuning(b"no_such_knob", 1) == -1 and lib.RSGPU_SetTuning(None, 1) == -1
+    # round 4: the hybrid tree query -- an empty tree / a NULL list is refused before any device work, and its knobs exist
+    args = S.HybridQueryArgs()
+    assert sl.RSGPU_HybridTreeQuery(None, C.byref(args)) == -1 and "empty tree" in V.last_error()
+    first = (C.c_size_t * 3)(0, 1, 2)
+    nul = (C.c_void_p * 2)()
+    tq = S.TreeQuery(S.OP_INTERSECT, 2, C.cast(first, C.c_void_p), None, None, C.cast(nul, C.c_void_p), -1, 0)
+    assert sl.RSGPU_HybridTreeQuery(C.byref(tq), C.byref(args)) == -1 and "NULL list" in V.last_error()
+    tq.root_op = 7
+    assert sl.RSGPU_HybridTreeQuery(C.byref(tq), C.byref(args)) == -1 and "root_op" in V.last_error()
+    assert sl.RSGPU_HybridQueryPath() in (0, 1, 2)
+    for knob in (b"hybrid_tree_tiles", b"hybrid_force_general", b"prioritize_union_children"):
+        assert lib.RSGPU_SetTuning(knob, 0) == 0
+    assert lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1) == 0
 
 
 def test_posting_upload_refuses_what_cannot_be_a_block_list(lib):
