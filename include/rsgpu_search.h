@@ -222,6 +222,11 @@ RSGPU_Hits *RSGPU_Union(RSGPU_Postings *const *lists, size_t n_lists);
 #define RSGPU_OP_TERM 0
 #define RSGPU_OP_UNION 1
 #define RSGPU_OP_INTERSECT 2
+/* The tree is evaluated AS GIVEN: an aggregate with a single child stays an aggregate (its weight applies, the result holds
+ * an Intersection / Union record around the child).  The reference reduces such nodes BEFORE it builds iterators -- an
+ * intersection with one real child becomes that child, wildcards are stripped, an empty child empties the whole
+ * (new_intersection_iterator, rqe_iterators/src/intersection.rs:354-420; the union reducer likewise) -- so a caller that
+ * mirrors the query AST applies those reductions first (RSGPU_EvalTreeNodes: the same). */
 typedef struct {
   int root_op;                 /* RSGPU_OP_INTERSECT or RSGPU_OP_UNION */
   size_t n_groups;
