@@ -41,6 +41,10 @@ import time
 
 import numpy as np
 
+# RCCL prints its version banner to stdout when a communicator comes up; this script's stdout is the driver's one JSON line:
+# ask the library to route the banner to stderr (opt-in since round 5 -- the swap is process-wide, csrc/shard_comm.cpp)
+os.environ.setdefault("RSGPU_QUIET_RCCL_BANNER", "1")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

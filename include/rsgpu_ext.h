@@ -41,6 +41,12 @@ long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t f
 /* Stored rows [row_begin, row_begin+n) in storage order, as they are in HBM (cosine rows: normalised), tightly packed
  * into host memory (n * dim * sizeof(type) bytes).  Inspection / tests.  0 on success. */
 int RSGPU_FlatIndex_ReadRows(VecSimIndex *index, size_t row_begin, size_t n, void *host_out);
+/* How the index maps labels (doc ids) to storage rows right now (csrc/label_table.hpp): 0 identity labelling -- label = base +
+ * row, no table; 1 a direct-addressed table in HBM that the hybrid kernels read (it survives DeleteVector, re-adds under new
+ * ids, documents without a vector, multi-value labels); 2 labels too sparse for a table -- host hash maps, the hybrid entry
+ * points translate on the host.  -1: a sharded handle (ask the shards).  Inspection / tests; the reference looks vectors up by
+ * label in src/iterators/hybrid_reader.c:309-327. */
+int RSGPU_FlatIndex_LabelTable(VecSimIndex *index);
 /* Top-k of one host query written to DEVICE buffers (k fp32 scores, k u64 labels; unused slots get
  * +inf / UINT64_MAX), ordered by (score,label). The call returns after the results are complete.
  * Returns the number of hits or -1. */

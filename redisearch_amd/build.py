@@ -25,7 +25,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-
 # library name -> sources
 LIBS = {
     "libVectorSimilarity.so": ["scan_kernels.hip", "scan_mq_kernels.hip", "select_kernels.hip", "gemm_kernels.hip", "gemm_qs_kernels.hip", "fusion_kernels.hip", "postings_kernels.hip", "hybrid_kernels.hip", "corpus_kernels.hip", "exchange_kernels.hip",
-                               "flat_index.cpp", "grow_buffer.cpp", "batch_query.cpp", "sharded_index.cpp", "shard_comm.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
+                               "flat_index.cpp", "label_table.cpp", "grow_buffer.cpp", "batch_query.cpp", "sharded_index.cpp", "shard_comm.cpp", "vecsim_abi.cpp", "search_abi.cpp"],
 }
 
 

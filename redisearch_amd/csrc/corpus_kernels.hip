@@ -129,4 +129,33 @@ void launch_max_f32_bits(const float *v, uint32_t begin, uint32_t end, uint32_t 
   hipLaunchKernelGGL(max_f32_bits_kernel, dim3(need < 1024 ? need : 1024), dim3(256), 0, s, v, begin, end, out_bits);
 }
 
+// ---- label table maintenance (label_table.cpp) ----
+__global__ __launch_bounds__(256) void label_fill_kernel(uint32_t *__restrict__ dst, size_t begin, size_t end, size_t lo, size_t hi,
+                                                         uint32_t first) {
+  for (size_t i = begin + (size_t)blockIdx.x * 256 + threadIdx.x; i < end; i += (size_t)gridDim.x * 256)
+    dst[i] = (i >= lo && i < hi) ? first + (uint32_t)(i - lo) : kNoRow;
+}
+__global__ __launch_bounds__(256) void label_scatter_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ idx,
+                                                            const uint32_t *__restrict__ val, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[idx[i]] = val[i];
+}
+__global__ __launch_bounds__(256) void label_decode_kernel(uint32_t *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] -= 1u;
+}
+void launch_label_fill(uint32_t *dst, size_t begin, size_t end, size_t lo, size_t hi, uint32_t first, hipStream_t s) {
+  if (end <= begin) return;
+  const size_t need = (end - begin + 255) / 256;
+  hipLaunchKernelGGL(label_fill_kernel, dim3((uint32_t)std::min<size_t>(need, 256u * 32u)), dim3(256), 0, s, dst, begin, end, lo, hi, first);
+}
+void launch_label_scatter(uint32_t *dst, const uint32_t *idx, const uint32_t *val, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(label_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, idx, val, n);
+}
+void launch_label_decode(uint32_t *dst, size_t n, hipStream_t s) {
+  if (!n) return;
+  const size_t need = (n + 255) / 256;
+  hipLaunchKernelGGL(label_decode_kernel, dim3((uint32_t)std::min<size_t>(need, 256u * 32u)), dim3(256), 0, s, dst, n);
+}
+
 }  // namespace rsgpu

@@ -290,7 +290,8 @@ static std::atomic<uint64_t> g_uid{1};
 
 FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     : type(p.type), metric(p.metric), dim(p.dim), multi(p.multi),
-      block_size(p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE), log_ctx(lctx) {
+      block_size(p.blockSize ? p.blockSize : DEFAULT_BLOCK_SIZE), log_ctx(lctx),
+      labels_(p.multi, round_up(p.dim * type_size(p.type), 16), &row_label_, &host_bytes_) {
   ktype = (int)type;
   const bool int_type = type == VecSimType_INT8 || type == VecSimType_UINT8;
   kmetric = metric == VecSimMetric_L2 ? KM_L2 : (metric == VecSimMetric_Cosine && int_type) ? KM_COS : KM_IP;
@@ -347,7 +348,7 @@ FlatIndex::~FlatIndex() {
 size_t FlatIndex::memory() const {
   return rows_buf_.physical() + shadow_buf_.physical() + s8g_f32_cap_rows_ * round_up(dim, 16) + hnorm_cap_rows_ * sizeof(float) +
          cap_rows_ * ((shadow_ == 2 ? 8 : 0) + sizeof(uint64_t)) +
-         host_bytes_ + stage_cap_ * stride_;
+         host_bytes_ + labels_.device_bytes() + stage_cap_ * stride_;
 }
 
 void FlatIndex::grow(size_t min_rows) {
@@ -405,6 +406,7 @@ void FlatIndex::grow(size_t min_rows) {
     d_sscale_ = nsc;
   }
   cap_rows_ = new_cap;
+  labels_.set_row_capacity(new_cap);
 }
 
 // new rows [row_begin,row_end) -> shadow, queued on wstream_ behind the copies / normalisation that produced them;
@@ -435,44 +437,6 @@ void FlatIndex::reserve(size_t rows) {
 void FlatIndex::normalize_host(void *blob) const {
   if (type == VecSimType_INT8 || type == VecSimType_UINT8) return;
   normalize_blob(blob, dim, type);
-}
-
-void FlatIndex::break_identity() {
-  if (!identity_) return;
-  identity_ = false;
-  size_t total = row_label_.size();
-  if (multi) {
-    multi_map_.reserve(total);
-    for (size_t r = 0; r < total; r++) rows_slot(row_label_[r]).push_back((uint32_t)r);
-  } else {
-    single_map_.reserve(total);
-    for (size_t r = 0; r < total; r++) single_map_[row_label_[r]] = (uint32_t)r;
-  }
-}
-
-void FlatIndex::map_insert(size_t label, uint32_t row) {
-  if (identity_) {
-    if (row == 0) identity_base_ = label;
-    if (label == identity_base_ + row) return;
-    break_identity();  // row_label_ does not contain `row` yet
-  }
-  if (multi) rows_slot(label).push_back(row);
-  else single_map_[label] = row;
-}
-
-void FlatIndex::rows_of(size_t label, std::vector<uint32_t> &out) const {
-  out.clear();
-  if (identity_) {
-    if (label >= identity_base_ && label - identity_base_ < row_label_.size()) out.push_back((uint32_t)(label - identity_base_));
-    return;
-  }
-  if (multi) {
-    auto it = multi_map_.find(label);
-    if (it != multi_map_.end()) out.assign(it->second.begin(), it->second.end());
-  } else {
-    auto it = single_map_.find(label);
-    if (it != single_map_.end()) out.push_back(it->second);
-  }
 }
 
 // int8 shadow with one index-wide scale (shadow_ == 3), brought up to date with the rows: see flat_index.hpp.
@@ -615,6 +579,7 @@ void FlatIndex::flush() {
   HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + n_rows_, stage_n_ * sizeof(uint64_t),
                            hipMemcpyHostToDevice, wstream_));
   shadow_convert(n_rows_, (uint32_t)(n_rows_ + stage_n_));
+  labels_.sync_device(wstream_);  // the staged rows' table entries
   HIP_CHECK(hipStreamSynchronize(wstream_));
   n_rows_ += (uint32_t)stage_n_;
   stage_n_ = 0;
@@ -640,7 +605,7 @@ int FlatIndex::add(const void *blob, size_t label) {
   memcpy(dst, blob, elem_bytes_);
   if (metric == VecSimMetric_Cosine) normalize_host(dst);
   uint32_t row = (uint32_t)(n_rows_ + stage_n_);
-  map_insert(label, row);
+  labels_.insert(label, row, wstream_);
   row_label_.push_back(label);
   stage_n_++;
   return ret;
@@ -653,7 +618,7 @@ int FlatIndex::remove(size_t label) {
   std::vector<uint32_t> rows;
   rows_of(label, rows);
   if (rows.empty()) return 0;
-  break_identity();
+  labels_.leave_identity(wstream_);
   std::sort(rows.begin(), rows.end(), std::greater<uint32_t>());
   for (uint32_t r : rows) {
     uint32_t last = n_rows_ - 1;
@@ -671,12 +636,7 @@ int FlatIndex::remove(size_t label) {
         HIP_CHECK(hipMemcpyAsync(d_sscale_ + 2 * (size_t)r, d_sscale_ + 2 * (size_t)last, 2 * sizeof(float), hipMemcpyDeviceToDevice,
                                  wstream_));
       row_label_[r] = moved;
-      if (multi) {
-        auto &v = rows_slot(moved);
-        for (auto &x : v) if (x == last) x = r;
-      } else {
-        single_map_[moved] = r;
-      }
+      labels_.move_row(moved, last, r);
     }
     row_label_.pop_back();
     n_rows_--;
@@ -685,9 +645,9 @@ int FlatIndex::remove(size_t label) {
     s8g_seen_ = std::min(s8g_seen_, n_rows_);
     hn_built_ = std::min(hn_built_, n_rows_);
   }
+  labels_.erase_label(label);
+  labels_.sync_device(wstream_);  // the two or three table entries this delete touched
   HIP_CHECK(hipStreamSynchronize(wstream_));
-  if (multi) multi_map_.erase(label);
-  else single_map_.erase(label);
   layout_epoch++;
   return (int)rows.size();
 }
@@ -696,14 +656,7 @@ int FlatIndex::remove(size_t label) {
 // (AddVector's overwrite semantics would need a row-by-row path; the caller uses AddVector for that)
 void FlatIndex::check_bulk_labels(size_t n, size_t first_label) const {
   if (multi) return;
-  if (identity_) {
-    const uint64_t lo = identity_base_, hi = identity_base_ + row_label_.size();  // stored labels [lo,hi)
-    if (!row_label_.empty() && first_label < hi && first_label + n > lo)
-      throw std::runtime_error("bulk load: label range overlaps stored labels");
-  } else {
-    for (size_t i = 0; i < n; i++)
-      if (single_map_.count(first_label + i)) throw std::runtime_error("bulk load: label already stored");
-  }
+  if (labels_.any_in_range(first_label, n)) throw std::runtime_error("bulk load: label range overlaps stored labels");
 }
 
 void FlatIndex::commit_bulk_rows(size_t n, size_t first_label) {
@@ -711,22 +664,12 @@ void FlatIndex::commit_bulk_rows(size_t n, size_t first_label) {
     launch_normalize_rows(d_rows_, stride_, (uint32_t)dim, ktype, n_rows_, (uint32_t)(n_rows_ + n), wstream_);
   shadow_convert(n_rows_, (uint32_t)(n_rows_ + n));
   const size_t old = row_label_.size();
-  if (identity_) {
-    if (old == 0) identity_base_ = first_label;
-    // still label == base + row for every row?  otherwise the maps are built now, from the rows stored so far
-    if (first_label != identity_base_ + old) break_identity();
-  }
+  // still label == base + row for every row?  otherwise the table takes the new (label, row) pairs -- it appears now if this
+  // very call ends identity labelling
+  labels_.insert_range(first_label, (uint32_t)old, n, wstream_);
   row_label_.resize(old + n);
   for (size_t i = 0; i < n; i++) row_label_[old + i] = first_label + i;
-  if (!identity_) {
-    // maps exist (an earlier delete / out-of-order add / this very call): every new (label,row) goes in
-    if (multi) {
-      for (size_t i = 0; i < n; i++) rows_slot(first_label + i).push_back((uint32_t)(old + i));
-    } else {
-      single_map_.reserve(single_map_.size() + n);
-      for (size_t i = 0; i < n; i++) single_map_[first_label + i] = (uint32_t)(old + i);
-    }
-  }
+  labels_.sync_device(wstream_);
   HIP_CHECK(hipMemcpyAsync(d_labels_ + n_rows_, row_label_.data() + old, n * sizeof(uint64_t), hipMemcpyHostToDevice, wstream_));
   HIP_CHECK(hipStreamSynchronize(wstream_));
   HIP_CHECK(hipGetLastError());
@@ -779,14 +722,11 @@ size_t FlatIndex::size() {
 }
 bool FlatIndex::contains(size_t label) {
   std::shared_lock<std::shared_mutex> g(mu);
-  std::vector<uint32_t> rows;
-  rows_of(label, rows);
-  return !rows.empty();
+  return labels_.contains(label);
 }
 size_t FlatIndex::label_count() {
   std::shared_lock<std::shared_mutex> g(mu);
-  if (!multi || identity_) return (size_t)n_rows_ + stage_n_;
-  return multi_map_.size();
+  return multi ? labels_.label_count() : (size_t)n_rows_ + stage_n_;
 }
 
 VecSimIndexBasicInfo FlatIndex::basic_info() const {

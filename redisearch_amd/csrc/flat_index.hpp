@@ -24,6 +24,7 @@
 #include "common.hpp"
 #include "grow_buffer.hpp"
 #include "kernels.hpp"
+#include "label_table.hpp"
 
 namespace rsgpu {
 
@@ -226,11 +227,12 @@ class FlatIndex {
     return row_label_[row];
   }
   size_t label_of_row(uint32_t row) const { return (size_t)label_at(row); }
-  // labels are identity_base + row for every row (no hash map needed, device can translate)
-  bool identity_labels(uint64_t *base) const {
-    if (base) *base = identity_base_;
-    return identity_;
-  }
+  // labels are base + row for every row (no table at all)
+  bool identity_labels(uint64_t *base) const { return labels_.identity(base); }
+  // label -> row as the kernels take it (label_table.hpp); false: the labels are too sparse for a device table and the
+  // caller translates on the host (first_row_of / gather)
+  bool device_label_rows(LabelRows *out) const { return labels_.device_view(n_rows_, out); }
+  int label_mode() const { return (int)labels_.mode(); }
   // first committed row of a label, 0xFFFFFFFF when absent
   uint32_t first_row_of(size_t label) const {
     std::vector<uint32_t> r;
@@ -263,12 +265,10 @@ class FlatIndex {
 
  private:
   void grow(size_t min_rows);
-  void break_identity();
   void normalize_host(void *blob) const;
-  void map_insert(size_t label, uint32_t row);
   void check_bulk_labels(size_t n, size_t first_label) const;
   void commit_bulk_rows(size_t n, size_t first_label);  // normalise/shadow/label the n rows written behind n_rows_
-  void rows_of(size_t label, std::vector<uint32_t> &out) const;
+  void rows_of(size_t label, std::vector<uint32_t> &out) const { labels_.rows_of(label, out); }
 
   size_t elem_bytes_, stride_;
   // optional low-precision shadow of the rows (FLOAT32, single-value; chosen at creation by ScanTuning::shadow16 --
@@ -349,24 +349,10 @@ class FlatIndex {
   uint8_t *h_stage_ = nullptr;
   size_t stage_cap_ = 0, stage_n_ = 0;
   hipStream_t wstream_ = nullptr;
-  // host maps
   // host maps live in memory from the installed VecSimMemoryFunctions and are counted (memory())
   size_t host_bytes_ = 0;
-  using RowVec = std::vector<uint32_t, HookAlloc<uint32_t>>;
-  using SingleMap = std::unordered_map<uint64_t, uint32_t, std::hash<uint64_t>, std::equal_to<uint64_t>,
-                                       HookAlloc<std::pair<const uint64_t, uint32_t>>>;
-  using MultiMap = std::unordered_map<uint64_t, RowVec, std::hash<uint64_t>, std::equal_to<uint64_t>,
-                                      HookAlloc<std::pair<const uint64_t, RowVec>>>;
   std::vector<uint64_t, HookAlloc<uint64_t>> row_label_{HookAlloc<uint64_t>(&host_bytes_)};  // committed + staged rows
-  bool identity_ = true;             // label == identity_base_ + row for every row, map unused
-  uint64_t identity_base_ = 0;
-  SingleMap single_map_{0, std::hash<uint64_t>(), std::equal_to<uint64_t>(), SingleMap::allocator_type(&host_bytes_)};
-  MultiMap multi_map_{0, std::hash<uint64_t>(), std::equal_to<uint64_t>(), MultiMap::allocator_type(&host_bytes_)};
-  RowVec &rows_slot(uint64_t label) {  // multi_map_[label], created with the counting allocator
-    auto it = multi_map_.find(label);
-    if (it == multi_map_.end()) it = multi_map_.emplace(label, RowVec(HookAlloc<uint32_t>(&host_bytes_))).first;
-    return it->second;
-  }
+  LabelTable labels_;  // label -> row(s): host copy + the device copy the kernels read (label_table.hpp)
 };
 
 // ---- reply objects (plain C structs behind the opaque ABI types) ----------------------------------

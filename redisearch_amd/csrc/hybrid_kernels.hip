@@ -235,6 +235,43 @@ __device__ __forceinline__ void hyb_knn_distances(const Args &A, const uint32_t 
   }
 }
 
+// One row's distance by its group of G lanes -- the gather's operations in its order (chunk i of a lane is lane + i G, absent
+// chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly): the bits of scan_kernel<GATHER>.
+template <int TYPE, int METRIC>
+__device__ __forceinline__ float hyb_row_distance(const void *rows_v, uint32_t stride16, uint32_t chunks, int G, int ITERS, uint32_t row,
+                                                  const u4 *qs, uint32_t gl) {
+  const u4 *__restrict__ p = reinterpret_cast<const u4 *>(rows_v) + (size_t)row * stride16;
+  float acc = 0.0f;
+  for (int i = 0; i < ITERS; i++) {
+    const uint32_t ch = gl + (uint32_t)i * (uint32_t)G;
+    const bool ok = ch < chunks;
+    const u4 x = load16<true>(p + (ok ? ch : 0u));
+    const u4 q = ok ? qs[ch] : zero4();
+    acc = Op<TYPE, METRIC>::add(acc, ok ? x : zero4(), q);
+  }
+  return finish<TYPE, METRIC>(group_reduce_rt(acc, G), zero4());
+}
+
+// Multi-value indexes off identity labelling (A.L.next): a document's distance is the MINIMUM over its vectors
+// (VecSimIndex_GetDistanceFrom_Unsafe of a multi index; FlatIndex::gather).  vkey[j] holds the key of the label's first row
+// vrow[j]; the label's further rows follow through next[].  A NaN's key is the largest: a number beats it.
+template <int TYPE, int METRIC, typename Args>
+__device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t *vrow, uint32_t *vkey, uint32_t nv, const u4 *qs) {
+  const int G = A.G;
+  const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
+  for (uint32_t j = grp; j < nv; j += GPB) {
+    uint32_t best = 0xFFFFFFFFu;
+    uint32_t r = A.L.next[vrow[j]];
+    for (uint32_t guard = 0; r < A.L.n_rows && guard < A.L.n_rows; guard++) {
+      const float d = hyb_row_distance<TYPE, METRIC>(A.rows, A.stride16, A.chunks, G, A.ITERS, r, qs, gl);
+      const uint32_t key = f2key(d);
+      best = key < best ? key : best;
+      r = A.L.next[r];
+    }
+    if (gl == 0 && best < vkey[j]) vkey[j] = best;
+  }
+}
+
 // phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
 #define RSGPU_HYB_MARK(p)                                                                                   \
   do {                                                                                                      \
@@ -301,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           bool u0, u1;
           const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
           const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
-          const uint32_t bf = xf >> sh, bn = (xn >> sh) + 1;
+          const uint32_t bf = xf >> sh, bn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);  // (xn = 2^32 - 1 at shift 0 must not wrap)
           const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
           w_lo = dlo;
           w_hi = i_next < n0 ? dhi : nl;
@@ -392,6 +429,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   __syncthreads();
   if (threadIdx.x == 0) A.tile_hits[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
   RSGPU_HYB_MARK(3);
+
+  // the hits' vector rows: identity arithmetic, or one gather from the device label table -- requested here, in flight while
+  // branch A scores (hybrid_reader.c:309-327 looks every candidate up by label)
+  uint32_t vr[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; k++) vr[k] = (A.k && hit[k]) ? label_first_row(A.L, A.ids_base + xc[k]) : kNoRow;
 
   // ---- branch A: score, the tile's top-N ----
   // The hits (about a hundred of 1 024 drivers in configs[4]) are compacted first -- doc id, frequency in the driving list and
@@ -487,8 +530,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     uint32_t *vrow = win, *vx = win + TILE, *vkey = win + 2 * TILE;
 #pragma unroll
     for (int k = 0; k < DPT; k++) {
-      const uint64_t id = A.ids_base + xc[k];
-      const bool has = hit[k] && id >= A.knn_base && id - A.knn_base < A.n_rows;
+      const bool has = vr[k] != kNoRow;
       const unsigned long long m = __ballot(has);
       if (m) {
         uint32_t first = 0;
@@ -497,7 +539,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         first = __shfl(first, leader, 64);
         if (has) {
           const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          vrow[slot] = (uint32_t)(id - A.knn_base);
+          vrow[slot] = vr[k];
           vx[slot] = xc[k];
         }
       }
@@ -506,6 +548,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     const uint32_t nv = nv_sh;
     hyb_knn_distances<TYPE, METRIC>(A, vrow, vkey, nv, qs);
     __syncthreads();
+    if (A.L.next) {
+      hyb_knn_chain_min<TYPE, METRIC>(A, vrow, vkey, nv, qs);
+      __syncthreads();
+    }
     RSGPU_HYB_MARK(7);
     uint64_t vk_mine[DPT];
     uint32_t vx_mine[DPT];
@@ -834,7 +880,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
           bool u0, u1;
           const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
           const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
-          const uint32_t bf = xf >> sh, bn = (xn >> sh) + 1;
+          const uint32_t bf = xf >> sh, bn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);  // (xn = 2^32 - 1 at shift 0 must not wrap)
           const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
           w_lo = dlo;
           w_hi = i_next < n0 ? dhi : nl;
@@ -1064,8 +1110,8 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
       const uint32_t e = j * 256 + threadIdx.x;
-      const uint64_t id = A.ids_base + my_x[j];
-      const bool has = e < nh && id >= A.knn_base && id - A.knn_base < A.n_rows;
+      const uint32_t vr = e < nh ? label_first_row(A.L, A.ids_base + my_x[j]) : kNoRow;
+      const bool has = vr != kNoRow;
       const unsigned long long m = __ballot(has);
       if (m) {
         uint32_t first = 0;
@@ -1074,7 +1120,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
         first = __shfl(first, leader, 64);
         if (has) {
           const uint32_t s = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          vrow[s] = (uint32_t)(id - A.knn_base);
+          vrow[s] = vr;
           vx[s] = my_x[j];
         }
       }
@@ -1083,6 +1129,10 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
     const uint32_t nv = nv_sh;
     hyb_knn_distances<TYPE, METRIC>(A, vrow, vkey, nv, qs);
     __syncthreads();
+    if (A.L.next) {
+      hyb_knn_chain_min<TYPE, METRIC>(A, vrow, vkey, nv, qs);
+      __syncthreads();
+    }
     uint64_t vk_mine[DPT];
     uint32_t vx_mine[DPT];
 #pragma unroll
@@ -1096,6 +1146,50 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
                        A.part_knn[(size_t)blockIdx.x * A.k + rank] = (my.k << 32) | my.i;
                      });
     if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
+  }
+}
+
+// The staged pipeline's form of hyb_knn_chain_min: dists[i] (of the label's first row first_rows[i], written by the gather)
+// becomes the minimum over the label's rows.  The query is staged in LDS; one group of G lanes per candidate.
+struct KnnChainArgs {
+  const void *rows;
+  uint32_t stride16, chunks;
+  int G, ITERS;
+  const void *query;
+  const uint32_t *first_rows;
+  uint32_t m;
+  const uint32_t *m_dev;
+  LabelRows L;
+  float *dists;
+};
+template <int TYPE, int METRIC>
+__global__ __launch_bounds__(256) void knn_chain_min_kernel(KnnChainArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_q[];
+  u4 *qs = reinterpret_cast<u4 *>(lds_q);
+  for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
+  __syncthreads();
+  const int G = A.G;
+  const uint32_t gl = threadIdx.x & (uint32_t)(G - 1), grp = threadIdx.x / (uint32_t)G, GPB = 256u / (uint32_t)G;
+  uint32_t m = A.m;
+  if (A.m_dev) {
+    const uint32_t md = *A.m_dev;
+    m = md < m ? md : m;
+  }
+  for (uint32_t i = blockIdx.x * GPB + grp; i < m; i += gridDim.x * GPB) {
+    const uint32_t r0 = A.first_rows[i];
+    if (r0 >= A.L.n_rows) continue;
+    float best = A.dists[i];
+    bool changed = false;
+    uint32_t r = A.L.next[r0];
+    for (uint32_t guard = 0; r < A.L.n_rows && guard < A.L.n_rows; guard++) {
+      const float d = hyb_row_distance<TYPE, METRIC>(A.rows, A.stride16, A.chunks, G, A.ITERS, r, qs, gl);
+      if (best != best || d < best) {  // (FlatIndex::gather: a number beats a NaN)
+        best = d;
+        changed = true;
+      }
+      r = A.L.next[r];
+    }
+    if (gl == 0 && changed) A.dists[i] = best;
   }
 }
 
@@ -1216,6 +1310,38 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, 
   else if (metric == KM_L2) RSGPU_HYBT(KT_BF16, KM_L2);
   else RSGPU_HYBT(KT_BF16, KM_IP);
 #undef RSGPU_HYBT
+}
+bool knn_chain_supported(int type, int metric, uint32_t stride16) {
+  if (type != KT_F32 && type != KT_F16 && type != KT_BF16) return false;
+  if (metric != KM_L2 && metric != KM_IP) return false;
+  return stride16 >= 1 && stride16 <= (uint32_t)kHybMaxChunks;
+}
+void launch_knn_chain_min(const void *rows, size_t stride, int type, int metric, const uint32_t *first_rows, uint32_t m,
+                          const uint32_t *m_dev, const LabelRows &L, const void *query, float *dists, hipStream_t s) {
+  if (!m || !L.next) return;
+  KnnChainArgs a;
+  a.rows = rows;
+  a.stride16 = a.chunks = (uint32_t)(stride / 16);
+  const Shape sh = pick_shape(a.stride16);
+  a.G = sh.G;
+  a.ITERS = sh.ITERS;
+  a.query = query;
+  a.first_rows = first_rows;
+  a.m = m;
+  a.m_dev = m_dev;
+  a.L = L;
+  a.dists = dists;
+  const uint32_t gpb = 256u / (uint32_t)a.G, need = (m + gpb - 1) / gpb;
+  const dim3 grid(need < 2048 ? need : 2048);
+  const size_t lds = (size_t)a.chunks * 16;
+#define RSGPU_CH(T, M) hipLaunchKernelGGL((knn_chain_min_kernel<T, M>), grid, dim3(256), lds, s, a)
+  if (type == KT_F32 && metric == KM_L2) RSGPU_CH(KT_F32, KM_L2);
+  else if (type == KT_F32) RSGPU_CH(KT_F32, KM_IP);
+  else if (type == KT_F16 && metric == KM_L2) RSGPU_CH(KT_F16, KM_L2);
+  else if (type == KT_F16) RSGPU_CH(KT_F16, KM_IP);
+  else if (metric == KM_L2) RSGPU_CH(KT_BF16, KM_L2);
+  else RSGPU_CH(KT_BF16, KM_IP);
+#undef RSGPU_CH
 }
 void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
                              const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,

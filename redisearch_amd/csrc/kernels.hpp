@@ -21,6 +21,33 @@ enum : int { KM_L2 = 0, KM_IP = 1, KM_COS = 2, KM_IPS = 3, KM_L2S = 4 };
 struct RowBand;
 inline int key_bytes_of(int type) { return type == KT_F64 ? 8 : 4; }
 
+// ---- label (doc id) -> storage row, as the kernels see it (label_table.hpp keeps it current under the index's writer lock) ----
+// The reference looks a candidate's vector up by label (src/iterators/hybrid_reader.c:309-327, VecSimIndex_GetDistanceFrom_Unsafe);
+// a label is a doc id: documents without the vector field have no row, an update is delete + a new id (src/indexer.c:179-190).
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+struct LabelRows {
+  const uint32_t *row_of;  // [span] first row of label base + i (>= n_rows: none); nullptr: identity labels, row = label - base
+  const uint32_t *next;    // multi-value indexes off identity labelling: [n_rows] the label's next row (>= n_rows: none); else nullptr
+  uint64_t base;
+  uint32_t span;           // labels in [base, base + span) may have a row
+  uint32_t n_rows;         // committed rows
+};
+#ifdef __HIPCC__
+// first row of doc id `id`, kNoRow when the document has no vector
+__device__ __forceinline__ uint32_t label_first_row(const LabelRows &m, uint64_t id) {
+  const uint64_t off = id - m.base;
+  if (id < m.base || off >= (uint64_t)m.span) return kNoRow;
+  const uint32_t r = m.row_of ? m.row_of[off] : (uint32_t)off;
+  return r < m.n_rows ? r : kNoRow;
+}
+#endif
+// table maintenance (corpus_kernels.hip): dst[i] = first + (i - lo) for i in [lo, hi), kNoRow elsewhere, i in [begin, end)
+void launch_label_fill(uint32_t *dst, size_t begin, size_t end, size_t lo, size_t hi, uint32_t first, hipStream_t s);
+// dst[idx[i]] = val[i], i < n (duplicate indices carry the same value)
+void launch_label_scatter(uint32_t *dst, const uint32_t *idx, const uint32_t *val, uint32_t n, hipStream_t s);
+// dst[i] -= 1 for i < n: an uploaded host table (0 = none, row + 1) becomes the device form (kNoRow = none)
+void launch_label_decode(uint32_t *dst, size_t n, hipStream_t s);
+
 // Orderable key of an fp32 distance: ascending key <=> ascending distance, NaN last.
 // (host mirror of the device f2key in scan_kernels.hip)
 inline uint32_t dist_to_key(float f) {

@@ -970,28 +970,23 @@ __global__ __launch_bounds__(256) void score_normalize_kernel(double *__restrict
 }
 
 __global__ __launch_bounds__(256) void labels_to_rows_kernel(const uint32_t *__restrict__ ids, uint32_t n,
-                                                             uint64_t ids_base, uint64_t base, uint32_t n_rows,
-                                                             uint32_t *__restrict__ rows) {
+                                                             uint64_t ids_base, LabelRows L, uint32_t *__restrict__ rows) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const uint64_t id = ids_base + ids[i];
-  rows[i] = (id >= base && id - base < n_rows) ? (uint32_t)(id - base) : 0xFFFFFFFFu;
+  rows[i] = label_first_row(L, ids_base + ids[i]);
 }
 
 // The hits that have a vector, compacted (order does not matter: the selection that follows ranks by (distance, hit
 // index)): rows_out[slot] = storage row, cand[slot] = (hit index, 0); count[0] = how many (slots >= cap are dropped and
 // the caller sees count > cap).  One atomic per wavefront.
 __global__ __launch_bounds__(256) void labels_to_cand_kernel(const uint32_t *__restrict__ ids, uint32_t n, uint64_t ids_base,
-                                                             uint64_t base, uint32_t n_rows, uint32_t *__restrict__ rows_out,
+                                                             LabelRows L, uint32_t *__restrict__ rows_out,
                                                              uint2 *__restrict__ cand, uint32_t *__restrict__ count,
                                                              uint32_t cap) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  uint64_t id = 0;
-  bool has = false;
-  if (i < n) {
-    id = ids_base + ids[i];
-    has = id >= base && id - base < n_rows;
-  }
+  uint32_t row = kNoRow;
+  if (i < n) row = label_first_row(L, ids_base + ids[i]);
+  const bool has = row != kNoRow;
   const unsigned long long m = __ballot(has);
   if (!m) return;
   uint32_t first = 0;
@@ -1000,7 +995,7 @@ __global__ __launch_bounds__(256) void labels_to_cand_kernel(const uint32_t *__r
   if (!has) return;
   const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   if (slot < cap) {
-    rows_out[slot] = (uint32_t)(id - base);
+    rows_out[slot] = row;
     cand[slot] = make_uint2(i, 0u);
   }
 }
@@ -1339,16 +1334,15 @@ void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, ui
   hipLaunchKernelGGL(score_normalize_kernel, dim3(need), dim3(256), 0, s, scores, keys, len,
                      (const unsigned long long *)max_key_zeroed);
 }
-void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows, uint32_t *rows,
-                           hipStream_t s) {
+void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, const LabelRows &L, uint32_t *rows, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(labels_to_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, base, n_rows, rows);
+  hipLaunchKernelGGL(labels_to_rows_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, L, rows);
 }
-void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows,
-                           uint32_t *rows_out, void *cand, uint32_t *count, uint32_t cap, hipStream_t s) {
+void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, const LabelRows &L, uint32_t *rows_out, void *cand,
+                           uint32_t *count, uint32_t cap, hipStream_t s) {
   if (!n) return;
-  hipLaunchKernelGGL(labels_to_cand_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, base, n_rows, rows_out,
-                     (uint2 *)cand, count, cap);
+  hipLaunchKernelGGL(labels_to_cand_kernel, dim3(blocks_for(n)), dim3(256), 0, s, ids, n, ids_base, L, rows_out, (uint2 *)cand, count,
+                     cap);
 }
 uint32_t knn_topk_max_k() { return kKnnTopkMaxK; }
 size_t knn_topk_scratch_bytes() { return (size_t)kKnnTopkBlocks * kKnnTopkMaxK * sizeof(uint64_t); }

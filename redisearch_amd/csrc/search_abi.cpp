@@ -2,8 +2,10 @@
 // device-resident posting lists in the reference's block format, GPU decode + N-way intersection,
 // the built-in scorers over the hits, score top-N and the hybrid ad-hoc KNN step.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <numeric>
+#include <thread>
 
 #include "flat_index.hpp"
 #include "rsgpu_search.h"
@@ -12,6 +14,17 @@
 using namespace rsgpu;
 
 namespace {
+// one step of a polling loop (the completion flags of the hybrid kernels in pinned memory): the x86 pause hint where there is
+// one, a yield elsewhere -- the library builds on any host (round-4 advisor)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
 
 thread_local double prof_ms[5] = {0, 0, 0, 0, 0};  // decode, intersect, score, topn, knn
 
@@ -1370,10 +1383,14 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   sc.keys32.ensure(h->len);
   f->upload_query(c.c, query, true);
   StageTimer tk(c.c, 4);
-  uint64_t base = 0;
-  if (f->multi && !f->identity_labels(nullptr)) {
-    // multi-value index with a real label map: a document's distance is the MINIMUM over its vectors, as
-    // GetDistanceFrom / the ad-hoc gather give it (FlatIndex::gather expands every label to all its rows)
+  // label -> row on the device (label_table.hpp): identity arithmetic or the direct table.  A multi-value index off identity
+  // labelling chains a label's rows: the gather's distance of the first row, then the minimum over the chain.
+  LabelRows L;
+  const bool on_device = f->device_label_rows(&L);
+  const bool chain = on_device && L.next != nullptr;
+  if (f->multi && (!on_device || (chain && !knn_chain_supported(f->ktype, f->kmetric, (uint32_t)(f->stride() / 16))))) {
+    // multi-value index whose labels have no device table (or a type without a chain kernel): a document's distance is the
+    // MINIMUM over its vectors, as GetDistanceFrom / the ad-hoc gather give it (FlatIndex::gather expands every label)
     const std::vector<uint32_t> &ids = h->host_ids();
     std::vector<size_t> labels(ids.size());
     for (size_t i = 0; i < ids.size(); i++) labels[i] = (size_t)(h->base + ids[i]);
@@ -1393,9 +1410,9 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
     }
     return (long)take;
   }
-  if (f->identity_labels(&base)) {
-    launch_labels_to_rows(h->ids.p, h->len, h->base, base, f->committed_rows(), sc.rows.p, c->stream);
-  } else {  // general label map lives on the host
+  if (on_device) {
+    launch_labels_to_rows(h->ids.p, h->len, h->base, L, sc.rows.p, c->stream);
+  } else {  // labels too sparse for a device table (label_table.hpp SPARSE): the host hash map
     const std::vector<uint32_t> &ids = h->host_ids();
     std::vector<uint32_t> rows(h->len);
     for (uint32_t i = 0; i < h->len; i++) rows[i] = f->first_row_of(h->base + ids[i]);
@@ -1404,6 +1421,7 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   }
   launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, h->len, c->d_query,
                 sc.dists.p, c->stream);
+  if (chain) launch_knn_chain_min(f->device_rows(), f->stride(), f->ktype, f->kmetric, sc.rows.p, h->len, nullptr, L, c->d_query, sc.dists.p, c->stream);
   launch_dist_to_keys(sc.dists.p, h->len, sc.keys32.p, c->stream);
   HIP_CHECK(hipGetLastError());
   std::vector<Hit> hits;
@@ -1531,16 +1549,60 @@ static void hyb_wait(QueryCtx *ca, bool may_poll, bool sync_after) {
   volatile uint32_t *done = ca->h_counters + 1;
   bool finished = false;
   if (may_poll && scan_tuning().hybrid_poll) {
-    for (int spin = 0; spin < 400000; spin++) {
+    // bounded by TIME (2 ms: forty times a query; a slower one sleeps in the stream sync below), not by an iteration count
+    // whose length depends on the host
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
       if (done[0] && done[1] && done[2]) {
         finished = true;
         break;
       }
-      __builtin_ia32_pause();
+      cpu_relax();
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!finished || sync_after) HIP_CHECK(hipStreamSynchronize(ca->stream));
+}
+// The reduce kernel met more candidates at its bound than it ranks in LDS (an adversarial arrangement of the tiles' lists: mass
+// ties across thousands of tiles) and wrote 0xFFFFFFFF instead of a count.  The tiles' lists are still in HBM: the exact radix
+// select (select_kernels.hip) takes the k smallest composites of ALL of them -- (score key, position) for the scores: a tile's
+// list is sorted by (key, doc id) and the tiles are consecutive doc-id ranges of the driving list, so position order among equal
+// keys IS doc-id order; (distance key << 32 | doc id) for the KNN lists -- and fills the pinned answers as the kernel would have.
+// Rounds 3-4 re-ran such a query through the ten-kernel staged pipeline, and a query with NOT children (no staged form) failed:
+// whether a query succeeded depended on its data (round-4 advisor).
+static void hyb_settle_overflow(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
+  if (!n_tiles) return;
+  if (top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) {
+    const uint32_t n_hits = ca->h_counters[0];  // (the select below reuses the pinned counters)
+    std::vector<Hit> top;
+    radix_select(ca, sc.hyb_skey.p, 8, n_tiles * top_n, top_n, Bound(), top, nullptr);
+    while (!top.empty() && top.back().key == ~0ull) top.pop_back();  // "none" slots of tiles with fewer hits than top_n
+    ca->ensure_gather(top.size() + 1);
+    for (size_t i = 0; i < top.size(); i++) ca->h_out_rows[i] = top[i].row;
+    if (!top.empty()) {
+      launch_gather_u32(sc.hyb_sidx.p, ca->h_out_rows, (uint32_t)top.size(), ca->h_ids, ca->stream);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(ca->stream));
+    }
+    for (size_t i = 0; i < top.size(); i++) ca->h_out_keys[i] = top[i].key;
+    ca->h_fcnt[2] = (uint32_t)top.size();
+    ca->h_counters[0] = n_hits;
+  }
+  if (k && cb->h_fcnt[2] == 0xFFFFFFFFu) {
+    std::vector<Hit> top;
+    radix_select(cb, sc.hyb_knn.p, 8, n_tiles * k, k, Bound(), top, nullptr);
+    while (!top.empty() && top.back().key == ~0ull) top.pop_back();
+    uint32_t *k32 = reinterpret_cast<uint32_t *>(cb->h_out_keys);
+    std::vector<uint64_t> comp(top.size());
+    for (size_t i = 0; i < top.size(); i++) comp[i] = top[i].key;  // (h_out_keys is the select's own staging: copy first)
+    for (size_t i = 0; i < comp.size(); i++) {
+      k32[i] = (uint32_t)(comp[i] >> 32);
+      cb->h_ids[i] = (uint32_t)comp[i];
+      cb->h_out_rows[i] = (uint32_t)comp[i];
+    }
+    cb->h_fcnt[2] = (uint32_t)comp.size();
+  }
 }
 // the answers out of pinned memory; false: the reduce kernel met more candidates at its bound than it ranks -- or, BM25STD.NORM,
 // the division made a tie across the cut (below): the staged pipeline takes the query.
@@ -1609,7 +1671,7 @@ static void hyb_profile(bool prof, FusedEvents &ev, uint32_t n_tiles) {
 // lock and has checked the shapes (hybrid_tile_supported); ca's stream carries everything, cb lends its pinned buffers to the
 // KNN answers; the prepared query is ca->d_query.  false: the reduce kernel met more candidates at its bound than it ranks
 // (an adversarial arrangement of the tiles' lists) -- nothing was written, the staged pipeline takes the query.
-static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t knn_base, bool want_score, bool want_knn,
+static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const LabelRows &knn_rows, bool want_score, bool want_knn,
                                 QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev) {
   const size_t n_lists = a->n_lists;
   std::vector<int> order(n_lists);
@@ -1668,8 +1730,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     T.stride16 = T.chunks = (uint32_t)(f->stride() / 16);
     T.query = ca->d_query;
     T.ids_base = h.base;
-    T.knn_base = knn_base;
-    T.n_rows = f->committed_rows();
+    T.L = knn_rows;
   }
   HybridReduceArgs R;
   hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
@@ -1694,6 +1755,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, uint64_t
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof && !T.trace, false);
+    hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
   hyb_profile(prof, ev, n_tiles);
@@ -1781,7 +1843,7 @@ static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const
 // non-empty, <= kHybTreeMaxLists lists, not BM25STD.NORM).  hits_out (may be NULL): receives the hit list.  false: the reduce
 // kernel met more candidates at its bound than it ranks -- nothing was handed out, the staged pipeline takes the query.
 static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *lists, const std::vector<HybGroup> &groups, long max_slop,
-                           int in_order, RSGPU_Hits **hits_out, FlatIndex *f, uint64_t knn_base, bool want_score, bool want_knn,
+                           int in_order, RSGPU_Hits **hits_out, FlatIndex *f, const LabelRows &knn_rows, bool want_score, bool want_knn,
                            QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev) {
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
   for (const HybGroup &g : groups)
@@ -1839,7 +1901,8 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   std::vector<RSGPU_Postings *> excluded;  // NOT children's lists: probed behind the leaves, no column of their own
   for (const HybGroup &g : groups)
     if (g.op == 3)
-      for (int li : g.lists) excluded.push_back(lists[li]);
+      for (int li : g.lists)
+        if (lists[li]->n_entries) excluded.push_back(lists[li]);  // (an empty list excludes nothing)
   if (n + (int)excluded.size() > kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight lists");
   if (!excluded.empty() && hits_out) throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children has no hit list (hits_out must be NULL)");
   HybridTreeArgs T;
@@ -1930,8 +1993,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     T.stride16 = T.chunks = (uint32_t)(f->stride() / 16);
     T.query = ca->d_query;
     T.ids_base = h.base;
-    T.knn_base = knn_base;
-    T.n_rows = f->committed_rows();
+    T.L = knn_rows;
   }
   HybridReduceArgs R;
   hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
@@ -1967,6 +2029,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
+    hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
   if (hits_out) {
@@ -1997,7 +2060,7 @@ static RSGPU_Hits *eval_tree_tiles(const RSGPU_TreeQuery *q, size_t n_lists) {
   RSGPU_HybridQueryArgs none;
   memset(&none, 0, sizeof none);
   RSGPU_Hits *out = nullptr;
-  if (!hybrid_general(&none, q->lists, groups, q->max_slop, q->in_order, &out, nullptr, 0, false, false, ca.c, cb.c, scratch(device), false,
+  if (!hybrid_general(&none, q->lists, groups, q->max_slop, q->in_order, &out, nullptr, LabelRows{}, false, false, ca.c, cb.c, scratch(device), false,
                       tls_events))
     return nullptr;
   tls_hybrid_path = 2;
@@ -2021,7 +2084,7 @@ static RSGPU_Hits *intersect_tiles(RSGPU_Postings *const *lists, size_t n_lists,
   RSGPU_HybridQueryArgs none;
   memset(&none, 0, sizeof none);
   RSGPU_Hits *out = nullptr;
-  if (!hybrid_general(&none, lists, hyb_groups_flat(lists, n_lists, in_order != 0), max_slop, in_order, &out, nullptr, 0, false, false, ca.c,
+  if (!hybrid_general(&none, lists, hyb_groups_flat(lists, n_lists, in_order != 0), max_slop, in_order, &out, nullptr, LabelRows{}, false, false, ca.c,
                       cb.c, scratch(device), false, tls_events))
     return nullptr;
   tls_hybrid_path = 2;
@@ -2079,17 +2142,20 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   tls_hybrid_path = 0;
 
   // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
-  uint64_t knn_base = 0;
-  bool knn_identity = false;
+  // doc id -> row: identity arithmetic or the device label table (label_table.hpp; it survives deletes, re-adds under new
+  // ids, documents without a vector and multi-value labels).  Only labels too sparse for a table are translated on the host.
+  LabelRows knn_rows{};
+  bool knn_identity = false;  // (historic name: the KNN branch translates on the device)
   std::shared_lock<std::shared_mutex> index_lock;
   if (f) {
     index_lock = std::shared_lock<std::shared_mutex>(f->mu);
-    knn_identity = f->identity_labels(&knn_base);
-    if (!knn_identity) tiles = general = false;  // a general label map lives on the host
+    knn_identity = f->device_label_rows(&knn_rows) &&
+                   (!knn_rows.next || knn_chain_supported(f->ktype, f->kmetric, (uint32_t)(f->stride() / 16)));
+    if (!knn_identity) tiles = general = false;  // SPARSE labels live on the host
     if (knn_identity) f->upload_query((tiles || general) ? ca.c : cb.c, a->query, true);
   }
   if (tiles) {
-    if (hybrid_two_launches(a, f, knn_base, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
+    if (hybrid_two_launches(a, f, knn_rows, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
       tls_hybrid_path = 1;
       return 0;
     }
@@ -2097,7 +2163,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     if (f) f->upload_query(cb.c, a->query, true);  // (the KNN branch of the staged pipeline reads it on its own stream)
   }
   if (general) {
-    if (hybrid_general(a, a->lists, hyb_groups_flat(a->lists, a->n_lists), -1, 0, a->hits_out, f, knn_base, want_score, want_knn,
+    if (hybrid_general(a, a->lists, hyb_groups_flat(a->lists, a->n_lists), -1, 0, a->hits_out, f, knn_rows, want_score, want_knn,
                        ca.c, cb.c, sc, prof, ev)) {
       tls_hybrid_path = 2;
       return 0;
@@ -2117,7 +2183,11 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   HIP_CHECK(hipEventRecord(ca->ev1, ca->stream));
   if (!prof) {
     volatile uint32_t *pending = h_total;
-    for (int spin = 0; spin < 200000 && *pending == kCountPending; spin++) __builtin_ia32_pause();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0; *pending == kCountPending; spin++) {
+      cpu_relax();
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
   }
   if (prof || h_total[0] == kCountPending) HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #1 (profiling / a very slow query)
   HIP_CHECK(hipStreamWaitEvent(cb->stream, ca->ev1, 0));
@@ -2149,10 +2219,11 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
         sc.knn_part.ensure(knn_topk_scratch_bytes() / sizeof(uint64_t));
         if (sc.knn_dirty) HIP_CHECK(hipMemsetAsync(sc.knn_cnt.p, 0, 4 * sizeof(uint32_t), cb->stream));
         sc.knn_dirty = true;
-        launch_labels_to_cand(h->ids.p, len, h->base, knn_base, f->committed_rows(), cb->d_ids, cb->d_cand, sc.knn_cnt.p,
-                              QueryCtx::kCandCap, cb->stream);
+        launch_labels_to_cand(h->ids.p, len, h->base, knn_rows, cb->d_ids, cb->d_cand, sc.knn_cnt.p, QueryCtx::kCandCap, cb->stream);
         launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, cb->d_ids, m_up, cb->d_query,
                       cb->d_dists, cb->stream, sc.knn_cnt.p);
+        launch_knn_chain_min(f->device_rows(), f->stride(), f->ktype, f->kmetric, cb->d_ids, m_up, sc.knn_cnt.p, knn_rows, cb->d_query,
+                             cb->d_dists, cb->stream);
         launch_knn_topk(cb->d_dists, cb->d_cand, sc.knn_cnt.p, QueryCtx::kCandCap, knn_k, h->ids.p, sc.knn_part.p,
                         sc.knn_cnt.p + 1, cb->h_out_rows, (uint32_t *)cb->h_out_keys, cb->h_ids, cb->h_fcnt + 2,
                         cb->h_fcnt + 1, cb->stream);
@@ -2160,10 +2231,11 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
       } else {
       HIP_CHECK(hipMemsetAsync(cb->d_fcnt, 0, 4 * sizeof(uint32_t), cb->stream));
       HIP_CHECK(hipMemsetAsync(cb->d_ids, 0xFF, (size_t)m_up * sizeof(uint32_t), cb->stream));  // unused slots: "no vector"
-      launch_labels_to_cand(h->ids.p, len, h->base, knn_base, f->committed_rows(), cb->d_ids, cb->d_cand, cb->d_fcnt,
-                            QueryCtx::kCandCap, cb->stream);
+      launch_labels_to_cand(h->ids.p, len, h->base, knn_rows, cb->d_ids, cb->d_cand, cb->d_fcnt, QueryCtx::kCandCap, cb->stream);
       launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, cb->d_ids, m_up, cb->d_query,
                     cb->d_dists, cb->stream);
+      launch_knn_chain_min(f->device_rows(), f->stride(), f->ktype, f->kmetric, cb->d_ids, m_up, nullptr, knn_rows, cb->d_query,
+                           cb->d_dists, cb->stream);
       launch_cand_set_keys(cb->d_cand, cb->d_dists, m_up, cb->stream);
       launch_batch_select_cand(cb->d_cand, cb->d_fcnt, QueryCtx::kCandCap, knn_k, 1, cb->h_out_rows, (uint32_t *)cb->h_out_keys,
                                cb->h_fcnt + 2, knn_k, cb->h_fcnt + 1, cb->stream);
@@ -2277,9 +2349,11 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
         sc.rows.ensure(len);
         sc.dists.ensure(len);
         sc.keys32.ensure(len);
-        launch_labels_to_rows(h->ids.p, len, h->base, knn_base, f->committed_rows(), sc.rows.p, cb->stream);
+        launch_labels_to_rows(h->ids.p, len, h->base, knn_rows, sc.rows.p, cb->stream);
         launch_gather(f->device_rows(), f->stride(), (uint32_t)f->dim, f->ktype, f->kmetric, sc.rows.p, len, cb->d_query,
                       sc.dists.p, cb->stream);
+        launch_knn_chain_min(f->device_rows(), f->stride(), f->ktype, f->kmetric, sc.rows.p, len, nullptr, knn_rows, cb->d_query,
+                             sc.dists.p, cb->stream);
         launch_dist_to_keys(sc.dists.p, len, sc.keys32.p, cb->stream);
         std::vector<Hit> knn_hits;
         select_keys32(cb.c, sc.keys32.p, len, knn_k, knn_hits);
@@ -2346,7 +2420,13 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) &&
                  q->root_op == RSGPU_OP_INTERSECT && n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
   const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
-  for (size_t l = 0; l < n_lists && general; l++) general = q->lists[l]->n_entries > 0;
+  // (an EXCLUDED list may be empty -- `a -b` with an empty b is `a`: the list is simply not probed -- a required one may not)
+  std::vector<char> excluded_list(n_lists, 0);
+  if (q->group_op)
+    for (size_t g = 0; g < q->n_groups; g++)
+      if (q->group_op[g] == RSGPU_OP_NOT)
+        for (size_t l = q->group_first[g]; l < q->group_first[g + 1] && l < n_lists; l++) excluded_list[l] = 1;
+  for (size_t l = 0; l < n_lists && general; l++) general = excluded_list[l] || q->lists[l]->n_entries > 0;
   if (general) {
     const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists);
     uint32_t n0 = 0;
@@ -2360,14 +2440,14 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
       const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
       FusedEvents &ev = tls_events;
       if (prof) ev.ensure(device);
-      uint64_t knn_base = 0;
+      LabelRows knn_rows{};
       std::shared_lock<std::shared_mutex> index_lock;
       if (f) {
         index_lock = std::shared_lock<std::shared_mutex>(f->mu);
-        general = f->identity_labels(&knn_base);  // (a general label map lives on the host)
+        general = f->device_label_rows(&knn_rows);  // (labels too sparse for a device table live on the host)
         if (general) f->upload_query(ca.c, a->query, true);
       }
-      if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, knn_base, want_score, want_knn, ca.c,
+      if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, knn_rows, want_score, want_knn, ca.c,
                                     cb.c, sc, prof, ev)) {
         tls_hybrid_path = 2;
         return 0;
@@ -2379,8 +2459,8 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
     for (size_t g = 0; g < q->n_groups; g++)
       if (q->group_op[g] == RSGPU_OP_NOT)
         throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children runs on the general tile kernel only -- a root "
-                                 "intersection of at most eight lists with a term to drive it, identity labels, no hits_out, top_n / k <= 32"
-                                 " (or its reduce kernel met a mass tie at its bound)");
+                                 "intersection of at most eight lists with a term to drive it, no hits_out, top_n / k <= 32, labels a "
+                                 "device table holds (RSGPU_FlatIndex_LabelTable != 2)");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
   tls_hybrid_path = 0;  // (RSGPU_EvalTree may have built the list with the tile kernel; this QUERY ran stage by stage)

@@ -6,6 +6,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "kernels.hpp"
+
 namespace rsgpu {
 
 // record layout of a codec: qint arity and slot of each field (-1 = absent); kind 0 qint, 1 varint
@@ -180,13 +182,18 @@ void launch_hit_records(const uint32_t *hit_ids, uint32_t first, uint32_t count,
 // max_key_zeroed: one u64 of scratch, zeroed by the caller on the same stream
 void launch_score_max_normalize(double *scores, uint64_t *keys, uint32_t len, uint64_t *max_key_zeroed, hipStream_t s);
 
-// rows[i] = ids_base + ids[i] - base if inside [base, base+n_rows) else 0xFFFFFFFF  (identity-labelled FLAT index)
-void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows, uint32_t *rows,
-                           hipStream_t s);
+// rows[i] = first row of doc id ids_base + ids[i] (kernels.hpp LabelRows: identity arithmetic or the device label table), else 0xFFFFFFFF
+void launch_labels_to_rows(const uint32_t *ids, uint32_t n, uint64_t ids_base, const LabelRows &L, uint32_t *rows, hipStream_t s);
 // the hits with a vector, compacted in any order: rows_out[slot] = row, cand[slot] = (hit index, 0) (uint2), count[0] += 1
 // per hit; slots >= cap are dropped (count[0] > cap tells).  count must be zeroed by the caller on the same stream.
-void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, uint64_t base, uint32_t n_rows,
-                           uint32_t *rows_out, void *cand, uint32_t *count, uint32_t cap, hipStream_t s);
+void launch_labels_to_cand(const uint32_t *ids, uint32_t n, uint64_t ids_base, const LabelRows &L, uint32_t *rows_out, void *cand,
+                           uint32_t *count, uint32_t cap, hipStream_t s);
+// multi-value indexes off identity labelling: dists[i] = min(dists[i], distances of the further rows of rows[i]'s label) for
+// i < m (and < *m_dev when given) -- the arithmetic of the gather (hybrid_kernels.hip).  false: no such kernel for the type /
+// metric / row length (the caller expands the labels on the host)
+bool knn_chain_supported(int type, int metric, uint32_t stride16);
+void launch_knn_chain_min(const void *rows, size_t stride, int type, int metric, const uint32_t *first_rows, uint32_t m,
+                          const uint32_t *m_dev, const LabelRows &L, const void *query, float *dists, hipStream_t s);
 // k (<= knn_topk_max_k()) best of the compacted candidates by (key of dists[slot], hit index cand[slot].x), one launch:
 // winners' hit indices / u32 keys / doc ids (ids[hit]) and their number go to out_* (pinned host memory), *overflow is
 // set when *count > cap.  `part`: knn_topk_scratch_bytes() of device scratch; `count` and `ticket` (device, zero on
@@ -201,7 +208,7 @@ void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStre
 
 // ---- a whole hybrid query in two launches (hybrid_kernels.hip) ---------------------------------------------------
 // flat AND of up to kHybMaxLists term lists (list 0 drives) -> top_n by score next to the k nearest among the hits that have a
-// vector (identity-labelled FLAT index: row = doc id - knn_base).  Either branch may be off (top_n == 0 / k == 0).
+// vector (L: doc id -> row, kernels.hpp LabelRows).  Either branch may be off (top_n == 0 / k == 0).
 constexpr int kHybMaxLists = 4, kHybMaxK = 32, kHybMaxChunks = 512;
 constexpr int kHybTracePhases = 9;  // start | window ends | window staged | probe done | hits compacted | scored | ranked | distances | end
 struct HybridTileArgs {
@@ -224,8 +231,7 @@ struct HybridTileArgs {
   int G, ITERS;                        // pick_shape(stride16): the lanes-per-row shape of scan_kernel
   const void *query;                   // [chunks] 16-byte chunks, prepared as for the scan
   uint64_t ids_base;                   // doc id = ids_base + (ids[0][i] + add[0])
-  uint64_t knn_base;
-  uint32_t n_rows;
+  LabelRows L;                         // doc id -> row of the index (identity arithmetic, or the device label table)
   // per tile, fixed slots
   uint32_t *tile_hits;                 // [n_tiles]
   uint64_t *part_skey;                 // [n_tiles][top_n]  ~d2key(score), ~0 = none
@@ -320,8 +326,8 @@ struct HybridTreeArgs {
   uint32_t stride16, chunks;
   int G, ITERS;
   const void *query;
-  uint64_t ids_base, knn_base;
-  uint32_t n_rows;
+  uint64_t ids_base;
+  LabelRows L;
   int knn_pipeline;
   // per tile, fixed slots (as HybridTileArgs)
   uint32_t *tile_hits;

@@ -16,7 +16,9 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -85,9 +87,14 @@ Nccl &nccl() {
 
 // RCCL prints a version banner to STDOUT when a communicator is created; a host program's stdout may be a protocol
 // (bench.py's one JSON line): the banner goes to stderr instead.
+// Swapping fd 1 is process-wide: in a multi-threaded host another thread's stdout output would go to stderr for the seconds a
+// communicator takes to come up (round-4 advisor).  So it is OPT-IN: only when RSGPU_QUIET_RCCL_BANNER=1 is in the environment
+// (bench.py sets it: single-threaded at that point, and its stdout is the driver's protocol).
 struct StdoutToStderr {
   int saved = -1;
   StdoutToStderr() {
+    const char *e = getenv("RSGPU_QUIET_RCCL_BANNER");
+    if (!e || e[0] != '1') return;
     fflush(stdout);
     saved = dup(1);
     if (saved >= 0) (void)dup2(2, 1);
@@ -121,9 +128,26 @@ void sync_or_throw(hipStream_t s, double seconds, const char *what) {
 
 struct Entry {  // one candidate on the wire
   uint64_t label;
-  uint32_t key;  // dist_to_key(fp32 distance): ascending key <=> ascending distance, NaN last
-  uint32_t pad;
+  // dist64_to_key(score): ascending key <=> ascending distance, NaN last.  The DOUBLE the reply carries -- for FLOAT64 indexes
+  // the distance itself, for every other type the exact widening of its fp32 distance -- so the merged order and the scores
+  // handed back are those of the host merge whatever the element type (round-4 advisor: a 32-bit key re-tied FLOAT64
+  // candidates that differ below fp32 precision)
+  uint64_t key;
 };
+inline Entry entry_of(uint64_t label, double score) { return Entry{label, dist64_to_key(score)}; }
+inline Entry entry_pad() { return Entry{~0ull, ~0ull}; }
+// the k best of `all` by (key, label), padding skipped: the merge kernel's order, on the host (k x world > 8192 candidates)
+size_t merge_entries_host(std::vector<Entry> &all, size_t k, uint64_t *labels_out, double *scores_out) {
+  all.erase(std::remove_if(all.begin(), all.end(), [](const Entry &e) { return e.label == ~0ull; }), all.end());
+  const size_t kk = std::min(k, all.size());
+  std::partial_sort(all.begin(), all.begin() + (long)kk, all.end(),
+                    [](const Entry &a, const Entry &b) { return a.key != b.key ? a.key < b.key : a.label < b.label; });
+  for (size_t i = 0; i < kk; i++) {
+    labels_out[i] = all[i].label;
+    scores_out[i] = key_to_dist64(all[i].key);
+  }
+  return kk;
+}
 static_assert(sizeof(Entry) == 16, "wire format");
 
 }  // namespace
@@ -177,8 +201,8 @@ size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, s
   HIP_CHECK(hipSetDevice(c->device));
   c->ensure(k);
   for (size_t i = 0; i < k; i++) {
-    if (i < n_local) c->h_send[i] = Entry{(uint64_t)local[i].id, dist_to_key((float)local[i].score), 0};
-    else c->h_send[i] = Entry{~0ull, 0xFFFFFFFFu, 0};
+    if (i < n_local) c->h_send[i] = entry_of((uint64_t)local[i].id, local[i].score);
+    else c->h_send[i] = entry_pad();
   }
   HIP_CHECK(hipMemcpyAsync(c->d_send, c->h_send, k * sizeof(Entry), hipMemcpyHostToDevice, c->stream));
   nccl_check(nccl().AllGather(c->d_send, c->d_recv, k * sizeof(Entry), /*ncclChar*/ 0, c->comm, c->stream), "ncclAllGather");
@@ -190,21 +214,13 @@ size_t shard_comm_exchange(RSGPU_ShardComm *c, const VecSimQueryResult *local, s
     got = std::min<size_t>(*c->h_n, k);
     for (size_t i = 0; i < got; i++) {
       labels_out[i] = c->h_out[i].label;
-      scores_out[i] = (double)key_to_dist(c->h_out[i].key);
+      scores_out[i] = key_to_dist64(c->h_out[i].key);
     }
   } else {  // more candidates than the merge kernel ranks in LDS (k x world > 8192): the host merge
     std::vector<Entry> all(n);
     HIP_CHECK(hipMemcpyAsync(all.data(), c->d_recv, (size_t)n * sizeof(Entry), hipMemcpyDeviceToHost, c->stream));
     sync_or_throw(c->stream, 20.0, "shard exchange (all-gather)");
-    std::vector<float> sc(n);
-    std::vector<uint64_t> lb(n);
-    for (uint32_t i = 0; i < n; i++) {
-      sc[i] = key_to_dist(all[i].key);
-      lb[i] = all[i].label;
-    }
-    const int m = RSGPU_MergeTopKHost(sc.data(), lb.data(), n, k, scores_out, labels_out);
-    if (m < 0) throw std::runtime_error("shard exchange: host merge failed");
-    got = (size_t)m;
+    got = merge_entries_host(all, k, labels_out, scores_out);
   }
   c->exchanges++;
   c->exchange_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -285,8 +301,8 @@ size_t shard_comm_exchange_group(const std::vector<RSGPU_ShardComm *> &cs, const
     HIP_CHECK(hipSetDevice(c->device));
     c->ensure(k);
     for (size_t i = 0; i < k; i++) {
-      if (i < n_local[r]) c->h_send[i] = Entry{(uint64_t)local[r][i].id, dist_to_key((float)local[r][i].score), 0};
-      else c->h_send[i] = Entry{~0ull, 0xFFFFFFFFu, 0};
+      if (i < n_local[r]) c->h_send[i] = entry_of((uint64_t)local[r][i].id, local[r][i].score);
+      else c->h_send[i] = entry_pad();
     }
     HIP_CHECK(hipMemcpyAsync(c->d_send, c->h_send, k * sizeof(Entry), hipMemcpyHostToDevice, c->stream));
   }
@@ -316,18 +332,10 @@ size_t shard_comm_exchange_group(const std::vector<RSGPU_ShardComm *> &cs, const
     got = std::min<size_t>(*c0->h_n, k);
     for (size_t i = 0; i < got; i++) {
       labels_out[i] = c0->h_out[i].label;
-      scores_out[i] = (double)key_to_dist(c0->h_out[i].key);
+      scores_out[i] = key_to_dist64(c0->h_out[i].key);
     }
   } else {
-    std::vector<float> sc(total);
-    std::vector<uint64_t> lb(total);
-    for (uint32_t i = 0; i < total; i++) {
-      sc[i] = key_to_dist(all[i].key);
-      lb[i] = all[i].label;
-    }
-    const int m = RSGPU_MergeTopKHost(sc.data(), lb.data(), total, k, scores_out, labels_out);
-    if (m < 0) throw std::runtime_error("shard exchange: host merge failed");
-    got = (size_t)m;
+    got = merge_entries_host(all, k, labels_out, scores_out);
   }
   c0->exchanges++;
   c0->exchange_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -400,7 +408,7 @@ long RSGPU_MergeTopKDevice(int device, const float *scores, const uint64_t *labe
   try {
     HIP_CHECK(hipSetDevice(device));
     std::vector<Entry> all(n);
-    for (size_t i = 0; i < n; i++) all[i] = Entry{labels[i], labels[i] == ~0ull ? 0xFFFFFFFFu : dist_to_key(scores[i]), 0};
+    for (size_t i = 0; i < n; i++) all[i] = labels[i] == ~0ull ? entry_pad() : entry_of(labels[i], (double)scores[i]);
     HIP_CHECK(hipMalloc((void **)&d, std::max<size_t>(n, 1) * sizeof(Entry)));
     HIP_CHECK(hipHostMalloc((void **)&h_out, k * sizeof(Entry), hipHostMallocDefault));
     HIP_CHECK(hipHostMalloc((void **)&h_n, 64, hipHostMallocDefault));
@@ -411,7 +419,7 @@ long RSGPU_MergeTopKDevice(int device, const float *scores, const uint64_t *labe
     got = (long)std::min<size_t>(*h_n, k);
     for (long i = 0; i < got; i++) {
       labels_out[i] = h_out[i].label;
-      scores_out[i] = (double)key_to_dist(h_out[i].key);
+      scores_out[i] = key_to_dist64(h_out[i].key);
     }
   } catch (const std::exception &e) {
     last_error() = e.what();

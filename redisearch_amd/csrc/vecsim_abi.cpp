@@ -582,6 +582,11 @@ long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t f
   return index->flat->add_philox_rows(seed, first_index, n, first_label);
   ABI_CATCH(log_ctx_of(index), "RSGPU_FlatIndex_AddPhiloxRows", -1)
 }
+int RSGPU_FlatIndex_LabelTable(VecSimIndex *index) {
+  if (!index || !index->flat) return -1;
+  std::shared_lock<std::shared_mutex> g(index->flat->mu);
+  return index->flat->label_mode();
+}
 int RSGPU_FlatIndex_TopKDevice(VecSimIndex *index, const void *query, size_t k, float *dev_scores, uint64_t *dev_labels) {
   if (!index || !query || !k) return -1;
   if (index->sharded) {

@@ -172,6 +172,7 @@ ABI = {
     "RSGPU_FlatIndex_AddDeviceRows": (_i, [_vp, _vp, _sz, _sz]),
     "RSGPU_FlatIndex_AddPhiloxRows": (C.c_long, [_vp, C.c_uint64, C.c_uint64, _sz, _sz]),
     "RSGPU_FlatIndex_ReadRows": (_i, [_vp, _sz, _sz, _vp]),
+    "RSGPU_FlatIndex_LabelTable": (_i, [_vp]),
     "RSGPU_FlatIndex_TopKDevice": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "RSGPU_ShardedIndex_New": (_vp, [C.POINTER(VecSimParams), _i, _vp, _i]),
     "RSGPU_ShardedIndex_Free": (None, [_vp]),
@@ -339,6 +340,10 @@ class VecSimIndex:
         if r < 0:
             raise RuntimeError(last_error())
         return r
+
+    def label_table(self):
+        """0 identity labels, 1 device label table, 2 sparse labels (host maps): RSGPU_FlatIndex_LabelTable"""
+        return self.lib.RSGPU_FlatIndex_LabelTable(self.ptr)
 
     def read_rows(self, row_begin, n):
         out = np.zeros((n, self.dim), dtype=TYPE_NP[self.vtype])

@@ -493,6 +493,50 @@ def test_not_children_against_the_oracle(name, pos, neg, with_offsets, max_slop,
     idx.free()
 
 
+def test_not_children_with_an_empty_excluded_list_and_under_a_mass_tie():
+    """round-4 advisor: `a -b` with an EMPTY b is `a` (plus the virtual child): the empty list is simply not probed; and a mass tie
+    at the reduce kernel's bound (forced with hybrid_surv_cap = 4) is settled by the exact select over the tiles' lists -- a NOT
+    query has no staged form to fall back to, so whether it succeeded used to depend on its data"""
+    rng = np.random.default_rng(17)
+    built = [rand_list(rng, O.C_FREQS_ONLY, int(rng.integers(1500, 2000)), 2500, False) for _ in range(2)]
+    recs, sizes = [x[1] for x in built], [x[0].unique_docs for x in built]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    empty = S.Postings.from_flat(O.InvertedIndex(O.C_FREQS_ONLY).flatten())
+    assert empty.num_entries == 0
+    n_docs = 2500
+    table = table_for(rng, n_docs)
+    dl, ds, mf = table._arrays
+    idf = [S.calculate_idf(n_docs, s_) for s_ in sizes] + [0.0]
+    bidf = [S.calculate_idf_bm25(n_docs, s_) for s_ in sizes] + [0.0]
+    w = [1.0, 2.0, 0.0]
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    idx.add_philox_rows(11, 0, 1200, 100)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    ot = OracleTree(I, [(T, 1.0, [0]), (T, 1.0, [1])], recs, sizes)
+    for scorer in ("BM25STD", "DOCSCORE", "TFIDF"):
+        scored = []
+        for d in ot.docs:
+            node = O.intersection(ot.node(d, idf, bidf, w).kids + [O.Node(O.R_VIRTUAL, 1.0, 0)])
+            node.c.weight = 1.5
+            scored.append((O.score(scorer, node, float(ds[d]), int(mf[d]), int(dl[d]), n_docs, 150.0), d))
+        scored.sort(key=lambda t: (-t[0], t[1]))
+        hq = S.HybridTreeQuery(I, [(T, 1.0, g[:1]), (T, 1.0, g[1:2]), (S.OP_NOT, 1.0, [empty])], table=table, scorer=scorer, idf=idf,
+                               bm25_idf=bidf, weight=w, num_docs=n_docs, avg_doc_len=150.0, top_n=10, index=idx, q=q, k=10, root_weight=1.5)
+        for cap in (2048, 4):
+            try:
+                knob("hybrid_surv_cap", cap)
+                hq.run()
+            finally:
+                knob("hybrid_surv_cap", 2048)
+            assert S.hybrid_path() == 2
+            a = hq.results()
+            assert a["n_hits"] == len(ot.docs)
+            assert a["top"][0].tolist() == [d for _, d in scored[:10]], (scorer, cap)
+            assert a["top"][1].tolist() == [x for x, _ in scored[:10]], (scorer, cap)
+            assert len(a["knn"][0]) == 10
+    idx.free()
+
+
 def test_not_children_where_the_tile_kernel_cannot_run():
     rng = np.random.default_rng(3)
     built = [rand_list(rng, O.C_FREQS_ONLY, 800, 2500, False) for _ in range(3)]

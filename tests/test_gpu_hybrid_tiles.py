@@ -227,7 +227,8 @@ def test_shapes_the_two_launches_leave_to_the_staged_pipeline():
 
 def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():
     """the way out of the reduce kernel (an adversarial arrangement of the tiles' lists leaves more than 2 048 entries at its
-    bound; forced here with a cap of 4): the same call answers through the staged pipeline -- same answers, path 0"""
+    bound; forced here with a cap of 4): since round 5 the exact radix select settles it over the tiles' lists, still in HBM --
+    same answers, the query stays on the tile path (rounds 3-4 re-ran it through the staged pipeline; a NOT query failed)"""
     lib = V.load()
     n_docs = 300_000
     lists_o, rng = corpus(n_docs, (0.5, 0.4), 41)
@@ -236,23 +237,31 @@ def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():
     idx = V.VecSimIndex(V.VecSimType_FLOAT32, 16, V.VecSimMetric_L2)
     idx.add_philox_rows(3, 0, 100_000, 1)
     q = O.philox_rows(3, 1 << 40, 1, 16)[0]
-    hq = S.HybridQuery(g, table, "BM25STD", [1.5, 0.5], [1.2, 0.7], [1, 1], n_docs, 200.0, top_n=10, index=idx, q=q, k=10)
-    hq.run()
-    assert S.hybrid_path() == 1
-    want = hq.results()
-    try:
-        lib.RSGPU_SetTuning(b"hybrid_surv_cap", 4)
-        for rep in range(2):
+    for scorer, top_n, k in (("BM25STD", 10, 10), ("DOCSCORE", 32, 3), ("BM25STD", 1, 32)):   # DOCSCORE: every hit ties -- by doc id
+        hq = S.HybridQuery(g, table, scorer, [1.5, 0.5], [1.2, 0.7], [1, 1], n_docs, 200.0, top_n=top_n, index=idx, q=q, k=k)
+        hq.run()
+        assert S.hybrid_path() == 1
+        want = hq.results()
+        try:
+            lib.RSGPU_SetTuning(b"hybrid_surv_cap", 4)
+            for rep in range(2):
+                hq.run()
+                assert S.hybrid_path() == 1
+                got = hq.results()
+                assert got["n_hits"] == want["n_hits"]
+                for key in ("top", "knn"):
+                    assert got[key][0].tolist() == want[key][0].tolist() and got[key][1].tolist() == want[key][1].tolist()
+            lib.RSGPU_SetTuning(b"hybrid_tiles", 0)                      # ... and the staged pipeline agrees
             hq.run()
             assert S.hybrid_path() == 0
-            got = hq.results()
-            assert got["n_hits"] == want["n_hits"]
+            st = hq.results()
             for key in ("top", "knn"):
-                assert got[key][0].tolist() == want[key][0].tolist() and got[key][1].tolist() == want[key][1].tolist()
-    finally:
-        lib.RSGPU_SetTuning(b"hybrid_surv_cap", 2048)
-    hq.run()
-    assert S.hybrid_path() == 1
+                assert st[key][0].tolist() == want[key][0].tolist() and st[key][1].tolist() == want[key][1].tolist()
+        finally:
+            lib.RSGPU_SetTuning(b"hybrid_surv_cap", 2048)
+            lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
+        hq.run()
+        assert S.hybrid_path() == 1
 
 
 @pytest.mark.parametrize("scorer", SCORERS)

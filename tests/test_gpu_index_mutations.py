@@ -73,7 +73,7 @@ def test_add_device_rows_rejects_a_stored_label_on_a_single_value_index():
         g.add_device_rows(t.data_ptr(), 4, 62)          # 62..65 overlaps 62..64 (identity labelling)
     g.delete_vector(5)
     with pytest.raises(RuntimeError):
-        g.add_device_rows(t.data_ptr(), 4, 62)          # same, through the hash map
+        g.add_device_rows(t.data_ptr(), 4, 62)          # same, through the label table
     assert g.add_device_rows(t.data_ptr(), 4, 65) == 4 and g.index_size() == 67
     assert g.add_device_rows(t.data_ptr(), 1, 5) == 1   # the deleted label is free again
 
@@ -156,7 +156,9 @@ def test_prefer_adhoc_ratio_is_over_labels_not_vectors():
 
 def test_label_maps_are_allocated_through_the_installed_memory_functions():
     """VecSim_SetMemoryFunctions (reference src/module-init/module-init.c:147): the label vector and, once identity
-    labelling ends, the label -> row hash map come from the module's allocator and are part of StatsInfo.memory."""
+    labelling ends, the host copy of the label -> row table (csrc/label_table.hpp: calloc'ed, "unchanged" encoded as zero)
+    come from the module's allocator and are part of StatsInfo.memory; labels too sparse for a table get the hash maps of
+    rounds 1-4, node by node through the same allocator."""
     import ctypes as C
     lib = V.load()
     libc = C.CDLL(None)
@@ -164,7 +166,7 @@ def test_label_maps_are_allocated_through_the_installed_memory_functions():
     libc.calloc.restype, libc.calloc.argtypes = C.c_void_p, [C.c_size_t, C.c_size_t]
     libc.realloc.restype, libc.realloc.argtypes = C.c_void_p, [C.c_void_p, C.c_size_t]
     libc.free.restype, libc.free.argtypes = None, [C.c_void_p]
-    stats = {"allocs": 0, "bytes": 0, "frees": 0}
+    stats = {"allocs": 0, "bytes": 0, "frees": 0, "callocs": 0, "calloc_bytes": 0}
     A, CA, RA, FR = (C.CFUNCTYPE(C.c_void_p, C.c_size_t), C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_size_t),
                      C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t), C.CFUNCTYPE(None, C.c_void_p))
 
@@ -173,10 +175,15 @@ def test_label_maps_are_allocated_through_the_installed_memory_functions():
         stats["bytes"] += n
         return libc.malloc(n)
 
+    def _calloc(a, b):
+        stats["callocs"] += 1
+        stats["calloc_bytes"] += a * b
+        return libc.calloc(a, b)
+
     def _free(p):
         stats["frees"] += 1
         libc.free(p)
-    cbs = (A(_alloc), CA(lambda a, b: libc.calloc(a, b)), RA(lambda p, n: libc.realloc(p, n)), FR(_free))
+    cbs = (A(_alloc), CA(_calloc), RA(lambda p, n: libc.realloc(p, n)), FR(_free))
     plain = V.VecSimMemoryFunctions(*[C.cast(f, C.c_void_p) for f in (libc.malloc, libc.calloc, libc.realloc, libc.free)])
     lib.VecSim_SetMemoryFunctions(V.VecSimMemoryFunctions(*[C.cast(c, C.c_void_p) for c in cbs]))
     try:
@@ -187,9 +194,14 @@ def test_label_maps_are_allocated_through_the_installed_memory_functions():
         g.topk_query(x[0], 1)
         b0, m0 = stats["bytes"], g.stats_info().memory
         assert b0 >= 3000 * 8                          # the row -> label vector
-        g.delete_vector(17)                            # identity ends: 2 999 hash nodes appear
-        assert stats["allocs"] >= 2999 and stats["bytes"] - b0 >= 2999 * 16
-        assert g.stats_info().memory - m0 >= 2999 * 16
+        g.delete_vector(17)                            # identity ends: the direct table appears (one calloc on the host)
+        assert g.label_table() == 1
+        assert stats["callocs"] >= 1 and stats["calloc_bytes"] >= 3000 * 4
+        assert g.stats_info().memory - m0 >= 2 * 3000 * 4          # host copy + device copy
+        a0, m1 = stats["allocs"], g.stats_info().memory
+        g.add_vector(x[0], 10 ** 12)                   # a label no table reaches: the hash maps, 3 000 nodes
+        assert g.label_table() == 2
+        assert stats["allocs"] - a0 >= 2999 and g.stats_info().memory - m1 >= 2999 * 16 - 2 * 5000 * 4
         f0 = stats["frees"]
         g.free()
         assert stats["frees"] - f0 >= 2999
