@@ -341,18 +341,26 @@ def encode_full(docs, freqs, masks, off_bytes, block_entries=100):
                 offset=byte_off, bytes=out[:total], codec=0)   # RSGPU_CODEC_FULL
 
 
-def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
-    """Independent check of timed answers without the oracle's corpus: the rows a query returned are REGENERATED on the
-    host from (seed, label) and re-scored in fp64; the K-th distance must also beat 2048 other regenerated rows."""
+def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2), answers=None, shards=1):
+    """The returned neighbours of a few queries against first principles, on the host: every returned row is regenerated from
+    the corpus key (oracle.philox_rows: the CPU twin of corpus_kernels.hip), its distance recomputed in fp64 (<= 1e-4 from the
+    reply), the reply is sorted, and the K-th beats regenerated probe rows -- 2 048 per query, drawn from EVERY shard's row range
+    when the corpus is row-sharded (shard s holds rows [s * total / shards, (s + 1) * total / shards)), so a shard whose winners
+    got lost in the exchange shows.  answers: {query index: (labels, scores)} when the caller produced them (the multi-rank
+    form: every rank takes part in the collective query, rank 0 checks); else index.topk_query.  Returns (worst error, answers)."""
     import oracle as O
     worst, got = 0.0, {}
     for qi in which:
         q = queries[qi].astype(np.float64)
-        ids, sc = index.topk_query(queries[qi], k).results()
+        ids, sc = answers[qi] if answers is not None else index.topk_query(queries[qi], k).results()
+        ids, sc = np.asarray(ids), np.asarray(sc)
         got[qi] = (ids.tolist(), sc.tolist())
         rows = np.stack([O.philox_rows(SEED, int(l) - 1, 1, dim)[0] for l in ids]).astype(np.float64)
-        p0 = (12345 + 4096 * qi) % max(total_rows - 2048, 1)
-        probe = O.philox_rows(SEED, p0, min(2048, total_rows), dim).astype(np.float64)
+        per = total_rows // shards
+        n_probe = max(min(2048 // shards, per), 1)
+        starts = [sh * per + (12345 + 4096 * qi) % max(per - n_probe, 1) for sh in range(shards)]
+        probe = np.concatenate([O.philox_rows(SEED, p0, n_probe, dim) for p0 in starts]).astype(np.float64)
+        probe_labels = np.concatenate([np.arange(p0 + 1, p0 + 1 + n_probe) for p0 in starts])
 
         def dist(x):
             if metric == "l2":
@@ -366,8 +374,7 @@ def verify_answers(index, queries, k, metric, dim, total_rows, which=(0, 1, 2)):
         assert np.all(np.diff(sc) >= 0), "reply not sorted"
         others = dist(probe)
         labels = set(int(l) for l in ids)
-        for j, dj in enumerate(others):
-            lab = p0 + j + 1
+        for lab, dj in zip(probe_labels.tolist(), others):
             assert lab in labels or dj >= sc[-1] - 1e-4, ("a regenerated row beats the returned K-th", qi, lab, dj, sc[-1])
     return worst, got
 
@@ -670,7 +677,7 @@ def _term_list(rng, n_docs, df):
     return docs, freqs, masks, offs
 
 
-def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3, decoded_bpp=8):
+def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3, decoded_bpp=8, modes=("warm", "cold")):
     """A STREAM of distinct queries: n_a x n_b term pairs over independent lists and a query vector of its
     own per query, issued round-robin so that consecutive queries share neither a list nor candidate rows.  One cycle touches
     every list's decoded arrays (240 MB at 4 + 4 lists) and 16 x 77 MB of rows -- several times the 256 MiB Infinity Cache --
@@ -680,7 +687,7 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
     pairs = [(i % n_a, n_a + (i + i // n_a) % n_b) for i in range(n_a * n_b)]
     enc_bytes = [len(e["bytes"]) for e in enc]
     out, answers = {}, None
-    for mode in ("warm", "cold"):
+    for mode in modes:
         lib.RSGPU_SetTuning(b"cache_decoded", 1 if mode == "warm" else 0)
         lists = [S.Postings.from_flat(e) for e in enc]
         try:
@@ -871,6 +878,10 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
             general = _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_docs, avg, n_a)
         except Exception as e:                      # (an extra: the stream record above stands on its own)
             general = {"error": repr(e)}
+        try:
+            mutated, mut_payload = _hybrid_after_deletes(lib, V, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, fo["warm"])
+        except Exception as e:
+            mutated, mut_payload = {"error": repr(e)}, None
         w = fo["warm"]
         rec = {"workload": "2-term intersect (Zipf ranks 2 and 4: df 0.1N / 0.05N, %d docs) -> FLAT %dx%d fp32 L2 ad-hoc KNN top-10 + BM25STD "
                            "top-10; a round-robin STREAM over %d distinct term pairs (%d + %d independent lists), a query vector per query"
@@ -882,6 +893,7 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
                "path": w["path"],
                "stream_freqs_only": fo, "stream_full_codec": full,
                "general_tile_kernel_shapes": general,
+               "after_deletes": mutated,
                "full_codec_answers_equal_freqs_only": bool(codec_same),
                "input_generation_s": gen_s,
                "repeat_same_query": rep,
@@ -891,9 +903,52 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
                                   idf=[S.calculate_idf(n_docs, raws[t][0].size) for t in (i, j)],
                                   bidf=[S.calculate_idf_bm25(n_docs, raws[t][0].size) for t in (i, j)])
                              for c, ans, qi in (("freqs_only", ans_fo, 0), ("full", ans_full, 5)) for (i, j) in [pairs[qi]]]
+        payload["after_deletes"] = mut_payload
         return rec, payload
     finally:
         idx.free()
+
+
+def _hybrid_after_deletes(lib, V, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, pristine, frac=0.01):
+    """VERDICT r04 next 1(b, c): the same stream over the index after it stopped being pristine -- 1 % of the vectors deleted at
+    random (VecSimIndex_DeleteVector, one call each, as src/spec.c:3533-3541 issues them) and half as many documents re-added
+    under NEW doc ids (an update is delete + a new id, src/indexer.c:179-190).  The label -> row table lives in HBM since round 5
+    (csrc/label_table.hpp): the queries stay on the two-launch tile path.  Reported: the first delete's latency (rounds 1-4: a
+    hash map of every row under the writer lock), the mean of the rest, the stream's p50 against the pristine index's.
+    LAST leg of the hybrid extra: it mutates the index."""
+    rng = np.random.default_rng(151)
+    n_del = int(n_vec * frac)
+    victims = rng.choice(n_vec, n_del, replace=False).astype(np.uint64) + 1
+    mode0 = idx.label_table()
+    t0 = time.perf_counter()
+    assert idx.delete_vector(int(victims[0])) == 1
+    first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    for lab in victims[1:].tolist():
+        idx.delete_vector(lab)
+    rest_ms = (time.perf_counter() - t0) * 1e3 / max(n_del - 1, 1)
+    n_add = n_del // 2
+    new_labels = n_vec + 1 + 2 * np.arange(n_add, dtype=np.uint64)     # (every other new doc id: documents without a vector between)
+    fresh_first = 1 << 33
+    chunk = 4096
+    t0 = time.perf_counter()
+    for a0 in range(0, n_add, chunk):
+        block = philox_host_rows(V, fresh_first + a0, min(chunk, n_add - a0), dim)
+        for j in range(block.shape[0]):
+            idx.add_vector(block[j], int(new_labels[a0 + j]))
+    add_ms = (time.perf_counter() - t0) * 1e3 / max(n_add, 1)
+    rec, answers, pairs = _hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec + 2 * n_add, avg, dim, n_a, modes=("warm",))
+    w = rec["warm"]
+    out = {"deleted": n_del, "re_added_under_new_doc_ids": n_add, "label_table_before": mode0, "label_table_after": idx.label_table(),
+           "label_table_legend": "0 identity labels, 1 device table (csrc/label_table.hpp), 2 host hash maps",
+           "first_delete_ms": first_ms, "delete_ms_mean_of_rest": rest_ms, "add_vector_ms_mean": add_ms,
+           "stream_warm": w, "path": w["path"], "wall_ms_p50": w["wall_ms_p50"],
+           "pristine_wall_ms_p50": pristine["wall_ms_p50"], "p50_over_pristine": w["wall_ms_p50"] / pristine["wall_ms_p50"]}
+    i, j = pairs[0]
+    payload = dict(raw=[raws[i], raws[j]], q=qvecs[0], n_vec=n_vec, dim=dim, ans=answers[0], victims=victims, new_labels=new_labels,
+                   fresh_first=fresh_first, idf=[S.calculate_idf(n_docs, raws[t][0].size) for t in (i, j)],
+                   bidf=[S.calculate_idf_bm25(n_docs, raws[t][0].size) for t in (i, j)])
+    return out, payload
 
 
 def _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_docs, n_vec, dim):
@@ -1110,7 +1165,37 @@ def check_hybrid_with_oracle(p):
         stream.append({"codec": sp["codec"], "top_n_ok": bool(top_ok), "knn_ok": bool(knn_ok), "hits": int(len(si)), "candidates": int(len(cand)),
                        "knn_max_abs_diff": float(np.max(np.abs(a["knn"][1] - kd))) if len(kd) == len(a["knn"][1]) else None})
         ok = ok and top_ok and knn_ok
-    return {"ok": bool(ok and p["ok"]), "cpu_oracle_intersect_ms": t_int, "stream_queries_vs_oracle": stream,
+    mut = None
+    mp = p.get("after_deletes")
+    if mp:   # the stream's first query over the MUTATED index: deleted labels have no vector, re-added doc ids have a fresh one
+        ls = []
+        for docs, freqs, _, _ in mp["raw"]:
+            ii = O.InvertedIndex(O.C_FREQS_ONLY)
+            ii.add_many(docs, freqs)
+            ls.append(ii)
+        si, sf, _ = O.intersect(ls)
+        sel2 = si.astype(np.int64)
+        ss = O.score_flat("BM25STD", sf, p["doc_len"][sel2], np.ones(len(sel2)), p["doc_score"][sel2], mp["idf"], mp["bidf"], [1.0, 1.0], 1.0,
+                          p["n_docs"], p["avg"])
+        o10 = np.lexsort((si, -ss))[:10]
+        a = mp["ans"]
+        top_ok = a["n_hits"] == len(si) and a["top"][0].tolist() == si[o10].tolist() and bool(np.allclose(a["top"][1], ss[o10], rtol=1e-12, atol=0))
+        old_c = si[(si <= mp["n_vec"]) & ~np.isin(si, mp["victims"])]
+        new_c = si[np.isin(si, mp["new_labels"])]
+        rows_old = [O.philox_rows(SEED, int(l) - 1, 1, mp["dim"]) for l in old_c]
+        rows_new = [O.philox_rows(SEED, mp["fresh_first"] + int((int(l) - mp["n_vec"] - 1) // 2), 1, mp["dim"]) for l in new_c]
+        cand = np.concatenate([old_c, new_c])
+        fo = O.FlatIndex(O.F32, mp["dim"], O.L2)
+        if len(cand):
+            fo.add_bulk(np.concatenate(rows_old + rows_new), 1)
+        ki, kd = fo.topk(mp["q"], 10) if len(cand) else (np.zeros(0, np.uint64), np.zeros(0))
+        order = np.lexsort((cand[ki.astype(np.int64) - 1], kd))        # (the oracle ranks by its own labels; equal distances by doc id)
+        knn_ids = cand[ki.astype(np.int64) - 1][order]
+        knn_ok = a["knn"][0].tolist() == knn_ids.tolist() and bool(np.all(np.abs(a["knn"][1] - kd[order]) <= 1e-4 + 1e-5 * np.abs(kd[order])))
+        mut = {"top_n_ok": bool(top_ok), "knn_ok": bool(knn_ok), "hits": int(len(si)), "candidates": int(len(cand)),
+               "candidates_re_added": int(len(new_c)), "candidates_dropped_by_deletes": int(np.sum((si <= mp["n_vec"]) & np.isin(si, mp["victims"])))}
+        ok = ok and top_ok and knn_ok
+    return {"ok": bool(ok and p["ok"]), "cpu_oracle_intersect_ms": t_int, "stream_queries_vs_oracle": stream, "after_deletes_query_vs_oracle": mut,
             "vs": "CPU oracle: intersection ids/freqs identical, BM25STD top-10 identical (scores rtol 1e-12), KNN distances equal "
                   "the per-label ad-hoc seam's; fused == stage-by-stage; two queries of the stream (FreqsOnly, Full): hit count, "
                   "BM25STD top-10 and the KNN top-10 (ids identical, distances within 1e-4 + 1e-5 |d|) against the oracle directly"}
@@ -1306,11 +1391,28 @@ def main():
         for d in range(torch.cuda.device_count() if inproc else 1):
             torch.cuda.synchronize(d if inproc else local_rank)
 
+    # `python bench.py --gpus N` in ONE process: the timed exchange is the north star's -- ONE ncclAllGather of the per-shard
+    # top-k + a merge kernel (knob shard_exchange = 1) -- whenever RCCL can form a communicator (one device per shard); the
+    # K-way host merge of rounds 2-4 is timed beside it (`collective_host_merge`).  Several shards on one device (tests,
+    # RSGPU_BENCH_OVERSUBSCRIBE=1) cannot form one: the host merge stays the headline and the record says so.
+    exchange_used = None
+    if inproc and not a.replicas:
+        exchange_used = "host_merge"
+        if torch.cuda.device_count() >= a.gpus and os.environ.get("RSGPU_BENCH_EXCHANGE", "rccl") == "rccl":
+            lib.RSGPU_SetTuning(b"shard_exchange", 1)
+            try:
+                assert one_query(0) == k
+                exchange_used = "rccl"
+            except Exception as e:
+                lib.RSGPU_SetTuning(b"shard_exchange", 0)
+                exchange_used = "host_merge (RCCL refused: %r / %s)" % (e, V.last_error())
     for i in range(a.warmup):
         assert one_query(i) == k
     if inproc:
         ex = (C.c_uint64 * 2)()
         lib.RSGPU_ShardedIndex_GetExchangeStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), ex, 1)
+        rst = (C.c_uint64 * 3)()
+        lib.RSGPU_ShardedIndex_GetRcclStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), rst, 1)
     if ranks_mode:
         sharded.stats(reset=True)
     lib.RSGPU_ResetProfile()
@@ -1330,10 +1432,18 @@ def main():
     kernel_name = V.last_scan_kernel()
     # the exchange step of the timed queries (N > 1): what it is, how many parties, what it cost per query
     collective = None
-    if inproc and not a.replicas:
+    if inproc and not a.replicas and exchange_used == "rccl":
+        lib.RSGPU_ShardedIndex_GetRcclStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), rst, 0)
+        collective = {"kind": "in-process: ncclCommInitAll over the shard devices; per query ONE ncclAllGather of k*16 B per rank + "
+                              "merge kernel (shard_comm.cpp), issued by the shard workers -- the exchange of the TIMED loop",
+                      "timed_exchange": "rccl", "ranks": int(rst[2]), "us_per_query": rst[1] / max(rst[0], 1) / 1e3, "queries": int(rst[0]),
+                      "payload_bytes_per_rank": k * 16}
+        assert int(rst[2]) == n_shards, "the communicator spans %d ranks, %d shards" % (int(rst[2]), n_shards)
+    elif inproc and not a.replicas:
         lib.RSGPU_ShardedIndex_GetExchangeStats(lib.RSGPU_ShardedIndex_FromHandle(index.ptr), ex, 0)
         collective = {"kind": "in-process: every shard's last kernel writes its top-k into pinned host memory; K-way host merge "
                               "by (score, label) (sharded_index.cpp merge_replies) -- no device collective inside one process",
+                      "timed_exchange": exchange_used,
                       "ranks": n_shards, "us_per_query": ex[1] / max(ex[0], 1) / 1e3, "queries": int(ex[0]),
                       "payload_bytes_per_rank": k * 16}
     elif ranks_mode:
@@ -1348,19 +1458,52 @@ def main():
 
     # ---- after the timed region: verification and the N=1 sub-records ------------------------------------------------
     verify, extras, gpu_answers = None, {}, None
+    # per-device scan profile of the timed loop (ranks mode: one device per rank) and, in the multi-rank form, the answers of
+    # three verification queries -- collective calls: EVERY rank issues them, rank 0 checks them below
+    per_device, rank_answers = None, None
+    if ranks_mode:
+        mine = {"rank": rank, "launches": int(launches), "kernel_ms": float(kern_ms), "bytes": float(kern_bytes)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_device = gathered
+        if not a.no_cpu_baseline:
+            rank_answers = {qi: sharded.query(queries[qi]) for qi in (0, 1, 2)}
     if rank == 0:
         try:
-            if ranks_mode:
-                verify = {"note": "multi-rank run: answers are checked by tests/test_sharded_cpu.py and the N=1 verification"}
-            elif a.no_cpu_baseline:   # the host-side regeneration is the oracle's Philox twin: part of the CPU leg
+            if a.no_cpu_baseline:   # the host-side regeneration is the oracle's Philox twin: part of the CPU leg
                 verify = {"skipped": "--no-cpu-baseline (the verification uses the CPU twin of the corpus generator)"}
             else:
-                worst, gpu_answers = verify_answers(index, queries, k, a.metric, dim, total_rows)
+                shards_v = world if ranks_mode else (n_shards if (inproc and not a.replicas) else 1)
+                worst, gpu_answers = verify_answers(index, queries, k, a.metric, dim, total_rows, answers=rank_answers, shards=shards_v)
                 verify = {"queries": 3, "returned_rows_regenerated_on_host": 3 * k, "max_abs_err_vs_fp64": worst,
-                          "ok": bool(worst <= 1e-4), "kth_beats_regenerated_probe_rows": 3 * 2048}
+                          "ok": bool(worst <= 1e-4), "kth_beats_regenerated_probe_rows": 3 * max(2048 // shards_v, 1) * shards_v,
+                          "probe_rows_drawn_from_every_shard": shards_v,
+                          "answers_from": ("the merged global top-k of the RCCL exchange (every rank took part; rank 0 regenerates the rows "
+                                           "of ANY shard from the corpus key)" if ranks_mode else
+                                           "VecSimIndex_TopKQuery on the handle the timed loop used" + (" (exchange: %s)" % exchange_used if exchange_used else ""))}
         except Exception as e:
             verify = {"ok": False, "error": repr(e)}
-    if inproc and not a.replicas:
+    if inproc and not a.replicas and exchange_used == "rccl":
+        # the same queries through the K-way host merge of rounds 2-4, beside the RCCL exchange the timed loop used
+        try:
+            lib.RSGPU_SetTuning(b"shard_exchange", 0)
+            for i in range(3):
+                one_query(i)
+            hl = np.zeros(max(a.steps, 1))
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                s_ = time.perf_counter()
+                one_query(a.warmup + i)
+                hl[i] = time.perf_counter() - s_
+            el_h = time.perf_counter() - t0
+            extras["collective_host_merge"] = {"kind": "K-way host merge of the shards' pinned top-k lists (sharded_index.cpp merge_replies)",
+                                               "global_qps": a.steps / el_h, "p50_ms": float(np.percentile(hl, 50) * 1e3),
+                                               "p95_ms": float(np.percentile(hl, 95) * 1e3)}
+        except Exception as e:
+            extras["collective_host_merge"] = {"error": repr(e), "last_error": V.last_error()}
+        finally:
+            lib.RSGPU_SetTuning(b"shard_exchange", 1)
+    elif inproc and not a.replicas:
         # the same queries through the RCCL exchange (knob shard_exchange = 1: ncclCommInitAll over the shard devices, one
         # ncclAllGather + merge kernel per query) -- reported next to the host merge the timed loop used
         try:
@@ -1469,7 +1612,7 @@ def main():
         scale = 1 if (inproc and a.replicas) else n_gpus
         par = ("single GPU" if n_gpus == 1 else
                "%d full replicas in one process behind the plain VecSim handle, one caller thread (replica mode)" % n_gpus if (inproc and a.replicas) else
-               "row-sharded x%d in ONE process behind the plain VecSim handle (\"shards\" knob: worker thread per device, host K-way merge)" % n_gpus if inproc else
+               "row-sharded x%d in ONE process behind the plain VecSim handle (\"shards\" knob: worker thread per device; exchange: %s)" % (n_gpus, exchange_used) if inproc else
                "row-sharded x%d, one rank per GPU: ncclAllGather of per-shard top-k issued from C + merge kernel on every rank" % n_gpus)
         out = {
             "metric": "KNN queries/sec + p50 latency, 10M×768 fp32 FLAT top-10, 1/2/4/8 GPU",  # BASELINE.json's metric
@@ -1506,6 +1649,20 @@ def main():
                 "algorithmic_bytes_per_launch": kern_bytes / max(launches, 1),
             },
         }
+        if per_device:
+            fr = []
+            for d_ in per_device:
+                l_ = max(d_["launches"], 1)
+                ach = (d_["bytes"] / l_) / ((d_["kernel_ms"] / 1e3) / l_) / 1e9 if d_["launches"] else 0.0
+                fr.append({"rank": d_["rank"], "launches": d_["launches"], "avg_kernel_ms": d_["kernel_ms"] / l_, "achieved_gbs": ach,
+                           "frac": ach / HBM_PEAK_GBS})
+            out["roofline"]["per_device"] = fr
+            out["roofline"]["frac_min_over_devices"] = min(x["frac"] for x in fr)
+            out["roofline"]["frac_max_over_devices"] = max(x["frac"] for x in fr)
+            out["roofline"]["note"] = "achieved / frac above are rank 0's device; per_device lists every rank's own scan profile"
+        elif inproc:
+            out["roofline"]["note"] = ("one process, %d devices: the scan profile is the mean over the launches of ALL shards (the library keeps one "
+                                       "profile per process); the torch.distributed.run form reports every device separately" % n_gpus)
         out["config"].update(extras)
         if pre is not None:
             out["config"]["preflight"] = pre

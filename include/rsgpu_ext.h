@@ -126,7 +126,12 @@ void RSGPU_ShardedIndex_GetExchangeStats(RSGPU_ShardedIndex *index, uint64_t out
 /* ... and of the queries that took the RCCL exchange instead (RSGPU_SetTuning("shard_exchange", 1): one ncclAllGather of the
  * per-shard top-k + a merge kernel, shard_comm.cpp; needs one device per shard): out[0] queries, out[1] nanoseconds of the
  * exchange (H2D of the winners + all-gather + merge kernel + sync; the first one includes creating the communicators),
- * out[2] ranks of the communicator (0 before the first such query) */
+ * out[2] ranks of the communicator (0 before the first such query).
+ * Concurrency: collectives of one communicator are ORDERED -- every rank must issue them in the same sequence -- so queries that
+ * take the RCCL exchange pass it ONE AT A TIME (a mutex around all-gather + merge, shard_comm.cpp): concurrent callers still
+ * overlap their shard scans (and share passes through the coalescer), only the ~tens-of-microseconds exchange serialises.  The
+ * host merge (shard_exchange 0) has no such step.  Scores travel as the 64-bit orderable key of the reply's double, so FLOAT64
+ * shards merge in the host merge's order. */
 void RSGPU_ShardedIndex_GetRcclStats(RSGPU_ShardedIndex *si, uint64_t out[3], int reset);
 /* VecSimIndex_AddVector / _DeleteVector / _GetDistanceFrom_Unsafe / _TopKQuery / _RangeQuery semantics over the
  * whole index; a label lives on exactly one shard (new labels go to the emptiest one) */

@@ -281,10 +281,13 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // Dynamic LDS: pool_words u32 (the probe's window of another list; then the hits' records -- doc id | frequency in list 0 |
 // position in list l -- then their keys | doc ids; then the vector rows | doc ids | distance keys of branch B), then the KNN
 // query (chunks x 16 bytes).
-template <int TYPE, int METRIC>
+// DPT drivers per thread (a tile = 256 DPT drivers), NL: the lists the instantiation holds positions for.  Only <kHybDpt,
+// kHybMaxLists> is instantiated: round 5 measured tiles of 2 048 (one round over the chip instead of two: 63.7 us against 45.7 --
+// every phase grows with the tile, the tiles that hold vectors take 55 us) and of 512 (54.2 us: the per-tile overhead) on the
+// configs[4] stream, profiles/r05_hybrid_tile_size_ab.json.
+template <int TYPE, int METRIC, int DPT, int NL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
-  constexpr int DPT = kHybDpt;
-  constexpr uint32_t TILE = kHybTile;
+  constexpr uint32_t TILE = 256u * DPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh, sel_cnt;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   bool hit[DPT];
   uint32_t xc[DPT];            // doc id in the frame the lists share
   uint32_t f0[DPT];            // its frequency in the driving list
-  uint32_t ps[DPT][kHybMaxLists - 1];  // match position in list l
+  uint32_t ps[DPT][NL - 1];  // match position in list l
 #pragma unroll
   for (int k = 0; k < DPT; k++) {
     const uint32_t i = i_first + k * 256 + threadIdx.x;
@@ -321,14 +324,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
     f0[k] = (A.top_n && A.freq[0]) ? A.freq[0][ic] : 1u;
 #pragma unroll
-    for (int l = 0; l < kHybMaxLists - 1; l++) ps[k][l] = 0;
+    for (int l = 0; l < NL - 1; l++) ps[k][l] = 0;
   }
   const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
   const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
 
   // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
 #pragma unroll
-  for (int l = 1; l < kHybMaxLists; l++) {
+  for (int l = 1; l < NL; l++) {
     if (l < A.n) {
       const uint32_t *__restrict__ a = A.ids[l];
       const uint32_t nl = A.len[l];
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           rx[slot] = xc[k];
           rf0[slot] = f0[k];
 #pragma unroll
-          for (int l = 1; l < kHybMaxLists; l++)
+          for (int l = 1; l < NL; l++)
             if (l < A.n) win[(l + 1) * TILE + slot] = ps[k][l - 1];
         }
       }
@@ -475,10 +478,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
       my_x[j] = ~0u;
       if (e < nh) {
         const uint32_t x = rx[e];
-        double fr[kHybMaxLists];
+        double fr[NL];
         fr[0] = (double)rf0[e];
 #pragma unroll
-        for (int l = 1; l < kHybMaxLists; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
+        for (int l = 1; l < NL; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
         const long long tid = (long long)x + A.P.table_off;
         const bool known = tid >= 0 && tid < (long long)A.table_n;
         const uint32_t id = known ? (uint32_t)tid : 0u;
@@ -493,8 +496,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
           dlen = known ? A.doc_len[id] : 0u;
         }
         const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
-        auto F = [&](int t) { return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[3])); };
-        const double s = score_one<false, kHybMaxLists>(A.P, F, dlen, dscore, mfreq, A.P.slop);
+        auto F = [&](int t) {
+          if constexpr (NL <= 2) return t == 0 ? fr[0] : fr[NL - 1];
+          else return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[NL - 1]));
+        };
+        const double s = score_one<false, NL>(A.P, F, dlen, dscore, mfreq, A.P.slop);
         my_k[j] = ~d2key(s);
         my_x[j] = x;
       }
@@ -1275,7 +1281,7 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
   // LDS: the pool -- a window of 4 Ki entries; (lists + 1) record arrays of a tile's hits -- and the KNN query
   a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
-#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M>), dim3(n_tiles), dim3(256), lds, s, a)
+#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M, kHybDpt, kHybMaxLists>), dim3(n_tiles), dim3(256), lds, s, a)
   if (!a.k) RSGPU_HYB(KT_F32, KM_IP);  // (no KNN branch: any instantiation)
   else if (type == KT_F32 && metric == KM_L2) RSGPU_HYB(KT_F32, KM_L2);
   else if (type == KT_F32) RSGPU_HYB(KT_F32, KM_IP);

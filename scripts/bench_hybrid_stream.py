@@ -1,7 +1,6 @@
-"""configs[4] as the distinct-query stream of bench.py (16 term pairs, a query vector each), with the round-4 knobs of the
-two-launch hybrid query toggled one by one inside ONE process (A/B only inside one call: box-to-box variance is larger than
-the effects): hybrid_dir (bucket directory for the window ends), hybrid_packed_docs ({doc length, doc score} in one gather),
-hybrid_poll (completion flags in pinned memory instead of a stream synchronisation).  Prints wall p50 / p95 and the device times of both kernels."""
+"""configs[4] as the distinct-query stream of bench.py (16 term pairs, a query vector each), with the knobs of the two-launch
+hybrid query A/B'd inside ONE process (box-to-box variance is larger than the effects): CONFIGS="name:key=v,...;name2:...".
+Prints wall p50 / p95, the device times of both kernels and whether the answers equal the first configuration's."""
 import json
 import os
 import sys
@@ -34,23 +33,38 @@ enc = [B.encode_freqs_only(d, f) for d, f, _, _ in raws] if codec == "freqs_only
 qvecs = B.philox_host_rows(V, B.QUERY_BASE + 100, n_a * n_b, dim)
 out = {}
 ref = None
-KEYS = (b"hybrid_dir", b"hybrid_packed_docs", b"hybrid_poll", b"hybrid_knn_pipeline")
-CONFIGS = (("all off (round 3)", (0, 0, 0, 0)), ("dir+packed+poll", (1, 1, 1, 0)), ("+ knn pipeline", (1, 1, 1, 1)),
-           ("dir+packed+poll, again", (1, 1, 1, 0)), ("+ knn pipeline, again", (1, 1, 1, 1)))
-if os.environ.get("ONLY_DEFAULT") == "1":   # (PMC passes: the shipped configuration alone)
-    CONFIGS = (("all on", (1, 1, 1, 1)),)
+# CONFIGS="name:key=v,key=v;name2:..."  (knobs not named keep their defaults; every configuration is timed in turn, inside this
+# one process); MODES=warm | warm,cold; OUT=<file under gpurun_out/>
+DEFAULTS = {"hybrid_dir": 1, "hybrid_packed_docs": 1, "hybrid_poll": 1, "hybrid_knn_pipeline": 1}
+spec = os.environ.get("CONFIGS", "defaults:")
+CONFIGS = []
+for part in spec.split(";"):
+    name, _, kv = part.partition(":")
+    knobs = dict(DEFAULTS)
+    for item in kv.split(","):
+        if item:
+            k, v = item.split("=")
+            knobs[k] = int(v)
+    CONFIGS.append((name, knobs))
+modes = tuple(os.environ.get("MODES", "warm").split(","))
 for name, knobs in CONFIGS:
-    for key, val in zip(KEYS, knobs):
-        lib.RSGPU_SetTuning(key, val)
-    rec, ans, pairs = B._hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 4)))
+    for key, val in knobs.items():
+        assert lib.RSGPU_SetTuning(key.encode(), val) == 0, key
+    rec, ans, pairs = B._hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 4)),
+                                       modes=modes)
     if ref is None:
         ref = ans
     same = all(a["top"][0].tolist() == b["top"][0].tolist() and a["top"][1].tolist() == b["top"][1].tolist() and
                a["knn"][0].tolist() == b["knn"][0].tolist() and a["knn"][1].tolist() == b["knn"][1].tolist() and a["n_hits"] == b["n_hits"]
                for a, b in zip(ans, ref))
-    out[name] = {"warm_p50": rec["warm"]["wall_ms_p50"], "warm_p95": rec["warm"]["wall_ms_p95"], "warm_dev": rec["warm"]["device_ms"],
-                 "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"), "cold_p50": rec["cold"]["wall_ms_p50"], "cold_dev": rec["cold"]["device_ms"],
-                 "cold_decode_gbs": rec["cold"].get("decode_gbs_of_encoded_bytes"), "same_answers_as_first_config": bool(same)}
+    out[name] = {"knobs": {k: v for k, v in knobs.items() if v != DEFAULTS[k]}, "warm_p50": rec["warm"]["wall_ms_p50"], "warm_p95": rec["warm"]["wall_ms_p95"],
+                 "warm_dev": rec["warm"]["device_ms"], "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"),
+                 "tile_plus_reduce_hbm_frac": rec["warm"].get("tile_plus_reduce_hbm_frac"), "same_answers_as_first_config": bool(same)}
+    if "cold" in rec:
+        out[name].update({"cold_p50": rec["cold"]["wall_ms_p50"], "cold_dev": rec["cold"]["device_ms"],
+                          "cold_decode_gbs": rec["cold"].get("decode_gbs_of_encoded_bytes")})
     print(name, json.dumps(out[name]), flush=True)
+for key, val in DEFAULTS.items():
+    lib.RSGPU_SetTuning(key.encode(), val)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r04_hybrid_stream_ab_%s.json" % codec, "w"), indent=1)
+json.dump(out, open(os.path.join("gpurun_out", os.environ.get("OUT", "hybrid_stream_ab_%s.json" % codec)), "w"), indent=1)

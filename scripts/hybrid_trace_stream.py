@@ -45,6 +45,8 @@ for rep in range(2):
     for qi, hq in enumerate(hqs):
         hq.run()
         t = S.hybrid_trace().astype(np.int64)
+        if os.environ.get("TRACE_NPY") and rep == 1:
+            np.save(os.path.join("gpurun_out", os.environ["TRACE_NPY"] + "_q%d.npy" % qi), t)
         red, t = t[-2:], t[:-2]
         t0 = t[:, 0].min()
         d = np.diff(t, axis=1) / 100.0
