@@ -2,8 +2,9 @@
 // whole FLAT corpus in one GEMM pass on the matrix cores, exact top-k per query.
 //
 // No reference counterpart exists: VecSim answers B queries with B VecSimIndex_TopKQuery calls
-// (reference src/iterators/hybrid_reader.c:374).  Results are identical to B single queries up to
-// the fp32 summation order (MFMA k-order vs the scan's lane order), i.e. inside the parity tolerance.
+// (reference src/iterators/hybrid_reader.c:374).  EVERY route re-scores the survivors of its matrix-core filter passes with the
+// single-query scan's arithmetic (thresholds widened by the route's error band): replies are bit-identical to B single
+// queries.  (Until round 5 the FLOAT16 / BFLOAT16 IP / cosine route -- BASELINE configs[2] itself -- handed out the MFMA sums.)
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -129,8 +130,11 @@ bool FlatIndex::wide_pass_capable(size_t k) const {
       return true;  // int8 rows with one scale
     return t.gemm_qs_f32 && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) && !(metric != VecSimMetric_Cosine && hn_bad_);
   }
-  return (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric == VecSimMetric_L2 && !hn_bad_ &&
-         gemm_qs_supported((uint32_t)(stride_ / 16));
+  // FLOAT16 / BFLOAT16: L2 through the half norms, cosine with a constant band (|x| = |q| = 1), IP with a per-query band from
+  // the largest row norm -- all three re-scored exactly (round 5: IP / cosine too)
+  if (type != VecSimType_FLOAT16 && type != VecSimType_BFLOAT16) return false;
+  if (metric != VecSimMetric_Cosine && hn_bad_) return false;
+  return gemm_qs_supported((uint32_t)(stride_ / 16));
 }
 
 void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size_t *ids_out, double *scores_out,
@@ -175,17 +179,28 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // half norms are computed for that bound; a per-query band 2 rel |x|max |q| widens every threshold of query q)
   const bool f32_ip = f32_shape && metric == VecSimMetric_IP;
   if (f32_ip) via_f32 = via_f32 && ensure_half_norms();
-  const bool gemm_ok = via_shadow || via_l2 || via_f32 || (s8g_shape && type == VecSimType_FLOAT32) ||
-                       ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi &&
-                        k > 0 && k <= 4096);
+  // FLOAT16 / BFLOAT16 IP / cosine WITHOUT the int8 shadow (BASELINE configs[2]; round 5): the passes' fp32 sums differ from
+  // the single-query scan's by the summation order only (16-bit x 16-bit products are exact in fp32) -- every threshold is
+  // widened by that band (cosine: rel x |x||q| with both norms 1; IP: per query, rel x |x|max x |q|), the survivors are
+  // re-scored from the same rows with the scan's arithmetic -> bit-identical to single queries
+  const bool h16_shape = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2 && !multi && k > 0 &&
+                         k <= 1024 && scan_tuning().gemm_qs && scan_tuning().batch_mfma &&
+                         gemm_qs_supported((uint32_t)(stride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
+  const bool h16_ip = h16_shape && metric == VecSimMetric_IP;
   // FLOAT16 IP / cosine indexes that carry the int8 shadow (shadow_ == 3): the filter passes run on the int8 matrix
   // cores over half the bytes, every threshold is widened by the query's own error band, the survivors are re-scored
   // from the fp16 rows with the single-query scan's arithmetic -> ids and distances bit-identical to single queries
   bool via_shadow8 = !via_shadow && s8g_shape && ensure_shadow8g();
+  // (a 16-bit index that carries the int8 shadow takes the int8 passes; the plain 16-bit passes when the shadow is not usable)
+  bool via_h16 = h16_shape && !via_shadow8 && (size_t)n_rows_ + stage_n_ > (1u << 19) && (!h16_ip || ensure_half_norms());
+  const bool ip_band = f32_ip || (h16_ip && via_h16);
+  const bool gemm_ok = via_shadow || via_l2 || via_f32 || via_h16 || via_shadow8;
   // a FLOAT32 index has no MFMA form of its own: without the int8 rows (too small, a non-finite row, ...) -> single queries
   const bool f32_needs_s8g = type == VecSimType_FLOAT32 && !via_shadow && !f32_shape;
   // eps of the fp16 shadow: FlatIndex::two_stage_topk; of the bf16 pass over normalised fp32 rows: |x|, |q| <= 1 + 1e-3
-  const float slack = via_shadow ? 2.0f * 4e-3f : (via_f32 && metric == VecSimMetric_Cosine ? 2.0f * 1.002f * gemm_qs_f32_rel(dim) : 0.0f);
+  const float slack = via_shadow ? 2.0f * 4e-3f
+                                 : (via_f32 && metric == VecSimMetric_Cosine ? 2.0f * 1.002f * gemm_qs_f32_rel(dim)
+                                                                             : (via_h16 && metric == VecSimMetric_Cosine ? 2.0f * 1.002f * hn_rel() : 0.0f));
   auto single = [&](size_t qi) {
     VecSimQueryReply *r;
     {  // (not through the coalescer: this may BE the coalescer's leader)
@@ -251,7 +266,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     if (via_shadow8 && (s8g_built_ < n || s_bad_ || n <= (1u << 19))) via_shadow8 = false;
     if (via_l2 && (hn_built_ < n || hn_bad_ || n <= (1u << 19))) via_l2 = false;
     if (via_f32 && (n <= (1u << 19) || (metric == VecSimMetric_L2 && !via_l2) || (f32_ip && (hn_built_ < n || hn_bad_)))) via_f32 = false;
-    if ((f32_needs_s8g && !via_shadow8) || (l2_any && !via_l2) || (f32_shape && !via_f32)) {
+    if (via_h16 && (n <= (1u << 19) || (h16_ip && (hn_built_ < n || hn_bad_)))) via_h16 = false;
+    const bool h16_type = (type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && metric != VecSimMetric_L2;
+    if ((f32_needs_s8g && !via_shadow8) || (l2_any && !via_l2) || (f32_shape && !via_f32) || (h16_type && !via_h16 && !via_shadow8)) {
       g.unlock();
       all_single();
       return;
@@ -282,7 +299,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
     const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && (via_f32 ? gemm_qs_f32_supported(stride16) : gemm_qs_supported(stride16));
-    if ((via_shadow || via_shadow8 || via_l2 || via_f32) && !use_qs) {  // small corpora: the single-query path is already cheap
+    if (!use_qs) {  // small corpora, K above the passes' limit: the exact multi-query scan is already cheap / the only exact form
       g.unlock();
       all_single();
       return;
@@ -311,7 +328,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         seen = std::max(seen, e);
         from = e;
       }
-      expect_total *= via_shadow || via_f32 ? 18 : (via_shadow8 ? 48 : 6);  // (a shadow's error band multiplies the survivors)
+      expect_total *= via_shadow || via_f32 || via_h16 ? 18 : (via_shadow8 ? 48 : 6);  // (an error band multiplies the survivors)
       if (phase0) expect_total += n0;
     }
     const uint32_t cand_cap = small ? 1 : (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(1u << 15, expect_total));
@@ -325,7 +342,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         sc.qscale.ensure(kBatch);
         sc.slack_q.ensure(kBatch);
       }
-      if (via_f32 && f32_ip) {
+      if (ip_band && (via_f32 || via_h16)) {
         sc.slack_q.ensure(kBatch);
         sc.h_l2.ensure<float>(2 * kBatch);
       }
@@ -354,7 +371,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         const uint32_t grid = gemm_qs_grid(e - from);
         qs_grid_max = std::max(qs_grid_max, grid);
         const uint64_t expect = (uint64_t)kk * ((e - from + seen - 1) / seen) / (2ull * grid) + 1;
-        while (sub_cap < (via_shadow || via_f32 ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
+        while (sub_cap < (via_shadow || via_f32 || via_h16 ? 24 : (via_shadow8 ? 64 : 8)) * expect) sub_cap *= 2;
         if (phase0 && from == 0)  // every row of the first phase lands in a sub-list: 16 per lane and tile
           while (sub_cap < 16u * (((e + 31) / 32 + grid - 1) / grid)) sub_cap *= 2;
         seen = std::max(seen, e);
@@ -398,9 +415,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         slack_q = sc.slack_q.p;
         qscale = sc.qscale.p;
       }
-      if (via_f32 && f32_ip) {  // per-query band: 2 rel |x|max |q|; a query whose norm is not finite goes to the exact scan
+      if (ip_band && (via_f32 || via_h16)) {  // per-query band: 2 rel |x|max |q|; a query whose norm is not finite goes to the exact scan
         float *hl = static_cast<float *>(sc.h_l2.p);
-        const float rel = gemm_qs_f32_rel(dim) * 1.002f, xmax = sqrtf(2.0f * hn_max_) * 1.000001f;
+        const float rel = (via_f32 ? gemm_qs_f32_rel(dim) : hn_rel()) * 1.002f, xmax = sqrtf(2.0f * hn_max_) * 1.000001f;
         l2_redo[sl].assign(kBatch, 0);
         for (uint32_t i = 0; i < kBatch; i++) {
           const float h = i < nb ? half_sq_norm_host((const uint8_t *)queries + (q0 + i) * elem_bytes_) : 0.0f;
@@ -438,18 +455,13 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         rb.inv2rel = 0.5f / rel;
       }
       if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-      if (small) {
-        launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 0, sc.keys.p, n0, nullptr, nullptr, nullptr, 0,
-                         c->stream);
-        launch_batch_select_keys(sc.keys.p, n0, n, kk, kBatch, sc.out_rows.p, sc.out_keys.p, sc.out_n.p, kk, c->stream);
-        HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
-      } else {
+      {
         // the sample's bound: from the exact rows when the filter runs on the int8 shadow (the tiled GEMM has no int8 form;
         // an exact bound widened by the band is as good as a shadow bound widened by it)
         if (phase0) {  // tau = +inf for the queries of the batch, -inf for the padding
           float *ht = sc.h_tau.ensure<float>(kBatch);  // (pinned, one per slot: free again once the slot's batch is finalized)
           for (uint32_t i = 0; i < kBatch; i++)
-            ht[i] = i < nb && !((via_l2 || f32_ip) && l2_redo[sl][i]) ? __builtin_inff() : -__builtin_inff();
+            ht[i] = i < nb && !((via_l2 || ip_band) && l2_redo[sl][i]) ? __builtin_inff() : -__builtin_inff();
           HIP_CHECK(hipMemcpyAsync(sc.tau.p, ht, kBatch * sizeof(float), hipMemcpyHostToDevice, c->stream));
         } else {
           if (via_shadow8)
@@ -461,7 +473,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         }
         HIP_CHECK(hipMemsetAsync(sc.cand_count.p, 0, kBatch * sizeof(uint32_t), c->stream));
         HIP_CHECK(hipMemsetAsync(sc.overflow.p, 0, kBatch * sizeof(uint32_t), c->stream));
-        if (use_qs) {
+        {
           uint32_t from = 0;
           for (size_t ph = 0; ph < phase_end.size(); ph++) {
             const uint32_t e = phase_end[ph];
@@ -477,17 +489,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                                           c->stream, slack, slack_q);
             from = e;
           }
-        } else {
-          launch_gemm_topk(ktype, d_rows_, sc.queries.p, stride16, 0, n, 1, nullptr, 0, sc.tau.p, sc.cand_count.p,
-                           sc.cand.p, cand_cap, c->stream);
         }
-        if (via_shadow || via_shadow8 || via_l2 || via_f32) {
+        {
           // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
           // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                       c->stream, slack, slack_q);
           if (!launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
-                                    sc.tau.p, c->stream, via_shadow8 || via_l2 ? ktype : KT_F32, via_l2 ? KM_L2 : KM_IP,
+                                    sc.tau.p, c->stream, via_shadow8 || via_l2 || via_h16 ? ktype : KT_F32, via_l2 ? KM_L2 : KM_IP,
                                     via_l2 ? &rb : nullptr))
             throw std::runtime_error("batched shadow pass: the re-scoring kernel refused a row shape the route was gated on");
         }
@@ -522,7 +531,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       std::vector<VecSimQueryResult> res;
       for (uint32_t i = 0; i < nb; i++) {
         const size_t qi = q0 + i;
-        if (h_over[i] || ((via_l2 || (via_f32 && f32_ip)) && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
+        if (h_over[i] || ((via_l2 || ip_band) && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
           redo.push_back(qi);
           continue;
         }

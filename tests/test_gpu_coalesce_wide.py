@@ -78,3 +78,43 @@ def test_forty_callers_share_wide_passes_and_get_their_serial_answers(dim, metri
         lib.RSGPU_SetTuning(b"coalesce", 1)
         lib.RSGPU_SetTuning(b"coalesce_wide", 1)
         idx.free()
+
+
+@pytest.mark.parametrize("vtype,metric", [(V.VecSimType_FLOAT16, V.VecSimMetric_Cosine), (V.VecSimType_BFLOAT16, V.VecSimMetric_IP),
+                                          (V.VecSimType_FLOAT16, V.VecSimMetric_IP)])
+def test_sixteen_bit_ip_and_cosine_indexes_take_wide_passes_too(vtype, metric):
+    """round 5: the FLOAT16 / BFLOAT16 IP / cosine batched route (BASELINE configs[2]) re-scores its survivors exactly, so
+    wide_pass_capable admits these indexes: forty callers share matrix-core passes and every reply is bit-identical to the
+    query issued alone"""
+    import oracle as O
+    lib = V.load()
+    n, dim = 600_000, 256                                   # (rows of 512 bytes: the multi-query scan's smallest shape)
+    idx = V.VecSimIndex(vtype, dim, metric)
+    idx.add_philox_rows(31, 0, n, 1)
+    t = O.F16 if vtype == V.VecSimType_FLOAT16 else O.BF16
+    try:
+        rng = np.random.default_rng(3)
+        for lab in rng.choice(n, 100, replace=False):
+            idx.delete_vector(int(lab) + 1)
+        nq = 96
+        qs = O.philox_rows(31, 1 << 40, nq, dim, t)
+        if t == O.BF16:
+            qs = (qs.astype(np.uint32) << 16).view(np.float32)
+        ks = [(1, 10, 33, 100)[i % 4] for i in range(nq)]
+        orders = [V.BY_SCORE] * nq
+        lib.RSGPU_SetTuning(b"coalesce", 0)
+        want = [idx.topk_query(q, k).results() for q, k in zip(qs, ks)]
+        lib.RSGPU_SetTuning(b"coalesce", 1)
+        V.coalesce_stats(reset=True)
+        errors = _hammer(idx, qs, ks, orders, want, 40, 3)
+        assert not errors, errors[:3]
+        st = V.coalesce_stats()
+        assert st["wide_passes"] > 0, st
+        # ... and the batch entry point itself: bit-identical to the single queries
+        ids, sc, cnt = idx.topk_batch(qs, 100)
+        for i in range(0, nq, 7):
+            wi, ws = idx.topk_query(qs[i], 100).results()
+            assert ids[i].tolist() == wi.tolist() and np.array_equal(sc[i], ws), i
+    finally:
+        lib.RSGPU_SetTuning(b"coalesce", 1)
+        idx.free()

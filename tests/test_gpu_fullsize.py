@@ -295,9 +295,12 @@ def test_batched_config3_full_size_against_the_oracle():
         assert ids[qi, :len(labs)].tolist() == labs
     assert np.all(np.diff(sc, axis=1) >= 0)
     assert all(len(set(ids[i].tolist())) == k for i in range(nq))
-    for qi in (0, 7, 200, 255):
+    # round 5: this route re-scores its survivors with the single-query scan's arithmetic like every other batched route --
+    # the batch IS the single-query path, id for id and bit for bit
+    for qi in (0, 7, 31, 64, 100, 128, 200, 255):
         si, ss = idx.topk_query(queries[qi], k).results()
-        assert len(set(si.tolist()) ^ set(ids[qi].tolist())) <= 2 and np.allclose(ss, sc[qi], rtol=1e-3, atol=2e-3)
+        assert si.tolist() == ids[qi].tolist(), qi
+        assert np.array_equal(ss, sc[qi]), qi
     if _host_gb() < 50:
         pytest.skip("oracle leg needs ~35 GB of host memory")
     o = O.FlatIndex(O.F16, dim, O.IP)
@@ -306,19 +309,19 @@ def test_batched_config3_full_size_against_the_oracle():
         o.add_bulk(O.philox_rows(SEED, a0, min(step, rows - a0), dim, O.F16), a0 + 1)
     for v, l in planted_rows:
         o.add(v, l)
-    tol = 2e-3   # |fp32 sums of 768 fp16 products| differ by summation order between MFMA tiles and the scalar loop
+    tol = 1e-4   # the oracle's scalar fp32 loop against the scan's lane order: north_star's fp32 tolerance
     for qi in (0, 7, 31, 64, 100, 128, 200, 255):
         oi, os_ = o.topk(queries[qi], k)
         gset, oset = set(ids[qi].tolist()), set(oi.tolist())
         nqb = o.normalized_query(queries[qi])
-        for lab_ in gset ^ oset:                                       # only rank-K near-ties may differ
-            assert abs(o.distance_from(int(lab_), nqb) - os_[-1]) <= tol, (qi, lab_)
-        assert len(gset ^ oset) <= 4, (qi, len(gset ^ oset))
-        assert np.allclose(np.sort(sc[qi]), np.sort(os_), rtol=1e-3, atol=tol)
+        for lab_ in gset ^ oset:                                       # only a true fp32 tie at rank K may differ
+            assert abs(o.distance_from(int(lab_), nqb) - os_[-1]) <= tol * max(1.0, abs(os_[-1])), (qi, lab_)
+        assert len(gset ^ oset) <= 2, (qi, len(gset ^ oset))
+        assert np.allclose(np.sort(sc[qi]), np.sort(os_), rtol=1e-4, atol=tol)
         common = [x for x in ids[qi].tolist() if x in oset]
         god = dict(zip(ids[qi].tolist(), sc[qi].tolist()))
         ood = dict(zip(oi.tolist(), os_.tolist()))
-        assert max(abs(god[x] - ood[x]) for x in common) <= tol
+        assert max(abs(god[x] - ood[x]) / max(1.0, abs(ood[x])) for x in common) <= tol
 
 
 def test_batched_config3_int8_shadow_full_size():
