@@ -813,6 +813,12 @@ def _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_
             mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridTreeQuery(S.OP_INTERSECT, [(S.OP_TERM, 1.0, [fu[i]]), (S.OP_TERM, 1.0, [fu[j]])], max_slop=30,
                                                                      index=idx, q=qvecs[qi], k=10, **a))
         shapes["two_terms_max_slop_30_full_codec_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 5: `a | b` -- a root union, one tile-kernel pass per child + one reduce
+            a = sc([i, j]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridTreeQuery(S.OP_UNION, [(S.OP_TERM, 1.0, [fo[i]]), (S.OP_TERM, 1.0, [fo[j]])],
+                                                                     index=idx, q=qvecs[qi], k=10, **a))
+        shapes["root_union_of_two_terms_freqs_only_bm25std_knn"] = mk
         for name, makers in shapes.items():
             rec = {}
             answers = {}

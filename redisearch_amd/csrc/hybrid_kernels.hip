@@ -974,7 +974,19 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 #pragma unroll
     for (int r = 0; r < ML; r++)
       if (r < A.n_req) h = h && (mb[k] & A.req[r]) != 0u;
-    hit[k] = h && (mb[k] & A.veto) == 0u;  // (NOT children: not.rs:171-209 -- the document must be absent from every excluded list)
+    h = h && (mb[k] & A.veto) == 0u;  // (NOT children: not.rs:171-209 -- the document must be absent from every excluded list)
+#pragma unroll
+    for (int r = 0; r < ML; r++)
+      if (r < A.n_veto_all) h = h && (mb[k] & A.veto_all[r]) != A.veto_all[r];  // (root union: an earlier child's pass reports it)
+    hit[k] = h;
+    // a later child intersection that does not match as a whole is not in the result: its terms are absent
+    uint32_t gone = 0u;
+#pragma unroll
+    for (int r = 0; r < ML; r++)
+      if (r < A.n_opt_all && (mb[k] & A.opt_all[r]) != A.opt_all[r]) gone |= A.opt_all[r];
+#pragma unroll
+    for (int l = 1; l < ML; l++)
+      if ((gone >> l) & 1u) ps[k][l - 1] = kHybNone;
   }
   uint32_t slot[DPT];
   const uint32_t nc = ordered_slots<DPT>(hit, slot, seg);

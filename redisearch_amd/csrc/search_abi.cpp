@@ -1820,7 +1820,9 @@ static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_
     }
     groups.push_back(t);
   }
-  if (!q->in_order) std::stable_sort(groups.begin(), groups.end(), [](const HybGroup &x, const HybGroup &y) { return x.key() < y.key(); });
+  // (an intersection iterates its children by ascending estimate; a union keeps the query's order: union_flat.rs)
+  if (!q->in_order && q->root_op == RSGPU_OP_INTERSECT)
+    std::stable_sort(groups.begin(), groups.end(), [](const HybGroup &x, const HybGroup &y) { return x.key() < y.key(); });
   return groups;
 }
 // the leaf that drives the probe: the shortest list every hit must hold (a term child, a term of a child intersection);
@@ -1839,12 +1841,42 @@ static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const
   return best;
 }
 
+// the shortest list of one child (a term, or the terms of a child intersection); -1: a union child has no list every hit holds
+static int hyb_group_driver(const HybGroup &g, RSGPU_Postings *const *lists, uint32_t *n0_out) {
+  int best = -1;
+  uint32_t n0 = 0;
+  if (g.op == 0 || g.op == 2)
+    for (int li : g.lists)
+      if (best < 0 || lists[li]->n_entries < n0) {
+        best = li;
+        n0 = lists[li]->n_entries;
+      }
+  *n0_out = n0;
+  return best;
+}
+// tiles of a root UNION (one pass per child, the child's shortest list drives); 0: a child is a union / empty -- no such form
+static uint32_t hyb_union_tiles(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists) {
+  uint64_t total = 0;
+  for (const HybGroup &g : groups) {
+    uint32_t n0 = 0;
+    if (hyb_group_driver(g, lists, &n0) < 0 || !n0) return 0;
+    total += hybrid_tiles(n0);
+  }
+  return (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull);
+}
+
 // The caller holds the index lock and has checked the shapes (hybrid_tree_supported over the driver's tiles, every list
-// non-empty, <= kHybTreeMaxLists lists, not BM25STD.NORM).  hits_out (may be NULL): receives the hit list.  false: the reduce
-// kernel met more candidates at its bound than it ranks -- nothing was handed out, the staged pipeline takes the query.
+// non-empty, <= kHybTreeMaxLists lists, not BM25STD.NORM).  hits_out (may be NULL): receives the hit list.  false: BM25STD.NORM
+// met a tie across its cut (hyb_collect) -- nothing was handed out, the staged pipeline takes the query.
+// root_union (round 5; `a | b`, `(a b) | (c d)`, `a | (b c)`: union_flat.rs:223-320): the children in the QUERY's order, one
+// pass of the tile kernel per child -- the child's shortest list drives, every other list is probed; a document an EARLIER
+// child matches belongs to that child's pass (veto_all), a LATER child intersection counts only when it matches as a whole
+// (opt_all) -- all passes write their tiles' fixed slots side by side and ONE reduce kernel ranks them: the composites are
+// total orders and every hit is reported by exactly one pass.  No hit list (its order would interleave the passes), no
+// slop-dependent scorer (a union result's slop depends on which children matched): the caller checks.
 static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *lists, const std::vector<HybGroup> &groups, long max_slop,
                            int in_order, RSGPU_Hits **hits_out, FlatIndex *f, const LabelRows &knn_rows, bool want_score, bool want_knn,
-                           QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev) {
+                           QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev, bool root_union = false) {
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
   for (const HybGroup &g : groups)
     for (int li : g.lists) decode_on(lists[li], ca);
@@ -1889,14 +1921,35 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     srcs.push_back(s);
   }
   ListView v;
-  const LeafMap m = adopt_sources(&h, srcs, v, 2);
-  h.is_union = false;
+  const LeafMap m = adopt_sources(&h, srcs, v, root_union ? 1 : 2);
+  h.is_union = root_union;
   const int n = h.n_lists;  // leaves
-  uint32_t n0 = 0;
-  const int driver = hyb_driver(groups, lists, &n0);  // (a caller's list index)
   const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;  // (one entry more: hyb_collect)
   const uint32_t top_n = want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, k = want_knn ? (uint32_t)a->k : 0u;
-  const uint32_t n_tiles = hybrid_tiles(n0);
+
+  // the passes: one (root intersection: the shortest required list drives), or one per child of a root union
+  struct Pass {
+    int driver;  // a caller's list index
+    int group;   // root union: the child this pass belongs to
+    uint32_t n0, tiles, first_tile;
+  };
+  std::vector<Pass> passes;
+  uint32_t n_tiles = 0;
+  if (root_union) {
+    for (size_t g = 0; g < groups.size(); g++) {
+      Pass p{-1, (int)g, 0, 0, n_tiles};
+      p.driver = hyb_group_driver(groups[g], lists, &p.n0);
+      if (p.driver < 0 || !p.n0) throw std::runtime_error("hybrid query: a root union's children must be terms or intersections of terms");
+      p.tiles = hybrid_tiles(p.n0);
+      n_tiles += p.tiles;
+      passes.push_back(p);
+    }
+  } else {
+    Pass p{-1, -1, 0, 0, 0};
+    p.driver = hyb_driver(groups, lists, &p.n0);
+    p.tiles = n_tiles = hybrid_tiles(p.n0);
+    passes.push_back(p);
+  }
 
   std::vector<RSGPU_Postings *> excluded;  // NOT children's lists: probed behind the leaves, no column of their own
   for (const HybGroup &g : groups)
@@ -1905,56 +1958,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
         if (lists[li]->n_entries) excluded.push_back(lists[li]);  // (an empty list excludes nothing)
   if (n + (int)excluded.size() > kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight lists");
   if (!excluded.empty() && hits_out) throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children has no hit list (hits_out must be NULL)");
+  if (root_union && (hits_out || !excluded.empty())) throw std::runtime_error("hybrid query: a root union on the tile path has neither a hit list nor NOT children");
   HybridTreeArgs T;
   memset(&T, 0, sizeof T);
   T.n = n + (int)excluded.size();
   T.n_leaves = n;
-  // lists in probe order: the driver, then the other leaves in leaf order
-  int leaf_of_list[kHybTreeMaxLists], list_of_leaf[kHybTreeMaxLists];
-  {
-    int driver_leaf = -1;
-    for (int t = 0; t < n; t++)
-      if (driver_leaf < 0 && h.order[t] == driver) driver_leaf = t;
-    int l = 1;
-    for (int t = 0; t < n; t++) {
-      const int slot = t == driver_leaf ? 0 : l++;
-      leaf_of_list[slot] = t;
-      list_of_leaf[t] = slot;
-    }
-  }
-  for (int l = 0; l < n; l++) {
-    const int t = leaf_of_list[l];
-    RSGPU_Postings *pl = const_cast<RSGPU_Postings *>(h.src[t]);
-    T.ids[l] = pl->ids.p;
-    T.len[l] = pl->n_entries;
-    T.add[l] = (long long)(pl->base - h.base);  // (two's complement: negative when the list's base lies below the frame's)
-    T.leaf_of[l] = (uint8_t)t;
-    if (l && scan_tuning().hybrid_dir) {
-      ensure_bucket_dir(pl, ca);
-      if (pl->dir_ready.load(std::memory_order_acquire)) {
-        T.dir[l] = pl->dir.p;
-        T.dir_shift[l] = pl->dir_shift;
-        T.dir_n[l] = pl->dir_n;
-      }
-    }
-  }
-  for (size_t x = 0; x < excluded.size(); x++) {
-    const int l = n + (int)x;
-    RSGPU_Postings *pl = excluded[x];
-    T.ids[l] = pl->ids.p;
-    T.len[l] = pl->n_entries;
-    T.add[l] = (long long)(pl->base - h.base);
-    T.leaf_of[l] = 0xFF;
-    T.veto |= 1u << l;
-    if (scan_tuning().hybrid_dir) {
-      ensure_bucket_dir(pl, ca);
-      if (pl->dir_ready.load(std::memory_order_acquire)) {
-        T.dir[l] = pl->dir.p;
-        T.dir_shift[l] = pl->dir_shift;
-        T.dir_n[l] = pl->dir_n;
-      }
-    }
-  }
   for (int t = 0; t < n; t++) {
     T.lfreq[t] = m.leaf_freq[t];
     const RSGPU_Postings *pl = h.src[t];
@@ -1962,25 +1970,16 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     T.O.off_pos[t] = pl->has_offsets() ? pl->off_pos.p : nullptr;
     T.O.off_len[t] = pl->has_offsets() ? pl->off_len.p : nullptr;
   }
-  // what a hit must hold: a term; every term of a child intersection; any term of a child union
-  for (int g = 0; g < h.n_groups; g++) {
-    uint32_t any = 0;
-    for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) {
-      if (h.group_op[g] == 1) any |= 1u << list_of_leaf[t];
-      else T.req[T.n_req++] = 1u << list_of_leaf[t];
-    }
-    if (h.group_op[g] == 1) T.req[T.n_req++] = any;  // (a NOT child's virtual group has no leaves: nothing required)
-  }
   T.X = tree_prox(&h, max_slop, in_order);
   // (combine_and: the filter runs when a window is asked for, the root has more than one child and some list stores offsets)
-  T.prox_filter = ((max_slop >= 0 || in_order) && h.n_groups > 1 && h.with_offsets) ? 1 : 0;
+  T.prox_filter = (!root_union && (max_slop >= 0 || in_order) && h.n_groups > 1 && h.with_offsets) ? 1 : 0;
   T.knn_pipeline = scan_tuning().hybrid_knn_pipeline;
   T.top_n = top_n;
   if (want_score) {
     bool max_norm = false;
     fill_score_params(T.P, &h, a->table, a->score, &max_norm);
     // (hit_slops: the per-hit slop exists when some list stores offsets and the root has two children or more)
-    T.prox_slop = (slop_dependent(T.P.scorer) && h.with_offsets && h.n_groups >= 2) ? 1 : 0;
+    T.prox_slop = (!root_union && slop_dependent(T.P.scorer) && h.with_offsets && h.n_groups >= 2) ? 1 : 0;
     T.doc_len = a->table->doc_len.p;
     T.doc_score = a->table->doc_score.p;
     T.max_freq = a->table->max_freq.p;
@@ -1998,10 +1997,6 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   HybridReduceArgs R;
   hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
   sc.hyb_trace_tiles = 0;
-  T.tile_hits = sc.hyb_hits.p;
-  T.part_skey = sc.hyb_skey.p;
-  T.part_sidx = sc.hyb_sidx.p;
-  T.part_knn = sc.hyb_knn.p;
   const uint32_t stride = n_tiles * 1024u;
   if (hits_out) {
     sc.hyb_hit_ids.ensure(stride);
@@ -2011,16 +2006,94 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     T.hit_freqs = sc.hyb_hit_freqs.p;
     T.hit_epos = h.with_offsets ? sc.hyb_hit_epos.p : nullptr;
     T.hit_stride = stride;
-    h.cap = std::max<uint32_t>(n0, 1);
+    h.cap = std::max<uint32_t>(passes[0].n0, 1);
     h.ids.alloc(h.cap);
     h.freqs.alloc((size_t)h.cap * n);
     if (h.with_offsets) h.epos.alloc((size_t)h.cap * n);
   }
   ca->h_fcnt[0] = 0;
 
+  // one pass: the lists in probe order (the driver, then the other leaves in leaf order, then the excluded lists), what a hit
+  // must hold, where the pass's tiles write
+  auto fill_pass = [&](HybridTreeArgs &P, const Pass &ps) {
+    P = T;
+    int leaf_of_list[kHybTreeMaxLists], list_of_leaf[kHybTreeMaxLists];
+    {
+      int driver_leaf = -1;
+      for (int t = 0; t < n; t++)
+        if (driver_leaf < 0 && h.order[t] == ps.driver) driver_leaf = t;
+      int l = 1;
+      for (int t = 0; t < n; t++) {
+        const int slot = t == driver_leaf ? 0 : l++;
+        leaf_of_list[slot] = t;
+        list_of_leaf[t] = slot;
+      }
+    }
+    for (int l = 0; l < n; l++) {
+      const int t = leaf_of_list[l];
+      RSGPU_Postings *pl = const_cast<RSGPU_Postings *>(h.src[t]);
+      P.ids[l] = pl->ids.p;
+      P.len[l] = pl->n_entries;
+      P.add[l] = (long long)(pl->base - h.base);  // (two's complement: negative when the list's base lies below the frame's)
+      P.leaf_of[l] = (uint8_t)t;
+      if (l && scan_tuning().hybrid_dir) {
+        ensure_bucket_dir(pl, ca);
+        if (pl->dir_ready.load(std::memory_order_acquire)) {
+          P.dir[l] = pl->dir.p;
+          P.dir_shift[l] = pl->dir_shift;
+          P.dir_n[l] = pl->dir_n;
+        }
+      }
+    }
+    for (size_t x = 0; x < excluded.size(); x++) {
+      const int l = n + (int)x;
+      RSGPU_Postings *pl = excluded[x];
+      P.ids[l] = pl->ids.p;
+      P.len[l] = pl->n_entries;
+      P.add[l] = (long long)(pl->base - h.base);
+      P.leaf_of[l] = 0xFF;
+      P.veto |= 1u << l;
+      if (scan_tuning().hybrid_dir) {
+        ensure_bucket_dir(pl, ca);
+        if (pl->dir_ready.load(std::memory_order_acquire)) {
+          P.dir[l] = pl->dir.p;
+          P.dir_shift[l] = pl->dir_shift;
+          P.dir_n[l] = pl->dir_n;
+        }
+      }
+    }
+    for (int g = 0; g < h.n_groups; g++) {
+      uint32_t all = 0;
+      for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) all |= 1u << list_of_leaf[t];
+      if (!root_union) {
+        // what a hit must hold: a term; every term of a child intersection; any term of a child union
+        if (h.group_op[g] == 1) {
+          P.req[P.n_req++] = all;  // (a NOT child's virtual group has no leaves: nothing required)
+        } else {
+          for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) P.req[P.n_req++] = 1u << list_of_leaf[t];
+        }
+      } else if (g == ps.group) {
+        for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) P.req[P.n_req++] = 1u << list_of_leaf[t];
+      } else {
+        if (g < ps.group) P.veto_all[P.n_veto_all++] = all;
+        // (any OTHER child intersection that does not match as a whole is not in the result -- an earlier one that does is
+        // vetoed above)
+        if (h.group_op[g] == 2 && h.group_first[g + 1] - h.group_first[g] > 1) P.opt_all[P.n_opt_all++] = all;
+      }
+    }
+    P.tile_hits = sc.hyb_hits.p + ps.first_tile;
+    P.part_skey = sc.hyb_skey.p + (size_t)ps.first_tile * top_n;
+    P.part_sidx = sc.hyb_sidx.p + (size_t)ps.first_tile * top_n;
+    P.part_knn = sc.hyb_knn.p + (size_t)ps.first_tile * k;
+  };
+
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
   if (n_tiles) {
-    launch_hybrid_tree_tiles(T, f ? f->ktype : 0, f ? f->kmetric : 0, n_tiles, ca->stream);
+    for (const Pass &ps : passes) {
+      HybridTreeArgs P;
+      fill_pass(P, ps);
+      launch_hybrid_tree_tiles(P, f ? f->ktype : 0, f ? f->kmetric : 0, ps.tiles, ca->stream);
+    }
     if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
     launch_hybrid_reduce(R, ca->stream);
     if (hits_out)
@@ -2029,6 +2102,9 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
+    // (the exact select settles a mass tie by (key, POSITION): doc-id order inside one pass, not across the passes of a root
+    // union -- that query, which has a staged form, takes it)
+    if (root_union && top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) return false;
     hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
@@ -2417,8 +2493,16 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   tls_hybrid_path = 0;
   HIP_CHECK(hipSetDevice(device));
 
+  // A root UNION of terms / intersections of terms (`a | b`, `(a b) | (c d)`: round 5) takes the tile kernel too -- one pass per
+  // child, one reduce -- when nobody asked for the hit list and the scorer does not divide by the result's slop (a union result
+  // holds the matched children only: its slop differs from hit to hit)
+  bool root_union = q->root_op == RSGPU_OP_UNION && !a->hits_out && !(want_score && slop_dependent(a->score->scorer));
+  if (root_union && q->group_op)
+    for (size_t g = 0; g < q->n_groups && root_union; g++)
+      root_union = q->group_op[g] == RSGPU_OP_TERM || q->group_op[g] == RSGPU_OP_INTERSECT;
   bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) &&
-                 q->root_op == RSGPU_OP_INTERSECT && n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
+                 (q->root_op == RSGPU_OP_INTERSECT || root_union) && n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
+  root_union = root_union && general;
   const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
   // (an EXCLUDED list may be empty -- `a -b` with an empty b is `a`: the list is simply not probed -- a required one may not)
   std::vector<char> excluded_list(n_lists, 0);
@@ -2430,8 +2514,9 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   if (general) {
     const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists);
     uint32_t n0 = 0;
-    general = hyb_driver(groups, q->lists, &n0) >= 0 &&
-              hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, hybrid_tiles(n0),
+    const uint32_t tiles = root_union ? hyb_union_tiles(groups, q->lists) : (hyb_driver(groups, q->lists, &n0) >= 0 ? hybrid_tiles(n0) : 0u);
+    general = tiles > 0 &&
+              hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
                                     want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
     if (general) {
       if (f) f->flush_if_needed();
@@ -2448,7 +2533,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
         if (general) f->upload_query(ca.c, a->query, true);
       }
       if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, knn_rows, want_score, want_knn, ca.c,
-                                    cb.c, sc, prof, ev)) {
+                                    cb.c, sc, prof, ev, root_union)) {
         tls_hybrid_path = 2;
         return 0;
       }

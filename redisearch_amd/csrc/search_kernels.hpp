@@ -307,6 +307,13 @@ struct HybridTreeArgs {
   uint8_t leaf_of[kHybTreeMaxLists];           // list l -> its leaf column in the result tree (0xFF: an excluded list, no column)
   int n_req;
   uint32_t req[kHybTreeMaxLists];              // bit l: list l; a candidate matches a list of EVERY set
+  // round 5 -- a root UNION, one pass per child (the pass's child drives; search_abi.cpp hybrid_general): a document that an
+  // EARLIER child matches is that child's pass's hit -- veto_all[v]: every list of the set holds it -> not a hit of this pass;
+  // any OTHER child that is an intersection contributes its terms only when it matches as a whole -- opt_all[o]: unless every
+  // list of the set holds the document, its leaves count as absent (frequency 0, union_flat.rs:297-320: the result holds the
+  // matched children only)
+  int n_veto_all, n_opt_all;
+  uint32_t veto_all[kHybTreeMaxLists], opt_all[kHybTreeMaxLists];
   const uint32_t *lfreq[kHybTreeMaxLists];     // by LEAF: decoded frequencies (NULL: the codec stores none -- 1)
   // proximity (by leaf): X.max_slop / X.in_order for the filter, the children for both
   int prox_filter, prox_slop;

@@ -327,18 +327,124 @@ def test_tree_query_shapes_the_general_kernel_declines():
     idf = [S.calculate_idf(2500, s) for s in sizes]
     bidf = [S.calculate_idf_bm25(2500, s) for s in sizes]
     w = [1.0, 2.0, 0.5, 1.0]
-    for root, groups, scorer in ((I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD"), (U, [(T, 1.0, g[:1]), (I, 1.0, g[1:3])], "BM25STD"),
-                                 (I, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD.NORM")):
+    # (round 5: a root union of terms / intersections takes the tile kernel -- unless it has a union child, the hit list is wanted or
+    # the scorer divides by the result's slop, which differs from hit to hit in a union)
+    for root, groups, scorer, kw, path in ((I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", {}, 0),
+                                           (U, [(T, 1.0, g[:1]), (I, 1.0, g[1:3])], "BM25STD", {}, 2),
+                                           (U, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD", {}, 0),
+                                           (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "TFIDF", {}, 0),
+                                           (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "BM25STD", dict(want_hits=True), 0),
+                                           (I, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD.NORM", {}, 2)):
         nl = sum(len(x[2]) for x in groups)
         hq = S.HybridTreeQuery(root, groups, table=table, scorer=scorer, idf=idf[:nl], bm25_idf=bidf[:nl], weight=w[:nl], num_docs=2500,
-                               avg_doc_len=150.0, top_n=10)
+                               avg_doc_len=150.0, top_n=10, **kw)
         hq.run()
-        assert S.hybrid_path() == (2 if scorer == "BM25STD.NORM" else 0)
+        assert S.hybrid_path() == path, (root, scorer, kw)
         r = hq.results()
         h = S.TreeHits(root, groups)
         h.score(table, scorer, idf[:nl], bidf[:nl], w[:nl], 2500, 150.0, want_scores=False)
         ti, ts = h.topn(10)
         assert r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
+
+
+# ---- a root UNION on the tile path (round 5) ----------------------------------------------------------------------------------------
+UNION_SHAPES = [
+    ("a|b", [(T, 1.0, [0]), (T, 1.0, [1])]),
+    ("a|b|c|d", [(T, 1.0, [0]), (T, 1.0, [1]), (T, 1.0, [2]), (T, 1.0, [3])]),
+    ("(a b)|(c d)", [(I, 2.0, [0, 1]), (I, 0.5, [2, 3])]),
+    ("a|(b c)|d", [(T, 1.0, [0]), (I, 1.5, [1, 2]), (T, 1.0, [3])]),
+    ("(a b c)|(d e)|f|(g h)", [(I, 1.0, [0, 1, 2]), (I, 2.0, [3, 4]), (T, 1.0, [5]), (I, 0.25, [6, 7])]),
+]
+
+
+@pytest.mark.parametrize("with_offsets", [False, True])
+@pytest.mark.parametrize("name,shape", UNION_SHAPES)
+def test_root_union_takes_the_tile_kernel(name, shape, with_offsets):
+    """`hello | world =>[KNN ...]`: the commonest shape the staged pipeline still held (0.69 ms against 0.13 for an AND).  One
+    pass of the tile kernel per child (its shortest list drives; a document an earlier child matches belongs to that child's
+    pass; a later child intersection counts only when it matches as a whole), ONE reduce: against the staged form bit for bit
+    and the CPU oracle directly -- set algebra, the result tree Union{matched children} scored by the oracle's scorers in the
+    reference's order, O.FlatIndex distances"""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + int(with_offsets))
+    codec = O.C_FULL if with_offsets else O.C_FREQS_ONLY
+    n_lists = sum(len(gp[2]) for gp in shape)
+    max_doc = 30_000
+    built = [rand_list(rng, codec, int(rng.integers(3000, 9000)), max_doc, with_offsets) for _ in range(n_lists)]
+    recs, sizes = [x[1] for x in built], [x[0].unique_docs for x in built]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    groups = [(op, wt, [g[i] for i in ix]) for op, wt, ix in shape]
+    doc_len = rng.integers(5, 200, max_doc + 1).astype(np.uint32)
+    doc_score = rng.choice([1.0, 0.5], max_doc + 1).astype(np.float32)
+    max_freq = rng.integers(1, 40, max_doc + 1).astype(np.uint32)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    idf = [S.calculate_idf(max_doc, s_) for s_ in sizes]
+    bidf = [S.calculate_idf_bm25(max_doc, s_) for s_ in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    avg = float(doc_len[1:].mean())
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    n_vec = 12_000
+    idx.add_philox_rows(11, 0, n_vec, 5000)                     # documents 5 000 .. 16 999 have a vector
+    idx.delete_vector(6000)                                     # (the device label table, not identity arithmetic)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    ot = OracleTree(U, shape, recs, sizes)
+    assert len(ot.docs) > 1500
+    for scorer in ("BM25STD", "BM25STD.TANH", "DOCSCORE", "DISMAX", "BM25STD.NORM"):
+        a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
+                                                                  num_docs=max_doc, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
+                                                                  root_weight=1.5))
+        assert a["n_hits"] == len(ot.docs), (scorer, a["n_hits"], len(ot.docs))
+        if scorer == "BM25STD.NORM":
+            continue                                             # (held to the staged form above; the oracle has no such scorer)
+        scored = []
+        for d in ot.docs:
+            node = ot.node(d, idf, bidf, w)
+            node.c.weight = 1.5
+            scored.append((O.score(scorer, node, float(doc_score[d]), int(max_freq[d]), int(doc_len[d]), max_doc, avg), d))
+        scored.sort(key=lambda t: (-t[0], t[1]))
+        assert a["top"][0].tolist() == [d for _, d in scored[:10]], (scorer, a["top"][0], scored[:10])
+        if scorer == "BM25STD.TANH":
+            assert a["top"][1] == pytest.approx([x for x, _ in scored[:10]], rel=1e-12)
+        else:
+            assert a["top"][1].tolist() == [x for x, _ in scored[:10]], scorer
+    cand = np.asarray([d for d in ot.docs if 5000 <= d < 5000 + n_vec and d != 6000], np.int64)
+    o = O.FlatIndex(O.F32, 24, O.L2)
+    o.add_bulk(O.philox_rows(11, 0, n_vec, 24)[cand - 5000], 1)
+    li, ls = o.topk(q, 10)
+    assert a["knn"][0].tolist() == cand[li.astype(np.int64) - 1].tolist()
+    assert np.all(np.abs(a["knn"][1] - ls) <= 1e-4 + 1e-5 * np.abs(ls))
+    idx.free()
+
+
+def test_root_union_over_many_tiles_and_one_sided_children():
+    """long lists (hundreds of tiles per pass), a child that matches almost everything next to one that matches almost nothing,
+    and a mass tie at the reduce kernel's bound settled by the exact select"""
+    rng = np.random.default_rng(5)
+    n_docs = 900_000
+    lists_o, rng = flat_corpus(n_docs, (0.6, 0.002, 0.3, 0.45), 909)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = table_for(rng, n_docs)
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists_o]
+    bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists_o]
+    w = [1.0, 0.5, 2.0, 1.5]
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 48, V.VecSimMetric_L2)
+    idx.add_philox_rows(7, 0, 200_000, 1)
+    q = O.philox_rows(7, 1 << 40, 1, 48)[0]
+    for groups in ([(T, 1.0, g[:1]), (T, 1.0, g[1:2])], [(T, 1.0, g[1:2]), (I, 2.0, g[2:4]), (T, 1.0, g[:1])]):
+        order = [x for _, _, gl in groups for x in gl]
+        sel = [g.index(x) for x in order]
+        kw = dict(table=table, idf=[idf[i] for i in sel], bm25_idf=[bidf[i] for i in sel], weight=[w[i] for i in sel], num_docs=n_docs,
+                  avg_doc_len=200.0, index=idx, q=q, root_weight=1.25)
+        for scorer, top_n, k, cap in (("BM25STD", 10, 10, 2048), ("DOCSCORE", 32, 5, 2048), ("DOCSCORE", 10, 10, 4)):
+            try:
+                knob("hybrid_surv_cap", cap)
+                # (cap 4: the reduce kernel hands a mass tie back; the exact select's (key, position) order is doc-id order inside
+                # one pass only, so a root union takes its staged form -- same answers, path 0)
+                a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, **kw),
+                                                want_path=2 if cap == 2048 else 0)
+            finally:
+                knob("hybrid_surv_cap", 2048)
+            assert a["n_hits"] > 500_000 and len(a["top"][0]) == top_n and len(a["knn"][0]) == k
+    idx.free()
 
 
 # ---- RSGPU_EvalTree through the tile kernel -----------------------------------------------------------------------------------------
