@@ -604,11 +604,12 @@ def extra_batched(lib, V, rows, dim):
         lib.RSGPU_SetProfiling(0)
         launches, ms, _ = V.scan_profile()
         dev_ms = ms / max(launches, 1)
-        # parity: 4 of the 256 queries against the single-query path of the same index (exact ids up to fp16-sum ties)
+        # parity: 4 of the 256 queries against the single-query path of the same index -- BIT-IDENTICAL since round 5 (the
+        # survivors of the matrix-core passes are re-scored with the single-query scan's arithmetic, as on every other route)
         ok, worst = True, 0.0
         for i in (0, 85, 170, 255):
             si, ss = idx.topk_query(qs[reps % 4][i], k).results()
-            ok &= len(set(si.tolist()) & set(ids[i].tolist())) >= k - 2
+            ok &= si.tolist() == ids[i].tolist() and ss.tolist() == sc[i].tolist()
             worst = max(worst, float(np.max(np.abs(np.sort(sc[i]) - np.sort(ss)))))
         flops = 2.0 * batch * dim * rows
         # opt-in int8 shadow of the same corpus (RSGPU_SetTuning("shadow8") before VecSimIndex_New): the filter passes run
@@ -656,9 +657,12 @@ def extra_batched(lib, V, rows, dim):
                 "device_ms_per_pass": dev_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": reps * batch / el,
                 "hbm_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac": rows * dim * 2 / dev_ms / 1e6 / HBM_PEAK_GBS,
                 "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
-                "kernel": "gemm_qs_kernel (query-stationary MFMA filter pass) + thresholds + per-query select; HIP events around the whole device pipeline of a pass",
-                "parity": {"ok": bool(ok and worst <= 2e-3), "vs": "single-query path, 4 of 256 queries: top-%d overlap >= %d, |d| <= 2e-3 "
-                                                                  "(replaced by the CPU-oracle check in the cpu_baseline leg)" % (k, k - 2),
+                "kernel": "gemm_qs_kernel (query-stationary MFMA filter pass, thresholds widened by the summation-order band) + exact re-scoring "
+                          "of the survivors (batch_rescore_kernel: the single-query scan's arithmetic) + per-query select; HIP events around the "
+                          "whole device pipeline of a pass",
+                "bit_identical_to_single_queries": bool(ok),
+                "parity": {"ok": bool(ok and worst == 0.0), "vs": "single-query path, 4 of 256 queries: ids and scores identical "
+                                                                   "(replaced by the CPU-oracle check in the cpu_baseline leg)",
                            "max_abs_dist_diff": worst}}, payload
     finally:
         idx.free()
@@ -1097,9 +1101,10 @@ def _hybrid_repeat_same_query(lib, V, S, table, idx, doc_len, doc_score, avg, n_
 
 
 def check_batched_with_oracle(p):
-    """cpu_baseline leg: the batched MFMA pass's answers against the CPU oracle over the same 10M fp16 rows (regenerated on
-    the host): the same bar as tests/test_gpu_fullsize.py -- exact ids except members that tie rank K within 2e-3 (fp32
-    sums of 768 fp16 products differ by summation order between MFMA tiles and the scalar loop), distances within 2e-3."""
+    """cpu_baseline leg: the batched pass's answers against the CPU oracle over the same 10M fp16 rows (regenerated on the host):
+    the same bar as tests/test_gpu_fullsize.py -- the replies ARE the single-query scan's (re-scored exactly since round 5), so
+    what separates them from the oracle's scalar fp32 loop is north_star's fp32 tolerance: ids identical except members that tie
+    rank K within 1e-4 (relative to max(1, |d|)), distances within 1e-4."""
     import oracle as O
     rows, dim, k = p["rows"], p["dim"], p["k"]
     if _mem_available_gb() < rows * dim * 2 * 2.2 / 1e9 + 8:
@@ -1115,14 +1120,14 @@ def check_batched_with_oracle(p):
         gset, oset = set(p["ids"][qi].tolist()), set(oi.tolist())
         nqb = o.normalized_query(p["queries"][qi])
         for lab in gset ^ oset:
-            ok &= abs(o.distance_from(int(lab), nqb) - os_[-1]) <= 2e-3
+            ok &= abs(o.distance_from(int(lab), nqb) - os_[-1]) <= 1e-4 * max(1.0, abs(os_[-1]))
         diff = max(diff, len(gset ^ oset))
-        worst = max(worst, float(np.max(np.abs(np.sort(p["scores"][qi]) - np.sort(os_)))))
+        worst = max(worst, float(np.max(np.abs(np.sort(p["scores"][qi]) - np.sort(os_)) / np.maximum(1.0, np.abs(np.sort(os_))))))
     t_ms = (time.perf_counter() - t0) * 1e3 / len(p["which"])
-    return {"ok": bool(ok and diff <= 4 and worst <= 2e-3), "cpu_oracle_ms": t_ms,
-            "vs": "CPU oracle on the full %dx%d fp16 corpus, %d of 256 queries: ids identical except rank-K near-ties (<= 2e-3, at most "
-                  "4 per query), distances within 2e-3" % (rows, dim, len(p["which"])),
-            "max_abs_dist_diff": worst, "max_symmetric_difference": diff}
+    return {"ok": bool(ok and diff <= 2 and worst <= 1e-4), "cpu_oracle_ms": t_ms,
+            "vs": "CPU oracle on the full %dx%d fp16 corpus, %d of 256 queries: ids identical except true fp32 ties at rank K (<= 1e-4 "
+                  "relative), distances within 1e-4 relative" % (rows, dim, len(p["which"])),
+            "max_rel_dist_diff": worst, "max_symmetric_difference": diff}
 
 
 def check_hybrid_with_oracle(p):
