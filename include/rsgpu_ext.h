@@ -149,7 +149,7 @@ void RSGPU_SetProfiling(int on);
 void RSGPU_ResetProfile(void);
 /* launches, summed kernel milliseconds, algorithmic bytes (rows*dim*sizeof(type)) */
 void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes);
-/* The query coalescer behind VecSimIndex_TopKQuery (DESIGN.md "coalescer"): calls that arrive while a pass over the corpus
+/* The query coalescer behind VecSimIndex_TopKQuery (docs/DESIGN_NOTES.md "the coalescer"): calls that arrive while a pass over the corpus
  * is in flight join the next pass, which scores every row against all of them at once (scan_mq_kernels.hip, up to 8
  * queries per pass); replies are bit-identical to uncoalesced ones.  out[0] passes, [1] queries served, [2] passes that
  * ran the multi-query scan, [3] queries those served, [4] times a new leader waited for the previous pass's callers,

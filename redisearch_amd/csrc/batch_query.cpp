@@ -431,7 +431,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       RowBand rb;
       if (via_l2) {
         // |d~ - d| <= rel (hn[row] + hq): the MFMA's summation order against the scan's, both within dim roundings of |x||q|
-        // <= hn + hq, the rows' norms within dim roundings of hn (DESIGN.md section 3 "L2 on the matrix cores").  The pass
+        // <= hn + hq, the rows' norms within dim roundings of hn (docs/DESIGN_NOTES.md section 3 "L2 on the matrix cores").  The pass
         // works with norms and hq shrunk by (1 - rel/2): what it emits is the lower bound d~ - band(row, q); the candidate
         // lists carry the upper bound lb + 2 band(row, q), the thresholds are selected from those without further slack.
         float *hl = static_cast<float *>(sc.h_l2.p);

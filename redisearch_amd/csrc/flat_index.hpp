@@ -1,7 +1,7 @@
 // flat_index.hpp -- host side of the MI355X FLAT index: HBM-resident corpus, label maps, per-query
 // workspaces and the query drivers that string the HIP kernels together.
 //
-// What lives where (DESIGN.md "data layout"):
+// What lives where (DESIGN.md section 2 "data layout"):
 //   HBM   rows      [cap_rows][stride]  row-contiguous, stride = dim*sizeof(T) rounded up to 16 B,
 //                                       zero padded; cosine rows are stored normalised
 //         labels    [cap_rows] u64      row -> label (doc id)
@@ -304,7 +304,7 @@ class FlatIndex {
   uint32_t *d_hn_bad_ = nullptr;  // [0] set by the kernel if a row's norm is not finite; [1] bits of the largest stored half norm
   bool hn_bad_ = false;
   float hn_max_ = 0.0f;           // upper bound of |x|^2 / 2 over the rows covered (deletes do not lower it: a bound may be loose)
-  // relative error band of the pass against the exact scan, per unit of |x|^2/2 + |q|^2/2 (DESIGN.md section 3 "L2 on the
+  // relative error band of the pass against the exact scan, per unit of |x|^2/2 + |q|^2/2 (docs/DESIGN_NOTES.md section 3 "L2 on the
   // matrix cores"): the stored norms are shrunk by (1 - rel/2)
   // (FLOAT32 rows go through the matrix cores as bf16: twice gemm_qs_f32_rel of |x||q| <= hn + hq on top, kernels.hpp)
   float hn_rel() const {

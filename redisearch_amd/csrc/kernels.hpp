@@ -202,7 +202,7 @@ void launch_half_norm_rows(int type, const void *rows, size_t stride, uint32_t r
                            float *hn, uint32_t *bad, hipStream_t s);
 // *out_bits = max(*out_bits, bits of v[i]), i in [begin, end): the largest non-negative float of the range
 void launch_max_f32_bits(const float *v, uint32_t begin, uint32_t end, uint32_t *out_bits, hipStream_t s);
-// The L2 form of the batched matrix-core pass carries a PER-ROW error band (DESIGN.md section 3 "L2 on the matrix cores"):
+// The L2 form of the batched matrix-core pass carries a PER-ROW error band (docs/DESIGN_NOTES.md section 3 "L2 on the matrix cores"):
 // the pass emits lower bounds lb of the distances, the candidate lists hold upper bounds ub = lb + band(row, q), the
 // re-scoring kernel derives lb back.  band(row, q) = c1 * hnorm[row] + hq2[q]; hnorm == nullptr: no band (IP passes).
 struct RowBand {

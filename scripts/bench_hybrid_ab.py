@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402,F401  (before the engine: see DESIGN.md 9)
+import torch  # noqa: E402,F401  (before the engine: see docs/DESIGN_NOTES.md 9)
 import bench as B  # noqa: E402
 from redisearch_amd import search as S  # noqa: E402
 from redisearch_amd import vecsim as V  # noqa: E402

@@ -49,7 +49,7 @@ print("scan", f, nf, w, nw)
 if f and w:
     name = json.load(open("gpurun_out/" + TAG + "_bench_under_rocprof.json"))["roofline"]["kernel"]
     traffic = (f * 2 + w) * 1024
-    out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras (scripts/gpu_prof_r04.sh)",
+    out = {"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-extras (scripts/gpu_prof.sh)",
            "kernel": name, "kernel_name_in_trace": kern, "kernel_source_sha256_16": bench.scan_source_hash(), "rows": 10_000_000, "dim": 768,
            "algorithmic_bytes_per_launch": alg, "FETCH_SIZE_raw_KB_avg": f, "FETCH_SIZE_launches": nf, "WRITE_SIZE_raw_KB_avg": w, "WRITE_SIZE_launches": nw,
            "fetch_bytes_corrected": f * 2 * 1024, "write_bytes_reported": w * 1024, "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": traffic / alg}
@@ -68,7 +68,7 @@ if fe["FETCH_SIZE"] and wr["WRITE_SIZE"]:
     except Exception:
         ab = {}
     alg_h = 109_722_430.0
-    out = {"command": "ONLY_DEFAULT=1 CYCLES=2 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python scripts/bench_hybrid_stream.py (16 distinct term pairs + query vectors, round-robin; warm and cold cycles)",
+    out = {"command": "CYCLES=2 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace -- python scripts/bench_hybrid_stream.py (16 distinct term pairs + query vectors, round-robin; warm and cold cycles)",
            "kernel_name_in_trace": kern, "launches": len(fe["FETCH_SIZE"]), "algorithmic_bytes_per_query": alg_h,
            "FETCH_SIZE_raw_KB_avg": f, "WRITE_SIZE_raw_KB_avg": w,
            "traffic_bytes_per_query_fetch_x2": (f * 2 + w) * 1024, "traffic_over_algorithmic_fetch_x2": (f * 2 + w) * 1024 / alg_h,
