@@ -215,6 +215,10 @@ struct RSGPU_Postings {
   // (8-12 B per posting decoded next to ~3 B encoded).
   std::mutex decode_mu;
   std::atomic<bool> decoded{false};
+  // ... of which the doc ids and frequencies alone (round 5): what the two-launch hybrid query reads.  A Full-codec list decodes
+  // into 20 bytes per posting -- ids, frequencies, field masks, offsets position / length -- and a query that neither walks the
+  // term offsets nor hands out term records needs 8 of them; the rest is decoded when a path first asks for it
+  std::atomic<bool> decoded_lean{false};
   // qint layouts: sub-block sync points, left behind by the first decode for all later ones (search_kernels.hpp)
   DevBuf<uint32_t> sync;
   std::atomic<bool> sync_ready{false};
@@ -288,46 +292,54 @@ struct RSGPU_DocTable {
     return failval;                              \
   }
 
-static void launch_decode(RSGPU_Postings *p, QueryCtx *c, int sync_mode) {
+// lean: doc ids + frequencies only (the field masks and the offsets index stay as they are)
+static void launch_decode(RSGPU_Postings *p, QueryCtx *c, int sync_mode, bool lean = false) {
+  const bool wide = p->cd.wide;  // (the wide codecs' masks travel with the generic loop: always whole)
   launch_decode_blocks(p->cd, p->bytes.p, p->byte_off.p, p->first.p, p->nent.p, p->entry_off.p, p->n_blocks, p->ids.p,
-                       p->cd.freq >= 0 ? p->freqs.p : nullptr, (p->cd.mask >= 0 || p->cd.wide) ? p->masks.p : nullptr,
-                       c->stream, p->cd.wide ? p->wmasks.p : nullptr, p->has_offsets() ? p->off_pos.p : nullptr,
-                       p->has_offsets() ? p->off_len.p : nullptr, p->sync.p, sync_mode, p->sync_span,
+                       p->cd.freq >= 0 ? p->freqs.p : nullptr, ((p->cd.mask >= 0 || wide) && (!lean || wide)) ? p->masks.p : nullptr,
+                       c->stream, wide ? p->wmasks.p : nullptr, (p->has_offsets() && (!lean || wide)) ? p->off_pos.p : nullptr,
+                       (p->has_offsets() && (!lean || wide)) ? p->off_len.p : nullptr, p->sync.p, sync_mode, p->sync_span,
                        (uint32_t)std::min<uint64_t>(p->n_blocks ? p->n_bytes / p->n_blocks : 0, 0xFFFFFFFFull));
   HIP_CHECK(hipGetLastError());
 }
 
-static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false) {
+// lean (round 5): the caller reads the doc ids and the frequencies only (hybrid_two_launches) -- see RSGPU_Postings::decoded_lean
+static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false, bool lean = false) {
   const bool cached = scan_tuning().cache_decoded && !force;
-  if (cached && p->decoded.load(std::memory_order_acquire)) return;
+  lean = lean && scan_tuning().decode_lean && !p->cd.wide;
+  if (cached && (p->decoded.load(std::memory_order_acquire) || (lean && p->decoded_lean.load(std::memory_order_acquire)))) return;
   const bool has_sync = p->sync.p != nullptr && scan_tuning().decode_sync;
   if (has_sync && p->sync_ready.load(std::memory_order_acquire) && !cached) {  // eight lanes per block
-    launch_decode(p, c, 2);
+    launch_decode(p, c, 2, lean);
     return;
   }
   if (!cached && !has_sync) {  // nothing to publish: no wait
-    launch_decode(p, c, 0);
+    launch_decode(p, c, 0, lean);
     return;
   }
   // the decode that publishes something other streams will read -- the decoded arrays (cache) or the sync points
   std::lock_guard<std::mutex> g(p->decode_mu);
-  if (cached && p->decoded.load(std::memory_order_relaxed)) return;
-  launch_decode(p, c, has_sync && !p->sync_ready.load(std::memory_order_relaxed) ? 1 : (has_sync ? 2 : 0));
+  if (cached && (p->decoded.load(std::memory_order_relaxed) || (lean && p->decoded_lean.load(std::memory_order_relaxed)))) return;
+  launch_decode(p, c, has_sync && !p->sync_ready.load(std::memory_order_relaxed) ? 1 : (has_sync ? 2 : 0), lean);
   HIP_CHECK(hipStreamSynchronize(c->stream));
   if (has_sync) p->sync_ready.store(true, std::memory_order_release);
-  if (cached) p->decoded.store(true, std::memory_order_release);
+  if (cached) {
+    p->decoded_lean.store(true, std::memory_order_release);
+    if (!lean) p->decoded.store(true, std::memory_order_release);
+  }
 }
 
 // Decode-per-query mode (cache_decoded = 0): two qint lists whose sync points are there go up in ONE launch (the fixed cost
 // of a launch is a third of a list's decode: profiles/r03_decode.txt).  false: not such a pair -- decode_on takes each.
-static bool decode_pair_on(RSGPU_Postings *p, RSGPU_Postings *q, QueryCtx *c) {
+static bool decode_pair_on(RSGPU_Postings *p, RSGPU_Postings *q, QueryCtx *c, bool lean = false) {
   if (scan_tuning().cache_decoded || !scan_tuning().decode_sync || !scan_tuning().decode_pair || p == q) return false;
+  lean = lean && scan_tuning().decode_lean;
   for (RSGPU_Postings *x : {p, q})
     if (!x->sync.p || !x->sync_ready.load(std::memory_order_acquire) || !x->n_blocks || x->cd.kind != 0 || x->cd.wide) return false;
-  auto args = [](RSGPU_Postings *x) {
+  auto args = [lean](RSGPU_Postings *x) {
     return DecodeListArgs{x->cd, x->bytes.p, x->byte_off.p, x->first.p, x->nent.p, x->entry_off.p, (uint32_t)x->n_blocks, x->ids.p,
-                          x->cd.freq >= 0 ? x->freqs.p : nullptr, x->cd.mask >= 0 ? x->masks.p : nullptr, nullptr,
-                          x->has_offsets() ? x->off_pos.p : nullptr, x->has_offsets() ? x->off_len.p : nullptr, x->sync.p, 2,
+                          x->cd.freq >= 0 ? x->freqs.p : nullptr, (x->cd.mask >= 0 && !lean) ? x->masks.p : nullptr, nullptr,
+                          (x->has_offsets() && !lean) ? x->off_pos.p : nullptr, (x->has_offsets() && !lean) ? x->off_len.p : nullptr, x->sync.p, 2,
                           x->sync_span};
   };
   const bool ok = launch_decode_blocks_pair(args(p), args(q), c->stream);
@@ -1679,8 +1691,9 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a->lists[x]->n_entries < a->lists[y]->n_entries; });
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
   for (size_t l = 0; l < n_lists; l++) {
-    if (l + 1 < n_lists && decode_pair_on(a->lists[l], a->lists[l + 1], ca)) l++;
-    else decode_on(a->lists[l], ca);
+    // (this form reads doc ids and frequencies only: a Full-codec list's masks / offsets index are not decoded for it)
+    if (l + 1 < n_lists && decode_pair_on(a->lists[l], a->lists[l + 1], ca, true)) l++;
+    else decode_on(a->lists[l], ca, false, true);
   }
   RSGPU_Hits h;  // the tree and the frame of the result (no arrays: nothing is written in hit order)
   h.device = ca->device;

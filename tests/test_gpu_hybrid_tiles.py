@@ -328,3 +328,60 @@ def test_knn_branch_against_the_cpu_oracle_directly(vtype, otype, metric, ometri
         gi.free()
         for x in g:
             x.free()
+
+
+def test_lean_decode_first_then_the_paths_that_need_the_rest():
+    """round 5: the two-launch form decodes a list's doc ids and frequencies only (a Full-codec list: 8 of 20 bytes per posting);
+    the field masks and the offsets index are decoded when a path first asks for them.  FRESH Full-codec lists: (1) the
+    two-launch query (BM25STD: nothing but ids + freqs), (2) a slop-dependent scorer over the offsets on the general tile kernel,
+    (3) the staged intersection with term records (masks, offsets) -- each against the same query on lists that were decoded
+    whole from the start (knob decode_lean = 0), bit for bit; and the decode-per-query mode (cache_decoded = 0) the same."""
+    from tests.test_gpu_tree import rand_list
+    lib = V.load()
+    rng = np.random.default_rng(12)
+    built = [rand_list(rng, O.C_FULL, n, 60_000, True) for n in (20_000, 30_000)]
+    flat = [b[0].flatten() for b in built]
+    n_docs = 60_000
+    table = S.DocTable(rng.integers(5, 200, n_docs + 1).astype(np.uint32), rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32),
+                       rng.integers(1, 40, n_docs + 1).astype(np.uint32))
+    idf = [S.calculate_idf(n_docs, b[0].unique_docs) for b in built]
+    bidf = [S.calculate_idf_bm25(n_docs, b[0].unique_docs) for b in built]
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 16, V.VecSimMetric_L2)
+    idx.add_philox_rows(5, 0, 30_000, 1)
+    q = O.philox_rows(5, 1 << 40, 1, 16)[0]
+
+    def run_all(cache):
+        out = []
+        lib.RSGPU_SetTuning(b"cache_decoded", cache)
+        g = [S.Postings.from_flat(f) for f in flat]                    # fresh lists: nothing decoded yet
+        hq = S.HybridQuery(g, table, "BM25STD", idf, bidf, [1.0, 2.0], n_docs, 100.0, top_n=10, index=idx, q=q, k=10)
+        hq.run()
+        assert S.hybrid_path() == 1
+        out.append(hq.results())
+        hq2 = S.HybridQuery(g, table, "TFIDF", idf, bidf, [1.0, 2.0], n_docs, 100.0, top_n=10, index=idx, q=q, k=10)
+        hq2.run()
+        assert S.hybrid_path() == 2
+        out.append(hq2.results())
+        h = S.intersect(g, max_slop=5)
+        ids, fr = h.read()
+        rec = h.read_records(1)
+        out.append(dict(n_hits=len(ids), top=(ids[:50], fr[0][:50].astype(np.float64)), knn=(rec["off_pos"][:50], rec["off_len"][:50].astype(np.float64))))
+        assert rec["mask"] == h.read_records(1)["mask"]
+        hq.run()                                                        # ... and the lean form again, afterwards
+        out.append(hq.results())
+        return out
+
+    try:
+        for cache in (1, 0):
+            lib.RSGPU_SetTuning(b"decode_lean", 1)
+            a = run_all(cache)
+            lib.RSGPU_SetTuning(b"decode_lean", 0)
+            b = run_all(cache)
+            for x, y in zip(a, b):
+                assert x["n_hits"] == y["n_hits"]
+                for key in ("top", "knn"):
+                    assert np.asarray(x[key][0]).tolist() == np.asarray(y[key][0]).tolist() and np.asarray(x[key][1]).tolist() == np.asarray(y[key][1]).tolist()
+    finally:
+        lib.RSGPU_SetTuning(b"decode_lean", 1)
+        lib.RSGPU_SetTuning(b"cache_decoded", 1)
+    idx.free()
