@@ -1020,9 +1020,13 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 #pragma unroll
         for (int t = 0; t < ML; t++)
           if (t < A.n_leaves) ee[j][t] = win[(1u + t) * TILE + e];
-        ProxCtx<ML> x;
-        prox_load<ML>(A.X, A.O, x, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
-        keep[j] = prox_within_range<ML>(A.X, x);
+        if (prox_two_terms(A.X)) {  // (two plain terms: the cursors in registers, postings_ops.hpp)
+          keep[j] = prox_within_range2(A.X, prox_term(A.O, 0, win[1u * TILE + e]), prox_term(A.O, 1, win[2u * TILE + e]));
+        } else {
+          ProxCtx<ML> x;
+          prox_load<ML>(A.X, A.O, x, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
+          keep[j] = prox_within_range<ML>(A.X, x);
+        }
       }
     }
     nh = ordered_slots<DPT>(keep, slot, seg);  // (its barriers: every record has been read before one is rewritten)
@@ -1053,9 +1057,13 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
       my_x[j] = x;
       int slop = A.P.slop;
       if (A.prox_slop && A.top_n) {  // IndexResult_MinOffsetDelta from the term offsets (prox_slop_kernel's)
-        ProxCtx<ML> c;
-        prox_load<ML>(A.X, A.O, c, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
-        slop = prox_min_offset_delta<ML>(A.X, c);
+        if (prox_two_terms(A.X) && !A.X.count_present) {
+          slop = prox_min_offset_delta2(prox_term(A.O, 0, win[1u * TILE + e]), prox_term(A.O, 1, win[2u * TILE + e]));
+        } else {
+          ProxCtx<ML> c;
+          prox_load<ML>(A.X, A.O, c, [&](int t) { return win[(1u + (uint32_t)t) * TILE + e]; });
+          slop = prox_min_offset_delta<ML>(A.X, c);
+        }
       }
 #pragma unroll
       for (int t = 0; t < ML; t++)

@@ -276,6 +276,72 @@ __device__ int prox_min_offset_delta(const ProxParams &P, ProxCtx<MAXL> &x) {
   return dist ? (int)sqrt((double)dist) : num - 1;
 }
 
+// ---- two plain terms (round 5): `"hello world"`, `hello world` with SLOP -- the commonest windowed query ----------------------
+// prox_within_range / prox_min_offset_delta restated for exactly two children that are single terms, with the two cursors and the
+// two positions in REGISTERS: the general forms index their cursor arrays with run-time child / leaf numbers, which puts them in
+// scratch memory (240 bytes per lane in hybrid_tree_tile_kernel, a memory round trip per position step).  Same walks, same
+// comparisons, same results (proximity.rs:134-298, index_result.c:51-103); a term takes part iff it has offsets (len > 0).
+__device__ __forceinline__ bool prox_two_terms(const ProxParams &P) {
+  return P.n_children == 2 && P.n_leaves == 2 && !P.is_agg[0] && !P.is_agg[1] && P.child_first[0] == 0 && P.child_first[1] == 1 &&
+         P.child_first[2] == 2;
+}
+__device__ __forceinline__ bool prox_within_range2(const ProxParams &P, TermIt a, TermIt b) {
+  if (a.len == 0 || b.len == 0) return true;  // fewer than two children carry positions
+  const uint32_t max_slop = P.max_slop < 0 ? 0xFFFFFFFFu : (uint32_t)P.max_slop;
+  if (P.in_order) {
+    uint32_t p1 = 0;
+    for (;;) {
+      const uint32_t p0 = term_next(a);
+      if (p0 == kPosEof) return false;
+      uint32_t pos = p1;
+      while (pos < p0) {
+        pos = term_next(b);
+        if (pos == kPosEof) return false;
+      }
+      p1 = pos;
+      const int span = (int)p1 - (int)p0 - 1;
+      if (span > 0 && (uint32_t)span > max_slop) continue;
+      return true;
+    }
+  }
+  uint32_t p0 = term_next(a);
+  if (p0 == kPosEof) return false;
+  uint32_t p1 = term_next(b);
+  if (p1 == kPosEof) return false;
+  uint32_t max_pos = p1 >= p0 ? p1 : p0;
+  for (;;) {
+    const bool first = !(p1 < p0);  // (the smaller position; child 0 on a tie)
+    const uint32_t min_pos = first ? p0 : p1;
+    if (min_pos != max_pos) {
+      const int span = (int)max_pos - (int)min_pos - 1;
+      if (span < 0 || (uint32_t)span <= max_slop) return true;
+    }
+    const uint32_t np = first ? term_next(a) : term_next(b);
+    if (np == kPosEof) return false;
+    if (first) p0 = np;
+    else p1 = np;
+    if (np > max_pos) max_pos = np;
+  }
+}
+__device__ __forceinline__ int prox_min_offset_delta2(TermIt a, TermIt b) {
+  if (a.len == 0 || b.len == 0) return 1;  // (no pair of children with positions: children - 1)
+  uint32_t p1 = term_next(a), p2 = term_next(b);
+  int cd = (int)(p2 > p1 ? p2 - p1 : p1 - p2);
+  while (cd > 1 && p1 != kPosEof && p2 != kPosEof) {
+    const uint32_t d = p2 > p1 ? p2 - p1 : p1 - p2;
+    if (d < (uint32_t)cd) cd = (int)d;
+    if (p2 > p1) p1 = term_next(a);
+    else p2 = term_next(b);
+  }
+  const int dist = cd * cd;
+  return dist ? (int)sqrt((double)dist) : 1;
+}
+template <typename View>
+__device__ __forceinline__ TermIt prox_term(const View &o, int leaf, uint32_t entry) {
+  const bool on = o.off_pos[leaf] != nullptr && entry != 0xFFFFFFFFu;
+  return TermIt{on ? o.bytes[leaf] + o.off_pos[leaf][entry] : nullptr, on ? o.off_len[leaf][entry] : 0u, 0u, 0u};
+}
+
 // (View: OffsetView, or any struct with the same three arrays over fewer leaves)
 template <int MAXL, typename View, typename EntryOf>
 __device__ __forceinline__ void prox_load(const ProxParams &P, const View &o, ProxCtx<MAXL> &x, EntryOf entry_of) {

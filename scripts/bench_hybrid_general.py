@@ -89,4 +89,4 @@ lib.RSGPU_SetTuning(b"hybrid_tree_tiles", 1)
 out["phrase_intersection_two_full_codec_terms"] = ph
 print("phrase", json.dumps(ph), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r04_hybrid_general_shapes.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/hybrid_general_shapes.json", "w"), indent=1)
