@@ -837,9 +837,11 @@ __device__ __forceinline__ uint32_t ordered_slots(const bool (&flag)[DPT], uint3
 // Dynamic LDS as hybrid_tile_kernel: pool_words u32 -- a probed list's window; then the candidates' records: doc id |
 // entry index per LEAF ((n + 1) arrays of a tile's drivers), the frequencies in the entry indices' place once they are
 // gathered; then keys | doc ids; then branch B's rows | doc ids | keys -- and the KNN query behind it.
-template <int TYPE, int METRIC>
+// ML: the lists (leaves + excluded) the instantiation holds positions / cursors for -- 4 (79 VGPRs: six wavefronts per SIMD) for
+// the queries of up to four lists, kHybTreeMaxLists = 8 (85: five) for the rest
+template <int TYPE, int METRIC, int ML>
 __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A) {
-  constexpr int DPT = kHybDpt, ML = kHybTreeMaxLists;
+  constexpr int DPT = kHybDpt;
   constexpr uint32_t TILE = kHybTile;
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t seg[DPT * 4 + 1];
@@ -1327,7 +1329,12 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, 
   }
   a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n_leaves + 1) * kHybTile);
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
-#define RSGPU_HYBT(T, M) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M>), dim3(n_tiles), dim3(256), lds, s, a)
+  const bool small = a.n <= 4 && a.n_leaves <= 4 && a.n_req <= 4 && a.n_veto_all <= 4 && a.n_opt_all <= 4;
+#define RSGPU_HYBT(T, M)                                                                                         \
+  do {                                                                                                           \
+    if (small) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, 4>), dim3(n_tiles), dim3(256), lds, s, a);      \
+    else hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists>), dim3(n_tiles), dim3(256), lds, s, a); \
+  } while (0)
   if (!a.k) RSGPU_HYBT(KT_F32, KM_IP);
   else if (type == KT_F32 && metric == KM_L2) RSGPU_HYBT(KT_F32, KM_L2);
   else if (type == KT_F32) RSGPU_HYBT(KT_F32, KM_IP);

@@ -846,13 +846,18 @@ __global__ __launch_bounds__(256) void prox_filter_kernel(ProxParams P, OffsetVi
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   bool keep = i < n0 && flags[i];
   if (keep) {
-    ProxCtx<MAXL> x;
-    prox_load<MAXL>(P, o, x, [&](int l) {
+    auto entry = [&](int l) {
       const uint32_t t = lm.leaf_list[l];
       const uint32_t p = t == 0 ? i : pos[(size_t)(t - 1) * n0 + i];
       return lm.leaf_epos[l] ? lm.leaf_epos[l][p] : p;
-    });
-    keep = prox_within_range<MAXL>(P, x);
+    };
+    if (prox_two_terms(P)) {  // (two plain terms: cursors in registers, postings_ops.hpp)
+      keep = prox_within_range2(P, prox_term(o, 0, entry(0)), prox_term(o, 1, entry(1)));
+    } else {
+      ProxCtx<MAXL> x;
+      prox_load<MAXL>(P, o, x, entry);
+      keep = prox_within_range<MAXL>(P, x);
+    }
     flags[i] = keep ? 1 : 0;
   }
   unsigned long long m = __ballot(keep);
@@ -866,6 +871,10 @@ __global__ __launch_bounds__(256) void prox_slop_kernel(ProxParams P, OffsetView
                                                         uint32_t len, uint32_t cap, int32_t *__restrict__ slops) {
   const uint32_t h = blockIdx.x * 256 + threadIdx.x;
   if (h >= len) return;
+  if (prox_two_terms(P) && !P.count_present) {
+    slops[h] = prox_min_offset_delta2(prox_term(o, 0, epos[h]), prox_term(o, 1, epos[(size_t)cap + h]));
+    return;
+  }
   ProxCtx<MAXL> x;
   prox_load<MAXL>(P, o, x, [&](int l) { return epos[(size_t)l * cap + h]; });
   slops[h] = prox_min_offset_delta<MAXL>(P, x);
