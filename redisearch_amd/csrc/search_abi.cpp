@@ -1891,8 +1891,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
                            int in_order, RSGPU_Hits **hits_out, FlatIndex *f, const LabelRows &knn_rows, bool want_score, bool want_knn,
                            QueryCtx *ca, QueryCtx *cb, Scratch &sc, bool prof, FusedEvents &ev, bool root_union = false) {
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
+  // (doc ids + frequencies only -- RSGPU_Postings::decoded_lean -- unless the query walks the term offsets: a window, a scorer
+  // that divides by the slop; a caller that takes the hit list may ask for term records later: whole)
+  bool lean = !hits_out && max_slop < 0 && !in_order && !(want_score && slop_dependent(a->score->scorer == RSGPU_SCORER_BM25STD_NORM ? (int)RSGPU_SCORER_BM25STD : a->score->scorer));
   for (const HybGroup &g : groups)
-    for (int li : g.lists) decode_on(lists[li], ca);
+    for (int li : g.lists) decode_on(lists[li], ca, false, lean);
   // the result's tree, frame and leaf columns: the children as sources (an aggregate child only lends its shape here -- its
   // lists are probed one by one, no hit list of its own is ever built)
   std::unique_ptr<RSGPU_Hits> hp(new RSGPU_Hits());

@@ -369,6 +369,19 @@ def test_lean_decode_first_then_the_paths_that_need_the_rest():
         assert rec["mask"] == h.read_records(1)["mask"]
         hq.run()                                                        # ... and the lean form again, afterwards
         out.append(hq.results())
+        # the general tile kernel decodes lean too when the query walks no offsets: fresh lists again, BM25STD forced through it
+        g2 = [S.Postings.from_flat(f) for f in flat]
+        try:
+            lib.RSGPU_SetTuning(b"hybrid_force_general", 1)
+            hq3 = S.HybridQuery(g2, table, "BM25STD", idf, bidf, [1.0, 2.0], n_docs, 100.0, top_n=10, index=idx, q=q, k=10)
+            hq3.run()
+            assert S.hybrid_path() == 2
+            out.append(hq3.results())
+        finally:
+            lib.RSGPU_SetTuning(b"hybrid_force_general", 0)
+        h2 = S.intersect(g2, max_slop=2, in_order=True)                 # ... and then the offsets, on demand
+        i2, f2 = h2.read()
+        out.append(dict(n_hits=len(i2), top=(i2[:50], f2[0][:50].astype(np.float64)), knn=(i2[:1], f2[1][:1].astype(np.float64))))
         return out
 
     try:
