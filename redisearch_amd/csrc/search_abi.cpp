@@ -2239,6 +2239,9 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   LabelRows knn_rows{};
   bool knn_identity = false;  // (historic name: the KNN branch translates on the device)
   std::shared_lock<std::shared_mutex> index_lock;
+  // (a handle over several device shards has no single row matrix: its KNN branch goes through the staged entry point, which
+  // routes every label to the shard that owns it -- RSGPU_Hits_KnnRerank)
+  if (want_knn && !f) tiles = general = false;
   if (f) {
     index_lock = std::shared_lock<std::shared_mutex>(f->mu);
     knn_identity = f->device_label_rows(&knn_rows) &&

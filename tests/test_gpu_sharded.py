@@ -317,3 +317,50 @@ def test_abi_handle_philox_rows_split_over_shards_and_multi_value():
     for _ in range(4):
         a, b = ig.next(40, V.BY_SCORE).results(), io.next(40, V.BY_SCORE).results()
         assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist()
+
+
+def test_hybrid_entry_points_on_a_sharded_handle_with_deletes():
+    """round 5: RSGPU_HybridQuery / RSGPU_HybridTreeQuery over a handle that spans device shards -- no single row matrix, so the
+    KNN branch is the staged one (every label routed to its shard, RSGPU_Hits_KnnRerank) -- with deletes and re-adds on the
+    shards (each shard keeps its own label table): the answers of a one-device index that received the same history, bit for
+    bit; the tile path used to dereference the missing FlatIndex."""
+    from redisearch_amd import search as S
+    import oracle as O
+    rng = np.random.default_rng(21)
+    n_docs, n_vec, dim = 120_000, 40_000, 32
+    g = abi_sharded(F32, dim, V.VecSimMetric_L2, 3)
+    one = V.VecSimIndex(F32, dim, V.VecSimMetric_L2)
+    g.add_philox_rows(9, 0, n_vec, 1)
+    one.add_philox_rows(9, 0, n_vec, 1)
+    fresh = O.philox_rows(9, 1 << 30, 600, dim)
+    for lab in rng.choice(n_vec, 400, replace=False).tolist():
+        assert g.delete_vector(lab + 1) == one.delete_vector(lab + 1) == 1
+    for j in range(600):
+        lab = n_vec + 1 + 2 * j
+        assert g.add_vector(fresh[j], lab) == one.add_vector(fresh[j], lab) == 1
+    assert g.index_size() == one.index_size()
+    lists = []
+    for df in (0.5, 0.4):
+        docs = np.flatnonzero(rng.random(n_docs) < df).astype(np.uint64) + 1
+        ii = O.InvertedIndex(O.C_FREQS_ONLY)
+        ii.add_many(docs, np.minimum(1 + rng.geometric(0.5, docs.size), 255).astype(np.uint32))
+        lists.append(ii)
+    gp = [S.Postings.from_flat(l.flatten()) for l in lists]
+    table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), np.ones(n_docs + 1, np.float32))
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists]
+    q = O.philox_rows(9, 1 << 40, 1, dim)[0]
+    for make in (lambda ix: S.HybridQuery(gp, table, "BM25STD", idf, idf, [1.0, 1.0], n_docs, 200.0, top_n=10, index=ix, q=q, k=10),
+                 lambda ix: S.HybridTreeQuery(S.OP_UNION, [(S.OP_TERM, 1.0, gp[:1]), (S.OP_TERM, 1.0, gp[1:])], table=table, scorer="BM25STD",
+                                              idf=idf, bm25_idf=idf, weight=[1.0, 1.0], num_docs=n_docs, avg_doc_len=200.0, top_n=10, index=ix,
+                                              q=q, k=10)):
+        a, b = make(g), make(one)
+        a.run()
+        assert S.hybrid_path() == 0                       # (sharded: staged)
+        b.run()
+        assert S.hybrid_path() in (1, 2)
+        ra, rb = a.results(), b.results()
+        assert ra["n_hits"] == rb["n_hits"]
+        for key in ("top", "knn"):
+            assert ra[key][0].tolist() == rb[key][0].tolist() and ra[key][1].tolist() == rb[key][1].tolist(), key
+    g.free()
+    one.free()
