@@ -1583,6 +1583,22 @@ def main():
         except Exception as e:  # the baseline leg must never cost the measured line
             cpu = {"value": None, "unit": "queries/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
     if single and rank == 0 and not a.no_extras:
+        # the first DeleteVector on the headline index (identity labels end: the device label table appears, csrc/label_table.hpp --
+        # rounds 1-4 built a hash map of all 10 M rows under the writer lock here), a second one, and a query after them
+        try:
+            t0 = time.perf_counter()
+            r1 = index.delete_vector(rows // 2)
+            d1 = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            r2 = index.delete_vector(rows // 3)
+            d2 = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            n_after = one_query(0)
+            dq = (time.perf_counter() - t0) * 1e3
+            extras["first_delete_on_the_headline_index"] = {"rows": rows, "first_delete_ms": d1, "second_delete_ms": d2, "deleted": [int(r1), int(r2)],
+                                                            "label_table_after": index.label_table(), "query_after_ms": dq, "results": int(n_after)}
+        except Exception as e:
+            extras["first_delete_on_the_headline_index"] = {"error": repr(e)}
         index.free()
         lib.RSGPU_SetTuning(b"shadow8", 0)
         lib.RSGPU_ReleaseWorkspaces()

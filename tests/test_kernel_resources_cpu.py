@@ -128,8 +128,12 @@ def test_general_hybrid_tile_kernel_budget(kernels):
     for the proximity cursors (ProxCtx<8>: 240 bytes per lane, touched by the lanes that hold a candidate when a window or a
     slop-dependent scorer asks for the term offsets), no vector spills.  The pack kernel is a copy."""
     tiles = [k for k in kernels if k["name"].startswith("hybrid_tree_tile_kernel<")]
-    assert len(tiles) == 6
+    assert len(tiles) == 12                       # (round 5: six type / metric pairs x ML = 4 | 8)
     for k in tiles:
         assert k["vgpr"] <= 128 and not k["vgpr_spill"] and k["scratch"] <= 512 and k["lds"] <= 4096 and k["wg"] == 256, k
+    # the ML = 4 instantiation (queries of up to four lists) exists for its register budget: six wavefronts per SIMD where the
+    # element type allows (<= 80 VGPRs), half the cursor scratch
+    small = [k for k in tiles if k["name"].rstrip(">").endswith(", 4")]
+    assert len(small) == 6 and all(k["scratch"] <= 128 for k in small) and sum(k["vgpr"] <= 80 for k in small) >= 3, small
     pack = [k for k in kernels if k["name"].startswith("hybrid_hits_pack_kernel")]
     assert len(pack) == 1 and pack[0]["vgpr"] <= 32 and not pack[0]["scratch"], pack
