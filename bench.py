@@ -1699,7 +1699,7 @@ def main():
                                                "the multi-shard path is exercised with several shards on one device")
         # HBM traffic of the scan kernel: a committed rocprofv3 --pmc pass of this same command (bench.py cannot read
         # PMCs itself); used only when it was taken for the same shape, the same kernel instantiation AND the very
-        # source of the kernel (sha256 of scan_kernels.hip + scan_ops.hpp recorded by scripts/gpu_prof_r03.sh): a change
+        # source of the kernel (sha256 of scan_kernels.hip + scan_ops.hpp recorded by scripts/gpu_prof.sh): a change
         # inside the kernel that keeps its template arguments must not inherit a stale figure
         src_hash = scan_source_hash()
         out["roofline"]["kernel_source_sha256_16"] = src_hash
@@ -1713,7 +1713,7 @@ def main():
                 out["roofline"]["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, KB->B; same kernel source hash)" % name
                 break
         if out["roofline"]["traffic"] is None:
-            out["roofline"]["traffic_note"] = "no committed PMC pass matches this kernel's source hash: run scripts/gpu_prof_r03.sh"
+            out["roofline"]["traffic_note"] = "no committed PMC pass matches this kernel's source hash: run scripts/gpu_prof.sh"
         if cpu is not None:
             out["cpu_baseline"] = cpu
         emit(out)
