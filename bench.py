@@ -823,6 +823,14 @@ def _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_
             mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridTreeQuery(S.OP_UNION, [(S.OP_TERM, 1.0, [fo[i]]), (S.OP_TERM, 1.0, [fo[j]])],
                                                                      index=idx, q=qvecs[qi], k=10, **a))
         shapes["root_union_of_two_terms_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 5: `a ((b c) | d)` -- a nested tree (RSGPU_HybridTreeNodesQuery), score folded node by node
+            j2, j3 = n_a + (j - n_a + 1) % n_b, n_a + (j - n_a + 2) % n_b
+            a = sc([i, j, j2, j3]); a["scorer"] = "BM25STD"
+            tree = ("and", 1.0, [("t", 0), ("or", 1.0, [("and", 1.0, [("t", 1), ("t", 2)]), ("t", 3)])])
+            mk.append(lambda a=a, i=i, j=j, j2=j2, j3=j3, qi=qi, tree=tree: S.HybridNodesQuery(tree, [fo[i], fo[j], fo[j2], fo[j3]], index=idx,
+                                                                                              q=qvecs[qi], k=10, **a))
+        shapes["nested_a_and_bc_or_d_freqs_only_bm25std_knn"] = mk
         for name, makers in shapes.items():
             rec = {}
             answers = {}

@@ -200,8 +200,9 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * <= 4 term lists, top_n / k <= 32 (31 for BM25STD.NORM), no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
  * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
  * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
- * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list).  A root union, a root whose children are
- * all unions, top_n / k > 32 and indexes with a general label map stay staged.  Same answers either way. */
+ * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list; round 5: a root union of terms /
+ * intersections of terms without hits_out -- one pass per child -- and, through RSGPU_HybridTreeNodesQuery, nested trees).  A root
+ * whose children are all unions, top_n / k > 32 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
@@ -251,9 +252,10 @@ int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *tree, RSGPU_HybridQueryArgs *ar
  * lists are the excluded terms (a document that any of them holds is not a hit).  The reference's Not iterator yields a VIRTUAL
  * result of frequency 0 (rqe_iterators/src/not.rs:106-118, index_result/src/core/mod.rs:103-112): it adds nothing to any scorer's
  * sum and has no offsets, but it IS a child of the intersection's result -- IndexResult_MinOffsetDelta counts it (the offset-less
- * slop is children - 1).  Its lists take no idf / weight (leave their RSGPU_ScoreArgs entries 0) and are not part of a hit list:
- * hits_out must be NULL, and the query runs on the general tile kernel or not at all (more than eight lists, no term to drive, a
- * general label map: -1 with a message; RSGPU_EvalTree rejects the operator). */
+ * slop is children - 1).  Its lists take no idf / weight (leave their RSGPU_ScoreArgs entries 0) and have no column in the hit
+ * list: hits_out (round 5) receives the positive children's columns and the result tree with the virtual child in it --
+ * RSGPU_Hits_Score on that list gives the scores the query ranked by.  The query runs on the general tile kernel or not at all
+ * (more than eight lists, no term to drive, a general label map: -1 with a message; RSGPU_EvalTree rejects the operator). */
 #define RSGPU_OP_NOT 3
 
 /* Query trees of ANY depth: `nodes` in POST-ORDER -- a term names its list; an aggregate (RSGPU_OP_UNION /
@@ -273,6 +275,14 @@ typedef struct {
   int in_order;       /* intersection */
 } RSGPU_TreeNode;
 RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *const *lists, size_t n_lists);
+/* RSGPU_HybridQuery over such a tree (round 5) -- the filter the reference hands its hybrid iterator may nest to any depth
+ * (src/iterators/hybrid_reader.c:625; `a ((b c)|d)`, `a (b|(c d)) (e|f)`): args->lists / n_lists are the terms the nodes name,
+ * RSGPU_ScoreArgs.idf / bm25_idf / weight per LIST in their order, everything else as RSGPU_HybridQuery, hits_out included.
+ * Results are those of RSGPU_EvalTreeNodes + RSGPU_Hits_Score / _TopN / _KnnRerank.  RSGPU_HybridQueryPath reads 2 when the
+ * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds, nested at most four
+ * levels, unions whose children are terms, unions or intersections of terms, no max_slop / in_order on any node, no hits_out,
+ * no slop-dependent scorer over lists that store offsets; 0 when it ran stage by stage. */
+int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_HybridQueryArgs *args);
 /* The result tree behind a hit list, post-order (after the intersections sorted their children by size): per node the
  * operator, the leaf column of a term (-1 for aggregates; leaves are the child slots of RSGPU_Hits_LeafOrder), the number
  * of children and the weight.  Arrays of 64 entries suffice; any may be NULL.  Returns the number of nodes or -1. */

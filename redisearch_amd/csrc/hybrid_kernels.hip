@@ -838,8 +838,13 @@ __device__ __forceinline__ uint32_t ordered_slots(const bool (&flag)[DPT], uint3
 // entry index per LEAF ((n + 1) arrays of a tile's drivers), the frequencies in the entry indices' place once they are
 // gathered; then keys | doc ids; then branch B's rows | doc ids | keys -- and the KNN query behind it.
 // ML: the lists (leaves + excluded) the instantiation holds positions / cursors for -- 4 (79 VGPRs: six wavefronts per SIMD) for
-// the queries of up to four lists, kHybTreeMaxLists = 8 (85: five) for the rest
-template <int TYPE, int METRIC, int ML>
+// the queries of up to four lists that read term offsets, kHybTreeMaxLists = 8 (85: five) for the rest of those; without the
+// proximity cursors (PROX = false) eight lists fit 74-84 registers and one instantiation serves every query
+// DEEP: the result tree has more levels than root -> children -> terms (ScoreParams::n_nodes > 0, at most kHybDeepLevels below the
+// root): the score folds it node by node (score_one<true>), accumulators in registers
+// PROX: the query reads term offsets (a window to check, a scorer that divides by the slop): only these instantiations carry the
+// proximity cursors (ProxCtx: scratch memory); the others are scratch-free
+template <int TYPE, int METRIC, int ML, bool DEEP = false, bool PROX = true>
 __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A) {
   constexpr int DPT = kHybDpt;
   constexpr uint32_t TILE = kHybTile;
@@ -972,20 +977,21 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
   bool hit[DPT];
 #pragma unroll
   for (int k = 0; k < DPT; k++) {
+    // a nested / later child intersection that does not match as a whole is not in the result: its terms are absent
+    uint32_t gone = 0u;
+#pragma unroll
+    for (int r = 0; r < ML; r++)
+      if (r < A.n_opt_all && (mb[k] & A.opt_all[r]) != A.opt_all[r]) gone |= A.opt_all[r];
+    const uint32_t held = mb[k] & ~gone;
     bool h = live[k];
 #pragma unroll
     for (int r = 0; r < ML; r++)
-      if (r < A.n_req) h = h && (mb[k] & A.req[r]) != 0u;
+      if (r < A.n_req) h = h && (held & A.req[r]) != 0u;
     h = h && (mb[k] & A.veto) == 0u;  // (NOT children: not.rs:171-209 -- the document must be absent from every excluded list)
 #pragma unroll
     for (int r = 0; r < ML; r++)
       if (r < A.n_veto_all) h = h && (mb[k] & A.veto_all[r]) != A.veto_all[r];  // (root union: an earlier child's pass reports it)
     hit[k] = h;
-    // a later child intersection that does not match as a whole is not in the result: its terms are absent
-    uint32_t gone = 0u;
-#pragma unroll
-    for (int r = 0; r < ML; r++)
-      if (r < A.n_opt_all && (mb[k] & A.opt_all[r]) != A.opt_all[r]) gone |= A.opt_all[r];
 #pragma unroll
     for (int l = 1; l < ML; l++)
       if ((gone >> l) & 1u) ps[k][l - 1] = kHybNone;
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
   // ---- max_slop / in_order (Intersection::current_is_relevant, intersection.rs:205-215): prox_filter_kernel's test, one
   // candidate per lane where they sit compacted; the survivors close ranks, still in driver order ----
   uint32_t nh = nc;
-  if (A.prox_filter) {
+  if (PROX && A.prox_filter) {
     bool keep[DPT];
     uint32_t ex_[DPT], ee[DPT][ML];
 #pragma unroll
@@ -1058,7 +1064,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
       const uint32_t x = win[e];
       my_x[j] = x;
       int slop = A.P.slop;
-      if (A.prox_slop && A.top_n) {  // IndexResult_MinOffsetDelta from the term offsets (prox_slop_kernel's)
+      if (PROX && A.prox_slop && A.top_n) {  // IndexResult_MinOffsetDelta from the term offsets (prox_slop_kernel's)
         if (prox_two_terms(A.X) && !A.X.count_present) {
           slop = prox_min_offset_delta2(prox_term(A.O, 0, win[1u * TILE + e]), prox_term(A.O, 1, win[2u * TILE + e]));
         } else {
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
         }
         const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
         auto F = [&](int t) { return (double)win[(1u + (uint32_t)t) * TILE + e]; };
-        const double s = score_one<false>(A.P, F, dlen, dscore, mfreq, slop);
+        const double s = score_one<DEEP, 0, DEEP ? kHybDeepLevels : kMaxTreeDepth>(A.P, F, dlen, dscore, mfreq, slop);
         my_k[j] = ~d2key(s);
       }
     }
@@ -1330,10 +1336,16 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, 
   a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n_leaves + 1) * kHybTile);
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
   const bool small = a.n <= 4 && a.n_leaves <= 4 && a.n_req <= 4 && a.n_veto_all <= 4 && a.n_opt_all <= 4;
-#define RSGPU_HYBT(T, M)                                                                                         \
-  do {                                                                                                           \
-    if (small) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, 4>), dim3(n_tiles), dim3(256), lds, s, a);      \
-    else hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists>), dim3(n_tiles), dim3(256), lds, s, a); \
+  const bool prox = a.prox_filter || (a.prox_slop && a.top_n);
+  if (a.P.n_nodes > 0 && prox) throw std::runtime_error("hybrid tile kernel: a nested result tree has no proximity form");
+#define RSGPU_HYBT(T, M)                                                                                                          \
+  do {                                                                                                                            \
+    if (a.P.n_nodes > 0)                                                                                                          \
+      hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists, true, false>), dim3(n_tiles), dim3(256), lds, s, a);   \
+    else if (small && prox) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, 4, false, true>), dim3(n_tiles), dim3(256), lds, s, a); \
+    else if (prox)                                                                                                                \
+      hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists, false, true>), dim3(n_tiles), dim3(256), lds, s, a);   \
+    else hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists, false, false>), dim3(n_tiles), dim3(256), lds, s, a); \
   } while (0)
   if (!a.k) RSGPU_HYBT(KT_F32, KM_IP);
   else if (type == KT_F32 && metric == KM_L2) RSGPU_HYBT(KT_F32, KM_L2);

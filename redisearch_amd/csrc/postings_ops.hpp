@@ -370,7 +370,9 @@ __device__ __forceinline__ void prox_load(const ProxParams &P, const View &o, Pr
 // anywhere): the same sum in the same order -- 0.0 + leaf(0) + leaf(1) ... -- with the leaf numbers compile-time constants,
 // so the weights / idfs come out of the argument block with constant offsets, all at once, instead of one dependent scalar
 // load after the other.
-template <bool DEEP, int FLAT = 0, typename FreqFn>
+// MAXD (DEEP only): the deepest node the caller admits.  Up to 4 levels the accumulators are picked by compare-and-select over
+// constant indices and stay in registers (the hybrid tile kernel's form: no scratch); beyond, they are indexed dynamically.
+template <bool DEEP, int FLAT = 0, int MAXD = kMaxTreeDepth, typename FreqFn>
 __device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint32_t dlen, float dscore, uint32_t mfreq,
                                             int slop) {
   double s = 0.0;
@@ -386,19 +388,36 @@ __device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint
       // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
       // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the
       // reference's recursions add them in -- and its own value, weight * that, goes to its parent's accumulator.
-      double acc[kMaxTreeDepth + 1];
+      double acc[MAXD + 1];
 #pragma unroll
-      for (int d = 0; d <= kMaxTreeDepth; d++) acc[d] = 0.0;
+      for (int d = 0; d <= MAXD; d++) acc[d] = 0.0;
       for (int i = 0; i < P.n_nodes - 1; i++) {
         const int d = P.node_depth[i];
         double v;
-        if (P.node_op[i] == 0) {
-          v = leaf((int)P.node_leaf[i]);
+        if constexpr (MAXD <= 4) {
+          double own = 0.0, up = 0.0;
+#pragma unroll
+          for (int q = 1; q <= MAXD; q++) {
+            own = q == d ? acc[q] : own;
+            up = q == d ? acc[q - 1] : up;
+          }
+          const bool agg = P.node_op[i] != 0;
+          v = agg ? P.node_weight[i] * own : leaf((int)P.node_leaf[i]);
+          const double nu = (dismax && P.node_in_union[i]) ? (v > up ? v : up) : up + v;
+#pragma unroll
+          for (int q = 1; q <= MAXD; q++) {
+            if (q == d && agg) acc[q] = 0.0;
+            if (q == d) acc[q - 1] = nu;
+          }
         } else {
-          v = P.node_weight[i] * acc[d];
-          acc[d] = 0.0;
+          if (P.node_op[i] == 0) {
+            v = leaf((int)P.node_leaf[i]);
+          } else {
+            v = P.node_weight[i] * acc[d];
+            acc[d] = 0.0;
+          }
+          acc[d - 1] = (dismax && P.node_in_union[i]) ? (v > acc[d - 1] ? v : acc[d - 1]) : acc[d - 1] + v;
         }
-        acc[d - 1] = (dismax && P.node_in_union[i]) ? (v > acc[d - 1] ? v : acc[d - 1]) : acc[d - 1] + v;
       }
       return acc[0];
     }

@@ -1783,7 +1783,16 @@ struct HybGroup {
   double weight = 1.0;
   std::vector<int> lists;  // the caller's list indices, in the child's own leaf order
   size_t estimate = 0;
-  double key() const { return op == 3 ? 1.0e300 : intersection_sort_key(estimate, op, lists.size()); }  // (a Not: max_doc_id, last)
+  // a child with aggregates of its own (RSGPU_HybridTreeNodesQuery): its result tree over `lists` (post-order, leaf j = lists[j],
+  // the child's own node last) and what a hit must hold, as sets of leaves -- any_of: one of them; whole: a nested intersection
+  // under a union, absent as a whole unless every term matched; must: the leaves every hit holds (a driver is picked among them)
+  bool deep = false;
+  size_t n_children = 0;
+  std::vector<TNode> tree;
+  std::vector<uint32_t> any_of, whole, must;
+  double key() const {  // (a Not: max_doc_id, last)
+    return op == 3 ? 1.0e300 : intersection_sort_key(estimate, op, deep ? n_children : lists.size());
+  }
 };
 // a flat AND: every list a term child, ascending by size, stable (intersection.rs:94-119; intersect_async)
 static std::vector<HybGroup> hyb_groups_flat(RSGPU_Postings *const *lists, size_t n_lists, bool in_order = false) {
@@ -1843,13 +1852,23 @@ static std::vector<HybGroup> hyb_groups_tree(const RSGPU_TreeQuery *q, size_t n_
 static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists, uint32_t *n0_out) {
   int best = -1;
   uint32_t n0 = 0;
-  for (const HybGroup &g : groups)
+  for (const HybGroup &g : groups) {
+    if (g.deep) {
+      for (uint32_t m : g.must)
+        for (size_t j = 0; j < g.lists.size(); j++)
+          if (((m >> j) & 1u) && (best < 0 || lists[g.lists[j]]->n_entries < n0)) {
+            best = g.lists[j];
+            n0 = lists[best]->n_entries;
+          }
+      continue;
+    }
     if (g.op == 0 || g.op == 2)
       for (int li : g.lists)
         if (best < 0 || lists[li]->n_entries < n0) {
           best = li;
           n0 = lists[li]->n_entries;
         }
+  }
   *n0_out = n0;
   return best;
 }
@@ -1930,10 +1949,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       s.orig[j] = g.lists[j];
       s.first = std::min(s.first, pl->first_id);
       s.last = std::max(s.last, pl->last);
-      s.tree.push_back(TNode{0, (uint8_t)j, 0, 1.0});
+      if (!g.deep) s.tree.push_back(TNode{0, (uint8_t)j, 0, 1.0});
     }
     s.base = s.first;  // (only v.add of the ListView uses it: not read here)
-    s.tree.push_back(TNode{(uint8_t)g.op, 0, (uint16_t)g.lists.size(), g.weight});
+    if (g.deep) s.tree = g.tree;
+    else s.tree.push_back(TNode{(uint8_t)g.op, 0, (uint16_t)g.lists.size(), g.weight});
     srcs.push_back(s);
   }
   ListView v;
@@ -1973,7 +1993,6 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       for (int li : g.lists)
         if (lists[li]->n_entries) excluded.push_back(lists[li]);  // (an empty list excludes nothing)
   if (n + (int)excluded.size() > kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight lists");
-  if (!excluded.empty() && hits_out) throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children has no hit list (hits_out must be NULL)");
   if (root_union && (hits_out || !excluded.empty())) throw std::runtime_error("hybrid query: a root union on the tile path has neither a hit list nor NOT children");
   HybridTreeArgs T;
   memset(&T, 0, sizeof T);
@@ -2081,7 +2100,23 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     for (int g = 0; g < h.n_groups; g++) {
       uint32_t all = 0;
       for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) all |= 1u << list_of_leaf[t];
-      if (!root_union) {
+      if (!root_union && groups[g].deep) {
+        // a child with aggregates of its own: its sets of leaves, moved to this pass's list slots
+        auto slots = [&](uint32_t leaves) {
+          uint32_t m = 0;
+          for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++)
+            if ((leaves >> (t - h.group_first[g])) & 1u) m |= 1u << list_of_leaf[t];
+          return m;
+        };
+        for (uint32_t m : groups[g].any_of) {
+          if (P.n_req >= kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight required sets");
+          P.req[P.n_req++] = slots(m);
+        }
+        for (uint32_t m : groups[g].whole) {
+          if (P.n_opt_all >= kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight nested intersections");
+          P.opt_all[P.n_opt_all++] = slots(m);
+        }
+      } else if (!root_union) {
         // what a hit must hold: a term; every term of a child intersection; any term of a child union
         if (h.group_op[g] == 1) {
           P.req[P.n_req++] = all;  // (a NOT child's virtual group has no leaves: nothing required)
@@ -2563,11 +2598,241 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
     for (size_t g = 0; g < q->n_groups; g++)
       if (q->group_op[g] == RSGPU_OP_NOT)
         throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children runs on the general tile kernel only -- a root "
-                                 "intersection of at most eight lists with a term to drive it, no hits_out, top_n / k <= 32, labels a "
+                                 "intersection of at most eight lists with a term to drive it, top_n / k <= 32, labels a "
                                  "device table holds (RSGPU_FlatIndex_LabelTable != 2)");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
   tls_hybrid_path = 0;  // (RSGPU_EvalTree may have built the list with the tile kernel; this QUERY ran stage by stage)
+  if (!h) return -1;
+  a->n_hits = h->len;
+  if (want_score) {
+    if (RSGPU_Hits_Score(h.get(), a->table, a->score, nullptr) != 0) return -1;
+    const long nt = RSGPU_Hits_TopN(h.get(), a->top_n, a->top_ids, a->top_scores);
+    if (nt < 0) return -1;
+    a->n_top = (size_t)nt;
+  }
+  if (want_knn) {
+    const long nk = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
+    if (nk < 0) return -1;
+    a->n_knn = (size_t)nk;
+  }
+  if (a->hits_out) *a->hits_out = h.release();
+  return 0;
+  S_CATCH(-1)
+}
+
+// ---- RSGPU_HybridTreeNodesQuery: the hybrid query over a tree of any depth ----
+// The node array as a tree, every intersection's children in the order it iterates them (ascending estimate x sort weight,
+// stable: intersection.rs:94-119; a union keeps the query's order) -- the order RSGPU_EvalTreeNodes gives the result tree.
+namespace {
+struct QNode {
+  int op = 0, list = -1;  // 0 term, 1 union, 2 intersection
+  double weight = 1.0;
+  std::vector<int> kids;
+  size_t estimate = 0;
+  double key = 0.0;
+  int leaf_first = 0, n_leaves = 0;  // its terms among the leaves of the root child it belongs to
+  bool has_union = false;            // some aggregate below (or itself) is a union
+};
+struct QTree {
+  std::vector<QNode> n;
+  int root = -1, depth = 0;
+  bool windows = false;  // some node carries max_slop / in_order
+};
+// false: not a well-formed post-order array (RSGPU_EvalTreeNodes names the fault)
+bool parse_nodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *const *lists, size_t n_lists, QTree &t) {
+  if (n_nodes > (size_t)kMaxNodes || n_lists > (size_t)kMaxLists) return false;
+  std::vector<int> st;
+  std::vector<char> used(n_lists, 0);
+  for (size_t i = 0; i < n_nodes; i++) {
+    const RSGPU_TreeNode &nd = nodes[i];
+    QNode q;
+    if (nd.op == RSGPU_OP_TERM) {
+      if (nd.list >= n_lists || used[nd.list]) return false;
+      used[nd.list] = 1;
+      q.list = (int)nd.list;
+      q.estimate = lists[nd.list]->n_entries;
+      q.key = intersection_sort_key(q.estimate, 0, 1);
+    } else if (nd.op == RSGPU_OP_UNION || nd.op == RSGPU_OP_INTERSECT) {
+      if (!nd.n_children || nd.n_children > st.size()) return false;
+      q.op = nd.op == RSGPU_OP_UNION ? 1 : 2;
+      q.weight = nd.weight;
+      q.kids.assign(st.end() - (long)nd.n_children, st.end());
+      st.resize(st.size() - nd.n_children);
+      if (nd.op == RSGPU_OP_INTERSECT && (nd.max_slop >= 0 || nd.in_order)) t.windows = true;
+      if (q.op == 2) {
+        std::stable_sort(q.kids.begin(), q.kids.end(), [&](int x, int y) { return t.n[x].key < t.n[y].key; });
+        q.estimate = ~(size_t)0;
+        for (int k : q.kids) q.estimate = std::min(q.estimate, t.n[k].estimate);
+      } else {
+        for (int k : q.kids) q.estimate += t.n[k].estimate;
+      }
+      q.has_union = q.op == 1;
+      for (int k : q.kids) q.has_union = q.has_union || t.n[k].has_union;
+      q.key = intersection_sort_key(q.estimate, q.op, nd.n_children);
+    } else {
+      return false;
+    }
+    t.n.push_back(q);
+    st.push_back((int)i);
+  }
+  if (st.size() != 1) return false;
+  t.root = st[0];
+  return true;
+}
+// one child of the root as a HybGroup: its leaves in result order, its result tree, what a hit must hold of it.
+// false: a shape the tile kernel's predicate (sets of which one / all must match) cannot express -- a union below a nested
+// intersection below a union
+struct GroupBuilder {
+  QTree &t;
+  HybGroup &g;
+  int depth_max = 0;
+  void emit(int i, int depth) {  // leaves, tree nodes (post-order)
+    QNode &q = t.n[i];
+    depth_max = std::max(depth_max, depth);
+    q.leaf_first = (int)g.lists.size();
+    if (q.op == 0) {
+      g.tree.push_back(TNode{0, (uint8_t)g.lists.size(), 0, 1.0});
+      g.lists.push_back(q.list);
+    } else {
+      for (int k : q.kids) emit(k, depth + 1);
+      g.tree.push_back(TNode{(uint8_t)q.op, 0, (uint16_t)q.kids.size(), q.weight});
+    }
+    q.n_leaves = (int)g.lists.size() - q.leaf_first;
+  }
+  uint32_t mask(int i) const { return (uint32_t)(((1ull << t.n[i].n_leaves) - 1ull) << t.n[i].leaf_first); }
+  bool under_union(int i) {  // a child of a union, or of a union below a union
+    const QNode &q = t.n[i];
+    if (q.op == 0) return true;
+    if (q.op == 2) {
+      if (q.has_union) return false;
+      g.whole.push_back(mask(i));
+      return true;
+    }
+    for (int k : q.kids)
+      if (!under_union(k)) return false;
+    return true;
+  }
+  bool required(int i) {  // a node every hit holds
+    const QNode &q = t.n[i];
+    if (q.op == 0) {
+      g.any_of.push_back(mask(i));
+      g.must.push_back(mask(i));
+      return true;
+    }
+    if (q.op == 2) {
+      for (int k : q.kids)
+        if (!required(k)) return false;
+      return true;
+    }
+    for (int k : q.kids)
+      if (!under_union(k)) return false;
+    g.any_of.push_back(mask(i));
+    return true;
+  }
+};
+// the root's children in the order the root intersection iterates them; false: no form on the tile kernel
+bool tree_groups(QTree &t, std::vector<HybGroup> &groups) {
+  const QNode &root = t.n[t.root];
+  if (root.op != 2 || t.windows) return false;
+  for (int c : root.kids) {  // (already in iteration order: parse_nodes sorted them)
+    const QNode &q = t.n[c];
+    HybGroup g;
+    g.op = q.op;
+    g.weight = q.op ? q.weight : 1.0;  // (a term's own weight stays in RSGPU_ScoreArgs.weight)
+    g.estimate = q.estimate;
+    bool plain = true;  // a term, or an aggregate of terms: the two-level forms hybrid_general knows
+    for (int k : q.kids) plain = plain && t.n[k].op == 0;
+    GroupBuilder b{t, g};
+    b.emit(c, 1);
+    if (b.depth_max > kHybDeepLevels) return false;
+    t.depth = std::max(t.depth, b.depth_max);
+    if (plain) {
+      g.tree.clear();
+    } else {
+      g.deep = true;
+      g.n_children = q.kids.size();
+      if (!b.required(c)) return false;
+    }
+    groups.push_back(std::move(g));
+  }
+  return true;
+}
+}  // namespace
+
+/* RSGPU_HybridQuery over a query tree of any depth (include/rsgpu_search.h): the general tile kernel for a root intersection over
+ * at most eight lists with a term to drive it, whose nested aggregates the kernel's predicate expresses (tree_groups) -- every
+ * list probed in place, the score folded over the whole result tree (score_one<true>) -- else stage by stage: RSGPU_EvalTreeNodes,
+ * then the entry points a caller would use on its hit list.  Same answers. */
+extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_HybridQueryArgs *a) {
+  if (!nodes || !n_nodes || !a || !a->lists || !a->n_lists) {
+    last_error() = "RSGPU_HybridTreeNodesQuery: empty tree";
+    return -1;
+  }
+  S_TRY
+  if (n_nodes > (size_t)kMaxNodes || a->n_lists > (size_t)kMaxLists) throw std::runtime_error("RSGPU_HybridTreeNodesQuery: at most 64 nodes over 32 terms");
+  check_lists("RSGPU_HybridTreeNodesQuery", a->lists, a->n_lists);
+  const size_t n_lists = a->n_lists;
+  const bool want_score = a->table && a->score && a->top_n;
+  const bool want_knn = a->index && a->query && a->k;
+  const int device = a->lists[0]->device;
+  FlatIndex *f = want_knn ? a->index->flat : nullptr;
+  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridTreeNodesQuery: postings and index live on different devices");
+  if (want_score && a->table->device != device)
+    throw std::runtime_error("RSGPU_HybridTreeNodesQuery: postings and document table live on different devices");
+  a->n_hits = a->n_top = a->n_knn = 0;
+  if (a->hits_out) *a->hits_out = nullptr;
+  tls_hybrid_path = 0;
+  HIP_CHECK(hipSetDevice(device));
+
+  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) && !a->hits_out &&
+                 n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
+  bool offsets = false;
+  for (size_t l = 0; l < n_lists && general; l++) {
+    general = a->lists[l]->n_entries > 0;
+    offsets = offsets || a->lists[l]->has_offsets();
+  }
+  // (a scorer that divides by the result's slop reads the term offsets through the nested children: staged)
+  if (want_score && offsets && slop_dependent(a->score->scorer)) general = false;
+  QTree qt;
+  std::vector<HybGroup> groups;
+  general = general && parse_nodes(nodes, n_nodes, a->lists, n_lists, qt) && tree_groups(qt, groups);
+  if (general) {
+    size_t leaves = 0;
+    for (const HybGroup &g : groups) leaves += g.lists.size();
+    general = leaves == n_lists;  // (a list no node names: RSGPU_EvalTreeNodes ignores it, the kernel's arrays would not)
+  }
+  if (general) {
+    const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
+    uint32_t n0 = 0;
+    const uint32_t tiles = hyb_driver(groups, a->lists, &n0) >= 0 ? hybrid_tiles(n0) : 0u;
+    general = tiles > 0 &&
+              hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
+                                    want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
+    if (general) {
+      if (f) f->flush_if_needed();
+      CtxLease ca(device), cb(device);
+      Scratch &sc = scratch(device);
+      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
+      FusedEvents &ev = tls_events;
+      if (prof) ev.ensure(device);
+      LabelRows knn_rows{};
+      std::shared_lock<std::shared_mutex> index_lock;
+      if (f) {
+        index_lock = std::shared_lock<std::shared_mutex>(f->mu);
+        general = f->device_label_rows(&knn_rows);
+        if (general) f->upload_query(ca.c, a->query, true);
+      }
+      if (general && hybrid_general(a, a->lists, groups, -1, 0, nullptr, f, knn_rows, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
+        tls_hybrid_path = 2;
+        return 0;
+      }
+      a->n_hits = a->n_top = a->n_knn = 0;
+    }
+  }
+  // stage by stage (the index lock is released: the entry points below take it themselves)
+  std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTreeNodes(nodes, n_nodes, a->lists, n_lists));
+  tls_hybrid_path = 0;
   if (!h) return -1;
   a->n_hits = h->len;
   if (want_score) {

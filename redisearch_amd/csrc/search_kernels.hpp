@@ -290,6 +290,7 @@ void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s);
 //     hybrid_hits_pack_kernel -- a third launch, behind the reduce kernel: the answers do not wait for it -- moves them to
 //     their place in the list (exclusive sum of the tiles' hit counts).
 constexpr int kHybTreeMaxLists = 8;
+constexpr int kHybDeepLevels = 4;  // the deepest result tree (levels below the root) the general tile kernel scores: RSGPU_HybridTreeNodesQuery
 struct HybridOffsetView {  // OffsetView over the tree's leaves
   const uint8_t *bytes[kHybTreeMaxLists];
   const uint32_t *off_pos[kHybTreeMaxLists];

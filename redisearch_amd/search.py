@@ -45,6 +45,7 @@ ABI = {
     "RSGPU_Hits_TreeNodes": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "RSGPU_HybridQuery": (_i, [C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridTreeQuery": (_i, [C.POINTER(TreeQuery), C.POINTER(HybridQueryArgs)]),
+    "RSGPU_HybridTreeNodesQuery": (_i, [C.POINTER(TreeNode), _sz, C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridQueryPath": (_i, []),
     "RSGPU_HybridTrace": (C.c_long, [_vp, _sz]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
@@ -370,6 +371,37 @@ class HybridTreeQuery(HybridQuery):
 
     def _call(self):
         return self._tfn(C.byref(self._tq), self._ref)
+
+
+def tree_nodes(tree):
+    """nested tuples -- ("t", list_index) | ("and" | "or", weight, [children...][, max_slop, in_order]) -- as the post-order
+    RSGPU_TreeNode array"""
+    nodes = []
+
+    def walk(t):
+        if t[0] == "t":
+            nodes.append(TreeNode(OP_TERM, int(t[1]), 0, 1.0, -1, 0))
+            return
+        for ch in t[2]:
+            walk(ch)
+        ms = t[3] if len(t) > 3 and t[3] is not None else -1
+        io = int(bool(t[4])) if len(t) > 4 else 0
+        nodes.append(TreeNode(OP_INTERSECT if t[0] == "and" else OP_UNION, 0, len(t[2]), float(t[1]), int(ms), io))
+    walk(tree)
+    return (TreeNode * len(nodes))(*nodes), len(nodes)
+
+
+class HybridNodesQuery(HybridQuery):
+    """RSGPU_HybridTreeNodesQuery: HybridQuery over a query tree of any depth (nested tuples as NodeHits takes them); idf /
+    bm25_idf / weight per list in the order of `lists`."""
+
+    def __init__(self, tree, lists, **kw):
+        HybridQuery.__init__(self, lists, **kw)
+        self._nodes, self._n_nodes = tree_nodes(tree)
+        self._nfn = self.lib.RSGPU_HybridTreeNodesQuery
+
+    def _call(self):
+        return self._nfn(self._nodes, self._n_nodes, self._ref)
 
 
 class TreeHits(Hits):

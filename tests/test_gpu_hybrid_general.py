@@ -569,6 +569,18 @@ def test_not_children_against_the_oracle(name, pos, neg, with_offsets, max_slop,
     gone = set().union(*[set(recs[i]) for _, ix in neg for i in ix])
     docs = [d for d in ot.docs if d not in gone]
     assert len(docs) < len(ot.docs) or not ot.docs
+    # round 5: the hit list of such a query (hits_out) -- the positive children's columns, the virtual children in its result tree
+    hq = S.HybridTreeQuery(I, groups, max_slop=max_slop, in_order=in_order, table=table, scorer="BM25STD", idf=idf, bm25_idf=bidf, weight=w,
+                           num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10, root_weight=1.5, want_hits=True)
+    hq.run()
+    assert S.hybrid_path() == 2
+    hh = hq.take_hits()
+    hi, hf = hh.read()
+    assert hi.tolist() == docs
+    positive = [i for _, _, ix in pos for i in ix]
+    for li in range(n_lists):
+        assert hf[li].tolist() == [(recs[li][d][0] if (li in positive and d in recs[li]) else 0) for d in docs], li
+    assert sorted(hh.leaf_order()) == sorted(positive)
     for scorer in SCORERS:
         hq = S.HybridTreeQuery(I, groups, max_slop=max_slop, in_order=in_order, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
                                num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10, root_weight=1.5)
@@ -582,6 +594,12 @@ def test_not_children_against_the_oracle(name, pos, neg, with_offsets, max_slop,
             node = O.intersection(kids)
             node.c.weight = 1.5
             scored.append((O.score(scorer, node, float(doc_score[d]), int(max_freq[d]), int(doc_len[d]), n_docs, avg), d))
+        # (RSGPU_Hits_Score over the returned list: every hit's score, not just the ranked ten)
+        hs = hh.score(table, scorer, idf, bidf, w, n_docs, avg, root_weight=1.5)
+        if scorer == "BM25STD.TANH":
+            assert hs == pytest.approx([x for x, _ in scored], rel=1e-12)
+        else:
+            assert hs.tolist() == [x for x, _ in scored], scorer
         scored.sort(key=lambda t: (-t[0], t[1]))
         assert a["top"][0].tolist() == [d for _, d in scored[:10]], (scorer, a["top"][0], scored[:10])
         if scorer == "BM25STD.TANH":
@@ -649,8 +667,8 @@ def test_not_children_where_the_tile_kernel_cannot_run():
     g = [S.Postings.from_flat(x[0].flatten()) for x in built]
     table = table_for(rng, 2500)
     ones = [1.0] * 3
-    # hits_out with a NOT child, a NOT child under a root of unions only, RSGPU_EvalTree: refused with a message, not answered wrongly
-    for kw, groups in ((dict(want_hits=True), [(T, 1.0, g[:1]), (S.OP_NOT, 1.0, g[1:2])]),
+    # a NOT child under a root of unions only (with and without hits_out), RSGPU_EvalTree: refused with a message, not answered wrongly
+    for kw, groups in ((dict(want_hits=True), [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])]),
                        (dict(), [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])])):
         hq = S.HybridTreeQuery(I, groups, table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones, num_docs=2500, avg_doc_len=150.0,
                                top_n=10, **kw)

@@ -126,14 +126,21 @@ def test_general_hybrid_tile_kernel_budget(kernels):
     """hybrid_tree_tile_kernel (round 4): up to eight lists' match positions per driver live in registers through the probe --
     at most 128 registers (four waves per SIMD; the LDS pool of (lists + 1) KiB-words bounds residency before that), scratch only
     for the proximity cursors (ProxCtx<8>: 240 bytes per lane, touched by the lanes that hold a candidate when a window or a
-    slop-dependent scorer asks for the term offsets), no vector spills.  The pack kernel is a copy."""
+    slop-dependent scorer asks for the term offsets), no vector spills; the instantiations for queries that read no offsets carry
+    no cursors and no scratch.  The pack kernel is a copy."""
     tiles = [k for k in kernels if k["name"].startswith("hybrid_tree_tile_kernel<")]
-    assert len(tiles) == 12                       # (round 5: six type / metric pairs x ML = 4 | 8)
+    # round 5: six type / metric pairs x {ML = 4 | 8 with the proximity cursors, ML = 8 without, ML = 8 without + nested trees}
+    assert len(tiles) == 24
     for k in tiles:
         assert k["vgpr"] <= 128 and not k["vgpr_spill"] and k["scratch"] <= 512 and k["lds"] <= 4096 and k["wg"] == 256, k
     # the ML = 4 instantiation (queries of up to four lists) exists for its register budget: six wavefronts per SIMD where the
     # element type allows (<= 80 VGPRs), half the cursor scratch
-    small = [k for k in tiles if k["name"].rstrip(">").endswith(", 4")]
+    small = [k for k in tiles if re.search(r", 4, false, true>$", k["name"])]
     assert len(small) == 6 and all(k["scratch"] <= 128 for k in small) and sum(k["vgpr"] <= 80 for k in small) >= 3, small
+    # the queries that read no term offsets (PROX = false; the nested-tree form DEEP among them): no scratch at all
+    plain = [k for k in tiles if k["name"].endswith(", false>")]
+    assert len(plain) == 12 and all(k["scratch"] == 0 and k["vgpr"] <= 85 for k in plain), plain
+    deep = [k for k in plain if k["name"].endswith(", true, false>")]
+    assert len(deep) == 6
     pack = [k for k in kernels if k["name"].startswith("hybrid_hits_pack_kernel")]
     assert len(pack) == 1 and pack[0]["vgpr"] <= 32 and not pack[0]["scratch"], pack
