@@ -831,6 +831,14 @@ def _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_
             mk.append(lambda a=a, i=i, j=j, j2=j2, j3=j3, qi=qi, tree=tree: S.HybridNodesQuery(tree, [fo[i], fo[j], fo[j2], fo[j3]], index=idx,
                                                                                               q=qvecs[qi], k=10, **a))
         shapes["nested_a_and_bc_or_d_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 5: `(a|b) (c|d)` -- no term every hit holds: the smaller union drives, a pass per term
+            i2, j2 = (i + 1) % n_a, n_a + (j - n_a + 1) % n_b
+            a = sc([i, i2, j, j2]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, i2=i2, j=j, j2=j2, qi=qi: S.HybridTreeQuery(S.OP_INTERSECT, [(S.OP_UNION, 1.0, [fo[i], fo[i2]]),
+                                                                                                   (S.OP_UNION, 1.0, [fo[j], fo[j2]])],
+                                                                                  index=idx, q=qvecs[qi], k=10, **a))
+        shapes["two_unions_of_two_freqs_only_bm25std_knn"] = mk
         for name, makers in shapes.items():
             rec = {}
             answers = {}

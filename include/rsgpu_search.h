@@ -201,8 +201,9 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
  * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
  * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list; round 5: a root union of terms /
- * intersections of terms without hits_out -- one pass per child -- and, through RSGPU_HybridTreeNodesQuery, nested trees).  A root
- * whose children are all unions, top_n / k > 32 and indexes whose labels no device table holds stay staged.  Same answers. */
+ * intersections of terms without hits_out -- one pass per child --, a root intersection whose children are all unions without
+ * hits_out -- the smallest union drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees).
+ * top_n / k > 32 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */

@@ -1873,6 +1873,37 @@ static int hyb_driver(const std::vector<HybGroup> &groups, RSGPU_Postings *const
   return best;
 }
 
+// No term every hit holds -- every child of the root intersection is a union, `(run|running|ran) (shoe|shoes)`, the stemmer's
+// expansions (round 5): the child union with the fewest postings drives, one pass of the tile kernel per term of it; a document an
+// EARLIER term of that union holds belongs to that term's pass.  -1: no child is a plain union of terms.
+static int hyb_union_driver_group(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists, uint32_t *tiles_out) {
+  int best = -1;
+  uint64_t best_n = 0, best_tiles = 0;
+  for (size_t g = 0; g < groups.size(); g++) {
+    if (groups[g].op != 1 || groups[g].deep) continue;
+    uint64_t n = 0, tiles = 0;
+    for (int li : groups[g].lists) {
+      n += lists[li]->n_entries;
+      tiles += hybrid_tiles(lists[li]->n_entries);
+    }
+    if (best < 0 || n < best_n) {
+      best = (int)g;
+      best_n = n;
+      best_tiles = tiles;
+    }
+  }
+  if (tiles_out) *tiles_out = (uint32_t)std::min<uint64_t>(best_tiles, 0xFFFFFFFFull);
+  return best;
+}
+// the tiles of a root intersection: its driver's, or -- no term every hit holds, nobody wants the hit list (its order would
+// interleave the passes) -- those of the union that drives it; 0: no form on the tile kernel
+static uint32_t hyb_intersection_tiles(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists, bool hits_wanted) {
+  uint32_t n0 = 0, tiles = 0;
+  if (hyb_driver(groups, lists, &n0) >= 0) return hybrid_tiles(n0);
+  if (hits_wanted || hyb_union_driver_group(groups, lists, &tiles) < 0) return 0;
+  return tiles;
+}
+
 // the shortest list of one child (a term, or the terms of a child intersection); -1: a union child has no list every hit holds
 static int hyb_group_driver(const HybGroup &g, RSGPU_Postings *const *lists, uint32_t *n0_out) {
   int best = -1;
@@ -1971,6 +2002,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   };
   std::vector<Pass> passes;
   uint32_t n_tiles = 0;
+  int union_driven = -1;  // the child union whose terms drive, one pass each (no term every hit holds)
   if (root_union) {
     for (size_t g = 0; g < groups.size(); g++) {
       Pass p{-1, (int)g, 0, 0, n_tiles};
@@ -1983,8 +2015,18 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   } else {
     Pass p{-1, -1, 0, 0, 0};
     p.driver = hyb_driver(groups, lists, &p.n0);
-    p.tiles = n_tiles = hybrid_tiles(p.n0);
-    passes.push_back(p);
+    if (p.driver >= 0) {
+      p.tiles = n_tiles = hybrid_tiles(p.n0);
+      passes.push_back(p);
+    } else {  // every child is a union: one of them drives, term by term (hyb_union_driver_group)
+      union_driven = hyb_union_driver_group(groups, lists, nullptr);
+      if (union_driven < 0 || hits_out) throw std::runtime_error("hybrid query: no term or union of terms to drive the tile kernel");
+      for (int li : groups[union_driven].lists) {
+        Pass q{li, union_driven, lists[li]->n_entries, hybrid_tiles(lists[li]->n_entries), n_tiles};
+        n_tiles += q.tiles;
+        passes.push_back(q);
+      }
+    }
   }
 
   std::vector<RSGPU_Postings *> excluded;  // NOT children's lists: probed behind the leaves, no column of their own
@@ -2100,7 +2142,10 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     for (int g = 0; g < h.n_groups; g++) {
       uint32_t all = 0;
       for (int t = h.group_first[g]; t < h.group_first[g + 1]; t++) all |= 1u << list_of_leaf[t];
-      if (!root_union && groups[g].deep) {
+      if (g == union_driven) {
+        // the driving union: this pass's term holds the document (it drives); one that an earlier term holds is that pass's hit
+        for (int t = h.group_first[g]; t < h.group_first[g + 1] && h.order[t] != ps.driver; t++) P.veto |= 1u << list_of_leaf[t];
+      } else if (!root_union && groups[g].deep) {
         // a child with aggregates of its own: its sets of leaves, moved to this pass's list slots
         auto slots = [&](uint32_t leaves) {
           uint32_t m = 0;
@@ -2154,8 +2199,8 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
     // (the exact select settles a mass tie by (key, POSITION): doc-id order inside one pass, not across the passes of a root
-    // union -- that query, which has a staged form, takes it)
-    if (root_union && top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) return false;
+    // union / of a driving union -- that query, which has a staged form, takes it)
+    if ((root_union || passes.size() > 1) && top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) return false;
     hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
@@ -2567,8 +2612,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   for (size_t l = 0; l < n_lists && general; l++) general = excluded_list[l] || q->lists[l]->n_entries > 0;
   if (general) {
     const std::vector<HybGroup> groups = hyb_groups_tree(q, n_lists);
-    uint32_t n0 = 0;
-    const uint32_t tiles = root_union ? hyb_union_tiles(groups, q->lists) : (hyb_driver(groups, q->lists, &n0) >= 0 ? hybrid_tiles(n0) : 0u);
+    const uint32_t tiles = root_union ? hyb_union_tiles(groups, q->lists) : hyb_intersection_tiles(groups, q->lists, a->hits_out != nullptr);
     general = tiles > 0 &&
               hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
                                     want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
@@ -2804,8 +2848,7 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
   }
   if (general) {
     const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
-    uint32_t n0 = 0;
-    const uint32_t tiles = hyb_driver(groups, a->lists, &n0) >= 0 ? hybrid_tiles(n0) : 0u;
+    const uint32_t tiles = hyb_intersection_tiles(groups, a->lists, false);
     general = tiles > 0 &&
               hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
                                     want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);

@@ -329,7 +329,9 @@ def test_tree_query_shapes_the_general_kernel_declines():
     w = [1.0, 2.0, 0.5, 1.0]
     # (round 5: a root union of terms / intersections takes the tile kernel -- unless it has a union child, the hit list is wanted or
     # the scorer divides by the result's slop, which differs from hit to hit in a union)
-    for root, groups, scorer, kw, path in ((I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", {}, 0),
+    # (... and a root intersection of unions only: the smallest union drives, term by term -- unless the hit list is wanted)
+    for root, groups, scorer, kw, path in ((I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", {}, 2),
+                                           (I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", dict(want_hits=True), 0),
                                            (U, [(T, 1.0, g[:1]), (I, 1.0, g[1:3])], "BM25STD", {}, 2),
                                            (U, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD", {}, 0),
                                            (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "TFIDF", {}, 0),
@@ -345,6 +347,31 @@ def test_tree_query_shapes_the_general_kernel_declines():
         h.score(table, scorer, idf[:nl], bidf[:nl], w[:nl], 2500, 150.0, want_scores=False)
         ti, ts = h.topn(10)
         assert r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
+
+
+# ---- a root intersection of unions only: `(run|running|ran) (shoe|shoes)` (round 5) ----------------------------------------------
+ALL_UNION_SHAPES = [
+    ("(a|b) (c|d)", [(U, 1.0, [0, 1]), (U, 0.5, [2, 3])]),
+    ("(a|b|c) (d|e) (f|g)", [(U, 2.0, [0, 1, 2]), (U, 1.0, [3, 4]), (U, 1.5, [5, 6])]),
+    ("(a) (b|c)", [(U, 2.0, [0]), (U, 1.0, [1, 2])]),
+]
+
+
+@pytest.mark.parametrize("with_offsets,max_slop,in_order", [(False, None, False), (True, None, False), (True, 6, False), (True, None, True)])
+@pytest.mark.parametrize("name,shape", ALL_UNION_SHAPES)
+def test_root_of_unions_only_is_driven_by_its_smallest_union(name, shape, with_offsets, max_slop, in_order):
+    """The stemmer's expansions on every term: no list every hit holds.  The child union with the fewest postings drives -- one pass
+    of the tile kernel per term of it, a document an earlier term of that union holds belongs to that term's pass (veto), one reduce
+    kernel over all passes' tiles: against the staged form bit for bit and the CPU oracle (tree_case)."""
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + int(with_offsets) + (max_slop or 0) + 3 * int(in_order))
+    assert tree_case(rng, shape, with_offsets, max_slop=max_slop, in_order=in_order, want_hits=False) > 0
+
+
+def test_root_of_unions_over_many_tiles():
+    rng = np.random.default_rng(41)
+    n = tree_case(rng, [(U, 1.0, [0, 1]), (U, 1.0, [2, 3, 4])], False, n_range=(10_000, 30_000), max_doc=200_000, scorers=["BM25STD", "DISMAX"],
+                  want_hits=False)
+    assert n > 2000
 
 
 # ---- a root UNION on the tile path (round 5) ----------------------------------------------------------------------------------------
@@ -667,13 +694,18 @@ def test_not_children_where_the_tile_kernel_cannot_run():
     g = [S.Postings.from_flat(x[0].flatten()) for x in built]
     table = table_for(rng, 2500)
     ones = [1.0] * 3
-    # a NOT child under a root of unions only (with and without hits_out), RSGPU_EvalTree: refused with a message, not answered wrongly
-    for kw, groups in ((dict(want_hits=True), [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])]),
-                       (dict(), [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])])):
-        hq = S.HybridTreeQuery(I, groups, table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones, num_docs=2500, avg_doc_len=150.0,
-                               top_n=10, **kw)
-        with pytest.raises(RuntimeError, match="NOT"):
-            hq.run()
+    # a NOT child under a root of unions only with hits_out, RSGPU_EvalTree: refused with a message, not answered wrongly
+    hq = S.HybridTreeQuery(I, [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])], table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones,
+                           num_docs=2500, avg_doc_len=150.0, top_n=10, want_hits=True)
+    with pytest.raises(RuntimeError, match="NOT"):
+        hq.run()
+    # (without hits_out the union drives, term by term: round 5)
+    hq = S.HybridTreeQuery(I, [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])], table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones,
+                           num_docs=2500, avg_doc_len=150.0, top_n=10)
+    hq.run()
+    assert S.hybrid_path() == 2
+    docs = [set(x[1]) for x in built]
+    assert hq.results()["n_hits"] == len((docs[0] | docs[1]) - docs[2])
     with pytest.raises(RuntimeError):
         S.TreeHits(I, [(T, 1.0, g[:1]), (S.OP_NOT, 1.0, g[1:2])])
 

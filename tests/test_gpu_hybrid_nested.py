@@ -39,6 +39,8 @@ NESTED = [
     ("a (b|(c d)) ((e f)|g|h)", ("and", 1.0, [t(0), ("or", 1.0, [t(1), ("and", 0.5, [t(2), t(3)])]),
                                               ("or", 2.0, [("and", 1.5, [t(4), t(5)]), t(6), t(7)])]), 8),
     ("single-child aggregates", ("and", 1.0, [t(0), ("or", 2.0, [("and", 0.5, [t(1)])]), ("and", 1.5, [("or", 0.5, [t(2)])])]), 3),
+    # (no term every hit holds: the plain union drives, term by term)
+    ("(a|b) ((c d)|e)", ("and", 1.0, [("or", 1.0, [t(0), t(1)]), ("or", 1.0, [("and", 1.0, [t(2), t(3)]), t(4)])]), 5),
     ("a ((b (c d))|e)", ("and", 1.0, [t(0), ("or", 1.0, [("and", 2.0, [t(1), ("and", 0.5, [t(2), t(3)])]), t(4)])]), 5),
 ]
 
@@ -115,7 +117,7 @@ DECLINED = [
     ("five levels", ("and", 1.0, [t(0), ("and", 1.0, [t(1), ("and", 1.0, [t(2), ("and", 1.0, [t(3), ("or", 1.0, [t(4), t(5)])])])])]), 6),
     ("a union below an intersection below a union", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [t(1), ("or", 1.0, [t(2), t(3)])]), t(4)])]), 5),
     ("a root union", ("or", 1.0, [t(0), ("and", 1.0, [t(1), ("or", 1.0, [t(2), t(3)])])]), 4),
-    ("no term every hit holds", ("and", 1.0, [("or", 1.0, [t(0), t(1)]), ("or", 1.0, [("and", 1.0, [t(2), t(3)]), t(4)])]), 5),
+    ("no term and no union of terms to drive", ("and", 1.0, [("or", 1.0, [("and", 1.0, [t(0), t(1)]), t(2)]), ("or", 1.0, [("and", 1.0, [t(3), t(4)]), t(5)])]), 6),
     ("a nested window", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [t(1), t(2)], 3, False), t(3)])]), 4),
 ]
 
