@@ -197,13 +197,13 @@ typedef struct {
 int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
 /* how the calling thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 = the staged pipeline (intersection written
  * out, score / top-N and KNN branches on two streams; stage by stage for trees), 1 = two launches (no hits_out, a flat AND of
- * <= 4 term lists, top_n / k <= 32 (31 for BM25STD.NORM), no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
+ * <= 4 term lists, top_n / k <= 64 (63 for BM25STD.NORM), no slop-dependent scorer over lists with offsets: one tile kernel -- probe, scores,
  * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
  * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
  * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list; round 5: a root union of terms /
  * intersections of terms without hits_out -- one pass per child --, a root intersection whose children are all unions without
  * hits_out -- the smallest union drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees).
- * top_n / k > 32 and indexes whose labels no device table holds stay staged.  Same answers. */
+ * top_n / k > 64 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */

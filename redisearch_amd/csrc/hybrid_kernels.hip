@@ -1227,6 +1227,14 @@ __global__ __launch_bounds__(256) void knn_chain_min_kernel(KnnChainArgs A) {
   }
 }
 
+// Settling a mass tie across the passes of one query (search_abi.cpp hyb_settle_overflow): the doc ids of the entries whose score
+// key is tau, "none" for every other entry -- the exact select then takes the smallest of them.
+__global__ __launch_bounds__(256) void hybrid_tie_ids_kernel(const uint64_t *__restrict__ skey, const uint32_t *__restrict__ sidx, uint32_t n,
+                                                             uint64_t tau, uint64_t *__restrict__ out) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+  if (e < n) out[e] = skey[e] == tau ? (uint64_t)sidx[e] : ~0ull;
+}
+
 // The hit list out of the tiles' fixed slots: tile t's hits go behind those of the tiles before it.  One workgroup per tile; it
 // sums the counts below its own (n_tiles <= 16 Ki words, L2-resident).  Runs BEHIND the reduce kernel: the query's answers are
 // in host memory before this kernel starts.
@@ -1387,6 +1395,10 @@ void launch_knn_chain_min(const void *rows, size_t stride, int type, int metric,
   else if (metric == KM_L2) RSGPU_CH(KT_BF16, KM_L2);
   else RSGPU_CH(KT_BF16, KM_IP);
 #undef RSGPU_CH
+}
+void launch_hybrid_tie_ids(const uint64_t *skey, const uint32_t *sidx, uint32_t n, uint64_t tau, uint64_t *out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(hybrid_tie_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, s, skey, sidx, n, tau, out);
 }
 void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
                              const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,

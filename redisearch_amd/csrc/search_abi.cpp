@@ -138,7 +138,7 @@ struct Scratch {
   bool knn_dirty = true;  // the counters may be non-zero (first use, or a query that failed half-way)
   // hybrid query in two launches (hybrid_kernels.hip): the tiles' lists, the reduce blocks' lists, the two tickets
   DevBuf<uint32_t> hyb_hits, hyb_sidx;
-  DevBuf<uint64_t> hyb_skey, hyb_knn, hyb_trace;
+  DevBuf<uint64_t> hyb_skey, hyb_knn, hyb_trace, hyb_tie;
   uint32_t hyb_trace_tiles = 0;
   // ... its general form, hit list wanted: doc id | frequencies | entry indices at the tiles' fixed slots (hybrid_hits_pack)
   DevBuf<uint32_t> hyb_hit_ids, hyb_hit_freqs, hyb_hit_epos;
@@ -156,7 +156,7 @@ Scratch &scratch(int device) {
     s.knn_part.reset();
     s.knn_dirty = true;
     s.hyb_hits.reset(); s.hyb_sidx.reset();
-    s.hyb_skey.reset(); s.hyb_knn.reset(); s.hyb_trace.reset();
+    s.hyb_skey.reset(); s.hyb_knn.reset(); s.hyb_trace.reset(); s.hyb_tie.reset();
     s.hyb_trace_tiles = 0;
     s.hyb_hit_ids.reset(); s.hyb_hit_freqs.reset(); s.hyb_hit_epos.reset();
     s.device = device;
@@ -1583,7 +1583,11 @@ static void hyb_wait(QueryCtx *ca, bool may_poll, bool sync_after) {
 // keys IS doc-id order; (distance key << 32 | doc id) for the KNN lists -- and fills the pinned answers as the kernel would have.
 // Rounds 3-4 re-ran such a query through the ten-kernel staged pipeline, and a query with NOT children (no staged form) failed:
 // whether a query succeeded depended on its data (round-4 advisor).
-static void hyb_settle_overflow(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k) {
+// across_passes (a root union, a root of unions: several passes' tiles side by side): position order is doc-id order inside one
+// pass only.  Every entry below the top_n-th key tau is in whatever the order; of the entries AT tau the smallest doc ids are --
+// a second select, over their doc ids -- and the list is put in (key, doc id) order on the host.
+static void hyb_settle_overflow(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_t n_tiles, uint32_t top_n, uint32_t k,
+                                bool across_passes = false) {
   if (!n_tiles) return;
   if (top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) {
     const uint32_t n_hits = ca->h_counters[0];  // (the select below reuses the pinned counters)
@@ -1597,8 +1601,29 @@ static void hyb_settle_overflow(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(ca->stream));
     }
-    for (size_t i = 0; i < top.size(); i++) ca->h_out_keys[i] = top[i].key;
-    ca->h_fcnt[2] = (uint32_t)top.size();
+    if (across_passes && !top.empty()) {
+      const uint64_t tau = top.back().key;
+      std::vector<std::pair<uint64_t, uint32_t>> fin;  // (key, doc id)
+      for (size_t i = 0; i < top.size() && top[i].key < tau; i++) fin.emplace_back(top[i].key, ca->h_ids[i]);
+      const uint32_t need = (uint32_t)(top.size() - fin.size());
+      sc.hyb_tie.ensure((size_t)n_tiles * top_n);
+      launch_hybrid_tie_ids(sc.hyb_skey.p, sc.hyb_sidx.p, n_tiles * top_n, tau, sc.hyb_tie.p, ca->stream);
+      HIP_CHECK(hipGetLastError());
+      std::vector<Hit> ties;
+      radix_select(ca, sc.hyb_tie.p, 8, n_tiles * top_n, need, Bound(), ties, nullptr);
+      for (const Hit &t : ties)
+        if (t.key != ~0ull) fin.emplace_back(tau, (uint32_t)t.key);
+      std::sort(fin.begin(), fin.end());
+      ca->ensure_gather(fin.size() + 1);
+      for (size_t i = 0; i < fin.size(); i++) {
+        ca->h_out_keys[i] = fin[i].first;
+        ca->h_ids[i] = fin[i].second;
+      }
+      ca->h_fcnt[2] = (uint32_t)fin.size();
+    } else {
+      for (size_t i = 0; i < top.size(); i++) ca->h_out_keys[i] = top[i].key;
+      ca->h_fcnt[2] = (uint32_t)top.size();
+    }
     ca->h_counters[0] = n_hits;
   }
   if (k && cb->h_fcnt[2] == 0xFFFFFFFFu) {
@@ -2198,10 +2223,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
-    // (the exact select settles a mass tie by (key, POSITION): doc-id order inside one pass, not across the passes of a root
-    // union / of a driving union -- that query, which has a staged form, takes it)
-    if ((root_union || passes.size() > 1) && top_n && ca->h_fcnt[2] == 0xFFFFFFFFu) return false;
-    hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
+    hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k, root_union || passes.size() > 1);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;
   if (hits_out) {
@@ -2642,7 +2664,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
     for (size_t g = 0; g < q->n_groups; g++)
       if (q->group_op[g] == RSGPU_OP_NOT)
         throw std::runtime_error("RSGPU_HybridTreeQuery: a query with NOT children runs on the general tile kernel only -- a root "
-                                 "intersection of at most eight lists with a term to drive it, top_n / k <= 32, labels a "
+                                 "intersection of at most eight lists with a term or a union of terms to drive it, top_n / k <= 64, labels a "
                                  "device table holds (RSGPU_FlatIndex_LabelTable != 2)");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));

@@ -209,7 +209,9 @@ void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStre
 // ---- a whole hybrid query in two launches (hybrid_kernels.hip) ---------------------------------------------------
 // flat AND of up to kHybMaxLists term lists (list 0 drives) -> top_n by score next to the k nearest among the hits that have a
 // vector (L: doc id -> row, kernels.hpp LabelRows).  Either branch may be off (top_n == 0 / k == 0).
-constexpr int kHybMaxLists = 4, kHybMaxK = 32, kHybMaxChunks = 512;
+// kHybMaxK: the tile's and the reduce kernel's bounds are the k-th of 64 bests (one wavefront ranks them) -- exact up to 64, tight
+// up to ~32; between, more entries pass them (the reduce kernel hands a query with too many back to the exact select)
+constexpr int kHybMaxLists = 4, kHybMaxK = 64, kHybMaxChunks = 512;
 constexpr int kHybTracePhases = 9;  // start | window ends | window staged | probe done | hits compacted | scored | ranked | distances | end
 struct HybridTileArgs {
   int n;                               // lists
@@ -351,6 +353,8 @@ struct HybridTreeArgs {
 };
 bool hybrid_tree_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k, int n_lists);
 void launch_hybrid_tree_tiles(const HybridTreeArgs &a, int type, int metric, uint32_t n_tiles, hipStream_t s);
+// out[e] = skey[e] == tau ? sidx[e] : none (settling a tie across the passes of one query)
+void launch_hybrid_tie_ids(const uint64_t *skey, const uint32_t *sidx, uint32_t n, uint64_t tau, uint64_t *out, hipStream_t s);
 // dst[off(t) + r] = src[t * 1024 + r], r < tile_hits[t], off(t) = sum of tile_hits below t; ids, then n leaf columns of freqs
 // (src stride src_stride, dst stride dst_cap) and -- unless NULL -- of entry indices; *total_out (device or pinned) = the sum
 void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,

@@ -349,6 +349,27 @@ def test_tree_query_shapes_the_general_kernel_declines():
         assert r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
 
 
+def test_tree_query_with_top_n_and_k_up_to_sixty_four():
+    """top_n / k between 33 and 64 (round 5; staged before): the tiles' and the reduce kernel's bounds are the k-th of 64 bests"""
+    rng = np.random.default_rng(64)
+    n_docs = 150_000
+    lists_o, rng = flat_corpus(n_docs, (0.3, 0.25, 0.2), 640)
+    g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
+    table = table_for(rng, n_docs)
+    idf = [S.calculate_idf(n_docs, l.unique_docs) for l in lists_o]
+    bidf = [S.calculate_idf_bm25(n_docs, l.unique_docs) for l in lists_o]
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    idx.add_philox_rows(11, 0, 60_000, 100)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    for root, groups in ((I, [(T, 1.0, g[:1]), (U, 0.5, g[1:])]), (U, [(T, 1.0, g[:1]), (I, 2.0, g[1:])]), (I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])])):
+        for scorer, top_n, k in (("BM25STD", 64, 40), ("DISMAX", 33, 64), ("BM25STD.NORM", 63, 64)):
+            a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(root, groups, table=table, scorer=scorer, idf=idf, bm25_idf=bidf,
+                                                                      weight=[1.0, 2.0, 0.5], num_docs=n_docs, avg_doc_len=200.0, top_n=top_n,
+                                                                      index=idx, q=q, k=k, root_weight=1.5))
+            assert len(a["top"][0]) == top_n and len(a["knn"][0]) == k
+    idx.free()
+
+
 # ---- a root intersection of unions only: `(run|running|ran) (shoe|shoes)` (round 5) ----------------------------------------------
 ALL_UNION_SHAPES = [
     ("(a|b) (c|d)", [(U, 1.0, [0, 1]), (U, 0.5, [2, 3])]),
@@ -372,6 +393,15 @@ def test_root_of_unions_over_many_tiles():
     n = tree_case(rng, [(U, 1.0, [0, 1]), (U, 1.0, [2, 3, 4])], False, n_range=(10_000, 30_000), max_doc=200_000, scorers=["BM25STD", "DISMAX"],
                   want_hits=False)
     assert n > 2000
+    # a mass tie (DOCSCORE: three distinct scores) handed back by the reduce kernel (forced: a cap of 4 survivors): settled across
+    # the passes by doc id, against the oracle's (score descending, doc id ascending)
+    try:
+        knob("hybrid_surv_cap", 4)
+        rng = np.random.default_rng(42)
+        assert tree_case(rng, [(U, 1.0, [0, 1]), (U, 1.0, [2, 3])], False, n_range=(10_000, 30_000), max_doc=200_000, scorers=["DOCSCORE", "DISMAX"],
+                         want_hits=False) > 1000
+    finally:
+        knob("hybrid_surv_cap", 2048)
 
 
 # ---- a root UNION on the tile path (round 5) ----------------------------------------------------------------------------------------
@@ -465,9 +495,8 @@ def test_root_union_over_many_tiles_and_one_sided_children():
             try:
                 knob("hybrid_surv_cap", cap)
                 # (cap 4: the reduce kernel hands a mass tie back; the exact select's (key, position) order is doc-id order inside
-                # one pass only, so a root union takes its staged form -- same answers, path 0)
-                a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, **kw),
-                                                want_path=2 if cap == 2048 else 0)
+                # one pass only: the entries at the cut's key are settled by a second select over their doc ids -- path 2 still)
+                a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, **kw))
             finally:
                 knob("hybrid_surv_cap", 2048)
             assert a["n_hits"] > 500_000 and len(a["top"][0]) == top_n and len(a["knn"][0]) == k

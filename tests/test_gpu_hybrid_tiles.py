@@ -2,7 +2,7 @@
 and one reduce kernel) against the staged pipeline behind the same entry point (knob hybrid_tiles = 0) and, through it, the
 stage-by-stage entry points the oracle tests pin: hit count, top-N ids and scores, KNN ids and distances, BIT FOR BIT -- on every
 scorer, element type, metric, row shape (lanes per row / chunks per lane of the scan kernels), list count, codec without
-frequencies, 64-bit doc ids, skewed lists whose windows overflow LDS, mass ties (decided by doc id) and N / k from 1 to 32."""
+frequencies, 64-bit doc ids, skewed lists whose windows overflow LDS, mass ties (decided by doc id) and N / k from 1 to 64."""
 import zlib
 
 import numpy as np
@@ -108,8 +108,8 @@ def test_every_element_type_metric_and_row_shape(vtype, metric, dim):
     idx.free()
 
 
-@pytest.mark.parametrize("top_n,k", [(1, 1), (3, 32), (32, 5), (32, 32)])
-def test_list_lengths_from_one_to_thirty_two_and_fewer_hits_than_asked_for(top_n, k):
+@pytest.mark.parametrize("top_n,k", [(1, 1), (3, 32), (32, 5), (32, 32), (48, 7), (10, 50), (64, 64)])
+def test_list_lengths_from_one_to_sixty_four_and_fewer_hits_than_asked_for(top_n, k):
     n_docs = 500_000
     lists_o, rng = corpus(n_docs, (0.3, 0.2), 31)
     g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
@@ -138,13 +138,15 @@ def test_mass_ties_are_decided_by_doc_id():
     table = S.DocTable(np.full(n_docs + 1, 100, np.uint32), np.ones(n_docs + 1, np.float32))
     idx = V.VecSimIndex(V.VecSimType_FLOAT32, 8, V.VecSimMetric_L2)
     idx.add_bulk(np.tile(np.arange(8, dtype=np.float32), (300_000, 1)), 200_001)
-    a, b, path = both_paths(lambda: S.HybridQuery(g, table, "DOCSCORE", [1, 1], [1, 1], [1, 1], n_docs, 100.0, top_n=20, index=idx,
-                                                  q=np.zeros(8, np.float32), k=20))
-    assert path == 1
     hits = O.intersect(lists_o)[0]
-    assert a["top"][0].tolist() == hits[:20].tolist() and set(a["top"][1].tolist()) == {1.0}
     with_vec = hits[(hits >= 200_001) & (hits <= 500_000)]
-    assert a["knn"][0].tolist() == with_vec[:20].tolist() and len(set(a["knn"][1].tolist())) == 1
+    # (64: every entry of the first 63 tiles sits at the reduce kernel's bound -- more than it ranks; the exact select settles it)
+    for n in (20, 64):
+        a, b, path = both_paths(lambda: S.HybridQuery(g, table, "DOCSCORE", [1, 1], [1, 1], [1, 1], n_docs, 100.0, top_n=n, index=idx,
+                                                      q=np.zeros(8, np.float32), k=n))
+        assert path == 1
+        assert a["top"][0].tolist() == hits[:n].tolist() and set(a["top"][1].tolist()) == {1.0}
+        assert a["knn"][0].tolist() == with_vec[:n].tolist() and len(set(a["knn"][1].tolist())) == 1
 
 
 @pytest.mark.parametrize("shape", ["skewed", "window_overflow", "clustered", "dense_equal", "ragged_tail", "disjoint"])
@@ -198,7 +200,7 @@ def test_lists_without_frequencies_and_sixty_four_bit_doc_ids():
 
 
 def test_shapes_the_two_launches_leave_to_the_staged_pipeline():
-    """N > 32: the staged pipeline answers.  Round 4: five lists run the general tile kernel (path 2,
+    """N > 64: the staged pipeline answers (round 5: 32 before).  Round 4: five lists run the general tile kernel (path 2,
     tests/test_gpu_hybrid_general.py); BM25STD.NORM -- the maximum over ALL hits is the first entry's score -- is ranked as BM25STD
     by the two launches and divided on the host.  Each against the staged pipeline (knob hybrid_tiles = 0), bit for bit."""
     lib = V.load()
@@ -207,9 +209,11 @@ def test_shapes_the_two_launches_leave_to_the_staged_pipeline():
     g = [S.Postings.from_flat(l.flatten()) for l in lists_o]
     table = S.DocTable((50 + rng.poisson(150, n_docs + 1)).astype(np.uint32), rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32))
     ones = [1.0] * 5
-    for args, path in ((dict(lists=g[:2], scorer="BM25STD.NORM", top_n=10), 1), (dict(lists=g[:2], scorer="BM25STD.NORM", top_n=32), 0),
+    for args, path in ((dict(lists=g[:2], scorer="BM25STD.NORM", top_n=10), 1), (dict(lists=g[:2], scorer="BM25STD.NORM", top_n=63), 1),
+                       (dict(lists=g[:2], scorer="BM25STD.NORM", top_n=64), 0),
                        (dict(lists=g, scorer="BM25STD", top_n=10), 2), (dict(lists=g, scorer="BM25STD.NORM", top_n=31), 2),
-                       (dict(lists=g[:2], scorer="BM25STD", top_n=40), 0)):
+                       (dict(lists=g, scorer="BM25STD", top_n=64), 2),
+                       (dict(lists=g[:2], scorer="BM25STD", top_n=40), 1), (dict(lists=g[:2], scorer="BM25STD", top_n=80), 0)):
         n = len(args["lists"])
         r = S.hybrid_query(args["lists"], table, args["scorer"], ones[:n], ones[:n], ones[:n], n_docs, 200.0, top_n=args["top_n"])
         assert S.hybrid_path() == path and len(r["top"][0]) == args["top_n"], args
