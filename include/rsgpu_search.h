@@ -281,8 +281,10 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
  * RSGPU_ScoreArgs.idf / bm25_idf / weight per LIST in their order, everything else as RSGPU_HybridQuery, hits_out included.
  * Results are those of RSGPU_EvalTreeNodes + RSGPU_Hits_Score / _TopN / _KnnRerank.  RSGPU_HybridQueryPath reads 2 when the
  * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds, nested at most four
- * levels, unions whose children are terms, unions or intersections of terms, no max_slop / in_order on any node, no hits_out,
- * no slop-dependent scorer over lists that store offsets; 0 when it ran stage by stage. */
+ * levels, unions whose children are terms, unions or intersections of terms, no max_slop / in_order below the root (nor on it
+ * when some child nests aggregates), no hits_out, no slop-dependent scorer over lists that store offsets under nested children;
+ * 0 when it ran stage by stage.  RSGPU_OP_NOT nodes (children: the excluded terms) are accepted as children of the root
+ * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form. */
 int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_HybridQueryArgs *args);
 /* The result tree behind a hit list, post-order (after the intersections sorted their children by size): per node the
  * operator, the leaf column of a term (-1 for aggregates; leaves are the child slots of RSGPU_Hits_LeafOrder), the number

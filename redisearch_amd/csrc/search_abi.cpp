@@ -2692,7 +2692,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
 // stable: intersection.rs:94-119; a union keeps the query's order) -- the order RSGPU_EvalTreeNodes gives the result tree.
 namespace {
 struct QNode {
-  int op = 0, list = -1;  // 0 term, 1 union, 2 intersection
+  int op = 0, list = -1;  // 0 term, 1 union, 2 intersection, 3 not (its children: the excluded terms)
   double weight = 1.0;
   std::vector<int> kids;
   size_t estimate = 0;
@@ -2703,7 +2703,10 @@ struct QNode {
 struct QTree {
   std::vector<QNode> n;
   int root = -1, depth = 0;
-  bool windows = false;  // some node carries max_slop / in_order
+  bool windows = false;   // some node below the root carries max_slop / in_order
+  bool has_not = false;   // some node is a NOT (no staged form: RSGPU_EvalTreeNodes has no such node)
+  long root_slop = -1;    // the root's own window
+  int root_in_order = 0;
 };
 // false: not a well-formed post-order array (RSGPU_EvalTreeNodes names the fault)
 bool parse_nodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *const *lists, size_t n_lists, QTree &t) {
@@ -2725,9 +2728,15 @@ bool parse_nodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *co
       q.weight = nd.weight;
       q.kids.assign(st.end() - (long)nd.n_children, st.end());
       st.resize(st.size() - nd.n_children);
-      if (nd.op == RSGPU_OP_INTERSECT && (nd.max_slop >= 0 || nd.in_order)) t.windows = true;
+      const bool window = nd.op == RSGPU_OP_INTERSECT && (nd.max_slop >= 0 || nd.in_order);
+      if (window && i + 1 < n_nodes) t.windows = true;
+      if (window && i + 1 == n_nodes) {
+        t.root_slop = nd.max_slop;
+        t.root_in_order = nd.in_order ? 1 : 0;
+      }
       if (q.op == 2) {
-        std::stable_sort(q.kids.begin(), q.kids.end(), [&](int x, int y) { return t.n[x].key < t.n[y].key; });
+        if (!nd.in_order)  // (in_order: the query's order is the order the children must appear in)
+          std::stable_sort(q.kids.begin(), q.kids.end(), [&](int x, int y) { return t.n[x].key < t.n[y].key; });
         q.estimate = ~(size_t)0;
         for (int k : q.kids) q.estimate = std::min(q.estimate, t.n[k].estimate);
       } else {
@@ -2736,6 +2745,17 @@ bool parse_nodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_Postings *co
       q.has_union = q.op == 1;
       for (int k : q.kids) q.has_union = q.has_union || t.n[k].has_union;
       q.key = intersection_sort_key(q.estimate, q.op, nd.n_children);
+    } else if (nd.op == RSGPU_OP_NOT) {  // (RSGPU_HybridTreeNodesQuery only: a child of the root intersection over terms)
+      if (!nd.n_children || nd.n_children > st.size()) return false;
+      q.op = 3;
+      q.weight = nd.weight;
+      q.kids.assign(st.end() - (long)nd.n_children, st.end());
+      st.resize(st.size() - nd.n_children);
+      for (int k : q.kids)
+        if (t.n[k].op != 0) return false;
+      q.estimate = ~(size_t)0;  // (a Not's estimate is max_doc_id: it sorts behind every real child)
+      q.key = 1.0e300;
+      t.has_not = true;
     } else {
       return false;
     }
@@ -2753,9 +2773,11 @@ struct GroupBuilder {
   QTree &t;
   HybGroup &g;
   int depth_max = 0;
+  bool misplaced_not = false;
   void emit(int i, int depth) {  // leaves, tree nodes (post-order)
     QNode &q = t.n[i];
     depth_max = std::max(depth_max, depth);
+    if (q.op == 3) misplaced_not = true;
     q.leaf_first = (int)g.lists.size();
     if (q.op == 0) {
       g.tree.push_back(TNode{0, (uint8_t)g.lists.size(), 0, 1.0});
@@ -2801,9 +2823,18 @@ struct GroupBuilder {
 bool tree_groups(QTree &t, std::vector<HybGroup> &groups) {
   const QNode &root = t.n[t.root];
   if (root.op != 2 || t.windows) return false;
+  bool deep = false;
   for (int c : root.kids) {  // (already in iteration order: parse_nodes sorted them)
     const QNode &q = t.n[c];
     HybGroup g;
+    if (q.op == 3) {  // excluded terms: no leaf of the result tree, a virtual child of frequency 0 (hyb_groups_tree)
+      g.op = 3;
+      g.weight = q.weight;
+      g.estimate = ~(size_t)0;
+      for (int k : q.kids) g.lists.push_back(t.n[k].list);
+      groups.push_back(std::move(g));
+      continue;
+    }
     g.op = q.op;
     g.weight = q.op ? q.weight : 1.0;  // (a term's own weight stays in RSGPU_ScoreArgs.weight)
     g.estimate = q.estimate;
@@ -2811,17 +2842,20 @@ bool tree_groups(QTree &t, std::vector<HybGroup> &groups) {
     for (int k : q.kids) plain = plain && t.n[k].op == 0;
     GroupBuilder b{t, g};
     b.emit(c, 1);
-    if (b.depth_max > kHybDeepLevels) return false;
+    if (b.misplaced_not || b.depth_max > kHybDeepLevels) return false;
     t.depth = std::max(t.depth, b.depth_max);
     if (plain) {
       g.tree.clear();
     } else {
-      g.deep = true;
+      g.deep = deep = true;
       g.n_children = q.kids.size();
       if (!b.required(c)) return false;
     }
     groups.push_back(std::move(g));
   }
+  // (the root's own window: the two-level forms check it -- prox_within_range over terms / unions / intersections of terms)
+  if (deep && (t.root_slop >= 0 || t.root_in_order)) return false;
+  t.depth = deep ? std::max(t.depth, 3) : t.depth;
   return true;
 }
 }  // namespace
@@ -2851,22 +2885,30 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
   tls_hybrid_path = 0;
   HIP_CHECK(hipSetDevice(device));
 
-  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) && !a->hits_out &&
-                 n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4));
-  bool offsets = false;
-  for (size_t l = 0; l < n_lists && general; l++) {
-    general = a->lists[l]->n_entries > 0;
-    offsets = offsets || a->lists[l]->has_offsets();
-  }
-  // (a scorer that divides by the result's slop reads the term offsets through the nested children: staged)
-  if (want_score && offsets && slop_dependent(a->score->scorer)) general = false;
   QTree qt;
   std::vector<HybGroup> groups;
-  general = general && parse_nodes(nodes, n_nodes, a->lists, n_lists, qt) && tree_groups(qt, groups);
+  const bool parsed = parse_nodes(nodes, n_nodes, a->lists, n_lists, qt);
+  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) && !a->hits_out &&
+                 n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4)) && parsed && tree_groups(qt, groups);
+  bool deep = false;
   if (general) {
-    size_t leaves = 0;
-    for (const HybGroup &g : groups) leaves += g.lists.size();
-    general = leaves == n_lists;  // (a list no node names: RSGPU_EvalTreeNodes ignores it, the kernel's arrays would not)
+    // every list a leaf or an excluded term (a list no node names: RSGPU_EvalTreeNodes ignores it, the kernel's arrays would
+    // not); an EXCLUDED list may be empty -- it is simply not probed -- a required one may not
+    std::vector<char> seen(n_lists, 0);
+    bool offsets = false;
+    for (const HybGroup &g : groups) {
+      deep = deep || g.deep;
+      for (int li : g.lists) {
+        seen[li] = 1;
+        if (g.op != 3) {
+          general = general && a->lists[li]->n_entries > 0;
+          offsets = offsets || a->lists[li]->has_offsets();
+        }
+      }
+    }
+    for (size_t l = 0; l < n_lists; l++) general = general && seen[l];
+    // (nested children: a scorer that divides by the result's slop would read the term offsets through them -- staged)
+    if (deep && want_score && offsets && slop_dependent(a->score->scorer)) general = false;
   }
   if (general) {
     const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
@@ -2888,13 +2930,18 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
         general = f->device_label_rows(&knn_rows);
         if (general) f->upload_query(ca.c, a->query, true);
       }
-      if (general && hybrid_general(a, a->lists, groups, -1, 0, nullptr, f, knn_rows, want_score, want_knn, ca.c, cb.c, sc, prof, ev)) {
+      if (general && hybrid_general(a, a->lists, groups, deep ? -1 : qt.root_slop, deep ? 0 : qt.root_in_order, nullptr, f, knn_rows, want_score,
+                                    want_knn, ca.c, cb.c, sc, prof, ev)) {
         tls_hybrid_path = 2;
         return 0;
       }
       a->n_hits = a->n_top = a->n_knn = 0;
     }
   }
+  if (parsed && qt.has_not)
+    throw std::runtime_error("RSGPU_HybridTreeNodesQuery: a query with NOT children runs on the general tile kernel only -- NOT nodes over "
+                             "terms under a root intersection of at most eight lists with a term or a union of terms to drive it, no "
+                             "hits_out, top_n / k <= 64, labels a device table holds");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTreeNodes(nodes, n_nodes, a->lists, n_lists));
   tls_hybrid_path = 0;

@@ -374,8 +374,8 @@ class HybridTreeQuery(HybridQuery):
 
 
 def tree_nodes(tree):
-    """nested tuples -- ("t", list_index) | ("and" | "or", weight, [children...][, max_slop, in_order]) -- as the post-order
-    RSGPU_TreeNode array"""
+    """nested tuples -- ("t", list_index) | ("and" | "or", weight, [children...][, max_slop, in_order]) | ("not", weight, [terms...]) --
+    as the post-order RSGPU_TreeNode array"""
     nodes = []
 
     def walk(t):
@@ -386,7 +386,7 @@ def tree_nodes(tree):
             walk(ch)
         ms = t[3] if len(t) > 3 and t[3] is not None else -1
         io = int(bool(t[4])) if len(t) > 4 else 0
-        nodes.append(TreeNode(OP_INTERSECT if t[0] == "and" else OP_UNION, 0, len(t[2]), float(t[1]), int(ms), io))
+        nodes.append(TreeNode({"and": OP_INTERSECT, "or": OP_UNION, "not": OP_NOT}[t[0]], 0, len(t[2]), float(t[1]), int(ms), io))
     walk(tree)
     return (TreeNode * len(nodes))(*nodes), len(nodes)
 

@@ -45,7 +45,7 @@ NESTED = [
 ]
 
 
-def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, n_range=(900, 2200), max_doc=2500, want_hits=False):
+def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, n_range=(900, 2200), max_doc=2500, want_hits=False, deep=True):
     codec = O.C_FULL if with_offsets else O.C_FREQS_ONLY
     built = [rand_list(rng, codec, int(rng.integers(*n_range)), max_doc, with_offsets) for _ in range(n_lists)]
     lists_o, recs = [x[0] for x in built], [x[1] for x in built]
@@ -67,7 +67,7 @@ def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, 
     ot = DeepOracle(tree, recs, sizes)
     for scorer in scorers:
         # (a scorer that divides by the slop reads the term offsets through the nested children: that query is staged)
-        path = 0 if (with_offsets and scorer in SLOP_DEPENDENT) else want_path
+        path = 0 if (deep and with_offsets and scorer in SLOP_DEPENDENT) else want_path
         a, b, ha, hb = general_and_staged(lambda: S.HybridNodesQuery(tree, g, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
                                                                      num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
                                                                      root_weight=1.5, want_hits=want_hits), want_path=path)
@@ -109,8 +109,9 @@ def test_two_level_trees_through_the_nodes_entry_point():
     """root -> children -> terms through RSGPU_HybridTreeNodesQuery: the two-level instantiation (ScoreParams::n_nodes = 0)"""
     rng = np.random.default_rng(77)
     tree = ("and", 1.0, [("or", 0.5, [t(0), t(1)]), t(2), ("and", 2.0, [t(3), t(4)])])
-    assert nested_case(rng, tree, 5, False) > 0
-    assert nested_case(rng, ("and", 1.0, [t(1), t(0)]), 2, True) > 0
+    assert nested_case(rng, tree, 5, False, deep=False) > 0
+    assert nested_case(rng, tree, 5, True, deep=False) > 0          # (the per-hit slop from the term offsets: the two-level form has it)
+    assert nested_case(rng, ("and", 1.0, [t(1), t(0)]), 2, True, deep=False) > 0
 
 
 DECLINED = [
@@ -192,3 +193,103 @@ def test_malformed_node_arrays_are_refused_with_a_message():
     hq.run()
     assert S.hybrid_path() == 0 and hq.results()["n_hits"] > 0
     knob("hybrid_tree_tiles", 1)
+
+
+# ---- NOT nodes under the root, the root's own window ---------------------------------------------------------------------------------
+def test_not_nodes_next_to_nested_children_against_the_oracle():
+    """`a ((b c)|d) -e -(f|g)`: the excluded terms veto a candidate in the tile kernel; the result is the positive children's plus
+    one virtual child of frequency 0 per NOT (not.rs:106-118), which adds nothing to any sum but counts as a child of the
+    intersection (the offset-less slop is children - 1).  No staged twin (RSGPU_EvalTreeNodes has no NOT node): the CPU oracle
+    directly -- DeepOracle over the positive subtree, set difference, its scorers over Intersection{..., Virtual, Virtual}."""
+    rng = np.random.default_rng(31)
+    n_lists = 7
+    built = [rand_list(rng, O.C_FREQS_ONLY, int(rng.integers(900, 2200)), 2500, False) for _ in range(n_lists)]
+    recs, sizes = [x[1] for x in built], [x[0].unique_docs for x in built]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    positive = ("and", 1.0, [t(0), ("or", 0.5, [("and", 2.0, [t(1), t(2)]), t(3)])])
+    nots = [(1.0, [4]), (2.0, [5, 6])]
+    tree = ("and", 1.0, positive[2] + [("not", wt, [t(i) for i in ix]) for wt, ix in nots])
+    n_docs = 2500
+    doc_len = rng.integers(5, 200, n_docs + 1).astype(np.uint32)
+    doc_score = rng.choice([1.0, 0.5], n_docs + 1).astype(np.float32)
+    max_freq = rng.integers(1, 40, n_docs + 1).astype(np.uint32)
+    table = S.DocTable(doc_len, doc_score, max_freq)
+    idf = [S.calculate_idf(n_docs, s) for s in sizes]
+    bidf = [S.calculate_idf_bm25(n_docs, s) for s in sizes]
+    w = [float(x) for x in rng.choice([1.0, 0.5, 2.0], n_lists)]
+    avg = float(doc_len[1:].mean())
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    idx.add_philox_rows(11, 0, 1200, 100)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    ot = DeepOracle(positive, recs, sizes)
+    gone = set().union(*[set(recs[i]) for _, ix in nots for i in ix])
+    docs = [d for d in ot.docs if d not in gone]
+    assert 0 < len(docs) < len(ot.docs)
+    for scorer in SCORERS:
+        hq = S.HybridNodesQuery(tree, g, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w, num_docs=n_docs, avg_doc_len=avg,
+                                top_n=10, index=idx, q=q, k=10, root_weight=1.5)
+        hq.run()
+        assert S.hybrid_path() == 2
+        a = hq.results()
+        assert a["n_hits"] == len(docs), (scorer, a["n_hits"], len(docs))
+        scored = []
+        for d in docs:
+            node = O.intersection(ot.node(ot.tree, d, idf, bidf, w).kids + [O.Node(O.R_VIRTUAL, wt, 0) for wt, _ in nots])
+            node.c.weight = 1.5
+            scored.append((O.score(scorer, node, float(doc_score[d]), int(max_freq[d]), int(doc_len[d]), n_docs, avg), d))
+        scored.sort(key=lambda x: (-x[0], x[1]))
+        assert a["top"][0].tolist() == [d for _, d in scored[:10]], (scorer, a["top"][0], scored[:10])
+        if scorer == "BM25STD.TANH":
+            assert a["top"][1] == pytest.approx([x for x, _ in scored[:10]], rel=1e-12)
+        else:
+            assert a["top"][1].tolist() == [x for x, _ in scored[:10]], scorer
+    cand = np.asarray([d for d in docs if 100 <= d < 1300], np.int64)
+    o = O.FlatIndex(O.F32, 24, O.L2)
+    o.add_bulk(O.philox_rows(11, 0, 1200, 24)[cand - 100], 1)
+    li, _ = o.topk(q, 10)
+    assert a["knn"][0].tolist() == cand[li.astype(np.int64) - 1].tolist()
+    # where the tile kernel cannot run, such a query is refused with a message (hits_out; a NOT below a union: malformed)
+    for tr, kw in ((tree, dict(want_hits=True)), (("and", 1.0, [t(0), ("or", 1.0, [t(1), ("not", 1.0, [t(2)])])]), {})):
+        hq = S.HybridNodesQuery(tr, g if kw else g[:3], table=table, scorer="BM25STD", idf=idf, bm25_idf=bidf, weight=w, num_docs=n_docs,
+                                avg_doc_len=avg, top_n=10, **kw)
+        with pytest.raises(RuntimeError):
+            hq.run()
+    idx.free()
+
+
+@pytest.mark.parametrize("max_slop,in_order", [(4, False), (None, True), (2, True)])
+def test_two_level_trees_with_a_window_and_a_not_node_match_the_tree_query(max_slop, in_order):
+    """root -> children -> terms through the nodes entry point is the two-level tree query: the root's max_slop / in_order, a
+    slop-dependent scorer over the term offsets, a NOT node -- the same answers as RSGPU_HybridTreeQuery, bit for bit (which
+    tests/test_gpu_hybrid_general.py holds to the oracle)"""
+    rng = np.random.default_rng(7 + (max_slop or 0) + int(in_order))
+    built = [rand_list(rng, O.C_FULL, int(rng.integers(1200, 2200)), 2500, True) for _ in range(5)]
+    sizes = [x[0].unique_docs for x in built]
+    g = [S.Postings.from_flat(x[0].flatten()) for x in built]
+    table = table_for(rng, 2500)
+    idf = [S.calculate_idf(2500, s) for s in sizes]
+    bidf = [S.calculate_idf_bm25(2500, s) for s in sizes]
+    w = [1.0, 0.5, 2.0, 1.5, 0.0]
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, 24, V.VecSimMetric_L2)
+    idx.add_philox_rows(11, 0, 1200, 100)
+    q = O.philox_rows(11, 1 << 40, 1, 24)[0]
+    tree = ("and", 1.0, [t(0), ("or", 0.5, [t(1), t(2)]), t(3), ("not", 1.0, [t(4)])], max_slop, in_order)
+    groups = [(S.OP_TERM, 1.0, g[:1]), (S.OP_UNION, 0.5, g[1:3]), (S.OP_TERM, 1.0, g[3:4]), (S.OP_NOT, 1.0, g[4:])]
+    total = 0
+    for scorer in ("BM25STD", "TFIDF.DOCNORM", "BM25"):
+        kw = dict(table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w, num_docs=2500, avg_doc_len=150.0, top_n=10, index=idx, q=q, k=10,
+                  root_weight=1.5)
+        hn = S.HybridNodesQuery(tree, g, **kw)
+        hn.run()
+        assert S.hybrid_path() == 2
+        a = hn.results()
+        ht = S.HybridTreeQuery(S.OP_INTERSECT, groups, max_slop=max_slop, in_order=in_order, **kw)
+        ht.run()
+        assert S.hybrid_path() == 2
+        b = ht.results()
+        assert a["n_hits"] == b["n_hits"]
+        total += a["n_hits"]
+        for key in ("top", "knn"):
+            assert a[key][0].tolist() == b[key][0].tolist() and a[key][1].tolist() == b[key][1].tolist(), (scorer, key)
+    assert total > 0 or max_slop == 2
+    idx.free()
