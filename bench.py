@@ -706,9 +706,6 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                 hq.run()
                 res.append(hq.results())
             path = S.hybrid_path()
-            if mode != "warm":   # (cold: a list's first decode left its sync points; from here on the tile kernel decodes)
-                hqs[0].run()
-            in_tile = bool(S.hybrid_cold_fused()) if mode != "warm" else False
             walls = []
             with no_gc():
                 for _ in range(cycles):
@@ -733,8 +730,6 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                    "device_ms": {"tile_kernel": tile, "reduce_kernel": red, "decode": dec} if path in (1, 2) else
                                 {k_: float(np.mean([x.get(k_) or 0.0 for x in prof])) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
                    "same_answers_every_cycle": bool(same)}
-            if mode != "warm":
-                rec["decode_inside_the_tile_kernel"] = in_tile
             if mode == "warm":
                 answers = res
                 # algorithmic bytes of the tile kernel, per query: 4 B per decoded posting of both lists + 12 B per hit

@@ -205,12 +205,6 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * hits_out -- the smallest union drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees).
  * top_n / k > 64 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
-/* 1: the calling thread's last two-launch query (path 1) decoded its posting lists INSIDE the tile kernel (round 5) -- lists
- * uploaded in decode-per-query mode (RSGPU_SetTuning("cache_decoded", 0)) in the FreqsOnly or the Full codec, after their first
- * decode left its sync points: a tile's blocks go from the encoded bytes straight into LDS, the decoded arrays are never
- * written (the reference's reader decodes as it intersects: inverted_index/src/reader/core.rs skip_to / next_record).  0: the
- * lists were decoded by a kernel of their own, or were cached.  Same answers.  RSGPU_SetTuning("hybrid_cold_fused", 0): off. */
-int RSGPU_HybridQueryColdFused(void);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
 long RSGPU_HybridTrace(uint64_t *out, size_t cap_tiles);

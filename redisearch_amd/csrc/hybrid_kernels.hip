@@ -275,7 +275,7 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
 #define RSGPU_HYB_MARK(p)                                                                                   \
   do {                                                                                                      \
-    if (COLD == 0 && A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
+    if (A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
 // Dynamic LDS: pool_words u32 (the probe's window of another list; then the hits' records -- doc id | frequency in list 0 |
@@ -285,17 +285,8 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // kHybMaxLists> is instantiated: round 5 measured tiles of 2 048 (one round over the chip instead of two: 63.7 us against 45.7 --
 // every phase grows with the tile, the tiles that hold vectors take 55 us) and of 512 (54.2 us: the per-tile overhead) on the
 // configs[4] stream, profiles/r05_hybrid_tile_size_ab.json.
-// COLD (round 5; 0: the lists' decoded arrays as above): the lists in their ENCODED form, decoded inside the tile -- 1: the
-// FreqsOnly record layout (qint2: delta, frequency), 2: Full (qint4: delta, frequency, field mask, offsets length + the offsets
-// bytes).  A tile = kHybColdBlocks consecutive blocks of the driving list (<= 1 020 postings): their bytes go global -> LDS by
-// DMA (the upper half of the pool), eight lanes parse a block from its sync points (16 records each) into doc ids | frequencies
-// in the lower half; then, per probed list, the blocks that can hold the tile's doc-id range (a bucket directory over the blocks'
-// first doc ids: one round trip) the same way, a fixed-length LDS search per driver, the match's frequency kept in the register
-// that holds its position otherwise.  The decoded arrays are never written; nothing after the probe differs
-// (reference: the reader decodes as it intersects -- inverted_index/src/reader/core.rs skip_to / next_record).
-// (the 16-bit COLD forms need a few registers more than six waves per SIMD leave: five)
-template <int TYPE, int METRIC, int DPT, int NL, int COLD = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((COLD != 0 && TYPE != KT_F32) ? 5 : 6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
+template <int TYPE, int METRIC, int DPT, int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
   constexpr uint32_t TILE = 256u * DPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t wave_cnt[4];
@@ -305,266 +296,130 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((COLD != 0 
   const uint32_t WIN = A.pool_words;
   u4 *qs = reinterpret_cast<u4 *>(win + WIN);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n0 = A.len[0];
+  const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  const uint32_t *__restrict__ ids0 = A.ids[0];
+
+  RSGPU_HYB_MARK(0);
+  // the first level of the window-end searches in list 1 (64 fixed positions), requested together with the tile's doc ids
+  uint32_t lvl1 = 0;
+  const bool pre1 = A.n > 1 && A.len[1] > 64 && !A.dir[1];
+  if (pre1) {
+    const uint32_t step = (A.len[1] + 63) / 64, p = (lane + 1) * step - 1;
+    lvl1 = A.ids[1][p < A.len[1] ? p : A.len[1] - 1];
+  }
+  if (A.k)  // the query: in flight while the probe runs
+    for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
+
   bool hit[DPT];
   uint32_t xc[DPT];            // doc id in the frame the lists share
   uint32_t f0[DPT];            // its frequency in the driving list
-  uint32_t ps[DPT][NL - 1];  // match position in list l (COLD: the match's frequency in list l)
-  if constexpr (COLD != 0) {
-    constexpr int NF = COLD == 1 ? 2 : 4, OS = COLD == 1 ? -1 : 3;
-    if (A.k)  // the query: in flight while the tile is decoded and probed
-      for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
-    static_assert(TILE >= kHybColdBlocks * kHybColdMaxNent, "a tile's blocks must fit its slots");
-    __shared__ uint64_t c_bo[kHybColdBlocks + 1];
-    __shared__ uint32_t c_eo[kHybColdBlocks + 1], c_first[kHybColdBlocks + 1], c_lo, c_hi;
-    uint32_t *dec_ids = win, *dec_fr = win + TILE;
-    uint8_t *stage = reinterpret_cast<uint8_t *>(win + 2 * TILE);  // kHybColdStageBytes (pool_words >= 4 Ki)
-    RSGPU_HYB_MARK(0);
-    // blocks [cb, cb + g) of list E -- g <= nb_max, as many as the stage holds -- to dec_ids / dec_fr [at, at + cnt); returns g
-    auto decode_group = [&](const HybEncList &E, uint32_t cb, uint32_t nb_max, uint32_t at, uint32_t &cnt) -> uint32_t {
-      __syncthreads();  // (c_*, the stage and the decoded arrays are free: everybody is past the previous group)
-      if (threadIdx.x <= nb_max) {
-        c_bo[threadIdx.x] = E.byte_off[cb + threadIdx.x];
-        c_eo[threadIdx.x] = E.entry_off[cb + threadIdx.x];
-        c_first[threadIdx.x] = E.first[cb + (threadIdx.x < nb_max ? threadIdx.x : nb_max - 1)];
-      }
-      // a parse lane's sync point, requested with the block descriptions (the lanes of blocks past g discard theirs)
-      const uint32_t j = threadIdx.x >> 3, part = threadIdx.x & kSyncPts;
-      uint32_t skip = 0, sbase = 0;
-      if (j < nb_max && part) {
-        const uint32_t *sp = E.sync + ((size_t)(cb + j) * kSyncPts + part - 1) * 2;
-        skip = sp[0];
-        sbase = sp[1];
-      }
-      __syncthreads();
-      const uint64_t w_beg = c_bo[0] & ~15ull;  // (16-byte aligned start: the DMA moves 16 bytes per lane)
-      uint32_t g = 1;
-      for (uint32_t q = 2; q <= nb_max; q++) g = (c_bo[q] - w_beg <= (uint64_t)kHybColdStageBytes) ? q : g;
-      const uint32_t span = (uint32_t)(c_bo[g] - w_beg);
-      {
-        const uint8_t *src = E.bytes + w_beg + (size_t)lane * 16;
-        for (uint32_t o = wave * 1024u; o < span; o += 4096u)
-          if (o + lane * 16 < span)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
-                                             (__attribute__((address_space(3))) void *)(stage + o), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      if (j < g) {
-        const uint32_t nent = c_eo[j + 1] - c_eo[j], done = part * kSyncSeg;
-        const uint32_t my_n = nent > done ? ((nent - done < kSyncSeg || part == kSyncPts) ? nent - done : kSyncSeg) : 0u;
-        const uint32_t out = at + (c_eo[j] - c_eo[0]) + done;
-        if (my_n)
-          qint_records_to_lds<NF, 1, OS>(stage, (uint32_t)(c_bo[j] - w_beg) + skip, (uint32_t)(c_bo[j + 1] - w_beg), my_n,
-                                         part ? sbase : c_first[j], dec_ids + out, dec_fr + out);
-      }
-      cnt = c_eo[g] - c_eo[0];
-      return g;
-    };
-    // the tile's drivers: kHybColdBlocks blocks of list 0
-    uint32_t n_live = 0;
-    {
-      const HybEncList &E0 = A.enc[0];
-      const uint32_t b_first = blockIdx.x * kHybColdBlocks;
-      const uint32_t b_end = b_first + kHybColdBlocks < E0.n_blocks ? b_first + kHybColdBlocks : E0.n_blocks;
-      for (uint32_t cb = b_first; cb < b_end;) {
-        uint32_t cnt;
-        const uint32_t g = decode_group(E0, cb, b_end - cb, n_live, cnt);
-        n_live += cnt;
-        cb += g;
-      }
-    }
-    __syncthreads();
+  uint32_t ps[DPT][NL - 1];  // match position in list l
 #pragma unroll
-    for (int k = 0; k < DPT; k++) {
-      const uint32_t i = k * 256 + threadIdx.x;
-      hit[k] = i < n_live;
-      const uint32_t ic = hit[k] ? i : 0u;
-      xc[k] = (uint32_t)((long long)dec_ids[ic] + A.add[0]);
-      f0[k] = dec_fr[ic];
+  for (int k = 0; k < DPT; k++) {
+    const uint32_t i = i_first + k * 256 + threadIdx.x;
+    hit[k] = i < n0;
+    const uint32_t ic = hit[k] ? i : n0 - 1;  // (unconditional loads)
+    xc[k] = (uint32_t)((long long)ids0[ic] + A.add[0]);
+    // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
+    f0[k] = (A.top_n && A.freq[0]) ? A.freq[0][ic] : 1u;
 #pragma unroll
-      for (int l = 0; l < NL - 1; l++) ps[k][l] = 0;
-    }
-    const uint32_t x_first = (uint32_t)((long long)dec_ids[0] + A.add[0]);
-    const uint32_t x_last = (uint32_t)((long long)dec_ids[n_live ? n_live - 1 : 0] + A.add[0]);
-    RSGPU_HYB_MARK(1);
-    // ---- probe: the blocks of list l that can hold [x_first, x_last], decoded group by group, searched where they sit ----
+    for (int l = 0; l < NL - 1; l++) ps[k][l] = 0;
+  }
+  const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
+  const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
+
+  // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
 #pragma unroll
-    for (int l = 1; l < NL; l++) {
-      if (l < A.n) {
-        const HybEncList &E = A.enc[l];
-        const long long add = A.add[l];
+  for (int l = 1; l < NL; l++) {
+    if (l < A.n) {
+      const uint32_t *__restrict__ a = A.ids[l];
+      const uint32_t nl = A.len[l];
+      const long long add = A.add[l];
+      if (A.dir[l]) {  // bucket directory: both ends in one round trip
         if (threadIdx.x == 0) {
           bool u0, u1;
-          const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_last, add, &u1);
-          const uint32_t sh = E.bdir_shift, dn = E.bdir_n;
-          const uint32_t qf = xf >> sh, qn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);
-          uint32_t lo = E.bdir[qf < dn ? qf : dn - 1], hi = E.bdir[qn];
-          lo = lo ? lo - 1 : 0;  // (the block before may reach into the range)
-          if ((long long)x_last - add < 0 || !n_live) hi = 0;  // every driver lies below the list's frame: nothing matches
-          c_lo = lo;
-          c_hi = hi > lo ? hi : lo;
+          const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
+          const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
+          const uint32_t bf = xf >> sh, bn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);  // (xn = 2^32 - 1 at shift 0 must not wrap)
+          const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
+          w_lo = dlo;
+          w_hi = i_next < n0 ? dhi : nl;
+        }
+      } else if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
+        bool u0;
+        uint32_t rlo, rhi;
+        wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+        if (lane == 0) w_lo = rlo;
+      } else if (wave == 1) {  // its end: at or above lower_bound(first driver of the next tile)
+        bool u1;
+        uint32_t rlo, rhi = nl;
+        if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, add, &u1), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
+        if (lane == 0) w_hi = rhi;
+      }
+      __syncthreads();
+      if (l == 1) RSGPU_HYB_MARK(1);
+      const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi] (up to 64 entries of slack at either end)
+      const uint32_t span = hi - lo;
+      if (span <= WIN) {
+        // the window, eight loads per lane in flight at a time (a load / ds_write loop is serialised by hipcc)
+        for (uint32_t base = 0; base < span; base += 8 * 256) {
+          uint32_t t[8];
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            t[j] = a[lo + (o < span ? o : span - 1)];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + j * 256 + threadIdx.x;
+            if (o < span) win[o] = t[j];
+          }
         }
         __syncthreads();
-        const uint32_t lo = c_lo, hi = c_hi;
-        bool got[DPT];
-#pragma unroll
-        for (int k = 0; k < DPT; k++) got[k] = false;
-        for (uint32_t cb = lo; cb < hi;) {
-          uint32_t cnt;
-          const uint32_t g = decode_group(E, cb, hi - cb < kHybColdBlocks ? hi - cb : kHybColdBlocks, 0u, cnt);
-          cb += g;
-          __syncthreads();
-          uint32_t xl[DPT], b[DPT];  // (the drivers in the list's frame: recomputed per group, not held across the parse)
-          bool under[DPT];
-#pragma unroll
-          for (int k = 0; k < DPT; k++) {
-            xl[k] = to_list_frame(xc[k], add, &under[k]);
-            b[k] = 0;
-          }
-          uint32_t rem = cnt;
-          while (rem > 1) {
-            const uint32_t half = rem >> 1;
-#pragma unroll
-            for (int k = 0; k < DPT; k++) b[k] = dec_ids[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
-            rem -= half;
-          }
-#pragma unroll
-          for (int k = 0; k < DPT; k++) {
-            if (cnt && dec_ids[b[k]] < xl[k]) b[k]++;
-            const bool m = hit[k] && !under[k] && b[k] < cnt && dec_ids[b[k] < cnt ? b[k] : 0] == xl[k];
-            if (m) {
-              ps[k][l - 1] = dec_fr[b[k]];
-              got[k] = true;
-            }
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < DPT; k++) hit[k] = hit[k] && got[k];
         if (l == 1) RSGPU_HYB_MARK(2);
-        __syncthreads();  // c_lo / c_hi and the pool are reused
-      }
-    }
-  } else {
-    const uint32_t n0 = A.len[0];
-    const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
-    const uint32_t *__restrict__ ids0 = A.ids[0];
-
-    RSGPU_HYB_MARK(0);
-    // the first level of the window-end searches in list 1 (64 fixed positions), requested together with the tile's doc ids
-    uint32_t lvl1 = 0;
-    const bool pre1 = A.n > 1 && A.len[1] > 64 && !A.dir[1];
-    if (pre1) {
-      const uint32_t step = (A.len[1] + 63) / 64, p = (lane + 1) * step - 1;
-      lvl1 = A.ids[1][p < A.len[1] ? p : A.len[1] - 1];
-    }
-    if (A.k)  // the query: in flight while the probe runs
-      for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
+        // lower bounds of the lane's four drivers in step: a fixed-length search (the halving sequence depends on the span
+        // alone), one LDS read per driver and step, the four reads of a step independent of each other -- four data-dependent
+        // loops one after the other were 48 dependent LDS round trips
+        uint32_t xl[DPT], b[DPT];
+        bool under[DPT];
 #pragma unroll
-    for (int k = 0; k < DPT; k++) {
-      const uint32_t i = i_first + k * 256 + threadIdx.x;
-      hit[k] = i < n0;
-      const uint32_t ic = hit[k] ? i : n0 - 1;  // (unconditional loads)
-      xc[k] = (uint32_t)((long long)ids0[ic] + A.add[0]);
-      // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
-      f0[k] = (A.top_n && A.freq[0]) ? A.freq[0][ic] : 1u;
-#pragma unroll
-      for (int l = 0; l < NL - 1; l++) ps[k][l] = 0;
-    }
-    const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
-    const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
-
-    // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
-#pragma unroll
-    for (int l = 1; l < NL; l++) {
-      if (l < A.n) {
-        const uint32_t *__restrict__ a = A.ids[l];
-        const uint32_t nl = A.len[l];
-        const long long add = A.add[l];
-        if (A.dir[l]) {  // bucket directory: both ends in one round trip
-          if (threadIdx.x == 0) {
-            bool u0, u1;
-            const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
-            const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
-            const uint32_t bf = xf >> sh, bn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);  // (xn = 2^32 - 1 at shift 0 must not wrap)
-            const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
-            w_lo = dlo;
-            w_hi = i_next < n0 ? dhi : nl;
-          }
-        } else if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
-          bool u0;
-          uint32_t rlo, rhi;
-          wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
-          if (lane == 0) w_lo = rlo;
-        } else if (wave == 1) {  // its end: at or above lower_bound(first driver of the next tile)
-          bool u1;
-          uint32_t rlo, rhi = nl;
-          if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, add, &u1), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
-          if (lane == 0) w_hi = rhi;
+        for (int k = 0; k < DPT; k++) {
+          xl[k] = to_list_frame(xc[k], add, &under[k]);
+          b[k] = 0;
         }
-        __syncthreads();
-        if (l == 1) RSGPU_HYB_MARK(1);
-        const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi] (up to 64 entries of slack at either end)
-        const uint32_t span = hi - lo;
-        if (span <= WIN) {
-          // the window, eight loads per lane in flight at a time (a load / ds_write loop is serialised by hipcc)
-          for (uint32_t base = 0; base < span; base += 8 * 256) {
-            uint32_t t[8];
+        uint32_t rem = span;
+        while (rem > 1) {
+          const uint32_t half = rem >> 1;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const uint32_t o = base + j * 256 + threadIdx.x;
-              t[j] = a[lo + (o < span ? o : span - 1)];
+          for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
+          rem -= half;
+        }
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          if (span && win[b[k]] < xl[k]) b[k]++;
+          const bool m = hit[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
+          ps[k][l - 1] = lo + b[k];
+          hit[k] = m;
+        }
+      } else {  // a window that does not fit (very skewed lists): a binary search in memory, confined to the window
+#pragma unroll
+        for (int k = 0; k < DPT; k++) {
+          bool under;
+          const uint32_t x = to_list_frame(xc[k], add, &under);
+          uint32_t b = lo, e = hi;
+          if (hit[k]) {
+            while (b < e) {
+              const uint32_t mid = b + ((e - b) >> 1);
+              if (a[mid] < x) b = mid + 1;
+              else e = mid;
             }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-              const uint32_t o = base + j * 256 + threadIdx.x;
-              if (o < span) win[o] = t[j];
-            }
-          }
-          __syncthreads();
-          if (l == 1) RSGPU_HYB_MARK(2);
-          // lower bounds of the lane's four drivers in step: a fixed-length search (the halving sequence depends on the span
-          // alone), one LDS read per driver and step, the four reads of a step independent of each other -- four data-dependent
-          // loops one after the other were 48 dependent LDS round trips
-          uint32_t xl[DPT], b[DPT];
-          bool under[DPT];
-#pragma unroll
-          for (int k = 0; k < DPT; k++) {
-            xl[k] = to_list_frame(xc[k], add, &under[k]);
-            b[k] = 0;
-          }
-          uint32_t rem = span;
-          while (rem > 1) {
-            const uint32_t half = rem >> 1;
-#pragma unroll
-            for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
-            rem -= half;
-          }
-#pragma unroll
-          for (int k = 0; k < DPT; k++) {
-            if (span && win[b[k]] < xl[k]) b[k]++;
-            const bool m = hit[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
-            ps[k][l - 1] = lo + b[k];
-            hit[k] = m;
-          }
-        } else {  // a window that does not fit (very skewed lists): a binary search in memory, confined to the window
-#pragma unroll
-          for (int k = 0; k < DPT; k++) {
-            bool under;
-            const uint32_t x = to_list_frame(xc[k], add, &under);
-            uint32_t b = lo, e = hi;
-            if (hit[k]) {
-              while (b < e) {
-                const uint32_t mid = b + ((e - b) >> 1);
-                if (a[mid] < x) b = mid + 1;
-                else e = mid;
-              }
-              ps[k][l - 1] = b;
-              hit[k] = !under && b < nl && a[b] == x;
-            }
+            ps[k][l - 1] = b;
+            hit[k] = !under && b < nl && a[b] == x;
           }
         }
-        __syncthreads();  // win / w_lo / w_hi are reused
       }
+      __syncthreads();  // win / w_lo / w_hi are reused
     }
   }
   {
@@ -626,10 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((COLD != 0 
         double fr[NL];
         fr[0] = (double)rf0[e];
 #pragma unroll
-        for (int l = 1; l < NL; l++) {
-          if constexpr (COLD != 0) fr[l] = l < A.n ? (double)win[(l + 1) * TILE + e] : 1.0;  // (the record holds the frequency itself)
-          else fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
-        }
+        for (int l = 1; l < NL; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
         const long long tid = (long long)x + A.P.table_off;
         const bool known = tid >= 0 && tid < (long long)A.table_n;
         const uint32_t id = known ? (uint32_t)tid : 0u;
@@ -1465,12 +1317,7 @@ void launch_hybrid_tiles(const HybridTileArgs &args, int type, int metric, uint3
   // LDS: the pool -- a window of 4 Ki entries; (lists + 1) record arrays of a tile's hits -- and the KNN query
   a.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
-#define RSGPU_HYB(T, M)                                                                                                      \
-  do {                                                                                                                       \
-    if (a.cold == 1) hipLaunchKernelGGL((hybrid_tile_kernel<T, M, kHybDpt, kHybMaxLists, 1>), dim3(n_tiles), dim3(256), lds + 64, s, a); \
-    else if (a.cold == 2) hipLaunchKernelGGL((hybrid_tile_kernel<T, M, kHybDpt, kHybMaxLists, 2>), dim3(n_tiles), dim3(256), lds + 64, s, a); \
-    else hipLaunchKernelGGL((hybrid_tile_kernel<T, M, kHybDpt, kHybMaxLists>), dim3(n_tiles), dim3(256), lds, s, a);         \
-  } while (0)
+#define RSGPU_HYB(T, M) hipLaunchKernelGGL((hybrid_tile_kernel<T, M, kHybDpt, kHybMaxLists>), dim3(n_tiles), dim3(256), lds, s, a)
   if (!a.k) RSGPU_HYB(KT_F32, KM_IP);  // (no KNN branch: any instantiation)
   else if (type == KT_F32 && metric == KM_L2) RSGPU_HYB(KT_F32, KM_L2);
   else if (type == KT_F32) RSGPU_HYB(KT_F32, KM_IP);

@@ -103,7 +103,6 @@ struct ScanTuning {
   int hybrid_surv_cap = 2048;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)
   int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
   int decode_lean = 1;     // the two-launch hybrid query decodes doc ids + frequencies only (a Full-codec list: 8 of 20 bytes per posting; A/B knob)
-  int hybrid_cold_fused = 0;  // (measured: not faster -- profiles/r05_cold_in_tile_decode_ab.json) decode-per-query mode: the two-launch hybrid query decodes a tile's blocks INSIDE the tile kernel (FreqsOnly / Full lists whose sync points exist; A/B knob)
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM

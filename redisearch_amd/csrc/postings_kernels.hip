@@ -46,8 +46,7 @@ namespace {
 // One kernel per record kind (0 qint, 1 varint delta, 2 raw u32 delta): keeping the three decoders in
 // one body made hipcc (ROCm 7.2) drop the cursor advance of the raw path.
 constexpr uint32_t kDecodeLds = 30 * 1024;  // bytes of encoded input staged per wavefront (5 wavefronts per CU)
-// (kSyncSeg / kSyncPts -- sync points before records 16, 32, .. 112 of a block, kSyncPts + 1 = 8 lanes -- live in postings_ops.hpp:
-// the hybrid tile kernel's in-tile decode shares them)
+constexpr uint32_t kSyncSeg = 16, kSyncPts = 7;  // sync points: before records 16, 32, .. 112 of a block (kSyncPts + 1 = 8 lanes)
 
 // 7-bit groups, most significant first, +1 per continuation (reference varint/src/lib.rs); 128-bit accumulator
 template <typename Bytes>

@@ -357,45 +357,6 @@ __device__ __forceinline__ void prox_load(const ProxParams &P, const View &o, Pr
   }
 }
 
-// ---- qint records parsed out of LDS into LDS (the hybrid tile kernel's in-tile decode, round 5) ----------------------------------
-// sync points: before records 16, 32, .. 112 of a block (kSyncPts + 1 = 8 lanes per block; postings_kernels.hip writes them)
-constexpr uint32_t kSyncSeg = 16, kSyncPts = 7;
-// n records of a qint layout (NF fields; FR / OS = which of fields 1..3 is the frequency / the offsets length, -1 none) starting at
-// byte `pos` of `stage` (4-byte aligned LDS, NF + 2 readable words behind the last record), the record before them had doc id
-// `base`: doc ids to ids[0..n), frequencies to fr[0..n).  The arithmetic of decode_qint_block_lds (postings_kernels.hip): ONE LDS
-// round trip per record (reference qint/src/lib.rs:139-214; inverted_index/src/codec/{freqs_only,full}.rs).
-template <int NF, int FR, int OS>
-__device__ __forceinline__ void qint_records_to_lds(const uint8_t *stage, uint32_t pos, uint32_t fin, uint32_t n, uint32_t base,
-                                                    uint32_t *ids, uint32_t *fr) {
-  for (uint32_t e = 0; e < n && pos < fin; e++) {
-    const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (pos >> 2);
-    uint32_t r[NF + 2];
-#pragma unroll
-    for (int i = 0; i < NF + 2; i++) r[i] = w[i];
-    const uint32_t sh = pos & 3u;
-    uint32_t a[NF + 1];  // the record from its control byte on
-#pragma unroll
-    for (int i = 0; i < NF + 1; i++) a[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sh);
-    const uint32_t hdr = a[0];
-    uint32_t v[NF], o = 1;
-#pragma unroll
-    for (int i = 0; i < NF; i++) {
-      const uint32_t len = ((hdr >> (2 * i)) & 3u) + 1u;
-      uint32_t raw = __builtin_amdgcn_alignbyte(a[1], a[0], o);
-#pragma unroll
-      for (int d = 1; d <= i; d++) raw = (o >> 2) == (uint32_t)d ? __builtin_amdgcn_alignbyte(a[d + 1], a[d], o) : raw;
-      const uint32_t drop = 32u - 8u * len;
-      v[i] = (raw << drop) >> drop;
-      o += len;
-    }
-    pos += o;
-    base += v[0];
-    ids[e] = base;
-    fr[e] = FR >= 0 ? v[FR >= 0 ? FR : 0] : 1u;
-    if (OS >= 0) pos += v[OS >= 0 ? OS : 0];  // (the offsets bytes are hopped over)
-  }
-}
-
 // ---- scorers ---------------------------------------------------------------------------------------
 // One document's score.  F(t): frequency of term column t in this document (fp64); dlen / dscore / mfreq: its doc-table
 // entry (0 when the table does not hold it); slop: IndexResult_MinOffsetDelta of the result.

@@ -229,13 +229,6 @@ struct RSGPU_Postings {
   DevBuf<uint32_t> dir;
   uint32_t dir_shift = 0, dir_n = 0;
   std::atomic<bool> dir_ready{false};
-  // in-tile decode (round 5; lists uploaded in decode-per-query mode whose layout has sync points): a bucket directory over
-  // the BLOCKS' first doc ids -- bdir[q] = number of blocks whose first doc id (relative to base) lies below q << bdir_shift --
-  // built on the host at upload, ~2 buckets per block; the largest block in bytes / entries (the tile kernel's staging limits)
-  DevBuf<uint32_t> bdir;
-  uint32_t bdir_shift = 0, bdir_n = 0;
-  uint64_t max_block_bytes = 0;
-  uint32_t max_nent = 0;
 };
 
 // one node of a hit list's result tree, post-order over its leaf columns (a term: op 0, `leaf`; an aggregate: op 1 union /
@@ -752,30 +745,6 @@ RSGPU_Postings *RSGPU_Postings_Upload(int codec, size_t n_blocks, const uint64_t
     if (cd.osz < 0 || widest + 256 < decode_stage_bytes()) {
       p->sync.alloc(decode_sync_words((uint32_t)n_blocks));
       p->sync_span = (uint32_t)std::min<uint64_t>(widest, 0xFFFFFFFFull);
-    }
-    // the block directory of the in-tile decode (hybrid_tile_kernel<.., COLD>): blocks ascending by first doc id
-    bool ascending = true;
-    for (size_t b = 0; b < n_blocks; b++) {
-      p->max_block_bytes = std::max<uint64_t>(p->max_block_bytes, byte_offset[b + 1] - byte_offset[b]);
-      p->max_nent = std::max(p->max_nent, num_entries[b]);
-      ascending = ascending && (b == 0 || first[b] >= first[b - 1]);
-    }
-    if (p->sync.p && ascending && scan_tuning().hybrid_cold_fused) {
-      const uint64_t rel_last = hi - p->base;
-      uint32_t shift = 0;
-      while (shift < 31 && (rel_last >> shift) + 2 > 2 * (uint64_t)n_blocks + 2) shift++;
-      const uint64_t dn = (rel_last >> shift) + 2;
-      if (dn <= (1ull << 28)) {
-        std::vector<uint32_t> bd((size_t)dn);
-        size_t b = 0;
-        for (uint64_t q = 0; q < dn; q++) {
-          while (b < n_blocks && (uint64_t)first[b] < (q << shift)) b++;
-          bd[(size_t)q] = (uint32_t)b;
-        }
-        p->bdir.upload(bd.data(), (size_t)dn);
-        p->bdir_shift = shift;
-        p->bdir_n = (uint32_t)dn;
-      }
     }
   }
   if (cd.osz >= 0) {
@@ -1524,7 +1493,6 @@ static void fill_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_D
 }
 
 thread_local int tls_hybrid_path = 0;  // how the last RSGPU_HybridQuery of this thread ran: 0 staged, 1 two launches
-thread_local int tls_hybrid_cold = 0;  // ... and whether its tile kernel decoded the lists itself (RSGPU_HybridQueryColdFused)
 
 // The bucket directory of a probed list (see RSGPU_Postings::dir): built on the query's stream right behind the decode, once.
 // Buckets of ~32 postings on average: shift = log2 of (doc-id range / (entries / 32)).
@@ -1747,28 +1715,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return a->lists[x]->n_entries < a->lists[y]->n_entries; });
   if (prof) HIP_CHECK(hipEventRecord(ev.e[0], ca->stream));
-  // Decode-per-query mode (cache_decoded = 0: every first touch of a term in the reference's terms; here every query): lists of
-  // one qint layout with a frequency (FreqsOnly, Full) whose sync points and block directory exist are decoded INSIDE the tile
-  // kernel, a tile's blocks at a time -- the decoded arrays are never written (round 5)
-  int cold = 0;
-  if (!scan_tuning().cache_decoded && scan_tuning().hybrid_cold_fused && scan_tuning().decode_sync) {
-    auto layout = [](const CodecDesc &cd) {
-      if (cd.kind != 0 || cd.wide) return 0;
-      if (cd.n == 2 && cd.freq == 1 && cd.mask < 0 && cd.osz < 0) return 1;
-      if (cd.n == 4 && cd.freq == 1 && cd.mask == 2 && cd.osz == 3) return 2;
-      return 0;
-    };
-    cold = layout(a->lists[0]->cd);
-    for (size_t l = 0; l < n_lists && cold; l++) {
-      const RSGPU_Postings *p = a->lists[l];
-      if (layout(p->cd) != cold || !p->sync.p || !p->sync_ready.load(std::memory_order_acquire) || !p->bdir.p || !p->n_blocks ||
-          p->max_nent > kHybColdMaxNent || p->max_block_bytes + 32 > kHybColdStageBytes)
-        cold = 0;
-    }
-    if (cold && (a->lists[order[0]]->n_blocks + kHybColdBlocks - 1) / kHybColdBlocks > 16384u) cold = 0;
-  }
-  tls_hybrid_cold = cold ? 1 : 0;
-  for (size_t l = 0; l < n_lists && !cold; l++) {
+  for (size_t l = 0; l < n_lists; l++) {
     // (this form reads doc ids and frequencies only: a Full-codec list's masks / offsets index are not decoded for it)
     if (l + 1 < n_lists && decode_pair_on(a->lists[l], a->lists[l + 1], ca, true)) l++;
     else decode_on(a->lists[l], ca, false, true);
@@ -1783,7 +1730,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
   const uint32_t n0 = v.len[0];
   const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;  // (one entry more: hyb_collect)
   const uint32_t top_n = want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, k = want_knn ? (uint32_t)a->k : 0u;
-  const uint32_t n_tiles = cold ? (a->lists[order[0]]->n_blocks + kHybColdBlocks - 1) / kHybColdBlocks : hybrid_tiles(n0);
+  const uint32_t n_tiles = hybrid_tiles(n0);
 
   HybridTileArgs T;
   memset(&T, 0, sizeof T);
@@ -1794,12 +1741,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
     T.len[l] = v.len[l];
     T.add[l] = v.add[l];
   }
-  T.cold = cold;
-  for (int l = 0; l < v.n && cold; l++) {
-    const RSGPU_Postings *pl = a->lists[order[l]];
-    T.enc[l] = HybEncList{pl->bytes.p, pl->byte_off.p, pl->first.p, pl->entry_off.p, pl->sync.p, pl->bdir.p, pl->n_blocks, pl->bdir_shift, pl->bdir_n};
-  }
-  if (scan_tuning().hybrid_dir && !cold)
+  if (scan_tuning().hybrid_dir)
     for (int l = 1; l < v.n; l++) {
       RSGPU_Postings *pl = a->lists[order[l]];
       ensure_bucket_dir(pl, ca);
@@ -3079,7 +3021,6 @@ double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs) {
 }
 
 int RSGPU_HybridQueryPath(void) { return tls_hybrid_path; }
-int RSGPU_HybridQueryColdFused(void) { return tls_hybrid_path == 1 ? tls_hybrid_cold : 0; }
 
 // diagnostics (knob hybrid_trace): the phase clock of every tile of the calling thread's last two-launch query, [tiles][9]
 // readings of the 100 MHz device clock; returns the number of tiles (0: no trace)

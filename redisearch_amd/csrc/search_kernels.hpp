@@ -213,18 +213,6 @@ void launch_dist_to_keys(const float *dists, uint32_t n, uint32_t *keys, hipStre
 // up to ~32; between, more entries pass them (the reduce kernel hands a query with too many back to the exact select)
 constexpr int kHybMaxLists = 4, kHybMaxK = 64, kHybMaxChunks = 512;
 constexpr int kHybTracePhases = 9;  // start | window ends | window staged | probe done | hits compacted | scored | ranked | distances | end
-// In-tile decode (round 5, hybrid_tile_kernel<.., COLD>): one list in its encoded form -- the uploaded block arrays, the sync points
-// the list's first decode left behind, and a bucket directory over the blocks' first doc ids: bdir[q] = number of blocks whose
-// first doc id (relative to the list's base) lies below q << bdir_shift, q < bdir_n, bdir[bdir_n - 1] = n_blocks
-struct HybEncList {
-  const uint8_t *bytes;
-  const uint64_t *byte_off;
-  const uint32_t *first, *entry_off, *sync, *bdir;
-  uint32_t n_blocks, bdir_shift, bdir_n;
-};
-constexpr uint32_t kHybColdBlocks = 10;            // driver blocks per tile (a block: <= kHybColdMaxNent entries)
-constexpr uint32_t kHybColdMaxNent = 102;          // 10 x 102 <= 1 024 slots
-constexpr uint32_t kHybColdStageBytes = 8 * 1024;  // encoded bytes staged at a time (the upper half of the 16 KiB pool)
 struct HybridTileArgs {
   int n;                               // lists
   const uint32_t *ids[kHybMaxLists];   // decoded doc ids (relative to the list's base)
@@ -261,10 +249,6 @@ struct HybridTileArgs {
   uint32_t dir_shift[kHybMaxLists], dir_n[kHybMaxLists];
   const uint2 *len_score;              // NULL, or {doc length, doc score bits} per document: one 8-byte gather per hit for two
   int knn_pipeline;                    // the next step's rows are requested before this step's distances are reduced
-  // round 5: cold queries -- 0: the decoded arrays above; 1 (FreqsOnly layout) / 2 (Full layout): enc[l] decoded inside the tile,
-  // ids / freq / len / dir unused; a tile = kHybColdBlocks consecutive blocks of list 0
-  int cold;
-  HybEncList enc[kHybMaxLists];
 };
 // dir[b] = lower_bound(ids, b << shift), b < dir_n (ids ascending, n > 0; dir_n >= (ids[n - 1] >> shift) + 2)
 void launch_build_bucket_dir(const uint32_t *ids, uint32_t n, uint32_t shift, uint32_t *dir, uint32_t dir_n, hipStream_t s);

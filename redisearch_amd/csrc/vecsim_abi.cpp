@@ -726,7 +726,6 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "hybrid_surv_cap")) scan_tuning().hybrid_surv_cap = value;
   else if (!strcmp(key, "hybrid_trace")) scan_tuning().hybrid_trace = value;
   else if (!strcmp(key, "decode_lean")) scan_tuning().decode_lean = value;
-  else if (!strcmp(key, "hybrid_cold_fused")) scan_tuning().hybrid_cold_fused = value;
   else if (!strcmp(key, "mq16")) scan_tuning().mq16 = value;
   else if (!strcmp(key, "coalesce_shadow8")) scan_tuning().coalesce_shadow8 = value;
   else if (!strcmp(key, "shadow16")) scan_tuning().shadow16 = value;

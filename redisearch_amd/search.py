@@ -47,7 +47,6 @@ ABI = {
     "RSGPU_HybridTreeQuery": (_i, [C.POINTER(TreeQuery), C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridTreeNodesQuery": (_i, [C.POINTER(TreeNode), _sz, C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridQueryPath": (_i, []),
-    "RSGPU_HybridQueryColdFused": (_i, []),
     "RSGPU_HybridTrace": (C.c_long, [_vp, _sz]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
@@ -333,11 +332,6 @@ def hybrid_path():
     """how this thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 staged pipeline, 1 two launches, 2 the general
     tile kernel (hybrid_kernels.hip)"""
     return load().RSGPU_HybridQueryPath()
-
-
-def hybrid_cold_fused():
-    """1: this thread's last two-launch hybrid query decoded its lists inside the tile kernel (RSGPU_HybridQueryColdFused)"""
-    return load().RSGPU_HybridQueryColdFused()
 
 
 def hybrid_trace(max_tiles=1 << 15):

@@ -39,10 +39,6 @@ for qi, (i, j) in enumerate([(0, 2), (1, 3), (0, 3), (1, 2)]):
                              [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10, index=idx, q=qv[qi], k=10))
 for hq in hqs * 3:
     hq.run()
-torch.cuda.synchronize()
-print("warm-up done; in-tile decode of the last query:", S.hybrid_cold_fused(), flush=True)
-if os.environ.get("NO_TRACE"):
-    sys.exit(0)
 lib.RSGPU_SetTuning(b"hybrid_trace", 1)
 names = ["window ends", "window staged", "probe done", "hits compacted", "scored", "ranked + written", "distances", "end"]
 for rep in range(2):
