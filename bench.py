@@ -681,7 +681,8 @@ def _term_list(rng, n_docs, df):
     return docs, freqs, masks, offs
 
 
-def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3, decoded_bpp=8, modes=("warm", "cold")):
+def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=3, decoded_bpp=8, modes=("warm", "cold"),
+                   concurrent_threads=()):
     """A STREAM of distinct queries: n_a x n_b term pairs over independent lists and a query vector of its
     own per query, issued round-robin so that consecutive queries share neither a list nor candidate rows.  One cycle touches
     every list's decoded arrays (240 MB at 4 + 4 lists) and 16 x 77 MB of rows -- several times the 256 MiB Infinity Cache --
@@ -695,12 +696,15 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
         lib.RSGPU_SetTuning(b"cache_decoded", 1 if mode == "warm" else 0)
         lists = [S.Postings.from_flat(e) for e in enc]
         try:
-            hqs = []
-            for qi, (i, j) in enumerate(pairs):
-                dfs = [raws[i][0].size, raws[j][0].size]
-                hqs.append(S.HybridQuery([lists[i], lists[j]], table, "BM25STD", [S.calculate_idf(n_docs, d) for d in dfs],
-                                         [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10, index=idx,
-                                         q=qvecs[qi], k=10))
+            def make_queries():
+                qq = []
+                for qi, (i, j) in enumerate(pairs):
+                    dfs = [raws[i][0].size, raws[j][0].size]
+                    qq.append(S.HybridQuery([lists[i], lists[j]], table, "BM25STD", [S.calculate_idf(n_docs, d) for d in dfs],
+                                            [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10, index=idx,
+                                            q=qvecs[qi], k=10))
+                return qq
+            hqs = make_queries()
             res = []
             for hq in hqs:   # untimed first cycle: allocations, and (warm) every list's one decode
                 hq.run()
@@ -730,6 +734,40 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                    "device_ms": {"tile_kernel": tile, "reduce_kernel": red, "decode": dec} if path in (1, 2) else
                                 {k_: float(np.mean([x.get(k_) or 0.0 for x in prof])) for k_ in ("intersect_ms", "score_ms", "topn_ms", "knn_ms")},
                    "same_answers_every_cycle": bool(same)}
+            if mode == "warm" and concurrent_threads:
+                # the reference runs its hybrid iterators on worker threads (src/util/workers.c:58,104): the same stream from
+                # T threads at once -- every thread its own argument blocks and device scratch, the lists / table / index shared
+                import threading
+                conc = {}
+                for nt in concurrent_threads:
+                    sets = [make_queries() for _ in range(nt)]
+                    gate, ok, span = threading.Barrier(nt + 1), [True] * nt, [0.0, 0.0]
+
+                    def work(t, sets=sets, gate=gate, ok=ok):
+                        for hq in sets[t]:          # untimed: this thread's scratch and streams
+                            hq.run()
+                        gate.wait()
+                        for _ in range(cycles):
+                            for q_, hq in enumerate(sets[t]):
+                                hq.run()
+                        gate.wait()
+                        for q_, hq in enumerate(sets[t]):
+                            r = hq.results()
+                            ok[t] = ok[t] and r["n_hits"] == res[q_]["n_hits"] and r["top"][0].tolist() == res[q_]["top"][0].tolist() and \
+                                r["top"][1].tolist() == res[q_]["top"][1].tolist() and r["knn"][0].tolist() == res[q_]["knn"][0].tolist()
+                    ths = [threading.Thread(target=work, args=(t,)) for t in range(nt)]
+                    for th in ths:
+                        th.start()
+                    gate.wait()
+                    t0 = time.perf_counter()
+                    gate.wait()
+                    t1 = time.perf_counter()
+                    for th in ths:
+                        th.join()
+                    conc["%d_threads" % nt] = {"qps": nt * cycles * len(pairs) / (t1 - t0), "queries": nt * cycles * len(pairs),
+                                               "same_answers_as_serial": bool(all(ok))}
+                    del sets
+                rec["concurrent_callers"] = conc
             if mode == "warm":
                 answers = res
                 # algorithmic bytes of the tile kernel, per query: 4 B per decoded posting of both lists + 12 B per hit
@@ -895,7 +933,7 @@ def extra_hybrid(lib, V, n_docs=50_000_000, n_vec=5_000_000, dim=768, n_a=4, n_b
         enc_full = [encode_full(d, f, m, o) for d, f, m, o in raws]
         gen_s = time.perf_counter() - t0
         qvecs = philox_host_rows(V, QUERY_BASE + 100, n_a * n_b, dim)
-        fo, ans_fo, pairs = _hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a)
+        fo, ans_fo, pairs = _hybrid_stream(lib, S, enc_fo, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, concurrent_threads=(2, 4, 8, 16))
         full, ans_full, _ = _hybrid_stream(lib, S, enc_full, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, decoded_bpp=20)
         codec_same = all(a["top"][0].tolist() == b_["top"][0].tolist() and a["top"][1].tolist() == b_["top"][1].tolist()
                          and a["knn"][0].tolist() == b_["knn"][0].tolist() and a["n_hits"] == b_["n_hits"] for a, b_ in zip(ans_fo, ans_full))

@@ -51,7 +51,7 @@ for name, knobs in CONFIGS:
     for key, val in knobs.items():
         assert lib.RSGPU_SetTuning(key.encode(), val) == 0, key
     rec, ans, pairs = B._hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim, n_a, cycles=int(os.environ.get("CYCLES", 4)),
-                                       modes=modes)
+                                       modes=modes, concurrent_threads=tuple(int(x) for x in os.environ.get("THREADS", "").split(",") if x))
     if ref is None:
         ref = ans
     same = all(a["top"][0].tolist() == b["top"][0].tolist() and a["top"][1].tolist() == b["top"][1].tolist() and
@@ -60,6 +60,8 @@ for name, knobs in CONFIGS:
     out[name] = {"knobs": {k: v for k, v in knobs.items() if v != DEFAULTS[k]}, "warm_p50": rec["warm"]["wall_ms_p50"], "warm_p95": rec["warm"]["wall_ms_p95"],
                  "warm_dev": rec["warm"]["device_ms"], "tile_hbm_frac": rec["warm"].get("tile_kernel_hbm_frac"),
                  "tile_plus_reduce_hbm_frac": rec["warm"].get("tile_plus_reduce_hbm_frac"), "same_answers_as_first_config": bool(same)}
+    if "concurrent_callers" in rec["warm"]:
+        out[name]["concurrent_callers"] = rec["warm"]["concurrent_callers"]
     if "cold" in rec:
         out[name].update({"cold_p50": rec["cold"]["wall_ms_p50"], "cold_dev": rec["cold"]["device_ms"],
                           "cold_decode_gbs": rec["cold"].get("decode_gbs_of_encoded_bytes")})
