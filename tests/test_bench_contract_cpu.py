@@ -125,3 +125,44 @@ def test_bench_imports_the_oracle_only_in_its_cpu_leg():
     top = [n for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
     assert not any(getattr(n, "module", None) == "oracle" or any(al.name == "oracle" for al in getattr(n, "names", [])) for n in top)
     assert users <= allowed, users
+
+
+def test_line_fits():
+    """The driver's capture lost round 5's 21.8 KB line: whatever the sub-records hold, the ONE stdout line stays below 8 KB
+    and still carries the contract keys, `roofline` and `cpu_baseline`; the full record goes to a side file."""
+    import json
+    b = load_bench([])
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_1gpu_driver_args.json")))   # a real full record (21 KB)
+    assert len(json.dumps(full)) > 20_000
+    line = b.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 8192, len(text)
+    assert "\n" not in text
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "summary"):
+        assert key in line, key
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"] and line["dtype"] == "f32"
+    assert line["config"]["workload"].startswith("10000000x768 fp32 FLAT COSINE top-10")
+    assert line["config"]["verify"]["ok"] is True
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert line["roofline"][key] == full["roofline"][key]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"]
+    assert line["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    s = line["summary"]
+    assert s["cfg3_f16"]["device_ms_per_pass"] > 0 and s["cfg3_f16"]["bit_identical"] is True
+    assert s["cfg5_hybrid"]["warm_p50_ms"] > 0 and s["cfg5_hybrid"]["parity_ok"] is True
+    assert s["callers"]["qps_64"] > 10_000
+
+    def only_scalars(o, depth=0):
+        assert depth <= 2
+        for v in o.values():
+            if isinstance(v, dict):
+                only_scalars(v, depth + 1)
+            else:
+                assert v is None or isinstance(v, (int, float, bool, str)), v
+    only_scalars(s)
+    # an absurd sub-record cannot push the line over the limit either
+    bloated = json.loads(json.dumps(full))
+    bloated["config"]["concurrent_callers"].update({"%d_threads" % (100 + i): {"qps": 1.0 + i} for i in range(2000)})
+    assert len(json.dumps(b.compact_line(bloated))) < 8192
