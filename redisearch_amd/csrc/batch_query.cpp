@@ -150,9 +150,13 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                           gemm_qs_supported((uint32_t)(sstride_ / 16)) && batch_rescore_supported((uint32_t)(stride_ / 16));
   // int8 rows with one index-wide scale (FLOAT16 indexes: shadow_ == 3; FLOAT32 indexes created with shadow8: next to
   // their per-row shadow): the filter passes of the batch run on the int8 matrix cores
-  const bool s8g_shape = s8g_enabled() && metric != VecSimMetric_L2 && !multi && k > 0 && k <= 1024 && scan_tuning().two_stage &&
-                         scan_tuning().gemm_qs && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) &&
-                         s8g_stride() / 16 <= 64 &&  // (int8 rows up to 1024 bytes)
+  // (round 6, h8_: FLOAT16 indexes WITHOUT the stored shadow take the same int8 passes over their fp16 rows, quantised in flight --
+  // launch_gemm_qs_h8; the "two_stage" switch belongs to the stored shadows, "gemm_qs_h8" to this form)
+  const bool h8 = h8_ && scan_tuning().gemm_qs_h8 != 0;
+  const bool s8g_shape = s8g_enabled() && metric != VecSimMetric_L2 && !multi && k > 0 && k <= 1024 && scan_tuning().gemm_qs &&
+                         (h8_ ? h8 && gemm_qs_h8_supported((uint32_t)(stride_ / 16))
+                              : scan_tuning().two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) &&
+                                    s8g_stride() / 16 <= 64) &&  // (int8 rows up to 1024 bytes)
                          batch_rescore_supported((uint32_t)(stride_ / 16));
   // FLOAT16 / BFLOAT16 L2 indexes (round 3): the passes compute x.q on the matrix cores and fold the rows' half norms in
   // (2 (|q|^2/2 + |x|^2/2 - x.q), gemm_qs_kernels.hip "L2"); every bound is widened by the summation-order band and the
@@ -275,7 +279,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     }
     // the corpus the MFMA passes read
     const int g_type = via_shadow ? KT_F16 : (via_shadow8 ? KT_I8 : ktype);  // (via_f32: KT_F32 rows, launch_gemm_qs_f32)
-    const size_t g_stride = via_shadow ? sstride_ : (via_shadow8 ? s8g_stride() : stride_);
+    const size_t g_stride = via_shadow ? sstride_ : (via_shadow8 && !h8 ? s8g_stride() : stride_);
     if (!n) {
       for (size_t qi = 0; qi < n_queries; qi++) counts_out[qi] = 0;
       return;
@@ -479,6 +483,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
             const uint32_t e = phase_end[ph];
             if (!(via_f32 ? launch_gemm_qs_f32(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
                                                c->stream, l2_hn, l2_hq)
+                  : via_shadow8 && h8
+                      ? launch_gemm_qs_h8(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap, c->stream,
+                                          qscale, h8_inv_bits_)
                           : launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
                                            c->stream, qscale, l2_hn, l2_hq)))
               throw std::runtime_error("batched pass: the matrix-core kernel refused a row shape the route was gated on");
@@ -524,7 +531,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
           ScanProfile &pf = scan_profile();
           pf.launches++;
-          pf.bytes += (uint64_t)n * (via_shadow ? dim * 2 : (via_shadow8 ? dim : elem_bytes_));
+          pf.bytes += (uint64_t)n * (via_shadow ? dim * 2 : (via_shadow8 && !h8 ? dim : elem_bytes_));
           pf.nanos += (uint64_t)((double)ms * 1e6);
         }
       }

@@ -306,6 +306,10 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   // (BFLOAT16 the same way since round 3: tests/test_gpu_batch_i8_shadow.py)
   if ((type == VecSimType_FLOAT16 || type == VecSimType_BFLOAT16) && !multi && metric != VecSimMetric_L2 && scan_tuning().shadow8)
     shadow_ = 3;
+  // ... and WITHOUT the knob (round 6): the same int8 passes over the fp16 rows themselves, quantised in flight -- nothing stored
+  if (type == VecSimType_FLOAT16 && !multi && metric != VecSimMetric_L2 && !shadow_ && scan_tuning().gemm_qs_h8 &&
+      gemm_qs_h8_supported((uint32_t)(stride_ / 16)))
+    h8_ = true;
   sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ >= 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
@@ -317,7 +321,7 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
     HIP_CHECK(hipMalloc((void **)&d_smax_, 4 * sizeof(uint32_t)));
     HIP_CHECK(hipMemset(d_smax_, 0, 4 * sizeof(uint32_t)));
   }
-  if (shadow_ == 3 || (shadow_ == 2 && metric != VecSimMetric_L2)) {  // (FLOAT16, or FLOAT32 next to its per-row shadow)
+  if (shadow_ == 3 || h8_ || (shadow_ == 2 && metric != VecSimMetric_L2)) {  // (FLOAT16, or FLOAT32 next to its per-row shadow)
     HIP_CHECK(hipMalloc((void **)&d_s8g_stats_, 4 * sizeof(uint32_t)));
     HIP_CHECK(hipMemset(d_s8g_stats_, 0, 4 * sizeof(uint32_t)));
   }
@@ -454,7 +458,7 @@ bool FlatIndex::ensure_shadow8g() {
   if (!n) return false;
   s8g_built_ = std::min(s8g_built_, n);
   s8g_seen_ = std::min(s8g_seen_, n);
-  if (shadow_ != 3 && (size_t)n + 32 > s8g_f32_cap_rows_) {  // FLOAT32: the int8 rows live in their own allocation
+  if (shadow_ != 3 && !h8_ && (size_t)n + 32 > s8g_f32_cap_rows_) {  // FLOAT32: the int8 rows live in their own allocation
     if (d_s8g_f32_) HIP_IGNORE(hipFree(d_s8g_f32_));
     d_s8g_f32_ = nullptr;
     s8g_f32_cap_rows_ = 0;
@@ -476,12 +480,30 @@ bool FlatIndex::ensure_shadow8g() {
     s_bad_ = true;
     return false;
   }
-  const float want = gmax > 0.0f ? gmax / 127.0f : 1.0f;
+  float want = gmax > 0.0f ? gmax / 127.0f : 1.0f;
+  uint16_t inv_bits = 0;
+  if (h8_) {  // the scale of the in-flight quantiser is 1 / inv, inv = the largest fp16 <= 127 / max |x_i| (h8_quant.hpp)
+    const float target = gmax > 0.0f ? std::min(127.0f / gmax, 65504.0f) : 127.0f;
+    _Float16 inv = (_Float16)target;
+    memcpy(&inv_bits, &inv, 2);
+    if ((float)inv > target) {  // rounded up: one fp16 step down (positive finite: the bit pattern orders like the value)
+      inv_bits--;
+      memcpy(&inv, &inv_bits, 2);
+    }
+    want = 1.0f / (float)inv;
+  }
   if (!(s8g_scale_ > 0.0f) || want > s8g_scale_) {  // first build, or a row outgrew the scale: every row again
     s8g_scale_ = want;
+    h8_inv_bits_ = inv_bits;
     s8g_built_ = 0;
     const uint32_t zero2[2] = {0, 0};  // the error maxima belong to the scale
     HIP_CHECK(hipMemcpyAsync(d_s8g_stats_ + 1, zero2, sizeof zero2, hipMemcpyHostToDevice, wstream_));
+  }
+  if (s8g_built_ < n && h8_) {  // nothing to store: the maxima of the rows not covered yet
+    launch_h8_stats(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, h8_inv_bits_, d_s8g_stats_, wstream_);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(wstream_));
+    s8g_built_ = n;
   }
   if (s8g_built_ < n) {
     launch_shadow8g_rows(ktype, d_rows_, stride_, (uint32_t)dim, s8g_built_, n, s8g_scale_, const_cast<uint8_t *>(s8g_rows()),
@@ -627,7 +649,8 @@ int FlatIndex::remove(size_t label) {
       HIP_CHECK(hipMemcpyAsync(d_rows_ + (size_t)r * stride_, d_rows_ + (size_t)last * stride_, stride_,
                                hipMemcpyDeviceToDevice, wstream_));
       HIP_CHECK(hipMemcpyAsync(d_labels_ + r, d_labels_ + last, sizeof(uint64_t), hipMemcpyDeviceToDevice, wstream_));
-      if (s8g_enabled()) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
+      if (s8g_enabled() && !h8_) s8g_built_ = std::min(s8g_built_, r);  // rows from r on are quantised again on demand
+      // (h8_: nothing is stored per row and the maxima do not care where a row lies)
       hn_built_ = std::min(hn_built_, r);                        // ... and their half norms recomputed
       if (shadow_ && shadow_ != 3)
         HIP_CHECK(hipMemcpyAsync(d_shadow_ + (size_t)r * sstride_, d_shadow_ + (size_t)last * sstride_, sstride_,

@@ -288,8 +288,13 @@ class FlatIndex {
   // index-wide-scale int8 rows for THEIR batched queries, in a buffer of their own (d_s8g_f32_), built on demand.
   uint8_t *d_s8g_f32_ = nullptr;
   size_t s8g_f32_cap_rows_ = 0;
+  // h8_ (round 6): FLOAT16 IP / cosine indexes WITHOUT the stored shadow -- the batched pass quantises the fp16 rows to int8 in
+  // flight (h8_quant.hpp, gemm_qs_f32_kernel<.., SRC_H8>); only the four index-wide numbers of d_s8g_stats_ exist, taken under
+  // the fp16 inverse scale h8_inv_bits_ (s8g_scale_ = 1 / float(inv)).  Everything else of the int8 route is shared.
+  bool h8_ = false;
+  uint16_t h8_inv_bits_ = 0;
   bool s8g_enabled() const { return d_s8g_stats_ != nullptr; }
-  const uint8_t *s8g_rows() const { return shadow_ == 3 ? d_shadow_ : d_s8g_f32_; }
+  const uint8_t *s8g_rows() const { return shadow_ == 3 ? d_shadow_ : (h8_ ? d_rows_ : d_s8g_f32_); }
   size_t s8g_stride() const { return round_up(dim, 16); }
   uint32_t *d_s8g_stats_ = nullptr;  // {max |x_i| (f32 bits), max |x8|^2, max |ex|^2 (f32 bits), non-finite flag}
   float s8g_scale_ = 0.0f;           // the scale the built rows were quantised with (0: nothing built)

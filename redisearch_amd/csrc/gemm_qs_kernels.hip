@@ -37,6 +37,7 @@
 // MFMA + LDS + 3.6 TB/s HBM load (power), which is what now bounds it.
 #include <hip/hip_runtime.h>
 
+#include "h8_quant.hpp"
 #include "kernels.hpp"
 
 namespace rsgpu {
@@ -96,6 +97,7 @@ struct QsArgs {
   const float *qscale;  // KT_I8: [256] distance = 1 - qscale[q] * (integer dot); row scale x query scale
   const float *hnorm;   // L2: |x|^2 / 2 per corpus row (readable up to row_end + 95), else unused
   const float *hq;      // L2: [256] |q|^2 / 2
+  uint32_t inv_h2;      // SRC_H8 (fp16 rows quantised in flight, h8_quant.hpp): the fp16 inverse scale, twice
 };
 
 // same for a wave-uniform value: pinned to an SGPR (otherwise kernel arguments and gridDim are re-loaded with
@@ -448,9 +450,17 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(uint32_t a, uint32_t b) {
   return r;
 }
 
-template <int KS, int KH, int NS, int QB, bool L2>
+// SRC_H8 (round 6): the SAME kernel over FLOAT16 rows, quantised to int8 on their way from LDS to the int8 matrix pipe
+// (h8_quant.hpp: one v_pk_fma_f16 per two elements, one v_perm_b32 per four) -- a k-step is 32 elements = the same 64 bytes
+// of a row, the ring / DMA / fragment geometry is the fp32 form's at half the dim, the instruction is v_mfma_i32_32x32x32_i8
+// (half the matrix-pipe cycles of the fp16 form per row, which at configs[2] is what the chip's power budget pays for) and
+// the filter is the int8 pass's integer compare.  Nothing is stored next to the index but four index-wide numbers.
+enum : int { SRC_F32 = 0, SRC_H8 = 1 };
+template <int KS, int KH, int NS, int QB, bool L2, int SRC = SRC_F32>
 __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
   static_assert(KS % KH == 0, "a tile is a whole number of K parts");
+  static_assert(SRC == SRC_F32 || !L2, "the int8 form has no L2 epilogue");
+  constexpr int ADT = SRC == SRC_H8 ? KT_I8 : KT_BF16;  // the matrix instruction's operand type
   constexpr int NW = 8 / QB;          // waves per workgroup
   constexpr int NPART = KS / KH;      // ring slots per 32-row tile
   constexpr int RC = 4 * KH;          // 16-byte chunks per slot row (fp32: four per k-step)
@@ -479,6 +489,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
       if (nb * KS + ks < NA) asm volatile("" : "+a"(Q[nb][ks]));
     }
   float tau[QB], thr[QB], qsc[QB];
+  int ithr[QB];  // SRC_H8 only
   uint32_t cur[QB];
 #pragma unroll
   for (int nb = 0; nb < QB; nb++) {
@@ -493,7 +504,15 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
       mag = fabsf(qsc[nb]) + fabsf(0.5f * tau[nb]) + fabsf(u);
     }
     thr[nb] = tau[nb] == -__builtin_inff() ? __builtin_inff() : (tau[nb] == __builtin_inff() ? -__builtin_inff() : u - mag * 2.4e-7f);
+    ithr[nb] = 0x7fffffff;
+    if constexpr (SRC == SRC_H8) {  // the int8 pass's test on the integer dot product (gemm_qs_kernel, KT_I8)
+      qsc[nb] = g.qscale[32 * QB * w + 32 * nb + r];
+      const float lim = thr[nb] / qsc[nb] - 1.0f - fabsf(thr[nb] / qsc[nb]) * 2.4e-7f;
+      ithr[nb] = !(qsc[nb] > 0.0f) || thr[nb] == __builtin_inff() || lim >= 2147483520.0f ? 0x7fffffff
+                 : (lim <= -2147483520.0f ? (int)0x80000000 : (int)floorf(lim));
+    }
   }
+  const uint32_t inv2 = opaque_s(g.inv_h2);
 
   const uint32_t n = g.row_end - g.row_begin;
   const uint32_t n_tiles = (n + 31) / 32;
@@ -547,7 +566,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
     }
   uint32_t stage = 0;
   for (uint32_t i = 0; i < mine; i++) {
-    typename AccT<KT_BF16>::t acc[QB];
+    typename AccT<ADT>::t acc[QB];
 #pragma unroll
     for (int e = 0; e < 16; e++)
 #pragma unroll
@@ -601,12 +620,19 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
         wait_lgkm(2 * ahead);
         __builtin_amdgcn_sched_barrier(0);
         u4 f;
-        f[0] = cvt_pk_bf16(xa[ksl % PF][0], xa[ksl % PF][1]);
-        f[1] = cvt_pk_bf16(xa[ksl % PF][2], xa[ksl % PF][3]);
-        f[2] = cvt_pk_bf16(xb[ksl % PF][0], xb[ksl % PF][1]);
-        f[3] = cvt_pk_bf16(xb[ksl % PF][2], xb[ksl % PF][3]);
+        if constexpr (SRC == SRC_H8) {  // 16 fp16 of the row -> 16 int8 (element order kept: the queries' int8 rows are plain)
+          f[0] = h8_pack4(h8_quant2(xa[ksl % PF][0], inv2), h8_quant2(xa[ksl % PF][1], inv2));
+          f[1] = h8_pack4(h8_quant2(xa[ksl % PF][2], inv2), h8_quant2(xa[ksl % PF][3], inv2));
+          f[2] = h8_pack4(h8_quant2(xb[ksl % PF][0], inv2), h8_quant2(xb[ksl % PF][1], inv2));
+          f[3] = h8_pack4(h8_quant2(xb[ksl % PF][2], inv2), h8_quant2(xb[ksl % PF][3], inv2));
+        } else {
+          f[0] = cvt_pk_bf16(xa[ksl % PF][0], xa[ksl % PF][1]);
+          f[1] = cvt_pk_bf16(xa[ksl % PF][2], xa[ksl % PF][3]);
+          f[2] = cvt_pk_bf16(xb[ksl % PF][0], xb[ksl % PF][1]);
+          f[3] = cvt_pk_bf16(xb[ksl % PF][2], xb[ksl % PF][3]);
+        }
 #pragma unroll
-        for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<KT_BF16>(f, Q[nb][part * KH + ksl], acc[nb]);
+        for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<ADT>(f, Q[nb][part * KH + ksl], acc[nb]);
         __builtin_amdgcn_sched_barrier(0);
         if (ksl + PF < KH) {
           xa[ksl % PF] = lds_read16(frag_addr(ksl + PF, 0), (ksl + PF) >> 2);
@@ -639,24 +665,219 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
     const uint32_t xr0 = row_first + i * row_step + 4 * (lr >> 5);
 #pragma unroll
     for (int nb = 0; nb < QB; nb++) {
-      float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+      if constexpr (SRC == SRC_H8) {  // the int8 pass's epilogue (gemm_qs_kernel, KT_I8)
+        int m = max3i(acc[nb][0], acc[nb][1], acc[nb][2]);
 #pragma unroll
-      for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
-      m = max3(m, acc[nb][15], acc[nb][15]);
-      if (m >= thr[nb]) {
-        uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+        for (int e = 3; e < 15; e += 2) m = max3i(m, acc[nb][e], acc[nb][e + 1]);
+        m = max3i(m, acc[nb][15], acc[nb][15]);
+        if (m >= ithr[nb]) {
+          uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+#pragma unroll
+          for (int eg = 0; eg < 4; eg++) {
+            const int gm = max3i(max3i(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+            if (gm >= ithr[nb]) {
+#pragma unroll
+              for (int el = 0; el < 4; el++) {
+                const float d = 1.0f - qsc[nb] * (float)acc[nb][4 * eg + el];
+                const uint32_t xr = xr0 + 8 * eg + el;
+                if (acc[nb][4 * eg + el] >= ithr[nb] && d <= tau[nb] && xr < row_end) {
+                  if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                  cur[nb]++;
+                }
+              }
+            }
+          }
+        }
+      } else {
+        float m = max3(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+        for (int e = 3; e < 15; e += 2) m = max3(m, acc[nb][e], acc[nb][e + 1]);
+        m = max3(m, acc[nb][15], acc[nb][15]);
+        if (m >= thr[nb]) {
+          uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + (lr & 31u)) * 2 + (lr >> 5)) * g.sub_cap);
+#pragma unroll
+          for (int eg = 0; eg < 4; eg++) {
+            const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+            if (gm >= thr[nb]) {
+#pragma unroll
+              for (int el = 0; el < 4; el++) {
+                const float d = L2 ? 2.0f * (qsc[nb] - acc[nb][4 * eg + el]) : 1.0f - acc[nb][4 * eg + el];
+                const uint32_t xr = xr0 + 8 * eg + el;
+                // (the test on the accumulator IS the filter -- a superset of d <= tau by the margin in thr, which is all a
+                // filter pass owes: the survivors are re-scored; tau itself is not kept in a register)
+                if (acc[nb][4 * eg + el] >= thr[nb] && xr < row_end) {
+                  if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+                  cur[nb]++;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+    g.sub_count[((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + r) * 2 + h] = cur[nb];
+}
+
+// ---- FLOAT16 rows -> int8 ONCE per workgroup, register-staged (round 6, gemm_qs_h8=5/6) ---------------------------------------
+// gemm_qs_f32_kernel<.., SRC_H8> quantises every fragment in every wave: 12 VALU per k-step per wave, 436 VALU per tile and wave --
+// its waves spend half their cycles issuing and a third parked at the per-slot barrier (profiles/r06_batch_qs_pmc_h8.json).  Here a
+// 32-row tile is quantised ONCE: the fp16 chunks travel global -> REGISTERS (plain nontemporal 16-byte loads, D tiles in flight per
+// thread: the registers are the ring), each thread turns its chunks into 8 int8 bytes (4 v_pk_fma_f16 + 2 v_perm_b32, h8_quant.hpp)
+// and stores them into a double-buffered int8 tile in LDS (24 KiB at dim 768, rows XOR-swizzled as everywhere in this file); every
+// wave then reads plain int8 fragments -- one ds_read_b128 per matrix instruction, no VALU in the matrix stream -- against its
+// register-stationary int8 queries.  One barrier per tile; eight waves (two per SIMD) so that one wave's barrier / memory waits are the
+// other's matrix time.  LDS traffic per tile: 24 KiB written + NW x 24 KiB read (the DMA form: 48 written + NW x 48 read).
+template <int KS, int QB, int D>
+__global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
+  constexpr int NW = 8 / QB, NT = 64 * NW;
+  constexpr int FC = 4 * KS;             // fp16 chunks per row
+  constexpr int CPT = 32 * FC / NT;      // chunks per thread and tile
+  static_assert(CPT * NT == 32 * FC, "a tile is a whole number of chunks per thread");
+  constexpr int RS = (2 * KS + 15) / 16 * 16;  // int8 row stride in 16-byte chunks (the swizzle needs whole groups of 16)
+  constexpr int TILE = 32 * RS;                // chunks per int8 tile
+  __shared__ u4 smem[2 * TILE];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t r = lane & 31, h = lane >> 5;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)smem;
+
+  u4 Q[QB][KS];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) Q[nb][ks] = g.queries[(size_t)(32 * QB * w + 32 * nb + r) * (2 * KS) + 2 * ks + h];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++)
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) asm volatile("" : "+a"(Q[nb][ks]));  // B operands straight from the accumulation registers
+  float tau[QB], qsc[QB];
+  int ithr[QB];
+  uint32_t cur[QB];
+#pragma unroll
+  for (int nb = 0; nb < QB; nb++) {
+    cur[nb] = 0;
+    tau[nb] = g.tau[32 * QB * w + 32 * nb + r];
+    const float u = 1.0f - tau[nb], mag = fabsf(tau[nb]) + fabsf(u);
+    const float thr = tau[nb] == -__builtin_inff() ? __builtin_inff() : (tau[nb] == __builtin_inff() ? -__builtin_inff() : u - mag * 2.4e-7f);
+    qsc[nb] = g.qscale[32 * QB * w + 32 * nb + r];
+    const float lim = thr / qsc[nb] - 1.0f - fabsf(thr / qsc[nb]) * 2.4e-7f;
+    ithr[nb] = !(qsc[nb] > 0.0f) || thr == __builtin_inff() || lim >= 2147483520.0f ? 0x7fffffff
+               : (lim <= -2147483520.0f ? (int)0x80000000 : (int)floorf(lim));
+  }
+  const uint32_t inv2 = g.inv_h2;
+
+  const uint32_t n = g.row_end - g.row_begin;
+  const uint32_t n_tiles = (n + 31) / 32;
+  const uint32_t mine = n_tiles > blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const uint32_t row_first = g.row_begin + blockIdx.x * 32, row_step = gridDim.x * 32, row_end = g.row_end;
+
+  // chunk c = tid + NT j of a tile: row c / FC, fp16 chunk c % FC -> the 8 bytes at int8 chunk (cc / 2) ^ (row & 15), half cc & 1
+  uint32_t woff[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; j++) {
+    const uint32_t c = tid + NT * j, rr = c / FC, cc = c - rr * FC;
+    woff[j] = 16u * (rr * RS + ((cc >> 1) ^ (rr & 15u))) + 8u * (cc & 1u);
+  }
+  // (a ragged last tile reads up to 31 rows past row_end: allocated by the launch_gemm_qs contract, multiplied, never emitted)
+  auto tile_src = [&](uint32_t i) { return g.rows + (size_t)(row_first + i * row_step) * FC + tid; };
+  auto quant_store = [&](const u4 &x, uint32_t buf, int j) {
+    const uint32_t t0 = h8_quant2(x[0], inv2), t1 = h8_quant2(x[1], inv2), t2 = h8_quant2(x[2], inv2), t3 = h8_quant2(x[3], inv2);
+    *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(smem) + buf * (TILE * 16) + woff[j]) = make_uint2(h8_pack4(t0, t1), h8_pack4(t2, t3));
+  };
+
+  // The ring: tiles i+1 .. i+D of this workgroup, on their way from HBM.  Loads and their waits are inline asm: hipcc's own
+  // vmcnt bookkeeping allowed CPT - 1 loads in flight where D CPT - 1 are (it drained a whole register set per chunk: 3.35 ms
+  // per pass against 2.9 with the counts below).  ld() requests, use() returns the register once only the D CPT - 1 requests
+  // issued after it may still be outstanding -- requests retire in order; the candidate stores of the epilogue (asm as well)
+  // can only make the wait conservative.  The "+v" operand ties every consumer to its wait.
+  u4 R[D][CPT];
+  auto ld = [&](u4 &dst, const u4 *src) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(src) : "memory"); };
+  auto use = [&](u4 &reg) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(D * CPT - 1) : "memory"); };
+  // prologue: tile 0 straight through, tiles 1 .. D requested (a workgroup with fewer tiles re-reads its last one)
+  if (mine) {
+    const u4 *src = tile_src(0);
+#pragma unroll
+    for (int j = 0; j < CPT; j++) ld(R[0][j], src + NT * j);
+#pragma unroll
+    for (int j = 0; j < CPT; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0][j])::"memory");
+#pragma unroll
+    for (int j = 0; j < CPT; j++) quant_store(R[0][j], 0, j);
+  }
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    const u4 *src = tile_src((uint32_t)(1 + d) < mine ? 1 + d : (mine ? mine - 1 : 0));
+#pragma unroll
+    for (int j = 0; j < CPT; j++) ld(R[d][j], src + NT * j);
+  }
+  // (drained once, here: hipcc may MOVE the ring's registers between this prologue and the loop -- it believes they hold their
+  // values since the asm -- and a register copied while its load is in flight carries the old bits: tiles 1 .. D went wrong)
+  // (no register operands: tying all D CPT registers to one statement cost 19 spills -- of in-flight registers -- at dim 768)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const uint32_t t16 = 16u * (h ^ (r & 15u));
+  // one tile: matrix stream over buffer i & 1; the registers of set d (tile i + 1) are quantised into buffer (i + 1) & 1 and
+  // re-requested (tile i + 1 + D) inside it
+  auto step = [&](uint32_t i, u4 (&regs)[CPT]) {
+    const uint32_t buf = i & 1u;
+    const uint32_t tbase = lds_base + 16u * (buf * TILE + r * RS);
+    const u4 *src = tile_src(i + 1 + D < mine ? i + 1 + D : i);
+    typename AccT<KT_I8>::t acc[QB];
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++) acc[nb][e] = 0;
+    // (accumulators pinned to the accumulation registers: with everything in VGPRs hipcc let the first matrix instruction of a
+    // tile write v[0:15] while reading its A fragment from v[0:3] -- rows went missing, differently from run to run)
+#pragma unroll
+    for (int nb = 0; nb < QB; nb++) asm volatile("" : "+a"(acc[nb]));
+    constexpr int EVERY = KS / CPT > 0 ? KS / CPT : 1;  // k-steps between two chunks of the next tile
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+      const u4 f = *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(smem) + (tbase - lds_base) + 256u * (uint32_t)(ks >> 3) +
+                                                 ((32u * (uint32_t)(ks & 7)) ^ t16));
+#pragma unroll
+      for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<KT_I8>(f, Q[nb][ks], acc[nb]);
+#pragma unroll
+      for (int j = 0; j < CPT; j++)
+        if (j * EVERY == ks || (KS < CPT && ks == 0)) {
+          // (unconditional: past the workgroup's last tile the store fills a buffer nobody reads and the load re-reads the
+          // tile it just finished -- straight-line code keeps hipcc's vmcnt waits COUNTED; under `if (refill)` every wait of
+          // the loop became vmcnt(0) and the tiles in flight were drained at every chunk)
+          __builtin_amdgcn_sched_barrier(0);  // (pinned: hipcc hoists all CPT conversions to the top of the tile and drains vmcnt there)
+          use(regs[j]);
+          quant_store(regs[j], buf ^ 1u, j);
+          ld(regs[j], src + NT * j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const uint32_t xr0 = row_first + i * row_step + 4 * h;
+#pragma unroll
+    for (int nb = 0; nb < QB; nb++) {
+      int m = max3i(acc[nb][0], acc[nb][1], acc[nb][2]);
+#pragma unroll
+      for (int e = 3; e < 15; e += 2) m = max3i(m, acc[nb][e], acc[nb][e + 1]);
+      m = max3i(m, acc[nb][15], acc[nb][15]);
+      if (m >= ithr[nb]) {
+        uint2 *list = g.sub_cand + ((((size_t)blockIdx.x * 256 + 32 * QB * w + 32 * nb + r) * 2 + h) * g.sub_cap);
 #pragma unroll
         for (int eg = 0; eg < 4; eg++) {
-          const float gm = max3(max3(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
-          if (gm >= thr[nb]) {
+          const int gm = max3i(max3i(acc[nb][4 * eg], acc[nb][4 * eg + 1], acc[nb][4 * eg + 2]), acc[nb][4 * eg + 3], acc[nb][4 * eg + 3]);
+          if (gm >= ithr[nb]) {
 #pragma unroll
             for (int el = 0; el < 4; el++) {
-              const float d = L2 ? 2.0f * (qsc[nb] - acc[nb][4 * eg + el]) : 1.0f - acc[nb][4 * eg + el];
+              const float d = 1.0f - qsc[nb] * (float)acc[nb][4 * eg + el];
               const uint32_t xr = xr0 + 8 * eg + el;
-              // (the test on the accumulator IS the filter -- a superset of d <= tau by the margin in thr, which is all a
-              // filter pass owes: the survivors are re-scored; tau itself is not kept in a register)
-              if (acc[nb][4 * eg + el] >= thr[nb] && xr < row_end) {
-                if (cur[nb] < g.sub_cap) list[cur[nb]] = make_uint2(xr, __float_as_uint(d));
+              if (acc[nb][4 * eg + el] >= ithr[nb] && d <= tau[nb] && xr < row_end) {
+                // (the store as inline asm: a store hipcc can see makes the vmcnt bracket "mixed" -- loads and stores pending -- and
+                // every wait on the tiles in flight becomes a drain)
+                if (cur[nb] < g.sub_cap) {
+                  const uint2 *dst = list + cur[nb];
+                  const uint2 val = make_uint2(xr, __float_as_uint(d));
+                  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+                }
                 cur[nb]++;
               }
             }
@@ -664,6 +885,17 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
         }
       }
     }
+    // The refills of the last D tiles (re-reads of a finished tile) must land before the wave moves on: behind the loop hipcc
+    // re-used v[2:3] -- dead to it, in flight in fact -- for the pointer of the final store, the load landed on it and the store
+    // went to a wild address (MEMORY_APERTURE_VIOLATION); a wave that ENDS under its loads faults as well.  Drained here, in
+    // the workgroup's last tile, where the ring is still live to the compiler (it cannot know this trip is the last).
+    if (i + 1 == mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // buffer (i + 1) & 1 is complete, buffer i & 1 is free
+  };
+  for (uint32_t i = 0; i < mine; i += D) {
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (i + d < mine) step(i + d, R[d]);
   }
 #pragma unroll
   for (int nb = 0; nb < QB; nb++)
@@ -820,6 +1052,41 @@ bool launch_gemm_qs_f32(const void *rows, const void *queries_bf16, uint32_t str
     case 96: launch_qs_f32_shape<24, 24, 3>(g, grid, s); return true;
     case 64: launch_qs_f32_shape<16, 16, 4>(g, grid, s); return true;
     case 32: launch_qs_f32_shape<8, 8, 8>(g, grid, s); return true;
+    default: return false;
+  }
+}
+
+// ---- FLOAT16 rows quantised to int8 in flight (SRC_H8): stride16 = fp16 chunks per row, queries = int8 rows of stride16 * 8 bytes
+bool gemm_qs_h8_supported(uint32_t stride16) { return stride16 == 96 || stride16 == 64 || stride16 == 48 || stride16 == 32 || stride16 == 16; }
+
+namespace {
+template <int KS, int NS>
+void launch_qs_h8_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
+  // 2 (default): four waves x 64 queries -- every quantised fragment feeds two matrix instructions; 1: eight waves x 32
+  // 5: the register-staged form (gemm_qs_h8r_kernel: quantised once per workgroup), eight waves x 32 queries, two tiles in flight
+  // (four waves x 64 queries measured 7.8 ms per pass -- one wave per SIMD hides nothing here; three tiles in flight spill at dim 768)
+  if (scan_tuning().gemm_qs_h8 == 5) hipLaunchKernelGGL((gemm_qs_h8r_kernel<KS, 1, 2>), dim3(grid), dim3(512), 0, s, g);
+  else if (scan_tuning().gemm_qs_h8 == 1) hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS, NS, 1, false, SRC_H8>), dim3(grid), dim3(512), 0, s, g);
+  else if (KS == 24 && scan_tuning().gemm_qs_h8 == 3)  // (A/B: K-part slots of 24 KiB, a ring of six)
+    hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS == 24 ? 12 : KS, KS == 24 ? 6 : NS, 2, false, SRC_H8>), dim3(grid), dim3(256), 0, s, g);
+  else if (KS == 24 && scan_tuning().gemm_qs_h8 == 4)  // (A/B: slots of 16 KiB, a ring of nine)
+    hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS == 24 ? 8 : KS, KS == 24 ? 9 : NS, 2, false, SRC_H8>), dim3(grid), dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS, NS, 2, false, SRC_H8>), dim3(grid), dim3(256), 0, s, g);
+}
+}  // namespace
+
+bool launch_gemm_qs_h8(const void *rows, const void *queries_i8, uint32_t stride16, uint32_t row_begin, uint32_t row_end, const float *tau,
+                       uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *qscale, uint16_t inv_h_bits) {
+  if (row_end <= row_begin || !gemm_qs_h8_supported(stride16) || !qscale) return false;
+  QsArgs g{(const u4 *)rows, (const u4 *)queries_i8, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, qscale, nullptr, nullptr,
+           (uint32_t)inv_h_bits | ((uint32_t)inv_h_bits << 16)};
+  const uint32_t grid = gemm_qs_grid(row_end - row_begin);
+  switch (stride16) {  // KS = dim / 32 int8 k-steps = stride16 / 4; slots of 32 rows x 64 B x KS, the ring as deep as ~144 KiB allow
+    case 96: launch_qs_h8_shape<24, 3>(g, grid, s); return true;
+    case 64: launch_qs_h8_shape<16, 4>(g, grid, s); return true;
+    case 48: launch_qs_h8_shape<12, 6>(g, grid, s); return true;
+    case 32: launch_qs_h8_shape<8, 8>(g, grid, s); return true;
+    case 16: launch_qs_h8_shape<4, 8>(g, grid, s); return true;
     default: return false;
   }
 }

@@ -110,6 +110,10 @@ struct ScanTuning {
                            // (gemm_qs_f32_kernel; 0 = off: the exact multi-query scan; 2 = four waves x 64 queries -- every converted
                            // fragment feeds two MFMAs, half the LDS reads: 6.20 vs 6.56 ms per pass, profiles/r04_batch_f32_shapes_ab.json
                            // -- 1 = eight waves x 32 queries)
+  int gemm_qs_h8 = 5;      // FLOAT16 IP / cosine indexes: the batched pass quantises the fp16 rows to int8 IN FLIGHT (h8_quant.hpp) and runs on the
+                           // int8 matrix cores -- no stored shadow.  5 (default) = once per workgroup, register-staged (gemm_qs_h8r_kernel, 2.91 ms
+                           // per configs[2] pass); 2 / 1 = in every wave, behind the LDS-DMA ring (four waves x 64 queries 3.87 ms / eight x 32
+                           // 4.29 ms); 3 / 4 = 2 with smaller ring slots (4.14 / 4.61 ms); 0 = the fp16 MFMA pass (3.96 ms)
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
@@ -275,6 +279,16 @@ bool launch_gemm_qs_f32(const void *rows, const void *queries_bf16, uint32_t str
                         const float *hnorm = nullptr, const float *hq = nullptr);
 void launch_convert_queries_bf16(const void *queries, size_t qstride, uint32_t dim, uint32_t n_queries, void *out, size_t ostride,
                                  hipStream_t s);
+// The same pass over FLOAT16 rows quantised to int8 on their way from LDS to the int8 matrix pipe (round 6; gemm_qs_f32_kernel<..,
+// SRC_H8>, h8_quant.hpp): no stored shadow, HBM traffic = the fp16 rows, half the matrix-pipe cycles of the fp16 form.  stride16 =
+// fp16 chunks per row in {16, 32, 48, 64, 96} (dim 128 .. 768); queries_i8 / qscale: launch_quantize_queries with scale = 1 /
+// float(inv_h); inv_h_bits: the fp16 inverse scale the rows' error maxima were taken with (launch_h8_stats).
+bool gemm_qs_h8_supported(uint32_t stride16);
+bool launch_gemm_qs_h8(const void *rows, const void *queries_i8, uint32_t stride16, uint32_t row_begin, uint32_t row_end, const float *tau,
+                       uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *qscale, uint16_t inv_h_bits);
+// stats[1] = max |x8|^2, stats[2] = max |ex|^2 (f32 bits) over FLOAT16 rows [row_begin, row_end) under THAT quantiser (atomicMax)
+void launch_h8_stats(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint16_t inv_h_bits,
+                     uint32_t *stats, hipStream_t s);
 // |x~.q~ - x.q| / (|x||q|) of that pass against the exact scan: both operands rounded to bf16 (u = 2^-9, to nearest:
 // 2u + u^2), the MFMA's and the scan's fp32 summation orders (dim 2^-24 each, of sum |x_i q_i| (1 + u)^2), 2 % to spare
 inline float gemm_qs_f32_rel(size_t dim) { return (0.00390625f + 3.9e-6f + (float)dim * 1.2e-7f * 1.004f) * 1.02f; }

@@ -42,3 +42,20 @@ def test_the_lint_bites(asm):
         f.write("\n".join(lines))
     findings = [x for _, (_, fs) in L.lint(bad).items() for x in fs]
     assert findings and "in flight" in findings[0][1]
+
+
+def test_h8r_ring_registers_are_never_touched_in_flight():
+    """gemm_qs_h8r_kernel (round 6) keeps two tiles in flight in registers behind inline-asm loads: hipcc believes they hold their
+    values from the asm on.  scripts/isa_lint_h8r.py walks the tile loop of every instantiation in the BUILT object (twice, for the
+    loop-carried loads) and the prologue: nothing but the quantiser's v_pk_fma_f16 may read such a register between its load and
+    its counted wait, nothing may write or spill it."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "redisearch_amd", "lib", "obj", "gemm_qs_kernels.hip.o")
+    if not os.path.exists(obj):
+        pytest.skip("library not built")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_lint_h8r.py")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("gemm_qs_h8r_kernel")]
+    assert len(lines) >= 5 and all(ln.rstrip().endswith("OK") for ln in lines), p.stdout
+    assert "gemm_qs_h8r_kernel<24,1,2>" in p.stdout and "registers in flight  48" in p.stdout   # 2 tiles x 6 chunks x 4 dwords
