@@ -632,6 +632,24 @@ def extra_batched(lib, V, rows, dim):
         wall_ms, same4 = _batched_wall(idx, qs, k, ids, reps % 4)
         ok &= same4
         flops = 2.0 * batch * dim * rows
+        # the fp16 MFMA pass over the same index (knob gemm_qs_h8 = 0: rounds 1-5's route), for the record
+        f16_ms, f16_same = None, None
+        try:
+            lib.RSGPU_SetTuning(b"gemm_qs_h8", 0)
+            idx.topk_batch(qs[0], k)
+            lib.RSGPU_ResetProfile()
+            lib.RSGPU_SetProfiling(1)
+            for i in range(5):
+                ids0, sc0, _ = idx.topk_batch(qs[(i + 1) % 4], k)
+            lib.RSGPU_SetProfiling(0)
+            l0, ms0, _ = V.scan_profile()
+            f16_ms = ms0 / max(l0, 1)
+            idsr, scr, _ = idx.topk_batch(qs[5 % 4], k)     # (the default route again on the block the loop ended with)
+            lib.RSGPU_SetTuning(b"gemm_qs_h8", 5)
+            idsr, scr, _ = idx.topk_batch(qs[5 % 4], k)
+            f16_same = bool(np.array_equal(ids0, idsr) and np.array_equal(sc0, scr))
+        finally:
+            lib.RSGPU_SetTuning(b"gemm_qs_h8", 5)
         # opt-in int8 shadow of the same corpus (RSGPU_SetTuning("shadow8") before VecSimIndex_New): the filter passes run
         # on the int8 matrix cores over half the bytes, survivors are re-scored from the fp16 rows -- the replies must be
         # BIT-IDENTICAL to single queries on the fp16 index
@@ -680,9 +698,13 @@ def extra_batched(lib, V, rows, dim):
                                    "host reply building with the next pass; device_ms_per_pass = HIP events around one pass alone",
                 "hbm_gbs": rows * dim * 2 / dev_ms / 1e6, "hbm_frac": rows * dim * 2 / dev_ms / 1e6 / HBM_PEAK_GBS,
                 "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
-                "kernel": "gemm_qs_kernel (query-stationary MFMA filter pass, thresholds widened by the summation-order band) + exact re-scoring "
-                          "of the survivors (batch_rescore_kernel: the single-query scan's arithmetic) + per-query select; HIP events around the "
-                          "whole device pipeline of a pass",
+                "kernel": "gemm_qs_h8r_kernel (round 6: fp16 rows quantised to int8 IN FLIGHT -- once per workgroup, register-staged ring, "
+                          "v_mfma_i32_32x32x32_i8 against register-stationary int8 queries; nothing stored next to the index; thresholds "
+                          "widened by the Cauchy-Schwarz band of the actual quantisation-error maxima) + exact re-scoring of the survivors "
+                          "(batch_rescore_kernel: the single-query scan's arithmetic) + per-query select; HIP events around the whole "
+                          "device pipeline of a pass",
+                "fp16_mfma_pass_device_ms": f16_ms, "fp16_mfma_pass_same_replies": f16_same,
+                "int8_tops": flops / dev_ms / 1e9, "int8_frac_of_5000_TOPS": flops / dev_ms / 1e9 / 5000.0,
                 "bit_identical_to_single_queries": bool(ok),
                 "parity": {"ok": bool(ok and worst == 0.0), "vs": "single-query path, 4 of 256 queries: ids and scores identical "
                                                                    "(replaced by the CPU-oracle check in the cpu_baseline leg)",
@@ -1437,7 +1459,8 @@ def summarise_extras(cfg):
         if isinstance(b, dict) and "device_ms_per_pass" in b:
             s[short] = _scalars({"device_ms_per_pass": b.get("device_ms_per_pass"), "wall_ms_per_pass": b.get("wall_ms_per_pass"),
                                  "qps_device": b.get("qps_device"), "qps_wall": b.get("qps_wall"), "hbm_frac": b.get("hbm_frac"),
-                                 "mfma_frac": b.get("mfma_frac"), "bit_identical": b.get("bit_identical_to_single_queries"),
+                                 "mfma_frac": b.get("mfma_frac"), "fp16_mfma_pass_ms": b.get("fp16_mfma_pass_device_ms"),
+                                 "bit_identical": b.get("bit_identical_to_single_queries"),
                                  "parity_ok": _g(b, "parity", "ok"),
                                  "int8_shadow_device_ms": _g(b, "int8_shadow_extra", "device_ms_per_pass")})
     h = cfg.get("hybrid")

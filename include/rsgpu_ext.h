@@ -43,8 +43,9 @@ long RSGPU_FlatIndex_AddPhiloxRows(VecSimIndex *index, uint64_t seed, uint64_t f
 int RSGPU_FlatIndex_ReadRows(VecSimIndex *index, size_t row_begin, size_t n, void *host_out);
 /* How the index maps labels (doc ids) to storage rows right now (csrc/label_table.hpp): 0 identity labelling -- label = base +
  * row, no table; 1 a direct-addressed table in HBM that the hybrid kernels read (it survives DeleteVector, re-adds under new
- * ids, documents without a vector, multi-value labels); 2 labels too sparse for a table -- host hash maps, the hybrid entry
- * points translate on the host.  -1: a sharded handle (ask the shards).  Inspection / tests; the reference looks vectors up by
+ * ids, documents without a vector, multi-value labels); 2 labels too far apart for that (1 M vectors in a 10^9-document index:
+ * reference src/document.c:712-725 gives only documents with the vector field a row) -- an open-addressing hash table in HBM that
+ * the same kernels read (round 6; rounds 1-5: host hash maps, host translation).  -1: a sharded handle (ask the shards).  Inspection / tests; the reference looks vectors up by
  * label in src/iterators/hybrid_reader.c:309-327. */
 int RSGPU_FlatIndex_LabelTable(VecSimIndex *index);
 /* Top-k of one host query written to DEVICE buffers (k fp32 scores, k u64 labels; unused slots get

@@ -152,6 +152,15 @@ void launch_label_scatter(uint32_t *dst, const uint32_t *idx, const uint32_t *va
   if (!n) return;
   hipLaunchKernelGGL(label_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, idx, val, n);
 }
+__global__ __launch_bounds__(256) void label_scatter16_kernel(uint4 *__restrict__ dst, const uint32_t *__restrict__ idx,
+                                                              const uint4 *__restrict__ val, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[idx[i]] = val[i];
+}
+void launch_label_scatter16(void *dst, const uint32_t *idx, const void *val, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(label_scatter16_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (uint4 *)dst, idx, (const uint4 *)val, n);
+}
 void launch_label_decode(uint32_t *dst, size_t n, hipStream_t s) {
   if (!n) return;
   const size_t need = (n + 255) / 256;

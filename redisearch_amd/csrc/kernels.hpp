@@ -31,10 +31,38 @@ struct LabelRows {
   uint64_t base;
   uint32_t span;           // labels in [base, base + span) may have a row
   uint32_t n_rows;         // committed rows
+  // round 6: labels too far apart for a direct table (1 M vectors in a 10^9-document index) -- an open-addressing hash table in HBM,
+  // 16 bytes per slot {label lo, label hi, first row, used}, linear probing, at most half full (label_table.hpp HASH)
+  const void *hash;        // nullptr: the forms above
+  uint32_t hash_mask;      // slots - 1 (a power of two)
 };
+// the tables' hash of a label (splitmix64 finaliser); host and device probe alike
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline uint64_t label_hash(uint64_t x) {
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ull;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebull;
+  x ^= x >> 31;
+  return x;
+}
 #ifdef __HIPCC__
 // first row of doc id `id`, kNoRow when the document has no vector
 __device__ __forceinline__ uint32_t label_first_row(const LabelRows &m, uint64_t id) {
+  if (m.hash) {
+    typedef uint32_t lr_u4 __attribute__((ext_vector_type(4)));
+    const lr_u4 *t = static_cast<const lr_u4 *>(m.hash);
+    const uint32_t lo = (uint32_t)id, hi = (uint32_t)(id >> 32);
+    uint32_t p = (uint32_t)label_hash(id) & m.hash_mask;
+    for (uint32_t guard = 0; guard <= m.hash_mask; guard++, p = (p + 1) & m.hash_mask) {
+      const lr_u4 e = t[p];
+      if (!e.w) return kNoRow;
+      if (e.x == lo && e.y == hi) return e.z < m.n_rows ? e.z : kNoRow;
+    }
+    return kNoRow;
+  }
   const uint64_t off = id - m.base;
   if (id < m.base || off >= (uint64_t)m.span) return kNoRow;
   const uint32_t r = m.row_of ? m.row_of[off] : (uint32_t)off;
@@ -45,6 +73,8 @@ __device__ __forceinline__ uint32_t label_first_row(const LabelRows &m, uint64_t
 void launch_label_fill(uint32_t *dst, size_t begin, size_t end, size_t lo, size_t hi, uint32_t first, hipStream_t s);
 // dst[idx[i]] = val[i], i < n (duplicate indices carry the same value)
 void launch_label_scatter(uint32_t *dst, const uint32_t *idx, const uint32_t *val, uint32_t n, hipStream_t s);
+// dst[idx[i]] = val[i] for 16-byte slots (the hash form)
+void launch_label_scatter16(void *dst, const uint32_t *idx, const void *val, uint32_t n, hipStream_t s);
 // dst[i] -= 1 for i < n: an uploaded host table (0 = none, row + 1) becomes the device form (kNoRow = none)
 void launch_label_decode(uint32_t *dst, size_t n, hipStream_t s);
 

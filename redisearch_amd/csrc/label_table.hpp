@@ -12,9 +12,14 @@
 //             tile kernels, labels_to_rows and the ad-hoc gather translate on the device, and AddVector / DeleteVector touch
 //             two or three entries.  Leaving IDENTITY is O(1) on the host: the host table is calloc'ed and encodes
 //             "unchanged since identity" as 0, so no page is touched until a label changes; the device table is one fill
-//             kernel.  Allowed while the table stays below max(64 MiB, 1/8 of the row matrix).
-//   SPARSE    labels too far apart for that (a test's label 10^9 in an index of ten rows): the host hash maps of rounds
-//             1-4; nothing on the device -- the hybrid entry points fall back to their host translation.
+//             kernel.  Allowed while the table stays below max(4 MiB, 1/4 of the row matrix).
+//   HASH      (round 6; replaces the host hash maps of rounds 1-5) labels too far apart for that -- in the reference a label is
+//             a doc id of the WHOLE document table (src/document.c:712-725: only documents with the vector field get a row),
+//             so "1 M vectors in a 10^9-document index" is the ordinary case, and a long-lived index's span only grows
+//             (src/indexer.c:179-190) -- an open-addressing table in HBM with a host copy: 16-byte slots {label, first row,
+//             used}, linear probing from a splitmix hash, at most half full (32 bytes per row), deleted labels stay as
+//             tombstones (labels are never reused) until a rebuild.  The same kernels read it (kernels.hpp label_first_row):
+//             the hybrid entry points keep their tile paths whatever the labels look like.
 #pragma once
 #include <unordered_map>
 #include <vector>
@@ -26,7 +31,7 @@ namespace rsgpu {
 
 class LabelTable {
  public:
-  enum Mode { IDENTITY = 0, DIRECT = 1, SPARSE = 2 };
+  enum Mode { IDENTITY = 0, DIRECT = 1, HASH = 2 };
   using LabelVec = std::vector<uint64_t, HookAlloc<uint64_t>>;
   // row_label: the index's row -> label vector (committed + staged rows); an insert of row r is announced BEFORE r is
   // appended to it.  host_bytes: the index's counter of host memory taken through the installed memory functions.
@@ -60,9 +65,9 @@ class LabelTable {
   // queue the pending entry updates behind the stream's work; the caller synchronises `s` before it lets readers in
   void sync_device(hipStream_t s);
 
-  // what the kernels take; false: SPARSE (no device form)
+  // what the kernels take (every mode has a device form since round 6: always true)
   bool device_view(uint32_t committed_rows, LabelRows *out) const;
-  size_t device_bytes() const { return (d_cap_ + d_next_cap_) * sizeof(uint32_t); }
+  size_t device_bytes() const { return (d_cap_ + d_next_cap_) * sizeof(uint32_t) + d_hcap_ * sizeof(HEnt); }
 
  private:
   static constexpr uint32_t kTomb = 0xFFFFFFFFu;  // host encoding: 0 = unchanged since identity, row + 1, kTomb = deleted
@@ -79,9 +84,9 @@ class LabelTable {
   }
   void set_next(uint32_t row, uint32_t to);
   void to_direct(hipStream_t s);
-  void to_sparse();
+  void to_hash(hipStream_t s);
   void rebuild_direct(uint64_t new_base, size_t need_span, hipStream_t s);
-  // the slot of `label`, growing / rebasing the table; false: the table went SPARSE
+  // the slot of `label`, growing / rebasing the table; false: the table went HASH
   bool slot_for(uint64_t label, size_t n, hipStream_t s, size_t *off);
   void grow_span(size_t need, hipStream_t s);
   void ensure_device_next(size_t rows, hipStream_t s);
@@ -111,19 +116,24 @@ class LabelTable {
   std::vector<uint32_t> pend_off_, pend_row_;
   uint32_t *h_pin_ = nullptr, *d_pend_ = nullptr;
   size_t pin_cap_ = 0;
-  // SPARSE
-  using RowVec = std::vector<uint32_t, HookAlloc<uint32_t>>;
-  using SingleMap = std::unordered_map<uint64_t, uint32_t, std::hash<uint64_t>, std::equal_to<uint64_t>,
-                                       HookAlloc<std::pair<const uint64_t, uint32_t>>>;
-  using MultiMap = std::unordered_map<uint64_t, RowVec, std::hash<uint64_t>, std::equal_to<uint64_t>,
-                                      HookAlloc<std::pair<const uint64_t, RowVec>>>;
-  SingleMap single_map_;
-  MultiMap multi_map_;
-  RowVec &rows_slot(uint64_t label) {
-    auto it = multi_map_.find(label);
-    if (it == multi_map_.end()) it = multi_map_.emplace(label, RowVec(HookAlloc<uint32_t>(host_bytes_))).first;
-    return it->second;
+  // HASH: host copy + device copy of the open-addressing table
+  struct HEnt {
+    uint32_t lo, hi, row, used;  // label, first row (kNoRow: deleted), 0 = empty slot
+  };
+  static constexpr size_t kNoSlot = ~(size_t)0;
+  HEnt *hent_ = nullptr;
+  size_t hcap_ = 0, h_used_ = 0, h_live_ = 0;  // slots (a power of two), used slots (live + tombstones), live labels
+  HEnt *d_hash_ = nullptr;
+  size_t d_hcap_ = 0;
+  std::vector<uint32_t> pend_slot_;
+  size_t hfind(uint64_t label) const;                       // the label's slot (live or tombstone) or kNoSlot
+  size_t hplace(uint64_t label);                            // ... or a fresh slot for it (the table has room)
+  void hset(size_t slot, uint32_t row) {
+    hent_[slot].row = row;
+    pend_slot_.push_back((uint32_t)slot);
   }
+  void hash_rebuild(size_t rows_hint, hipStream_t s);       // every label again, from row_label_ (+ chains), uploaded
+  void free_hash();
 };
 
 }  // namespace rsgpu

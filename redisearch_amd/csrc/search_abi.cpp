@@ -1424,7 +1424,7 @@ long RSGPU_Hits_KnnRerank(RSGPU_Hits *h, VecSimIndex *index, const void *query, 
   }
   if (on_device) {
     launch_labels_to_rows(h->ids.p, h->len, h->base, L, sc.rows.p, c->stream);
-  } else {  // labels too sparse for a device table (label_table.hpp SPARSE): the host hash map
+  } else {  // (no device form of the label map: cannot happen since round 6 -- every mode of label_table.hpp has one)
     const std::vector<uint32_t> &ids = h->host_ids();
     std::vector<uint32_t> rows(h->len);
     for (uint32_t i = 0; i < h->len; i++) rows[i] = f->first_row_of(h->base + ids[i]);
@@ -2336,8 +2336,8 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   tls_hybrid_path = 0;
 
   // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
-  // doc id -> row: identity arithmetic or the device label table (label_table.hpp; it survives deletes, re-adds under new
-  // ids, documents without a vector and multi-value labels).  Only labels too sparse for a table are translated on the host.
+  // doc id -> row: identity arithmetic, the direct table or -- labels far apart -- the hash table in HBM (label_table.hpp; every
+  // form survives deletes, re-adds under new ids, documents without a vector and multi-value labels; round 6: no host translation).
   LabelRows knn_rows{};
   bool knn_identity = false;  // (historic name: the KNN branch translates on the device)
   std::shared_lock<std::shared_mutex> index_lock;
@@ -2348,7 +2348,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     index_lock = std::shared_lock<std::shared_mutex>(f->mu);
     knn_identity = f->device_label_rows(&knn_rows) &&
                    (!knn_rows.next || knn_chain_supported(f->ktype, f->kmetric, (uint32_t)(f->stride() / 16)));
-    if (!knn_identity) tiles = general = false;  // SPARSE labels live on the host
+    if (!knn_identity) tiles = general = false;  // (a multi-value chain over a type without a chain kernel)
     if (knn_identity) f->upload_query((tiles || general) ? ca.c : cb.c, a->query, true);
   }
   if (tiles) {

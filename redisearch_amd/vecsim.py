@@ -342,7 +342,7 @@ class VecSimIndex:
         return r
 
     def label_table(self):
-        """0 identity labels, 1 device label table, 2 sparse labels (host maps): RSGPU_FlatIndex_LabelTable"""
+        """0 identity labels, 1 direct device table, 2 device hash table (labels far apart; round 6): RSGPU_FlatIndex_LabelTable"""
         return self.lib.RSGPU_FlatIndex_LabelTable(self.ptr)
 
     def read_rows(self, row_begin, n):

@@ -286,9 +286,9 @@ def test_staged_entry_points_translate_on_the_device_too():
         idx.free()
 
 
-def test_labels_too_sparse_for_a_table_fall_back_to_the_host_maps():
-    """a label 10^12 away from the others: no direct table (label_table.hpp SPARSE); the hybrid query still answers -- staged, with
-    the host translation -- and says so through RSGPU_HybridQueryPath"""
+def test_labels_too_sparse_for_a_direct_table_take_the_device_hash_table():
+    """a label 10^12 away from the others: no direct table -- the open-addressing table in HBM (label_table.hpp HASH, round 6;
+    rounds 1-5: host hash maps and the staged pipeline's host translation).  The hybrid query stays on its tile kernels."""
     rng = np.random.default_rng(5)
     n_docs, dim = 50_000, 16
     lists_o = freqs_only_lists(rng, n_docs, (0.5, 0.5))
@@ -306,7 +306,7 @@ def test_labels_too_sparse_for_a_table_fall_back_to_the_host_maps():
     q = O.philox_rows(SEED, 1 << 40, 1, dim)[0]
     hq = S.HybridQuery(g, index=idx, q=q, k=10)
     hq.run()
-    assert S.hybrid_path() == 0
+    assert S.hybrid_path() == 1
     check_knn(hq.results()["knn"], oracle_knn(o, O.intersect(lists_o)[0], q, 10))
     gi, _ = idx.topk_query(v, 1).results()
     assert gi.tolist() == [10 ** 12]

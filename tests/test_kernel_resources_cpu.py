@@ -72,7 +72,10 @@ def test_fp32_source_query_stationary_pass_budget(kernels):
     reloaded through the counted vmcnt queue of the LDS-DMA ring every tile -- two waves per SIMD in the eight-wave shape,
     one 512-register wave in the four-wave shape, the K-part ring inside the CU's LDS."""
     qs = [k for k in kernels if k["name"].startswith("gemm_qs_f32_kernel<")]
-    assert len(qs) == 20                  # five row widths x two shapes x {IP / cosine, L2}
+    f32 = [k for k in qs if k["name"].rstrip(">").endswith(", 0")]
+    h8 = [k for k in qs if k["name"].rstrip(">").endswith(", 1")]      # round 6: SRC_H8, fp16 rows quantised in every wave
+    assert len(f32) == 20                 # five row widths x two shapes x {IP / cosine, L2}
+    assert len(h8) >= 10                  # five row widths x two shapes (+ the two A/B ring shapes at dim 768)
     for k in qs:
         ks, kh, ns, qb = (int(x) for x in re.match(r"gemm_qs_f32_kernel<(\d+), (\d+), (\d+), (\d+)", k["name"]).groups())
         assert not k["vgpr_spill"] and not k["scratch"], k["name"]
@@ -144,3 +147,17 @@ def test_general_hybrid_tile_kernel_budget(kernels):
     assert len(deep) == 6
     pack = [k for k in kernels if k["name"].startswith("hybrid_hits_pack_kernel")]
     assert len(pack) == 1 and pack[0]["vgpr"] <= 32 and not pack[0]["scratch"], pack
+
+
+def test_register_staged_int8_pass_budget(kernels):
+    """gemm_qs_h8r_kernel<KS, 1, 2> (round 6, BASELINE configs[2]'s default pass): eight waves = two per SIMD (<= 256 registers),
+    NO spill and no scratch -- a spilled ring register would be copied while its load is in flight (scripts/isa_lint_h8r.py holds
+    the ISA to that) -- and an int8 double buffer of at most 48 KiB."""
+    qs = [k for k in kernels if k["name"].startswith("gemm_qs_h8r_kernel<")]
+    assert len(qs) == 5                   # five row widths
+    for k in qs:
+        ks, qb, d = (int(x) for x in re.match(r"gemm_qs_h8r_kernel<(\d+), (\d+), (\d+)", k["name"]).groups())
+        assert (qb, d) == (1, 2)
+        assert not k["vgpr_spill"] and not k["scratch"], k["name"]
+        assert k["wg"] == 512 and k["vgpr"] <= 256, (k["name"], k["vgpr"])
+        assert k["lds"] <= 49152, (k["name"], k["lds"])
