@@ -193,7 +193,16 @@ typedef struct {
   double *knn_dists;            /* out [k] */
   size_t n_hits, n_top, n_knn;  /* out: intersection size, entries written to top_* / knn_* */
   RSGPU_Hits **hits_out;        /* optional out: the hit list itself (caller frees); NULL = dropped */
+  /* round 6 -- the query's deadline.  The reference polls TimedOut_WithCtx per candidate (src/iterators/hybrid_reader.c:311,
+   * src/util/timeout.h:57-100), its iterators return ITERATOR_TIMEOUT (src/iterators/iterator_api.h), and VecSim polls
+   * timeoutCallback(queryParams->timeoutCtx) (src/module-init/module-init.c:150): the same callback shape.  NULL = no deadline.
+   * Polled on entry (at least once, however small the query), while the host waits for the device, and between the stages of
+   * the staged forms; when it returns non-zero the call waits for what it has in flight, returns RSGPU_TIMED_OUT with n_hits =
+   * n_top = n_knn = 0 and no hit list, and may be issued again.  (A caller that zero-initialises the block gets no deadline.) */
+  int (*timeout_cb)(void *ctx);
+  void *timeout_ctx;
 } RSGPU_HybridQueryArgs;
+#define RSGPU_TIMED_OUT 1       /* RSGPU_HybridQuery / _TreeQuery / _TreeNodesQuery: 0 ok, -1 error (RSGPU_LastError), 1 deadline */
 int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
 /* how the calling thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 = the staged pipeline (intersection written
  * out, score / top-N and KNN branches on two streams; stage by stage for trees), 1 = two launches (no hits_out, a flat AND of

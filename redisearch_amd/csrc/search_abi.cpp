@@ -1514,6 +1514,119 @@ static void ensure_bucket_dir(RSGPU_Postings *p, QueryCtx *c) {
   p->dir_ready.store(true, std::memory_order_release);
 }
 
+// ---- what the three hybrid entry points share (round 6: one plan instead of three copies of the same prologue) ----------------
+// The query's deadline: the reference polls TimedOut_WithCtx per candidate (src/iterators/hybrid_reader.c:311, src/util/timeout.h:
+// 57-100) and its iterators return ITERATOR_TIMEOUT; VecSim polls timeoutCallback(queryParams->timeoutCtx).  Here the callback of
+// RSGPU_HybridQueryArgs is polled at entry, while the host waits for the device (hyb_wait) and between the stages of the staged
+// forms.  A poll that fires first waits for what the query has in flight -- its pinned flags and scratch go back to the pools with
+// the leases -- and then unwinds to the entry point, which answers RSGPU_TIMED_OUT with empty outputs.
+namespace {
+struct QueryTimedOut {
+  int unused = 0;
+};
+thread_local const RSGPU_HybridQueryArgs *tls_query = nullptr;
+struct QueryScope {
+  const RSGPU_HybridQueryArgs *prev;
+  explicit QueryScope(const RSGPU_HybridQueryArgs *a) : prev(tls_query) { tls_query = a; }
+  ~QueryScope() { tls_query = prev; }
+};
+inline bool deadline_passed() {
+  const RSGPU_HybridQueryArgs *a = tls_query;
+  return a && a->timeout_cb && a->timeout_cb(a->timeout_ctx) != 0;
+}
+inline void poll_deadline(QueryCtx *ca, QueryCtx *cb) {
+  if (!deadline_passed()) return;
+  if (ca) (void)hipStreamSynchronize(ca->stream);
+  if (cb) (void)hipStreamSynchronize(cb->stream);
+  throw QueryTimedOut();
+}
+
+// validation, the branches wanted, the device, the index behind the KNN branch, outputs zeroed, the first poll of the deadline
+struct HybridPlan {
+  RSGPU_HybridQueryArgs *a;
+  const char *who;
+  bool want_score, want_knn;
+  int device;
+  FlatIndex *f;
+  QueryScope scope;
+  HybridPlan(const char *who_, RSGPU_HybridQueryArgs *a_, RSGPU_Postings *const *lists, size_t n_lists) : a(a_), who(who_), scope(a_) {
+    check_lists(who, lists, n_lists);
+    want_score = a->table && a->score && a->top_n;
+    want_knn = a->index && a->query && a->k;
+    device = lists[0]->device;
+    f = want_knn ? a->index->flat : nullptr;
+    if (f && f->device != device) throw std::runtime_error(std::string(who) + ": postings and index live on different devices");
+    if (want_score && a->table->device != device)
+      throw std::runtime_error(std::string(who) + ": postings and document table live on different devices");
+    a->n_hits = a->n_top = a->n_knn = 0;
+    if (a->hits_out) *a->hits_out = nullptr;
+    tls_hybrid_path = 0;
+    HIP_CHECK(hipSetDevice(device));
+    poll_deadline(nullptr, nullptr);  // (at least once, however small the query: SURVEY.md App. B-7)
+    if (f) f->flush_if_needed();
+  }
+  bool norm() const { return want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM; }
+  uint32_t top_n_launched() const { return want_score ? (uint32_t)a->top_n + (norm() ? 1u : 0u) : 0u; }
+  // the stage-by-stage tail over a hit list: the entry points a caller would use on it (each takes the index's locks itself)
+  int staged(std::unique_ptr<RSGPU_Hits> h) {
+    tls_hybrid_path = 0;
+    if (!h) return -1;
+    a->n_hits = h->len;
+    poll_deadline(nullptr, nullptr);
+    if (want_score) {
+      if (RSGPU_Hits_Score(h.get(), a->table, a->score, nullptr) != 0) return -1;
+      const long nt = RSGPU_Hits_TopN(h.get(), a->top_n, a->top_ids, a->top_scores);
+      if (nt < 0) return -1;
+      a->n_top = (size_t)nt;
+      poll_deadline(nullptr, nullptr);
+    }
+    if (want_knn) {
+      const long nk = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
+      if (nk < 0) return -1;
+      a->n_knn = (size_t)nk;
+    }
+    if (a->hits_out) *a->hits_out = h.release();
+    return 0;
+  }
+};
+
+// the leases, scratch and profiling events of a tile-path attempt; the index's shared lock and the label view it covers
+struct HybridTileRun {
+  CtxLease ca, cb;
+  Scratch &sc;
+  bool prof;
+  FusedEvents &ev;
+  LabelRows knn_rows{};
+  std::shared_lock<std::shared_mutex> index_lock;
+  bool labels_ok = true;  // false: a multi-value chain over a type without a chain kernel (the staged KNN expands on the host)
+  explicit HybridTileRun(const HybridPlan &p)
+      : ca(p.device), cb(p.device), sc(scratch(p.device)), prof(scan_profile().enabled.load(std::memory_order_relaxed) != 0), ev(tls_events) {
+    if (prof) ev.ensure(p.device);
+    if (p.f) {
+      index_lock = std::shared_lock<std::shared_mutex>(p.f->mu);
+      labels_ok = p.f->device_label_rows(&knn_rows) &&
+                  (!knn_rows.next || knn_chain_supported(p.f->ktype, p.f->kmetric, (uint32_t)(p.f->stride() / 16)));
+    }
+  }
+};
+}  // namespace
+#define S_CATCH_HYBRID(args)                                               \
+  }                                                                        \
+  catch (const QueryTimedOut &) {                                          \
+    (args)->n_hits = (args)->n_top = (args)->n_knn = 0;                    \
+    if ((args)->hits_out && *(args)->hits_out) {                           \
+      RSGPU_Hits_Free(*(args)->hits_out);                                  \
+      *(args)->hits_out = nullptr;                                         \
+    }                                                                      \
+    last_error() = "the query's deadline passed";                          \
+    return RSGPU_TIMED_OUT;                                                \
+  }                                                                        \
+  catch (const std::exception &e) {                                        \
+    last_error() = e.what();                                               \
+    logf(nullptr, "warning", "%s", e.what());                              \
+    return -1;                                                             \
+  }
+
 // ---- shared by the two forms of the tile path (hybrid_two_launches, hybrid_general) ----
 // Scratch for the tiles' lists, the reduce kernel's arguments (answers and completion flags in pinned host memory: ca's for the
 // hit count and the scores, cb's for the KNN winners), the flags re-armed.
@@ -1570,11 +1683,13 @@ static void hyb_wait(QueryCtx *ca, bool may_poll, bool sync_after) {
         break;
       }
       cpu_relax();
+      if ((spin & 255u) == 255u) poll_deadline(ca, nullptr);  // (waits for the stream before it unwinds: everything rides on ca's)
       if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!finished || sync_after) HIP_CHECK(hipStreamSynchronize(ca->stream));
+  poll_deadline(nullptr, nullptr);
 }
 // The reduce kernel met more candidates at its bound than it ranks in LDS (an adversarial arrangement of the tiles' lists: mass
 // ties across thousands of tiles) and wrote 0xFFFFFFFF instead of a count.  The tiles' lists are still in HBM: the exact radix
@@ -2291,23 +2406,16 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     return -1;
   }
   S_TRY
-  check_lists("RSGPU_HybridQuery", a->lists, a->n_lists);
-  const bool want_score = a->table && a->score && a->top_n;
-  const bool want_knn = a->index && a->query && a->k;
-  const int device = a->lists[0]->device;
-  FlatIndex *f = want_knn ? a->index->flat : nullptr;
-  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridQuery: postings and index live on different devices");
-  if (want_score && a->table->device != device)
-    throw std::runtime_error("RSGPU_HybridQuery: postings and document table live on different devices");
+  HybridPlan plan("RSGPU_HybridQuery", a, a->lists, a->n_lists);
+  const bool want_score = plan.want_score, want_knn = plan.want_knn;
+  const int device = plan.device;
+  FlatIndex *f = plan.f;
   if (f && f->key_bytes != 4) throw std::runtime_error("RSGPU_HybridQuery: FLOAT64 indexes are not served by the fused path");
-  a->n_hits = a->n_top = a->n_knn = 0;
-  HIP_CHECK(hipSetDevice(device));
-  if (f) f->flush_if_needed();
-  CtxLease ca(device), cb(device);
-  Scratch &sc = scratch(device);
-  const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
-  FusedEvents &ev = tls_events;
-  if (prof) ev.ensure(device);
+  HybridTileRun run(plan);
+  CtxLease &ca = run.ca, &cb = run.cb;
+  Scratch &sc = run.sc;
+  const bool prof = run.prof;
+  FusedEvents &ev = run.ev;
   std::unique_ptr<RSGPU_Hits> h(new RSGPU_Hits());
   h->device = device;
   h->n_lists = (int)a->n_lists;
@@ -2333,21 +2441,18 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     tiles = tiles && ok;
     general = general && ok;
   }
-  tls_hybrid_path = 0;
 
   // the KNN branch's query goes up first, on its own stream: it does not depend on the hits
   // doc id -> row: identity arithmetic, the direct table or -- labels far apart -- the hash table in HBM (label_table.hpp; every
   // form survives deletes, re-adds under new ids, documents without a vector and multi-value labels; round 6: no host translation).
-  LabelRows knn_rows{};
-  bool knn_identity = false;  // (historic name: the KNN branch translates on the device)
-  std::shared_lock<std::shared_mutex> index_lock;
+  // The plan's run holds the index's shared lock and the label view it covers.
+  const LabelRows &knn_rows = run.knn_rows;
+  std::shared_lock<std::shared_mutex> &index_lock = run.index_lock;
+  const bool knn_identity = f && run.labels_ok;  // (historic name: the KNN branch translates on the device)
   // (a handle over several device shards has no single row matrix: its KNN branch goes through the staged entry point, which
   // routes every label to the shard that owns it -- RSGPU_Hits_KnnRerank)
   if (want_knn && !f) tiles = general = false;
   if (f) {
-    index_lock = std::shared_lock<std::shared_mutex>(f->mu);
-    knn_identity = f->device_label_rows(&knn_rows) &&
-                   (!knn_rows.next || knn_chain_supported(f->ktype, f->kmetric, (uint32_t)(f->stride() / 16)));
     if (!knn_identity) tiles = general = false;  // (a multi-value chain over a type without a chain kernel)
     if (knn_identity) f->upload_query((tiles || general) ? ca.c : cb.c, a->query, true);
   }
@@ -2387,6 +2492,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     }
   }
   if (prof || h_total[0] == kCountPending) HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #1 (profiling / a very slow query)
+  poll_deadline(ca.c, nullptr);
   HIP_CHECK(hipStreamWaitEvent(cb->stream, ca->ev1, 0));
   const uint32_t len = h_total[0];
   h->len = len;
@@ -2489,6 +2595,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
     if (knn_mode == 2) sc.knn_dirty = false;      // knn_topk_kernel ran to its end: the counters are back at zero
   }
   HIP_CHECK(hipStreamSynchronize(ca->stream));  // sync #2 (branch A)
+  poll_deadline(nullptr, nullptr);
 
   // ---- results ----
   if (want_score && len) {
@@ -2585,7 +2692,7 @@ extern "C" int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *a) {
   }
   if (a->hits_out) *a->hits_out = h.release();
   return 0;
-  S_CATCH(-1)
+  S_CATCH_HYBRID(a)
 }
 
 /* RSGPU_HybridQuery over a two-level query tree (include/rsgpu_search.h): the general tile kernel when the root is an
@@ -2601,18 +2708,9 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   if (q->n_groups > (size_t)kMaxLists || n_lists > (size_t)kMaxLists || !n_lists)
     throw std::runtime_error("RSGPU_HybridTreeQuery: at most 32 groups and 32 terms");
   if (q->root_op != RSGPU_OP_INTERSECT && q->root_op != RSGPU_OP_UNION) throw std::runtime_error("RSGPU_HybridTreeQuery: bad root_op");
-  check_lists("RSGPU_HybridTreeQuery", q->lists, n_lists);
-  const bool want_score = a->table && a->score && a->top_n;
-  const bool want_knn = a->index && a->query && a->k;
-  const int device = q->lists[0]->device;
-  FlatIndex *f = want_knn ? a->index->flat : nullptr;
-  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridTreeQuery: postings and index live on different devices");
-  if (want_score && a->table->device != device)
-    throw std::runtime_error("RSGPU_HybridTreeQuery: postings and document table live on different devices");
-  a->n_hits = a->n_top = a->n_knn = 0;
-  if (a->hits_out) *a->hits_out = nullptr;
-  tls_hybrid_path = 0;
-  HIP_CHECK(hipSetDevice(device));
+  HybridPlan plan("RSGPU_HybridTreeQuery", a, q->lists, n_lists);
+  const bool want_score = plan.want_score, want_knn = plan.want_knn;
+  FlatIndex *f = plan.f;
 
   // A root UNION of terms / intersections of terms (`a | b`, `(a b) | (c d)`: round 5) takes the tile kernel too -- one pass per
   // child, one reduce -- when nobody asked for the hit list and the scorer does not divide by the result's slop (a union result
@@ -2639,21 +2737,11 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
               hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
                                     want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
     if (general) {
-      if (f) f->flush_if_needed();
-      CtxLease ca(device), cb(device);
-      Scratch &sc = scratch(device);
-      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
-      FusedEvents &ev = tls_events;
-      if (prof) ev.ensure(device);
-      LabelRows knn_rows{};
-      std::shared_lock<std::shared_mutex> index_lock;
-      if (f) {
-        index_lock = std::shared_lock<std::shared_mutex>(f->mu);
-        general = f->device_label_rows(&knn_rows);  // (labels too sparse for a device table live on the host)
-        if (general) f->upload_query(ca.c, a->query, true);
-      }
-      if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, knn_rows, want_score, want_knn, ca.c,
-                                    cb.c, sc, prof, ev, root_union)) {
+      HybridTileRun run(plan);
+      general = !f || run.labels_ok;
+      if (general && f) f->upload_query(run.ca.c, a->query, true);
+      if (general && hybrid_general(a, q->lists, groups, q->max_slop, q->in_order, a->hits_out, f, run.knn_rows, want_score, want_knn,
+                                    run.ca.c, run.cb.c, run.sc, run.prof, run.ev, root_union)) {
         tls_hybrid_path = 2;
         return 0;
       }
@@ -2667,24 +2755,9 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
                                  "intersection of at most eight lists with a term or a union of terms to drive it, top_n / k <= 64, labels a "
                                  "device table holds (RSGPU_FlatIndex_LabelTable != 2)");
   // stage by stage (the index lock is released: the entry points below take it themselves)
-  std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTree(q));
-  tls_hybrid_path = 0;  // (RSGPU_EvalTree may have built the list with the tile kernel; this QUERY ran stage by stage)
-  if (!h) return -1;
-  a->n_hits = h->len;
-  if (want_score) {
-    if (RSGPU_Hits_Score(h.get(), a->table, a->score, nullptr) != 0) return -1;
-    const long nt = RSGPU_Hits_TopN(h.get(), a->top_n, a->top_ids, a->top_scores);
-    if (nt < 0) return -1;
-    a->n_top = (size_t)nt;
-  }
-  if (want_knn) {
-    const long nk = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
-    if (nk < 0) return -1;
-    a->n_knn = (size_t)nk;
-  }
-  if (a->hits_out) *a->hits_out = h.release();
-  return 0;
-  S_CATCH(-1)
+  // (RSGPU_EvalTree may build the list with the tile kernel; this QUERY runs stage by stage: the plan says path 0)
+  return plan.staged(std::unique_ptr<RSGPU_Hits>(RSGPU_EvalTree(q)));
+  S_CATCH_HYBRID(a)
 }
 
 // ---- RSGPU_HybridTreeNodesQuery: the hybrid query over a tree of any depth ----
@@ -2871,19 +2944,10 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
   }
   S_TRY
   if (n_nodes > (size_t)kMaxNodes || a->n_lists > (size_t)kMaxLists) throw std::runtime_error("RSGPU_HybridTreeNodesQuery: at most 64 nodes over 32 terms");
-  check_lists("RSGPU_HybridTreeNodesQuery", a->lists, a->n_lists);
   const size_t n_lists = a->n_lists;
-  const bool want_score = a->table && a->score && a->top_n;
-  const bool want_knn = a->index && a->query && a->k;
-  const int device = a->lists[0]->device;
-  FlatIndex *f = want_knn ? a->index->flat : nullptr;
-  if (f && f->device != device) throw std::runtime_error("RSGPU_HybridTreeNodesQuery: postings and index live on different devices");
-  if (want_score && a->table->device != device)
-    throw std::runtime_error("RSGPU_HybridTreeNodesQuery: postings and document table live on different devices");
-  a->n_hits = a->n_top = a->n_knn = 0;
-  if (a->hits_out) *a->hits_out = nullptr;
-  tls_hybrid_path = 0;
-  HIP_CHECK(hipSetDevice(device));
+  HybridPlan plan("RSGPU_HybridTreeNodesQuery", a, a->lists, n_lists);
+  const bool want_score = plan.want_score, want_knn = plan.want_knn;
+  FlatIndex *f = plan.f;
 
   QTree qt;
   std::vector<HybGroup> groups;
@@ -2917,21 +2981,11 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
               hybrid_tree_supported(f ? f->ktype : 0, f ? f->kmetric : 0, f ? (uint32_t)(f->stride() / 16) : 1u, tiles,
                                     want_score ? (uint32_t)a->top_n + (norm ? 1u : 0u) : 0u, want_knn ? (uint32_t)a->k : 0u, (int)n_lists);
     if (general) {
-      if (f) f->flush_if_needed();
-      CtxLease ca(device), cb(device);
-      Scratch &sc = scratch(device);
-      const bool prof = scan_profile().enabled.load(std::memory_order_relaxed) != 0;
-      FusedEvents &ev = tls_events;
-      if (prof) ev.ensure(device);
-      LabelRows knn_rows{};
-      std::shared_lock<std::shared_mutex> index_lock;
-      if (f) {
-        index_lock = std::shared_lock<std::shared_mutex>(f->mu);
-        general = f->device_label_rows(&knn_rows);
-        if (general) f->upload_query(ca.c, a->query, true);
-      }
-      if (general && hybrid_general(a, a->lists, groups, deep ? -1 : qt.root_slop, deep ? 0 : qt.root_in_order, nullptr, f, knn_rows, want_score,
-                                    want_knn, ca.c, cb.c, sc, prof, ev)) {
+      HybridTileRun run(plan);
+      general = !f || run.labels_ok;
+      if (general && f) f->upload_query(run.ca.c, a->query, true);
+      if (general && hybrid_general(a, a->lists, groups, deep ? -1 : qt.root_slop, deep ? 0 : qt.root_in_order, nullptr, f, run.knn_rows,
+                                    want_score, want_knn, run.ca.c, run.cb.c, run.sc, run.prof, run.ev)) {
         tls_hybrid_path = 2;
         return 0;
       }
@@ -2943,24 +2997,8 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
                              "terms under a root intersection of at most eight lists with a term or a union of terms to drive it, no "
                              "hits_out, top_n / k <= 64, labels a device table holds");
   // stage by stage (the index lock is released: the entry points below take it themselves)
-  std::unique_ptr<RSGPU_Hits> h(RSGPU_EvalTreeNodes(nodes, n_nodes, a->lists, n_lists));
-  tls_hybrid_path = 0;
-  if (!h) return -1;
-  a->n_hits = h->len;
-  if (want_score) {
-    if (RSGPU_Hits_Score(h.get(), a->table, a->score, nullptr) != 0) return -1;
-    const long nt = RSGPU_Hits_TopN(h.get(), a->top_n, a->top_ids, a->top_scores);
-    if (nt < 0) return -1;
-    a->n_top = (size_t)nt;
-  }
-  if (want_knn) {
-    const long nk = RSGPU_Hits_KnnRerank(h.get(), a->index, a->query, a->k, a->knn_ids, a->knn_dists);
-    if (nk < 0) return -1;
-    a->n_knn = (size_t)nk;
-  }
-  if (a->hits_out) *a->hits_out = h.release();
-  return 0;
-  S_CATCH(-1)
+  return plan.staged(std::unique_ptr<RSGPU_Hits>(RSGPU_EvalTreeNodes(nodes, n_nodes, a->lists, n_lists)));
+  S_CATCH_HYBRID(a)
 }
 
 // reference src/result_processor.c:2549-2571 (window, ranks), src/hybrid/hybrid_scoring.c:41-84

@@ -24,7 +24,12 @@ class ScoreArgs(C.Structure):
 class HybridQueryArgs(C.Structure):
     _fields_ = [("lists", _vp), ("n_lists", _sz), ("table", _vp), ("score", C.POINTER(ScoreArgs)), ("top_n", _sz),
                 ("index", _vp), ("query", _vp), ("k", _sz), ("top_ids", _vp), ("top_scores", _vp), ("knn_ids", _vp),
-                ("knn_dists", _vp), ("n_hits", _sz), ("n_top", _sz), ("n_knn", _sz), ("hits_out", _vp)]
+                ("knn_dists", _vp), ("n_hits", _sz), ("n_top", _sz), ("n_knn", _sz), ("hits_out", _vp),
+                ("timeout_cb", _vp), ("timeout_ctx", _vp)]   # round 6: int (*)(void *ctx), NULL = no deadline
+
+
+TIMEOUT_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)     # the reference's / VecSim's timeoutCallbackFunction shape
+TIMED_OUT = 1                                     # RSGPU_TIMED_OUT
 
 
 class TreeQuery(C.Structure):
@@ -302,12 +307,22 @@ class HybridQuery:
     def _call(self):
         return self._fn(self._ref)
 
+    def set_timeout(self, fn):
+        """fn() -> truthy once the deadline has passed (polled by the library: RSGPU_HybridQueryArgs.timeout_cb); None clears it"""
+        self._tcb = TIMEOUT_CB(lambda ctx: int(bool(fn()))) if fn is not None else None
+        self.args.timeout_cb = C.cast(self._tcb, _vp) if fn is not None else None
+
     def run(self):
+        """the bare C call; returns False when the deadline passed (RSGPU_TIMED_OUT: empty outputs), raises on an error"""
         if self._hits_ptr is not None and self._hits_ptr.value:      # the previous run's hit list
             self.lib.RSGPU_Hits_Free(self._hits_ptr)
             self._hits_ptr.value = None
-        if self._call() != 0:
+        rc = self._call()
+        if rc == TIMED_OUT:
+            return False
+        if rc != 0:
             raise RuntimeError(V.last_error())
+        return True
 
     def results(self):
         a = self.args
