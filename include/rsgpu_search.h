@@ -293,7 +293,9 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
  * levels, unions whose children are terms, unions or intersections of terms, no max_slop / in_order below the root (nor on it
  * when some child nests aggregates), no hits_out, no slop-dependent scorer over lists that store offsets under nested children;
  * 0 when it ran stage by stage.  RSGPU_OP_NOT nodes (children: the excluded terms) are accepted as children of the root
- * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form. */
+ * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form, and
+ * through THIS entry point no hit list either: a tree with RSGPU_OP_NOT nodes and hits_out set is refused (-1, RSGPU_LastError says
+ * so) -- `a (b|c) -d` with its hit list is RSGPU_HybridTreeQuery's (two levels), which hands the positive children's columns out. */
 int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_HybridQueryArgs *args);
 /* The result tree behind a hit list, post-order (after the intersections sorted their children by size): per node the
  * operator, the leaf column of a term (-1 for aggregates; leaves are the child slots of RSGPU_Hits_LeafOrder), the number

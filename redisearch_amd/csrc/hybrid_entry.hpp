@@ -19,6 +19,9 @@ namespace {
 struct QueryTimedOut {
   int unused = 0;
 };
+struct TileShapeRefused {  // hybrid_general: a query shape the tile kernel's fixed arrays do not hold -> the staged form
+  int unused = 0;
+};
 thread_local const RSGPU_HybridQueryArgs *tls_query = nullptr;
 struct QueryScope {
   const RSGPU_HybridQueryArgs *prev;
@@ -789,11 +792,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
           return m;
         };
         for (uint32_t m : groups[g].any_of) {
-          if (P.n_req >= kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight required sets");
+          if (P.n_req >= kHybTreeMaxLists) throw TileShapeRefused();  // more than eight required sets: the staged form takes it
           P.req[P.n_req++] = slots(m);
         }
         for (uint32_t m : groups[g].whole) {
-          if (P.n_opt_all >= kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight nested intersections");
+          if (P.n_opt_all >= kHybTreeMaxLists) throw TileShapeRefused();  // more than eight nested intersections
           P.opt_all[P.n_opt_all++] = slots(m);
         }
       } else if (!root_union) {
@@ -820,11 +823,16 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
 
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
   if (n_tiles) {
-    for (const Pass &ps : passes) {
-      HybridTreeArgs P;
-      fill_pass(P, ps);
-      launch_hybrid_tree_tiles(P, f ? f->ktype : 0, f ? f->kmetric : 0, ps.tiles, ca->stream);
+    // every pass's arguments BEFORE the first launch: a shape the kernel's arrays do not hold is handed back to the staged form
+    // with nothing in flight (round-5 advisor: the refusal used to surface as an error after earlier passes had been launched)
+    std::vector<HybridTreeArgs> filled(passes.size());
+    try {
+      for (size_t pi = 0; pi < passes.size(); pi++) fill_pass(filled[pi], passes[pi]);
+    } catch (const TileShapeRefused &) {
+      return false;
     }
+    for (size_t pi = 0; pi < passes.size(); pi++)
+      launch_hybrid_tree_tiles(filled[pi], f ? f->ktype : 0, f ? f->kmetric : 0, passes[pi].tiles, ca->stream);
     if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
     launch_hybrid_reduce(R, ca->stream);
     if (hits_out)

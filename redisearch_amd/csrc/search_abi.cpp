@@ -318,6 +318,10 @@ static void decode_on(RSGPU_Postings *p, QueryCtx *c, bool force = false, bool l
     return;
   }
   // the decode that publishes something other streams will read -- the decoded arrays (cache) or the sync points
+  // (UPGRADE of a lean decode -- decoded_lean set, a consumer of masks / offsets arrives: the full decode writes ids / freqs
+  // AGAIN while other threads' tile kernels may be reading them, without a lock.  Sound by the identical-rewrite invariant: the
+  // encoded bytes are immutable after RSGPU_Postings_Upload and the decode is a pure function of them, so every 4-byte store
+  // stores the value that is already there; aligned 4-byte stores are atomic.  Nothing a reader can observe changes.)
   std::lock_guard<std::mutex> g(p->decode_mu);
   if (cached && (p->decoded.load(std::memory_order_relaxed) || (lean && p->decoded_lean.load(std::memory_order_relaxed)))) return;
   launch_decode(p, c, has_sync && !p->sync_ready.load(std::memory_order_relaxed) ? 1 : (has_sync ? 2 : 0), lean);
