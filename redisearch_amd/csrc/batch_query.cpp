@@ -126,8 +126,10 @@ bool FlatIndex::wide_pass_capable(size_t k) const {
   if (type == VecSimType_FLOAT32) {
     if (shadow_ == 1 && metric == VecSimMetric_Cosine && t.two_stage && dim <= 1024 && dim % 8 == 0 && gemm_qs_supported((uint32_t)(sstride_ / 16)))
       return true;  // fp16 shadow
-    if (s8g_enabled() && metric != VecSimMetric_L2 && t.two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) && s8g_stride() / 16 <= 64 && !s_bad_)
+    if (s8g_enabled() && metric != VecSimMetric_L2 && !h8_ && t.two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) && s8g_stride() / 16 <= 64 && !s_bad_)
       return true;  // int8 rows with one scale
+    if (h8_ && t.gemm_qs_f8 && metric != VecSimMetric_L2 && gemm_qs_f8_supported((uint32_t)(stride_ / 16)) && !s_bad_)
+      return true;  // ... quantised in flight (round 6)
     return t.gemm_qs_f32 && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) && !(metric != VecSimMetric_Cosine && hn_bad_);
   }
   // FLOAT16 / BFLOAT16: L2 through the half norms, cosine with a constant band (|x| = |q| = 1), IP with a per-query band from
@@ -152,9 +154,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // their per-row shadow): the filter passes of the batch run on the int8 matrix cores
   // (round 6, h8_: FLOAT16 indexes WITHOUT the stored shadow take the same int8 passes over their fp16 rows, quantised in flight --
   // launch_gemm_qs_h8; the "two_stage" switch belongs to the stored shadows, "gemm_qs_h8" to this form)
-  const bool h8 = h8_ && scan_tuning().gemm_qs_h8 != 0;
+  const bool f8 = h8_ && type == VecSimType_FLOAT32;  // (the fp32 form: knob gemm_qs_f8)
+  const bool h8 = h8_ && (f8 ? scan_tuning().gemm_qs_f8 != 0 : scan_tuning().gemm_qs_h8 != 0);
   const bool s8g_shape = s8g_enabled() && metric != VecSimMetric_L2 && !multi && k > 0 && k <= 1024 && scan_tuning().gemm_qs &&
-                         (h8_ ? h8 && gemm_qs_h8_supported((uint32_t)(stride_ / 16))
+                         (h8_ ? h8 && (f8 ? gemm_qs_f8_supported((uint32_t)(stride_ / 16)) : gemm_qs_h8_supported((uint32_t)(stride_ / 16)))
                               : scan_tuning().two_stage && gemm_qs_supported((uint32_t)(s8g_stride() / 16)) &&
                                     s8g_stride() / 16 <= 64) &&  // (int8 rows up to 1024 bytes)
                          batch_rescore_supported((uint32_t)(stride_ / 16));
@@ -169,7 +172,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
   // stored next to the index.  Every bound is widened by the rounding band (gemm_qs_f32_rel: 2u + u^2 of |x||q| + the two
   // summation orders; cosine: |x| = |q| = 1; L2: per row through the half norms, as the 16-bit L2 passes), the survivors are
   // re-scored from the same fp32 rows with the single-query scan's arithmetic -> bit-identical to single queries
-  const bool f32_shape = type == VecSimType_FLOAT32 && !via_shadow && !(s8g_shape && scan_tuning().two_stage) && !multi && k > 0 &&
+  const bool f32_shape = type == VecSimType_FLOAT32 && !via_shadow && !(s8g_shape && (h8 || scan_tuning().two_stage)) && !multi && k > 0 &&
                          k <= 1024 && scan_tuning().gemm_qs &&
                          scan_tuning().gemm_qs_f32 && scan_tuning().batch_mfma && gemm_qs_f32_supported((uint32_t)(stride_ / 16)) &&
                          batch_rescore_supported((uint32_t)(stride_ / 16));
@@ -302,7 +305,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // (the exact k-th distance of those rows), the pass over the next 3/16 does it again, and the last
     // 3/4 of the corpus is filtered with a bound ~80x tighter than the sample's: ~2.5 k candidates per query
     // instead of 6.4 k at k = 100, and the filter epilogue almost never fires.
-    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 && (via_f32 ? gemm_qs_f32_supported(stride16) : gemm_qs_supported(stride16));
+    const bool use_qs = !small && scan_tuning().gemm_qs && kk <= 1024 &&
+                        (via_f32 ? gemm_qs_f32_supported(stride16) : (via_shadow8 && h8 && f8 ? gemm_qs_f8_supported(stride16) : gemm_qs_supported(stride16)));
     if (!use_qs) {  // small corpora, K above the passes' limit: the exact multi-query scan is already cheap / the only exact form
       g.unlock();
       all_single();
@@ -484,8 +488,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
             if (!(via_f32 ? launch_gemm_qs_f32(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
                                                c->stream, l2_hn, l2_hq)
                   : via_shadow8 && h8
-                      ? launch_gemm_qs_h8(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap, c->stream,
-                                          qscale, h8_inv_bits_)
+                      ? (f8 ? launch_gemm_qs_f8(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap, c->stream,
+                                                qscale, f8_inv_)
+                            : launch_gemm_qs_h8(g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap, c->stream,
+                                                qscale, h8_inv_bits_))
                           : launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
                                            c->stream, qscale, l2_hn, l2_hq)))
               throw std::runtime_error("batched pass: the matrix-core kernel refused a row shape the route was gated on");

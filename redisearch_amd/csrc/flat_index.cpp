@@ -310,6 +310,10 @@ FlatIndex::FlatIndex(const BFParams &p, void *lctx)
   if (type == VecSimType_FLOAT16 && !multi && metric != VecSimMetric_L2 && !shadow_ && scan_tuning().gemm_qs_h8 &&
       gemm_qs_h8_supported((uint32_t)(stride_ / 16)))
     h8_ = true;
+  // FLOAT32 IP / cosine (knob gemm_qs_f8): the same, through gemm_qs_h8r_kernel<.., SRC_F8>
+  if (type == VecSimType_FLOAT32 && !multi && metric != VecSimMetric_L2 && !shadow_ && scan_tuning().gemm_qs_f8 &&
+      gemm_qs_f8_supported((uint32_t)(stride_ / 16)))
+    h8_ = true;
   sstride_ = shadow_ == 1 ? round_up(dim * 2, 16) : (shadow_ >= 2 ? round_up(dim, 16) : 0);
   uid = g_uid++;
   HIP_CHECK(hipGetDevice(&device));
@@ -482,7 +486,12 @@ bool FlatIndex::ensure_shadow8g() {
   }
   float want = gmax > 0.0f ? gmax / 127.0f : 1.0f;
   uint16_t inv_bits = 0;
-  if (h8_) {  // the scale of the in-flight quantiser is 1 / inv, inv = the largest fp16 <= 127 / max |x_i| (h8_quant.hpp)
+  float f8_inv = 0.0f;
+  if (h8_ && type == VecSimType_FLOAT32) {  // ... inv = the largest fp32 <= 127 / max |x_i|
+    f8_inv = gmax > 0.0f ? std::min(127.0f / gmax, 3.0e38f) : 127.0f;
+    while (gmax > 0.0f && (double)f8_inv * (double)gmax > 127.0) f8_inv = std::nextafterf(f8_inv, 0.0f);
+    want = 1.0f / f8_inv;
+  } else if (h8_) {  // the scale of the in-flight quantiser is 1 / inv, inv = the largest fp16 <= 127 / max |x_i| (h8_quant.hpp)
     const float target = gmax > 0.0f ? std::min(127.0f / gmax, 65504.0f) : 127.0f;
     _Float16 inv = (_Float16)target;
     memcpy(&inv_bits, &inv, 2);
@@ -495,12 +504,14 @@ bool FlatIndex::ensure_shadow8g() {
   if (!(s8g_scale_ > 0.0f) || want > s8g_scale_) {  // first build, or a row outgrew the scale: every row again
     s8g_scale_ = want;
     h8_inv_bits_ = inv_bits;
+    f8_inv_ = f8_inv;
     s8g_built_ = 0;
     const uint32_t zero2[2] = {0, 0};  // the error maxima belong to the scale
     HIP_CHECK(hipMemcpyAsync(d_s8g_stats_ + 1, zero2, sizeof zero2, hipMemcpyHostToDevice, wstream_));
   }
   if (s8g_built_ < n && h8_) {  // nothing to store: the maxima of the rows not covered yet
-    launch_h8_stats(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, h8_inv_bits_, d_s8g_stats_, wstream_);
+    if (type == VecSimType_FLOAT32) launch_f8_stats(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, f8_inv_, d_s8g_stats_, wstream_);
+    else launch_h8_stats(d_rows_, stride_, (uint32_t)dim, s8g_built_, n, h8_inv_bits_, d_s8g_stats_, wstream_);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(wstream_));
     s8g_built_ = n;

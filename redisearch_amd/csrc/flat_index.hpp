@@ -293,6 +293,7 @@ class FlatIndex {
   // the fp16 inverse scale h8_inv_bits_ (s8g_scale_ = 1 / float(inv)).  Everything else of the int8 route is shared.
   bool h8_ = false;
   uint16_t h8_inv_bits_ = 0;
+  float f8_inv_ = 0.0f;  // (h8_ on a FLOAT32 index -- knob gemm_qs_f8: the fp32 inverse scale of f8_quant1)
   bool s8g_enabled() const { return d_s8g_stats_ != nullptr; }
   const uint8_t *s8g_rows() const { return shadow_ == 3 ? d_shadow_ : (h8_ ? d_rows_ : d_s8g_f32_); }
   size_t s8g_stride() const { return round_up(dim, 16); }

@@ -730,10 +730,13 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_f32_kernel(QsArgs g) {
 // wave then reads plain int8 fragments -- one ds_read_b128 per matrix instruction, no VALU in the matrix stream -- against its
 // register-stationary int8 queries.  One barrier per tile; eight waves (two per SIMD) so that one wave's barrier / memory waits are the
 // other's matrix time.  LDS traffic per tile: 24 KiB written + NW x 24 KiB read (the DMA form: 48 written + NW x 48 read).
-template <int KS, int QB, int D>
+// SRC_F8 (fp32 rows, the RediSearch default type): the same kernel -- a 16-byte chunk holds four elements instead of eight and becomes
+// one dword of the int8 tile (f8_quant4: four v_fma_f32 + three v_perm_b32); twice the chunks per tile and thread.
+enum : int { SRC_F8 = 2 };
+template <int KS, int QB, int D, int SRC = SRC_H8>
 __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
   constexpr int NW = 8 / QB, NT = 64 * NW;
-  constexpr int FC = 4 * KS;             // fp16 chunks per row
+  constexpr int FC = (SRC == SRC_F8 ? 8 : 4) * KS;  // source chunks per row (a k-step is 32 elements)
   constexpr int CPT = 32 * FC / NT;      // chunks per thread and tile
   static_assert(CPT * NT == 32 * FC, "a tile is a whole number of chunks per thread");
   constexpr int RS = (2 * KS + 15) / 16 * 16;  // int8 row stride in 16-byte chunks (the swizzle needs whole groups of 16)
@@ -767,24 +770,42 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
                : (lim <= -2147483520.0f ? (int)0x80000000 : (int)floorf(lim));
   }
   const uint32_t inv2 = g.inv_h2;
+  const float invf = __uint_as_float(g.inv_h2);  // SRC_F8: the fp32 inverse scale travels in the same field
 
   const uint32_t n = g.row_end - g.row_begin;
   const uint32_t n_tiles = (n + 31) / 32;
   const uint32_t mine = n_tiles > blockIdx.x ? (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   const uint32_t row_first = g.row_begin + blockIdx.x * 32, row_step = gridDim.x * 32, row_end = g.row_end;
 
-  // chunk c = tid + NT j of a tile: row c / FC, fp16 chunk c % FC -> the 8 bytes at int8 chunk (cc / 2) ^ (row & 15), half cc & 1
-  uint32_t woff[CPT];
+  // chunk c = tid + NT j of a tile: row c / FC, source chunk c % FC -> fp16: the 8 bytes at int8 chunk (cc / 2) ^ (row & 15), half
+  // cc & 1; fp32: the 4 bytes at int8 chunk (cc / 4) ^ (row & 15), quarter cc & 3.  The fp16 form keeps the CPT offsets in
+  // registers; the fp32 form (twice the chunks, twice the ring) recomputes them -- FC = 2^s or 3 * 2^s: a shift and, for the
+  // factor three, (x * 171) >> 9 (exact below 384) -- the twelve registers are the difference between fitting 256 and spilling.
+  constexpr bool kKeepOff = SRC != SRC_F8;
+  constexpr int FS = (FC % 3 == 0) ? __builtin_ctz(FC / 3) : __builtin_ctz(FC);
+  auto off_of = [&](int j) {
+    const uint32_t c = tid + NT * j;
+    const uint32_t rr = (FC % 3 == 0) ? (((c >> FS) * 171u) >> 9) : (c >> FS), cc = c - rr * FC;
+    return SRC == SRC_F8 ? 16u * (rr * RS + ((cc >> 2) ^ (rr & 15u))) + 4u * (cc & 3u)
+                         : 16u * (rr * RS + ((cc >> 1) ^ (rr & 15u))) + 8u * (cc & 1u);
+  };
+  uint32_t woff[kKeepOff ? CPT : 1];
+  if constexpr (kKeepOff) {
 #pragma unroll
-  for (int j = 0; j < CPT; j++) {
-    const uint32_t c = tid + NT * j, rr = c / FC, cc = c - rr * FC;
-    woff[j] = 16u * (rr * RS + ((cc >> 1) ^ (rr & 15u))) + 8u * (cc & 1u);
+    for (int j = 0; j < CPT; j++) woff[j] = off_of(j);
   }
   // (a ragged last tile reads up to 31 rows past row_end: allocated by the launch_gemm_qs contract, multiplied, never emitted)
-  auto tile_src = [&](uint32_t i) { return g.rows + (size_t)(row_first + i * row_step) * FC + tid; };
+  // a tile's first byte (wave-uniform: an SGPR pair); the thread's chunk j of it lies 16 (tid + NT j) bytes behind -- SGPR base +
+  // 32-bit VGPR offset, so that the CPT addresses of a tile cost one register and an add each, not a 64-bit pair each
+  auto tile_src = [&](uint32_t i) { return g.rows + (size_t)(row_first + i * row_step) * FC; };
+  const uint32_t toff = 16u * tid;
   auto quant_store = [&](const u4 &x, uint32_t buf, int j) {
-    const uint32_t t0 = h8_quant2(x[0], inv2), t1 = h8_quant2(x[1], inv2), t2 = h8_quant2(x[2], inv2), t3 = h8_quant2(x[3], inv2);
-    *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(smem) + buf * (TILE * 16) + woff[j]) = make_uint2(h8_pack4(t0, t1), h8_pack4(t2, t3));
+    if constexpr (SRC == SRC_F8) {
+      *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(smem) + buf * (TILE * 16) + off_of(j)) = f8_quant4(x, invf);
+    } else {
+      const uint32_t t0 = h8_quant2(x[0], inv2), t1 = h8_quant2(x[1], inv2), t2 = h8_quant2(x[2], inv2), t3 = h8_quant2(x[3], inv2);
+      *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(smem) + buf * (TILE * 16) + woff[j]) = make_uint2(h8_pack4(t0, t1), h8_pack4(t2, t3));
+    }
   };
 
   // The ring: tiles i+1 .. i+D of this workgroup, on their way from HBM.  Loads and their waits are inline asm: hipcc's own
@@ -793,13 +814,15 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
   // issued after it may still be outstanding -- requests retire in order; the candidate stores of the epilogue (asm as well)
   // can only make the wait conservative.  The "+v" operand ties every consumer to its wait.
   u4 R[D][CPT];
-  auto ld = [&](u4 &dst, const u4 *src) { asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(dst) : "v"(src) : "memory"); };
+  auto ld = [&](u4 &dst, const u4 *tile, int j) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(dst) : "v"(toff + 16u * NT * (uint32_t)j), "s"(tile) : "memory");
+  };
   auto use = [&](u4 &reg) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(D * CPT - 1) : "memory"); };
   // prologue: tile 0 straight through, tiles 1 .. D requested (a workgroup with fewer tiles re-reads its last one)
   if (mine) {
     const u4 *src = tile_src(0);
 #pragma unroll
-    for (int j = 0; j < CPT; j++) ld(R[0][j], src + NT * j);
+    for (int j = 0; j < CPT; j++) ld(R[0][j], src, j);
 #pragma unroll
     for (int j = 0; j < CPT; j++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0][j])::"memory");
 #pragma unroll
@@ -809,7 +832,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
   for (int d = 0; d < D; d++) {
     const u4 *src = tile_src((uint32_t)(1 + d) < mine ? 1 + d : (mine ? mine - 1 : 0));
 #pragma unroll
-    for (int j = 0; j < CPT; j++) ld(R[d][j], src + NT * j);
+    for (int j = 0; j < CPT; j++) ld(R[d][j], src, j);
   }
   // (drained once, here: hipcc may MOVE the ring's registers between this prologue and the loop -- it believes they hold their
   // values since the asm -- and a register copied while its load is in flight carries the old bits: tiles 1 .. D went wrong)
@@ -834,12 +857,23 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
 #pragma unroll
     for (int nb = 0; nb < QB; nb++) asm volatile("" : "+a"(acc[nb]));
     constexpr int EVERY = KS / CPT > 0 ? KS / CPT : 1;  // k-steps between two chunks of the next tile
+    auto frag = [&](int ks) {
+      return *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(smem) + (tbase - lds_base) + 256u * (uint32_t)(ks >> 3) +
+                                           ((32u * (uint32_t)(ks & 7)) ^ t16));
+    };
+    // fragments two k-steps ahead, the order pinned per k-step: left alone hipcc hoists a dozen ds_read_b128 to the top of the tile
+    // (48 registers) -- with the fp32 form's twelve chunks per tile that spilled ring registers at dim 768
+    constexpr int PF = 2;
+    u4 fq[PF];
+#pragma unroll
+    for (int p = 0; p < PF; p++) fq[p] = frag(p < KS ? p : KS - 1);
 #pragma unroll
     for (int ks = 0; ks < KS; ks++) {
-      const u4 f = *reinterpret_cast<const u4 *>(reinterpret_cast<const char *>(smem) + (tbase - lds_base) + 256u * (uint32_t)(ks >> 3) +
-                                                 ((32u * (uint32_t)(ks & 7)) ^ t16));
+      const u4 f = fq[ks % PF];
 #pragma unroll
       for (int nb = 0; nb < QB; nb++) acc[nb] = mfma<KT_I8>(f, Q[nb][ks], acc[nb]);
+      if (ks + PF < KS) fq[ks % PF] = frag(ks + PF);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < CPT; j++)
         if (j * EVERY == ks || (KS < CPT && ks == 0)) {
@@ -849,7 +883,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
           __builtin_amdgcn_sched_barrier(0);  // (pinned: hipcc hoists all CPT conversions to the top of the tile and drains vmcnt there)
           use(regs[j]);
           quant_store(regs[j], buf ^ 1u, j);
-          ld(regs[j], src + NT * j);
+          ld(regs[j], src, j);
           __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1087,6 +1121,26 @@ bool launch_gemm_qs_h8(const void *rows, const void *queries_i8, uint32_t stride
     case 48: launch_qs_h8_shape<12, 6>(g, grid, s); return true;
     case 32: launch_qs_h8_shape<8, 8>(g, grid, s); return true;
     case 16: launch_qs_h8_shape<4, 8>(g, grid, s); return true;
+    default: return false;
+  }
+}
+
+// ---- FLOAT32 rows quantised to int8 once per workgroup (gemm_qs_h8r_kernel<.., SRC_F8>): stride16 = fp32 chunks per row
+bool gemm_qs_f8_supported(uint32_t stride16) { return stride16 == 192 || stride16 == 128 || stride16 == 96 || stride16 == 64 || stride16 == 32; }
+bool launch_gemm_qs_f8(const void *rows, const void *queries_i8, uint32_t stride16, uint32_t row_begin, uint32_t row_end, const float *tau,
+                       uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *qscale, float inv) {
+  if (row_end <= row_begin || !gemm_qs_f8_supported(stride16) || !qscale) return false;
+  uint32_t inv_bits;
+  memcpy(&inv_bits, &inv, 4);
+  QsArgs g{(const u4 *)rows, (const u4 *)queries_i8, row_begin, row_end, tau, sub_count, (uint2 *)sub_cand, sub_cap, qscale, nullptr, nullptr, inv_bits};
+  const uint32_t grid = gemm_qs_grid(row_end - row_begin);
+  // (ONE tile in flight per thread: an fp32 tile is 96 KiB -- what two fp16 tiles are -- and two of them do not fit 256 registers)
+  switch (stride16) {  // KS = dim / 32 = stride16 / 8
+    case 192: hipLaunchKernelGGL((gemm_qs_h8r_kernel<24, 1, 1, SRC_F8>), dim3(grid), dim3(512), 0, s, g); return true;
+    case 128: hipLaunchKernelGGL((gemm_qs_h8r_kernel<16, 1, 1, SRC_F8>), dim3(grid), dim3(512), 0, s, g); return true;
+    case 96: hipLaunchKernelGGL((gemm_qs_h8r_kernel<12, 1, 1, SRC_F8>), dim3(grid), dim3(512), 0, s, g); return true;
+    case 64: hipLaunchKernelGGL((gemm_qs_h8r_kernel<8, 1, 1, SRC_F8>), dim3(grid), dim3(512), 0, s, g); return true;
+    case 32: hipLaunchKernelGGL((gemm_qs_h8r_kernel<4, 1, 1, SRC_F8>), dim3(grid), dim3(512), 0, s, g); return true;
     default: return false;
   }
 }

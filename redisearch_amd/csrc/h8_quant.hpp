@@ -30,4 +30,17 @@ __device__ __forceinline__ uint32_t h8_quant2(uint32_t x2, uint32_t inv2) {
 // bytes 0 and 2 of lo, bytes 0 and 2 of hi -> one dword of four int8 (element order kept)
 __device__ __forceinline__ uint32_t h8_pack4(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x06040200u); }
 
+// ---- the same for FLOAT32 rows (gemm_qs_h8r_kernel<.., SRC_F8>): q(x) = low byte of the fp32 bits of fma(x, inv, 1.5 * 2^23) -- fp32
+// values in [2^23, 2^24) have ulp 1, the fused multiply-add rounds x * inv to the nearest-even integer v in [-127, 127] and the
+// mantissa's low byte is v in two's complement.  inv = the largest fp32 <= 127 / max |x_i|.  Four elements (one 16-byte chunk)
+// -> one dword of four int8: four v_fma_f32 + three v_perm_b32.
+typedef uint32_t h8_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t f8_quant1(uint32_t x, float inv) { return __float_as_uint(__builtin_fmaf(__uint_as_float(x), inv, 12582912.0f)); }
+__device__ __forceinline__ uint32_t f8_quant4(const h8_u4 &x, float inv) {
+  const uint32_t t0 = f8_quant1(x[0], inv), t1 = f8_quant1(x[1], inv), t2 = f8_quant1(x[2], inv), t3 = f8_quant1(x[3], inv);
+  const uint32_t lo = __builtin_amdgcn_perm(t1, t0, 0x0c0c0400u);  // {t0.b0, t1.b0, 0, 0}
+  const uint32_t hi = __builtin_amdgcn_perm(t3, t2, 0x04000c0cu);  // {0, 0, t2.b0, t3.b0}
+  return lo | hi;
+}
+
 }  // namespace rsgpu

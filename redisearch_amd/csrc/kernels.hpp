@@ -144,6 +144,8 @@ struct ScanTuning {
                            // int8 matrix cores -- no stored shadow.  5 (default) = once per workgroup, register-staged (gemm_qs_h8r_kernel, 2.91 ms
                            // per configs[2] pass); 2 / 1 = in every wave, behind the LDS-DMA ring (four waves x 64 queries 3.87 ms / eight x 32
                            // 4.29 ms); 3 / 4 = 2 with smaller ring slots (4.14 / 4.61 ms); 0 = the fp16 MFMA pass (3.96 ms)
+  int gemm_qs_f8 = 0;      // FLOAT32 IP / cosine indexes: the batched / coalesced passes quantise the fp32 rows to int8 in flight (gemm_qs_h8r_kernel<..,
+                           // SRC_F8>) instead of rounding them to bf16 (gemm_qs_f32_kernel); read at index creation and at query time
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range
@@ -316,6 +318,13 @@ void launch_convert_queries_bf16(const void *queries, size_t qstride, uint32_t d
 bool gemm_qs_h8_supported(uint32_t stride16);
 bool launch_gemm_qs_h8(const void *rows, const void *queries_i8, uint32_t stride16, uint32_t row_begin, uint32_t row_end, const float *tau,
                        uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *qscale, uint16_t inv_h_bits);
+// ... and over FLOAT32 rows (gemm_qs_h8r_kernel<.., SRC_F8>; stride16 = fp32 chunks per row in {32, 64, 96, 128, 192}; inv: the fp32
+// inverse scale of launch_f8_stats)
+bool gemm_qs_f8_supported(uint32_t stride16);
+bool launch_gemm_qs_f8(const void *rows, const void *queries_i8, uint32_t stride16, uint32_t row_begin, uint32_t row_end, const float *tau,
+                       uint32_t *sub_count, void *sub_cand, uint32_t sub_cap, hipStream_t s, const float *qscale, float inv);
+void launch_f8_stats(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float inv, uint32_t *stats,
+                     hipStream_t s);
 // stats[1] = max |x8|^2, stats[2] = max |ex|^2 (f32 bits) over FLOAT16 rows [row_begin, row_end) under THAT quantiser (atomicMax)
 void launch_h8_stats(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint16_t inv_h_bits,
                      uint32_t *stats, hipStream_t s);

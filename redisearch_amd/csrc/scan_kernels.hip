@@ -598,6 +598,42 @@ __global__ __launch_bounds__(256) void h8_stats_kernel(const u4 *__restrict__ ro
   (void)dim;
 }
 
+// ... and of the fp32 form (f8_quant1): x8 from the very instruction the pass executes, ex = x * inv - x8 (one fma)
+__global__ __launch_bounds__(256) void f8_stats_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t dim, uint32_t row_begin,
+                                                       uint32_t row_end, float inv, uint32_t *__restrict__ stats) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t n8_max = 0;
+  float ne_max = 0.0f;
+  for (uint32_t r = row_begin + blockIdx.x * 4 + wave; r < row_end; r += gridDim.x * 4) {
+    const u4 *src = rows + (size_t)r * stride16;
+    uint32_t n8 = 0;
+    float ne = 0.0f;
+    for (uint32_t c = lane; c < stride16; c += 64) {
+      const u4 x = src[c];
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int v = (int)(int8_t)(f8_quant1(w[j], inv) & 0xffu);
+        const float e = __builtin_fmaf(__uint_as_float(w[j]), inv, -(float)v);
+        n8 += (uint32_t)(v * v);
+        ne = fmaf(e, e, ne);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      n8 += __shfl_xor(n8, o, 64);
+      ne += __shfl_xor(ne, o, 64);
+    }
+    n8_max = n8 > n8_max ? n8 : n8_max;
+    ne_max = fmaxf(ne_max, ne);
+  }
+  if (lane == 0) {
+    atomicMax(stats + 1, n8_max);
+    atomicMax(stats + 2, __float_as_uint(ne_max));
+  }
+  (void)dim;
+}
+
 // The 256 queries of a pass (fp16, already normalised for cosine) -> int8 with their own scales; qscale[q] = s sq
 // (distance = 1 - qscale * integer dot) and slack[q] >= 2 E_q, E_q >= |shadow distance - fp32 distance of the fp16 row|:
 // the Cauchy-Schwarz band above (x 1.001 for the fp32 arithmetic that computes it) plus the rounding of both distance
@@ -849,6 +885,13 @@ void launch_shadow8g_rows(int type, const void *rows, size_t stride, uint32_t di
   else
     hipLaunchKernelGGL(shadow8g_rows_kernel<_Float16>, grid, block, 0, s, (const _Float16 *)rows, (uint32_t)(stride / 2), dim,
                        row_begin, row_end, scale, (int8_t *)shadow, (uint32_t)sstride, stats);
+}
+void launch_f8_stats(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, float inv, uint32_t *stats,
+                     hipStream_t s) {
+  if (row_end <= row_begin) return;
+  const uint32_t n = row_end - row_begin, need = (n + 3) / 4, cap = (uint32_t)(scan_tuning().num_cus * 8);
+  hipLaunchKernelGGL(f8_stats_kernel, dim3(need < cap ? need : cap), dim3(256), 0, s, (const u4 *)rows, (uint32_t)(stride / 16), dim, row_begin,
+                     row_end, inv, stats);
 }
 void launch_h8_stats(const void *rows, size_t stride, uint32_t dim, uint32_t row_begin, uint32_t row_end, uint16_t inv_h_bits,
                      uint32_t *stats, hipStream_t s) {

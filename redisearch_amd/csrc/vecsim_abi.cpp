@@ -707,6 +707,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_qs")) scan_tuning().gemm_qs = value;
   else if (!strcmp(key, "gemm_qs_f32")) scan_tuning().gemm_qs_f32 = value;
   else if (!strcmp(key, "gemm_qs_h8")) scan_tuning().gemm_qs_h8 = value;
+  else if (!strcmp(key, "gemm_qs_f8")) scan_tuning().gemm_qs_f8 = value;
   else if (!strcmp(key, "shard_exchange")) scan_tuning().shard_exchange = value;
   else if (!strcmp(key, "hybrid_dir")) scan_tuning().hybrid_dir = value;
   else if (!strcmp(key, "hybrid_poll")) scan_tuning().hybrid_poll = value;

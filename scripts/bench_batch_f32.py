@@ -19,7 +19,10 @@ k = int(os.environ.get("K", 100))
 reps = int(os.environ.get("REPS", 8))
 torch.cuda.set_device(0)
 lib = V.load()
-out = {"rows": rows, "dim": dim, "k": k}
+for kv in filter(None, os.environ.get("TUNING", "").split(",")):   # TUNING="gemm_qs_f8=1": any engine knob (read at index creation too)
+    key, val = kv.split("=")
+    assert lib.RSGPU_SetTuning(key.encode(), int(val)) == 0, kv
+out = {"rows": rows, "dim": dim, "k": k, "tuning": os.environ.get("TUNING", "")}
 for mname, metric in (("cosine", V.VecSimMetric_Cosine), ("l2", V.VecSimMetric_L2)):
     if os.environ.get("METRICS") and mname not in os.environ["METRICS"]:
         continue
@@ -57,4 +60,4 @@ for mname, metric in (("cosine", V.VecSimMetric_Cosine), ("l2", V.VecSimMetric_L
     idx.free()
     lib.RSGPU_ReleaseWorkspaces()
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r04_batch_f32.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/batch_f32%s.json" % os.environ.get("OUT_TAG", ""), "w"), indent=1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ISA lint of gemm_qs_h8r_kernel (no GPU needed): the kernel keeps tiles in flight in registers that hipcc believes were written
 by the inline-asm load at its issue.  That is only sound if, INSIDE the tile loop, nothing but (a) the asm load itself writes a ring
-register and (b) nothing reads one except the quantiser's v_pk_fma_f16 behind an s_waitcnt vmcnt -- in particular no v_mov /
+register and (b) nothing reads one except the quantiser's v_pk_fma_f16 / v_fma_f32 behind an s_waitcnt vmcnt -- in particular no v_mov /
 v_accvgpr copy of a ring register (a copy made while the load is in flight carries stale bits).  Prints one line per kernel and
 exits 1 on a violation.  tests/test_isa_lint_cpu.py runs it."""
 import os
@@ -54,7 +54,7 @@ def lint(name, body):
             stores = mn.startswith(("global_store", "ds_write", "buffer_store", "scratch_store"))
             dst = set() if stores else regs_of(ops[0])
             srcs = set().union(*[regs_of(o) for o in (ops if stores else ops[1:])]) if ops else set()
-            if mn == "v_pk_fma_f16":
+            if mn in ("v_pk_fma_f16", "v_fma_f32"):   # the quantisers (fp16 / fp32 rows)
                 flight -= srcs          # consumed (behind its s_waitcnt vmcnt)
                 continue
             if trip == 1 and dst & flight:
@@ -102,8 +102,17 @@ def main():
                 results.append((cur, 0, ["no backward branch found"]))
                 ok = False
                 return
-            end, target = max(back, key=lambda bt: body[bt[0]][2] - bt[1])   # the longest backward span: the tile loop
-            start = next(i for i, (_, _, a) in enumerate(body) if a == target)
+            # the tile loop: the longest backward span that starts BEHIND the prologue's barrier (block placement may add longer
+            # jumps back into the prologue)
+            first_barrier = next(i for i, (mn, _, _) in enumerate(body) if mn == "s_barrier")
+            idx_of = {a: i for i, (_, _, a) in enumerate(body) if a is not None}
+            back = [(i, t) for i, t in back if t in idx_of and idx_of[t] > first_barrier]
+            if not back:
+                results.append((cur, 0, ["no tile loop found behind the prologue"]))
+                ok = False
+                return
+            end, target = max(back, key=lambda bt: body[bt[0]][2] - bt[1])
+            start = idx_of[target]
             ring, bad = lint(cur, [(mn, ops) for mn, ops, _ in body[start:end + 1]])
             bad += lint_prologue([(mn, ops) for mn, ops, _ in body[:start]])
             results.append((cur, ring, bad))
@@ -127,8 +136,8 @@ def main():
         body.append((mn, ops, addr))
     flush()
     for name, nring, bad in results:
-        short = re.search(r"gemm_qs_h8r_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
-        tag = "gemm_qs_h8r_kernel<%s,%s,%s>" % short.groups() if short else name
+        short = re.search(r"gemm_qs_h8r_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        tag = "gemm_qs_h8r_kernel<%s,%s,%s,%s>" % short.groups() if short else name
         print("%-36s registers in flight %3d  %s" % (tag, nring, "OK" if not bad else "VIOLATIONS: " + "; ".join(sorted(set(bad))[:6])))
     if not results:
         print("no gemm_qs_h8r_kernel in the object")

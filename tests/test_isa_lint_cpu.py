@@ -57,5 +57,6 @@ def test_h8r_ring_registers_are_never_touched_in_flight():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_lint_h8r.py")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("gemm_qs_h8r_kernel")]
-    assert len(lines) >= 5 and all(ln.rstrip().endswith("OK") for ln in lines), p.stdout
-    assert "gemm_qs_h8r_kernel<24,1,2>" in p.stdout and "registers in flight  48" in p.stdout   # 2 tiles x 6 chunks x 4 dwords
+    assert len(lines) >= 10 and all(ln.rstrip().endswith("OK") for ln in lines), p.stdout    # fp16 and fp32 rows, five widths each
+    assert "gemm_qs_h8r_kernel<24,1,2,1>" in p.stdout and "registers in flight  48" in p.stdout   # 2 tiles x 6 chunks x 4 dwords
+    assert "gemm_qs_h8r_kernel<24,1,1,2>" in p.stdout                                             # fp32 rows: 1 tile x 12 chunks

@@ -150,14 +150,15 @@ def test_general_hybrid_tile_kernel_budget(kernels):
 
 
 def test_register_staged_int8_pass_budget(kernels):
-    """gemm_qs_h8r_kernel<KS, 1, 2> (round 6, BASELINE configs[2]'s default pass): eight waves = two per SIMD (<= 256 registers),
-    NO spill and no scratch -- a spilled ring register would be copied while its load is in flight (scripts/isa_lint_h8r.py holds
-    the ISA to that) -- and an int8 double buffer of at most 48 KiB."""
+    """gemm_qs_h8r_kernel<KS, 1, D, SRC> (round 6; SRC 1: fp16 rows, BASELINE configs[2]'s default pass, two tiles in flight; SRC 2:
+    fp32 rows, one 96 KiB tile in flight): eight waves = two per SIMD (<= 256 registers), NO spill and no scratch -- a spilled ring
+    register would be copied while its load is in flight (scripts/isa_lint_h8r.py holds the ISA to that) -- and an int8 double
+    buffer of at most 48 KiB."""
     qs = [k for k in kernels if k["name"].startswith("gemm_qs_h8r_kernel<")]
-    assert len(qs) == 5                   # five row widths
+    assert len(qs) == 10                  # five row widths x {fp16, fp32} rows
     for k in qs:
-        ks, qb, d = (int(x) for x in re.match(r"gemm_qs_h8r_kernel<(\d+), (\d+), (\d+)", k["name"]).groups())
-        assert (qb, d) == (1, 2)
+        ks, qb, d, src = (int(x) for x in re.match(r"gemm_qs_h8r_kernel<(\d+), (\d+), (\d+), (\d+)", k["name"]).groups())
+        assert (qb, d, src) in ((1, 2, 1), (1, 1, 2)), k["name"]
         assert not k["vgpr_spill"] and not k["scratch"], k["name"]
         assert k["wg"] == 512 and k["vgpr"] <= 256, (k["name"], k["vgpr"])
         assert k["lds"] <= 49152, (k["name"], k["lds"])
