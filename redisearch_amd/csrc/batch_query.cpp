@@ -394,9 +394,17 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     std::vector<uint8_t> l2_redo[2];  // per slot: queries of the batch the L2 pass leaves to the exact scan
 
     // everything of batch q0.. onto the slot's stream, nothing waited for
+    // (RSGPU_DEBUG_SYNC=1: wait after every step and name it on stderr -- which kernel of the pipeline faulted)
+    static const bool dbg_sync = getenv("RSGPU_DEBUG_SYNC") != nullptr;
     auto enqueue = [&](int sl, size_t q0) {
       BatchScratch &sc = tls_batch[sl];
       QueryCtx *c = ctxs[sl];
+      auto dbg = [&](const char *what) {
+        if (!dbg_sync) return;
+        fprintf(stderr, "[batch] %s ...", what);
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+      };
       const uint32_t nb = (uint32_t)std::min<size_t>(kBatch, n_queries - q0);
       uint8_t *hq = static_cast<uint8_t *>(sc.hq.p);
       memset(hq, 0, (size_t)kBatch * stride_);  // unused query rows stay zero (their results are ignored)
@@ -419,6 +427,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       if (via_shadow8) {  // int8 copies of the queries with their own scales + the per-query error band
         launch_quantize_queries(ktype, sc.queries.p, stride_, (uint32_t)dim, kBatch, s8g_scale_, d_s8g_stats_, sc.queries16.p,
                                 s8g_stride(), sc.qscale.p, sc.slack_q.p, c->stream);
+        dbg("quantize_queries");
         g_queries = sc.queries16.p;
         slack_q = sc.slack_q.p;
         qscale = sc.qscale.p;
@@ -495,11 +504,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                           : launch_gemm_qs(g_type, g_rows, g_queries, stride16, from, e, sc.tau.p, sc.sub_count.p, sc.sub_cand.p, sub_cap,
                                            c->stream, qscale, l2_hn, l2_hq)))
               throw std::runtime_error("batched pass: the matrix-core kernel refused a row shape the route was gated on");
+            dbg("filter pass");
             launch_compact_cand(sc.sub_count.p, sc.sub_cand.p, sub_cap, gemm_qs_grid(e - from), sc.cand_count.p,
                                 sc.cand.p, cand_cap, ph > 0, c->stream, via_l2 ? &rb : nullptr);
+            dbg("compact");
             if (ph + 1 < phase_end.size())
               launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
                                           c->stream, slack, slack_q);
+            dbg("threshold");
             from = e;
           }
         }
@@ -512,6 +524,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                                     sc.tau.p, c->stream, via_shadow8 || via_l2 || via_h16 ? ktype : KT_F32, via_l2 ? KM_L2 : KM_IP,
                                     via_l2 ? &rb : nullptr))
             throw std::runtime_error("batched shadow pass: the re-scoring kernel refused a row shape the route was gated on");
+          dbg("rescore");
         }
         launch_batch_select_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, sc.out_rows.p, sc.out_keys.p,
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);

@@ -888,6 +888,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
         }
     }
     const uint32_t xr0 = row_first + i * row_step + 4 * h;
+    bool stored = false;
 #pragma unroll
     for (int nb = 0; nb < QB; nb++) {
       int m = max3i(acc[nb][0], acc[nb][1], acc[nb][2]);
@@ -911,6 +912,7 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
                   const uint2 *dst = list + cur[nb];
                   const uint2 val = make_uint2(xr, __float_as_uint(d));
                   asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(dst), "v"(val) : "memory");
+                  stored = true;
                 }
                 cur[nb]++;
               }
@@ -923,7 +925,15 @@ __global__ __launch_bounds__(512 / QB, 1) void gemm_qs_h8r_kernel(QsArgs g) {
     // re-used v[2:3] -- dead to it, in flight in fact -- for the pointer of the final store, the load landed on it and the store
     // went to a wild address (MEMORY_APERTURE_VIOLATION); a wave that ENDS under its loads faults as well.  Drained here, in
     // the workgroup's last tile, where the ring is still live to the compiler (it cannot know this trip is the last).
-    if (i + 1 == mine) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // A wave that stored candidates waits for them: vmcnt counts loads and stores alike, loads return in order among themselves
+    // but a younger store may retire before an older load -- with stores in the queue the counted waits of the next tile could
+    // pass before the register they guard has landed.  Drained, the counts are exact again; only the waves with a hit pay.
+    if (i + 1 == mine || __builtin_amdgcn_ballot_w64(stored) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and the ring is LIVE to the compiler up to here, in every trip: the re-requests of the last D trips are never converted --
+    // dead values to hipcc, which (peeling the last trip when one tile is in flight) parked them in registers it then used for
+    // this epilogue's store pointers; the load landed on the pointer and the store went wild (MEMORY_APERTURE_VIOLATION).
+#pragma unroll
+    for (int j = 0; j < CPT; j++) asm volatile("" : "+v"(regs[j]));
     __syncthreads();  // buffer (i + 1) & 1 is complete, buffer i & 1 is free
   };
   for (uint32_t i = 0; i < mine; i += D) {
@@ -1100,6 +1110,7 @@ void launch_qs_h8_shape(const QsArgs &g, uint32_t grid, hipStream_t s) {
   // 5: the register-staged form (gemm_qs_h8r_kernel: quantised once per workgroup), eight waves x 32 queries, two tiles in flight
   // (four waves x 64 queries measured 7.8 ms per pass -- one wave per SIMD hides nothing here; three tiles in flight spill at dim 768)
   if (scan_tuning().gemm_qs_h8 == 5) hipLaunchKernelGGL((gemm_qs_h8r_kernel<KS, 1, 2>), dim3(grid), dim3(512), 0, s, g);
+  else if (scan_tuning().gemm_qs_h8 == 8) hipLaunchKernelGGL((gemm_qs_h8r_kernel<KS, 1, 1>), dim3(grid), dim3(512), 0, s, g);  // (A/B: one tile in flight)
   else if (scan_tuning().gemm_qs_h8 == 1) hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS, NS, 1, false, SRC_H8>), dim3(grid), dim3(512), 0, s, g);
   else if (KS == 24 && scan_tuning().gemm_qs_h8 == 3)  // (A/B: K-part slots of 24 KiB, a ring of six)
     hipLaunchKernelGGL((gemm_qs_f32_kernel<KS, KS == 24 ? 12 : KS, KS == 24 ? 6 : NS, 2, false, SRC_H8>), dim3(grid), dim3(256), 0, s, g);

@@ -144,8 +144,9 @@ struct ScanTuning {
                            // int8 matrix cores -- no stored shadow.  5 (default) = once per workgroup, register-staged (gemm_qs_h8r_kernel, 2.91 ms
                            // per configs[2] pass); 2 / 1 = in every wave, behind the LDS-DMA ring (four waves x 64 queries 3.87 ms / eight x 32
                            // 4.29 ms); 3 / 4 = 2 with smaller ring slots (4.14 / 4.61 ms); 0 = the fp16 MFMA pass (3.96 ms)
-  int gemm_qs_f8 = 0;      // FLOAT32 IP / cosine indexes: the batched / coalesced passes quantise the fp32 rows to int8 in flight (gemm_qs_h8r_kernel<..,
-                           // SRC_F8>) instead of rounding them to bf16 (gemm_qs_f32_kernel); read at index creation and at query time
+  int gemm_qs_f8 = 1;      // FLOAT32 IP / cosine indexes: the batched / coalesced passes quantise the fp32 rows to int8 in flight (gemm_qs_h8r_kernel<..,
+                           // SRC_F8>: 5.48 ms per 256-query pass over 10M x 768, 0.70 of HBM) instead of rounding them to bf16 (gemm_qs_f32_kernel:
+                           // 6.15 ms); read at index creation and at query time; 0 = the bf16 route
   int qs_phases = 0;       // batched pass: 4 = one more, shorter first filter phase (A/B knob)
   int qs_force_i8 = 0;     // timing experiment: run the query-stationary pass with the int8 MFMA over whatever bytes are there
   int vmm = 1;             // row matrices above 256 MiB grow by mapping physical chunks behind a reserved virtual range

@@ -40,6 +40,30 @@ def main():
     hqs = [S.HybridQuery(g, table, "BM25STD", idf, idf, [1.0, 1.0], n_docs, avg, top_n=10, index=idx, q=qs[t], k=10) for t in range(16)]
     import gc
     gc.disable()
+    # pthread callers through the plain C ABI (examples/concurrent_hybrid_callers.c): what a C module's worker pool pays -- no
+    # interpreter between two calls
+    import ctypes as C
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "redisearch_amd", "lib")
+    so = os.path.join(tempfile.mkdtemp(prefix="rs_hcallers_"), "libhybrid_callers.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "concurrent_hybrid_callers.c"),
+                           "-L" + libdir, "-lVectorSimilarity", "-Wl,-rpath," + libdir, "-lpthread", "-o", so])
+    cl = C.CDLL(so)
+    cl.rs_hybrid_callers_run.restype = C.c_long
+    cl.rs_hybrid_callers_run.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_double)]
+    blocks = (C.c_void_p * len(hqs))(*[C.addressof(h.args) for h in hqs])
+    for threads in (1, 2, 4, 8, 16):
+        cap = 100000
+        lat = np.zeros((threads, cap), np.uint64)
+        counts = np.zeros(threads, np.uint64)
+        el = C.c_double(0)
+        total = cl.rs_hybrid_callers_run(blocks, len(hqs), threads, 1.0, lat.ctypes.data_as(C.c_void_p), cap, counts.ctypes.data_as(C.c_void_p), C.byref(el))
+        allv = np.concatenate([lat[t, :int(min(counts[t], cap))] for t in range(threads)]).astype(np.float64) / 1e6
+        print(json.dumps({"driver": "C pthreads", "threads": threads, "queries": int(total), "qps": total / el.value,
+                          "p50_ms": float(np.percentile(allv, 50)), "p95_ms": float(np.percentile(allv, 95))}), flush=True)
+    if os.environ.get("C_ONLY") == "1":
+        return
     for tiles in (1, 0, 1):
         lib.RSGPU_SetTuning(b"hybrid_tiles", tiles)
         serial = []

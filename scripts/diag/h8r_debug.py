@@ -12,7 +12,7 @@ q = np.random.default_rng(dim + k).uniform(-1, 1, (300, dim)).astype(np.float16)
 g = V.VecSimIndex(V.VecSimType_FLOAT16, dim, V.VecSimMetric_IP)
 torch.cuda.synchronize(); g.add_device_rows(x.data_ptr(), n, 1)
 res = {}
-for shape in (2, 5):
+for shape in (2, 5, 8):
     lib.RSGPU_SetTuning(b"gemm_qs_h8", shape)
     res[shape] = g.topk_batch(q, k)
     for rep in range(3):
@@ -20,7 +20,7 @@ for shape in (2, 5):
         if not np.array_equal(again[0], res[shape][0]):
             print("shape", shape, "not deterministic at rep", rep, int((again[0] != res[shape][0]).sum()))
 ref = res[2][0]
-for shape in (5,):
+for shape in (5, 8):
     ids = res[shape][0]
     bad = np.argwhere((ids != ref).any(axis=1)).ravel()
     print("shape", shape, "queries differing:", bad.tolist()[:20])

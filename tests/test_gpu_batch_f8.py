@@ -20,7 +20,7 @@ def lib():
     lb = V.load()
     lb.RSGPU_SetTuning(b"gemm_qs_f8", 1)
     yield lb
-    lb.RSGPU_SetTuning(b"gemm_qs_f8", 0)
+    lb.RSGPU_SetTuning(b"gemm_qs_f8", 1)
 
 
 def check(lib, g, queries, k, want, expect_launches=None):
@@ -48,7 +48,9 @@ def test_fp32_rows_quantised_in_flight_are_bit_identical_to_single_queries(lib, 
     want = [g.topk_query(q, k).results() for q in queries]
     got = check(lib, g, queries, k, want, expect_launches=2)
     lib.RSGPU_SetTuning(b"gemm_qs_f8", 0)               # the bf16-in-flight route over the same index: the same replies
+    lib.RSGPU_ResetProfile()
     ids0, sc0, cnt0 = g.topk_batch(queries, k)
+    lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
     assert np.array_equal(ids0, got[0]) and np.array_equal(sc0, got[1]) and np.array_equal(cnt0, got[2])
     g.free()
 
@@ -87,7 +89,7 @@ def test_gaussian_rows_outliers_appends_and_deletes(lib):
     g.add_vector(queries[3] * 9.0, 9_000_000)            # a row that outgrows the scale: the maxima are taken again
     want = single()
     assert want[3][0][0] == 9_000_000
-    check(lib, g, queries, k, want, expect_launches=1)
+    check(lib, g, queries, k, want)                      # (nine times coarser levels: lists may overflow -> the exact fall-back)
     g.free()
 
 

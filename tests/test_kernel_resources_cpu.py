@@ -155,10 +155,10 @@ def test_register_staged_int8_pass_budget(kernels):
     register would be copied while its load is in flight (scripts/isa_lint_h8r.py holds the ISA to that) -- and an int8 double
     buffer of at most 48 KiB."""
     qs = [k for k in kernels if k["name"].startswith("gemm_qs_h8r_kernel<")]
-    assert len(qs) == 10                  # five row widths x {fp16, fp32} rows
+    assert len(qs) == 15                  # five row widths x {fp16 rows (two tiles / A-B: one tile in flight), fp32 rows}
     for k in qs:
         ks, qb, d, src = (int(x) for x in re.match(r"gemm_qs_h8r_kernel<(\d+), (\d+), (\d+), (\d+)", k["name"]).groups())
-        assert (qb, d, src) in ((1, 2, 1), (1, 1, 2)), k["name"]
+        assert (qb, d, src) in ((1, 2, 1), (1, 1, 1), (1, 1, 2)), k["name"]
         assert not k["vgpr_spill"] and not k["scratch"], k["name"]
         assert k["wg"] == 512 and k["vgpr"] <= 256, (k["name"], k["vgpr"])
         assert k["lds"] <= 49152, (k["name"], k["lds"])
