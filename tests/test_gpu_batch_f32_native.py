@@ -16,6 +16,16 @@ pytestmark = pytest.mark.gpu
 F32, COS, L2, IP = V.VecSimType_FLOAT32, V.VecSimMetric_Cosine, V.VecSimMetric_L2, V.VecSimMetric_IP
 
 
+@pytest.fixture(autouse=True)
+def bf16_in_flight_route():
+    """This file holds the bf16-in-flight form; since round 6 IP / cosine default to the int8-in-flight one (knob gemm_qs_f8,
+    tests/test_gpu_batch_f8.py), so the knob is off here for the indexes these tests build and query."""
+    lib = V.load()
+    lib.RSGPU_SetTuning(b"gemm_qs_f8", 0)
+    yield
+    lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
+
+
 def rows(n, dim, seed, spread=False):
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev)
