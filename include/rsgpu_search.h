@@ -214,6 +214,15 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * hits_out -- the smallest union drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees).
  * top_n / k > 64 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
+/* The hybrid coalescer (round 6; knobs "hybrid_coalesce" 1, "hybrid_coalesce_depth" 2, "hybrid_coalesce_interleave" 0 of
+ * RSGPU_SetTuning): RediSearch issues queries from a pool of worker threads (src/util/workers.c:58,104; the hybrid iterator's
+ * loop, src/iterators/hybrid_reader.c:309-327, runs on each).  Two-launch queries (path 1) of concurrent callers share tile grids: at
+ * most `depth` grids are in flight per device; a caller that arrives below that launches at once, one that arrives at it queues and is
+ * launched -- with up to six others, as ONE grid + ONE reduce launch -- by the caller whose grid finishes next.  Every query keeps
+ * its own output slots and pinned answers: replies are bit-identical to serial ones; a single caller never queues.
+ * out[0] queries launched alone, [1] shared grids, [2] queries they carried, [3] queries that queued, [4] queries that re-launched
+ * alone after a shared launch failed.  reset != 0: the counters go back to zero after they were read. */
+void RSGPU_GetHybridCoalesceStats(uint64_t out[5], int reset);
 /* diagnostics (RSGPU_SetTuning("hybrid_trace", 1)): the phase clock of every tile of the calling thread's last two-launch query,
  * out[tile * 9 + phase] readings of the 100 MHz device clock; returns the number of tiles copied (0: no trace), -1 on error */
 long RSGPU_HybridTrace(uint64_t *out, size_t cap_tiles);

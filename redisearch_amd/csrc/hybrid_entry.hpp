@@ -317,6 +317,140 @@ static void hyb_profile(bool prof, FusedEvents &ev, uint32_t n_tiles) {
   }
 }
 
+// ---- the hybrid coalescer (round 6) ----------------------------------------------------------------------------------------------
+// RediSearch runs queries from a pool of worker threads (src/util/workers.c:58,104; the hybrid iterator's loop src/iterators/
+// hybrid_reader.c:309-327 runs on each of them).  One query's grid is 2 443 tiles on ~1 536 resident workgroups -- a full round and
+// a half-empty one -- and its reduce launch waits for the last tile; from eight threads the engine plateaued at 25-26 k QPS (rounds
+// 3-5).  Here the two-launch queries of concurrent callers share grids: at most `hybrid_coalesce_depth` grids are in flight per
+// device; a caller that arrives below that depth launches at once -- alone, or together with whatever is queued -- and one that
+// arrives at it queues its description (HybJob: the tile / reduce arguments over ITS OWN scratch, pinned answers and flags) and
+// spins on its own completion flags.  Every grid has an OWNER, the first job of it; when the owner has seen its answers it takes
+// the queue (up to kHybBatchMax compatible jobs), launches them as ONE grid + ONE reduce launch on the first one's stream, and
+// returns to its caller -- nobody sleeps, nobody is woken.  A single caller never queues: its path is the one of rounds 3-5.
+// A job's query vector went up on its own stream; the launching stream waits for the event recorded behind it.  Answers are
+// bit-identical to serial ones (fixed slots per tile, total orders: tests/test_gpu_hybrid_coalesce.py).
+namespace {
+struct HybJob {
+  HybridTileLite T;
+  HybridReduceArgs R;
+  uint32_t n_tiles = 0;
+  int sig = -1;  // kernel instantiation the KNN branch needs (type * 8 + metric); -1: no KNN branch -- fits any grid
+  size_t lds = 0;
+  QueryCtx *ca = nullptr;  // its stream carries the grid this job owns; ev0 = behind the upload of its query
+  bool has_event = false;
+  bool owner = false;           // written by the launcher before state
+  std::atomic<int> state{0};    // 0 queued, 1 launched, -1 the launch failed (the member launches on its own)
+};
+struct HybCoalescer {
+  std::mutex mu;
+  std::vector<HybJob *> pending;
+  int in_flight = 0;
+  std::atomic<int> hint{0};  // in_flight, for the decision to record an event before the lock is taken
+};
+HybCoalescer *hyb_coalescer_of(int device) {
+  static HybCoalescer c[32];
+  return &c[device & 31];
+}
+struct HybCoalesceStats {
+  std::atomic<uint64_t> solo{0}, grids{0}, grid_queries{0}, queued{0}, relaunched{0};
+};
+HybCoalesceStats *hyb_coalesce_stats_ptr() {
+  static HybCoalesceStats s;
+  return &s;
+}
+#define hyb_coalesce_stats() (*hyb_coalesce_stats_ptr())
+int hyb_depth() { return std::min(std::max(scan_tuning().hybrid_coalesce_depth, 1), 8); }
+// compatible jobs off the queue, in arrival order (caller holds the lock)
+void hyb_take(HybCoalescer &co, std::vector<HybJob *> &batch, size_t room) {
+  int sig = -1;
+  for (HybJob *j : batch)
+    if (j->sig >= 0) sig = j->sig;
+  size_t w = 0;
+  for (size_t i = 0; i < co.pending.size(); i++) {
+    HybJob *j = co.pending[i];
+    if (room && (j->sig < 0 || sig < 0 || j->sig == sig)) {
+      if (j->sig >= 0) sig = j->sig;
+      batch.push_back(j);
+      room--;
+    } else {
+      co.pending[w++] = j;
+    }
+  }
+  co.pending.resize(w);
+}
+// ONE grid + ONE reduce launch for the batch, on its first job's stream; every job is told (state) whatever happens
+void hyb_launch_batch(std::vector<HybJob *> &batch) {
+  HybJob *own = batch.front();
+  hipStream_t st = own->ca->stream;
+  try {
+    std::vector<HybJob *> ord(batch);
+    std::stable_sort(ord.begin(), ord.end(), [](const HybJob *x, const HybJob *y) { return x->n_tiles < y->n_tiles; });
+    HybridTileBatch B;
+    HybridReduceBatch RB;
+    memset(&RB, 0, sizeof RB);
+    B.n_q = RB.n_q = (uint32_t)ord.size();
+    B.interleave = scan_tuning().hybrid_coalesce_interleave ? 1u : 0u;
+    size_t lds = 0;
+    int sig = -1;
+    for (size_t i = 0; i < ord.size(); i++) {
+      B.q[i] = ord[i]->T;
+      B.n_tiles[i] = ord[i]->n_tiles;
+      B.tile_end[i] = 0;
+      RB.q[i] = ord[i]->R;
+      lds = std::max(lds, ord[i]->lds);
+      if (ord[i]->sig >= 0) sig = ord[i]->sig;
+      if (ord[i]->has_event && ord[i]->ca->stream != st) HIP_CHECK(hipStreamWaitEvent(st, ord[i]->ca->ev0, 0));
+    }
+    if (!launch_hybrid_tiles_batch(B, sig >= 0 ? sig / 8 : 0, sig >= 0 ? sig % 8 : 0, lds, st))
+      throw std::runtime_error("hybrid coalescer: the shared grid was refused");
+    launch_hybrid_reduce_batch(RB, st);
+    HIP_CHECK(hipGetLastError());
+  } catch (...) {
+    for (HybJob *j : batch) {
+      j->owner = false;
+      j->state.store(-1, std::memory_order_release);
+    }
+    throw;
+  }
+  hyb_coalesce_stats().grids++;
+  hyb_coalesce_stats().grid_queries += batch.size();
+  for (HybJob *j : batch) {
+    j->owner = j == own;
+    j->state.store(1, std::memory_order_release);
+  }
+}
+// the owner of a grid has its answers: one grid fewer in flight; the queue, if any, goes up as the next one
+void hyb_grid_finished(int device) noexcept {
+  HybCoalescer &co = *hyb_coalescer_of(device);
+  std::vector<HybJob *> next;
+  {
+    std::lock_guard<std::mutex> g(co.mu);
+    co.in_flight--;
+    if (!co.pending.empty() && co.in_flight < hyb_depth()) {
+      hyb_take(co, next, (size_t)kHybBatchMax);
+      co.in_flight++;
+    }
+    co.hint.store(co.in_flight, std::memory_order_relaxed);
+  }
+  if (next.empty()) return;
+  try {
+    hyb_launch_batch(next);
+  } catch (const std::exception &e) {  // (the members were told: each launches on its own)
+    logf(nullptr, "warning", "%s", e.what());
+    std::lock_guard<std::mutex> g(co.mu);
+    co.in_flight--;
+    co.hint.store(co.in_flight, std::memory_order_relaxed);
+  }
+}
+struct HybGridOwner {  // runs the owner's duty on every way out of the query
+  HybJob &job;
+  int device;
+  ~HybGridOwner() {
+    if (job.owner) hyb_grid_finished(device);
+  }
+};
+}  // namespace
+
 // The query in two launches (hybrid_kernels.hip): for callers that do not ask for the hit list.  The caller holds the index
 // lock and has checked the shapes (hybrid_tile_supported); ca's stream carries everything, cb lends its pinned buffers to the
 // KNN answers; the prepared query is ca->d_query.  false: the reduce kernel met more candidates at its bound than it ranks
@@ -399,13 +533,103 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
   R.trace = T.trace ? T.trace + (size_t)n_tiles * kHybTracePhases : nullptr;
 
   if (prof) HIP_CHECK(hipEventRecord(ev.e[1], ca->stream));
-  if (n_tiles) {
+  auto launch_alone = [&]() {
     launch_hybrid_tiles(T, f ? f->ktype : 0, f ? f->kmetric : 0, n_tiles, ca->stream);
     if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
     launch_hybrid_reduce(R, ca->stream);
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
+  };
+  // (the coalescer needs lists any stream may read -- the cached decode publishes them with a stream sync -- and the flags)
+  const bool coalesce = n_tiles && scan_tuning().hybrid_coalesce && scan_tuning().cache_decoded && scan_tuning().hybrid_poll && !prof && !T.trace;
+  if (n_tiles && !coalesce) {
+    launch_alone();
     hyb_wait(ca, !prof && !T.trace, false);
+    hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
+  } else if (n_tiles) {
+    HybCoalescer &co = *hyb_coalescer_of(ca->device);
+    HybJob job;
+    job.T = hybrid_tile_lite(T, &job.lds);
+    job.R = R;
+    job.n_tiles = n_tiles;
+    job.sig = want_knn ? f->ktype * 8 + f->kmetric : -1;
+    job.ca = ca;
+    HybGridOwner duty{job, ca->device};
+    if (want_knn && co.hint.load(std::memory_order_relaxed) >= hyb_depth()) {  // (probably queued: the upload's event, outside the lock)
+      HIP_CHECK(hipEventRecord(ca->ev0, ca->stream));
+      job.has_event = true;
+    }
+    std::vector<HybJob *> batch;
+    bool alone = false;
+    {
+      std::lock_guard<std::mutex> g(co.mu);
+      if (co.in_flight < hyb_depth()) {
+        co.in_flight++;
+        co.hint.store(co.in_flight, std::memory_order_relaxed);
+        if (co.pending.empty()) {
+          alone = true;
+        } else {
+          batch.push_back(&job);
+          hyb_take(co, batch, (size_t)kHybBatchMax - 1);
+        }
+      } else {
+        if (want_knn && !job.has_event) {
+          HIP_CHECK(hipEventRecord(ca->ev0, ca->stream));
+          job.has_event = true;
+        }
+        co.pending.push_back(&job);
+        hyb_coalesce_stats().queued++;
+      }
+    }
+    if (alone) {
+      job.owner = true;  // (from here on the duty is this thread's, whatever the launch does)
+      hyb_coalesce_stats().solo++;
+      launch_alone();
+      job.state.store(1, std::memory_order_relaxed);
+    } else if (!batch.empty()) {
+      try {
+        hyb_launch_batch(batch);
+      } catch (...) {  // (every member was told; the grid's place goes back through this thread's duty)
+        job.owner = true;
+        throw;
+      }
+    }
+    // the answers: this job's own flags, wherever its grid was launched from
+    {
+      volatile uint32_t *done = ca->h_counters + 1;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool timed_out = false, slow = false, left_queue = false;
+      for (uint32_t spin = 0;; spin++) {
+        if (done[0] && done[1] && done[2]) break;
+        const int st = job.state.load(std::memory_order_acquire);
+        if (st < 0) {  // the shared launch failed before anything of this job was enqueued: on its own, the classic way
+          hyb_coalesce_stats().relaunched++;
+          job.state.store(1, std::memory_order_relaxed);
+          launch_alone();
+        }
+        if (slow) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else cpu_relax();
+        if ((spin & 255u) == 255u && !timed_out && deadline_passed()) {
+          timed_out = true;
+          std::lock_guard<std::mutex> g(co.mu);
+          auto it = std::find(co.pending.begin(), co.pending.end(), &job);
+          if (it != co.pending.end()) {  // still queued: nothing of this job is on the device but its query's upload
+            co.pending.erase(it);
+            left_queue = true;
+            break;
+          }
+        }
+        if ((spin & 1023u) == 1023u && !slow && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) slow = true;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      // (the flags can be up before the launching thread has written owner / state: its last touch of the job is the state)
+      while (!left_queue && job.state.load(std::memory_order_acquire) == 0) cpu_relax();
+      if (timed_out) {
+        (void)hipStreamSynchronize(ca->stream);
+        throw QueryTimedOut();
+      }
+    }
+    poll_deadline(nullptr, nullptr);
     hyb_settle_overflow(sc, ca, cb, n_tiles, top_n, k);
   }
   if (!hyb_collect(a, h.base, ca, cb, n_tiles, top_n, k, norm)) return false;

@@ -275,7 +275,7 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // phase clock of a tile (knob hybrid_trace: where a workgroup's time goes; s_memrealtime ticks at 100 MHz)
 #define RSGPU_HYB_MARK(p)                                                                                   \
   do {                                                                                                      \
-    if (A.trace && threadIdx.x == 0) A.trace[(size_t)blockIdx.x * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
+    if (A.trace && threadIdx.x == 0) A.trace[(size_t)tile * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 
 // Dynamic LDS: pool_words u32 (the probe's window of another list; then the hits' records -- doc id | frequency in list 0 |
@@ -285,8 +285,10 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // kHybMaxLists> is instantiated: round 5 measured tiles of 2 048 (one round over the chip instead of two: 63.7 us against 45.7 --
 // every phase grows with the tile, the tiles that hold vectors take 55 us) and of 512 (54.2 us: the per-tile overhead) on the
 // configs[4] stream, profiles/r05_hybrid_tile_size_ab.json.
-template <int TYPE, int METRIC, int DPT, int NL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
+// (the body of both kernels below: Args = HybridTileArgs, tile = blockIdx.x -- one query per grid -- or HybridTileLite and the
+// tile the block maps to in a grid several queries share)
+template <int TYPE, int METRIC, int DPT, int NL, typename Args>
+__device__ __forceinline__ void hybrid_tile_body(const Args &A, const uint32_t tile) {
   constexpr uint32_t TILE = 256u * DPT;
   extern __shared__ __attribute__((aligned(16))) uint32_t win[];
   __shared__ uint32_t wave_cnt[4];
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
   u4 *qs = reinterpret_cast<u4 *>(win + WIN);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n0 = A.len[0];
-  const uint32_t i_first = blockIdx.x * TILE, i_next = i_first + TILE;
+  const uint32_t i_first = tile * TILE, i_next = i_first + TILE;
   const uint32_t *__restrict__ ids0 = A.ids[0];
 
   RSGPU_HYB_MARK(0);
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     if (threadIdx.x == 0) nv_sh = nh_sh = 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) A.tile_hits[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  if (threadIdx.x == 0) A.tile_hits[tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
   RSGPU_HYB_MARK(3);
 
   // the hits' vector rows: identity arithmetic, or one gather from the device label table -- requested here, in flight while
@@ -520,12 +522,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     __syncthreads();
     tile_select<DPT>(my_k, my_x, nh, A.top_n, [&](uint32_t o) { return SKey{ek[o], ex[o]}; }, sel_k, sel_x, &sel_cnt, sel_wtk, sel_wtx,
                      [&](uint32_t rank, const SKey &my) {
-                       A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
-                       A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
+                       A.part_skey[(size_t)tile * A.top_n + rank] = my.k;
+                       A.part_sidx[(size_t)tile * A.top_n + rank] = my.i;
                      });
     if (threadIdx.x >= nh && threadIdx.x < A.top_n) {  // fewer hits than slots
-      A.part_skey[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0ull;
-      A.part_sidx[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0u;
+      A.part_skey[(size_t)tile * A.top_n + threadIdx.x] = ~0ull;
+      A.part_sidx[(size_t)tile * A.top_n + threadIdx.x] = ~0u;
     }
     __syncthreads();  // the arrays are reused by branch B
   }
@@ -569,13 +571,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
     }
     tile_select<DPT>(vk_mine, vx_mine, nv, A.k, [&](uint32_t o) { return SKey{(uint64_t)vkey[o], vx[o]}; }, sel_k, sel_x, &sel_cnt,
                      sel_wtk, sel_wtx, [&](uint32_t rank, const SKey &my) {
-                       A.part_knn[(size_t)blockIdx.x * A.k + rank] = (my.k << 32) | my.i;
+                       A.part_knn[(size_t)tile * A.k + rank] = (my.k << 32) | my.i;
                      });
-    if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
+    if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)tile * A.k + threadIdx.x] = ~0ull;
   }
   RSGPU_HYB_MARK(8);
 }
 #undef RSGPU_HYB_MARK
+template <int TYPE, int METRIC, int DPT, int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
+  hybrid_tile_body<TYPE, METRIC, DPT, NL>(A, blockIdx.x);
+}
+// Several queries in one grid (search_kernels.hpp HybridTileBatch).  Block -> (query, tile): the queries sit in ascending order of
+// their tile counts; segment j = the rounds in which the queries j .. n_q - 1 still have tiles, its blocks deal those queries'
+// next tiles out in turn -- every query's first tiles (the vector-bearing ones of a corpus whose vectors carry the low doc ids)
+// start at once, behind them the light tiles of all queries fill the chip without a half-empty second round per query.
+template <int TYPE, int METRIC, int DPT, int NL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_batch_kernel(HybridTileBatch B) {
+  uint32_t j = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < kHybBatchMax; i++)
+    if (i + 1 < (int)B.n_q && blockIdx.x >= B.tile_end[i]) j = (uint32_t)i + 1;
+  const uint32_t seg0 = j ? B.tile_end[j - 1] : 0u;
+  uint32_t qi = j, tile = blockIdx.x - seg0;
+  if (B.interleave) {
+    const uint32_t alive = B.n_q - j, off = blockIdx.x - seg0;
+    tile = (j ? B.n_tiles[j - 1] : 0u) + off / alive;
+    qi = j + off % alive;
+  }
+  hybrid_tile_body<TYPE, METRIC, DPT, NL>(B.q[qi], tile);
+}
 
 // One workgroup of 1 024 per branch (block 0: the score lists; the last block: the hit count and the KNN lists), nothing shared
 // between them.  The k best of the tiles' lists (a list is sorted: its first entry is the tile's best):
@@ -767,13 +792,14 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
 }
 #undef RSGPU_RED_MARK
 
-__global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R) {
+// role 0: the score lists, 1: the KNN lists, 2: the hit count
+__device__ __forceinline__ void hybrid_reduce_body(const HybridReduceArgs &R, const uint32_t role) {
   __shared__ uint64_t lk[kHybSurvivors];
   __shared__ uint32_t li[kHybSurvivors];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t cnt_sh;
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (blockIdx.x == gridDim.x - 1) {  // the hit count: a workgroup of its own (it was two memory round trips in front of the KNN branch)
+  if (role == 2) {  // the hit count: a workgroup of its own (it was two memory round trips in front of the KNN branch)
     uint32_t s = 0;
     for (uint32_t t0 = threadIdx.x; t0 < R.n_tiles; t0 += 4 * 1024) {  // (four loads in flight)
       uint32_t v[4];
@@ -796,8 +822,16 @@ __global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R)
     }
     return;
   }
-  if (blockIdx.x == 0 && R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
-  else if (R.k) hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+  if (role == 0 && R.top_n) hybrid_reduce_branch<true>(R, lk, li, &cnt_sh);
+  else if (role == 1 && R.k) hybrid_reduce_branch<false>(R, lk, li, &cnt_sh);
+}
+__global__ __launch_bounds__(1024) void hybrid_reduce_kernel(HybridReduceArgs R) {
+  // (the grid holds the enabled branches only: block 0 is the score branch when there is one, the last block the hit count)
+  hybrid_reduce_body(R, blockIdx.x == gridDim.x - 1 ? 2u : (blockIdx.x == 0 && R.top_n ? 0u : 1u));
+}
+// the reduce launches of the queries of a shared grid in one: three workgroups per query (a disabled branch's returns at once)
+__global__ __launch_bounds__(1024) void hybrid_reduce_batch_kernel(HybridReduceBatch B) {
+  hybrid_reduce_body(B.q[blockIdx.x / 3u], blockIdx.x % 3u);
 }
 
 
@@ -1406,6 +1440,85 @@ void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_
   if (!n_tiles) return;
   hipLaunchKernelGGL(hybrid_hits_pack_kernel, dim3(n_tiles), dim3(256), 0, s, tile_hits, n_tiles, n_leaves, src_ids, src_freqs, src_epos,
                      src_stride, dst_ids, dst_freqs, dst_epos, dst_cap, total_out);
+}
+HybridTileLite hybrid_tile_lite(const HybridTileArgs &a, size_t *lds_out) {
+  HybridTileLite t;
+  memset(&t, 0, sizeof t);
+  t.n = a.n;
+  for (int l = 0; l < kHybMaxLists; l++) {
+    t.ids[l] = a.ids[l];
+    t.freq[l] = a.freq[l];
+    t.len[l] = a.len[l];
+    t.add[l] = a.add[l];
+    t.dir[l] = a.dir[l];
+    t.dir_shift[l] = a.dir_shift[l];
+    t.dir_n[l] = a.dir_n[l];
+    t.P.idf[l] = a.P.idf[l];
+    t.P.bm25_idf[l] = a.P.bm25_idf[l];
+    t.P.weight[l] = a.P.weight[l];
+  }
+  t.top_n = a.top_n;
+  t.P.scorer = a.P.scorer;
+  t.P.n_groups = a.P.n_groups;
+  t.P.avg_doc_len = a.P.avg_doc_len;
+  t.P.root_weight = a.P.root_weight;
+  t.P.min_score = a.P.min_score;
+  t.P.inv_tanh = a.P.inv_tanh;
+  t.P.slop = a.P.slop;
+  t.P.table_off = a.P.table_off;
+  t.doc_len = a.doc_len;
+  t.doc_score = a.doc_score;
+  t.max_freq = a.max_freq;
+  t.table_n = a.table_n;
+  t.k = a.k;
+  t.rows = a.rows;
+  t.stride16 = a.stride16;
+  t.chunks = a.chunks;
+  if (a.k) {
+    const Shape sh = pick_shape(a.stride16);
+    t.G = sh.G;
+    t.ITERS = sh.ITERS;
+  } else {
+    t.G = 1;
+    t.ITERS = 0;
+  }
+  t.query = a.query;
+  t.ids_base = a.ids_base;
+  t.L = a.L;
+  t.tile_hits = a.tile_hits;
+  t.part_skey = a.part_skey;
+  t.part_sidx = a.part_sidx;
+  t.part_knn = a.part_knn;
+  t.pool_words = std::max<uint32_t>(4096u, (uint32_t)(a.n + 1) * kHybTile);
+  t.len_score = a.len_score;
+  t.knn_pipeline = a.knn_pipeline;
+  if (lds_out) *lds_out = (size_t)t.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
+  return t;
+}
+bool launch_hybrid_tiles_batch(HybridTileBatch &b, int type, int metric, size_t lds, hipStream_t s) {
+  if (b.n_q < 1 || b.n_q > (uint32_t)kHybBatchMax) return false;
+  bool any_k = false;
+  for (uint32_t i = 0; i < b.n_q; i++) any_k |= b.q[i].k != 0;
+  uint32_t blocks = 0, prev = 0;
+  for (uint32_t j = 0; j < b.n_q; j++) {  // (ascending tile counts: the caller sorted)
+    if (b.n_tiles[j] < prev || !b.n_tiles[j]) return false;
+    blocks += b.interleave ? (b.n_tiles[j] - prev) * (b.n_q - j) : b.n_tiles[j];
+    b.tile_end[j] = blocks;
+    prev = b.n_tiles[j];
+  }
+#define RSGPU_HYBB(T, M) hipLaunchKernelGGL((hybrid_tile_batch_kernel<T, M, kHybDpt, kHybMaxLists>), dim3(blocks), dim3(256), lds, s, b)
+  if (!any_k) RSGPU_HYBB(KT_F32, KM_IP);
+  else if (type == KT_F32 && metric == KM_L2) RSGPU_HYBB(KT_F32, KM_L2);
+  else if (type == KT_F32) RSGPU_HYBB(KT_F32, KM_IP);
+  else if (type == KT_F16 && metric == KM_L2) RSGPU_HYBB(KT_F16, KM_L2);
+  else if (type == KT_F16) RSGPU_HYBB(KT_F16, KM_IP);
+  else if (metric == KM_L2) RSGPU_HYBB(KT_BF16, KM_L2);
+  else RSGPU_HYBB(KT_BF16, KM_IP);
+#undef RSGPU_HYBB
+  return true;
+}
+void launch_hybrid_reduce_batch(const HybridReduceBatch &r, hipStream_t s) {
+  hipLaunchKernelGGL(hybrid_reduce_batch_kernel, dim3(3 * r.n_q), dim3(1024), 0, s, r);
 }
 void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s) {
   hipLaunchKernelGGL(hybrid_reduce_kernel, dim3((r.k ? 1 : 0) + (r.top_n ? 1 : 0) + 1), dim3(1024), 0, s, r);

@@ -128,6 +128,10 @@ struct ScanTuning {
   int hybrid_dir = 1;      // ... a probed list's window ends come from its bucket directory (one round trip; 0 = wave-wide searches)
   int hybrid_packed_docs = 1;  // document tables uploaded while set also keep {doc length, doc score} side by side (one gather per hit)
   int hybrid_knn_pipeline = 1;  // ... the tile kernel requests the next step's vector rows before it reduces this step's distances
+  int hybrid_coalesce = 1;  // ... the two-launch queries of concurrent callers share grids (hybrid_entry.hpp: the hybrid coalescer); 0 = every query its own two launches
+  int hybrid_coalesce_depth = 2;  // ... grids in flight per device before arriving callers queue (1..8)
+  int hybrid_coalesce_interleave = 0;  // ... 1: a shared grid deals the queries' tiles out in turn (every query's vector-bearing tiles first: measured 10-15 % SLOWER,
+                                       // profiles/r06_hybrid_coalesce_ab.json); 0: one query after the other
   int hybrid_poll = 1;     // ... the host polls completion flags in pinned memory instead of synchronising the stream
   int hybrid_trace = 0;    // diagnostics: the tile kernel records a phase clock per tile (RSGPU_HybridTrace)
   int hybrid_surv_cap = 2048;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)

@@ -372,8 +372,9 @@ __device__ __forceinline__ void prox_load(const ProxParams &P, const View &o, Pr
 // load after the other.
 // MAXD (DEEP only): the deepest node the caller admits.  Up to 4 levels the accumulators are picked by compare-and-select over
 // constant indices and stay in registers (the hybrid tile kernel's form: no scratch); beyond, they are indexed dynamically.
-template <bool DEEP, int FLAT = 0, int MAXD = kMaxTreeDepth, typename FreqFn>
-__device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint32_t dlen, float dscore, uint32_t mfreq,
+// SP: ScoreParams, or -- FLAT > 0 only -- ScoreParamsFlat (search_kernels.hpp: the fields a flat AND of <= FLAT terms reads).
+template <bool DEEP, int FLAT = 0, int MAXD = kMaxTreeDepth, typename SP, typename FreqFn>
+__device__ __forceinline__ double score_one(const SP &P, FreqFn F, uint32_t dlen, float dscore, uint32_t mfreq,
                                             int slop) {
   double s = 0.0;
   auto fold = [&](auto leaf, bool dismax) {
@@ -383,8 +384,7 @@ __device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint
       for (int g = 0; g < FLAT; g++)
         if (g < P.n_groups) ret = ret + leaf(g);
       return ret;
-    }
-    if constexpr (DEEP) {
+    } else if constexpr (DEEP) {
       // any depth: one accumulator per open level.  Post-order: when an aggregate comes up, acc[its depth] holds the
       // sum (DISMAX under a union: the maximum) of its children, in the result's child order -- the order the
       // reference's recursions add them in -- and its own value, weight * that, goes to its parent's accumulator.
@@ -420,24 +420,25 @@ __device__ __forceinline__ double score_one(const ScoreParams &P, FreqFn F, uint
         }
       }
       return acc[0];
-    }
-    double ret = 0.0;
-    for (int g = 0; g < P.n_groups; g++) {
-      const int a = P.group_first[g], b = P.group_first[g + 1];
-      double child;
-      if (P.group_op[g] == 0) {
-        child = leaf(a);
-      } else {
-        double acc = 0.0;
-        for (int t = a; t < b; t++) {
-          const double v = leaf(t);
-          acc = (dismax && P.group_op[g] == 1) ? (v > acc ? v : acc) : acc + v;
+    } else {
+      double ret = 0.0;
+      for (int g = 0; g < P.n_groups; g++) {
+        const int a = P.group_first[g], b = P.group_first[g + 1];
+        double child;
+        if (P.group_op[g] == 0) {
+          child = leaf(a);
+        } else {
+          double acc = 0.0;
+          for (int t = a; t < b; t++) {
+            const double v = leaf(t);
+            acc = (dismax && P.group_op[g] == 1) ? (v > acc ? v : acc) : acc + v;
+          }
+          child = P.group_weight[g] * acc;
         }
-        child = P.group_weight[g] * acc;
+        ret = (dismax && P.is_union) ? (child > ret ? child : ret) : ret + child;
       }
-      ret = (dismax && P.is_union) ? (child > ret ? child : ret) : ret + child;
+      return ret;
     }
-    return ret;
   };
   switch (P.scorer) {
     case 0:    // BM25STD      reference src/ext/default.c:241-316

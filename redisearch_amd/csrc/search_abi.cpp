@@ -1580,6 +1580,17 @@ double RSGPU_CalculateIDF_BM25(size_t total_docs, size_t term_docs) {
 }
 
 int RSGPU_HybridQueryPath(void) { return tls_hybrid_path; }
+void RSGPU_GetHybridCoalesceStats(uint64_t out[5], int reset) {
+  HybCoalesceStats &c = hyb_coalesce_stats();
+  if (out) {
+    out[0] = c.solo.load();
+    out[1] = c.grids.load();
+    out[2] = c.grid_queries.load();
+    out[3] = c.queued.load();
+    out[4] = c.relaunched.load();
+  }
+  if (reset) c.solo = c.grids = c.grid_queries = c.queued = c.relaunched = 0;
+}
 
 // diagnostics (knob hybrid_trace): the phase clock of every tile of the calling thread's last two-launch query, [tiles][9]
 // readings of the 100 MHz device clock; returns the number of tiles (0: no trace)

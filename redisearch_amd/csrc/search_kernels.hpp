@@ -270,6 +270,71 @@ struct HybridReduceArgs {
   uint32_t *done;                      // pinned host memory, [3] (score branch, KNN branch, hit count): set to 1 -- system-scope
                                        // release -- once that workgroup's answers are in host memory; the host polls them
 };
+// ---- several callers' queries in ONE grid (round 6: the hybrid coalescer, hybrid_entry.hpp) -----------------------------------
+// RediSearch issues queries from a pool of worker threads (src/util/workers.c:58,104); a query's 2 443 tiles are one and a half
+// rounds over the chip's ~1 536 resident workgroups and its reduce launch waits for the last of them.  Queries that meet in the
+// coalescer's queue share one tile grid (block -> (query, tile): one query's tiles after the other's; knob: dealt out in turn) and
+// one reduce launch (three workgroups per query); every query keeps its own FIXED output slots and
+// its own pinned answers / completion flags, so the answers are those of its own two launches bit for bit.
+// The kernel arguments hold up to kHybBatchMax descriptions side by side (4 KB of kernarg): the flat-AND form reads a tenth of
+// ScoreParams -- ScoreParamsFlat carries those fields under the same names (score_one<false, FLAT> is generic in its type).
+struct ScoreParamsFlat {
+  int scorer, n_groups;
+  double avg_doc_len, root_weight, min_score, inv_tanh;
+  double idf[kHybMaxLists], bm25_idf[kHybMaxLists], weight[kHybMaxLists];
+  int slop;
+  long long table_off;
+};
+struct HybridTileLite {  // HybridTileArgs without the diagnostics; same names, same meaning
+  int n;
+  const uint32_t *ids[kHybMaxLists];
+  const uint32_t *freq[kHybMaxLists];
+  uint32_t len[kHybMaxLists];
+  long long add[kHybMaxLists];
+  uint32_t top_n;
+  ScoreParamsFlat P;
+  const uint32_t *doc_len;
+  const float *doc_score;
+  const uint32_t *max_freq;
+  uint32_t table_n;
+  uint32_t k;
+  const void *rows;
+  uint32_t stride16, chunks;
+  int G, ITERS;
+  const void *query;
+  uint64_t ids_base;
+  LabelRows L;
+  uint32_t *tile_hits;
+  uint64_t *part_skey;
+  uint32_t *part_sidx;
+  uint64_t *part_knn;
+  uint32_t pool_words;
+  const uint32_t *dir[kHybMaxLists];
+  uint32_t dir_shift[kHybMaxLists], dir_n[kHybMaxLists];
+  const uint2 *len_score;
+  int knn_pipeline;
+  static constexpr uint64_t *trace = nullptr;
+};
+constexpr int kHybBatchMax = 7;
+struct HybridTileBatch {
+  uint32_t n_q;                       // 1 .. kHybBatchMax queries, ascending by their number of tiles
+  uint32_t interleave;                // 1: block b of the segment where queries j.. are alive -> tile seg_tile0 + b / alive of query j + b % alive
+                                      // 0: the queries' tiles one query after the other
+  uint32_t tile_end[kHybBatchMax];    // interleave: blocks before the end of segment j; else blocks before the end of query j
+  uint32_t n_tiles[kHybBatchMax];
+  HybridTileLite q[kHybBatchMax];
+};
+static_assert(sizeof(HybridTileBatch) <= 4096, "the batch rides in the kernel arguments");
+struct HybridReduceBatch {
+  uint32_t n_q;
+  HybridReduceArgs q[kHybBatchMax];   // (trace must be NULL)
+};
+// the description of a query for a shared grid (G / ITERS / pool_words filled as launch_hybrid_tiles fills them); lds_out: the
+// dynamic LDS its tiles need
+HybridTileLite hybrid_tile_lite(const HybridTileArgs &a, size_t *lds_out);
+// false: nothing launched (no instantiation: the caller launches each query on its own)
+bool launch_hybrid_tiles_batch(HybridTileBatch &b, int type, int metric, size_t lds, hipStream_t s);
+void launch_hybrid_reduce_batch(const HybridReduceBatch &r, hipStream_t s);
 uint32_t hybrid_tiles(uint32_t n0);
 // type / metric: the index's kernel type and metric (kernels.hpp KT_* / KM_*); false: the staged pipeline takes the query
 bool hybrid_tile_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k);

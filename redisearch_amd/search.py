@@ -52,6 +52,7 @@ ABI = {
     "RSGPU_HybridTreeQuery": (_i, [C.POINTER(TreeQuery), C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridTreeNodesQuery": (_i, [C.POINTER(TreeNode), _sz, C.POINTER(HybridQueryArgs)]),
     "RSGPU_HybridQueryPath": (_i, []),
+    "RSGPU_GetHybridCoalesceStats": (None, [_vp, _i]),
     "RSGPU_HybridTrace": (C.c_long, [_vp, _sz]),
     "RSGPU_Postings_Upload": (_vp, [_i, _sz, _vp, _vp, _vp, _vp, _vp]),
     "RSGPU_Postings_Free": (None, [_vp]),
@@ -347,6 +348,13 @@ def hybrid_path():
     """how this thread's last RSGPU_HybridQuery / RSGPU_HybridTreeQuery ran: 0 staged pipeline, 1 two launches, 2 the general
     tile kernel (hybrid_kernels.hip)"""
     return load().RSGPU_HybridQueryPath()
+
+
+def hybrid_coalesce_stats(reset=False):
+    """the hybrid coalescer's counters (rsgpu_search.h RSGPU_GetHybridCoalesceStats)"""
+    out = (C.c_uint64 * 5)()
+    load().RSGPU_GetHybridCoalesceStats(out, 1 if reset else 0)
+    return dict(zip(("alone", "grids", "grid_queries", "queued", "relaunched"), (int(v) for v in out)))
 
 
 def hybrid_trace(max_tiles=1 << 15):
