@@ -745,9 +745,10 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
                 qq = []
                 for qi, (i, j) in enumerate(pairs):
                     dfs = [raws[i][0].size, raws[j][0].size]
-                    qq.append(S.HybridQuery([lists[i], lists[j]], table, "BM25STD", [S.calculate_idf(n_docs, d) for d in dfs],
-                                            [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10, index=idx,
-                                            q=qvecs[qi], k=10))
+                    form = os.environ.get("RSGPU_BENCH_HYBRID_FORM", "both")   # diagnostics (scripts/gpu_prof_hybrid.sh): one branch only
+                    qq.append(S.HybridQuery([lists[i], lists[j]], table if form != "knn" else None, "BM25STD", [S.calculate_idf(n_docs, d) for d in dfs],
+                                            [S.calculate_idf_bm25(n_docs, d) for d in dfs], [1.0, 1.0], n_docs, avg, top_n=10 if form != "knn" else 0,
+                                            index=idx if form != "score" else None, q=qvecs[qi], k=10 if form != "score" else 0))
                 return qq
             hqs = make_queries()
             res = []

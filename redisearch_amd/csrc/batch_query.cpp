@@ -5,6 +5,7 @@
 // (reference src/iterators/hybrid_reader.c:374).  EVERY route re-scores the survivors of its matrix-core filter passes with the
 // single-query scan's arithmetic (thresholds widened by the route's error band): replies are bit-identical to B single
 // queries.  (Until round 5 the FLOAT16 / BFLOAT16 IP / cosine route -- BASELINE configs[2] itself -- handed out the MFMA sums.)
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -398,7 +399,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     static const bool dbg_sync = getenv("RSGPU_DEBUG_SYNC") != nullptr;
     auto enqueue = [&](int sl, size_t q0) {
       BatchScratch &sc = tls_batch[sl];
-      QueryCtx *c = ctxs[sl];
+      // ONE stream carries every batch of the call (round 6; the slots own scratch, pinned mirrors and events only): two batches on
+      // two streams interleaved their kernels -- 3.49 ms per pass where a pass alone takes 3.16 -- and the host is ahead anyway
+      QueryCtx *c = ctxs[0];
       auto dbg = [&](const char *what) {
         if (!dbg_sync) return;
         fprintf(stderr, "[batch] %s ...", what);
@@ -471,7 +474,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         rb.c1 = 2.0f * rel / shrink;
         rb.inv2rel = 0.5f / rel;
       }
-      if (prof) HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+      if (prof) HIP_CHECK(hipEventRecord(ctxs[sl]->ev0, c->stream));
       {
         // the sample's bound: from the exact rows when the filter runs on the int8 shadow (the tiled GEMM has no int8 form;
         // an exact bound widened by the band is as good as a shadow bound widened by it)
@@ -530,13 +533,21 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                                  sc.out_n.p, kk, sc.overflow.p, c->stream);
       }
       HIP_CHECK(hipGetLastError());
-      if (prof) HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+      if (prof) HIP_CHECK(hipEventRecord(ctxs[sl]->ev1, c->stream));
       HIP_CHECK(hipMemcpyAsync(sc.h_rows.p, sc.out_rows.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
       HIP_CHECK(hipMemcpyAsync(sc.h_keys.p, sc.out_keys.p, (size_t)kBatch * kk * 4, hipMemcpyDeviceToHost, c->stream));
       HIP_CHECK(hipMemcpyAsync(sc.h_n.p, sc.out_n.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
       HIP_CHECK(hipMemcpyAsync(sc.h_over.p, sc.overflow.p, kBatch * 4, hipMemcpyDeviceToHost, c->stream));
+      if (!prof) HIP_CHECK(hipEventRecord(ctxs[sl]->ev1, c->stream));  // the slot's answers are in pinned memory behind this one
     };
 
+    // (RSGPU_BATCH_TRACE=1: host timestamps of the pipeline on stderr -- where a call's wall time goes)
+    static const bool trace = getenv("RSGPU_BATCH_TRACE") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what, size_t b) {
+      if (trace) fprintf(stderr, "[batch-trace] %-14s %zu  %8.3f ms\n", what, b,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count());
+    };
     // wait for the slot's batch and build its replies
     auto finalize = [&](int sl, size_t q0) {
       BatchScratch &sc = tls_batch[sl];
@@ -544,7 +555,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
       const uint32_t nb = (uint32_t)std::min<size_t>(kBatch, n_queries - q0);
       const uint32_t *h_rows = static_cast<const uint32_t *>(sc.h_rows.p), *h_keys = static_cast<const uint32_t *>(sc.h_keys.p);
       const uint32_t *h_n = static_cast<const uint32_t *>(sc.h_n.p), *h_over = static_cast<const uint32_t *>(sc.h_over.p);
-      HIP_CHECK(hipStreamSynchronize(c->stream));
+      if (prof) HIP_CHECK(hipStreamSynchronize(ctxs[0]->stream));  // (ev1 sits in front of the copies there)
+      else HIP_CHECK(hipEventSynchronize(c->ev1));
+      stamp("synced", q0 / kBatch);
       if (prof) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) {
@@ -555,8 +568,19 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
         }
       }
       std::vector<VecSimQueryResult> res;
+      // the winners' labels are random reads of a table of 8 B per row (80 MB at 10 M rows): requested a query ahead, 100 misses in
+      // flight instead of one after the other (1.25 ms per 256 x 100 replies before: a third of a pass)
+      auto prefetch_labels = [&](uint32_t i) {
+        const uint32_t m = std::min(h_n[i], kk);
+        for (uint32_t j = 0; j < m; j++) {
+          const uint32_t r = h_rows[(size_t)i * kk + j];
+          if (r < row_label_.size()) __builtin_prefetch(&row_label_[r]);
+        }
+      };
+      if (nb) prefetch_labels(0);
       for (uint32_t i = 0; i < nb; i++) {
         const size_t qi = q0 + i;
+        if (i + 1 < nb) prefetch_labels(i + 1);
         if (h_over[i] || ((via_l2 || ip_band) && l2_redo[sl][i])) {  // candidate list overflowed (or a non-finite L2 query): redo this query on the single-query path
           redo.push_back(qi);
           continue;
@@ -580,9 +604,8 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           for (uint32_t j = 0; j < got; j++)
             res[j] = VecSimQueryResult{(size_t)label_at(h_rows[(size_t)i * kk + j]), score_of(h_keys[(size_t)i * kk + j])};
         }
-        std::sort(res.begin(), res.end(), [](const VecSimQueryResult &a, const VecSimQueryResult &b) {
-          return score_id_before(a.score, a.id, b.score, b.id);
-        });
+        const auto before = [](const VecSimQueryResult &a, const VecSimQueryResult &b) { return score_id_before(a.score, a.id, b.score, b.id); };
+        if (!std::is_sorted(res.begin(), res.end(), before)) std::sort(res.begin(), res.end(), before);
         counts_out[qi] = take;
         for (uint32_t j = 0; j < take; j++) {
           ids_out[qi * k + j] = res[j].id;
@@ -592,10 +615,14 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     };
 
     for (size_t b = 0; b < n_batches; b++) {
+      stamp("enqueue", b);
       enqueue((int)(b & 1) % n_slots, b * kBatch);
+      stamp("enqueued", b);
       if (b > 0) finalize((int)((b - 1) & 1), (b - 1) * kBatch);
+      if (b > 0) stamp("finalized", b - 1);
     }
     finalize((int)((n_batches - 1) & 1) % n_slots, (n_batches - 1) * kBatch);
+    stamp("finalized", n_batches - 1);
   }
   for (size_t qi : redo) single(qi);
 }

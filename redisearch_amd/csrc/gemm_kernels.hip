@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void gemm_topk_kernel(GemmArgs g) {
 // One workgroup per query.  PAIRS=false: elements are keys[q*ld + i], i<n, composite (key,i);
 // PAIRS=true: elements are cand[q*cap + i] = (row,key), i<min(count[q],cap), composite (key,row).
 // Finds the k smallest composites; writes the k-th smallest key as a float threshold (tau_out) and/or
-// the winners (unordered) to out_rows/out_keys[q*k_ld + j], out_n[q] = how many.
+// the winners -- in (key, row) order up to 1 024 of them -- to out_rows/out_keys[q*k_ld + j], out_n[q] = how many.
 struct BatchSel {
   const uint32_t *keys;
   uint32_t ld, n;
@@ -339,6 +339,7 @@ template <bool PAIRS>
 __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
   __shared__ uint32_t hist[256];
   __shared__ u64 sh_prefix;
+  __shared__ u64 win[1024];
   __shared__ uint32_t sh_krem, sh_exact, sh_levels, sh_out;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   uint32_t n = s.n;
@@ -437,14 +438,26 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
       }
       if (take) {
         uint32_t o = atomicAdd(&sh_out, 1u);
-        if (o < s.k_ld) {
+        if (o < s.k_ld && o < 1024u) win[o] = c;
+        else if (o < s.k_ld) {  // (k_ld above the sorted list's room: as before, unordered)
           s.out_rows[(size_t)q * s.k_ld + o] = (uint32_t)c;
           s.out_keys[(size_t)q * s.k_ld + o] = (uint32_t)(c >> 32);
         }
       }
     }
     __syncthreads();
-    if (tid == 0) s.out_n[q] = sh_out < s.k_ld ? sh_out : s.k_ld;
+    // the winners in (key, row) order (round 6: the host sorted every reply -- 100 x 256 per pass, a fifth of a pass's time): every
+    // winner counts the winners before it; composites are distinct (a row appears once)
+    const uint32_t got = sh_out < s.k_ld ? sh_out : s.k_ld, ranked = got < 1024u ? got : 1024u;
+    for (uint32_t t = tid; t < ranked; t += blockDim.x) {
+      const u64 c = win[t];
+      uint32_t rank = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < ranked; j++) rank += win[j] < c ? 1u : 0u;
+      s.out_rows[(size_t)q * s.k_ld + rank] = (uint32_t)c;
+      s.out_keys[(size_t)q * s.k_ld + rank] = (uint32_t)(c >> 32);
+    }
+    if (tid == 0) s.out_n[q] = got;
   }
 }
 
