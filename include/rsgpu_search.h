@@ -210,8 +210,10 @@ int RSGPU_HybridQuery(RSGPU_HybridQueryArgs *args);
  * distances, per-tile winners -- and one reduce kernel), 2 = the general tile kernel + the reduce kernel (<= 8 lists under a
  * root intersection of terms / unions of terms / intersections of terms, max_slop / in_order, per-hit slop from the term
  * offsets, NOT children, BM25STD.NORM; hits_out wanted: a third launch packs the list; round 5: a root union of terms /
- * intersections of terms without hits_out -- one pass per child --, a root intersection whose children are all unions without
- * hits_out -- the smallest union drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees).
+ * intersections of terms -- one pass per child --, a root intersection whose children are all unions -- the smallest union
+ * drives, one pass per term of it -- and, through RSGPU_HybridTreeNodesQuery, nested trees; round 6: hits_out of those
+ * several-pass queries too -- every pass reports its hits in doc-id order, a document by exactly one pass, and one more launch
+ * merges the packed runs by doc id: union_flat.rs:223-320 yields a union's documents in doc-id order).
  * top_n / k > 64 and indexes whose labels no device table holds stay staged.  Same answers. */
 int RSGPU_HybridQueryPath(void);
 /* The hybrid coalescer (round 6; knobs "hybrid_coalesce" 1, "hybrid_coalesce_depth" 2, "hybrid_coalesce_interleave" 0 of

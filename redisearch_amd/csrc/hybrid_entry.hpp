@@ -762,7 +762,8 @@ static int hyb_union_driver_group(const std::vector<HybGroup> &groups, RSGPU_Pos
 static uint32_t hyb_intersection_tiles(const std::vector<HybGroup> &groups, RSGPU_Postings *const *lists, bool hits_wanted) {
   uint32_t n0 = 0, tiles = 0;
   if (hyb_driver(groups, lists, &n0) >= 0) return hybrid_tiles(n0);
-  if (hits_wanted || hyb_union_driver_group(groups, lists, &tiles) < 0) return 0;
+  (void)hits_wanted;  // (round 6: the passes' runs are merged by doc id -- hybrid_hits_merge_kernel)
+  if (hyb_union_driver_group(groups, lists, &tiles) < 0) return 0;
   return tiles;
 }
 
@@ -882,7 +883,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       passes.push_back(p);
     } else {  // every child is a union: one of them drives, term by term (hyb_union_driver_group)
       union_driven = hyb_union_driver_group(groups, lists, nullptr);
-      if (union_driven < 0 || hits_out) throw std::runtime_error("hybrid query: no term or union of terms to drive the tile kernel");
+      if (union_driven < 0) throw std::runtime_error("hybrid query: no term or union of terms to drive the tile kernel");
       for (int li : groups[union_driven].lists) {
         Pass q{li, union_driven, lists[li]->n_entries, hybrid_tiles(lists[li]->n_entries), n_tiles};
         n_tiles += q.tiles;
@@ -897,7 +898,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       for (int li : g.lists)
         if (lists[li]->n_entries) excluded.push_back(lists[li]);  // (an empty list excludes nothing)
   if (n + (int)excluded.size() > kHybTreeMaxLists) throw std::runtime_error("hybrid query: more than eight lists");
-  if (root_union && (hits_out || !excluded.empty())) throw std::runtime_error("hybrid query: a root union on the tile path has neither a hit list nor NOT children");
+  if (root_union && !excluded.empty()) throw std::runtime_error("hybrid query: a root union on the tile path has no NOT children");
   HybridTreeArgs T;
   memset(&T, 0, sizeof T);
   T.n = n + (int)excluded.size();
@@ -945,7 +946,18 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     T.hit_freqs = sc.hyb_hit_freqs.p;
     T.hit_epos = h.with_offsets ? sc.hyb_hit_epos.p : nullptr;
     T.hit_stride = stride;
-    h.cap = std::max<uint32_t>(passes[0].n0, 1);
+    // (several passes -- round 6: every pass reports its hits in doc-id order, a doc id once over all passes; the packed runs are
+    // merged into one ascending list behind the reduce kernel, hybrid_hits_merge_kernel)
+    uint64_t cap = 0;
+    for (const Pass &ps : passes) cap += ps.n0;
+    h.cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cap, 1), stride);
+    if (passes.size() > 1) {
+      if (passes.size() > 8) throw std::runtime_error("hybrid query: more than eight passes");  // (<= 8 lists: cannot happen)
+      sc.hyb_run_ids.ensure(h.cap);
+      sc.hyb_run_freqs.ensure((size_t)h.cap * n);
+      if (h.with_offsets) sc.hyb_run_epos.ensure((size_t)h.cap * n);
+      sc.hyb_run_start.ensure(16);
+    }
     h.ids.alloc(h.cap);
     h.freqs.alloc((size_t)h.cap * n);
     if (h.with_offsets) h.epos.alloc((size_t)h.cap * n);
@@ -1039,6 +1051,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
         if (h.group_op[g] == 2 && h.group_first[g + 1] - h.group_first[g] > 1) P.opt_all[P.n_opt_all++] = all;
       }
     }
+    if (P.hit_ids) {  // (the tiles of a pass index their records by their own block numbers)
+      P.hit_ids += (size_t)ps.first_tile * 1024u;
+      P.hit_freqs += (size_t)ps.first_tile * 1024u;
+      if (P.hit_epos) P.hit_epos += (size_t)ps.first_tile * 1024u;
+    }
     P.tile_hits = sc.hyb_hits.p + ps.first_tile;
     P.part_skey = sc.hyb_skey.p + (size_t)ps.first_tile * top_n;
     P.part_sidx = sc.hyb_sidx.p + (size_t)ps.first_tile * top_n;
@@ -1059,9 +1076,21 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       launch_hybrid_tree_tiles(filled[pi], f ? f->ktype : 0, f ? f->kmetric : 0, passes[pi].tiles, ca->stream);
     if (prof) HIP_CHECK(hipEventRecord(ev.e[2], ca->stream));
     launch_hybrid_reduce(R, ca->stream);
-    if (hits_out)
+    if (hits_out && passes.size() == 1) {
       launch_hybrid_hits_pack(sc.hyb_hits.p, n_tiles, n, T.hit_ids, T.hit_freqs, T.hit_epos, stride, h.ids.p, h.freqs.p,
                               h.with_offsets ? h.epos.p : nullptr, h.cap, ca->h_fcnt, ca->stream);
+    } else if (hits_out) {
+      HybridRuns runs;
+      memset(&runs, 0, sizeof runs);
+      runs.n = (uint32_t)passes.size();
+      for (size_t pi = 0; pi < passes.size(); pi++) runs.first_tile[pi] = passes[pi].first_tile;
+      runs.first_tile[passes.size()] = n_tiles;
+      runs.run_start = sc.hyb_run_start.p;
+      launch_hybrid_hits_pack(sc.hyb_hits.p, n_tiles, n, T.hit_ids, T.hit_freqs, T.hit_epos, stride, sc.hyb_run_ids.p, sc.hyb_run_freqs.p,
+                              h.with_offsets ? sc.hyb_run_epos.p : nullptr, h.cap, ca->h_fcnt, ca->stream, &runs);
+      launch_hybrid_hits_merge(runs, n, sc.hyb_run_ids.p, sc.hyb_run_freqs.p, h.with_offsets ? sc.hyb_run_epos.p : nullptr, h.cap, h.ids.p,
+                               h.freqs.p, h.with_offsets ? h.epos.p : nullptr, h.cap, h.cap, ca->stream);
+    }
     HIP_CHECK(hipGetLastError());
     if (prof) HIP_CHECK(hipEventRecord(ev.e[3], ca->stream));
     hyb_wait(ca, !prof, hits_out != nullptr);
@@ -1442,7 +1471,7 @@ extern "C" int RSGPU_HybridTreeQuery(const RSGPU_TreeQuery *q, RSGPU_HybridQuery
   // A root UNION of terms / intersections of terms (`a | b`, `(a b) | (c d)`: round 5) takes the tile kernel too -- one pass per
   // child, one reduce -- when nobody asked for the hit list and the scorer does not divide by the result's slop (a union result
   // holds the matched children only: its slop differs from hit to hit)
-  bool root_union = q->root_op == RSGPU_OP_UNION && !a->hits_out && !(want_score && slop_dependent(a->score->scorer));
+  bool root_union = q->root_op == RSGPU_OP_UNION && !(want_score && slop_dependent(a->score->scorer));
   if (root_union && q->group_op)
     for (size_t g = 0; g < q->n_groups && root_union; g++)
       root_union = q->group_op[g] == RSGPU_OP_TERM || q->group_op[g] == RSGPU_OP_INTERSECT;

@@ -1276,7 +1276,8 @@ __global__ __launch_bounds__(256) void hybrid_hits_pack_kernel(const uint32_t *_
                                                                const uint32_t *__restrict__ src_ids, const uint32_t *__restrict__ src_freqs,
                                                                const uint32_t *__restrict__ src_epos, uint32_t src_stride,
                                                                uint32_t *__restrict__ dst_ids, uint32_t *__restrict__ dst_freqs,
-                                                               uint32_t *__restrict__ dst_epos, uint32_t dst_cap, uint32_t *total_out) {
+                                                               uint32_t *__restrict__ dst_epos, uint32_t dst_cap, uint32_t *total_out,
+                                                               HybridRuns runs) {
   __shared__ uint32_t wsum[4];
   const uint32_t t = blockIdx.x;
   uint32_t s = 0;
@@ -1295,6 +1296,48 @@ __global__ __launch_bounds__(256) void hybrid_hits_pack_kernel(const uint32_t *_
     }
   }
   if (t == n_tiles - 1 && threadIdx.x == 0) *total_out = off + cnt;
+  if (runs.n && threadIdx.x == 0) {
+    for (uint32_t p = 0; p < runs.n; p++)
+      if (runs.first_tile[p] == t) runs.run_start[p] = off;
+    if (t == n_tiles - 1) runs.run_start[runs.n] = off + cnt;
+  }
+}
+
+// (search_kernels.hpp launch_hybrid_hits_merge)
+__global__ __launch_bounds__(256) void hybrid_hits_merge_kernel(HybridRuns runs, int n_leaves, const uint32_t *__restrict__ src_ids,
+                                                                const uint32_t *__restrict__ src_freqs, const uint32_t *__restrict__ src_epos,
+                                                                uint32_t src_cap, uint32_t *__restrict__ dst_ids, uint32_t *__restrict__ dst_freqs,
+                                                                uint32_t *__restrict__ dst_epos, uint32_t dst_cap) {
+  uint32_t start[9];
+#pragma unroll
+  for (int p = 0; p < 9; p++) start[p] = p <= (int)runs.n ? runs.run_start[p] : 0u;
+  const uint32_t total = runs.run_start[runs.n];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < total; j += gridDim.x * 256) {
+    const uint32_t x = src_ids[j];
+    uint32_t dest = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (q < (int)runs.n) {
+        const uint32_t b0 = start[q], e0 = start[q + 1];
+        if (j >= b0 && j < e0) {
+          dest += j - b0;
+        } else {
+          uint32_t b = b0, e = e0;
+          while (b < e) {
+            const uint32_t mid = b + ((e - b) >> 1);
+            if (src_ids[mid] < x) b = mid + 1;
+            else e = mid;
+          }
+          dest += b - b0;
+        }
+      }
+    }
+    dst_ids[dest] = x;
+    for (int l = 0; l < n_leaves; l++) {
+      dst_freqs[(size_t)l * dst_cap + dest] = src_freqs[(size_t)l * src_cap + j];
+      if (src_epos) dst_epos[(size_t)l * dst_cap + dest] = src_epos[(size_t)l * src_cap + j];
+    }
+  }
 }
 
 // dir[b] = lower_bound(ids, b << shift): entry i owns the buckets behind its predecessor's up to its own (the first entry
@@ -1436,10 +1479,22 @@ void launch_hybrid_tie_ids(const uint64_t *skey, const uint32_t *sidx, uint32_t 
 }
 void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
                              const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,
-                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s) {
+                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s,
+                             const HybridRuns *runs) {
   if (!n_tiles) return;
+  HybridRuns r;
+  memset(&r, 0, sizeof r);
+  if (runs) r = *runs;
   hipLaunchKernelGGL(hybrid_hits_pack_kernel, dim3(n_tiles), dim3(256), 0, s, tile_hits, n_tiles, n_leaves, src_ids, src_freqs, src_epos,
-                     src_stride, dst_ids, dst_freqs, dst_epos, dst_cap, total_out);
+                     src_stride, dst_ids, dst_freqs, dst_epos, dst_cap, total_out, r);
+}
+void launch_hybrid_hits_merge(const HybridRuns &runs, int n_leaves, const uint32_t *src_ids, const uint32_t *src_freqs,
+                              const uint32_t *src_epos, uint32_t src_cap, uint32_t *dst_ids, uint32_t *dst_freqs, uint32_t *dst_epos,
+                              uint32_t dst_cap, uint32_t max_total, hipStream_t s) {
+  if (!runs.n || !max_total) return;
+  const uint32_t need = (max_total + 255) / 256;
+  hipLaunchKernelGGL(hybrid_hits_merge_kernel, dim3(need < 16384 ? need : 16384), dim3(256), 0, s, runs, n_leaves, src_ids, src_freqs,
+                     src_epos, src_cap, dst_ids, dst_freqs, dst_epos, dst_cap);
 }
 HybridTileLite hybrid_tile_lite(const HybridTileArgs &a, size_t *lds_out) {
   HybridTileLite t;

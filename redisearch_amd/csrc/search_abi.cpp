@@ -142,6 +142,7 @@ struct Scratch {
   uint32_t hyb_trace_tiles = 0;
   // ... its general form, hit list wanted: doc id | frequencies | entry indices at the tiles' fixed slots (hybrid_hits_pack)
   DevBuf<uint32_t> hyb_hit_ids, hyb_hit_freqs, hyb_hit_epos;
+  DevBuf<uint32_t> hyb_run_ids, hyb_run_freqs, hyb_run_epos, hyb_run_start;  // the packed runs of a multi-pass query's hit list, before the merge
 };
 thread_local Scratch tls_scratch;
 Scratch &scratch(int device) {
@@ -159,6 +160,7 @@ Scratch &scratch(int device) {
     s.hyb_skey.reset(); s.hyb_knn.reset(); s.hyb_trace.reset(); s.hyb_tie.reset();
     s.hyb_trace_tiles = 0;
     s.hyb_hit_ids.reset(); s.hyb_hit_freqs.reset(); s.hyb_hit_epos.reset();
+    s.hyb_run_ids.reset(); s.hyb_run_freqs.reset(); s.hyb_run_epos.reset(); s.hyb_run_start.reset();
     s.device = device;
   }
   return s;

@@ -422,9 +422,23 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &a, int type, int metric, uin
 void launch_hybrid_tie_ids(const uint64_t *skey, const uint32_t *sidx, uint32_t n, uint64_t tau, uint64_t *out, hipStream_t s);
 // dst[off(t) + r] = src[t * 1024 + r], r < tile_hits[t], off(t) = sum of tile_hits below t; ids, then n leaf columns of freqs
 // (src stride src_stride, dst stride dst_cap) and -- unless NULL -- of entry indices; *total_out (device or pinned) = the sum
+// runs (round 6: the hit list of a query of several passes -- a root union, a root of unions): pass p's tiles start at
+// runs->first_tile[p]; the workgroup of that tile also writes run_start[p] = off(first_tile[p]), the last one run_start[n] = the sum
+struct HybridRuns {
+  uint32_t n;                 // passes (<= 8; 0: no runs)
+  uint32_t first_tile[9];     // first_tile[n] = n_tiles
+  uint32_t *run_start;        // device, [n + 1]
+};
 void launch_hybrid_hits_pack(const uint32_t *tile_hits, uint32_t n_tiles, int n_leaves, const uint32_t *src_ids,
                              const uint32_t *src_freqs, const uint32_t *src_epos, uint32_t src_stride, uint32_t *dst_ids,
-                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s);
+                             uint32_t *dst_freqs, uint32_t *dst_epos, uint32_t dst_cap, uint32_t *total_out, hipStream_t s,
+                             const HybridRuns *runs = nullptr);
+// The packed runs -- each ascending by doc id, no doc id in two of them (every hit is reported by exactly one pass) -- merged into
+// ONE ascending list (union_flat.rs:223-320 yields a union's documents in doc-id order): entry j of run p goes to its index in the
+// run + the number of entries below its doc id in every other run (a binary search per other run).  src / dst as the pack's dst.
+void launch_hybrid_hits_merge(const HybridRuns &runs, int n_leaves, const uint32_t *src_ids, const uint32_t *src_freqs,
+                              const uint32_t *src_epos, uint32_t src_cap, uint32_t *dst_ids, uint32_t *dst_freqs, uint32_t *dst_epos,
+                              uint32_t dst_cap, uint32_t max_total, hipStream_t s);
 
 // ---- FT.HYBRID fusion (fusion_kernels.hip) -------------------------------------------------------------
 constexpr uint32_t kFuseMaxWindow = 4096;  // per upstream: (2 * 4096) * 17 bytes of LDS

@@ -327,15 +327,15 @@ def test_tree_query_shapes_the_general_kernel_declines():
     idf = [S.calculate_idf(2500, s) for s in sizes]
     bidf = [S.calculate_idf_bm25(2500, s) for s in sizes]
     w = [1.0, 2.0, 0.5, 1.0]
-    # (round 5: a root union of terms / intersections takes the tile kernel -- unless it has a union child, the hit list is wanted or
-    # the scorer divides by the result's slop, which differs from hit to hit in a union)
-    # (... and a root intersection of unions only: the smallest union drives, term by term -- unless the hit list is wanted)
+    # (round 5: a root union of terms / intersections takes the tile kernel -- unless it has a union child or the scorer divides
+    # by the result's slop, which differs from hit to hit in a union; round 6: also when the hit list is wanted)
+    # (... and a root intersection of unions only: the smallest union drives, term by term -- round 6: with the hit list too)
     for root, groups, scorer, kw, path in ((I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", {}, 2),
-                                           (I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", dict(want_hits=True), 0),
+                                           (I, [(U, 1.0, g[:2]), (U, 1.0, g[2:])], "BM25STD", dict(want_hits=True), 2),
                                            (U, [(T, 1.0, g[:1]), (I, 1.0, g[1:3])], "BM25STD", {}, 2),
                                            (U, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD", {}, 0),
                                            (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "TFIDF", {}, 0),
-                                           (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "BM25STD", dict(want_hits=True), 0),
+                                           (U, [(T, 1.0, g[:1]), (T, 1.0, g[1:2])], "BM25STD", dict(want_hits=True), 2),
                                            (I, [(T, 1.0, g[:1]), (U, 1.0, g[1:3])], "BM25STD.NORM", {}, 2)):
         nl = sum(len(x[2]) for x in groups)
         hq = S.HybridTreeQuery(root, groups, table=table, scorer=scorer, idf=idf[:nl], bm25_idf=bidf[:nl], weight=w[:nl], num_docs=2500,
@@ -347,6 +347,9 @@ def test_tree_query_shapes_the_general_kernel_declines():
         h.score(table, scorer, idf[:nl], bidf[:nl], w[:nl], 2500, 150.0, want_scores=False)
         ti, ts = h.topn(10)
         assert r["n_hits"] == len(h) and r["top"][0].tolist() == ti.tolist() and r["top"][1].tolist() == ts.tolist()
+        if kw.get("want_hits"):
+            hh = hq.take_hits()
+            assert hh.read()[0].tolist() == h.read()[0].tolist() and np.array_equal(hh.read()[1], h.read()[1])
 
 
 def test_tree_query_with_top_n_and_k_up_to_sixty_four():
@@ -385,13 +388,15 @@ def test_root_of_unions_only_is_driven_by_its_smallest_union(name, shape, with_o
     of the tile kernel per term of it, a document an earlier term of that union holds belongs to that term's pass (veto), one reduce
     kernel over all passes' tiles: against the staged form bit for bit and the CPU oracle (tree_case)."""
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + int(with_offsets) + (max_slop or 0) + 3 * int(in_order))
-    assert tree_case(rng, shape, with_offsets, max_slop=max_slop, in_order=in_order, want_hits=False) > 0
+    # (round 6: WITH the hit list -- every pass's hits in doc-id order, the runs merged by doc id behind the reduce kernel; ids,
+    # per-leaf frequencies, term records and leaf order against the staged list and the oracle's)
+    assert tree_case(rng, shape, with_offsets, max_slop=max_slop, in_order=in_order, want_hits=True) > 0
 
 
 def test_root_of_unions_over_many_tiles():
     rng = np.random.default_rng(41)
     n = tree_case(rng, [(U, 1.0, [0, 1]), (U, 1.0, [2, 3, 4])], False, n_range=(10_000, 30_000), max_doc=200_000, scorers=["BM25STD", "DISMAX"],
-                  want_hits=False)
+                  want_hits=True)
     assert n > 2000
     # a mass tie (DOCSCORE: three distinct scores) handed back by the reduce kernel (forced: a cap of 4 survivors): settled across
     # the passes by doc id, against the oracle's (score descending, doc id ascending)
@@ -446,10 +451,14 @@ def test_root_union_takes_the_tile_kernel(name, shape, with_offsets):
     ot = OracleTree(U, shape, recs, sizes)
     assert len(ot.docs) > 1500
     for scorer in ("BM25STD", "BM25STD.TANH", "DOCSCORE", "DISMAX", "BM25STD.NORM"):
-        a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
-                                                                  num_docs=max_doc, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
-                                                                  root_weight=1.5))
+        want_hits = scorer in ("BM25STD", "DISMAX")             # (round 6: the hit list of a multi-pass query -- runs merged by doc id)
+        a, b, ha, hb = general_and_staged(lambda: S.HybridTreeQuery(U, groups, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
+                                                                    num_docs=max_doc, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
+                                                                    root_weight=1.5, want_hits=want_hits))
         assert a["n_hits"] == len(ot.docs), (scorer, a["n_hits"], len(ot.docs))
+        if want_hits:
+            ids, _ = same_hit_lists(ha, hb, n_lists, with_records=with_offsets)
+            assert ids.tolist() == ot.docs
         if scorer == "BM25STD.NORM":
             continue                                             # (held to the staged form above; the oracle has no such scorer)
         scored = []
@@ -496,10 +505,13 @@ def test_root_union_over_many_tiles_and_one_sided_children():
                 knob("hybrid_surv_cap", cap)
                 # (cap 4: the reduce kernel hands a mass tie back; the exact select's (key, position) order is doc-id order inside
                 # one pass only: the entries at the cut's key are settled by a second select over their doc ids -- path 2 still)
-                a, b, _, _ = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, **kw))
+                a, b, ha, hb = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, want_hits=cap == 2048, **kw))
             finally:
                 knob("hybrid_surv_cap", 2048)
             assert a["n_hits"] > 500_000 and len(a["top"][0]) == top_n and len(a["knn"][0]) == k
+            if ha is not None:                                   # hundreds of tiles per run, runs of very different lengths
+                ids, _ = same_hit_lists(ha, hb, len(order))
+                assert len(ids) == a["n_hits"] and np.all(np.diff(ids.astype(np.int64)) > 0)
     idx.free()
 
 
@@ -723,12 +735,20 @@ def test_not_children_where_the_tile_kernel_cannot_run():
     g = [S.Postings.from_flat(x[0].flatten()) for x in built]
     table = table_for(rng, 2500)
     ones = [1.0] * 3
-    # a NOT child under a root of unions only with hits_out, RSGPU_EvalTree: refused with a message, not answered wrongly
+    # a NOT child under a root of unions only WITH hits_out (refused until round 6): the union drives term by term, the runs are
+    # merged by doc id -- (a | b) - c in doc-id order, a's / b's frequency columns (0 where the term is absent)
     hq = S.HybridTreeQuery(I, [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])], table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones,
                            num_docs=2500, avg_doc_len=150.0, top_n=10, want_hits=True)
-    with pytest.raises(RuntimeError, match="NOT"):
-        hq.run()
-    # (without hits_out the union drives, term by term: round 5)
+    hq.run()
+    assert S.hybrid_path() == 2
+    docs_ = [set(x[1]) for x in built]
+    want = sorted((docs_[0] | docs_[1]) - docs_[2])
+    hh = hq.take_hits()
+    hi, hf = hh.read()
+    assert hi.tolist() == want
+    for col, l in enumerate(hh.leaf_order()):
+        assert hf[col].tolist() == [built[l][1][d][0] if d in built[l][1] else 0 for d in want], (col, l)
+    # (without hits_out: round 5)
     hq = S.HybridTreeQuery(I, [(U, 1.0, g[:2]), (S.OP_NOT, 1.0, g[2:])], table=table, scorer="BM25STD", idf=ones, bm25_idf=ones, weight=ones,
                            num_docs=2500, avg_doc_len=150.0, top_n=10)
     hq.run()
