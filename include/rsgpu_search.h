@@ -300,9 +300,11 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
  * (src/iterators/hybrid_reader.c:625; `a ((b c)|d)`, `a (b|(c d)) (e|f)`): args->lists / n_lists are the terms the nodes name,
  * RSGPU_ScoreArgs.idf / bm25_idf / weight per LIST in their order, everything else as RSGPU_HybridQuery, hits_out included.
  * Results are those of RSGPU_EvalTreeNodes + RSGPU_Hits_Score / _TopN / _KnnRerank.  RSGPU_HybridQueryPath reads 2 when the
- * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds, nested at most four
- * levels, unions whose children are terms, unions or intersections of terms, no max_slop / in_order below the root (nor on it
- * when some child nests aggregates), no hits_out, no slop-dependent scorer over lists that store offsets under nested children;
+ * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds (or a child that is a plain
+ * union of terms to drive it), nested at most eight levels (four until round 6), unions and intersections in any arrangement (round
+ * 6: a union below an intersection below a union too -- the kernel folds the match over the result tree), no max_slop / in_order
+ * below the root (nor on it when some child nests aggregates), no hits_out, no slop-dependent scorer over lists that store offsets
+ * under nested children;
  * 0 when it ran stage by stage.  RSGPU_OP_NOT nodes (children: the excluded terms) are accepted as children of the root
  * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form, and
  * through THIS entry point no hit list either: a tree with RSGPU_OP_NOT nodes and hits_out set is refused (-1, RSGPU_LastError says

@@ -649,6 +649,7 @@ struct HybGroup {
   // the child's own node last) and what a hit must hold, as sets of leaves -- any_of: one of them; whole: a nested intersection
   // under a union, absent as a whole unless every term matched; must: the leaves every hit holds (a driver is picked among them)
   bool deep = false;
+  bool pred_tree = false;  // (round 6) its shape is beyond the sets below: the kernel folds the match over the result tree
   size_t n_children = 0;
   std::vector<TNode> tree;
   std::vector<uint32_t> any_of, whole, must;
@@ -934,6 +935,11 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
     T.ids_base = h.base;
     T.L = knn_rows;
   }
+  for (const HybGroup &g : groups) T.tree_pred |= g.pred_tree ? 1 : 0;
+  if (T.tree_pred) {
+    if (!want_score) tree_score_params(T.P, &h, nullptr);  // (the tree alone: the match is folded over it)
+    if (T.P.n_nodes <= 0 || root_union) return false;       // (no node array: the staged form)
+  }
   HybridReduceArgs R;
   hyb_outputs(sc, ca, cb, n_tiles, top_n, k, R);
   sc.hyb_trace_tiles = 0;
@@ -1019,6 +1025,8 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
       if (g == union_driven) {
         // the driving union: this pass's term holds the document (it drives); one that an earlier term holds is that pass's hit
         for (int t = h.group_first[g]; t < h.group_first[g + 1] && h.order[t] != ps.driver; t++) P.veto |= 1u << list_of_leaf[t];
+      } else if (T.tree_pred) {
+        // (the kernel folds the match over the result tree: no sets)
       } else if (!root_union && groups[g].deep) {
         // a child with aggregates of its own: its sets of leaves, moved to this pass's list slots
         auto slots = [&](uint32_t leaves) {
@@ -1630,6 +1638,12 @@ struct GroupBuilder {
       if (!under_union(k)) return false;
     return true;
   }
+  void must_only(int i) {  // the terms every hit holds: those below intersections only
+    const QNode &q = t.n[i];
+    if (q.op == 0) g.must.push_back(mask(i));
+    else if (q.op == 2)
+      for (int k : q.kids) must_only(k);
+  }
   bool required(int i) {  // a node every hit holds
     const QNode &q = t.n[i];
     if (q.op == 0) {
@@ -1678,7 +1692,13 @@ bool tree_groups(QTree &t, std::vector<HybGroup> &groups) {
     } else {
       g.deep = deep = true;
       g.n_children = q.kids.size();
-      if (!b.required(c)) return false;
+      if (!b.required(c)) {  // (a union below an intersection below a union: the match folded over the tree, HybridTreeArgs::tree_pred)
+        g.any_of.clear();
+        g.whole.clear();
+        g.must.clear();
+        g.pred_tree = true;
+        b.must_only(c);
+      }
     }
     groups.push_back(std::move(g));
   }

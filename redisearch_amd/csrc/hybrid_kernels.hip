@@ -1009,6 +1009,62 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 
   // ---- candidates: a list of every required set holds the document; compacted in driver order ----
   bool hit[DPT];
+  if (DEEP && A.tree_pred) {
+    // the match folded over the result tree (HybridTreeArgs::tree_pred): bottom-up which nodes match -- per level the AND / OR of
+    // the children seen so far, as score_one<DEEP> keeps its sums --, then top-down which of them are in the result
+    uint32_t lf[DPT], all_[DPT], any_[DPT];
+    uint64_t matched[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      lf[k] = 0u;
+#pragma unroll
+      for (int l = 0; l < ML; l++)
+        if (l < A.n_leaves) lf[k] |= ((mb[k] >> l) & 1u) << A.leaf_of[l];
+      all_[k] = ~0u;
+      any_[k] = 0u;
+      matched[k] = 0ull;
+    }
+    const int nn = A.P.n_nodes;
+    for (int i = 0; i < nn; i++) {
+      const uint32_t d = A.P.node_depth[i], op = A.P.node_op[i], leaf = A.P.node_leaf[i];
+#pragma unroll
+      for (int k = 0; k < DPT; k++) {
+        uint32_t v;
+        if (op == 0u) {
+          v = (lf[k] >> leaf) & 1u;
+        } else {
+          v = ((op == 2u ? all_[k] : any_[k]) >> d) & 1u;
+          all_[k] |= 1u << d;
+          any_[k] &= ~(1u << d);
+        }
+        if (d) {
+          all_[k] &= ~((v ^ 1u) << (d - 1u));
+          any_[k] |= v << (d - 1u);
+        }
+        matched[k] |= (uint64_t)v << i;
+      }
+    }
+    uint32_t alive[DPT], present[DPT];
+#pragma unroll
+    for (int k = 0; k < DPT; k++) alive[k] = present[k] = 0u;
+    for (int i = nn - 1; i >= 0; i--) {
+      const uint32_t d = A.P.node_depth[i], op = A.P.node_op[i], leaf = A.P.node_leaf[i];
+#pragma unroll
+      for (int k = 0; k < DPT; k++) {
+        const uint32_t up = d ? (alive[k] >> (d - 1u)) & 1u : 1u;
+        const uint32_t in = (uint32_t)(matched[k] >> i) & 1u & up;
+        alive[k] = (alive[k] & ~(1u << d)) | (in << d);
+        if (op == 0u) present[k] |= in << leaf;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < DPT; k++) {
+      hit[k] = live[k] && nn > 0 && ((matched[k] >> (nn - 1)) & 1ull) != 0ull && (mb[k] & A.veto) == 0u;
+#pragma unroll
+      for (int l = 1; l < ML; l++)
+        if (l < A.n_leaves && !((present[k] >> A.leaf_of[l]) & 1u)) ps[k][l - 1] = kHybNone;
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < DPT; k++) {
     // a nested / later child intersection that does not match as a whole is not in the result: its terms are absent
@@ -1029,6 +1085,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
 #pragma unroll
     for (int l = 1; l < ML; l++)
       if ((gone >> l) & 1u) ps[k][l - 1] = kHybNone;
+  }
   }
   uint32_t slot[DPT];
   const uint32_t nc = ordered_slots<DPT>(hit, slot, seg);

@@ -370,7 +370,7 @@ __device__ __forceinline__ void prox_load(const ProxParams &P, const View &o, Pr
 // anywhere): the same sum in the same order -- 0.0 + leaf(0) + leaf(1) ... -- with the leaf numbers compile-time constants,
 // so the weights / idfs come out of the argument block with constant offsets, all at once, instead of one dependent scalar
 // load after the other.
-// MAXD (DEEP only): the deepest node the caller admits.  Up to 4 levels the accumulators are picked by compare-and-select over
+// MAXD (DEEP only): the deepest node the caller admits.  Up to 8 levels the accumulators are picked by compare-and-select over
 // constant indices and stay in registers (the hybrid tile kernel's form: no scratch); beyond, they are indexed dynamically.
 // SP: ScoreParams, or -- FLAT > 0 only -- ScoreParamsFlat (search_kernels.hpp: the fields a flat AND of <= FLAT terms reads).
 template <bool DEEP, int FLAT = 0, int MAXD = kMaxTreeDepth, typename SP, typename FreqFn>
@@ -394,7 +394,7 @@ __device__ __forceinline__ double score_one(const SP &P, FreqFn F, uint32_t dlen
       for (int i = 0; i < P.n_nodes - 1; i++) {
         const int d = P.node_depth[i];
         double v;
-        if constexpr (MAXD <= 4) {
+        if constexpr (MAXD <= 8) {
           double own = 0.0, up = 0.0;
 #pragma unroll
           for (int q = 1; q <= MAXD; q++) {

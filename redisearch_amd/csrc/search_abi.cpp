@@ -636,7 +636,7 @@ static bool slop_dependent(int scorer) {
 }
 static void tree_score_params(ScoreParams &P, const RSGPU_Hits *h, const RSGPU_DocTable *t) {
   // table entry of hit id x (relative to the hits' base): x + (hits base - table first); may be negative
-  P.table_off = (long long)(h->base - t->first);
+  P.table_off = t ? (long long)(h->base - t->first) : 0;  // (t == NULL: the tree alone -- a query without a scoring branch)
   P.n_lists = h->n_lists;
   P.n_groups = h->n_groups;
   for (int g = 0; g <= h->n_groups; g++) P.group_first[g] = h->group_first[g];

@@ -357,7 +357,7 @@ void launch_hybrid_reduce(const HybridReduceArgs &r, hipStream_t s);
 //     hybrid_hits_pack_kernel -- a third launch, behind the reduce kernel: the answers do not wait for it -- moves them to
 //     their place in the list (exclusive sum of the tiles' hit counts).
 constexpr int kHybTreeMaxLists = 8;
-constexpr int kHybDeepLevels = 4;  // the deepest result tree (levels below the root) the general tile kernel scores: RSGPU_HybridTreeNodesQuery
+constexpr int kHybDeepLevels = 8;  // the deepest result tree (levels below the root) the general tile kernel scores: RSGPU_HybridTreeNodesQuery (4 until round 6)
 struct HybridOffsetView {  // OffsetView over the tree's leaves
   const uint8_t *bytes[kHybTreeMaxLists];
   const uint32_t *off_pos[kHybTreeMaxLists];
@@ -415,6 +415,12 @@ struct HybridTreeArgs {
   uint32_t *hit_epos;                          // [n][hit_stride], NULL: no list stores offsets
   uint32_t hit_stride;
   uint32_t pool_words;                         // set by the launcher
+  // round 6 -- nested trees the sets above cannot express (a union below an intersection below a union: `a (b | (c (d|e)))`): the
+  // kernel folds the MATCH over the result tree in P.node_* (post-order, leaves by column): a term matches when its list holds the
+  // document, a union when a child does, an intersection when every child does; a node is IN THE RESULT when it matches and its
+  // parent is in the result (union_flat.rs:297-320, intersection.rs:256-288) -- a hit = the root matches, the leaves outside the
+  // result count as absent.  req / opt_all are not read then; veto still is.
+  int tree_pred;
 };
 bool hybrid_tree_supported(int type, int metric, uint32_t stride16, uint32_t n_tiles, uint32_t top_n, uint32_t k, int n_lists);
 void launch_hybrid_tree_tiles(const HybridTreeArgs &a, int type, int metric, uint32_t n_tiles, hipStream_t s);

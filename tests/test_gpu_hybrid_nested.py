@@ -42,6 +42,14 @@ NESTED = [
     # (no term every hit holds: the plain union drives, term by term)
     ("(a|b) ((c d)|e)", ("and", 1.0, [("or", 1.0, [t(0), t(1)]), ("or", 1.0, [("and", 1.0, [t(2), t(3)]), t(4)])]), 5),
     ("a ((b (c d))|e)", ("and", 1.0, [t(0), ("or", 1.0, [("and", 2.0, [t(1), ("and", 0.5, [t(2), t(3)])]), t(4)])]), 5),
+    # round 6 (staged until then): more than four levels; a union below an intersection below a union -- the match is folded over
+    # the result tree inside the kernel (HybridTreeArgs::tree_pred)
+    ("five levels", ("and", 1.0, [t(0), ("and", 1.0, [t(1), ("and", 1.0, [t(2), ("and", 1.0, [t(3), ("or", 1.0, [t(4), t(5)])])])])]), 6),
+    ("a (b|(c (d|e)))... as ((b (c|d))|e)", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [t(1), ("or", 1.0, [t(2), t(3)])]), t(4)])]), 5),
+    ("(a|((b|c) d)) e", ("and", 1.0, [("or", 1.5, [t(0), ("and", 2.0, [("or", 0.5, [t(1), t(2)]), t(3)])]), t(4)]), 5),
+    ("seven levels, unions and intersections in turn",
+     ("and", 1.0, [t(0), ("or", 0.5, [t(1), ("and", 2.0, [t(2), ("or", 1.5, [t(3), ("and", 0.7, [t(4), ("or", 1.0, [t(5), ("and", 3.0, [t(6), t(7)])])])])])])]), 8),
+    ("a ((b|c) (d|(e f)))|g)", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [("or", 2.0, [t(1), t(2)]), ("or", 0.5, [t(3), ("and", 1.0, [t(4), t(5)])])]), t(6)])]), 7),
 ]
 
 
@@ -115,8 +123,8 @@ def test_two_level_trees_through_the_nodes_entry_point():
 
 
 DECLINED = [
-    ("five levels", ("and", 1.0, [t(0), ("and", 1.0, [t(1), ("and", 1.0, [t(2), ("and", 1.0, [t(3), ("or", 1.0, [t(4), t(5)])])])])]), 6),
-    ("a union below an intersection below a union", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [t(1), ("or", 1.0, [t(2), t(3)])]), t(4)])]), 5),
+    ("ten levels", ("and", 1.0, [t(0), ("and", 1.0, [t(1), ("and", 1.0, [("and", 1.0, [("and", 1.0, [("and", 1.0, [("and", 1.0, [("and", 1.0, [("and", 1.0, [
+        ("or", 1.0, [t(2), t(3)])])])])])])]), t(4)])])]), 5),
     ("a root union", ("or", 1.0, [t(0), ("and", 1.0, [t(1), ("or", 1.0, [t(2), t(3)])])]), 4),
     ("no term and no union of terms to drive", ("and", 1.0, [("or", 1.0, [("and", 1.0, [t(0), t(1)]), t(2)]), ("or", 1.0, [("and", 1.0, [t(3), t(4)]), t(5)])]), 6),
     ("a nested window", ("and", 1.0, [t(0), ("or", 1.0, [("and", 1.0, [t(1), t(2)], 3, False), t(3)])]), 4),
