@@ -303,8 +303,8 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
  * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds (or a child that is a plain
  * union of terms to drive it), nested at most eight levels (four until round 6), unions and intersections in any arrangement (round
  * 6: a union below an intersection below a union too -- the kernel folds the match over the result tree), no max_slop / in_order
- * below the root (nor on it when some child nests aggregates), no hits_out, no slop-dependent scorer over lists that store offsets
- * under nested children;
+ * BELOW the root (on the root: yes, also over nested children -- round 6), no hits_out; slop-dependent scorers over lists that
+ * store offsets under nested children included (round 6: a child's offsets are its leaves' in the result, merged);
  * 0 when it ran stage by stage.  RSGPU_OP_NOT nodes (children: the excluded terms) are accepted as children of the root
  * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form, and
  * through THIS entry point no hit list either: a tree with RSGPU_OP_NOT nodes and hits_out set is refused (-1, RSGPU_LastError says

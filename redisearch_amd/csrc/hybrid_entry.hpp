@@ -1702,8 +1702,9 @@ bool tree_groups(QTree &t, std::vector<HybGroup> &groups) {
     }
     groups.push_back(std::move(g));
   }
-  // (the root's own window: the two-level forms check it -- prox_within_range over terms / unions / intersections of terms)
-  if (deep && (t.root_slop >= 0 || t.root_in_order)) return false;
+  // (the root's own window over nested children -- round 6: a child's offsets are those of its leaves in the result, merged
+  // (RSIndexResult_IterateOffsets of an aggregate, src/index_result/index_result.c:51-103 reads them through it): the two-level
+  // proximity code over the children's leaf ranges, absent leaves skipped)
   t.depth = deep ? std::max(t.depth, 3) : t.depth;
   return true;
 }
@@ -1747,8 +1748,7 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
       }
     }
     for (size_t l = 0; l < n_lists; l++) general = general && seen[l];
-    // (nested children: a scorer that divides by the result's slop would read the term offsets through them -- staged)
-    if (deep && want_score && offsets && slop_dependent(a->score->scorer)) general = false;
+    (void)offsets;  // (round 6: a scorer that divides by the result's slop over nested children runs on the tile path too)
   }
   if (general) {
     const bool norm = want_score && a->score->scorer == RSGPU_SCORER_BM25STD_NORM;
@@ -1760,7 +1760,7 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
       HybridTileRun run(plan);
       general = !f || run.labels_ok;
       if (general && f) f->upload_query(run.ca.c, a->query, true);
-      if (general && hybrid_general(a, a->lists, groups, deep ? -1 : qt.root_slop, deep ? 0 : qt.root_in_order, nullptr, f, run.knn_rows,
+      if (general && hybrid_general(a, a->lists, groups, qt.root_slop, qt.root_in_order, nullptr, f, run.knn_rows,
                                     want_score, want_knn, run.ca.c, run.cb.c, run.sc, run.prof, run.ev)) {
         tls_hybrid_path = 2;
         return 0;

@@ -1479,10 +1479,11 @@ void launch_hybrid_tree_tiles(const HybridTreeArgs &args, int type, int metric, 
   const size_t lds = (size_t)a.pool_words * 4 + (a.k ? (size_t)a.chunks * 16 : 0);
   const bool small = a.n <= 4 && a.n_leaves <= 4 && a.n_req <= 4 && a.n_veto_all <= 4 && a.n_opt_all <= 4;
   const bool prox = a.prox_filter || (a.prox_slop && a.top_n);
-  if (a.P.n_nodes > 0 && prox) throw std::runtime_error("hybrid tile kernel: a nested result tree has no proximity form");
 #define RSGPU_HYBT(T, M)                                                                                                          \
   do {                                                                                                                            \
-    if (a.P.n_nodes > 0)                                                                                                          \
+    if (a.P.n_nodes > 0 && prox) /* (round 6: the root's window / the per-hit slop over nested children: their leaves, flattened) */ \
+      hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists, true, true>), dim3(n_tiles), dim3(256), lds, s, a);    \
+    else if (a.P.n_nodes > 0)                                                                                                     \
       hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, kHybTreeMaxLists, true, false>), dim3(n_tiles), dim3(256), lds, s, a);   \
     else if (small && prox) hipLaunchKernelGGL((hybrid_tree_tile_kernel<T, M, 4, false, true>), dim3(n_tiles), dim3(256), lds, s, a); \
     else if (prox)                                                                                                                \

@@ -74,8 +74,9 @@ def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, 
     q = O.philox_rows(11, 1 << 40, 1, 24)[0]
     ot = DeepOracle(tree, recs, sizes)
     for scorer in scorers:
-        # (a scorer that divides by the slop reads the term offsets through the nested children: that query is staged)
-        path = 0 if (deep and with_offsets and scorer in SLOP_DEPENDENT) else want_path
+        # (a scorer that divides by the slop reads the term offsets through the nested children: staged until round 6 -- a child's
+        # offsets are its leaves' in the result, merged: the two-level proximity code over the children's leaf ranges)
+        path = want_path
         a, b, ha, hb = general_and_staged(lambda: S.HybridNodesQuery(tree, g, table=table, scorer=scorer, idf=idf, bm25_idf=bidf, weight=w,
                                                                      num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
                                                                      root_weight=1.5, want_hits=want_hits), want_path=path)
@@ -111,6 +112,16 @@ def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, 
 def test_nested_trees_take_the_tile_kernel(name, tree, n_lists, with_offsets):
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 10000 + int(with_offsets))
     assert nested_case(rng, tree, n_lists, with_offsets) > 0
+
+
+@pytest.mark.parametrize("max_slop,in_order", [(4, False), (None, True), (12, True)])
+def test_the_roots_window_over_nested_children(max_slop, in_order):
+    """`a ((b c)|d)` SLOP n / INORDER on the ROOT (round 6; staged until then): IndexResult_IsWithinRange reads a nested child's offsets
+    through the aggregate -- its leaves' positions, merged -- so the window is the two-level one over the children's leaf ranges"""
+    rng = np.random.default_rng(600 + (max_slop or 0) + int(in_order))
+    for tree, n_lists in ((("and", 1.0, [t(0), ("or", 0.5, [("and", 2.0, [t(1), t(2)]), t(3)])], max_slop, in_order), 4),
+                          (("and", 1.0, [t(0), ("and", 0.7, [t(1), ("or", 1.5, [t(2), t(3)])]), t(4)], max_slop, in_order), 5)):
+        assert nested_case(rng, tree, n_lists, True, scorers=["BM25STD", "TFIDF", "DISMAX"]) >= 0
 
 
 def test_two_level_trees_through_the_nodes_entry_point():
