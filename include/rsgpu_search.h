@@ -303,12 +303,12 @@ RSGPU_Hits *RSGPU_EvalTreeNodes(const RSGPU_TreeNode *nodes, size_t n_nodes, RSG
  * general tile kernel took it: a root intersection over <= 8 lists, one of them a term every hit holds (or a child that is a plain
  * union of terms to drive it), nested at most eight levels (four until round 6), unions and intersections in any arrangement (round
  * 6: a union below an intersection below a union too -- the kernel folds the match over the result tree), no max_slop / in_order
- * BELOW the root (on the root: yes, also over nested children -- round 6), no hits_out; slop-dependent scorers over lists that
+ * BELOW the root (on the root: yes, also over nested children -- round 6); hits_out (round 6) and slop-dependent scorers over lists that
  * store offsets under nested children included (round 6: a child's offsets are its leaves' in the result, merged);
  * 0 when it ran stage by stage.  RSGPU_OP_NOT nodes (children: the excluded terms) are accepted as children of the root
- * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form, and
- * through THIS entry point no hit list either: a tree with RSGPU_OP_NOT nodes and hits_out set is refused (-1, RSGPU_LastError says
- * so) -- `a (b|c) -d` with its hit list is RSGPU_HybridTreeQuery's (two levels), which hands the positive children's columns out. */
+ * intersection -- `a ((b c)|d) -e` -- with the meaning they have in RSGPU_HybridTreeQuery; such a query has no staged form (a shape
+ * the tile kernel declines is refused: -1, RSGPU_LastError says so); hits_out (round 6) receives the positive children's columns and
+ * the result tree with the virtual child in it, as RSGPU_HybridTreeQuery's. */
 int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_nodes, RSGPU_HybridQueryArgs *args);
 /* The result tree behind a hit list, post-order (after the intersections sorted their children by size): per node the
  * operator, the leaf column of a term (-1 for aggregates; leaves are the child slots of RSGPU_Hits_LeafOrder), the number

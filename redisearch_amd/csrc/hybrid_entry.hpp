@@ -1729,7 +1729,7 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
   QTree qt;
   std::vector<HybGroup> groups;
   const bool parsed = parse_nodes(nodes, n_nodes, a->lists, n_lists, qt);
-  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) && !a->hits_out &&
+  bool general = scan_tuning().hybrid_tiles && scan_tuning().hybrid_tree_tiles && (want_score || want_knn) &&
                  n_lists <= (size_t)kHybTreeMaxLists && (!want_knn || (f && f->key_bytes == 4)) && parsed && tree_groups(qt, groups);
   bool deep = false;
   if (general) {
@@ -1760,7 +1760,7 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
       HybridTileRun run(plan);
       general = !f || run.labels_ok;
       if (general && f) f->upload_query(run.ca.c, a->query, true);
-      if (general && hybrid_general(a, a->lists, groups, qt.root_slop, qt.root_in_order, nullptr, f, run.knn_rows,
+      if (general && hybrid_general(a, a->lists, groups, qt.root_slop, qt.root_in_order, a->hits_out, f, run.knn_rows,
                                     want_score, want_knn, run.ca.c, run.cb.c, run.sc, run.prof, run.ev)) {
         tls_hybrid_path = 2;
         return 0;
@@ -1770,8 +1770,8 @@ extern "C" int RSGPU_HybridTreeNodesQuery(const RSGPU_TreeNode *nodes, size_t n_
   }
   if (parsed && qt.has_not)
     throw std::runtime_error("RSGPU_HybridTreeNodesQuery: a query with NOT children runs on the general tile kernel only -- NOT nodes over "
-                             "terms under a root intersection of at most eight lists with a term or a union of terms to drive it, no "
-                             "hits_out, top_n / k <= 64, labels a device table holds");
+                             "terms under a root intersection of at most eight lists with a term or a union of terms to drive it, "
+                             "top_n / k <= 64, labels a device table holds");
   // stage by stage (the index lock is released: the entry points below take it themselves)
   return plan.staged(std::unique_ptr<RSGPU_Hits>(RSGPU_EvalTreeNodes(nodes, n_nodes, a->lists, n_lists)));
   S_CATCH_HYBRID(a)

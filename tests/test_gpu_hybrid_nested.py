@@ -16,7 +16,7 @@ import pytest
 import oracle as O
 from redisearch_amd import search as S
 from redisearch_amd import vecsim as V
-from tests.test_gpu_hybrid_general import general_and_staged, knob, table_for
+from tests.test_gpu_hybrid_general import general_and_staged, knob, same_hit_lists, table_for
 from tests.test_gpu_tree import DeepOracle, rand_list
 
 pytestmark = pytest.mark.gpu
@@ -81,6 +81,9 @@ def nested_case(rng, tree, n_lists, with_offsets, want_path=2, scorers=SCORERS, 
                                                                      num_docs=n_docs, avg_doc_len=avg, top_n=10, index=idx, q=q, k=10,
                                                                      root_weight=1.5, want_hits=want_hits), want_path=path)
         assert a["n_hits"] == len(ot.docs), (scorer, a["n_hits"], len(ot.docs))
+        if want_hits:
+            ids, _ = same_hit_lists(ha, hb, n_lists, with_records=with_offsets)
+            assert ids.tolist() == list(ot.docs)
         scored = []
         for d in ot.docs:
             node = ot.node(ot.tree, d, idf, bidf, w)
@@ -154,10 +157,14 @@ def test_shapes_the_tile_kernel_declines_are_answered_stage_by_stage(name, tree,
         assert nested_case(rng, tree, n_lists, False, want_path=0, scorers=scorers) > 0
 
 
-def test_hits_out_of_a_nested_tree_is_the_staged_hit_list():
-    rng = np.random.default_rng(5)
-    tree = NESTED[0][1]
-    assert nested_case(rng, tree, 4, False, want_path=0, scorers=["BM25STD"], want_hits=True) > 0
+@pytest.mark.parametrize("with_offsets", [False, True])
+@pytest.mark.parametrize("which", [0, 1, 5, 8, 11, 12, 14])
+def test_hits_out_of_a_nested_tree_is_the_staged_hit_list(which, with_offsets):
+    """round 6: on the tile path (staged until then) -- doc ids, per-leaf frequencies (0 for a leaf outside the result), term
+    records and leaf order of RSGPU_EvalTreeNodes' list"""
+    rng = np.random.default_rng(5 + which)
+    name, tree, n_lists = NESTED[which]
+    assert nested_case(rng, tree, n_lists, with_offsets, scorers=["BM25STD", "TFIDF"], want_hits=True) > 0
 
 
 def test_nested_tree_over_many_tiles_and_a_mutated_index():
@@ -267,12 +274,16 @@ def test_not_nodes_next_to_nested_children_against_the_oracle():
     o.add_bulk(O.philox_rows(11, 0, 1200, 24)[cand - 100], 1)
     li, _ = o.topk(q, 10)
     assert a["knn"][0].tolist() == cand[li.astype(np.int64) - 1].tolist()
-    # where the tile kernel cannot run, such a query is refused with a message (hits_out; a NOT below a union: malformed)
-    for tr, kw in ((tree, dict(want_hits=True)), (("and", 1.0, [t(0), ("or", 1.0, [t(1), ("not", 1.0, [t(2)])])]), {})):
-        hq = S.HybridNodesQuery(tr, g if kw else g[:3], table=table, scorer="BM25STD", idf=idf, bm25_idf=bidf, weight=w, num_docs=n_docs,
-                                avg_doc_len=avg, top_n=10, **kw)
-        with pytest.raises(RuntimeError):
-            hq.run()
+    # with the hit list (round 6; refused through this entry point until then): the positive children's documents, in order
+    hq = S.HybridNodesQuery(tree, g, table=table, scorer="BM25STD", idf=idf, bm25_idf=bidf, weight=w, num_docs=n_docs, avg_doc_len=avg,
+                            top_n=10, want_hits=True)
+    hq.run()
+    assert S.hybrid_path() == 2 and hq.take_hits().read()[0].tolist() == docs
+    # where the tile kernel cannot run, such a query is refused with a message (a NOT below a union: malformed)
+    hq = S.HybridNodesQuery(("and", 1.0, [t(0), ("or", 1.0, [t(1), ("not", 1.0, [t(2)])])]), g[:3], table=table, scorer="BM25STD", idf=idf,
+                            bm25_idf=bidf, weight=w, num_docs=n_docs, avg_doc_len=avg, top_n=10)
+    with pytest.raises(RuntimeError):
+        hq.run()
     idx.free()
 
 
