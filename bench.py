@@ -923,6 +923,28 @@ def _hybrid_general_shapes(lib, S, enc_fo, enc_full, raws, table, idx, qvecs, n_
                                                                                                    (S.OP_UNION, 1.0, [fo[j], fo[j2]])],
                                                                                   index=idx, q=qvecs[qi], k=10, **a))
         shapes["two_unions_of_two_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 6: `a | b` WITH the hit list -- the passes' runs merged by doc id (7 M hits)
+            a = sc([i, j]); a["scorer"] = "BM25STD"
+            mk.append(lambda a=a, i=i, j=j, qi=qi: S.HybridTreeQuery(S.OP_UNION, [(S.OP_TERM, 1.0, [fo[i]]), (S.OP_TERM, 1.0, [fo[j]])],
+                                                                     index=idx, q=qvecs[qi], k=10, want_hits=True, **a))
+        shapes["root_union_of_two_terms_hit_list_wanted_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 6: `a ((b (c|d)) | e)` -- a union below an intersection below a union: the match folded over the tree
+            j2, j3, i2 = n_a + (j - n_a + 1) % n_b, n_a + (j - n_a + 2) % n_b, (i + 1) % n_a
+            a = sc([i, j, j2, j3, i2]); a["scorer"] = "BM25STD"
+            tree = ("and", 1.0, [("t", 0), ("or", 1.0, [("and", 1.0, [("t", 1), ("or", 1.0, [("t", 2), ("t", 3)])]), ("t", 4)])])
+            mk.append(lambda a=a, i=i, j=j, j2=j2, j3=j3, i2=i2, qi=qi, tree=tree: S.HybridNodesQuery(tree, [fo[i], fo[j], fo[j2], fo[j3], fo[i2]], index=idx,
+                                                                                                     q=qvecs[qi], k=10, **a))
+        shapes["nested_union_below_intersection_below_union_freqs_only_bm25std_knn"] = mk
+        mk = []
+        for qi, (i, j) in enumerate(pairs):   # round 6: `a ((b c) | d)` over Full-codec lists, TFIDF.DOCNORM -- the per-hit slop through nested children
+            j2, j3 = n_a + (j - n_a + 1) % n_b, n_a + (j - n_a + 2) % n_b
+            a = sc([i, j, j2, j3]); a["scorer"] = "TFIDF.DOCNORM"
+            tree = ("and", 1.0, [("t", 0), ("or", 1.0, [("and", 1.0, [("t", 1), ("t", 2)]), ("t", 3)])])
+            mk.append(lambda a=a, i=i, j=j, j2=j2, j3=j3, qi=qi, tree=tree: S.HybridNodesQuery(tree, [fu[i], fu[j], fu[j2], fu[j3]], index=idx,
+                                                                                              q=qvecs[qi], k=10, **a))
+        shapes["nested_a_and_bc_or_d_full_codec_tfidf_docnorm_slop_knn"] = mk
         for name, makers in shapes.items():
             rec = {}
             answers = {}
