@@ -139,7 +139,7 @@ static void hyb_outputs(Scratch &sc, QueryCtx *ca, QueryCtx *cb, uint32_t n_tile
   R.n_tiles = n_tiles;
   R.top_n = top_n;
   R.k = k;
-  R.surv_cap = (uint32_t)std::min(std::max(scan_tuning().hybrid_surv_cap, 1), 2048);
+  R.surv_cap = (uint32_t)std::min(std::max(scan_tuning().hybrid_surv_cap, 1), 4096);
   R.tile_hits = sc.hyb_hits.p;
   R.part_skey = sc.hyb_skey.p;
   R.part_sidx = sc.hyb_sidx.p;

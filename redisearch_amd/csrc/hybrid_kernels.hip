@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
 //      ranked; ranks below k are the answer.
 // More survivors than the LDS list holds (an adversarial arrangement): *out_n = 0xFFFFFFFF and the caller answers the query
 // with the staged pipeline.
-constexpr uint32_t kHybSurvivors = 2048;  // (R.surv_cap <= this: a knob for the tests of the way out)
+constexpr uint32_t kHybSurvivors = 4096;  // (R.surv_cap <= this: a knob for the tests of the way out; 2 048 until round 6)
 #define RSGPU_RED_MARK(p)                                                                                              \
   do {                                                                                                                 \
     if (R.trace && threadIdx.x == 0) R.trace[(SCORE ? 0 : kHybTracePhases) + (p)] = __builtin_amdgcn_s_memrealtime(); \
@@ -694,7 +694,24 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
     }
   }
   __syncthreads();
-  const SKey tau{wtau_k[0], wtau_i[0]};  // (none: fewer than k groups hold anything -- everything passes)
+  SKey tau{wtau_k[0], wtau_i[0]};
+  if (sk_same(tau, sk_none())) {
+    // fewer than k of the 64 groups hold anything (k above 32 over a few dozen tiles: round-5 advisor -- everything passed and
+    // queries of ordinary size went to the exact-select settlement): the k-th of the 1 024 THREAD bests instead, every thread
+    // counting the bests before its own -- rare, 1 024 LDS reads per thread.  Fewer than k tiles hold anything: no bound at all,
+    // every entry is ranked (at most 63 x 64 of them: they fit the survivors' list)
+    if (!sk_same(best, sk_none())) {
+      uint32_t rank = 0;
+#pragma unroll 8
+      for (uint32_t j = 0; j < 1024; j++) rank += sk_less(SKey{lk[j], li[j]}, best) ? 1u : 0u;
+      if (rank == k - 1) {
+        wtau_k[0] = best.k;
+        wtau_i[0] = best.i;
+      }
+    }
+    __syncthreads();
+    tau = SKey{wtau_k[0], wtau_i[0]};
+  }
   __syncthreads();  // (lk / li are rewritten below)
   RSGPU_RED_MARK(2);  // bound
   // 3. the lists of the tiles whose first entry passes; survivors.  The passing tiles (about k of them) are listed first, then

@@ -134,7 +134,7 @@ struct ScanTuning {
                                        // profiles/r06_hybrid_coalesce_ab.json); 0: one query after the other
   int hybrid_poll = 1;     // ... the host polls completion flags in pinned memory instead of synchronising the stream
   int hybrid_trace = 0;    // diagnostics: the tile kernel records a phase clock per tile (RSGPU_HybridTrace)
-  int hybrid_surv_cap = 2048;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)
+  int hybrid_surv_cap = 4096;  // ... candidates its reduce kernel ranks at the bound before it hands the query back (tests: small values)
   int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
   int decode_lean = 1;     // the two-launch hybrid query decodes doc ids + frequencies only (a Full-codec list: 8 of 20 bytes per posting; A/B knob)
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)

@@ -256,7 +256,7 @@ void launch_build_bucket_dir(const uint32_t *ids, uint32_t n, uint32_t shift, ui
 void launch_pack_len_score(const uint32_t *doc_len, const float *doc_score, uint32_t n, void *ls, hipStream_t s);
 struct HybridReduceArgs {
   uint32_t n_tiles, top_n, k;
-  uint32_t surv_cap;                   // survivors the reduce workgroup ranks in LDS (<= 2048); more: *out_n = 0xFFFFFFFF
+  uint32_t surv_cap;                   // survivors the reduce workgroup ranks in LDS (<= 4096); more: *out_n = 0xFFFFFFFF
   const uint32_t *tile_hits;
   const uint64_t *part_skey;
   const uint32_t *part_sidx;

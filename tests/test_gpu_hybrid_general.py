@@ -406,7 +406,7 @@ def test_root_of_unions_over_many_tiles():
         assert tree_case(rng, [(U, 1.0, [0, 1]), (U, 1.0, [2, 3])], False, n_range=(10_000, 30_000), max_doc=200_000, scorers=["DOCSCORE", "DISMAX"],
                          want_hits=False) > 1000
     finally:
-        knob("hybrid_surv_cap", 2048)
+        knob("hybrid_surv_cap", 4096)
 
 
 # ---- a root UNION on the tile path (round 5) ----------------------------------------------------------------------------------------
@@ -507,7 +507,7 @@ def test_root_union_over_many_tiles_and_one_sided_children():
                 # one pass only: the entries at the cut's key are settled by a second select over their doc ids -- path 2 still)
                 a, b, ha, hb = general_and_staged(lambda: S.HybridTreeQuery(U, groups, scorer=scorer, top_n=top_n, k=k, want_hits=cap == 2048, **kw))
             finally:
-                knob("hybrid_surv_cap", 2048)
+                knob("hybrid_surv_cap", 4096)
             assert a["n_hits"] > 500_000 and len(a["top"][0]) == top_n and len(a["knn"][0]) == k
             if ha is not None:                                   # hundreds of tiles per run, runs of very different lengths
                 ids, _ = same_hit_lists(ha, hb, len(order))
@@ -719,7 +719,7 @@ def test_not_children_with_an_empty_excluded_list_and_under_a_mass_tie():
                 knob("hybrid_surv_cap", cap)
                 hq.run()
             finally:
-                knob("hybrid_surv_cap", 2048)
+                knob("hybrid_surv_cap", 4096)
             assert S.hybrid_path() == 2
             a = hq.results()
             assert a["n_hits"] == len(ot.docs)

@@ -262,7 +262,7 @@ def test_more_candidates_at_the_bound_than_the_reduce_kernel_ranks():
             for key in ("top", "knn"):
                 assert st[key][0].tolist() == want[key][0].tolist() and st[key][1].tolist() == want[key][1].tolist()
         finally:
-            lib.RSGPU_SetTuning(b"hybrid_surv_cap", 2048)
+            lib.RSGPU_SetTuning(b"hybrid_surv_cap", 4096)
             lib.RSGPU_SetTuning(b"hybrid_tiles", 1)
         hq.run()
         assert S.hybrid_path() == 1
