@@ -566,42 +566,72 @@ def _batched_wall(index, qs, k, ids_of_block, block, calls=3):
 
 
 def extra_batched_f32(lib, V, index, rows, dim):
-    """The rest of K5: 256 queries per corpus pass on the PLAIN fp32 headline index (RediSearch's default type) through
-    RSGPU_FlatIndex_TopKBatch -- the matrix-core filter pass reads the fp32 rows themselves (no shadow; gemm_qs_f32_kernel),
-    survivors are re-scored exactly.  Replies must be bit-identical to VecSimIndex_TopKQuery."""
+    """The rest of K5: 256 queries per corpus pass on a PLAIN fp32 cosine index (RediSearch's default type; an index of its own --
+    the headline index carries the two-stage extra's opt-in shadow) through RSGPU_FlatIndex_TopKBatch.  Default route since round
+    6: the fp32 rows are quantised to int8 on their way to the int8 matrix cores (gemm_qs_h8r_kernel<.., SRC_F8>; nothing stored);
+    beside it the bf16-in-flight form (knob gemm_qs_f8 = 0: gemm_qs_f32_kernel).  Survivors are re-scored exactly: replies must be
+    bit-identical to VecSimIndex_TopKQuery."""
     k, batch, reps = 100, 256, 8
-    qs = philox_host_rows(V, QUERY_BASE + 5000, batch * 4, dim).reshape(4, batch, dim)
-    index.topk_batch(qs[0], k)  # allocations
-    V.coalesce_stats(reset=True)
-    lib.RSGPU_ResetProfile()
-    lib.RSGPU_SetProfiling(1)
-    t0 = time.perf_counter()
-    for i in range(reps):
-        ids, sc, cnt = index.topk_batch(qs[(i + 1) % 4], k)
-    el = time.perf_counter() - t0
-    lib.RSGPU_SetProfiling(0)
-    launches, ms, _ = V.scan_profile()
-    mq = V.coalesce_stats()["mq_passes"]
-    dev_ms = ms / max(launches, 1)
-    same = True
-    for i in (0, 85, 170, 255):
-        si, ss = index.topk_query(qs[reps % 4][i], k).results()
-        same &= si.tolist() == ids[i].tolist() and ss.tolist() == sc[i].tolist()
-    wall_ms, same4 = _batched_wall(index, qs, k, ids, reps % 4)
-    same &= same4
-    flops = 2.0 * batch * dim * rows
-    return {"workload": "%dx%d fp32 FLAT COSINE top-%d on the plain index (no shadow), batch=%d queries per corpus pass "
-                        "(RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
-            "device_ms_per_pass": dev_ms, "wall_ms_per_pass": wall_ms, "qps_device": batch / dev_ms * 1e3, "qps_wall": batch / wall_ms * 1e3,
-            "qps_wall_one_pass_per_call": reps * batch / el,
-            "matrix_core_passes": int(launches), "exact_multi_query_scan_passes_instead": int(mq),
-            "hbm_gbs": rows * dim * 4 / dev_ms / 1e6, "hbm_frac": rows * dim * 4 / dev_ms / 1e6 / HBM_PEAK_GBS,
-            "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
-            "kernel": "gemm_qs_f32_kernel (fp32 tiles global->LDS by DMA in K-part ring slots, v_cvt_pk_bf16_f32 on the way to "
-                      "v_mfma_f32_32x32x16_bf16, 256 queries register-stationary) + progressive thresholds + batch_rescore_kernel "
-                      "(the single-query scan's arithmetic) + per-query select; HIP events around the whole device pipeline of a pass",
-            "bit_identical_to_single_queries": bool(same),
-            "algorithmic_bytes_per_pass": rows * dim * 4}
+    del index
+    idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_Cosine)
+    try:
+        idx.reserve(rows)
+        idx.add_philox_rows(SEED, 0, rows, 1)
+        qs = philox_host_rows(V, QUERY_BASE + 5000, batch * 4, dim).reshape(4, batch, dim)
+        idx.topk_batch(qs[0], k)  # allocations, the index-wide quantisation statistics
+        V.coalesce_stats(reset=True)
+        lib.RSGPU_ResetProfile()
+        lib.RSGPU_SetProfiling(1)
+        t0 = time.perf_counter()
+        for i in range(reps):
+            ids, sc, cnt = idx.topk_batch(qs[(i + 1) % 4], k)
+        el = time.perf_counter() - t0
+        lib.RSGPU_SetProfiling(0)
+        launches, ms, _ = V.scan_profile()
+        mq = V.coalesce_stats()["mq_passes"]
+        dev_ms = ms / max(launches, 1)
+        same = True
+        for i in (0, 85, 170, 255):
+            si, ss = idx.topk_query(qs[reps % 4][i], k).results()
+            same &= si.tolist() == ids[i].tolist() and ss.tolist() == sc[i].tolist()
+        wall_ms, same4 = _batched_wall(idx, qs, k, ids, reps % 4)
+        same &= same4
+        bf16_ms, bf16_same = None, None
+        try:   # the bf16-in-flight form over the same index, for the record (rounds 4-5's route)
+            lib.RSGPU_SetTuning(b"gemm_qs_f8", 0)
+            idx.topk_batch(qs[0], k)
+            lib.RSGPU_ResetProfile()
+            lib.RSGPU_SetProfiling(1)
+            for i in range(5):
+                ids0, sc0, _ = idx.topk_batch(qs[(i + 1) % 4], k)
+            lib.RSGPU_SetProfiling(0)
+            l0, ms0, _ = V.scan_profile()
+            bf16_ms = ms0 / max(l0, 1)
+            lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
+            idsr, scr, _ = idx.topk_batch(qs[5 % 4], k)
+            bf16_same = bool(np.array_equal(ids0, idsr) and np.array_equal(sc0, scr))
+        finally:
+            lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
+        flops = 2.0 * batch * dim * rows
+        return {"workload": "%dx%d fp32 FLAT COSINE top-%d on a plain index (no shadow), batch=%d queries per corpus pass "
+                            "(RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
+                "device_ms_per_pass": dev_ms, "wall_ms_per_pass": wall_ms, "wall_over_device": wall_ms / dev_ms,
+                "qps_device": batch / dev_ms * 1e3, "qps_wall": batch / wall_ms * 1e3,
+                "qps_wall_one_pass_per_call": reps * batch / el,
+                "matrix_core_passes": int(launches), "exact_multi_query_scan_passes_instead": int(mq),
+                "hbm_gbs": rows * dim * 4 / dev_ms / 1e6, "hbm_frac": rows * dim * 4 / dev_ms / 1e6 / HBM_PEAK_GBS,
+                "mfma_tflops": flops / dev_ms / 1e9, "mfma_frac": flops / dev_ms / 1e9 / MFMA_PEAK_TFLOPS,
+                "int8_tops": flops / dev_ms / 1e9, "int8_frac_of_5000_TOPS": flops / dev_ms / 1e9 / 5000.0,
+                "kernel": "gemm_qs_h8r_kernel<.., SRC_F8> (round 6: fp32 rows quantised to int8 IN FLIGHT -- four v_fma_f32 + three "
+                          "v_perm_b32 per chunk, once per workgroup, register-staged ring -- v_mfma_i32_32x32x32_i8 against 256 "
+                          "register-stationary int8 queries; thresholds widened by the Cauchy-Schwarz band of the measured quantisation "
+                          "errors) + progressive thresholds + batch_rescore_kernel (the single-query scan's arithmetic) + per-query "
+                          "select; HIP events around the whole device pipeline of a pass",
+                "bf16_in_flight_pass_device_ms": bf16_ms, "bf16_in_flight_pass_same_replies": bf16_same,
+                "bit_identical_to_single_queries": bool(same),
+                "algorithmic_bytes_per_pass": rows * dim * 4}
+    finally:
+        idx.free()
 
 
 def extra_batched(lib, V, rows, dim):
@@ -1483,6 +1513,7 @@ def summarise_extras(cfg):
             s[short] = _scalars({"device_ms_per_pass": b.get("device_ms_per_pass"), "wall_ms_per_pass": b.get("wall_ms_per_pass"),
                                  "qps_device": b.get("qps_device"), "qps_wall": b.get("qps_wall"), "hbm_frac": b.get("hbm_frac"),
                                  "mfma_frac": b.get("mfma_frac"), "fp16_mfma_pass_ms": b.get("fp16_mfma_pass_device_ms"),
+                                 "bf16_in_flight_pass_ms": b.get("bf16_in_flight_pass_device_ms"),
                                  "bit_identical": b.get("bit_identical_to_single_queries"),
                                  "parity_ok": _g(b, "parity", "ok"),
                                  "int8_shadow_device_ms": _g(b, "int8_shadow_extra", "device_ms_per_pass")})
