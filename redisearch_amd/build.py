@@ -33,7 +33,7 @@ def _deps_mtime():
     m = 0.0
     for d in (CSRC, os.path.join(ROOT, "include"), os.path.join(ROOT, "include", "VecSim")):
         for f in os.listdir(d):
-            if f.endswith((".h", ".hpp")):
+            if f.endswith((".h", ".hpp", ".inc")):
                 m = max(m, os.path.getmtime(os.path.join(d, f)))
     return m
 

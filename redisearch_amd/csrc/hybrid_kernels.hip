@@ -289,298 +289,18 @@ __device__ __forceinline__ void hyb_knn_chain_min(const Args &A, const uint32_t 
 // tile the block maps to in a grid several queries share)
 template <int TYPE, int METRIC, int DPT, int NL, typename Args>
 __device__ __forceinline__ void hybrid_tile_body(const Args &A, const uint32_t tile) {
-  constexpr uint32_t TILE = 256u * DPT;
-  extern __shared__ __attribute__((aligned(16))) uint32_t win[];
-  __shared__ uint32_t wave_cnt[4];
-  __shared__ uint32_t w_lo, w_hi, nv_sh, nh_sh, sel_cnt;
-  __shared__ uint64_t sel_k[kHybScratch], sel_wtk[4];
-  __shared__ uint32_t sel_x[kHybScratch], sel_wtx[4];
-  const uint32_t WIN = A.pool_words;
-  u4 *qs = reinterpret_cast<u4 *>(win + WIN);
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n0 = A.len[0];
-  const uint32_t i_first = tile * TILE, i_next = i_first + TILE;
-  const uint32_t *__restrict__ ids0 = A.ids[0];
-
-  RSGPU_HYB_MARK(0);
-  // the first level of the window-end searches in list 1 (64 fixed positions), requested together with the tile's doc ids
-  uint32_t lvl1 = 0;
-  const bool pre1 = A.n > 1 && A.len[1] > 64 && !A.dir[1];
-  if (pre1) {
-    const uint32_t step = (A.len[1] + 63) / 64, p = (lane + 1) * step - 1;
-    lvl1 = A.ids[1][p < A.len[1] ? p : A.len[1] - 1];
-  }
-  if (A.k)  // the query: in flight while the probe runs
-    for (uint32_t c = threadIdx.x; c < A.chunks; c += 256) qs[c] = reinterpret_cast<const u4 *>(A.query)[c];
-
-  bool hit[DPT];
-  uint32_t xc[DPT];            // doc id in the frame the lists share
-  uint32_t f0[DPT];            // its frequency in the driving list
-  uint32_t ps[DPT][NL - 1];  // match position in list l
-#pragma unroll
-  for (int k = 0; k < DPT; k++) {
-    const uint32_t i = i_first + k * 256 + threadIdx.x;
-    hit[k] = i < n0;
-    const uint32_t ic = hit[k] ? i : n0 - 1;  // (unconditional loads)
-    xc[k] = (uint32_t)((long long)ids0[ic] + A.add[0]);
-    // (a codec that stores no frequency yields the term record's default, 1: intersect_write_kernel)
-    f0[k] = (A.top_n && A.freq[0]) ? A.freq[0][ic] : 1u;
-#pragma unroll
-    for (int l = 0; l < NL - 1; l++) ps[k][l] = 0;
-  }
-  const uint32_t x_first = (uint32_t)((long long)ids0[i_first] + A.add[0]);  // (i_first < n0: the grid is ceil(n0 / TILE))
-  const uint32_t x_next = (uint32_t)((long long)ids0[i_next < n0 ? i_next : n0 - 1] + A.add[0]);
-
-  // ---- probe (intersect_probe_kernel, the positions kept in registers) ----
-#pragma unroll
-  for (int l = 1; l < NL; l++) {
-    if (l < A.n) {
-      const uint32_t *__restrict__ a = A.ids[l];
-      const uint32_t nl = A.len[l];
-      const long long add = A.add[l];
-      if (A.dir[l]) {  // bucket directory: both ends in one round trip
-        if (threadIdx.x == 0) {
-          bool u0, u1;
-          const uint32_t xf = to_list_frame(x_first, add, &u0), xn = to_list_frame(x_next, add, &u1);
-          const uint32_t sh = A.dir_shift[l], dn = A.dir_n[l];
-          const uint32_t bf = xf >> sh, bn = (uint32_t)min((uint64_t)(xn >> sh) + 1ull, (uint64_t)dn - 1ull);  // (xn = 2^32 - 1 at shift 0 must not wrap)
-          const uint32_t dlo = A.dir[l][bf < dn ? bf : dn - 1], dhi = A.dir[l][bn < dn ? bn : dn - 1];
-          w_lo = dlo;
-          w_hi = i_next < n0 ? dhi : nl;
-        }
-      } else if (wave == 0) {  // the window's start: at or below lower_bound(first driver)
-        bool u0;
-        uint32_t rlo, rhi;
-        wave_lower_bound_range(a, nl, to_list_frame(x_first, add, &u0), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
-        if (lane == 0) w_lo = rlo;
-      } else if (wave == 1) {  // its end: at or above lower_bound(first driver of the next tile)
-        bool u1;
-        uint32_t rlo, rhi = nl;
-        if (i_next < n0) wave_lower_bound_range(a, nl, to_list_frame(x_next, add, &u1), lane, lvl1, l == 1 && pre1, &rlo, &rhi);
-        if (lane == 0) w_hi = rhi;
-      }
-      __syncthreads();
-      if (l == 1) RSGPU_HYB_MARK(1);
-      const uint32_t lo = w_lo, hi = w_hi;  // every driver x of this tile has lower_bound(x) in [lo, hi] (up to 64 entries of slack at either end)
-      const uint32_t span = hi - lo;
-      if (span <= WIN) {
-        // the window, eight loads per lane in flight at a time (a load / ds_write loop is serialised by hipcc)
-        for (uint32_t base = 0; base < span; base += 8 * 256) {
-          uint32_t t[8];
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const uint32_t o = base + j * 256 + threadIdx.x;
-            t[j] = a[lo + (o < span ? o : span - 1)];
-          }
-#pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const uint32_t o = base + j * 256 + threadIdx.x;
-            if (o < span) win[o] = t[j];
-          }
-        }
-        __syncthreads();
-        if (l == 1) RSGPU_HYB_MARK(2);
-        // lower bounds of the lane's four drivers in step: a fixed-length search (the halving sequence depends on the span
-        // alone), one LDS read per driver and step, the four reads of a step independent of each other -- four data-dependent
-        // loops one after the other were 48 dependent LDS round trips
-        uint32_t xl[DPT], b[DPT];
-        bool under[DPT];
-#pragma unroll
-        for (int k = 0; k < DPT; k++) {
-          xl[k] = to_list_frame(xc[k], add, &under[k]);
-          b[k] = 0;
-        }
-        uint32_t rem = span;
-        while (rem > 1) {
-          const uint32_t half = rem >> 1;
-#pragma unroll
-          for (int k = 0; k < DPT; k++) b[k] = win[b[k] + half - 1] < xl[k] ? b[k] + half : b[k];
-          rem -= half;
-        }
-#pragma unroll
-        for (int k = 0; k < DPT; k++) {
-          if (span && win[b[k]] < xl[k]) b[k]++;
-          const bool m = hit[k] && !under[k] && b[k] < span && win[b[k] < span ? b[k] : 0] == xl[k];
-          ps[k][l - 1] = lo + b[k];
-          hit[k] = m;
-        }
-      } else {  // a window that does not fit (very skewed lists): a binary search in memory, confined to the window
-#pragma unroll
-        for (int k = 0; k < DPT; k++) {
-          bool under;
-          const uint32_t x = to_list_frame(xc[k], add, &under);
-          uint32_t b = lo, e = hi;
-          if (hit[k]) {
-            while (b < e) {
-              const uint32_t mid = b + ((e - b) >> 1);
-              if (a[mid] < x) b = mid + 1;
-              else e = mid;
-            }
-            ps[k][l - 1] = b;
-            hit[k] = !under && b < nl && a[b] == x;
-          }
-        }
-      }
-      __syncthreads();  // win / w_lo / w_hi are reused
-    }
-  }
-  {
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < DPT; k++) cnt += (uint32_t)__popcll(__ballot(hit[k]));
-    if (lane == 0) wave_cnt[wave] = cnt;
-    if (threadIdx.x == 0) nv_sh = nh_sh = 0;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) A.tile_hits[tile] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-  RSGPU_HYB_MARK(3);
-
-  // the hits' vector rows: identity arithmetic, or one gather from the device label table -- requested here, in flight while
-  // branch A scores (hybrid_reader.c:309-327 looks every candidate up by label)
-  uint32_t vr[DPT];
-#pragma unroll
-  for (int k = 0; k < DPT; k++) vr[k] = (A.k && hit[k]) ? label_first_row(A.L, A.ids_base + xc[k]) : kNoRow;
-
-  // ---- branch A: score, the tile's top-N ----
-  // The hits (about a hundred of 1 024 drivers in configs[4]) are compacted first -- doc id, frequency in the driving list and
-  // match positions into LDS -- and scored DENSELY, one hit per lane: scoring where the hits sit (four slots per lane, a tenth
-  // of the lanes live) ran the fp64 scorer sixteen times per workgroup for the work of two wavefronts.
-  // Selection by RANK: every hit counts the hits that precede it in the total order (descending score, ascending doc id),
-  // ranks below N are the list -- written straight to their slots.  (k rounds of a wave-wide arg-min per wave plus a merge
-  // were a serial chain of ~20 x 150 dependent instructions.)
-  if (A.top_n) {
-    uint32_t *rx = win, *rf0 = win + TILE;  // then the position in list l at win + (l + 1) * TILE
-#pragma unroll
-    for (int k = 0; k < DPT; k++) {
-      const unsigned long long m = __ballot(hit[k]);
-      if (m) {
-        uint32_t first = 0;
-        const int leader = __builtin_ctzll(m);
-        if (lane == (uint32_t)leader) first = atomicAdd(&nh_sh, (uint32_t)__popcll(m));
-        first = __shfl(first, leader, 64);
-        if (hit[k]) {
-          const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          rx[slot] = xc[k];
-          rf0[slot] = f0[k];
-#pragma unroll
-          for (int l = 1; l < NL; l++)
-            if (l < A.n) win[(l + 1) * TILE + slot] = ps[k][l - 1];
-        }
-      }
-    }
-    __syncthreads();
-    RSGPU_HYB_MARK(4);
-    const uint32_t nh = nh_sh;
-    uint64_t my_k[DPT];
-    uint32_t my_x[DPT];
-#pragma unroll
-    for (int j = 0; j < DPT; j++) {
-      const uint32_t e = j * 256 + threadIdx.x;
-      my_k[j] = ~0ull;
-      my_x[j] = ~0u;
-      if (e < nh) {
-        const uint32_t x = rx[e];
-        double fr[NL];
-        fr[0] = (double)rf0[e];
-#pragma unroll
-        for (int l = 1; l < NL; l++) fr[l] = (l < A.n && A.freq[l]) ? (double)A.freq[l][win[(l + 1) * TILE + e]] : 1.0;
-        const long long tid = (long long)x + A.P.table_off;
-        const bool known = tid >= 0 && tid < (long long)A.table_n;
-        const uint32_t id = known ? (uint32_t)tid : 0u;
-        float dscore;
-        uint32_t dlen;
-        if (A.len_score) {  // (one 8-byte gather: a 64-byte line per hit instead of two)
-          const uint2 ls = A.len_score[id];
-          dlen = known ? ls.x : 0u;
-          dscore = known ? __uint_as_float(ls.y) : 0.0f;
-        } else {
-          dscore = known ? A.doc_score[id] : 0.0f;
-          dlen = known ? A.doc_len[id] : 0u;
-        }
-        const uint32_t mfreq = (known && A.max_freq) ? A.max_freq[id] : 0u;
-        auto F = [&](int t) {
-          if constexpr (NL <= 2) return t == 0 ? fr[0] : fr[NL - 1];
-          else return t == 0 ? fr[0] : (t == 1 ? fr[1] : (t == 2 ? fr[2] : fr[NL - 1]));
-        };
-        const double s = score_one<false, NL>(A.P, F, dlen, dscore, mfreq, A.P.slop);
-        my_k[j] = ~d2key(s);
-        my_x[j] = x;
-      }
-    }
-    __syncthreads();  // every record has been read: keys | doc ids take their place
-    RSGPU_HYB_MARK(5);
-    uint64_t *ek = reinterpret_cast<uint64_t *>(win);
-    uint32_t *ex = win + 2 * TILE;
-#pragma unroll
-    for (int j = 0; j < DPT; j++) {
-      const uint32_t e = j * 256 + threadIdx.x;
-      if (e < nh) {
-        ek[e] = my_k[j];
-        ex[e] = my_x[j];
-      }
-    }
-    __syncthreads();
-    tile_select<DPT>(my_k, my_x, nh, A.top_n, [&](uint32_t o) { return SKey{ek[o], ex[o]}; }, sel_k, sel_x, &sel_cnt, sel_wtk, sel_wtx,
-                     [&](uint32_t rank, const SKey &my) {
-                       A.part_skey[(size_t)tile * A.top_n + rank] = my.k;
-                       A.part_sidx[(size_t)tile * A.top_n + rank] = my.i;
-                     });
-    if (threadIdx.x >= nh && threadIdx.x < A.top_n) {  // fewer hits than slots
-      A.part_skey[(size_t)tile * A.top_n + threadIdx.x] = ~0ull;
-      A.part_sidx[(size_t)tile * A.top_n + threadIdx.x] = ~0u;
-    }
-    __syncthreads();  // the arrays are reused by branch B
-  }
-  RSGPU_HYB_MARK(6);
-
-  // ---- branch B: the hits that have a vector, their distances, the tile's top-k ----
-  if (A.k) {
-    uint32_t *vrow = win, *vx = win + TILE, *vkey = win + 2 * TILE;
-#pragma unroll
-    for (int k = 0; k < DPT; k++) {
-      const bool has = vr[k] != kNoRow;
-      const unsigned long long m = __ballot(has);
-      if (m) {
-        uint32_t first = 0;
-        const int leader = __builtin_ctzll(m);
-        if (lane == (uint32_t)leader) first = atomicAdd(&nv_sh, (uint32_t)__popcll(m));
-        first = __shfl(first, leader, 64);
-        if (has) {
-          const uint32_t slot = first + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          vrow[slot] = vr[k];
-          vx[slot] = xc[k];
-        }
-      }
-    }
-    __syncthreads();
-    const uint32_t nv = nv_sh;
-    hyb_knn_distances<TYPE, METRIC>(A, vrow, vkey, nv, qs);
-    __syncthreads();
-    if (A.L.next) {
-      hyb_knn_chain_min<TYPE, METRIC>(A, vrow, vkey, nv, qs);
-      __syncthreads();
-    }
-    RSGPU_HYB_MARK(7);
-    uint64_t vk_mine[DPT];
-    uint32_t vx_mine[DPT];
-#pragma unroll
-    for (int j = 0; j < DPT; j++) {
-      const uint32_t e = j * 256 + threadIdx.x;
-      vk_mine[j] = e < nv ? (uint64_t)vkey[e] : ~0ull;
-      vx_mine[j] = e < nv ? vx[e] : ~0u;
-    }
-    tile_select<DPT>(vk_mine, vx_mine, nv, A.k, [&](uint32_t o) { return SKey{(uint64_t)vkey[o], vx[o]}; }, sel_k, sel_x, &sel_cnt,
-                     sel_wtk, sel_wtx, [&](uint32_t rank, const SKey &my) {
-                       A.part_knn[(size_t)tile * A.k + rank] = (my.k << 32) | my.i;
-                     });
-    if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)tile * A.k + threadIdx.x] = ~0ull;
-  }
-  RSGPU_HYB_MARK(8);
+#include "hybrid_tile_body.inc"
 }
 #undef RSGPU_HYB_MARK
 template <int TYPE, int METRIC, int DPT, int NL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void hybrid_tile_kernel(HybridTileArgs A) {
-  hybrid_tile_body<TYPE, METRIC, DPT, NL>(A, blockIdx.x);
+  const uint32_t tile = blockIdx.x;
+#define RSGPU_HYB_MARK(p)                                                                                   \
+  do {                                                                                                      \
+    if (A.trace && threadIdx.x == 0) A.trace[(size_t)tile * kHybTracePhases + (p)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#include "hybrid_tile_body.inc"
+#undef RSGPU_HYB_MARK
 }
 // Several queries in one grid (search_kernels.hpp HybridTileBatch).  Block -> (query, tile): the queries sit in ascending order of
 // their tile counts; segment j = the rounds in which the queries j .. n_q - 1 still have tiles, its blocks deal those queries'
