@@ -460,6 +460,21 @@ def _callers_lib(V):
     return cl
 
 
+def _hybrid_callers_lib():
+    """examples/concurrent_hybrid_callers.c (pthread callers of RSGPU_HybridQuery through the plain C ABI), built on the spot."""
+    import subprocess
+    import tempfile
+    libdir = os.path.join(ROOT, "redisearch_amd", "lib")
+    out = os.path.join(tempfile.mkdtemp(prefix="rs_hcallers_"), "libhybrid_callers.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "concurrent_hybrid_callers.c"), "-L" + libdir, "-lVectorSimilarity",
+                           "-Wl,-rpath," + libdir, "-lpthread", "-o", out])
+    cl = C.CDLL(out)
+    cl.rs_hybrid_callers_run.restype = C.c_long
+    cl.rs_hybrid_callers_run.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_double)]
+    return cl
+
+
 def run_callers(cl, index, queries, k, threads, seconds, keep_answers=False):
     nq, cap = len(queries), 20000
     lat = np.zeros((threads, cap), np.uint64)
@@ -813,36 +828,38 @@ def _hybrid_stream(lib, S, enc, raws, table, idx, qvecs, n_docs, n_vec, avg, dim
             if mode == "warm" and concurrent_threads:
                 # the reference runs its hybrid iterators on worker threads (src/util/workers.c:58,104): the same stream from
                 # T threads at once -- every thread its own argument blocks and device scratch, the lists / table / index shared
-                import threading
+                # (round 6: pthread callers through the plain C ABI -- examples/concurrent_hybrid_callers.c, what a C module's worker
+                # pool pays; rounds 3-5 drove this leg from Python threads, an interpreter between two calls)
                 conc = {}
-                for nt in concurrent_threads:
-                    sets = [make_queries() for _ in range(nt)]
-                    gate, ok, span = threading.Barrier(nt + 1), [True] * nt, [0.0, 0.0]
-
-                    def work(t, sets=sets, gate=gate, ok=ok):
-                        for hq in sets[t]:          # untimed: this thread's scratch and streams
-                            hq.run()
-                        gate.wait()
-                        for _ in range(cycles):
-                            for q_, hq in enumerate(sets[t]):
-                                hq.run()
-                        gate.wait()
-                        for q_, hq in enumerate(sets[t]):
-                            r = hq.results()
-                            ok[t] = ok[t] and r["n_hits"] == res[q_]["n_hits"] and r["top"][0].tolist() == res[q_]["top"][0].tolist() and \
-                                r["top"][1].tolist() == res[q_]["top"][1].tolist() and r["knn"][0].tolist() == res[q_]["knn"][0].tolist()
-                    ths = [threading.Thread(target=work, args=(t,)) for t in range(nt)]
-                    for th in ths:
-                        th.start()
-                    gate.wait()
-                    t0 = time.perf_counter()
-                    gate.wait()
-                    t1 = time.perf_counter()
-                    for th in ths:
-                        th.join()
-                    conc["%d_threads" % nt] = {"qps": nt * cycles * len(pairs) / (t1 - t0), "queries": nt * cycles * len(pairs),
-                                               "same_answers_as_serial": bool(all(ok))}
-                    del sets
+                try:
+                    hcl = _hybrid_callers_lib()
+                    sets = [make_queries() for _ in range(4)]         # 64 argument blocks: thread t cycles over t, t + n, ...
+                    flat = [hq for st in sets for hq in st]
+                    for hq in flat:                                   # untimed: allocations
+                        hq.run()
+                    blocks = (C.c_void_p * len(flat))(*[C.addressof(h.args) for h in flat])
+                    for nt in concurrent_threads:
+                        cap = 60000
+                        lat = np.zeros((nt, cap), np.uint64)
+                        counts = np.zeros(nt, np.uint64)
+                        el = C.c_double(0)
+                        S.hybrid_coalesce_stats(reset=True)
+                        total = hcl.rs_hybrid_callers_run(blocks, len(flat), nt, 0.5, lat.ctypes.data_as(C.c_void_p), cap,
+                                                          counts.ctypes.data_as(C.c_void_p), C.byref(el))
+                        st = S.hybrid_coalesce_stats()
+                        allv = np.concatenate([lat[t, :int(min(counts[t], cap))] for t in range(nt)]).astype(np.float64) / 1e6
+                        ok = total > 0
+                        for q_, hq in enumerate(flat):
+                            r, want = hq.results(), res[q_ % len(res)]
+                            ok = ok and r["n_hits"] == want["n_hits"] and r["top"][0].tolist() == want["top"][0].tolist() and \
+                                r["top"][1].tolist() == want["top"][1].tolist() and r["knn"][0].tolist() == want["knn"][0].tolist()
+                        conc["%d_threads" % nt] = {"qps": total / el.value, "queries": int(total), "p50_ms": float(np.percentile(allv, 50)),
+                                                   "p95_ms": float(np.percentile(allv, 95)), "same_answers_as_serial": bool(ok),
+                                                   "queries_per_shared_grid": (st["grid_queries"] / st["grids"]) if st["grids"] else None,
+                                                   "queries_launched_alone": st["alone"]}
+                    del sets, flat
+                except Exception as e:   # the extra must never take the headline down
+                    conc["error"] = repr(e)[:200]
                 rec["concurrent_callers"] = conc
             if mode == "warm":
                 answers = res
@@ -1532,6 +1549,8 @@ def summarise_extras(cfg):
             for key, val in lad.items():
                 if isinstance(val, dict) and "qps" in val:
                     rec["qps_%s" % key] = val["qps"]
+            rec["callers_same_answers"] = all(v.get("same_answers_as_serial", False) for v in lad.values() if isinstance(v, dict))
+            rec["queries_per_shared_grid_16_threads"] = _g(lad, "16_threads", "queries_per_shared_grid")
         shapes = h.get("general_tile_kernel_shapes")
         if isinstance(shapes, dict):
             rec["shapes"] = len(shapes)
