@@ -317,6 +317,9 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
     // (row, query) pair becomes a candidate -- and the first bound is the K-th shadow distance among them + the band
     // (L2 passes the same way: the tiled GEMM computes 1 - x.q only)
     const bool phase0 = (via_shadow8 && type == VecSimType_FLOAT32) || via_l2 || via_f32;
+    // the threshold selects drop what the new bound excludes from the lists (the L2 lists carry UPPER bounds: their test is the
+    // re-scoring kernel's, on the lower bound)
+    const bool prune_lists = !via_l2 && scan_tuning().batch_prune != 0;
     std::vector<uint32_t> phase_end;  // row boundaries of the filter passes
     if (use_qs) {
       n0 = std::min<uint32_t>(n, std::max<uint32_t>(1u << 15, (uint32_t)round_up((size_t)kk * 16, 256)));
@@ -513,7 +516,7 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
             dbg("compact");
             if (ph + 1 < phase_end.size())
               launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
-                                          c->stream, slack, slack_q);
+                                          c->stream, slack, slack_q, prune_lists);
             dbg("threshold");
             from = e;
           }
@@ -522,10 +525,10 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
           // final band: tau = exact k-th shadow distance of the whole corpus + 2 eps; the candidates inside it get
           // their exact keys (the single-query scan's arithmetic), then the usual exact select over (key, row)
           launch_batch_threshold_cand(sc.cand.p, sc.cand_count.p, cand_cap, kk, kBatch, nb, sc.tau.p, sc.overflow.p,
-                                      c->stream, slack, slack_q);
+                                      c->stream, slack, slack_q, prune_lists);
           if (!launch_batch_rescore(d_rows_, stride_, n, sc.queries.p, stride_, sc.cand.p, sc.cand_count.p, cand_cap, kBatch,
                                     sc.tau.p, c->stream, via_shadow8 || via_l2 || via_h16 ? ktype : KT_F32, via_l2 ? KM_L2 : KM_IP,
-                                    via_l2 ? &rb : nullptr))
+                                    via_l2 ? &rb : nullptr, prune_lists))
             throw std::runtime_error("batched shadow pass: the re-scoring kernel refused a row shape the route was gated on");
           dbg("rescore");
         }

@@ -333,21 +333,29 @@ struct BatchSel {
   uint32_t stride;     // PAIRS=false: element i is keys[q*ld + i*stride] (strided sample of a key array)
   float slack;         // added to the bound written to tau_out (error band of a low-precision filter pass)
   const float *slack_q;  // per-query band (overrides slack)
+  uint32_t prune;        // PAIRS, threshold only: the list keeps just the candidates at or below the new bound
 };
+__device__ __forceinline__ uint32_t sel_f2key(float f) {  // (scan_ops.hpp f2key: the orderable image of a distance, NaN last)
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xFFFFFFFFu;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 template <bool PAIRS>
 __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
   __shared__ uint32_t hist[256];
   __shared__ u64 sh_prefix;
   __shared__ u64 win[1024];
-  __shared__ uint32_t sh_krem, sh_exact, sh_levels, sh_out;
+  __shared__ uint32_t sh_krem, sh_exact, sh_levels, sh_out, sh_thr;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   uint32_t n = s.n;
+  bool overflowed = false;
   if (PAIRS) {
     uint32_t c = s.cand_count[q];
     if (c > s.cand_cap) {
       if (tid == 0) s.overflow[q] = 1;
       c = s.cand_cap;
+      overflowed = true;
     }
     n = c;
   }
@@ -367,15 +375,52 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
     }
     return ((u64)s.keys[(size_t)q * s.ld + (size_t)i * s.stride] << 32) | i;
   };
+  // The elements stay in registers when 16 per thread hold them (round 6: every digit pass re-read the list from memory, one
+  // dependent round trip per 1 024 elements and pass -- 20 us per select at 4 k candidates, 85 us at 16 k, six to seven selects
+  // per corpus pass): ONE batch of independent loads, the passes run on LDS alone.
+  constexpr int MAXE = 16;
+  const bool cached = n <= (uint32_t)MAXE * 1024u;  // (uniform)
+  const uint32_t nj = (n + 1023u) / 1024u;
+  u64 E[MAXE];
+  if (cached) {
+#pragma unroll
+    for (int j = 0; j < MAXE; j++) {
+      const uint32_t i = (uint32_t)j * 1024u + tid;
+      E[j] = i < n ? elem(i) : ~0ull;
+    }
+  }
+  // a threshold is the key part alone: four digits settle it (the row digits below would only break ties the bound includes anyway)
+  const int passes = s.out_rows ? 8 : 4;
   const bool take_all = (k == n);
-  for (int p = 0; p < 8 && !sh_exact; p++) {
+  for (int p = 0; p < passes && !sh_exact; p++) {
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     const u64 prefix = sh_prefix;
     const int mshift = 64 - 8 * p, dshift = 56 - 8 * p;
-    for (uint32_t i = tid; i < n; i += blockDim.x) {
-      u64 c = elem(i);
-      if (p == 0 || (c >> mshift) == (prefix >> mshift)) atomicAdd(&hist[(uint32_t)(c >> dshift) & 0xffu], 1u);
+    auto count = [&](bool live, u64 c) {
+      // (the leading digits of a list of near-equal distances are the same for every element: one atomic per wavefront then,
+      // not 64 serialised on one LDS word)
+      const bool in = live && (p == 0 || (c >> mshift) == (prefix >> mshift));
+      const uint32_t d = (uint32_t)(c >> dshift) & 0xffu;
+      const unsigned long long m = __ballot(in);
+      if (!m) return;
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, __builtin_ctzll(m));
+      if (__ballot(in && d != d0) == 0ull) {
+        if (lane == (uint32_t)__builtin_ctzll(m)) atomicAdd(&hist[d0], (uint32_t)__popcll(m));
+      } else if (in)
+        atomicAdd(&hist[d], 1u);
+    };
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < MAXE; j++) {
+        if ((uint32_t)j >= nj) break;
+        count(E[j] != ~0ull, E[j]);  // (a slot past the end holds ~0: no composite is)
+      }
+    } else {
+      for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t i = i0 + tid;
+        count(i < n, i < n ? elem(i) : 0ull);
+      }
     }
     __syncthreads();
     if (tid < 64) {  // wavefront 0 picks the digit
@@ -418,31 +463,78 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
   if (tid == 0 && s.tau_out) {
     // k-th smallest key as a distance: the selection's bound, key part (ties included by the filter)
     uint32_t kk = (k == 0) ? 0u : (uint32_t)(hi >> 32);
+    sh_thr = 0xFFFFFFFFu;
     if (q >= s.n_valid) {
       s.tau_out[q] = __uint_as_float(0xff800000u);
     } else if (take_all) {  // fewer than k elements: no (new) bound
       if (!PAIRS) s.tau_out[q] = __uint_as_float(0x7f800000u);
     } else {
       uint32_t u = (kk & 0x80000000u) ? (kk ^ 0x80000000u) : ~kk;
-      s.tau_out[q] = __uint_as_float(u) + (s.slack_q ? s.slack_q[q] : s.slack);
+      const float t = __uint_as_float(u) + (s.slack_q ? s.slack_q[q] : s.slack);
+      s.tau_out[q] = t;
+      sh_thr = sel_f2key(t);
+    }
+  }
+  if (PAIRS && s.prune && s.tau_out && !s.out_rows) {  // (uniform)
+    // The list keeps only what the NEW bound admits (round 6).  The candidates of the early phases were collected under loose
+    // bounds -- the first phase of an fp32 pass keeps all 16 Ki rows it sees -- and every later threshold, the re-scoring and the
+    // final select walked them again (selects of 40-80 us).  The re-scoring's own test is this one (key <= f2key(tau), the bounds
+    // only fall), so the same candidates reach it; the order within the list is not kept and nothing depends on it.
+    __syncthreads();
+    const uint32_t thr = sh_thr;
+    if (thr != 0xFFFFFFFFu && !overflowed) {
+      uint2 *list = const_cast<uint2 *>(s.cand) + (size_t)q * s.cand_cap;
+      auto keep_one = [&](bool live, u64 c) {
+        const bool keep = live && (uint32_t)(c >> 32) <= thr;
+        const unsigned long long m = __ballot(keep);
+        if (!m) return;
+        const int leader = __builtin_ctzll(m);
+        uint32_t base = 0;
+        if (lane == (uint32_t)leader) base = atomicAdd(&sh_out, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (keep) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)c, (uint32_t)(c >> 32));
+      };
+      if (cached) {  // (every element was read at the start)
+#pragma unroll
+        for (int j = 0; j < MAXE; j++) {
+          if ((uint32_t)j >= nj) break;
+          keep_one(E[j] != ~0ull, E[j]);  // (a slot past the end holds ~0: no composite is)
+        }
+      } else {
+        // in place, a chunk of 1 024 at a time: what a chunk keeps lands at or below the chunk's own start + 1 024, so its reads
+        // come first (the barrier) and the next chunk's are never touched
+        for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+          const uint32_t i = i0 + tid;
+          const u64 c = i < n ? elem(i) : 0ull;
+          __syncthreads();
+          keep_one(i < n, c);
+        }
+      }
+      __syncthreads();
+      if (tid == 0) const_cast<uint32_t *>(s.cand_count)[q] = sh_out;
     }
   }
   if (s.out_rows) {
-    for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
-      const uint32_t i = i0 + tid;
-      bool take = false;
-      u64 c = 0;
-      if (i < n && k > 0) {
-        c = elem(i);
-        take = c <= hi;
-      }
-      if (take) {
+    auto emit = [&](bool live, u64 c) {
+      if (live && k > 0 && c <= hi) {
         uint32_t o = atomicAdd(&sh_out, 1u);
         if (o < s.k_ld && o < 1024u) win[o] = c;
         else if (o < s.k_ld) {  // (k_ld above the sorted list's room: as before, unordered)
           s.out_rows[(size_t)q * s.k_ld + o] = (uint32_t)c;
           s.out_keys[(size_t)q * s.k_ld + o] = (uint32_t)(c >> 32);
         }
+      }
+    };
+    if (cached) {
+#pragma unroll
+      for (int j = 0; j < MAXE; j++) {
+        if ((uint32_t)j >= nj) break;
+        emit(E[j] != ~0ull, E[j]);  // (a slot past the end holds ~0: no composite is)
+      }
+    } else {
+      for (uint32_t i0 = 0; i0 < n; i0 += blockDim.x) {
+        const uint32_t i = i0 + tid;
+        emit(i < n, i < n ? elem(i) : 0ull);
       }
     }
     __syncthreads();
@@ -506,9 +598,9 @@ void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint3
 // old tau, so the new one can only be smaller; a query with fewer than k candidates keeps its bound)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
-                                 hipStream_t s, float slack, const float *slack_q) {
+                                 hipStream_t s, float slack, const float *slack_q, bool prune) {
   BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, tau_inout, nullptr, nullptr, nullptr, 0, overflow,
-             n_valid, 1, slack, slack_q};
+             n_valid, 1, slack, slack_q, prune ? 1u : 0u};
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 

@@ -967,22 +967,35 @@ __global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__re
                                                            uint2 *__restrict__ cand, uint32_t cand_cap, int append,
                                                            RowBand band) {
   __shared__ uint32_t offs[513];
+  __shared__ uint32_t wsum[8];
   __shared__ uint32_t over;
-  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   if (tid == 0) over = 0;
   __syncthreads();
-  for (uint32_t sg = tid; sg < 512; sg += blockDim.x) {  // segment sg = (workgroup sg/2, lane half sg%2)
-    uint32_t c = sg < 2 * n_wg ? sub_count[((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)] : 0;
+  // the sub-lists' starts: a prefix over 512 counts by eight wavefronts (round 6: one thread summed them through LDS, and a
+  // wavefront copied its 32 sub-lists one dependent round trip after the other -- 30 us per launch, four to five launches per pass)
+  uint32_t c = 0;
+  if (tid < 512) {  // segment sg = (workgroup sg/2, lane half sg%2)
+    c = tid < 2 * n_wg ? sub_count[((size_t)(tid >> 1) * 256 + q) * 2 + (tid & 1)] : 0;
     if (c > sub_cap) {
       over = 1;
       c = sub_cap;
     }
-    offs[sg + 1] = c;
+  }
+  uint32_t inc = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= (uint32_t)off) inc += t;
+  }
+  if (tid < 512 && lane == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  if (tid < 512) {
+    uint32_t add = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) add += wsum[w];
+    offs[tid + 1] = inc + add;
   }
   if (tid == 0) offs[0] = 0;
-  __syncthreads();
-  if (tid == 0)
-    for (uint32_t i = 1; i <= 512; i++) offs[i] += offs[i - 1];
   __syncthreads();
   const uint32_t base = append ? cand_count[q] : 0;  // (every thread reads it before thread 0 rewrites it below)
   const uint32_t total = offs[512];
@@ -991,16 +1004,19 @@ __global__ __launch_bounds__(1024) void compact_cand_kernel(const uint32_t *__re
     if (tid == 0) cand_count[q] = cand_cap + 1;
     return;
   }
-  const uint32_t lane = tid & 63, wv = tid >> 6;
-  for (uint32_t sg = wv; sg < 2 * n_wg; sg += blockDim.x / 64) {  // wavefront per sub-list: coalesced copies
-    const uint32_t beg = offs[sg], cnt = offs[sg + 1] - beg;
-    const uint2 *src = sub_cand + (((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap;
-    for (uint32_t i = lane; i < cnt; i += 64) {
-      const uint2 e = src[i];
-      float d = __uint_as_float(e.y);
-      if (band.hnorm) d += band.c1 * band.hnorm[e.x] + band.hq2[q];  // lower bound -> upper bound (L2 passes)
-      cand[(size_t)q * cand_cap + base + beg + i] = make_uint2(e.x, f2key(d));
+  // entry o of the concatenation: its sub-list by a search over the starts, every load independent of every other
+  for (uint32_t o = tid; o < total; o += blockDim.x) {
+    uint32_t lo = 0, hi = 512;  // offs[lo] <= o < offs[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (offs[mid] <= o) lo = mid;
+      else hi = mid;
     }
+    const uint32_t sg = lo, i = o - offs[sg];
+    const uint2 e = sub_cand[(((size_t)(sg >> 1) * 256 + q) * 2 + (sg & 1)) * sub_cap + i];
+    float d = __uint_as_float(e.y);
+    if (band.hnorm) d += band.c1 * band.hnorm[e.x] + band.hq2[q];  // lower bound -> upper bound (L2 passes)
+    cand[(size_t)q * cand_cap + base + o] = make_uint2(e.x, f2key(d));
   }
   if (tid == 0) cand_count[q] = over ? cand_cap + 1 : base + total;
 }

@@ -148,6 +148,7 @@ struct ScanTuning {
                            // int8 matrix cores -- no stored shadow.  5 (default) = once per workgroup, register-staged (gemm_qs_h8r_kernel, 2.91 ms
                            // per configs[2] pass); 2 / 1 = in every wave, behind the LDS-DMA ring (four waves x 64 queries 3.87 ms / eight x 32
                            // 4.29 ms); 3 / 4 = 2 with smaller ring slots (4.14 / 4.61 ms); 0 = the fp16 MFMA pass (3.96 ms)
+  int batch_prune = 1;     // batched passes: a threshold select leaves only the candidates its new bound admits in the list (0: the lists only grow)
   int gemm_qs_f8 = 1;      // FLOAT32 IP / cosine indexes: the batched / coalesced passes quantise the fp32 rows to int8 in flight (gemm_qs_h8r_kernel<..,
                            // SRC_F8>: 5.48 ms per 256-query pass over 10M x 768, 0.70 of HBM) instead of rounding them to bf16 (gemm_qs_f32_kernel:
                            // 6.15 ms); read at index creation and at query time; 0 = the bf16 route
@@ -237,7 +238,8 @@ bool batch_rescore_supported(uint32_t stride16);
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
                           int type = KT_F32, int metric = KM_IP,   // KT_F16: fp16 rows / queries, the fp16 scan's arithmetic;
-                          const struct RowBand *band = nullptr);   // KM_L2: the L2 scan's; band: the keys are upper bounds
+                          const struct RowBand *band = nullptr,    // KM_L2: the L2 scan's; band: the keys are upper bounds
+                          bool dense = false);  // the lists were pruned to the band (launch_batch_threshold_cand prune): candidates dealt out one per group
 // hn[row] = shrink * |x|^2 / 2 (fp32) of rows [row_begin, row_end) of KT_F16 / KT_BF16 / KT_F32 rows; *bad is set if one is
 // not finite
 void launch_half_norm_rows(int type, const void *rows, size_t stride, uint32_t row_begin, uint32_t row_end, float shrink,
@@ -362,10 +364,12 @@ void launch_filter_keys_batch(const uint32_t *keys, uint32_t keys_ld, uint32_t n
 // (slack is added to *tau first: the two-stage scan's error bound)
 void launch_filter_keys(const uint32_t *keys, uint32_t n, const float *tau, void *cand, uint32_t *cand_count,
                         uint32_t cap, hipStream_t s, float slack = 0.0f);
-// per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k)
+// per query: tau_inout[q] = k-th smallest distance among its candidates so far (kept if it has fewer than k); prune: the list
+// (cand / cand_count, rewritten in place, order not kept) keeps only the candidates whose key is at or below the new bound --
+// for lists whose keys are the distances the bound is compared with (NOT the upper bounds of the L2 passes)
 void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, uint32_t cand_cap, uint32_t k,
                                  uint32_t n_queries, uint32_t n_valid, float *tau_inout, uint32_t *overflow,
-                                 hipStream_t s, float slack = 0.0f, const float *slack_q = nullptr);
+                                 hipStream_t s, float slack = 0.0f, const float *slack_q = nullptr, bool prune = false);
 // per query: the k smallest (key,index) of keys[q*ld .. +n) -> out_rows/out_keys[q*k_ld ..], out_n[q]
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s);

@@ -690,7 +690,7 @@ template <int TYPE, int METRIC, int G, int ITERS>
 __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict__ rows, uint32_t stride16, uint32_t n_rows,
                                                             const u4 *__restrict__ queries, uint32_t qstride16,
                                                             uint2 *__restrict__ cand, const uint32_t *__restrict__ cand_count,
-                                                            uint32_t cand_cap, const float *__restrict__ tau, RowBand band) {
+                                                            uint32_t cand_cap, const float *__restrict__ tau, RowBand band, int dense) {
   constexpr int GPB = 256 / G;
   const uint32_t q = blockIdx.y, lane = threadIdx.x % G, grp = threadIdx.x / G;
   const uint32_t cnt = cand_count[q];
@@ -704,6 +704,26 @@ __global__ __launch_bounds__(256) void batch_rescore_kernel(const u4 *__restrict
 #pragma unroll
   for (int i = 0; i < ITERS; i++) qv[i] = queries[(size_t)q * qstride16 + lane + i * G];
   uint2 *list = cand + (size_t)q * cand_cap;
+  if (dense && !band.hnorm) {
+    // A list the last threshold select has pruned (round 6): short, and every entry inside the band -- G consecutive candidates per
+    // group would be G re-scorings one after the other in a handful of groups (0.28 ms where the long lists took 0.11).  The
+    // groups of the query's slices take the candidates in turn, one row each per step.  Same lanes, same order of operations.
+    const uint32_t ng = gridDim.x * GPB;
+    for (uint32_t j = blockIdx.x * GPB + grp; j < cnt; j += ng) {
+      const uint2 e = list[j];
+      const bool inside = e.x < n_rows && e.y <= thr;
+      const u4 *p = rows + (size_t)(inside ? e.x : 0u) * stride16;
+      u4 x[ITERS];
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) x[i] = load16<false>(p + lane + i * G);
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < ITERS; i++) acc = Op<TYPE, METRIC>::add(acc, x[i], qv[i]);
+      const float d = finish<TYPE, METRIC>(group_reduce<G>(acc), zero4());
+      if (lane == 0) list[j].y = inside ? to_key(d) : 0xFFFFFFFFu;
+    }
+    return;
+  }
   // A group looks at G candidates at a time, one per lane (a coalesced read); the few inside the band are then re-scored one
   // after the other by the whole group.  (The lists are long and mostly outside: the int8 band leaves ~10 k collected
   // candidates per query, the first phase of an L2 pass 16 k, of which a few hundred are inside the final band -- walking
@@ -804,7 +824,7 @@ bool batch_rescore_supported(uint32_t stride16) {
 
 bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, const void *queries, size_t qstride, void *cand,
                           const uint32_t *cand_count, uint32_t cand_cap, uint32_t n_queries, const float *tau, hipStream_t s,
-                          int type, int metric, const RowBand *band) {
+                          int type, int metric, const RowBand *band, bool dense) {
   const uint32_t s16 = (uint32_t)(stride / 16);
   if (!batch_rescore_supported(s16) || !n_queries || (type != KT_F32 && type != KT_F16 && type != KT_BF16)) return false;
   if (metric != KM_IP && metric != KM_L2) return false;
@@ -816,7 +836,7 @@ bool launch_batch_rescore(const void *rows, size_t stride, uint32_t n_rows, cons
   const dim3 grid(64, n_queries), block(256);
 #define RSGPU_RESCORE_M(TT, MM, GG, II)                                                                                    \
   hipLaunchKernelGGL((batch_rescore_kernel<TT, MM, GG, II>), grid, block, 0, s, (const u4 *)rows, s16, n_rows,             \
-                     (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau, rb)
+                     (const u4 *)queries, (uint32_t)(qstride / 16), (uint2 *)cand, cand_count, cand_cap, tau, rb, dense ? 1 : 0)
 #define RSGPU_RESCORE_T(TT, GG, II)                                                                                        \
   do {                                                                                                                     \
     if (metric == KM_L2) RSGPU_RESCORE_M(TT, KM_L2, GG, II);                                                               \
