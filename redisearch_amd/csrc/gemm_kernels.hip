@@ -334,6 +334,7 @@ struct BatchSel {
   float slack;         // added to the bound written to tau_out (error band of a low-precision filter pass)
   const float *slack_q;  // per-query band (overrides slack)
   uint32_t prune;        // PAIRS, threshold only: the list keeps just the candidates at or below the new bound
+  uint32_t no_regs;      // the list is re-read from memory in every pass even when the registers would hold it (knob batch_select_regs = 0: the tests' way onto the path lists above 16 Ki entries take)
 };
 __device__ __forceinline__ uint32_t sel_f2key(float f) {  // (scan_ops.hpp f2key: the orderable image of a distance, NaN last)
   const uint32_t u = __float_as_uint(f);
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(1024) void batch_select_kernel(BatchSel s) {
   // dependent round trip per 1 024 elements and pass -- 20 us per select at 4 k candidates, 85 us at 16 k, six to seven selects
   // per corpus pass): ONE batch of independent loads, the passes run on LDS alone.
   constexpr int MAXE = 16;
-  const bool cached = n <= (uint32_t)MAXE * 1024u;  // (uniform)
+  const bool cached = n <= (uint32_t)MAXE * 1024u && !s.no_regs;  // (uniform)
   const uint32_t nj = (n + 1023u) / 1024u;
   u64 E[MAXE];
   if (cached) {
@@ -591,6 +592,7 @@ void launch_batch_threshold(const uint32_t *keys, uint32_t ld, uint32_t n, uint3
                             uint32_t n_valid, float *tau_out, hipStream_t s, uint32_t stride, float slack,
                             const float *slack_q) {
   BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, tau_out, nullptr, nullptr, nullptr, 0, nullptr, n_valid, stride, slack, slack_q};
+  b.no_regs = scan_tuning().batch_select_regs ? 0u : 1u;
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
@@ -601,12 +603,14 @@ void launch_batch_threshold_cand(const void *cand, const uint32_t *cand_count, u
                                  hipStream_t s, float slack, const float *slack_q, bool prune) {
   BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, tau_inout, nullptr, nullptr, nullptr, 0, overflow,
              n_valid, 1, slack, slack_q, prune ? 1u : 0u};
+  b.no_regs = scan_tuning().batch_select_regs ? 0u : 1u;
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
 void launch_batch_select_keys(const uint32_t *keys, uint32_t ld, uint32_t n, uint32_t k, uint32_t n_queries,
                               uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n, uint32_t k_ld, hipStream_t s) {
   BatchSel b{keys, ld, n, nullptr, nullptr, 0, k, nullptr, out_rows, out_keys, out_n, k_ld, nullptr, n_queries, 1, 0.0f, nullptr};
+  b.no_regs = scan_tuning().batch_select_regs ? 0u : 1u;
   hipLaunchKernelGGL(batch_select_kernel<false>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 
@@ -614,6 +618,7 @@ void launch_batch_select_cand(const void *cand, const uint32_t *cand_count, uint
                               uint32_t n_queries, uint32_t *out_rows, uint32_t *out_keys, uint32_t *out_n,
                               uint32_t k_ld, uint32_t *overflow, hipStream_t s) {
   BatchSel b{nullptr, 0, 0, (const uint2 *)cand, cand_count, cand_cap, k, nullptr, out_rows, out_keys, out_n, k_ld, overflow, n_queries, 1, 0.0f, nullptr};
+  b.no_regs = scan_tuning().batch_select_regs ? 0u : 1u;
   hipLaunchKernelGGL(batch_select_kernel<true>, dim3(n_queries), dim3(1024), 0, s, b);
 }
 

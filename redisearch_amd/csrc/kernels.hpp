@@ -148,6 +148,7 @@ struct ScanTuning {
                            // int8 matrix cores -- no stored shadow.  5 (default) = once per workgroup, register-staged (gemm_qs_h8r_kernel, 2.91 ms
                            // per configs[2] pass); 2 / 1 = in every wave, behind the LDS-DMA ring (four waves x 64 queries 3.87 ms / eight x 32
                            // 4.29 ms); 3 / 4 = 2 with smaller ring slots (4.14 / 4.61 ms); 0 = the fp16 MFMA pass (3.96 ms)
+  int batch_select_regs = 1;  // batch_select_kernel keeps a list of up to 16 Ki entries in registers (0: every digit pass re-reads it -- the longer lists' path, for the tests)
   int batch_prune = 1;     // batched passes: a threshold select leaves only the candidates its new bound admits in the list (0: the lists only grow)
   int gemm_qs_f8 = 1;      // FLOAT32 IP / cosine indexes: the batched / coalesced passes quantise the fp32 rows to int8 in flight (gemm_qs_h8r_kernel<..,
                            // SRC_F8>: 5.48 ms per 256-query pass over 10M x 768, 0.70 of HBM) instead of rounding them to bf16 (gemm_qs_f32_kernel:

@@ -709,6 +709,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "gemm_qs_h8")) scan_tuning().gemm_qs_h8 = value;
   else if (!strcmp(key, "gemm_qs_f8")) scan_tuning().gemm_qs_f8 = value;
   else if (!strcmp(key, "batch_prune")) scan_tuning().batch_prune = value;
+  else if (!strcmp(key, "batch_select_regs")) scan_tuning().batch_select_regs = value;
   else if (!strcmp(key, "hybrid_coalesce")) scan_tuning().hybrid_coalesce = value;
   else if (!strcmp(key, "hybrid_coalesce_depth")) scan_tuning().hybrid_coalesce_depth = value;
   else if (!strcmp(key, "hybrid_coalesce_interleave")) scan_tuning().hybrid_coalesce_interleave = value;
