@@ -138,6 +138,7 @@ struct ScanTuning {
   int probe_dpt = 4;       // intersection of long lists: drivers per thread of the probe / write kernels (1 = tiles of 256; A/B knob)
   int decode_lean = 1;     // the two-launch hybrid query decodes doc ids + frequencies only (a Full-codec list: 8 of 20 bytes per posting; A/B knob)
   int decode_pair = 1;     // decode-per-query mode: two qint lists of a query in one launch (A/B knob)
+  int decode_dense = 1;    // qint lists without inline offsets: groups of sixteen blocks whose records are all of the minimal length decode data-parallel (decode_dense_kernel; 0: eight lanes per block everywhere)
   int decode_sync = 1;     // qint lists: the first decode leaves sub-block sync points, later decodes use 8 lanes per block (A/B knob)
   int gemm_qs = 1;         // batched path: query-stationary filter pass (gemm_qs_kernels.hip); 0 = tiled GEMM
   int gemm_qs_f32 = 2;     // FLOAT32 indexes: batched / coalesced queries through the matrix cores, rows converted to bf16 in flight

@@ -213,6 +213,49 @@ __device__ __forceinline__ void decode_qint_block_lds(const uint8_t *stage, uint
     }
     uint32_t b_id[4], b_fr[4], b_mk[4], b_op[4], b_ol[4];
     uint32_t got = 0;
+    if constexpr (OS < 0) {
+      // FOUR records at once when their control bytes are all zero (round 6): every field is one byte then, the records are
+      // NF + 1 bytes each and sit at fixed offsets in the NF + 1 words one LDS round trip delivers anyway -- no position depends
+      // on a value, ~8 vector instructions per record instead of ~37 and a quarter of the round trips.  That is the usual
+      // record of the lists that cost the most to decode: dense ones (deltas and frequencies below 256).  Any other control
+      // byte among the four, a block end or fewer than four records left: the record-by-record path below, same bytes out.
+      constexpr uint32_t RL = NF + 1;
+      if (e + 4 <= n && pos + 4 * RL <= fin) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (pos >> 2);
+        uint32_t r[NF + 2];
+#pragma unroll
+        for (int i = 0; i < NF + 2; i++) r[i] = w[i];
+        uint32_t a[NF + 1];
+#pragma unroll
+        for (int i = 0; i < NF + 1; i++) a[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], pos & 3u);
+        uint32_t ctrl = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) ctrl |= a[(i * RL) >> 2] & (0xFFu << (8 * ((i * RL) & 3u)));
+        if (ctrl == 0) {
+          auto byte_at = [&](uint32_t b) { return (a[b >> 2] >> (8 * (b & 3u))) & 0xFFu; };
+#pragma unroll
+          for (uint32_t i = 0; i < 4; i++) {
+            base += byte_at(i * RL + 1);
+            b_id[i] = base;
+            b_fr[i] = FR >= 0 ? byte_at(i * RL + 1 + (FR >= 0 ? FR : 0)) : 0u;
+            b_mk[i] = MK >= 0 ? byte_at(i * RL + 1 + (MK >= 0 ? MK : 0)) : 0u;
+            b_op[i] = abs_base + pos + (i + 1) * RL;
+            b_ol[i] = 0u;
+          }
+          pos += 4 * RL;
+          e += 4;
+          *reinterpret_cast<u4u *>(ids + out) = (u4u){b_id[0], b_id[1], b_id[2], b_id[3]};
+          if (freqs) *reinterpret_cast<u4u *>(freqs + out) = (u4u){b_fr[0], b_fr[1], b_fr[2], b_fr[3]};
+          if (masks) *reinterpret_cast<u4u *>(masks + out) = (u4u){b_mk[0], b_mk[1], b_mk[2], b_mk[3]};
+          if (off_pos) {
+            *reinterpret_cast<u4u *>(off_pos + out) = (u4u){b_op[0], b_op[1], b_op[2], b_op[3]};
+            *reinterpret_cast<u4u *>(off_len + out) = (u4u){b_ol[0], b_ol[1], b_ol[2], b_ol[3]};
+          }
+          out += 4;
+          continue;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       if (e < n && pos < fin) {
@@ -402,6 +445,137 @@ __global__ __launch_bounds__(64) void decode_blocks_pair_kernel(DecodeArgs a, De
   extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
   if (blockIdx.x < wgs_a) decode_blocks_body<KIND>(a, blockIdx.x, stage);
   else decode_blocks_body<KIND>(b, blockIdx.x - wgs_a, stage);
+}
+
+// ---- round 6: DENSE groups -- sixteen consecutive blocks whose records are all of the minimal length ----
+// A qint record is one control byte + 1..4 bytes per field; a block whose byte length is (NF + 1) x its entry count can only hold
+// records of NF + 1 bytes -- every control byte zero, every field one byte -- and that is what the lists that cost the most to
+// decode look like (a term in a tenth of the documents: deltas ~10, frequencies 1..3: configs[4]'s lists are 3.00 bytes per posting).
+// Then NOTHING depends on a parse: record i of the group sits at byte (NF + 1) i.  A wavefront takes sixteen blocks (lane j < 16 holds
+// block j's description -- no sync points read), stages their bytes by DMA, and in steps of 256 records every lane decodes FOUR
+// consecutive records: one LDS round trip, byte extracts, a wave-wide prefix of the deltas; the doc ids are the prefix + a per-block
+// constant (the block's first id - the prefix in front of it: wave-uniform, taken with v_readlane from the lane that holds the
+// block's first record).  Adjacent lanes write adjacent 16 bytes: a store instruction covers 1 KiB of consecutive addresses where
+// the chain parsers write 64 pieces 64 bytes apart (64 partial-line requests per instruction -- the L2's request rate, not the
+// parse, was what the two-round kernel's time had come down to once four zero-control records were taken at a time).
+// A group with any longer record, or one too wide to stage: the eight-lanes-per-block form, its two halves one after the other.
+// Same bytes in, same arrays out (reference qint/src/lib.rs:139-214; inverted_index/src/codec/{freqs_only,fields_only,freqs_fields}.rs).
+constexpr uint32_t kDenseBlocks = 16;
+template <int NF, int FR, int MK>
+__device__ __forceinline__ bool decode_dense_group(const DecodeArgs &A, uint32_t g16, uint8_t *stage, uint32_t stage_cap) {
+  typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr uint32_t RL = NF + 1;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t b0 = g16 * kDenseBlocks;
+  const uint32_t nb = A.n_blocks - b0 < kDenseBlocks ? A.n_blocks - b0 : kDenseBlocks;
+  const uint32_t b = b0 + (lane < nb ? lane : nb - 1);
+  const uint64_t beg = A.byte_off[b], fin = A.byte_off[b + 1];
+  const uint32_t n = A.nent[b], first = A.first[b], out = A.entry_off[b];
+  // every record minimal, the blocks' entries consecutive in the arrays (they are: entry_off is a running sum -- checked, not assumed)
+  const uint32_t out_next = __shfl_down(out, 1, 64);
+  const bool bad = fin - beg != (uint64_t)RL * n || (lane + 1 < nb && out + n != out_next);
+  if (__ballot(bad)) return false;
+  const uint64_t beg0 = __shfl(beg, 0, 64), w_beg = beg0 & ~15ull, w_end = __shfl(fin, (int)nb - 1, 64);
+  if (w_end - w_beg > stage_cap) return false;
+  const uint32_t span = (uint32_t)(w_end - w_beg);
+  {
+    const uint8_t *src = A.bytes + w_beg + lane * 16;
+    for (uint32_t o = 0; o < span; o += 64 * 16)
+      if (o + lane * 16 < span)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                         (__attribute__((address_space(3))) void *)(stage + o), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  const uint32_t out0 = __shfl(out, 0, 64);
+  const uint32_t R = __shfl(out, (int)nb - 1, 64) + __shfl(n, (int)nb - 1, 64) - out0;  // records of the group
+  const uint32_t byte0 = (uint32_t)(beg0 - w_beg);
+  const uint32_t start = out - out0;  // lane j < nb: the group-relative index of block j's first record
+  uint32_t carry = 0;                 // the deltas of every record in front of this step (wave-uniform)
+  uint32_t cur_c = 0;                 // first id - prefix in front, of the block the step's first record is in
+  uint32_t jn = 0;                    // the next block whose first record has not been passed
+  uint32_t s_next = __builtin_amdgcn_readlane((int)start, 0);
+  for (uint32_t t0 = 0; t0 < R; t0 += 256) {
+    const uint32_t i0 = t0 + 4 * lane;
+    const uint32_t boff = byte0 + RL * (i0 < R ? i0 : 0u);  // (a lane past the end reads the group's first record: values unused)
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(stage) + (boff >> 2);
+    uint32_t r[NF + 2];
+#pragma unroll
+    for (int i = 0; i < NF + 2; i++) r[i] = w[i];  // (past the group's last byte: inside the staging buffer's slack, unused)
+    uint32_t a[NF + 1];
+#pragma unroll
+    for (int i = 0; i < NF + 1; i++) a[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], boff & 3u);
+    auto byte_at = [&](uint32_t x) { return (a[x >> 2] >> (8 * (x & 3u))) & 0xFFu; };
+    uint32_t p[4], fr[4], mk[4];
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      run += i0 + k < R ? byte_at(k * RL + 1) : 0u;
+      p[k] = run;  // inclusive, within the lane
+      fr[k] = FR >= 0 ? byte_at(k * RL + 1 + (FR >= 0 ? FR : 0)) : 0u;
+      mk[k] = MK >= 0 ? byte_at(k * RL + 1 + (MK >= 0 ? MK : 0)) : 0u;
+    }
+    uint32_t inc = run;  // inclusive over the lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(inc, off, 64);
+      if (lane >= (uint32_t)off) inc += v;
+    }
+    const uint32_t exc = inc - run + carry;  // everything in front of the lane's first record
+    // the blocks that begin inside this step: their constants, and which of the lane's records they own
+    uint32_t base[4] = {cur_c, cur_c, cur_c, cur_c};
+    while (jn < nb && s_next < t0 + 256) {  // (wave-uniform)
+      const uint32_t rel = s_next - t0, lj = rel >> 2, kj = rel & 3u;
+      const uint32_t e_lane = (uint32_t)__builtin_amdgcn_readlane((int)exc, lj);
+      const uint32_t e_in = kj == 0 ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)(kj == 1 ? p[0] : (kj == 2 ? p[1] : p[2])), lj);
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)first, jn) - (e_lane + e_in);
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) base[k] = 4 * lane + k >= rel ? c : base[k];
+      cur_c = c;
+      jn++;
+      s_next = jn < nb ? (uint32_t)__builtin_amdgcn_readlane((int)start, jn) : 0xFFFFFFFFu;
+    }
+    carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    uint32_t id[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) id[k] = exc + p[k] + base[k];
+    const uint32_t o = out0 + i0;
+    if (i0 + 4 <= R) {
+      *reinterpret_cast<u4u *>(A.ids + o) = (u4u){id[0], id[1], id[2], id[3]};
+      if (A.freqs) *reinterpret_cast<u4u *>(A.freqs + o) = (u4u){fr[0], fr[1], fr[2], fr[3]};
+      if (A.masks) *reinterpret_cast<u4u *>(A.masks + o) = (u4u){mk[0], mk[1], mk[2], mk[3]};
+    } else {
+#pragma unroll
+      for (uint32_t k = 0; k < 3; k++)
+        if (i0 + k < R) {
+          A.ids[o + k] = id[k];
+          if (A.freqs) A.freqs[o + k] = fr[k];
+          if (A.masks) A.masks[o + k] = mk[k];
+        }
+    }
+  }
+  return true;
+}
+__device__ __forceinline__ void decode_dense_body(const DecodeArgs &A, uint32_t g16, uint8_t *stage, uint32_t stage_cap) {
+  const CodecDesc cd = A.cd;
+  bool done = false;
+  if (cd.n == 2 && cd.freq == 1 && cd.mask == -1) done = decode_dense_group<2, 1, -1>(A, g16, stage, stage_cap);        // FreqsOnly
+  else if (cd.n == 2 && cd.freq == -1 && cd.mask == 1) done = decode_dense_group<2, -1, 1>(A, g16, stage, stage_cap);   // FieldsOnly
+  else if (cd.n == 3 && cd.freq == 1 && cd.mask == 2) done = decode_dense_group<3, 1, 2>(A, g16, stage, stage_cap);    // FreqsFields
+  if (done) return;
+  constexpr uint32_t HALVES = kDenseBlocks / (64u / (kSyncPts + 1));
+  for (uint32_t h = 0; h < HALVES; h++) {  // (a loop, not two inlined bodies)
+    const uint32_t wg = g16 * HALVES + h;
+    if (wg * (64u / (kSyncPts + 1)) < A.n_blocks) decode_blocks_body<0>(A, wg, stage);
+    __syncthreads();
+  }
+}
+// one list (b.n_blocks = 0) or two: workgroup -> (list, group of sixteen blocks)
+__global__ __launch_bounds__(64) void decode_dense_kernel(DecodeArgs a, DecodeArgs b, uint32_t wgs_a, uint32_t stage_cap) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t stage[];
+  // (a branch per list: a reference chosen between the two argument blocks would be a select between their addresses -- scratch)
+  if (blockIdx.x < wgs_a) decode_dense_body(a, blockIdx.x, stage, stage_cap);
+  else decode_dense_body(b, blockIdx.x - wgs_a, stage, stage_cap);
 }
 
 // One WAVEFRONT per block for the two record kinds whose boundaries need no parse from the block start: a varint delta
@@ -1146,6 +1320,23 @@ static uint32_t decode_bpw1(uint32_t avg_block_bytes) {
   return bpw;
 }
 
+// the dense-group kernel takes a list (or two) when its layout has no inline offsets, its sync points are there (the groups that are
+// not dense go through them) and sixteen blocks fit the staging buffer
+static bool dense_eligible(const DecodeArgs &a) {
+  return scan_tuning().decode_dense && a.sync_mode == 2 && a.cd.kind == 0 && !a.cd.wide && a.cd.osz < 0 && !a.wmasks && !a.off_pos &&
+         ((a.cd.n == 2 && ((a.cd.freq == 1 && a.cd.mask == -1) || (a.cd.freq == -1 && a.cd.mask == 1))) ||
+          (a.cd.n == 3 && a.cd.freq == 1 && a.cd.mask == 2)) &&
+         2 * a.lds_cap + 64 <= 64 * 1024;
+}
+static void launch_decode_dense(const DecodeArgs &a, const DecodeArgs *b, hipStream_t s) {
+  const uint32_t cap = b && b->lds_cap > a.lds_cap ? b->lds_cap : a.lds_cap;
+  const uint32_t wgs_a = (a.n_blocks + kDenseBlocks - 1) / kDenseBlocks, wgs_b = b ? (b->n_blocks + kDenseBlocks - 1) / kDenseBlocks : 0;
+  DecodeArgs none = a;
+  none.n_blocks = 0;
+  // (the staging buffer: two eight-block spans + the parsers' slack)
+  hipLaunchKernelGGL(decode_dense_kernel, dim3(wgs_a + wgs_b), dim3(64), 2 * cap + 64, s, a, b ? *b : none, wgs_a, 2 * cap);
+}
+
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
                           const uint32_t *nent, const uint32_t *entry_off, uint32_t n_blocks, uint32_t *ids,
                           uint32_t *freqs, uint32_t *masks, hipStream_t s, uint32_t *wmasks, uint32_t *off_pos,
@@ -1157,6 +1348,10 @@ void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint6
   const uint32_t bpw = sync_mode == 2 ? 64 / (kSyncPts + 1) : bpw1;
   const DecodeArgs a{cd, bytes, byte_off, first, nent, entry_off, n_blocks, ids, freqs, masks, wmasks, off_pos, off_len, sync,
                      sync_mode, lds_cap, bpw1};
+  if (dense_eligible(a)) {
+    launch_decode_dense(a, nullptr, s);
+    return;
+  }
 #define RSGPU_DECODE(K) hipLaunchKernelGGL(decode_blocks_kernel<K>, dim3((n_blocks + bpw - 1) / bpw), dim3(64), lds_cap + 64, s, a)
   // varint / raw deltas without a wide mask: one wavefront per block (decode_blocks_wave_kernel)
   const bool wave = (cd.kind == 1 || cd.kind == 2) && !cd.wide && !wmasks && !off_pos;
@@ -1184,6 +1379,10 @@ bool launch_decode_blocks_pair(const DecodeListArgs &x, const DecodeListArgs &y,
   const DecodeArgs b{y.cd, y.bytes, y.byte_off, y.first, y.nent, y.entry_off, y.n_blocks, y.ids, y.freqs, y.masks, nullptr,
                      y.off_pos, y.off_len, y.sync, my, cap_y, 64};
   if (mx != 2 || my != 2) return false;  // (the pair launch is for lists whose sync points are there)
+  if (dense_eligible(a) && dense_eligible(b)) {
+    launch_decode_dense(a, &b, s);
+    return true;
+  }
   const uint32_t lds = (cap_x > cap_y ? cap_x : cap_y) + 64;
   hipLaunchKernelGGL(decode_blocks_pair_kernel<0>, dim3(wgs_x + wgs_y), dim3(64), lds, s, a, b, wgs_x);
   return true;

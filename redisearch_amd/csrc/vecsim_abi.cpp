@@ -723,6 +723,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shards")) scan_tuning().shards = value;
   else if (!strcmp(key, "shard_replicas")) scan_tuning().shard_replicas = value;
   else if (!strcmp(key, "cache_decoded")) scan_tuning().cache_decoded = value;
+  else if (!strcmp(key, "decode_dense")) scan_tuning().decode_dense = value;
   else if (!strcmp(key, "decode_sync")) scan_tuning().decode_sync = value;
   else if (!strcmp(key, "probe_dpt")) scan_tuning().probe_dpt = value;
   else if (!strcmp(key, "decode_pair")) scan_tuning().decode_pair = value;
