@@ -460,7 +460,8 @@ __global__ __launch_bounds__(64) void decode_blocks_pair_kernel(DecodeArgs a, De
 // parse, was what the two-round kernel's time had come down to once four zero-control records were taken at a time).
 // A group with any longer record, or one too wide to stage: the eight-lanes-per-block form, its two halves one after the other.
 // Same bytes in, same arrays out (reference qint/src/lib.rs:139-214; inverted_index/src/codec/{freqs_only,fields_only,freqs_fields}.rs).
-constexpr uint32_t kDenseBlocks = 16;
+constexpr uint32_t kDenseBlocks = 16;  // (32 measured: 26-27 us where 16 take 22-23 -- a wavefront's steps are one after the other; 8 would be two rounds over the chip again)
+constexpr uint32_t kDenseSpans = kDenseBlocks / (64u / (kSyncPts + 1));  // eight-block spans (what lds_cap holds) per group
 template <int NF, int FR, int MK>
 __device__ __forceinline__ bool decode_dense_group(const DecodeArgs &A, uint32_t g16, uint8_t *stage, uint32_t stage_cap) {
   typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -515,12 +516,18 @@ __device__ __forceinline__ bool decode_dense_group(const DecodeArgs &A, uint32_t
       fr[k] = FR >= 0 ? byte_at(k * RL + 1 + (FR >= 0 ? FR : 0)) : 0u;
       mk[k] = MK >= 0 ? byte_at(k * RL + 1 + (MK >= 0 ? MK : 0)) : 0u;
     }
-    uint32_t inc = run;  // inclusive over the lanes
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(inc, off, 64);
-      if (lane >= (uint32_t)off) inc += v;
-    }
+    // inclusive over the lanes: four shifts inside a row of sixteen, then the rows' last lanes broadcast to the rows behind them --
+    // six DPP adds (a lane without a source adds 0); __shfl_up would be six dependent ds_bpermute round trips
+    // inclusive over the lanes: four shifts inside a row of sixteen, then the rows' last lanes broadcast to the rows behind them --
+    // six DPP adds (a lane without a source adds 0) instead of six ds_bpermute round trips (measured the same: the kernel's time is
+    // its three dependent round trips -- descriptions, staging, stores -- and the launch of 4 688 workgroups, not this)
+    uint32_t inc = run;
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);  // row_shr:1
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);  // row_shr:2
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);  // row_shr:4
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);  // row_shr:8
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
     const uint32_t exc = inc - run + carry;  // everything in front of the lane's first record
     // the blocks that begin inside this step: their constants, and which of the lane's records they own
     uint32_t base[4] = {cur_c, cur_c, cur_c, cur_c};
@@ -1326,15 +1333,15 @@ static bool dense_eligible(const DecodeArgs &a) {
   return scan_tuning().decode_dense && a.sync_mode == 2 && a.cd.kind == 0 && !a.cd.wide && a.cd.osz < 0 && !a.wmasks && !a.off_pos &&
          ((a.cd.n == 2 && ((a.cd.freq == 1 && a.cd.mask == -1) || (a.cd.freq == -1 && a.cd.mask == 1))) ||
           (a.cd.n == 3 && a.cd.freq == 1 && a.cd.mask == 2)) &&
-         2 * a.lds_cap + 64 <= 64 * 1024;
+         kDenseSpans * a.lds_cap + 64 <= 64 * 1024;
 }
 static void launch_decode_dense(const DecodeArgs &a, const DecodeArgs *b, hipStream_t s) {
   const uint32_t cap = b && b->lds_cap > a.lds_cap ? b->lds_cap : a.lds_cap;
   const uint32_t wgs_a = (a.n_blocks + kDenseBlocks - 1) / kDenseBlocks, wgs_b = b ? (b->n_blocks + kDenseBlocks - 1) / kDenseBlocks : 0;
   DecodeArgs none = a;
   none.n_blocks = 0;
-  // (the staging buffer: two eight-block spans + the parsers' slack)
-  hipLaunchKernelGGL(decode_dense_kernel, dim3(wgs_a + wgs_b), dim3(64), 2 * cap + 64, s, a, b ? *b : none, wgs_a, 2 * cap);
+  // (the staging buffer: the group's eight-block spans + the parsers' slack)
+  hipLaunchKernelGGL(decode_dense_kernel, dim3(wgs_a + wgs_b), dim3(64), kDenseSpans * cap + 64, s, a, b ? *b : none, wgs_a, kDenseSpans * cap);
 }
 
 void launch_decode_blocks(const CodecDesc &cd, const uint8_t *bytes, const uint64_t *byte_off, const uint32_t *first,
