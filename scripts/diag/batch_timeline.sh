@@ -34,7 +34,7 @@ for kind in ("f16", "f32"):
     t0 = rows[lo][0]
     prev_end = None
     for s, e, n in rows[lo:j]:
-        short = re.sub(r"\(.*", "", n).replace("void rsgpu::(anonymous namespace)::", "").replace("rsgpu::(anonymous namespace)::", "").replace("rsgpu::", "")
+        short = re.sub(r"\(.*", "", n.replace("(anonymous namespace)::", "").replace("rsgpu::", "").replace("void ", ""))[:60]
         out.append("%9.1f us  dur %8.1f  gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev_end is None else (s - prev_end) / 1e3, short))
         prev_end = e if prev_end is None else max(prev_end, e)
     total = (rows[j - 1][1] - rows[lo][0]) / 1e3
