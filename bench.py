@@ -580,7 +580,7 @@ def _batched_wall(index, qs, k, ids_of_block, block, calls=3):
     return el / (calls * nb) * 1e3, same
 
 
-def extra_batched_f32(lib, V, index, rows, dim):
+def extra_batched_f32(lib, V, index, rows, dim, want_shadow8_back=False):
     """The rest of K5: 256 queries per corpus pass on a PLAIN fp32 cosine index (RediSearch's default type; an index of its own --
     the headline index carries the two-stage extra's opt-in shadow) through RSGPU_FlatIndex_TopKBatch.  Default route since round
     6: the fp32 rows are quantised to int8 on their way to the int8 matrix cores (gemm_qs_h8r_kernel<.., SRC_F8>; nothing stored);
@@ -588,7 +588,13 @@ def extra_batched_f32(lib, V, index, rows, dim):
     bit-identical to VecSimIndex_TopKQuery."""
     k, batch, reps = 100, 256, 8
     del index
+    # a PLAIN index: the headline index was created with the shadow8 knob set (the two-stage extra's shadow) and the knob is read at
+    # creation -- left on, this index would carry a stored shadow too and never take the in-flight route (rounds 6's first records
+    # measured the bf16 form twice that way)
+    lib.RSGPU_SetTuning(b"shadow8", 0)
     idx = V.VecSimIndex(V.VecSimType_FLOAT32, dim, V.VecSimMetric_Cosine)
+    if want_shadow8_back:
+        lib.RSGPU_SetTuning(b"shadow8", 1)
     try:
         idx.reserve(rows)
         idx.add_philox_rows(SEED, 0, rows, 1)
@@ -603,6 +609,7 @@ def extra_batched_f32(lib, V, index, rows, dim):
         el = time.perf_counter() - t0
         lib.RSGPU_SetProfiling(0)
         launches, ms, _ = V.scan_profile()
+        route = int(lib.RSGPU_LastBatchRoute())   # 6: fp32 rows quantised to int8 in flight (rsgpu_ext.h)
         mq = V.coalesce_stats()["mq_passes"]
         dev_ms = ms / max(launches, 1)
         same = True
@@ -611,7 +618,7 @@ def extra_batched_f32(lib, V, index, rows, dim):
             same &= si.tolist() == ids[i].tolist() and ss.tolist() == sc[i].tolist()
         wall_ms, same4 = _batched_wall(idx, qs, k, ids, reps % 4)
         same &= same4
-        bf16_ms, bf16_same = None, None
+        bf16_ms, bf16_same, bf16_route = None, None, None
         try:   # the bf16-in-flight form over the same index, for the record (rounds 4-5's route)
             lib.RSGPU_SetTuning(b"gemm_qs_f8", 0)
             idx.topk_batch(qs[0], k)
@@ -621,6 +628,7 @@ def extra_batched_f32(lib, V, index, rows, dim):
                 ids0, sc0, _ = idx.topk_batch(qs[(i + 1) % 4], k)
             lib.RSGPU_SetProfiling(0)
             l0, ms0, _ = V.scan_profile()
+            bf16_route = int(lib.RSGPU_LastBatchRoute())   # 2: fp32 rows rounded to bf16 in flight
             bf16_ms = ms0 / max(l0, 1)
             lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
             idsr, scr, _ = idx.topk_batch(qs[5 % 4], k)
@@ -643,6 +651,7 @@ def extra_batched_f32(lib, V, index, rows, dim):
                           "errors) + progressive thresholds + batch_rescore_kernel (the single-query scan's arithmetic) + per-query "
                           "select; HIP events around the whole device pipeline of a pass",
                 "bf16_in_flight_pass_device_ms": bf16_ms, "bf16_in_flight_pass_same_replies": bf16_same,
+                "route": route, "route_is_int8_in_flight": route == 6, "bf16_in_flight_route": bf16_route,
                 "bit_identical_to_single_queries": bool(same),
                 "algorithmic_bytes_per_pass": rows * dim * 4}
     finally:
@@ -666,6 +675,7 @@ def extra_batched(lib, V, rows, dim):
         el = time.perf_counter() - t0
         lib.RSGPU_SetProfiling(0)
         launches, ms, _ = V.scan_profile()
+        route = int(lib.RSGPU_LastBatchRoute())   # 5: fp16 rows quantised to int8 in flight (rsgpu_ext.h)
         dev_ms = ms / max(launches, 1)
         # parity: 4 of the 256 queries against the single-query path of the same index -- BIT-IDENTICAL since round 5 (the
         # survivors of the matrix-core passes are re-scored with the single-query scan's arithmetic, as on every other route)
@@ -736,7 +746,7 @@ def extra_batched(lib, V, rows, dim):
         payload = {"kind": "batched", "rows": rows, "dim": dim, "k": k, "queries": qs[reps % 4].copy(),
                    "ids": ids.copy(), "scores": sc.copy(), "which": (0, 85, 170, 255)}
         return {"workload": "%dx%d fp16 FLAT IP top-%d, batch=%d queries per corpus pass (RSGPU_FlatIndex_TopKBatch)" % (rows, dim, k, batch),
-                "int8_shadow_extra": i8,
+                "int8_shadow_extra": i8, "route": route, "route_is_int8_in_flight": route == 5,
                 "device_ms_per_pass": dev_ms, "wall_ms_per_pass": wall_ms, "wall_over_device": wall_ms / dev_ms,
                 "qps_device": batch / dev_ms * 1e3, "qps_wall": batch / wall_ms * 1e3, "qps_wall_one_pass_per_call": reps * batch / el,
                 "wall_definition": "4 passes (1024 queries) per RSGPU_FlatIndex_TopKBatch call: the call's two pipeline slots overlap "
@@ -1532,6 +1542,7 @@ def summarise_extras(cfg):
                                  "mfma_frac": b.get("mfma_frac"), "fp16_mfma_pass_ms": b.get("fp16_mfma_pass_device_ms"),
                                  "bf16_in_flight_pass_ms": b.get("bf16_in_flight_pass_device_ms"),
                                  "bit_identical": b.get("bit_identical_to_single_queries"),
+                                 "route": b.get("route"),
                                  "parity_ok": _g(b, "parity", "ok"),
                                  "int8_shadow_device_ms": _g(b, "int8_shadow_extra", "device_ms_per_pass")})
     h = cfg.get("hybrid")
@@ -1879,7 +1890,7 @@ def main():
             extras["collective_rccl"] = {"error": repr(e)}
         if not a.no_batched_extra and a.metric == "cosine":
             try:
-                extras["batched_mfma_f32"] = extra_batched_f32(lib, V, index, rows, dim)
+                extras["batched_mfma_f32"] = extra_batched_f32(lib, V, index, rows, dim, want_shadow8_back=want_two_stage_extra)
             except Exception as e:
                 extras["batched_mfma_f32"] = {"error": repr(e)}
     cpu = None

@@ -157,6 +157,12 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
  * [5] nanoseconds spent so, [6] device nanoseconds of the multi-query scans (HIP events), [7] queries of a multi-query
  * pass whose batched selection overflowed and was redone through the radix levels. */
 void RSGPU_GetCoalesceStats(uint64_t out[8]);
+/* Which filter the last RSGPU_FlatIndex_TopKBatch call (of any thread; wide coalesced passes included) ran its corpus passes through:
+ * 0 none yet, 1 fp16 / bf16 matrix-core pass (gemm_qs_kernel), 2 FLOAT32 rows rounded to bf16 in flight (gemm_qs_f32_kernel), 3 stored
+ * fp16 shadow, 4 stored int8 shadow, 5 FLOAT16 / BFLOAT16 rows quantised to int8 in flight, 6 FLOAT32 rows quantised to int8 in flight
+ * (gemm_qs_h8r_kernel), 7 no matrix-core pass (small corpus / K above 1024: exact multi-query scans), 8 the L2 form of 1.  Every route
+ * re-scores its survivors exactly; this is a record for benches and tests that claim a route, not a contract. */
+int RSGPU_LastBatchRoute(void);
 void RSGPU_ResetCoalesceStats(void);
 /* ... of those passes, the WIDE ones (round 4): more than sixteen calls queued on an index whose batched queries are exact
  * (FLOAT32 cosine / L2 with or without a shadow, FLOAT16 / BFLOAT16 L2) share ONE matrix-core filter pass + exact

@@ -5,6 +5,7 @@
 // (reference src/iterators/hybrid_reader.c:374).  EVERY route re-scores the survivors of its matrix-core filter passes with the
 // single-query scan's arithmetic (thresholds widened by the route's error band): replies are bit-identical to B single
 // queries.  (Until round 5 the FLOAT16 / BFLOAT16 IP / cosine route -- BASELINE configs[2] itself -- handed out the MFMA sums.)
+#include <atomic>
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -101,6 +102,11 @@ struct BatchLease {
 };
 
 }  // namespace
+
+// which filter the last call of RSGPU_FlatIndex_TopKBatch (of any thread) ran its passes through -- a record for benches and tests
+// that claim a route (RSGPU_LastBatchRoute, rsgpu_ext.h)
+static std::atomic<int> g_last_batch_route{0};
+int last_batch_route() { return g_last_batch_route.load(std::memory_order_relaxed); }
 
 void release_batch_pool() {
   std::vector<std::unique_ptr<BatchScratchPair>> drop;
@@ -310,9 +316,12 @@ void FlatIndex::topk_batch(const void *queries, size_t n_queries, size_t k, size
                         (via_f32 ? gemm_qs_f32_supported(stride16) : (via_shadow8 && h8 && f8 ? gemm_qs_f8_supported(stride16) : gemm_qs_supported(stride16)));
     if (!use_qs) {  // small corpora, K above the passes' limit: the exact multi-query scan is already cheap / the only exact form
       g.unlock();
+      g_last_batch_route.store(7, std::memory_order_relaxed);
       all_single();
       return;
     }
+    g_last_batch_route.store(via_f32 ? 2 : via_shadow8 ? (h8 ? (f8 ? 6 : 5) : 4) : via_shadow ? 3 : via_l2 ? 8 : via_h16 ? 1 : 0,
+                             std::memory_order_relaxed);
     // FLOAT32 rows have no tiled GEMM for the sample bound: the first int8 phase runs over n0 rows with tau = +inf -- every
     // (row, query) pair becomes a candidate -- and the first bound is the K-th shadow distance among them + the band
     // (L2 passes the same way: the tiled GEMM computes 1 - x.q only)

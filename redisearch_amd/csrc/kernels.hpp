@@ -209,6 +209,7 @@ const char *last_scan_mq_kernel_name(char *buf, size_t cap);
 
 // name of the kernel instantiation the last full scan of this process launched (template arguments + grid)
 const char *last_scan_kernel_name(char *buf, size_t cap);
+int last_batch_route();  // batch_query.cpp: the filter of the last RSGPU_FlatIndex_TopKBatch call (codes: rsgpu_ext.h RSGPU_LastBatchRoute)
 
 // Distances of the rows listed in row_ids[0..m) (0xFFFFFFFF => NaN) as values out[i] (fp32; fp64 for KT_F64).
 // m_dev (optional, device memory): the actual candidate count when the host only knows the upper bound m

@@ -664,6 +664,7 @@ void RSGPU_GetScanProfile(uint64_t *launches, double *total_ms, uint64_t *bytes)
   if (total_ms) *total_ms = (double)scan_profile().nanos.load() / 1e6;
   if (bytes) *bytes = scan_profile().bytes.load();
 }
+int RSGPU_LastBatchRoute(void) { return last_batch_route(); }
 void RSGPU_GetCoalesceStats(uint64_t out[8]) {
   if (!out) return;
   CoalesceStats &c = coalesce_stats();

@@ -197,6 +197,7 @@ ABI = {
     "RSGPU_ShardedIndex_GetExchangeStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_ShardedIndex_GetRcclStats": (None, [_vp, C.POINTER(C.c_uint64), _i]),
     "RSGPU_GetCoalesceStats": (None, [C.POINTER(C.c_uint64)]),
+    "RSGPU_LastBatchRoute": (C.c_int, []),
     "RSGPU_GetWidePassStats": (None, [C.POINTER(C.c_uint64)]),
     "RSGPU_GetCoalesceTimeouts": (C.c_uint64, []),
     "RSGPU_ShardComm_GetUniqueId": (_i, [_vp]),

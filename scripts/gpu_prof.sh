@@ -60,7 +60,7 @@ fe, kern = counters(TAG + "_prof_hyb_FETCH_SIZE", "hybrid_tile_kernel", ["FETCH_
 wr, _ = counters(TAG + "_prof_hyb_WRITE_SIZE", "hybrid_tile_kernel", ["WRITE_SIZE"])
 du = durations(TAG + "_prof_hyb_FETCH_SIZE", "hybrid_tile_kernel")
 red = durations(TAG + "_prof_hyb_FETCH_SIZE", "hybrid_reduce_kernel")
-dec = durations(TAG + "_prof_hyb_FETCH_SIZE", "decode_blocks")
+dec = durations(TAG + "_prof_hyb_FETCH_SIZE", "decode_")  # (decode_dense_kernel since round 6; decode_blocks_* where it does not apply)
 if fe["FETCH_SIZE"] and wr["WRITE_SIZE"]:
     f = sum(fe["FETCH_SIZE"]) / len(fe["FETCH_SIZE"]); w = sum(wr["WRITE_SIZE"]) / len(wr["WRITE_SIZE"])
     try:
@@ -79,10 +79,11 @@ if fe["FETCH_SIZE"] and wr["WRITE_SIZE"]:
     json.dump(out, open("gpurun_out/" + TAG + "_hybrid_tiles_pmc.json", "w"), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != "stream_record_same_process"}))
 # ---- the fp32-native matrix-core pass
-fe, kern = counters(TAG + "_prof_f32_FETCH_SIZE", "gemm_qs_f32_kernel", ["FETCH_SIZE"])
-wr, _ = counters(TAG + "_prof_f32_WRITE_SIZE", "gemm_qs_f32_kernel", ["WRITE_SIZE"])
-ck, _ = counters(TAG + "_prof_f32_clk", "gemm_qs_f32_kernel", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"])
-du = durations(TAG + "_prof_f32_clk", "gemm_qs_f32_kernel")
+KP32 = os.environ.get("F32_KPAT", "gemm_qs_h8r_kernel")  # (the default FLOAT32 route since round 6; gemm_qs_f32_kernel with TUNING=gemm_qs_f8=0)
+fe, kern = counters(TAG + "_prof_f32_FETCH_SIZE", KP32, ["FETCH_SIZE"])
+wr, _ = counters(TAG + "_prof_f32_WRITE_SIZE", KP32, ["WRITE_SIZE"])
+ck, _ = counters(TAG + "_prof_f32_clk", KP32, ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"])
+du = durations(TAG + "_prof_f32_clk", KP32)
 f, nf = big_avg(fe["FETCH_SIZE"]); w, nw = big_avg(wr["WRITE_SIZE"])
 if f and du:
     long_us = [x for x in du if x > 0.5 * max(du)]

@@ -47,9 +47,11 @@ def test_fp32_rows_quantised_in_flight_are_bit_identical_to_single_queries(lib, 
     queries = np.random.default_rng(dim * 3 + k).uniform(-1, 1, (300, dim)).astype(np.float32)
     want = [g.topk_query(q, k).results() for q in queries]
     got = check(lib, g, queries, k, want, expect_launches=2)
+    assert lib.RSGPU_LastBatchRoute() == 6               # (fp32 rows quantised to int8 in flight: rsgpu_ext.h)
     lib.RSGPU_SetTuning(b"gemm_qs_f8", 0)               # the bf16-in-flight route over the same index: the same replies
     lib.RSGPU_ResetProfile()
     ids0, sc0, cnt0 = g.topk_batch(queries, k)
+    assert lib.RSGPU_LastBatchRoute() == 2
     lib.RSGPU_SetTuning(b"gemm_qs_f8", 1)
     assert np.array_equal(ids0, got[0]) and np.array_equal(sc0, got[1]) and np.array_equal(cnt0, got[2])
     g.free()
