@@ -498,7 +498,7 @@ static bool hybrid_two_launches(RSGPU_HybridQueryArgs *a, FlatIndex *f, const La
         T.dir_n[l] = pl->dir_n;
       }
     }
-  T.knn_pipeline = scan_tuning().hybrid_knn_pipeline;
+  T.knn_pipeline = (scan_tuning().hybrid_knn_pipeline ? 1 : 0) | (scan_tuning().hybrid_select_split ? 2 : 0);  // (bit 1: tile_select shares the counting among the wavefronts)
   T.top_n = top_n;
   if (want_score) {
     bool max_norm = false;
@@ -914,7 +914,7 @@ static bool hybrid_general(RSGPU_HybridQueryArgs *a, RSGPU_Postings *const *list
   T.X = tree_prox(&h, max_slop, in_order);
   // (combine_and: the filter runs when a window is asked for, the root has more than one child and some list stores offsets)
   T.prox_filter = (!root_union && (max_slop >= 0 || in_order) && h.n_groups > 1 && h.with_offsets) ? 1 : 0;
-  T.knn_pipeline = scan_tuning().hybrid_knn_pipeline;
+  T.knn_pipeline = (scan_tuning().hybrid_knn_pipeline ? 1 : 0) | (scan_tuning().hybrid_select_split ? 2 : 0);  // (bit 1: tile_select shares the counting among the wavefronts)
   T.top_n = top_n;
   if (want_score) {
     bool max_norm = false;

@@ -67,9 +67,33 @@ __device__ __forceinline__ float group_reduce_rt(float v, int G) {  // group_red
 constexpr uint32_t kHybDirect = 192, kHybScratch = 256;
 template <int DPT, typename Get, typename Put>
 __device__ __forceinline__ void tile_select(const uint64_t (&mk)[DPT], const uint32_t (&mx)[DPT], uint32_t n, uint32_t k, Get get,
-                                            uint64_t *sk, uint32_t *sx, uint32_t *cnt, uint64_t *wtk, uint32_t *wtx, Put put) {
+                                            uint64_t *sk, uint32_t *sx, uint32_t *cnt, uint64_t *wtk, uint32_t *wtx, Put put, bool split) {
   const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   bool direct = n <= kHybDirect;
+  if (split && n <= 128) {
+    // up to 128 entries (the usual tile: a hundred hits): the entries sit in the first n threads and the other wavefronts idled while
+    // those counted all n (3.6 of a light tile's 17 us).  The workgroup's 256 threads are W columns (W = 32 / 64 / 128 >= n) x P rows:
+    // thread (row, e) counts the entries of the row's SHARE that precede entry e, the shares add up in LDS (sx: free on this path).
+    const uint32_t W = n <= 32 ? 32u : (n <= 64 ? 64u : 128u), P = 256u / W;
+    const uint32_t e = threadIdx.x & (W - 1), part = threadIdx.x / W, chunk = (n + P - 1) / P;
+    const uint32_t lo = part * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (threadIdx.x < W) sx[threadIdx.x] = 0;
+    __syncthreads();
+    if (e < n && lo < hi) {
+      const SKey my = get(e);
+      uint32_t rank = 0;
+#pragma unroll 8
+      for (uint32_t o = lo; o < hi; o++) rank += sk_less(get(o), my) ? 1u : 0u;
+      if (rank) atomicAdd(&sx[e], rank);
+    }
+    __syncthreads();
+    if (threadIdx.x < n) {  // (entry e = thread e of slot 0)
+      const SKey my{mk[0], mx[0]};
+      const uint32_t rank = sx[threadIdx.x];
+      if (!sk_same(my, sk_none()) && rank < k) put(rank, my);
+    }
+    return;
+  }
   if (!direct) {
     SKey best = sk_none();
 #pragma unroll
@@ -147,7 +171,7 @@ __device__ __forceinline__ void hyb_knn_distances(const Args &A, const uint32_t 
   // chunk 0 where the lane has none, from the step's first row past the end), the operations of scan_kernel in its order --
   // chunk i of a lane is lane + i G, absent chunks are zeros, one Op::add per chunk slot i < ITERS, then the butterfly
   constexpr int RU = 3, CU = 3;
-  if (ITERS <= CU && A.knn_pipeline) {
+  if (ITERS <= CU && (A.knn_pipeline & 1)) {
     // Rows of at most CU chunks per lane (3 KiB fp32 rows at 64 lanes per row: every configs[4] row): ONE batch of loads per
     // step, so the NEXT step's rows are requested as soon as this step's have been multiplied in -- their round trip
     // (3.7 us under the kernel's own traffic) runs behind this step's butterfly, distance and store instead of after them.
@@ -958,7 +982,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
                      [&](uint32_t rank, const SKey &my) {
                        A.part_skey[(size_t)blockIdx.x * A.top_n + rank] = my.k;
                        A.part_sidx[(size_t)blockIdx.x * A.top_n + rank] = my.i;
-                     });
+                     }, !PROX && (A.knn_pipeline & 2) != 0);  // (the instantiations that carry the proximity cursors sit at their register budget: 80)
     if (threadIdx.x >= nh && threadIdx.x < A.top_n) {
       A.part_skey[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0ull;
       A.part_sidx[(size_t)blockIdx.x * A.top_n + threadIdx.x] = ~0u;
@@ -1006,7 +1030,7 @@ __global__ __launch_bounds__(256) void hybrid_tree_tile_kernel(HybridTreeArgs A)
     tile_select<DPT>(vk_mine, vx_mine, nv, A.k, [&](uint32_t o) { return SKey{(uint64_t)vkey[o], vx[o]}; }, sel_k, sel_x, &sel_cnt,
                      sel_wtk, sel_wtx, [&](uint32_t rank, const SKey &my) {
                        A.part_knn[(size_t)blockIdx.x * A.k + rank] = (my.k << 32) | my.i;
-                     });
+                     }, !PROX && (A.knn_pipeline & 2) != 0);  // (the instantiations that carry the proximity cursors sit at their register budget: 80)
     if (threadIdx.x >= nv && threadIdx.x < A.k) A.part_knn[(size_t)blockIdx.x * A.k + threadIdx.x] = ~0ull;
   }
 }

@@ -127,6 +127,7 @@ struct ScanTuning {
   int hybrid_force_general = 0;  // diagnostics: RSGPU_HybridQuery takes the general tile kernel even for the shapes the two-launch form serves
   int hybrid_dir = 1;      // ... a probed list's window ends come from its bucket directory (one round trip; 0 = wave-wide searches)
   int hybrid_packed_docs = 1;  // document tables uploaded while set also keep {doc length, doc score} side by side (one gather per hit)
+  int hybrid_select_split = 1;  // ... a tile's rank-by-count selection over up to 128 entries shares the counting among the workgroup's four wavefronts (0: the first n threads count all n)
   int hybrid_knn_pipeline = 1;  // ... the tile kernel requests the next step's vector rows before it reduces this step's distances
   int hybrid_coalesce = 1;  // ... the two-launch queries of concurrent callers share grids (hybrid_entry.hpp: the hybrid coalescer); 0 = every query its own two launches
   int hybrid_coalesce_depth = 2;  // ... grids in flight per device before arriving callers queue (1..8)

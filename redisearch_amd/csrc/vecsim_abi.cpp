@@ -717,6 +717,7 @@ int RSGPU_SetTuning(const char *key, int value) {
   else if (!strcmp(key, "shard_exchange")) scan_tuning().shard_exchange = value;
   else if (!strcmp(key, "hybrid_dir")) scan_tuning().hybrid_dir = value;
   else if (!strcmp(key, "hybrid_poll")) scan_tuning().hybrid_poll = value;
+  else if (!strcmp(key, "hybrid_select_split")) scan_tuning().hybrid_select_split = value;
   else if (!strcmp(key, "hybrid_knn_pipeline")) scan_tuning().hybrid_knn_pipeline = value;
   else if (!strcmp(key, "hybrid_packed_docs")) scan_tuning().hybrid_packed_docs = value;
   else if (!strcmp(key, "qs_phases")) scan_tuning().qs_phases = value;

@@ -35,7 +35,7 @@ out = {}
 ref = None
 # CONFIGS="name:key=v,key=v;name2:..."  (knobs not named keep their defaults; every configuration is timed in turn, inside this
 # one process); MODES=warm | warm,cold; OUT=<file under gpurun_out/>
-DEFAULTS = {"hybrid_dir": 1, "hybrid_packed_docs": 1, "hybrid_poll": 1, "hybrid_knn_pipeline": 1, "decode_lean": 1, "decode_dense": 1}
+DEFAULTS = {"hybrid_dir": 1, "hybrid_packed_docs": 1, "hybrid_poll": 1, "hybrid_knn_pipeline": 1, "decode_lean": 1, "decode_dense": 1, "hybrid_select_split": 1}
 spec = os.environ.get("CONFIGS", "defaults:")
 CONFIGS = []
 for part in spec.split(";"):
