@@ -419,22 +419,34 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
   // above it; a tile that is not its group's best passes it with probability ~k / tiles, so about k tiles pass.  One
   // wavefront ranks 64 values -- the first version ranked the 1 024 thread bests inside every wavefront and 16 k of them
   // against each other: 9 of the kernel's 17 us on one CU (profiles/r04_hybrid_trace.txt).
+  // (round 6: the 64 x 64 comparisons are shared among the sixteen wavefronts -- wavefront w compares every group minimum with the
+  // four minima 4 w .. 4 w + 3, the shares add up in LDS; one wavefront alone counted 64 entries per lane, 2 of the branch's 11 us)
+  __shared__ uint32_t grank[64];
   if (threadIdx.x < 64) {
     SKey g = sk_none();
 #pragma unroll
     for (int j = 0; j < 16; j++) g = sk_min(SKey{lk[threadIdx.x + 64 * j], li[threadIdx.x + 64 * j]}, g);
     lk[1024 + threadIdx.x] = g.k;
     li[1024 + threadIdx.x] = g.i;
-    // (one wavefront: its own LDS writes are visible to it after the wait the compiler inserts; no barrier needed)
-    __builtin_amdgcn_wave_barrier();
+    grank[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  {
+    const uint32_t l = threadIdx.x & 63, w4 = (threadIdx.x >> 6) * 4;
+    const SKey g{lk[1024 + l], li[1024 + l]};
     if (!sk_same(g, sk_none())) {
       uint32_t rank = 0;
-#pragma unroll 8
-      for (uint32_t j = 0; j < 64; j++) rank += sk_less(SKey{lk[1024 + j], li[1024 + j]}, g) ? 1u : 0u;
-      if (rank == k - 1) {
-        wtau_k[0] = g.k;
-        wtau_i[0] = g.i;
-      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) rank += sk_less(SKey{lk[1024 + w4 + j], li[1024 + w4 + j]}, g) ? 1u : 0u;
+      if (rank) atomicAdd(&grank[l], rank);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const SKey g{lk[1024 + threadIdx.x], li[1024 + threadIdx.x]};
+    if (!sk_same(g, sk_none()) && grank[threadIdx.x] == k - 1) {
+      wtau_k[0] = g.k;
+      wtau_i[0] = g.i;
     }
   }
   __syncthreads();
@@ -527,21 +539,42 @@ __device__ __forceinline__ void hybrid_reduce_branch(const HybridReduceArgs &R, 
     }
     return;
   }
-  for (uint32_t e = threadIdx.x; e < S; e += 1024) {
-    const SKey my{lk[e], li[e]};
-    uint32_t rank = 0;
+  auto answer = [&](uint32_t rank, const SKey &my) {
+    if (SCORE) {
+      R.out_skeys[rank] = my.k;
+      R.out_sids[rank] = my.i;
+    } else {
+      R.out_krows[rank] = (uint32_t)my.k;
+      R.out_kkeys[rank] = (uint32_t)(my.k >> 32);
+      R.out_kids[rank] = (uint32_t)my.k;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (the few threads that wrote an answer: it is in host memory before the flag)
+  };
+  if (S <= 512) {
+    // the usual few dozen survivors: W columns (a power of two >= S) x P rows of the 1 024 threads, a row counts its share of the
+    // survivors in front of each entry, the shares add up in LDS (round 6: the first S threads counted all S, the other wavefronts idle)
+    __shared__ uint32_t srank[512];
+    const uint32_t W = S <= 64 ? 64u : (S <= 128 ? 128u : (S <= 256 ? 256u : 512u)), P = 1024u / W;
+    const uint32_t e = threadIdx.x & (W - 1), part = threadIdx.x / W, chunk = (S + P - 1) / P;
+    const uint32_t lo = part * chunk, hi = lo + chunk < S ? lo + chunk : S;
+    if (threadIdx.x < W) srank[threadIdx.x] = 0;
+    __syncthreads();
+    if (e < S && lo < hi) {
+      const SKey my{lk[e], li[e]};
+      uint32_t rank = 0;
+#pragma unroll 4
+      for (uint32_t j = lo; j < hi; j++) rank += sk_less(SKey{lk[j], li[j]}, my) ? 1u : 0u;
+      if (rank) atomicAdd(&srank[e], rank);
+    }
+    __syncthreads();
+    if (threadIdx.x < S && srank[threadIdx.x] < k) answer(srank[threadIdx.x], SKey{lk[threadIdx.x], li[threadIdx.x]});
+  } else {
+    for (uint32_t e = threadIdx.x; e < S; e += 1024) {
+      const SKey my{lk[e], li[e]};
+      uint32_t rank = 0;
 #pragma unroll 8
-    for (uint32_t j = 0; j < S; j++) rank += sk_less(SKey{lk[j], li[j]}, my) ? 1u : 0u;
-    if (rank < k) {
-      if (SCORE) {
-        R.out_skeys[rank] = my.k;
-        R.out_sids[rank] = my.i;
-      } else {
-        R.out_krows[rank] = (uint32_t)my.k;
-        R.out_kkeys[rank] = (uint32_t)(my.k >> 32);
-        R.out_kids[rank] = (uint32_t)my.k;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // (the few threads that wrote an answer: it is in host memory before the flag)
+      for (uint32_t j = 0; j < S; j++) rank += sk_less(SKey{lk[j], li[j]}, my) ? 1u : 0u;
+      if (rank < k) answer(rank, my);
     }
   }
   __syncthreads();
