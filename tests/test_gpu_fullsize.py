@@ -147,7 +147,7 @@ def test_two_stage_int8_shadow_at_the_baseline_size(big, big_oracle):
 
 def test_fp32_native_matrix_core_batch_at_the_baseline_size(big, big_oracle):
     """Round 4 (K5): 256 queries per corpus pass on the PLAIN fp32 index of the headline configuration -- the matrix-core
-    filter reads the fp32 rows themselves (bf16 in flight), survivors are re-scored exactly.  Every one of 300 replies is
+    filter reads the fp32 rows themselves (bf16 in flight in rounds 4-5, int8 in flight since round 6: asserted), survivors are re-scored exactly.  Every one of 300 replies is
     bit-identical to VecSimIndex_TopKQuery on the same index, the passes were really taken, and whole queries -- the planted
     one among them -- are held to the CPU oracle on the full 10 M + 12 rows."""
     idx, q, planted, _ = big
@@ -160,6 +160,7 @@ def test_fp32_native_matrix_core_batch_at_the_baseline_size(big, big_oracle):
         ids, sc, cnt = idx.topk_batch(queries, k)
         lib.RSGPU_SetProfiling(0)
         assert V.scan_profile()[0] == 2 and V.coalesce_stats()["mq_passes"] == before, "the matrix-core passes were not taken"
+        assert lib.RSGPU_LastBatchRoute() == 6   # (round 6: the fp32 rows quantised to int8 in flight, the default route; rsgpu_ext.h)
         assert (cnt == k).all()
         for i in range(0, 300, 7):
             si, ss = idx.topk_query(queries[i], k).results()
@@ -290,6 +291,7 @@ def test_batched_config3_full_size_against_the_oracle():
             want[qi].append(lab)
             lab += 1
     ids, sc, cnt = idx.topk_batch(queries, k)
+    assert V.load().RSGPU_LastBatchRoute() == 5   # (round 6: the fp16 rows quantised to int8 in flight, the default route; rsgpu_ext.h)
     assert (cnt == k).all()
     for qi, labs in want.items():
         assert ids[qi, :len(labs)].tolist() == labs
